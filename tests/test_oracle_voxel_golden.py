@@ -1,0 +1,137 @@
+"""Pin the voxelizer oracle (oracle/voxel_ref.c) against the reference's own gninagrid goldens.
+
+Goldens: test/gninagrid/files/* of the reference, converted by tests/golden/make_voxel_goldens.py.
+Tolerance 1e-4 abs = the reference's own (test/gninagrid/compare_dx.py:24, compare_map.py:24,
+compare_bin.py:22); the raw-float binmap golden is held to 1e-6.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import voxel as V
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "voxel_goldens.npz"))
+
+
+@pytest.fixture(scope="module")
+def maps(G):
+    return V.typer_parse(str(G["recmap"])), V.typer_parse(str(G["ligmap"]))
+
+
+ALIPH_C = 2  # smina_atom_type::AliphaticCarbonXSHydrophobe (atom_constants.h:48)
+
+
+def test_typer_default2017_maps(maps):
+    (rec, nrec), (lig, nlig) = maps
+    assert nrec == 16 and nlig == 19  # default2017 = 35 channels
+    names = V.smina_type_names()
+    assert rec[names.index("Hydrogen")] == -1 and rec[names.index("PolarHydrogen")] == -1
+    assert rec[names.index("AliphaticCarbonXSHydrophobe")] == 0
+    assert rec[names.index("Zinc")] == 15
+    assert rec[names.index("Oxygen")] == -1          # not in recmap -> dropped
+    assert lig[names.index("Boron")] == 18
+    assert lig[names.index("OxygenXSDonor")] == -1
+
+
+def test_radii_table():
+    r = V.xs_radii()
+    names = V.smina_type_names()
+    assert r[names.index("AliphaticCarbonXSHydrophobe")] == np.float32(1.9)
+    assert r[names.index("Iodine")] == np.float32(2.2)
+    assert r[names.index("Boron")] == np.float32(1.92)
+    assert r[names.index("Hydrogen")] == np.float32(0.37)
+    assert len(names) == 28
+
+
+def test_ccdx_gaussian_lig_and_center(G, maps):
+    lig = G["cc_xyz"]
+    smt = np.full(len(lig), ALIPH_C)
+    grid, cen = V.voxelize_pose(lig, smt, lig, smt, maps[0], maps[1])
+    assert grid.shape == (35, 48, 48, 48)
+    # dx header origin = centre - dimension/2 (5 printed decimals)
+    np.testing.assert_allclose(cen - 11.75, G["ccdx_lig_origin"], atol=1e-5)
+    np.testing.assert_allclose(grid[16], G["ccdx_lig"], atol=1e-4)
+    assert np.abs(grid[16] - G["ccdx_lig"]).max() < 1e-5  # print precision of the golden
+    # support set identical where the golden is unambiguous
+    assert ((grid[16] > 5e-6) == (G["ccdx_lig"] > 5e-6)).mean() > 0.9999
+    # only rec channel 0 and lig channel 16 are populated
+    others = np.delete(grid, [0, 16], axis=0)
+    assert not others.any()
+
+
+def test_ccdx_gaussian_rec_rounded_coords(G, maps):
+    lig = G["cc_xyz"]
+    smt = np.full(len(lig), ALIPH_C)
+    rec = np.round(lig.astype(np.float64), 3).astype(np.float32)  # PDB text round trip
+    grid, _ = V.voxelize_pose(rec, smt, lig, smt, maps[0], maps[1])
+    assert np.abs(grid[0] - G["ccdx_rec"]).max() < 1e-5
+
+
+def test_ccmap_layout_x_slowest(G, maps):
+    lig = G["cc_xyz"]
+    smt = np.full(len(lig), ALIPH_C)
+    grid, cen = V.voxelize_pose(lig, smt, lig, smt, maps[0], maps[1])
+    np.testing.assert_allclose(cen, G["ccmap_lig_center"], atol=1e-4)
+    assert np.abs(grid[16] - G["ccmap_lig"]).max() < 1e-4
+    # a transposed layout must NOT match (guards the x-slowest / z-fastest order)
+    assert np.abs(grid[16].transpose(2, 1, 0) - G["ccmap_lig"]).max() > 0.1
+
+
+def test_ccbin_binary_occupancy(G, maps):
+    lig = G["cc_xyz"]
+    smt = np.full(len(lig), ALIPH_C)
+    ch, rad = V.type_atoms(smt, maps[1][0])
+    cen = V.center(lig)
+    g = V.grid_forward(cen, lig, ch, rad, 19, 0.5, 8.0, 1.0, True)
+    assert g.shape == (19, 17, 17, 17)
+    np.testing.assert_allclose(cen - 4.0, G["ccbin_lig_origin"], atol=1e-5)
+    assert np.array_equal(g[0], G["ccbin_lig"])  # set, not summed: values in {0,1}
+    assert set(np.unique(g[0])) == {0.0, 1.0}
+
+
+def test_ccgrid_binmap_full_precision(G):
+    """Raw float32 golden, single off-centre carbon, centre taken from the user grid."""
+    cen = (G["usergrid_origin"] + 6.0).astype(np.float32)  # 25 points at 0.5 A -> dimension 12
+    xyz = G["c_xyz"]
+    g = V.grid_forward(cen, xyz, np.array([0]), np.array([1.9], dtype=np.float32), 1, 0.5, 12.0)
+    b = G["ccgrid_binmap"]
+    assert g.shape[1:] == b.shape[1:] == (25, 25, 25)
+    # channel 0 = user grid, 1..14 receptor, 15..28 ligand (molgridder.cpp:110-131)
+    assert np.abs(b[0] - G["usergrid"]).max() < 1e-5
+    assert np.abs(g[0] - b[15]).max() < 1e-6          # ligand: exact coordinates
+    assert np.array_equal(g[0] != 0, b[15] != 0)      # support set bit-exact
+    rec = np.round(xyz.astype(np.float64), 3).astype(np.float32)
+    g3 = V.grid_forward(cen, rec, np.array([0]), np.array([1.9], dtype=np.float32), 1, 0.5, 12.0)
+    assert np.abs(g3[0] - b[1]).max() < 1e-6          # receptor: PDB-rounded coordinates
+    assert not b[2:15].any() and not b[16:].any()
+
+
+def test_center_all_rows_vs_typed():
+    xyz = np.array([[0, 0, 0], [2, 0, 0], [10, 10, 10]], dtype=np.float32)
+    chan = np.array([0, 0, -1])
+    np.testing.assert_allclose(V.center(xyz), [4, 10 / 3, 10 / 3], rtol=1e-6)
+    np.testing.assert_allclose(V.center(xyz, chan, only_typed=True), [1, 0, 0], rtol=1e-6)
+
+
+def test_backward_matches_finite_difference():
+    rng = np.random.default_rng(0)
+    xyz = rng.normal(0, 2.0, (6, 3)).astype(np.float32)
+    chan = np.array([0, 1, 0, 1, -1, 0])
+    rad = np.array([1.9, 1.7, 1.8, 2.0, 0.37, 1.2], dtype=np.float32)
+    cen = np.zeros(3, dtype=np.float32)
+    w = rng.normal(0, 1, (2, 25, 25, 25)).astype(np.float32)
+    ana = V.grid_backward(cen, xyz, chan, rad, 2, w, 0.5, 12.0)
+    assert not ana[4].any()
+    h = 1e-2
+    for a in (0, 1, 3):
+        for d in range(3):
+            p, m = xyz.copy(), xyz.copy()
+            p[a, d] += h
+            m[a, d] -= h
+            fp = (V.grid_forward(cen, p, chan, rad, 2, 0.5, 12.0).astype(np.float64) * w).sum()
+            fm = (V.grid_forward(cen, m, chan, rad, 2, 0.5, 12.0).astype(np.float64) * w).sum()
+            assert abs((fp - fm) / (2 * h) - ana[a, d]) < 2e-2 * max(1.0, abs(ana[a, d]))
