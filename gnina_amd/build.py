@@ -1,0 +1,55 @@
+"""Build libmi_gnina.so (HIP, gfx950) in-tree with hipcc.  No torch, no cmake: plain C ABI library.
+
+    python -m gnina_amd.build            # incremental
+    python -m gnina_amd.build --force
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmi_gnina.so")
+SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip"]
+# -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
+# bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-x", "hip"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.exists(c) or c == "hipcc"):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "mi_gnina.h"))
+    hdr_mtime = max(os.path.getmtime(h) for h in headers)
+    objs, rebuilt = [], False
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_mtime):
+            cmd = [hipcc()] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

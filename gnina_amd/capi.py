@@ -1,0 +1,219 @@
+"""ctypes binding of libmi_gnina.so (include/mi_gnina.h) -- the parity-test / bench harness side
+of the C ABI.  There is NO fallback: if the HIP library is missing this module raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi_gnina.so")
+
+MI_OK = 0
+MI_LIG_ON_DEVICE = 1
+MI_OUT_ON_DEVICE = 2
+MI_CENTER_TYPED_ONLY = 4
+
+# every function include/mi_gnina.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "mi_gnina_init", "mi_gnina_device_count", "mi_gnina_abi_version", "mi_last_error",
+    "mi_model_load", "mi_model_load_file", "mi_model_retain", "mi_model_release", "mi_model_info",
+    "mi_model_name", "mi_model_type_channel",
+    "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
+    "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
+]
+
+_lib = None
+
+
+class MiGninaError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiGninaError(
+                f"{LIB_PATH} not built: run `python __graft_entry__.py build` (hipcc, gfx950). "
+                "gnina_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        f32p, i32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+        L.mi_gnina_init.argtypes = [C.c_int]
+        L.mi_gnina_init.restype = C.c_int
+        L.mi_gnina_device_count.restype = C.c_int
+        L.mi_gnina_abi_version.restype = C.c_int
+        L.mi_last_error.restype = C.c_char_p
+        L.mi_model_load.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
+        L.mi_model_load.restype = vp
+        L.mi_model_load_file.argtypes = [C.c_char_p]
+        L.mi_model_load_file.restype = vp
+        L.mi_model_retain.argtypes = [vp]
+        L.mi_model_retain.restype = None
+        L.mi_model_release.argtypes = [vp]
+        L.mi_model_release.restype = None
+        L.mi_model_info.argtypes = [vp, f32p, f32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mi_model_info.restype = C.c_int
+        L.mi_model_name.argtypes = [vp]
+        L.mi_model_name.restype = C.c_char_p
+        L.mi_model_type_channel.argtypes = [vp, C.c_int, C.c_int, f32p]
+        L.mi_model_type_channel.restype = C.c_int
+        L.mi_scorer_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.mi_scorer_create.restype = vp
+        L.mi_scorer_destroy.argtypes = [vp]
+        L.mi_scorer_destroy.restype = None
+        L.mi_scorer_num_models.argtypes = [vp]
+        L.mi_scorer_num_models.restype = C.c_int
+        L.mi_scorer_set_receptor.argtypes = [vp, vp, vp, C.c_int]
+        L.mi_scorer_set_receptor.restype = C.c_int
+        L.mi_scorer_score_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.mi_scorer_score_batch.restype = C.c_int
+        L.mi_scorer_score_batch_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint]
+        L.mi_scorer_score_batch_ex.restype = C.c_int
+        L.mi_scorer_last_model_outputs.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+        L.mi_scorer_last_model_outputs.restype = C.c_int
+        L.mi_voxelize_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_uint]
+        L.mi_voxelize_batch.restype = C.c_int
+        L.mi_model_forward_grids.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.mi_model_forward_grids.restype = C.c_int
+        L.mi_scorer_stream.argtypes = [vp]
+        L.mi_scorer_stream.restype = vp
+        L.mi_scorer_synchronize.argtypes = [vp]
+        L.mi_scorer_synchronize.restype = C.c_int
+        L.mi_scorer_set_chunk.argtypes = [vp, C.c_int]
+        L.mi_scorer_set_chunk.restype = C.c_int
+        L.mi_scorer_enable_timing.argtypes = [vp, C.c_int]
+        L.mi_scorer_enable_timing.restype = C.c_int
+        L.mi_scorer_last_timing.argtypes = [vp, f32p]
+        L.mi_scorer_last_timing.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != MI_OK:
+        raise MiGninaError(f"mi_gnina error {status}: {lib().mi_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+WEIGHTS_DIR = os.path.join(_HERE, "weights")
+
+
+class Model:
+    """One network (mirror of TorchModel's constructor, gninasrc/lib/torch_model.cpp:49-118)."""
+
+    def __init__(self, path_or_name):
+        path = path_or_name
+        if not os.path.exists(path):
+            path = os.path.join(WEIGHTS_DIR, path_or_name.replace(".", "_") + ".mgw")
+        self.handle = lib().mi_model_load_file(path.encode())
+        if not self.handle:
+            raise MiGninaError(f"could not load model {path_or_name}: {lib().mi_last_error().decode()}")
+        res, dim = C.c_float(), C.c_float()
+        nr, nl, n = C.c_int(), C.c_int(), C.c_int()
+        check(lib().mi_model_info(self.handle, C.byref(res), C.byref(dim), C.byref(nr), C.byref(nl), C.byref(n)))
+        self.resolution, self.dimension = res.value, dim.value
+        self.n_rec_channels, self.n_lig_channels, self.grid_points = nr.value, nl.value, n.value
+        self.name = lib().mi_model_name(self.handle).decode()
+
+    @property
+    def n_channels(self):
+        return self.n_rec_channels + self.n_lig_channels
+
+    def type_channel(self, is_ligand, smt):
+        r = C.c_float()
+        c = lib().mi_model_type_channel(self.handle, int(is_ligand), int(smt), C.byref(r))
+        return c, r.value
+
+    def chan_of_smt(self, is_ligand):
+        return np.array([self.type_channel(is_ligand, t)[0] for t in range(28)], dtype=np.int32)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.mi_model_release(self.handle)
+            self.handle = None
+
+
+class Scorer:
+    """An ensemble bound to one receptor (mirror of CNNTorchScorer, cnn_torch_scorer.cpp:24-198)."""
+
+    def __init__(self, models):
+        self.models = [m if isinstance(m, Model) else Model(m) for m in models]
+        arr = (C.c_void_p * len(self.models))(*[m.handle for m in self.models])
+        self.handle = lib().mi_scorer_create(arr, len(self.models))
+        if not self.handle:
+            raise MiGninaError(lib().mi_last_error().decode())
+
+    def set_receptor(self, xyz, smt):
+        xyz = _f32(xyz).reshape(-1, 3)
+        smt = _i32(smt)
+        assert len(xyz) == len(smt)
+        check(lib().mi_scorer_set_receptor(self.handle, _ptr(xyz), _ptr(smt), len(smt)))
+
+    def score_batch(self, lig_xyz, lig_smt, centers=None, flags=0):
+        """lig_xyz [B][L][3] -> dict(pose, affinity, loss, variance), each float32 [B]."""
+        lig_xyz = _f32(lig_xyz)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        lig_smt = _i32(lig_smt)
+        assert len(lig_smt) == L
+        centers = _f32(centers)
+        pose, aff, loss, var = (np.empty(B, dtype=np.float32) for _ in range(4))
+        check(lib().mi_scorer_score_batch_ex(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers),
+                                             _ptr(pose), _ptr(aff), _ptr(loss), _ptr(var), flags))
+        return {"pose": pose, "affinity": aff, "loss": loss, "variance": var}
+
+    def last_model_outputs(self, m, B):
+        pose, aff, loss = (np.empty(B, dtype=np.float32) for _ in range(3))
+        check(lib().mi_scorer_last_model_outputs(self.handle, m, _ptr(pose), _ptr(aff), _ptr(loss), B))
+        return pose, aff, loss
+
+    def voxelize_batch(self, lig_xyz, lig_smt, centers=None, model=0, flags=0):
+        """GridMaker::forward for model `model`: returns (grids [B,C,N,N,N], centers [B,3])."""
+        lig_xyz = _f32(lig_xyz)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        lig_smt = _i32(lig_smt)
+        centers = _f32(centers)
+        m = self.models[model]
+        N = m.grid_points
+        grids = np.empty((B, m.n_channels, N, N, N), dtype=np.float32)
+        cen = np.empty((B, 3), dtype=np.float32)
+        check(lib().mi_voxelize_batch(self.handle, model, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers),
+                                      _ptr(grids), _ptr(cen), flags))
+        return grids, cen
+
+    def forward_grids(self, grids, model=0):
+        grids = _f32(grids)
+        B = grids.shape[0]
+        pose, aff, loss = (np.empty(B, dtype=np.float32) for _ in range(3))
+        check(lib().mi_model_forward_grids(self.handle, model, _ptr(grids), B, _ptr(pose), _ptr(aff), _ptr(loss)))
+        return pose, aff, loss
+
+    def set_chunk(self, n):
+        check(lib().mi_scorer_set_chunk(self.handle, int(n)))
+
+    def stream(self):
+        return lib().mi_scorer_stream(self.handle)
+
+    def synchronize(self):
+        check(lib().mi_scorer_synchronize(self.handle))
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.mi_scorer_destroy(self.handle)
+            self.handle = None
+
+
+def init(device=0):
+    check(lib().mi_gnina_init(device))

@@ -1,0 +1,43 @@
+// conv3d.h -- argument block + launchers of the CNN kernels (conv3d.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace mig {
+
+struct ConvArgs {
+  const float *in;   // [B][S][S][S][in_cs] channels last
+  int in_cs;
+  float *out;        // [B][So][So][So][out_cs], So = S (pool 0) or S/2
+  int out_cs, out_c0;
+  const float *wp;   // packed weights [chunk][pair][2][coutp][4]
+  const float *bias; // [coutp]
+  const float *bn_scale, *bn_shift;  // [cin4*4] or nullptr
+  int S;
+  int cout, coutp;   // real / padded-to-32 output channels
+  int ksize;         // 1 or 3
+  int relu, pool;    // pool: 0 none, 1 max, 2 avg (2x2x2 after ReLU)
+  int tcx, tcy, tcz; // workgroup tile in 2x2x2 cells
+  int ntx, nty, ntz; // tiles per axis
+  int cc4;           // channel quads per K chunk
+  int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
+  int nchunks;
+};
+
+enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_3x2_2x1 = 1, CONV_CFG_1x4_7x1 = 2 };
+
+size_t conv_lds_bytes(const ConvArgs &p);
+void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn);
+void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s);
+
+void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);
+void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,
+                    hipStream_t s);
+void launch_gmax(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
+void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
+                     int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s);
+void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
+                            float *pose, float *aff, float *loss, float *var, hipStream_t s);
+
+}  // namespace mig

@@ -1,0 +1,426 @@
+// conv3d.hip -- 3x3x3 / 1x1x1 stride-1 "same" 3-D convolution as an fp32-MFMA implicit GEMM (gfx950).
+//
+// Replaces the cuDNN/oneDNN `_convolution` calls inside the TorchScript graphs that gnina runs
+// at gninasrc/lib/torch_model.cpp:185 (layer lists: SURVEY.md App. B), with bias, ReLU, eval
+// BatchNorm-on-input (Dense family) and the following 2x2x2 Max/AvgPool fused in.
+//
+// GEMM view:  M = output voxels,  N = output channels,  K = taps x input channels.
+//   A[m][k] is gathered on the fly from an LDS-resident halo tile of the channels-last input,
+//   B[k][n] streams from a pre-packed weight array (L2 resident, 1.5 MB per network),
+//   D accumulates in registers through v_mfma_f32_32x32x2_f32 -- exact fp32 (an fmaf chain),
+//   which is what the 1e-4 score parity budget needs; there is no TF32 on gfx950.
+//
+// Wavefront tiling (64 lanes, not a warp-shaped CUDA tiling):
+//   * An M-tile is 32 voxels = four 2x2x2 pooling cells.  Row i of the MFMA maps to
+//     (cell = i.bit2 + 2*i.bit4, x = i.bit3, y = i.bit1, z = i.bit0), so that in the 32x32
+//     accumulator layout (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) registers 0-7 of a lane are
+//     the eight voxels of ONE pooling cell and registers 8-15 those of another: ReLU + 2x2x2
+//     max/avg pooling happen entirely in registers, no cross-lane traffic, and the pooled
+//     activation (8x smaller) is what goes back to HBM.
+//   * K runs over "quads" (one tap x 4 consecutive input channels).  One ds_read_b128 per lane
+//     feeds four MFMAs; lanes 0-31 take quad 2p, lanes 32-63 quad 2p+1 (the k=0 / k=1 halves of
+//     the 32x32x2 instruction), each with its own LDS address, so K needs no padding beyond a
+//     multiple of 4 channels and an even quad count.
+//   * A workgroup is WM x WN waves, each wave owning TM M-tiles x TN 32-wide N-tiles.
+#include "conv3d.h"
+
+namespace mig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
+  constexpr int NWAVES = WM * WN;
+  constexpr int NTHREADS = 64 * NWAVES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int kh = lane >> 5;   // which k of the 32x32x2 MFMA this lane feeds
+  const int row = lane & 31;  // A row / B column
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int b = blockIdx.x / tiles_per_pose;
+  int t = blockIdx.x - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+  const int n_base = (blockIdx.y * WN + wn) * TN * 32;  // first output channel of this wave
+
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const int HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo;
+  const int HV = HX * HY * HZ;
+  const int CC4 = p.cc4, CCs = p.ccs;
+  const int taps = p.ksize == 3 ? 27 : 1;
+  const int Q = taps * CC4;       // quads per chunk
+  const int P = (Q + 1) >> 1;     // quad pairs per chunk
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_tile = smem;                                  // [HV][CCs]
+  int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);  // [Q]
+
+  for (int q = tid; q < Q; q += NTHREADS) {
+    int tap = q / CC4, c4 = q - tap * CC4;
+    int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = (p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4;
+  }
+
+  // A-row geometry of this lane for each of its M-tiles
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
+  const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cell = (wm * TM + m) * 4 + cell_in_mt;
+    if (cell >= NC) cell = 0;
+    int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; m++)
+#pragma unroll
+    for (int n = 0; n < TN; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
+  const float *wq = p.wp + (size_t)(n_base + row) * 4;  // + ((pair*2 + kh) * coutp) * 4
+  const size_t wstride = (size_t)p.coutp * 4;           // floats per quad row of packed weights
+
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    __syncthreads();  // previous chunk's reads done (and s_qoff visible on the first pass)
+    // ---- stage the halo tile of this channel chunk into LDS (zero padded; BN folded in) ----
+    const int c_base = chunk * CC4 * 4;
+    for (int it = tid; it < HV * CC4; it += NTHREADS) {
+      int hv = it / CC4, c4 = it - hv * CC4;
+      int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+      int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S) {
+        const int c = c_base + c4 * 4;
+        val = *reinterpret_cast<const float4 *>(in_b + (((size_t)x * S + y) * S + z) * p.in_cs + c);
+        if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
+          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
+          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
+          val.x = val.x * sc.x + sh.x;
+          val.y = val.y * sc.y + sh.y;
+          val.z = val.z * sc.z + sh.z;
+          val.w = val.w * sc.w + sh.w;
+        }
+      }
+      *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
+    }
+    __syncthreads();
+
+    // ---- K loop over quad pairs of this chunk ----
+    const float *wchunk = wq + (size_t)chunk * P * 2 * wstride + (size_t)kh * wstride;
+    for (int pr = 0; pr < P; pr++) {
+      int q = 2 * pr + kh;
+      q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
+      const int qo = s_qoff[q];
+      float4 a[TM], w[TN];
+#pragma unroll
+      for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+#pragma unroll
+      for (int n = 0; n < TN; n++)
+        w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: bias, ReLU, optional 2x2x2 pool, store channels-last ----
+  const int So = p.pool ? S / 2 : S;
+  float *out_b = p.out + (size_t)b * So * So * So * p.out_cs + p.out_c0;
+  const int ncx = S / 2;  // cells per axis of the whole grid
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int cell = (wm * TM + m) * 4 + kh + 2 * half;  // accumulator rows: bit2 = lane>>5, bit4 = reg>>3
+      if (cell >= NC) continue;
+      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+#pragma unroll
+      for (int n = 0; n < TN; n++) {
+        const int ch = n_base + n * 32 + row;
+        if (ch >= p.cout) continue;
+        const float bias = p.bias[ch];
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          float t = acc[m][n][half * 8 + r] + bias;
+          v[r] = p.relu ? fmaxf(t, 0.f) : t;
+        }
+        if (p.pool == 1) {
+          float mx = v[0];
+#pragma unroll
+          for (int r = 1; r < 8; r++) mx = fmaxf(mx, v[r]);
+          out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = mx;
+        } else if (p.pool == 2) {
+          float s = v[0];
+#pragma unroll
+          for (int r = 1; r < 8; r++) s = s + v[r];  // r = x*4 + y*2 + z: avg_pool3d's (kd,kh,kw) order
+          out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+            out_b[(((size_t)vx * So + vy) * So + vz) * p.out_cs + ch] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+size_t conv_lds_bytes(const ConvArgs &p) {
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
+  const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
+  return HV * p.ccs * sizeof(float) + (size_t)Q * sizeof(int);
+}
+
+template <int WM, int WN, int TM, int TN> static void launch_cfg(const ConvArgs &p, int B, hipStream_t s) {
+  const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
+  dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
+  const size_t lds = conv_lds_bytes(p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN>), grid, block, lds, s, p);
+}
+
+void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
+  switch (cfg) {
+    case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1>(p, B, s); break;
+    case CONV_CFG_3x2_2x1: launch_cfg<3, 2, 2, 1>(p, B, s); break;
+    case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
+    default: break;
+  }
+}
+
+void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
+  switch (cfg) {
+    case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
+    case CONV_CFG_3x2_2x1: *wm = 3, *wn = 2, *tm = 2, *tn = 1; break;
+    default: *wm = 1, *wn = 4, *tm = 7, *tn = 1; break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small helpers of the layer program
+// ---------------------------------------------------------------------------------------------
+// reference-layout grid [B][C][N][N][N] -> 2x2x2 pooled channels-last [B][N/2]^3[Cp]
+// (used only by mi_model_forward_grids, the CNN-on-given-grids test entry point)
+__global__ void pool_input_ncdhw_kernel(const float *in, float *out, int C, int Cp, int N, int mode, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int S = N / 2;
+  int c = i % Cp;
+  long r = i / Cp;
+  int z = r % S;
+  r /= S;
+  int y = r % S;
+  r /= S;
+  int x = r % S;
+  long b = r / S;
+  float res = 0.f;
+  if (c < C) {
+    const float *src = in + (((size_t)b * C + c) * N) * N * N;
+    float acc = 0.f;
+    bool first = true;
+    for (int dx = 0; dx < 2; dx++)
+      for (int dy = 0; dy < 2; dy++)
+        for (int dz = 0; dz < 2; dz++) {
+          float v = src[((size_t)(2 * x + dx) * N + (2 * y + dy)) * N + (2 * z + dz)];
+          if (mode == 1)
+            acc = first ? v : fmaxf(acc, v);
+          else
+            acc = first ? v : acc + v;
+          first = false;
+        }
+    res = mode == 1 ? acc : acc * 0.125f;
+  }
+  out[i] = res;
+}
+
+void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s) {
+  const int S = N / 2;
+  long total = (long)B * S * S * S * Cp;
+  hipLaunchKernelGGL(pool_input_ncdhw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, C,
+                     Cp, N, mode, total);
+}
+
+// channels-last 2x2x2 pool: in [B][S]^3[in_cs] (first C channels) -> out [B][S/2]^3[out_cs]
+__global__ void pool_cl_kernel(const float *in, float *out, int C, int in_cs, int out_cs, int S, int mode,
+                               long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int So = S / 2;
+  int c = i % C;
+  long r = i / C;
+  int z = r % So;
+  r /= So;
+  int y = r % So;
+  r /= So;
+  int x = r % So;
+  long b = r / So;
+  float acc = 0.f;
+  bool first = true;
+  for (int dx = 0; dx < 2; dx++)
+    for (int dy = 0; dy < 2; dy++)
+      for (int dz = 0; dz < 2; dz++) {
+        float v = in[((((size_t)b * S + 2 * x + dx) * S + 2 * y + dy) * S + 2 * z + dz) * in_cs + c];
+        if (mode == 1)
+          acc = first ? v : fmaxf(acc, v);
+        else
+          acc = first ? v : acc + v;
+        first = false;
+      }
+  out[((((size_t)b * So + x) * So + y) * So + z) * out_cs + c] = mode == 1 ? acc : acc * 0.125f;
+}
+
+void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,
+                    hipStream_t s) {
+  const int So = S / 2;
+  long total = (long)B * So * So * So * C;
+  hipLaunchKernelGGL(pool_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, C, in_cs,
+                     out_cs, S, mode, total);
+}
+
+// global max over space: in [B][S]^3[in_cs] -> out [B][out_cs]
+__global__ void gmax_kernel(const float *in, float *out, int C, int in_cs, int out_cs, int S3) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float *src = in + (size_t)b * S3 * in_cs + c;
+    float m = src[0];
+    for (int v = 1; v < S3; v++) m = fmaxf(m, src[(size_t)v * in_cs]);
+    out[(size_t)b * out_cs + c] = m;
+  }
+}
+
+void launch_gmax(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s) {
+  hipLaunchKernelGGL(gmax_kernel, dim3(B), dim3(256), 0, s, in, out, C, in_cs, out_cs, S * S * S);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FC heads + score post-processing
+// ---------------------------------------------------------------------------------------------
+// in [B][n_in] (channels-last flatten), w [3][n_in], bias [3] -> logits/affinity, then
+// TorchModel::forward's post-processing (gninasrc/lib/torch_model.cpp:188-195):
+//   logp = log_softmax(z); pose = softmax(logp)[1] (or logp[1] if skip_softmax);
+//   loss = cross_entropy(logp, 1) (or -log(logp[1]) if apply_logistic_loss)
+__global__ __launch_bounds__(256) void fc_heads_kernel(const float *in, const float *w, const float *bias, int n_in,
+                                                       int skip_softmax, int logistic_loss, float *pose, float *aff,
+                                                       float *loss, float *raw3) {
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)b * n_in);
+  const float4 *w0 = reinterpret_cast<const float4 *>(w);
+  const float4 *w1 = reinterpret_cast<const float4 *>(w + n_in);
+  const float4 *w2 = reinterpret_cast<const float4 *>(w + 2 * (size_t)n_in);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const int n4 = n_in / 4;
+  for (int i = tid; i < n4; i += 256) {
+    float4 xv = x[i], a = w0[i], bb = w1[i], c = w2[i];
+    s0 = fmaf(xv.x, a.x, s0); s0 = fmaf(xv.y, a.y, s0); s0 = fmaf(xv.z, a.z, s0); s0 = fmaf(xv.w, a.w, s0);
+    s1 = fmaf(xv.x, bb.x, s1); s1 = fmaf(xv.y, bb.y, s1); s1 = fmaf(xv.z, bb.z, s1); s1 = fmaf(xv.w, bb.w, s1);
+    s2 = fmaf(xv.x, c.x, s2); s2 = fmaf(xv.y, c.y, s2); s2 = fmaf(xv.z, c.z, s2); s2 = fmaf(xv.w, c.w, s2);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off);
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  __shared__ float red[3][4];
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s0;
+    red[1][tid >> 6] = s1;
+    red[2][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float z0 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + bias[0];
+    float z1 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + bias[1];
+    float a = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) + bias[2];
+    // log_softmax (what the TorchScript module returns)
+    float m = fmaxf(z0, z1);
+    float lse = logf(expf(z0 - m) + expf(z1 - m));
+    float lp0 = (z0 - m) - lse, lp1 = (z1 - m) - lse;
+    // softmax of the log-probabilities (torch_model.cpp:189)
+    float m2 = fmaxf(lp0, lp1);
+    float e0 = expf(lp0 - m2), e1 = expf(lp1 - m2);
+    float ps = skip_softmax ? lp1 : e1 / (e0 + e1);
+    // cross_entropy(logp, label 1) = -log_softmax(logp)[1]   (torch_model.cpp:195)
+    float ls = logistic_loss ? -logf(lp1) : -((lp1 - m2) - logf(e0 + e1));
+    pose[b] = ps;
+    aff[b] = a;
+    loss[b] = ls;
+    if (raw3) {
+      raw3[3 * b + 0] = lp0;
+      raw3[3 * b + 1] = lp1;
+      raw3[3 * b + 2] = a;
+    }
+  }
+}
+
+void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
+                     int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s) {
+  hipLaunchKernelGGL(fc_heads_kernel, dim3(B), dim3(256), 0, s, in, w, bias, n_in, skip_softmax, logistic_loss,
+                     pose, aff, loss, raw3);
+}
+
+// ensemble mean / variance over models (cnn_torch_scorer.cpp:177-191)
+__global__ void ensemble_reduce_kernel(const float *pose_m, const float *aff_m, const float *loss_m, int n_models,
+                                       int B, float *pose, float *aff, float *loss, float *var) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double sc = 0.0;   // reference accumulates the score in double (cnn_torch_scorer.cpp:117)
+  float af = 0.f, ls = 0.f;
+  for (int m = 0; m < n_models; m++) {
+    sc += (double)pose_m[(size_t)m * B + b];
+    af += aff_m[(size_t)m * B + b];
+    ls += loss_m[(size_t)m * B + b];
+  }
+  af /= (float)n_models;
+  ls /= (float)n_models;
+  sc /= (double)n_models;
+  float v = 0.f;
+  if (n_models > 1) {
+    float sum = 0.f;
+    for (int m = 0; m < n_models; m++) {
+      float d = af - aff_m[(size_t)m * B + b];
+      sum += d * d;
+    }
+    v = sum / (float)n_models;
+  }
+  pose[b] = (float)sc;
+  aff[b] = af;
+  loss[b] = ls;
+  if (var) var[b] = v;
+}
+
+void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
+                            float *pose, float *aff, float *loss, float *var, hipStream_t s) {
+  hipLaunchKernelGGL(ensemble_reduce_kernel, dim3((B + 127) / 128), dim3(128), 0, s, pose_m, aff_m, loss_m,
+                     n_models, B, pose, aff, loss, var);
+}
+
+}  // namespace mig

@@ -1,0 +1,808 @@
+// engine.cpp -- device-resident models, scorers and the C ABI (include/mi_gnina.h).
+//
+// Host-side restatement of what gnina does around the kernels:
+//   TorchModel ctor        gninasrc/lib/torch_model.cpp:49-118   -> Model (weights packed for the MFMA kernel)
+//   TorchModel::forward    gninasrc/lib/torch_model.cpp:153-224  -> Scorer::run_model (batched, no host syncs)
+//   CNNTorchScorer::score  gninasrc/lib/cnn_torch_scorer.cpp:105-198 -> Scorer::score_batch (ensemble mean/variance)
+//   DLScorer::setReceptor  gninasrc/lib/dl_scorer.cpp:93-193     -> Scorer::set_receptor (typed once, kept in HBM)
+// Differences by design: B poses per call instead of 1, the receptor is typed and
+// uploaded once instead of per pose, models with identical type maps share one voxelization,
+// results leave the device once per batch instead of three .item() syncs per pose.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <numeric>
+
+#include "../../include/mi_gnina.h"
+#include "common.h"
+#include "conv3d.h"
+#include "model.h"
+#include "typer.h"
+#include "voxelize.h"
+
+namespace mig {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+// -------------------------------------------------------------------------------------------
+// Model: parsed program + device weights
+// -------------------------------------------------------------------------------------------
+struct ConvPlan {
+  int cfg = 0;
+  ConvArgs a{};          // device pointers to weights filled at load; in/out patched per run
+  int src = -1, dst = -1;
+};
+
+struct Step {
+  OpKind kind;
+  ConvPlan conv;         // Conv
+  int src = -1, dst = -1;
+  int pool_mode = 0;     // Pool
+  int C = 0;             // channels moved by Pool/GMax
+  long w_off = 0, b_off = 0;  // Fc (offsets into dev_data)
+  int n_in = 0;
+};
+
+struct Model {
+  std::atomic<int> refs{1};
+  ModelDesc d;
+  int N = 0;             // grid points per side
+  int C = 0, Cp = 0;     // input channels / padded
+  int input_pool = 0;    // 1 max, 2 avg: first op, fused into the voxelizer
+  int input_dst = -1;    // buffer receiving the pooled grid
+  std::vector<int> buf_cp;          // padded channel stride per buffer (0 = never materialised)
+  std::vector<Step> steps;          // executable program after fusion
+  DevBuf<float> dev_data;           // fc weights, biases, bn params (canonical payload)
+  std::vector<std::unique_ptr<DevBuf<float>>> packed;  // packed conv weights / padded bias / bn
+  float qa, qb, qc;                 // quadratic tail coefficients
+  DensityConsts dens[kNumSminaTypes];
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static const float *push_dev(Model &m, const std::vector<float> &host) {
+  m.packed.emplace_back(new DevBuf<float>());
+  auto &buf = *m.packed.back();
+  buf.ensure(host.size());
+  MIG_HIP(hipMemcpy(buf.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return buf.p;
+}
+
+static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0) {
+  const int S = m.d.bufs[o.src].S;
+  MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
+  const int cells = S / 2;
+  const int NT = cdiv(o.cout, 32);
+  ConvArgs &a = cp.a;
+  a.S = S;
+  a.cout = o.cout;
+  a.coutp = NT * 32;
+  a.ksize = o.ksize;
+  a.relu = o.relu;
+  a.pool = pool_mode;
+  a.out_c0 = dst_c0;
+  // workgroup shape
+  if (cells == 3 && NT % 4 == 0) {
+    cp.cfg = CONV_CFG_1x4_7x1;
+    a.tcx = a.tcy = a.tcz = 3;
+  } else if (cells == 6 && NT % 2 == 0) {
+    cp.cfg = CONV_CFG_3x2_2x1;
+    a.tcx = 2, a.tcy = 2, a.tcz = 6;
+  } else {
+    cp.cfg = CONV_CFG_4x1_2x1;  // 8 M-tiles = 32 cells
+    if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
+    else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
+    else if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
+    else a.tcx = 2, a.tcy = 4, a.tcz = 4;
+  }
+  a.ntx = cdiv(cells, a.tcx);
+  a.nty = cdiv(cells, a.tcy);
+  a.ntz = cdiv(cells, a.tcz);
+  // K chunking: largest divisor of cin4 whose halo tile fits the LDS budget
+  const int cin4 = cdiv(o.cin, 4);
+  MIG_CHECK(cin4 * 4 <= round_up(m.d.bufs[o.src].C, 4), 2, "conv input channels exceed buffer");
+  const int halo = o.ksize == 3 ? 1 : 0;
+  const size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
+  const size_t budget = 72 * 1024;
+  int best = 1;
+  for (int c = 1; c <= cin4; c++) {
+    if (cin4 % c) continue;
+    int ccs = 4 * (c | 1);
+    if (HV * ccs * 4 + 27 * c * 4 <= budget) best = c;
+  }
+  a.cc4 = best;
+  a.ccs = 4 * (best | 1);  // odd quad stride: consecutive voxels land on different 16-byte LDS slots
+  a.nchunks = cin4 / best;
+  // pack weights [chunk][pair][2][coutp][4]
+  const int taps = o.ksize * o.ksize * o.ksize;
+  const int Q = taps * a.cc4, P = (Q + 1) / 2;
+  std::vector<float> wp((size_t)a.nchunks * P * 2 * a.coutp * 4, 0.f);
+  const float *w = m.d.data.data() + o.w_off;  // [tap][cin][cout]
+  for (int ch = 0; ch < a.nchunks; ch++)
+    for (int pr = 0; pr < P; pr++)
+      for (int kh = 0; kh < 2; kh++) {
+        int q = 2 * pr + kh;
+        if (q >= Q) continue;
+        int tap = q / a.cc4, c4 = q % a.cc4;
+        for (int j = 0; j < 4; j++) {
+          int c = (ch * a.cc4 + c4) * 4 + j;
+          if (c >= o.cin) continue;
+          for (int n = 0; n < o.cout; n++)
+            wp[((((size_t)ch * P + pr) * 2 + kh) * a.coutp + n) * 4 + j] = w[((size_t)tap * o.cin + c) * o.cout + n];
+        }
+      }
+  a.wp = push_dev(m, wp);
+  std::vector<float> bias(a.coutp, 0.f);
+  std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
+  a.bias = push_dev(m, bias);
+  a.bn_scale = a.bn_shift = nullptr;
+  if (o.bn_scale_off >= 0) {
+    std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
+    std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+    std::copy(m.d.data.begin() + o.bn_shift_off, m.d.data.begin() + o.bn_shift_off + o.cin, sh.begin());
+    a.bn_scale = push_dev(m, sc);
+    a.bn_shift = push_dev(m, sh);
+  }
+  cp.src = o.src;
+  cp.dst = dst_buf;
+  MIG_CHECK(conv_lds_bytes(a) <= 160 * 1024, 2, "conv tile exceeds LDS");
+}
+
+static Model *build_model(ModelDesc &&desc) {
+  std::unique_ptr<Model> m(new Model());
+  m->d = std::move(desc);
+  ModelDesc &d = m->d;
+  m->N = d.grid_points();
+  m->C = d.n_channels();
+  m->Cp = round_up(m->C, 4);
+  // density constants exactly as the oracle computes them (fp32)
+  {
+    float e = expf(-2.0f);
+    m->qa = e * 4.0f;
+    m->qb = -e * 12.0f;
+    m->qc = e * 9.0f;
+    for (int t = 0; t < kNumSminaTypes; t++) m->dens[t] = density_consts(smina_xs_radius(t), d.radius_scaling);
+  }
+  m->buf_cp.assign(d.bufs.size(), 0);
+  // op 0 = pool of the voxel grid -> fused into the voxelizer
+  m->input_pool = d.ops[0].pool_mode;
+  m->input_dst = d.ops[0].dst;
+  m->buf_cp[m->input_dst] = round_up(d.bufs[m->input_dst].C, 4);
+  for (size_t i = 1; i < d.ops.size(); i++) {
+    const Op &o = d.ops[i];
+    Step st;
+    st.kind = o.kind;
+    if (o.kind == OpKind::Conv) {
+      // fuse "conv -> pool" when the pool directly consumes this conv's private output
+      int pool_mode = 0, dst = o.dst, dst_c0 = o.dst_c0;
+      if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == o.dst &&
+          o.src != o.dst && o.dst_c0 == 0 && o.cout == d.bufs[o.dst].C) {
+        bool used_elsewhere = false;
+        for (size_t j = i + 2; j < d.ops.size(); j++)
+          if (d.ops[j].src == o.dst) used_elsewhere = true;
+        if (!used_elsewhere) {
+          pool_mode = d.ops[i + 1].pool_mode;
+          dst = d.ops[i + 1].dst;
+          i++;  // swallow the pool
+        }
+      }
+      plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
+      m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
+    } else if (o.kind == OpKind::Pool) {
+      st.src = o.src;
+      st.dst = o.dst;
+      st.pool_mode = o.pool_mode;
+      st.C = d.bufs[o.src].C;
+      m->buf_cp[o.dst] = round_up(d.bufs[o.dst].C, 4);
+    } else if (o.kind == OpKind::GMax) {
+      st.src = o.src;
+      st.dst = o.dst;
+      st.C = d.bufs[o.src].C;
+      m->buf_cp[o.dst] = d.bufs[o.dst].C;
+    } else {
+      st.src = o.src;
+      st.w_off = o.w_off;
+      st.b_off = o.b_off;
+      st.n_in = o.n_in;
+      MIG_CHECK(m->buf_cp[o.src] == d.bufs[o.src].C, 2, "fc input buffer must not be channel padded");
+      MIG_CHECK(o.n_in % 4 == 0, 2, "fc input size must be a multiple of 4");
+    }
+    m->steps.push_back(st);
+  }
+  for (const Step &st : m->steps) {
+    int s = st.kind == OpKind::Conv ? st.conv.src : st.src;
+    MIG_CHECK(s >= 0 && m->buf_cp[s] > 0, 2, "layer program reads a buffer nothing produced");
+  }
+  m->dev_data.ensure(d.data.size());
+  MIG_HIP(hipMemcpy(m->dev_data.p, d.data.data(), d.data.size() * sizeof(float), hipMemcpyHostToDevice));
+  return m.release();
+}
+
+// -------------------------------------------------------------------------------------------
+// Scorer
+// -------------------------------------------------------------------------------------------
+struct TypedReceptor {  // one per distinct (recmap, radius_scaling)
+  TypeMap map;
+  float radius_scaling = 1.f;
+  int n = 0;
+  DevBuf<AtomRec> rec;
+  DevBuf<int> chan;
+};
+
+struct VoxGroup {  // models sharing one voxelization: same maps, geometry, radius scale, input pool
+  int rec_idx = -1;
+  int first_model = -1;
+  std::vector<int> models;
+};
+
+struct Scorer {
+  std::vector<Model *> models;
+  hipStream_t stream = nullptr;
+  int chunk = 256;
+  bool have_receptor = false;
+  int n_rec_atoms_in = 0;
+  std::vector<std::unique_ptr<TypedReceptor>> receptors;
+  std::vector<VoxGroup> groups;
+  // per-call ligand staging
+  DevBuf<float> d_lig, d_centers_in, d_centers;
+  DevBuf<int> d_lig_perm, d_lig_chan, d_cand_chan, d_cand_n;
+  DevBuf<LigConsts> d_lig_consts;
+  DevBuf<unsigned char> d_lig_typed;
+  DevBuf<AtomRec> d_cand;
+  // activations: one set of buffers sized for `chunk` poses, shared by all models (max size per id)
+  std::vector<std::unique_ptr<DevBuf<float>>> act;
+  // outputs per model [n_models][B] and reduced
+  DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var;
+  int last_B = 0;
+  bool timing = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_ms[3] = {0, 0, 0};
+  ~Scorer() {
+    for (auto *m : models)
+      if (m && --m->refs == 0) delete m;
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
+
+static float *act_buf(Scorer &s, size_t id, size_t floats) {
+  if (s.act.size() <= id) s.act.resize(id + 1);
+  if (!s.act[id]) s.act[id].reset(new DevBuf<float>());
+  s.act[id]->ensure(floats);
+  return s.act[id]->p;
+}
+
+static void build_groups(Scorer &s) {
+  s.groups.clear();
+  for (size_t mi = 0; mi < s.models.size(); mi++) {
+    Model *m = s.models[mi];
+    bool placed = false;
+    for (auto &g : s.groups) {
+      Model *f = s.models[g.first_model];
+      if (f->d.recmap == m->d.recmap && f->d.ligmap == m->d.ligmap && f->d.resolution == m->d.resolution &&
+          f->d.dimension == m->d.dimension && f->d.radius_scaling == m->d.radius_scaling &&
+          f->input_pool == m->input_pool && f->Cp == m->Cp) {
+        g.models.push_back((int)mi);
+        placed = true;
+        break;
+      }
+    }
+    if (!placed) {
+      VoxGroup g;
+      g.first_model = (int)mi;
+      g.models.push_back((int)mi);
+      s.groups.push_back(g);
+    }
+  }
+}
+
+static void set_receptor(Scorer &s, const float *xyz, const int32_t *smt, int n) {
+  s.receptors.clear();
+  for (auto &g : s.groups) {
+    Model *m = s.models[g.first_model];
+    int found = -1;
+    for (size_t r = 0; r < s.receptors.size(); r++)
+      if (s.receptors[r]->map == m->d.recmap && s.receptors[r]->radius_scaling == m->d.radius_scaling) found = (int)r;
+    if (found < 0) {
+      std::unique_ptr<TypedReceptor> tr(new TypedReceptor());
+      tr->map = m->d.recmap;
+      tr->radius_scaling = m->d.radius_scaling;
+      // type (make_coordset, torch_model.cpp:120-142), drop untyped atoms, stable sort by channel
+      std::vector<int> idx;
+      for (int i = 0; i < n; i++) {
+        int t = smt[i];
+        MIG_CHECK(t >= 0 && t < kNumSminaTypes, 1, "receptor smina type out of range");
+        if (tr->map.chan_of_smt[t] >= 0) idx.push_back(i);
+      }
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        return tr->map.chan_of_smt[smt[a]] < tr->map.chan_of_smt[smt[b]];
+      });
+      std::vector<AtomRec> recs(idx.size());
+      std::vector<int> chans(idx.size());
+      for (size_t k = 0; k < idx.size(); k++) {
+        int i = idx[k];
+        const DensityConsts &dc = m->dens[smt[i]];
+        recs[k] = AtomRec{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], dc.ar, dc.t2, dc.g2, dc.kexp, dc.inv_ar};
+        chans[k] = tr->map.chan_of_smt[smt[i]];
+      }
+      tr->n = (int)idx.size();
+      tr->rec.upload(recs.data(), recs.size(), s.stream);
+      tr->chan.upload(chans.data(), chans.size(), s.stream);
+      MIG_HIP(hipStreamSynchronize(s.stream));
+      s.receptors.push_back(std::move(tr));
+      found = (int)s.receptors.size() - 1;
+    }
+    g.rec_idx = found;
+  }
+  s.have_receptor = true;
+  s.n_rec_atoms_in = n;
+}
+
+struct LigSetup {
+  int n_lig = 0;  // typed ligand atoms
+};
+
+// Type the ligand rows with the group's ligand map, upload permutation / constants.
+static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_smt, int L) {
+  Model *m = s.models[g.first_model];
+  std::vector<int> idx;
+  std::vector<unsigned char> typed(L, 0);
+  for (int i = 0; i < L; i++) {
+    int t = lig_smt[i];
+    MIG_CHECK(t >= 0 && t < kNumSminaTypes, 1, "ligand smina type out of range");
+    if (m->d.ligmap.chan_of_smt[t] >= 0) {
+      idx.push_back(i);
+      typed[i] = 1;
+    }
+  }
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    return m->d.ligmap.chan_of_smt[lig_smt[a]] < m->d.ligmap.chan_of_smt[lig_smt[b]];
+  });
+  std::vector<int> chan(idx.size());
+  std::vector<LigConsts> lc(idx.size());
+  for (size_t k = 0; k < idx.size(); k++) {
+    const DensityConsts &dc = m->dens[lig_smt[idx[k]]];
+    lc[k] = LigConsts{dc.ar, dc.t2, dc.g2, dc.kexp, dc.inv_ar};
+    chan[k] = m->d.ligmap.chan_of_smt[lig_smt[idx[k]]] + m->d.recmap.n_channels;  // torch_model.cpp:168
+  }
+  s.d_lig_perm.upload(idx.data(), idx.size(), s.stream);
+  s.d_lig_chan.upload(chan.data(), chan.size(), s.stream);
+  s.d_lig_consts.upload(lc.data(), lc.size(), s.stream);
+  s.d_lig_typed.upload(typed.data(), typed.size(), s.stream);
+  // the uploads read from stack vectors: make them complete before those die
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  LigSetup ls;
+  ls.n_lig = (int)idx.size();
+  return ls;
+}
+
+// gather + voxelize poses [b0, b0+nb) of the batch for one group. mode: 0 full grid, 1/2 pooled.
+static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, const float *d_lig_xyz, int L,
+                           const float *d_centers_in, unsigned flags, int b0, int nb, int mode, float *out) {
+  Model *m = s.models[g.first_model];
+  TypedReceptor &tr = *s.receptors[g.rec_idx];
+  const int cap = tr.n + ls.n_lig + 1;
+  s.d_cand.ensure((size_t)nb * cap);
+  s.d_cand_chan.ensure((size_t)nb * cap);
+  s.d_cand_n.ensure(nb);
+  GatherArgs ga{};
+  ga.rec = tr.rec.p;
+  ga.rec_chan = tr.chan.p;
+  ga.n_rec = tr.n;
+  ga.lig_xyz = d_lig_xyz + (size_t)b0 * L * 3;
+  ga.L = L;
+  ga.lig_perm = s.d_lig_perm.p;
+  ga.lig_consts = s.d_lig_consts.p;
+  ga.lig_chan = s.d_lig_chan.p;
+  ga.n_lig = ls.n_lig;
+  ga.lig_typed = s.d_lig_typed.p;
+  ga.centers_in = d_centers_in ? d_centers_in + (size_t)b0 * 3 : nullptr;
+  ga.center_typed_only = (flags & MI_CENTER_TYPED_ONLY) ? 1 : 0;
+  ga.half_dim = m->d.dimension / 2.0f;
+  ga.centers_out = s.d_centers.p + (size_t)b0 * 3;
+  ga.cand = s.d_cand.p;
+  ga.cand_chan = s.d_cand_chan.p;
+  ga.cand_n = s.d_cand_n.p;
+  ga.cap = cap;
+  launch_gather(ga, nb, s.stream);
+  VoxArgs va{};
+  va.cand = s.d_cand.p;
+  va.cand_chan = s.d_cand_chan.p;
+  va.cand_n = s.d_cand_n.p;
+  va.cap = cap;
+  va.centers = ga.centers_out;
+  va.N = m->N;
+  va.tiles_per_axis = cdiv(cdiv(m->N, 2), 4);
+  va.C = m->C;
+  va.Cp = m->Cp;
+  va.res = m->d.resolution;
+  va.half_dim = ga.half_dim;
+  va.qa = m->qa;
+  va.qb = m->qb;
+  va.qc = m->qc;
+  va.out = out;
+  launch_voxelize(va, nb, mode, s.stream);
+  MIG_HIP(hipGetLastError());
+}
+
+// Run the layer program of model mi on `nb` poses whose pooled grid already sits in
+// act[input_dst]; writes pose/aff/loss at out offsets.
+static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss) {
+  Model *m = s.models[mi];
+  auto buf_ptr = [&](int id) -> float * {
+    const BufDecl &bd = m->d.bufs[id];
+    // the pooled voxel grid lives in a dedicated slot shared by all models of a voxelization group
+    const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
+    return act_buf(s, slot, (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id]);
+  };
+  for (const Step &st : m->steps) {
+    switch (st.kind) {
+      case OpKind::Conv: {
+        ConvArgs a = st.conv.a;
+        a.in = buf_ptr(st.conv.src);
+        a.in_cs = m->buf_cp[st.conv.src];
+        a.out = buf_ptr(st.conv.dst);
+        a.out_cs = m->buf_cp[st.conv.dst];
+        launch_conv(a, st.conv.cfg, nb, s.stream);
+        break;
+      }
+      case OpKind::Pool:
+        launch_pool_cl(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
+                       m->d.bufs[st.src].S, st.pool_mode, s.stream);
+        break;
+      case OpKind::GMax:
+        launch_gmax(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
+                    m->d.bufs[st.src].S, s.stream);
+        break;
+      case OpKind::Fc:
+        launch_fc_heads(buf_ptr(st.src), m->dev_data.p + st.w_off, m->dev_data.p + st.b_off, st.n_in,
+                        m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss, nullptr, nb, s.stream);
+        break;
+    }
+  }
+  MIG_HIP(hipGetLastError());
+}
+
+static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                        const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags) {
+  MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
+  MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
+  MIG_CHECK(pose && aff && loss, 1, "output arrays must not be NULL");
+  if (B == 0) return;
+  const int nm = (int)s.models.size();
+  const float *d_lig = lig_xyz;
+  const float *d_cen = centers;
+  if (!(flags & MI_LIG_ON_DEVICE)) {
+    s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
+    d_lig = s.d_lig.p;
+    if (centers) {
+      s.d_centers_in.upload(centers, (size_t)B * 3, s.stream);
+      d_cen = s.d_centers_in.p;
+    }
+  }
+  s.d_centers.ensure((size_t)B * 3);
+  s.d_pose_m.ensure((size_t)nm * B);
+  s.d_aff_m.ensure((size_t)nm * B);
+  s.d_loss_m.ensure((size_t)nm * B);
+  if (s.timing) {
+    for (auto &e : s.ev)
+      if (!e) MIG_HIP(hipEventCreate(&e));
+    s.last_ms[0] = s.last_ms[1] = 0.f;
+    MIG_HIP(hipEventRecord(s.ev[0], s.stream));
+  }
+  for (const VoxGroup &g : s.groups) {
+    Model *m0 = s.models[g.first_model];
+    LigSetup ls = setup_ligand(s, g, lig_smt, L);
+    const BufDecl &ib = m0->d.bufs[m0->input_dst];
+    for (int b0 = 0; b0 < B; b0 += s.chunk) {
+      const int nb = std::min(s.chunk, B - b0);
+      float *pooled = act_buf(s, kPooledSlot, (size_t)s.chunk * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst]);
+      voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled);
+      for (int mi : g.models)
+        run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
+                    s.d_loss_m.p + (size_t)mi * B + b0);
+    }
+  }
+  const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
+  float *o_pose = pose, *o_aff = aff, *o_loss = loss, *o_var = var;
+  if (!out_dev) {
+    s.d_pose.ensure(B);
+    s.d_aff.ensure(B);
+    s.d_loss.ensure(B);
+    s.d_var.ensure(B);
+    o_pose = s.d_pose.p, o_aff = s.d_aff.p, o_loss = s.d_loss.p, o_var = s.d_var.p;
+  }
+  launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, o_pose, o_aff, o_loss, o_var, s.stream);
+  if (s.timing) MIG_HIP(hipEventRecord(s.ev[2], s.stream));
+  s.last_B = B;
+  if (!out_dev) {
+    MIG_HIP(hipMemcpyAsync(pose, o_pose, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    MIG_HIP(hipMemcpyAsync(aff, o_aff, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    MIG_HIP(hipMemcpyAsync(loss, o_loss, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    if (var) MIG_HIP(hipMemcpyAsync(var, o_var, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    MIG_HIP(hipStreamSynchronize(s.stream));
+    if (s.timing) MIG_HIP(hipEventElapsedTime(&s.last_ms[2], s.ev[0], s.ev[2]));
+  }
+}
+
+}  // namespace mig
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace mig;
+
+#define MI_TRY try {
+#define MI_CATCH_STATUS                                  \
+  }                                                      \
+  catch (const mig::Error &e) {                          \
+    mig::set_last_error(e.what());                       \
+    return e.code;                                       \
+  }                                                      \
+  catch (const std::exception &e) {                      \
+    mig::set_last_error(e.what());                       \
+    return MI_ERR_INVALID;                               \
+  }
+#define MI_CATCH_NULL                                    \
+  }                                                      \
+  catch (const std::exception &e) {                      \
+    mig::set_last_error(e.what());                       \
+    return nullptr;                                      \
+  }
+
+extern "C" {
+
+int mi_gnina_abi_version(void) { return MI_GNINA_ABI_VERSION; }
+
+const char *mi_last_error(void) { return g_last_error.c_str(); }
+
+int mi_gnina_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+mi_status mi_gnina_init(int device) {
+  MI_TRY
+  int n = 0;
+  MIG_HIP(hipGetDeviceCount(&n));
+  MIG_CHECK(n > 0, 3, "no HIP device visible");
+  MIG_CHECK(device >= 0 && device < n, 1, "device index out of range");
+  MIG_HIP(hipSetDevice(device));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_model *mi_model_load(const void *blob, size_t nbytes, const char *name) {
+  MI_TRY
+  ModelDesc d = parse_blob(blob, nbytes, name);
+  Model *m = build_model(std::move(d));
+  return reinterpret_cast<mi_model *>(m);
+  MI_CATCH_NULL
+}
+
+mi_model *mi_model_load_file(const char *path) {
+  MI_TRY
+  MIG_CHECK(path, 1, "NULL path");
+  std::ifstream f(path, std::ios::binary);
+  MIG_CHECK((bool)f, 2, std::string("could not open model file ") + path);  // usage_error, cnn_torch_scorer.cpp:87
+  std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  ModelDesc d = parse_blob(raw.data(), raw.size(), nullptr);
+  return reinterpret_cast<mi_model *>(build_model(std::move(d)));
+  MI_CATCH_NULL
+}
+
+void mi_model_retain(mi_model *m) {
+  if (m) reinterpret_cast<Model *>(m)->refs++;
+}
+
+void mi_model_release(mi_model *m) {
+  if (!m) return;
+  Model *p = reinterpret_cast<Model *>(m);
+  if (--p->refs == 0) delete p;
+}
+
+mi_status mi_model_info(const mi_model *m, float *resolution, float *dimension, int *n_rec, int *n_lig, int *N) {
+  MI_TRY
+  MIG_CHECK(m, 1, "NULL model");
+  const Model *p = reinterpret_cast<const Model *>(m);
+  if (resolution) *resolution = p->d.resolution;
+  if (dimension) *dimension = p->d.dimension;
+  if (n_rec) *n_rec = p->d.recmap.n_channels;
+  if (n_lig) *n_lig = p->d.ligmap.n_channels;
+  if (N) *N = p->N;
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+const char *mi_model_name(const mi_model *m) { return m ? reinterpret_cast<const Model *>(m)->d.name.c_str() : ""; }
+
+int mi_model_type_channel(const mi_model *m, int is_ligand, int smt, float *radius) {
+  if (!m || smt < 0 || smt >= kNumSminaTypes) {
+    if (radius) *radius = 0.f;
+    return -1;
+  }
+  const Model *p = reinterpret_cast<const Model *>(m);
+  if (radius) *radius = smina_xs_radius(smt);
+  return (is_ligand ? p->d.ligmap : p->d.recmap).chan_of_smt[smt];
+}
+
+mi_scorer *mi_scorer_create(mi_model *const *models, int n_models) {
+  MI_TRY
+  MIG_CHECK(models && n_models > 0, 1, "scorer needs at least one model");
+  std::unique_ptr<Scorer> s(new Scorer());
+  for (int i = 0; i < n_models; i++) {
+    MIG_CHECK(models[i], 1, "NULL model in ensemble");
+    Model *m = reinterpret_cast<Model *>(models[i]);
+    m->refs++;
+    s->models.push_back(m);
+  }
+  MIG_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  build_groups(*s);
+  return reinterpret_cast<mi_scorer *>(s.release());
+  MI_CATCH_NULL
+}
+
+void mi_scorer_destroy(mi_scorer *s) { delete reinterpret_cast<Scorer *>(s); }
+
+int mi_scorer_num_models(const mi_scorer *s) { return s ? (int)reinterpret_cast<const Scorer *>(s)->models.size() : 0; }
+
+mi_status mi_scorer_set_receptor(mi_scorer *sc, const float *xyz, const int32_t *smt, int n) {
+  MI_TRY
+  MIG_CHECK(sc && n >= 0 && (n == 0 || (xyz && smt)), 1, "bad receptor arguments");
+  set_receptor(*reinterpret_cast<Scorer *>(sc), xyz, smt, n);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_score_batch_ex(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                   const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
+                                   unsigned flags) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  score_batch(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, flags);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_score_batch(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                const float *centers, float *pose, float *affinity, float *loss, float *aff_var) {
+  return mi_scorer_score_batch_ex(sc, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, MI_MEM_HOST);
+}
+
+mi_status mi_scorer_last_model_outputs(mi_scorer *sc, int m, float *pose, float *affinity, float *loss, int B) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_CHECK(m >= 0 && m < (int)s.models.size() && B == s.last_B && B > 0, 1, "bad model index or batch size");
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  if (pose) MIG_HIP(hipMemcpy(pose, s.d_pose_m.p + (size_t)m * B, B * sizeof(float), hipMemcpyDeviceToHost));
+  if (affinity) MIG_HIP(hipMemcpy(affinity, s.d_aff_m.p + (size_t)m * B, B * sizeof(float), hipMemcpyDeviceToHost));
+  if (loss) MIG_HIP(hipMemcpy(loss, s.d_loss_m.p + (size_t)m * B, B * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_voxelize_batch(mi_scorer *sc, int mi, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                            const float *centers, float *grid_out, float *centers_out, unsigned flags) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before voxelizing");
+  MIG_CHECK(mi >= 0 && mi < (int)s.models.size(), 1, "model index out of range");
+  MIG_CHECK(B >= 0 && L >= 0 && grid_out && (B == 0 || (lig_xyz && lig_smt)), 1, "bad arguments");
+  if (B == 0) return MI_OK;
+  const VoxGroup *grp = nullptr;
+  for (auto &g : s.groups)
+    for (int m : g.models)
+      if (m == mi) grp = &g;
+  Model *m = s.models[mi];
+  const float *d_lig = lig_xyz, *d_cen = centers;
+  if (!(flags & MI_LIG_ON_DEVICE)) {
+    s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
+    d_lig = s.d_lig.p;
+    if (centers) {
+      s.d_centers_in.upload(centers, (size_t)B * 3, s.stream);
+      d_cen = s.d_centers_in.p;
+    }
+  }
+  s.d_centers.ensure((size_t)B * 3);
+  LigSetup ls = setup_ligand(s, *grp, lig_smt, L);
+  const size_t per_pose = (size_t)m->C * m->N * m->N * m->N;
+  const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
+  DevBuf<float> tmp;
+  for (int b0 = 0; b0 < B; b0 += s.chunk) {
+    const int nb = std::min(s.chunk, B - b0);
+    float *dst = out_dev ? grid_out + (size_t)b0 * per_pose : (tmp.ensure((size_t)s.chunk * per_pose), tmp.p);
+    MIG_HIP(hipMemsetAsync(dst, 0, (size_t)nb * per_pose * sizeof(float), s.stream));  // torch::zeros, torch_model.cpp:179
+    voxelize_chunk(s, *grp, ls, d_lig, L, d_cen, flags, b0, nb, 0, dst);
+    if (!out_dev)
+      MIG_HIP(hipMemcpyAsync(grid_out + (size_t)b0 * per_pose, dst, (size_t)nb * per_pose * sizeof(float),
+                             hipMemcpyDeviceToHost, s.stream));
+  }
+  if (centers_out)
+    MIG_HIP(hipMemcpyAsync(centers_out, s.d_centers.p, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int B, float *pose, float *affinity,
+                                 float *loss) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_CHECK(mi >= 0 && mi < (int)s.models.size() && B >= 0 && grids && pose && affinity && loss, 1, "bad arguments");
+  if (B == 0) return MI_OK;
+  Model *m = s.models[mi];
+  const size_t per_pose = (size_t)m->C * m->N * m->N * m->N;
+  DevBuf<float> d_grid, d_out;
+  d_grid.ensure((size_t)std::min(B, s.chunk) * per_pose);
+  d_out.ensure((size_t)3 * B);
+  const BufDecl &ib = m->d.bufs[m->input_dst];
+  for (int b0 = 0; b0 < B; b0 += s.chunk) {
+    const int nb = std::min(s.chunk, B - b0);
+    MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
+                           hipMemcpyHostToDevice, s.stream));
+    float *pooled = act_buf(s, kPooledSlot, (size_t)s.chunk * ib.S * ib.S * ib.S * m->buf_cp[m->input_dst]);
+    launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
+    run_program(s, mi, nb, d_out.p + b0, d_out.p + B + b0, d_out.p + 2 * (size_t)B + b0);
+  }
+  MIG_HIP(hipMemcpyAsync(pose, d_out.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipMemcpyAsync(affinity, d_out.p + B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipMemcpyAsync(loss, d_out.p + 2 * (size_t)B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+void *mi_scorer_stream(mi_scorer *sc) { return sc ? (void *)reinterpret_cast<Scorer *>(sc)->stream : nullptr; }
+
+mi_status mi_scorer_synchronize(mi_scorer *sc) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  if (s.timing && s.ev[2]) (void)hipEventElapsedTime(&s.last_ms[2], s.ev[0], s.ev[2]);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_set_chunk(mi_scorer *sc, int poses_per_chunk) {
+  MI_TRY
+  MIG_CHECK(sc && poses_per_chunk > 0 && poses_per_chunk <= 65535, 1, "chunk must be in [1, 65535]");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  s.chunk = poses_per_chunk;
+  s.act.clear();
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_enable_timing(mi_scorer *sc, int on) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  reinterpret_cast<Scorer *>(sc)->timing = on != 0;
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_last_timing(mi_scorer *sc, float *ms3) {
+  MI_TRY
+  MIG_CHECK(sc && ms3, 1, "bad arguments");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  ms3[0] = s.last_ms[0];
+  ms3[1] = s.last_ms[1];
+  ms3[2] = s.last_ms[2];
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// voxelize.h -- argument blocks for the voxelization kernels (voxelize.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mig {
+
+// One typed atom, 32 bytes, with the density constants of its smina type (typer.h DensityConsts).
+struct AtomRec {
+  float x, y, z, ar;
+  float t2, g2, kexp, inv_ar;
+};
+
+struct LigConsts {
+  float ar, t2, g2, kexp, inv_ar;
+};
+
+struct GatherArgs {
+  const AtomRec *rec;      // typed receptor atoms, sorted by channel (stable)
+  const int *rec_chan;     // their channel in the combined set
+  int n_rec;
+  const float *lig_xyz;    // [B][L][3]
+  int L;
+  const int *lig_perm;     // [n_lig] index into the L ligand rows (typed atoms, sorted by channel)
+  const LigConsts *lig_consts;  // [n_lig]
+  const int *lig_chan;     // [n_lig] channel in the combined set (already offset by n_rec_channels)
+  int n_lig;
+  const unsigned char *lig_typed;  // [L] 1 if the row has a channel (for the typed-only centre switch)
+  const float *centers_in;  // [B][3] or nullptr; non-finite x -> ligand mean
+  int center_typed_only;
+  float half_dim;
+  float *centers_out;  // [B][3]
+  AtomRec *cand;       // [B][cap]
+  int *cand_chan;      // [B][cap]
+  int *cand_n;         // [B]
+  int cap;
+};
+
+struct VoxArgs {
+  const AtomRec *cand;
+  const int *cand_chan;
+  const int *cand_n;
+  int cap;
+  const float *centers;  // [B][3]
+  int N;                 // grid points per side
+  int tiles_per_axis;    // ceil(ceil(N/2) / 4)
+  int C;                 // channels
+  int Cp;                // channel stride of the pooled channels-last output (multiple of 4)
+  float res, half_dim;
+  float qa, qb, qc;      // quadratic tail coefficients (4 e^-2, -12 e^-2, 9 e^-2)
+  float *out;
+};
+
+void launch_gather(const GatherArgs &g, int B, hipStream_t s);
+// mode 0: full grid [B][C][N][N][N] (out must be pre-zeroed); 1: max-pooled; 2: avg-pooled
+// ([B][N/2]^3[Cp], fully written).
+void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s);
+
+}  // namespace mig

@@ -1,0 +1,133 @@
+/*
+ * mi_gnina.h -- C ABI of the MI355X-native gnina CNN-scoring engine (libmi_gnina.so).
+ *
+ * gnina has no plugin/FFI loader: its seams are C++ abstract classes compiled into the binary
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds those seams to; every entry
+ * point names the reference interface it replaces.  Plain pointers and sizes only, status
+ * codes instead of exceptions, caller owns host buffers, library owns device memory.  A handle
+ * must not be shared across host threads (the reference's contract too: one scorer copy per
+ * thread, gninasrc/main/main.cpp:1438, gninasrc/lib/parallel_mc.cpp:146).
+ *
+ * Coordinates are float[n][3] Angstrom; atom types are `smt` enum values 0..27
+ * (gninasrc/lib/atom_constants.h:45-75) as int32.
+ */
+#ifndef MI_GNINA_H_
+#define MI_GNINA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_GNINA_ABI_VERSION 1
+
+typedef int mi_status;
+enum {
+  MI_OK = 0,
+  MI_ERR_INVALID = 1,    /* bad argument (reference: internal_error / VINA_CHECK, common.h:280-288) */
+  MI_ERR_MODEL = 2,      /* unreadable / unsupported model (reference: usage_error, torch_model.cpp:115-117) */
+  MI_ERR_DEVICE = 3,     /* HIP runtime failure */
+  MI_ERR_STATE = 4       /* call order violated (e.g. score before set_receptor) */
+};
+
+typedef struct mi_model mi_model;   /* one network: weights + metadata, device resident, refcounted */
+typedef struct mi_scorer mi_scorer; /* one ensemble bound to one receptor; = a DLScorer copy */
+typedef struct mi_vina mi_vina;     /* Vina/smina pair-table engine (igrid seam) */
+
+/* flags for the *_ex entry points */
+enum {
+  MI_MEM_HOST = 0,
+  MI_LIG_ON_DEVICE = 1,     /* lig_xyz / centers are device pointers */
+  MI_OUT_ON_DEVICE = 2,     /* output arrays are device pointers; call returns after enqueue */
+  MI_CENTER_TYPED_ONLY = 4  /* grid centre = mean of TYPED ligand rows only (SURVEY App. A.3 switch) */
+};
+
+/* ---- process / thread setup --------------------------------------------------------------
+ * Replaces initializeCUDA(int device) (gninasrc/lib/dl_scorer.h:20-21, called main.cpp:753 and
+ * parallel_mc.cpp:197): must be called in every host thread that uses the engine. */
+mi_status mi_gnina_init(int device);
+int mi_gnina_device_count(void);
+int mi_gnina_abi_version(void);
+/* Last error message of the calling thread ("" if none). */
+const char *mi_last_error(void);
+
+/* ---- models -------------------------------------------------------------------------------
+ * Replaces TorchModel<isCUDA>::TorchModel(std::istream&, name, log) (gninasrc/lib/torch_model.h:32,
+ * torch_model.cpp:49-118): `blob` is a MIGNINA1 weight blob (gnina_amd/tools/extract_weights.py
+ * output for one .pt of gninasrc/lib/models/).  Returns NULL on failure (see mi_last_error). */
+mi_model *mi_model_load(const void *blob, size_t nbytes, const char *name);
+mi_model *mi_model_load_file(const char *path);
+void mi_model_retain(mi_model *);
+void mi_model_release(mi_model *);
+/* TorchModel::get_grid_res / get_grid_dim (torch_model.h:42-43) + channel counts of the two
+ * typers (torch_model.h:45-46) + grid points per side (GridMaker::get_first_dim, torch_model.cpp:176). */
+mi_status mi_model_info(const mi_model *, float *resolution, float *dimension, int *n_rec_channels,
+                        int *n_lig_channels, int *grid_points);
+const char *mi_model_name(const mi_model *);
+/* FileMappedGninaTyper::get_int_type(smt) as used by make_coordset (torch_model.cpp:120-142):
+ * returns the channel index (or -1) and the xs_radius of the original smina type. */
+int mi_model_type_channel(const mi_model *, int is_ligand, int smt, float *radius);
+
+/* ---- scorer -------------------------------------------------------------------------------
+ * Replaces CNNTorchScorer<isCUDA> (gninasrc/lib/cnn_torch_scorer.h / .cpp:24-92): an ensemble of
+ * models.  Creation is cheap (= DLScorer::fresh_copy(), dl_scorer.h:65): models are shared,
+ * refcounted and stay device resident. */
+mi_scorer *mi_scorer_create(mi_model *const *models, int n_models);
+void mi_scorer_destroy(mi_scorer *);
+int mi_scorer_num_models(const mi_scorer *);
+
+/* DLScorer::setReceptor (gninasrc/lib/dl_scorer.cpp:93-193): all receptor atoms with their smina
+ * types, once; the receptor is assumed constant afterwards (dl_scorer.cpp:112,150).  Types are
+ * mapped with each model's receptor typer exactly as make_coordset does for every call in the
+ * reference (torch_model.cpp:159). */
+mi_status mi_scorer_set_receptor(mi_scorer *, const float *xyz, const int32_t *smt, int n_atoms);
+
+/* Batched form of CNNTorchScorer::score(model&, compute_gradient=false, affinity, loss, variance)
+ * (cnn_torch_scorer.cpp:105-198) -> TorchModel::forward (torch_model.cpp:153-224) for B poses of
+ * ONE ligand (same atoms/types, different coordinates):
+ *   lig_xyz [B][L][3], lig_smt [L]  = DLScorer::setLigand's view of the model (dl_scorer.cpp:36-88)
+ *   centers [B][3] or NULL          = cnn_center / NaN -> per-pose ligand mean (torch_model.cpp:163-166)
+ *   pose/affinity/loss [B]          = mean over the ensemble of TorchModel::forward's {pose, affinity, loss}
+ *   aff_var [B] or NULL             = population variance of affinity over the ensemble
+ *                                     (cnn_torch_scorer.cpp:181-191)
+ * Synchronous: results are host visible on return (like the reference's score). */
+mi_status mi_scorer_score_batch(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                const float *centers, float *pose, float *affinity, float *loss, float *aff_var);
+/* Same with MI_* flags: device-resident inputs/outputs, asynchronous on the scorer's stream
+ * when MI_OUT_ON_DEVICE is set (use mi_scorer_synchronize). */
+mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                   const float *centers, float *pose, float *affinity, float *loss,
+                                   float *aff_var, unsigned flags);
+/* Per-model raw outputs of the last mi_scorer_score_batch* call: TorchModel::forward's
+ * {pose, affinity, loss} for model `m` (host arrays [B]); used by the parity tests. */
+mi_status mi_scorer_last_model_outputs(mi_scorer *, int m, float *pose, float *affinity, float *loss, int B);
+
+/* GridMaker::forward as invoked at torch_model.cpp:175-181 (and by gninagrid, molgridder.cpp:100-138)
+ * for model `m` of the ensemble: writes float [B][C][N][N][N] (x slowest, z fastest), zero filled
+ * first.  grid_out is host memory unless flags has MI_OUT_ON_DEVICE.  centers_out [B][3] (host,
+ * optional) receives the grid centres used. */
+mi_status mi_voxelize_batch(mi_scorer *, int m, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                            const float *centers, float *grid_out, float *centers_out, unsigned flags);
+
+/* CNN forward only, on caller-provided grids in the reference layout [B][C][N][N][N]
+ * (= module.forward, torch_model.cpp:185, plus the post-processing of :188-195). Host pointers. */
+mi_status mi_model_forward_grids(mi_scorer *, int m, const float *grids, int B, float *pose, float *affinity,
+                                 float *loss);
+
+/* Stream plumbing for benchmarks: the hipStream_t all work of this scorer is enqueued on. */
+void *mi_scorer_stream(mi_scorer *);
+mi_status mi_scorer_synchronize(mi_scorer *);
+/* Max poses processed per internal chunk (activation workspace is sized for it). */
+mi_status mi_scorer_set_chunk(mi_scorer *, int poses_per_chunk);
+/* Per-stage device time of the last score call, milliseconds, measured with HIP events on the
+ * scorer's stream: [0] gather+voxelize, [1] CNN convs+heads, [2] total.  Requires
+ * mi_scorer_enable_timing(s, 1) before the call. */
+mi_status mi_scorer_enable_timing(mi_scorer *, int on);
+mi_status mi_scorer_last_timing(mi_scorer *, float *ms3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_GNINA_H_ */

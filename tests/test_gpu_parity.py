@@ -1,0 +1,207 @@
+"""GPU parity tests (MI355X): the HIP path, called through the C ABI, against
+  (a) the reference's own goldens (gninagrid grids; TorchScript outputs in tests/golden/*.npz),
+  (b) the CPU oracle (oracle/) on the same seeded inputs.
+Tolerances: voxel grids 1e-5 abs vs the oracle (reference's own: 1e-4, compare_dx.py:24), support
+set and grid centres bit-exact; CNN pose / affinity 1e-4 abs (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref, voxel
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHTS = os.path.join(ROOT, "gnina_amd", "weights")
+MODELS = ["default2017", "crossdock_default2018", "dense", "dense_1_3", "dense_1_3_PT_KD_3",
+          "crossdock_default2018_KD_4"]
+ALIPH_C = 2
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import capi as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def VG(golden_dir):
+    return np.load(os.path.join(golden_dir, "voxel_goldens.npz"))
+
+
+@pytest.fixture(scope="module")
+def CG(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+
+
+def oracle_maps(blob):
+    return voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
+
+
+def test_library_loaded_and_device(capi):
+    assert capi.lib().mi_gnina_device_count() >= 1
+    assert capi.lib().mi_gnina_abi_version() == 1
+
+
+def test_typer_bit_exact(capi):
+    for name in ("default2017", "crossdock_default2018"):
+        m = capi.Model(name)
+        blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+        rmap, lmap = oracle_maps(blob)
+        assert np.array_equal(m.chan_of_smt(False), rmap[0]) and m.n_rec_channels == rmap[1]
+        assert np.array_equal(m.chan_of_smt(True), lmap[0]) and m.n_lig_channels == lmap[1]
+        radii = np.array([m.type_channel(False, t)[1] for t in range(28)], dtype=np.float32)
+        assert np.array_equal(radii, voxel.xs_radii())
+
+
+def test_voxelize_reference_golden_cc(capi, VG):
+    """gninagrid golden (test/gninagrid/CMakeLists.txt:26-28): CC.xyz as receptor and ligand, default2017 maps."""
+    s = capi.Scorer(["default2017"])
+    lig = VG["cc_xyz"]
+    smt = np.full(len(lig), ALIPH_C, dtype=np.int32)
+    rec = np.round(lig.astype(np.float64), 3).astype(np.float32)
+    s.set_receptor(rec, smt)
+    grids, cen = s.voxelize_batch(lig[None], smt)
+    assert grids.shape == (1, 35, 48, 48, 48)
+    np.testing.assert_allclose(cen[0] - 11.75, VG["ccdx_lig_origin"], atol=1e-5)
+    assert np.abs(grids[0, 16] - VG["ccdx_lig"]).max() < 1e-4
+    assert np.abs(grids[0, 0] - VG["ccdx_rec"]).max() < 1e-4
+    assert np.abs(grids[0, 16] - VG["ccmap_lig"]).max() < 1e-4
+    assert not np.delete(grids[0], [0, 16], axis=0).any()
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018"])
+def test_voxelize_vs_oracle_synthetic(capi, CG, name):
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    grids, cen = s.voxelize_batch(poses, lig_smt)
+    for b in range(len(poses)):
+        ref, c = voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap)
+        assert np.array_equal(c, cen[b])                       # grid centre bit-exact
+        assert np.array_equal(ref != 0, grids[b] != 0)          # grid indexing / support set bit-exact
+        assert np.abs(ref - grids[b]).max() < 1e-5
+    np.testing.assert_allclose(grids.reshape(len(poses), -1).sum(1, dtype=np.float64), CG[name + "/grid_sum"],
+                               rtol=1e-6)
+
+
+def test_voxelize_edge_cases(capi):
+    name = "crossdock_default2018"
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rng = np.random.RandomState(7)
+    rec_xyz = rng.uniform(-12, 12, (300, 3)).astype(np.float32)
+    rec_smt = rng.randint(0, 28, 300).astype(np.int32)          # includes hydrogens / unmapped types
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    # (a) ligand with hydrogens (untyped rows count for the centre), explicit centres mixed with NaN
+    lig_smt = np.array([0, 1, 2, 6, 10, 17, 0, 14], dtype=np.int32)
+    poses = rng.normal(0, 3, (3, len(lig_smt), 3)).astype(np.float32)
+    centers = np.array([[np.nan] * 3, [1.0, -2.0, 0.5], [np.nan] * 3], dtype=np.float32)
+    grids, cen = s.voxelize_batch(poses, lig_smt, centers)
+    for b in range(3):
+        cin = None if np.isnan(centers[b, 0]) else centers[b]
+        ref, c = voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap, cin)
+        assert np.array_equal(c, cen[b])
+        assert np.array_equal(ref != 0, grids[b] != 0)
+        assert np.abs(ref - grids[b]).max() < 1e-5
+    # (b) atoms straddling the box boundary and far outside
+    far = poses[:1].copy()
+    far[0, :, 0] += 11.0
+    g2, c2 = s.voxelize_batch(far, lig_smt, np.zeros((1, 3), dtype=np.float32))
+    ref, _ = voxel.voxelize_pose(rec_xyz, rec_smt, far[0], lig_smt, rmap, lmap, np.zeros(3, dtype=np.float32))
+    assert np.array_equal(ref != 0, g2[0] != 0) and np.abs(ref - g2[0]).max() < 1e-5
+    # (c) empty batch and a ligand with no typed atom at all
+    g0, _ = s.voxelize_batch(np.zeros((0, 4, 3), dtype=np.float32), np.zeros(4, dtype=np.int32))
+    assert g0.shape[0] == 0
+    hs = np.zeros(3, dtype=np.int32)
+    g3, c3 = s.voxelize_batch(poses[:1, :3], hs)
+    ref, c = voxel.voxelize_pose(rec_xyz, rec_smt, poses[0, :3], hs, rmap, lmap)
+    assert np.array_equal(c, c3[0]) and np.abs(ref - g3[0]).max() < 1e-5
+    assert not g3[0, rmap[1]:].any()
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_scores_match_reference_torchscript_goldens(capi, CG, name):
+    """End to end (voxelize + CNN) vs outputs of the reference's own .pt on the same atoms."""
+    s = capi.Scorer([name])
+    s.set_receptor(CG[name + "/rec_xyz"], CG[name + "/rec_smt"])
+    out = s.score_batch(CG[name + "/poses"], CG[name + "/lig_smt"])
+    assert np.abs(out["pose"] - CG[name + "/pose"]).max() < 1e-4
+    assert np.abs(out["affinity"] - CG[name + "/affinity"]).max() < 1e-4
+    assert np.abs(out["loss"] - CG[name + "/loss"]).max() < 1e-3
+    assert not out["variance"].any()                    # single model -> variance 0
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "dense"])
+def test_cnn_forward_on_given_grids_vs_oracle(capi, name):
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    C = blob.n_rec_ch + blob.n_lig_ch
+    rng = np.random.RandomState(3)
+    grids = (rng.rand(3, C, 48, 48, 48) * (rng.rand(3, C, 48, 48, 48) < 0.08)).astype(np.float32)
+    s = capi.Scorer([name])
+    pose, aff, loss = s.forward_grids(grids)
+    with torch.no_grad():
+        p0, a0, l0 = cnn_ref.scores(blob, grids)
+        p64, a64, _ = cnn_ref.scores(blob, grids, torch.float64)
+    # random dense-valued grids give large logits: compare against fp64 with a relative budget
+    scale = max(1.0, float(a64.abs().max()))
+    assert np.abs(pose - p64.numpy()).max() < 1e-4
+    assert np.abs(aff - a64.numpy()).max() < 1e-4 * scale
+    assert np.abs(aff - a0.numpy()).max() < 2e-4 * scale
+
+
+def test_ensemble_mean_and_variance(capi, CG):
+    names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]  # gnina's default ensemble
+    s = capi.Scorer(names)
+    base = names[0]
+    s.set_receptor(CG[base + "/rec_xyz"], CG[base + "/rec_smt"])
+    out = s.score_batch(CG[base + "/poses"], CG[base + "/lig_smt"])
+    pose = np.mean([CG[n + "/pose"] for n in names], axis=0)
+    affs = np.stack([CG[n + "/affinity"] for n in names])
+    assert np.abs(out["pose"] - pose).max() < 1e-4
+    assert np.abs(out["affinity"] - affs.mean(0)).max() < 1e-4
+    assert np.abs(out["variance"] - affs.var(0)).max() < 1e-4      # population variance (cnn_torch_scorer.cpp:181-191)
+    for i, n in enumerate(names):
+        p, a, l = s.last_model_outputs(i, len(pose))
+        assert np.abs(p - CG[n + "/pose"]).max() < 1e-4 and np.abs(a - CG[n + "/affinity"]).max() < 1e-4
+
+
+def test_chunking_and_batch_independence(capi, CG):
+    """A pose's score must not depend on batch size / chunking (poses are independent)."""
+    name = "default2017"
+    from gnina_amd import synth
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rec_xyz, rec_smt, lig_smt, poses = synth.make_complex(5, synth.mapped_types(rmap[0]),
+                                                          synth.mapped_types(lmap[0]), 1500, 24, 11)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    full = s.score_batch(poses, lig_smt)
+    s.set_chunk(4)
+    chunked = s.score_batch(poses, lig_smt)
+    single = s.score_batch(poses[5:6], lig_smt)
+    assert np.array_equal(full["pose"], chunked["pose"]) and np.array_equal(full["affinity"], chunked["affinity"])
+    assert single["pose"][0] == full["pose"][5] and single["affinity"][0] == full["affinity"][5]
+    # and against the oracle end to end
+    grids = np.stack([voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap)[0] for b in (0, 5, 10)])
+    with torch.no_grad():
+        p, a, _ = cnn_ref.scores(blob, grids)
+    assert np.abs(full["pose"][[0, 5, 10]] - p.numpy()).max() < 1e-4
+    assert np.abs(full["affinity"][[0, 5, 10]] - a.numpy()).max() < 1e-4
+
+
+def test_error_paths(capi):
+    s = capi.Scorer(["default2017"])
+    with pytest.raises(capi.MiGninaError):      # score before set_receptor (MI_ERR_STATE)
+        s.score_batch(np.zeros((1, 2, 3), dtype=np.float32), np.array([2, 2]))
+    with pytest.raises(capi.MiGninaError):      # unreadable model -> usage_error in the reference
+        capi.Model("/nonexistent/model.mgw")
+    s.set_receptor(np.zeros((1, 3), dtype=np.float32), np.array([2]))
+    with pytest.raises(capi.MiGninaError):      # smina type out of range
+        s.score_batch(np.zeros((1, 1, 3), dtype=np.float32), np.array([99]))
