@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
 // voxelize_tiles
 // ---------------------------------------------------------------------------------------------
 // density of one atom (wave-uniform constants) at squared distance rsq; SURVEY App. A.2.
-__device__ __forceinline__ float density(float rsq, float t2, float g2, float kexp, float inv_ar, float qa,
-                                         float qb, float qc) {
+__device__ __forceinline__ float density(float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
+                                         float qa, float qb, float qc) {
   float v = 0.f;
   if (rsq < t2) {
     if (rsq <= g2) {
@@ -140,6 +140,13 @@ __device__ __forceinline__ float density(float rsq, float t2, float g2, float ke
     } else {
       float dr = __builtin_amdgcn_sqrtf(rsq) * inv_ar;
       float q = (qa * dr + qb) * dr + qc;
+      if (q < 4e-6f) {
+        // thin shell next to the 1.5 r cut-off, where the tail is ~1e-7 and its SIGN decides whether
+        // the voxel is non-zero: redo it with the reference's exact operation sequence
+        // (correctly rounded sqrtf and divide, unfused polynomial) so the support set is bit-exact.
+        float dre = sqrtf(rsq) / ar;
+        q = (qa * dre + qb) * dre + qc;
+      }
       v = q > 0.f ? q : 0.f;
     }
   }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
       mask &= mask - 1;
       const float ax = rl_f(a.x, src), ay = rl_f(a.y, src), az = rl_f(a.z, src);
       const float t2 = rl_f(a.t2, src), g2 = rl_f(a.g2, src), kexp = rl_f(a.kexp, src);
-      const float inv_ar = rl_f(a.inv_ar, src);
+      const float inv_ar = rl_f(a.inv_ar, src), ar = rl_f(a.ar, src);
       const int c = __builtin_amdgcn_readlane(ch, src);
       if (c != cur) {
         flush(cur);
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
           for (int dz = 0; dz < 2; dz++) {
             float rsq = (dxx[dx] + dyy[dy]) + dzz[dz];
             acc[dx * 4 + dy * 2 + dz] =
-                acc[dx * 4 + dy * 2 + dz] + density(rsq, t2, g2, kexp, inv_ar, v.qa, v.qb, v.qc);
+                acc[dx * 4 + dy * 2 + dz] + density(rsq, t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
           }
     }
   }
