@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- CNN-scored poses/sec on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (atom gather -> voxelize -> CNN forward -> pose/affinity
+scores) over one batch of synthetic poses (2,500-atom receptor, 32-atom
+ligand, 1,024 rigid poses, 48^3 grid at 0.5 A) per GPU, inputs resident in HBM when the timed
+region starts, real reference weights (gnina_amd/weights/*.mgw extracted from the reference's .pt).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model default2017] [--batch 1024]
+
+N>1 is launched by the driver with torch.distributed.run (one rank per GPU); the path shards by
+pose with no data-path collective (weak scaling: every rank scores its own 1,024-pose batch), so
+the only collectives are the timing barrier and the max-over-ranks reduction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="default2017")
+    ap.add_argument("--batch", type=int, default=1024, help="poses per step per GPU")
+    ap.add_argument("--chunk", type=int, default=0, help="poses per internal chunk (0 = engine default)")
+    ap.add_argument("--n-rec", type=int, default=2500)
+    ap.add_argument("--n-lig", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
+    """The oracle ("port" of the reference CPU path: libmolgrid-style voxelization in C, one
+    thread like libmolgrid's CPU path, then the network with PyTorch CPU ops at B=1 on all host
+    cores, which is what gnina does: torch::set_num_threads, main.cpp:1374) on a bounded sample."""
+    import torch
+    from oracle import cnn_ref, voxel
+    blob = cnn_ref.Blob(blob_path)
+    rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one(b):
+        t0 = time.perf_counter()
+        grid, _ = voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap, None, blob.resolution,
+                                      blob.dimension, blob.radius_scaling)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            p, a, l = cnn_ref.scores(blob, grid[None])
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, float(p[0]), float(a[0])
+
+    one(0)  # warm-up
+    tv = tc = 0.0
+    n = 0
+    scores = []
+    t_start = time.perf_counter()
+    while n < len(poses) and (time.perf_counter() - t_start) < budget_s:
+        a, b, p, af = one(n)
+        tv += a
+        tc += b
+        scores.append((p, af))
+        n += 1
+    return {"value": n / (tv + tc), "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": f"{n} poses of the same workload, B=1 per call like the reference "
+                      f"(torch_model.cpp:179); voxelize {1e3 * tv / n:.1f} ms/pose (C oracle, 1 thread) + "
+                      f"CNN {1e3 * tc / n:.1f} ms/pose (PyTorch CPU fp32, {cores} threads)"}, scores
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from gnina_amd import capi, synth
+    capi.init(local_rank)
+    model = capi.Model(args.model)
+    scorer = capi.Scorer([model])
+    if args.chunk:
+        scorer.set_chunk(args.chunk)
+    rec_types = synth.mapped_types(model.chan_of_smt(False))
+    lig_types = synth.mapped_types(model.chan_of_smt(True))
+    # every rank has the same receptor (replicated) and its own shard of poses
+    rng0 = np.random.RandomState(0)
+    rec_xyz, rec_smt = synth.make_receptor(rng0, args.n_rec, rec_types)
+    lig_xyz, lig_smt = synth.make_ligand(rng0, args.n_lig, lig_types)
+    poses = synth.make_poses(np.random.RandomState(1000 + rank), lig_xyz, args.batch)
+    scorer.set_receptor(rec_xyz, rec_smt)
+
+    B, L = args.batch, args.n_lig
+    d_lig = torch.from_numpy(poses).to(dev)
+    d_out = torch.empty(4, B, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        scorer.score_batch_device(d_lig.data_ptr(), lig_smt, B, L, d_out[0].data_ptr(), d_out[1].data_ptr(),
+                                  d_out[2].data_ptr(), d_out[3].data_ptr())
+
+    def fence():
+        scorer.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    scorer.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing of the same steps with HIP events on the scorer's stream (separate pass so the
+    # event records do not perturb the timed region)
+    scorer.enable_profile(True)
+    for _ in range(args.steps):
+        step()
+    prof = scorer.profile()
+    scorer.enable_profile(False)
+    gpu_scores = d_out.cpu().numpy()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        dom = max(prof, key=lambda r: r["ms_total"])
+        convs = [r for r in prof if r["kernel"].startswith("conv")]
+        dom_conv = max(convs, key=lambda r: r["ms_total"])
+        avg_ms = dom_conv["ms_total"] / dom_conv["launches"]
+        achieved = dom_conv["flops"] / dom_conv["launches"] / (avg_ms * 1e-3) / 1e12
+        total_kernel_ms = sum(r["ms_total"] for r in prof) / args.steps
+        vox = [r for r in prof if r["kernel"].startswith("voxelize")][0]
+        vox_ms = vox["ms_total"] / vox["launches"]
+        res = {
+            "metric": "CNN-scored poses/sec (voxelize + CNN forward, 48^3 grid)",
+            "value": round(value, 1),
+            "unit": "poses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic atoms (SURVEY 8d C2, seeded); real reference weights extracted from the shipped .pt",
+            "config": {
+                "workload": f"C2: {B} poses/GPU/step, receptor {args.n_rec} atoms, ligand {args.n_lig} atoms, "
+                            f"{model.grid_points}^3 x {model.n_channels}ch grid at {model.resolution} A, "
+                            f"model {model.name} (as shipped)",
+                "model_file": model.name, "channels": model.n_channels, "batch_per_gpu": B,
+                "sharding": f"pose-sharded x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": dom_conv["kernel"] + " (conv3d_mfma_kernel)",
+                "achieved": round(achieved, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_flops_per_launch": dom_conv["flops"] / dom_conv["launches"],
+                "poses_per_launch": dom_conv["poses"] // dom_conv["launches"],
+            },
+            "kernels": [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
+                         "ms_per_step": round(r["ms_total"] / args.steps, 4),
+                         "tflops": round(r["flops"] / (r["ms_total"] * 1e-3) / 1e12, 2) if r["flops"] else None,
+                         "gbs_algorithmic": round(r["bytes"] / (r["ms_total"] * 1e-3) / 1e9, 1)}
+                        for r in prof],
+            "voxelizer": {"bound": "hbm", "ms_per_launch": round(vox_ms, 4),
+                          "achieved_GBs_unfused_equivalent": round(vox["bytes"] / vox["launches"] / (vox_ms * 1e-3) / 1e9, 1),
+                          "peak_GBs": PEAK_HBM_GBS,
+                          "note": "bytes = C*N^3*4 per pose (un-fused figure, SURVEY 8d); the kernel writes the "
+                                  "2x2x2-pooled grid, 8x fewer bytes"},
+            "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
+            "dominant_kernel_overall": dom["kernel"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_scores = cpu_baseline(args, os.path.join(ROOT, "gnina_amd", "weights", args.model + ".mgw"),
+                                          rec_xyz, rec_smt, lig_smt, poses, args.cpu_seconds)
+            res["cpu_baseline"] = cb
+            cs = np.array(cpu_scores, dtype=np.float64)
+            n = len(cs)
+            res["score_delta_vs_cpu_oracle"] = {
+                "poses": n,
+                "max_abs_dpose": float(np.abs(gpu_scores[0, :n] - cs[:, 0]).max()),
+                "max_abs_daffinity": float(np.abs(gpu_scores[1, :n] - cs[:, 1]).max())}
+            res["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,7 @@ SYMBOLS = [
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
     "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
+    "mi_scorer_enable_profile", "mi_scorer_profile_json",
 ]
 
 _lib = None
@@ -87,6 +88,10 @@ def lib():
         L.mi_scorer_enable_timing.restype = C.c_int
         L.mi_scorer_last_timing.argtypes = [vp, f32p]
         L.mi_scorer_last_timing.restype = C.c_int
+        L.mi_scorer_enable_profile.argtypes = [vp, C.c_int]
+        L.mi_scorer_enable_profile.restype = C.c_int
+        L.mi_scorer_profile_json.argtypes = [vp]
+        L.mi_scorer_profile_json.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -199,6 +204,25 @@ class Scorer:
         pose, aff, loss = (np.empty(B, dtype=np.float32) for _ in range(3))
         check(lib().mi_model_forward_grids(self.handle, model, _ptr(grids), B, _ptr(pose), _ptr(aff), _ptr(loss)))
         return pose, aff, loss
+
+    def score_batch_device(self, lig_ptr, lig_smt, B, L, pose_ptr, aff_ptr, loss_ptr, var_ptr=None, centers_ptr=None):
+        """Device-resident inputs/outputs (raw pointers), asynchronous on the scorer's stream."""
+        lig_smt = _i32(lig_smt)
+        check(lib().mi_scorer_score_batch_ex(self.handle, C.c_void_p(lig_ptr), _ptr(lig_smt), B, L,
+                                             C.c_void_p(centers_ptr) if centers_ptr else None,
+                                             C.c_void_p(pose_ptr), C.c_void_p(aff_ptr), C.c_void_p(loss_ptr),
+                                             C.c_void_p(var_ptr) if var_ptr else None,
+                                             MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE))
+
+    def enable_profile(self, on=True):
+        check(lib().mi_scorer_enable_profile(self.handle, int(on)))
+
+    def profile(self):
+        import json
+        raw = lib().mi_scorer_profile_json(self.handle)
+        if raw is None:
+            raise MiGninaError(lib().mi_last_error().decode())
+        return json.loads(raw.decode())
 
     def set_chunk(self, n):
         check(lib().mi_scorer_set_chunk(self.handle, int(n)))

@@ -33,6 +33,7 @@ void set_last_error(const std::string &msg) { g_last_error = msg; }
 // -------------------------------------------------------------------------------------------
 struct ConvPlan {
   int cfg = 0;
+  int cin = 0;           // real (unpadded) input channels, for FLOP accounting
   ConvArgs a{};          // device pointers to weights filled at load; in/out patched per run
   int src = -1, dst = -1;
 };
@@ -149,6 +150,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
   cp.src = o.src;
   cp.dst = dst_buf;
+  cp.cin = o.cin;
   MIG_CHECK(conv_lds_bytes(a) <= 160 * 1024, 2, "conv tile exceeds LDS");
 }
 
@@ -258,6 +260,17 @@ struct Scorer {
   // outputs per model [n_models][B] and reduced
   DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var;
   int last_B = 0;
+  // per-kernel profiling (mi_scorer_enable_profile): HIP events around every launch on `stream`
+  struct ProfRec {
+    std::string name;
+    double flops, bytes;
+    int poses;
+    hipEvent_t e0, e1;
+  };
+  bool profile = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  std::string prof_json;
   bool timing = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
@@ -266,7 +279,45 @@ struct Scorer {
       if (m && --m->refs == 0) delete m;
     for (auto &e : ev)
       if (e) (void)hipEventDestroy(e);
+    for (auto &r : prof) {
+      (void)hipEventDestroy(r.e0);
+      (void)hipEventDestroy(r.e1);
+    }
+    for (auto &e : ev_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static hipEvent_t prof_event(Scorer &s) {
+  hipEvent_t e;
+  if (!s.ev_pool.empty()) {
+    e = s.ev_pool.back();
+    s.ev_pool.pop_back();
+  } else {
+    MIG_HIP(hipEventCreate(&e));
+  }
+  return e;
+}
+
+// RAII: records an event pair around one kernel launch when profiling is on
+struct ProfScope {
+  Scorer &s;
+  bool on;
+  Scorer::ProfRec r;
+  ProfScope(Scorer &sc, const std::string &name, double flops, double bytes, int poses) : s(sc), on(sc.profile) {
+    if (!on) return;
+    r.name = name;
+    r.flops = flops;
+    r.bytes = bytes;
+    r.poses = poses;
+    r.e0 = prof_event(s);
+    r.e1 = prof_event(s);
+    (void)hipEventRecord(r.e0, s.stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.e1, s.stream);
+    s.prof.push_back(r);
   }
 };
 
@@ -411,7 +462,10 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.cand_chan = s.d_cand_chan.p;
   ga.cand_n = s.d_cand_n.p;
   ga.cap = cap;
-  launch_gather(ga, nb, s.stream);
+  {
+    ProfScope ps(s, "gather_pose_atoms", 0.0, (double)nb * (tr.n + ls.n_lig) * 36.0, nb);
+    launch_gather(ga, nb, s.stream);
+  }
   VoxArgs va{};
   va.cand = s.d_cand.p;
   va.cand_chan = s.d_cand_chan.p;
@@ -428,7 +482,12 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   va.qb = m->qb;
   va.qc = m->qc;
   va.out = out;
-  launch_voxelize(va, nb, mode, s.stream);
+  {
+    // algorithmic bytes: the un-fused figure C*N^3*4 written once per pose
+    ProfScope ps(s, mode == 0 ? "voxelize_tiles<full>" : "voxelize_tiles<pooled>", 0.0,
+                 (double)nb * m->C * m->N * m->N * m->N * 4.0, nb);
+    launch_voxelize(va, nb, mode, s.stream);
+  }
   MIG_HIP(hipGetLastError());
 }
 
@@ -450,7 +509,16 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.in_cs = m->buf_cp[st.conv.src];
         a.out = buf_ptr(st.conv.dst);
         a.out_cs = m->buf_cp[st.conv.dst];
-        launch_conv(a, st.conv.cfg, nb, s.stream);
+        {
+          const double S3 = (double)a.S * a.S * a.S;
+          const int taps = a.ksize * a.ksize * a.ksize;
+          char nm[96];
+          snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s", a.ksize, a.S, st.conv.cin, a.cout,
+                   a.pool ? "_pool" : "");
+          ProfScope ps(s, nm, 2.0 * nb * S3 * taps * st.conv.cin * a.cout,
+                       (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
+          launch_conv(a, st.conv.cfg, nb, s.stream);
+        }
         break;
       }
       case OpKind::Pool:
@@ -461,10 +529,12 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         launch_gmax(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
                     m->d.bufs[st.src].S, s.stream);
         break;
-      case OpKind::Fc:
+      case OpKind::Fc: {
+        ProfScope ps(s, "fc_heads", 2.0 * nb * 3.0 * st.n_in, (double)nb * st.n_in * 4.0, nb);
         launch_fc_heads(buf_ptr(st.src), m->dev_data.p + st.w_off, m->dev_data.p + st.b_off, st.n_in,
                         m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss, nullptr, nb, s.stream);
         break;
+      }
     }
   }
   MIG_HIP(hipGetLastError());
@@ -784,6 +854,68 @@ mi_status mi_scorer_set_chunk(mi_scorer *sc, int poses_per_chunk) {
   s.act.clear();
   return MI_OK;
   MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_enable_profile(mi_scorer *sc, int on) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  s.profile = on != 0;
+  for (auto &r : s.prof) {
+    s.ev_pool.push_back(r.e0);
+    s.ev_pool.push_back(r.e1);
+  }
+  s.prof.clear();
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+const char *mi_scorer_profile_json(mi_scorer *sc) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  struct Agg {
+    std::string name;
+    double ms = 0, flops = 0, bytes = 0;
+    long launches = 0, poses = 0;
+  };
+  std::vector<Agg> aggs;
+  for (auto &r : s.prof) {
+    float ms = 0.f;
+    MIG_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    Agg *a = nullptr;
+    for (auto &x : aggs)
+      if (x.name == r.name) a = &x;
+    if (!a) {
+      aggs.emplace_back();
+      a = &aggs.back();
+      a->name = r.name;
+    }
+    a->ms += ms;
+    a->flops += r.flops;
+    a->bytes += r.bytes;
+    a->launches++;
+    a->poses += r.poses;
+    s.ev_pool.push_back(r.e0);
+    s.ev_pool.push_back(r.e1);
+  }
+  s.prof.clear();
+  std::string j = "[";
+  for (size_t i = 0; i < aggs.size(); i++) {
+    char buf[512];
+    snprintf(buf, sizeof buf,
+             "%s{\"kernel\": \"%s\", \"launches\": %ld, \"poses\": %ld, \"ms_total\": %.6f, \"flops\": %.6e, "
+             "\"bytes\": %.6e}",
+             i ? ", " : "", aggs[i].name.c_str(), aggs[i].launches, aggs[i].poses, aggs[i].ms, aggs[i].flops,
+             aggs[i].bytes);
+    j += buf;
+  }
+  j += "]";
+  s.prof_json = j;
+  return s.prof_json.c_str();
+  MI_CATCH_NULL
 }
 
 mi_status mi_scorer_enable_timing(mi_scorer *sc, int on) {

@@ -127,6 +127,14 @@ mi_status mi_scorer_set_chunk(mi_scorer *, int poses_per_chunk);
 mi_status mi_scorer_enable_timing(mi_scorer *, int on);
 mi_status mi_scorer_last_timing(mi_scorer *, float *ms3);
 
+/* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this
+ * scorer is bracketed by HIP events on the scorer's stream.  mi_scorer_profile_json drains the
+ * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes}], where
+ * flops / bytes are the ALGORITHMIC work of those launches (2*MACs with unpadded channel counts;
+ * bytes as stated in DESIGN.md).  The string stays valid until the next call on this scorer. */
+mi_status mi_scorer_enable_profile(mi_scorer *, int on);
+const char *mi_scorer_profile_json(mi_scorer *);
+
 #ifdef __cplusplus
 }
 #endif
