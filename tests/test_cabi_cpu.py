@@ -1,0 +1,92 @@
+"""CPU-side checks of the C ABI (no GPU needed): the library builds, loads, exports every symbol
+include/mi_gnina.h declares, and fails LOUDLY (no CPU fallback) when there is no device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import build, capi as c
+    build.build()
+    return c
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "mi_gnina.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree(capi):
+    decl = declared_functions()
+    assert decl, "no declarations parsed"
+    assert sorted(capi.SYMBOLS) == decl
+
+
+def test_library_exports_every_declared_symbol(capi):
+    L = capi.lib()
+    for sym in declared_functions():
+        assert hasattr(L, sym), f"libmi_gnina.so does not export {sym}"
+    assert L.mi_gnina_abi_version() == 1
+
+
+def test_no_torch_or_oracle_dependency(capi):
+    """The product library must not link the oracle or torch (plain C ABI over HIP)."""
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in out and "libtorch" not in out and "libc10" not in out
+    assert "libamdhip64" in out
+
+
+def test_product_sources_never_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import oracle/."""
+    pkg = os.path.join(ROOT, "gnina_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+                assert "voxel_ref" not in txt, f
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: the failure path is for GPU-less hosts")
+def test_fails_loudly_without_gpu(capi):
+    assert capi.lib().mi_gnina_device_count() == 0
+    with pytest.raises(capi.MiGninaError):
+        capi.init(0)
+    with pytest.raises(capi.MiGninaError) as ei:
+        capi.Model("default2017")
+    assert "device" in str(ei.value).lower() or "hip" in str(ei.value).lower()
+
+
+def test_null_and_error_paths_do_not_crash(capi):
+    L = capi.lib()
+    assert L.mi_scorer_create(None, 0) is None
+    assert L.mi_last_error().decode() != ""
+    assert L.mi_model_load(b"garbage", 7, b"x") is None
+    assert "MIGNINA1" in L.mi_last_error().decode()
+    assert L.mi_scorer_num_models(None) == 0
+    L.mi_model_release(None)
+    L.mi_scorer_destroy(None)
+    assert L.mi_model_type_channel(None, 0, 2, None) == -1
+
+
+def test_synth_generator_is_deterministic_and_in_spec():
+    from gnina_amd import synth
+    types = np.arange(2, 20, dtype=np.int32)
+    a = synth.make_complex(3, types, types, 500, 16, 5)
+    b = synth.make_complex(3, types, types, 500, 16, 5)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    rec_xyz, rec_smt, lig_smt, poses = a
+    assert rec_xyz.shape == (500, 3) and poses.shape == (5, 16, 3)
+    assert np.linalg.norm(rec_xyz, axis=1).min() >= 4.0 and np.abs(rec_xyz).max() <= 20.0
+    # poses are rigid: pairwise distances preserved
+    d0 = np.linalg.norm(poses[0][:, None] - poses[0][None], axis=-1)
+    d3 = np.linalg.norm(poses[3][:, None] - poses[3][None], axis=-1)
+    assert np.abs(d0 - d3).max() < 1e-4
