@@ -51,5 +51,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_host(force=False, verbose=False):
+    """C++ host adapters (HipCNNScorer : DLScorer) + their test driver, plain g++ over the C ABI."""
+    build(force=force, verbose=verbose)
+    root = os.path.dirname(HERE)
+    exe = os.path.join(LIBDIR, "test_host_scorer")
+    srcs = [os.path.join(root, "tests", "cpp", "test_host_scorer.cpp"), os.path.join(HERE, "host", "hip_cnn_scorer.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "hip_cnn_scorer.h"), os.path.join(HERE, "host", "gnina_types.h"), LIB]
+    if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", exe] + srcs + ["-L" + LIBDIR, "-lmi_gnina",
+                                                                      "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

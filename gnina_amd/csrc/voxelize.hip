@@ -4,7 +4,7 @@
 // gninasrc/lib/torch_model.cpp:175-181 (zeros + gmaker.forward) together with the host work the
 // reference repeats per pose: make_coordset (:120-142), lig.center() (:163-166) and
 // CoordinateSet(rec, lig) (:168).  Semantics follow SURVEY.md App. A (pinned by the gninagrid
-// goldens through oracle/voxel_ref.c).
+// goldens through the CPU restatement under oracle/ -- test infrastructure, never linked here).
 //
 // Design (MI355X-first, not a translation of libmolgrid's CUDA kernel):
 //  * The receptor is typed, filtered and channel-sorted ONCE (engine.cpp) and stays in HBM as

@@ -1,0 +1,257 @@
+#include "hip_cnn_scorer.h"
+
+#include <dirent.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace gnina_amd {
+
+static std::string g_model_dir = "gnina_amd/weights";
+void set_builtin_model_dir(const std::string &dir) { g_model_dir = dir; }
+std::string builtin_model_dir() { return g_model_dir; }
+
+std::vector<std::string> builtin_model_names() {
+  std::vector<std::string> out;
+  if (DIR *d = opendir(g_model_dir.c_str())) {
+    while (dirent *e = readdir(d)) {
+      std::string f = e->d_name;
+      if (f.size() > 4 && f.substr(f.size() - 4) == ".mgw") out.push_back(f.substr(0, f.size() - 4));
+    }
+    closedir(d);
+  }
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+HipTorchModel::HipTorchModel(const std::string &path, const std::string &name) {
+  model_ = mi_model_load_file(path.c_str());
+  if (!model_) throw usage_error("Could not read torch model " + name + ": " + mi_last_error());  // torch_model.cpp:115-117
+  mi_model_info(model_, &res_, &dim_, nullptr, nullptr, nullptr);
+  scorer_ = mi_scorer_create(&model_, 1);
+  if (!scorer_) throw internal_error(mi_last_error());
+}
+
+HipTorchModel::~HipTorchModel() {
+  mi_scorer_destroy(scorer_);
+  mi_model_release(model_);
+}
+
+std::vector<float> HipTorchModel::forward(const std::vector<float3> &rec_coords, const std::vector<smt> &rec_types,
+                                          const std::vector<float3> &lig_coords, const std::vector<smt> &lig_types,
+                                          const vec &center, bool rotate, bool compute_gradient) {
+  if (rec_coords.size() != rec_types.size() || lig_coords.size() != lig_types.size())
+    throw internal_error("Shape mismatch");  // torch_model.cpp:122-123
+  if (rotate || compute_gradient) throw internal_error("rotate / compute_gradient not supported by the HIP engine yet");
+  if (rec_key_ != rec_coords.data() || rec_n_ != rec_coords.size()) {  // receptor assumed constant (dl_scorer.cpp:112)
+    std::vector<int32_t> t(rec_types.begin(), rec_types.end());
+    if (mi_scorer_set_receptor(scorer_, &rec_coords[0].x, t.data(), (int)t.size()) != MI_OK)
+      throw internal_error(mi_last_error());
+    rec_key_ = rec_coords.data();
+    rec_n_ = rec_coords.size();
+  }
+  std::vector<int32_t> lt(lig_types.begin(), lig_types.end());
+  float c[3] = {center[0], center[1], center[2]};
+  float pose, aff, loss;
+  if (mi_scorer_score_batch(scorer_, &lig_coords[0].x, lt.data(), 1, (int)lt.size(), c, &pose, &aff, &loss,
+                            nullptr) != MI_OK)
+    throw internal_error(mi_last_error());
+  return {pose, aff, loss};
+}
+
+// ---------------------------------------------------------------------------------------------
+// DLScorer pieces (stand-alone build only; inside gnina the real dl_scorer.cpp provides them)
+#ifndef MI_GNINA_WITH_GNINA_HEADERS
+}  // namespace gnina_amd
+
+// Ligand = movable atoms from the first ligand's root to m_num_movable_atoms, hydrogens included
+// (dl_scorer.cpp:71-87).  The covalent-docking branch (:43-69) is not restated.
+void DLScorer::setLigand(const model &m) {
+  num_atoms = m.atoms.size();
+  if (m.ligands.empty()) return;
+  const sz off = m.ligands[0].node.begin;
+  const sz n = m.m_num_movable_atoms - off;
+  ligand_smtypes.resize(n);
+  ligand_coords.resize(n);
+  ligand_map.resize(n);
+  for (sz i = 0; i < n; i++) {
+    ligand_smtypes[i] = m.atoms[i + off].sm;
+    const vec &c = m.coords[i + off];
+    ligand_coords[i] = float3{c[0], c[1], c[2]};
+    ligand_map[i] = (int)(i + off);
+  }
+}
+
+// Receptor = flexible-residue movable atoms (before the ligand), then inflex atoms, then fixed
+// atoms; types cached on the first call, flexible coordinates refreshed afterwards (dl_scorer.cpp:93-193).
+void DLScorer::setReceptor(const model &m) {
+  num_atoms = m.atoms.size();
+  const sz n_flex = m.ligands.empty() ? m.m_num_movable_atoms : m.ligands[0].node.begin;
+  const sz n_total = n_flex + (m.atoms.size() - m.m_num_movable_atoms) + m.grid_atoms.size();
+  if (receptor_smtypes.empty()) {
+    for (sz i = 0; i < n_flex; i++) receptor_smtypes.push_back(m.atoms[i].sm);
+    for (sz i = m.m_num_movable_atoms; i < m.atoms.size(); i++) receptor_smtypes.push_back(m.atoms[i].sm);
+    for (const atom &a : m.grid_atoms) receptor_smtypes.push_back(a.sm);
+  }
+  if (receptor_coords.empty()) {
+    for (sz i = 0; i < n_flex; i++) {
+      receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
+      receptor_map.push_back((int)i);
+    }
+    for (sz i = m.m_num_movable_atoms; i < m.coords.size(); i++)
+      receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
+    for (const atom &a : m.grid_atoms) receptor_coords.push_back(float3{a.coords[0], a.coords[1], a.coords[2]});
+  } else if (receptor_coords.size() == n_total) {
+    for (sz i = 0; i < n_flex; i++) receptor_coords[i] = float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]};
+  }
+}
+
+// Centre of the heavy movable atoms (dl_scorer.cpp:197-217)
+void DLScorer::set_center_from_model(model &m) {
+  current_center = vec(0, 0, 0);
+  unsigned cnt = 0;
+  for (const vec &c : m.get_heavy_atom_movable_coords()) {
+    current_center[0] += c[0];
+    current_center[1] += c[1];
+    current_center[2] += c[2];
+    cnt++;
+  }
+  for (int i = 0; i < 3; i++) current_center[i] /= (float)cnt;
+}
+
+namespace gnina_amd {
+#endif
+
+static bool ends_with(const std::string &s, const std::string &suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// Model-name handling of CNNTorchScorer's constructor (cnn_torch_scorer.cpp:24-92): default
+// ensemble, "fast", "default1.0", "<prefix>_ensemble" expansion, external files.
+HipCNNScorer::HipCNNScorer(const cnn_options &opts) : DLScorer(opts) {
+  if (cnnopts.cnn_scoring == CNNnone) return;
+  if (cnnopts.cnn_models.empty()) {
+    auto &names = cnnopts.cnn_model_names;
+    if (names.empty()) {
+      names = {"dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"};
+    } else if (names.size() == 1 && names[0] == "fast") {
+      names[0] = "all_default_to_default_1_3_1";
+    } else if (names.size() == 1 && names[0] == "default1.0") {
+      names = {"dense", "general_default2018_3", "dense_3", "crossdock_default2018", "redock_default2018_2"};
+    }
+  }
+  const std::vector<std::string> avail = builtin_model_names();
+  std::vector<std::string> expanded;
+  for (const std::string &name : cnnopts.cnn_model_names) {
+    if (ends_with(name, "_ensemble")) {
+      const std::string prefix = name.substr(0, name.size() - 9);
+      for (const std::string &a : avail)
+        if (a.compare(0, prefix.size(), prefix) == 0) expanded.push_back(a);
+    } else {
+      expanded.push_back(name);
+    }
+  }
+  for (const std::string &name : expanded) {
+    if (std::find(avail.begin(), avail.end(), name) == avail.end()) throw usage_error("Invalid model name: " + name);
+    models.push_back(std::make_shared<HipTorchModel>(g_model_dir + "/" + name + ".mgw", name));
+  }
+  for (const std::string &f : cnnopts.cnn_models) models.push_back(std::make_shared<HipTorchModel>(f, f));
+  if (!models.empty()) {
+    std::vector<mi_model *> hs;
+    for (auto &m : models) hs.push_back(m->handle());
+    mi_scorer *s = mi_scorer_create(hs.data(), (int)hs.size());
+    if (!s) throw internal_error(mi_last_error());
+    ensemble.reset(s, mi_scorer_destroy);
+  }
+}
+
+std::shared_ptr<DLScorer> HipCNNScorer::fresh_copy() const {
+  // cheap by construction: device weights are shared and refcounted; only the per-copy
+  // workspace and receptor binding are new (the reference reloads every model, main.cpp:1438)
+  auto c = std::make_shared<HipCNNScorer>();
+  c->cnnopts = cnnopts;
+  c->models = models;
+  if (!models.empty()) {
+    std::vector<mi_model *> hs;
+    for (auto &m : models) hs.push_back(m->handle());
+    c->ensemble.reset(mi_scorer_create(hs.data(), (int)hs.size()), mi_scorer_destroy);
+  }
+  return c;
+}
+
+float HipCNNScorer::score(model &m, float &variance) {
+  float aff = 0, loss = 0;
+  return score(m, false, aff, loss, variance);
+}
+
+void HipCNNScorer::score_poses(model &m, const std::vector<float> &lig_xyz, int B, std::vector<float> &pose,
+                               std::vector<float> &affinity, std::vector<float> &loss,
+                               std::vector<float> &variance) {
+  if (!initialized()) throw internal_error("scorer not initialised");
+  setLigand(m);
+  setReceptor(m);
+  if (!receptor_uploaded) {
+    std::vector<int32_t> t(receptor_smtypes.begin(), receptor_smtypes.end());
+    if (mi_scorer_set_receptor(ensemble.get(), &receptor_coords[0].x, t.data(), (int)t.size()) != MI_OK)
+      throw internal_error(mi_last_error());
+    receptor_uploaded = true;
+  }
+  const int L = (int)ligand_smtypes.size();
+  if ((size_t)B * L * 3 != lig_xyz.size()) throw internal_error("Shape mismatch");
+  std::vector<int32_t> lt(ligand_smtypes.begin(), ligand_smtypes.end());
+  std::vector<float> centers;
+  const float *cptr = nullptr;
+  if (!std::isnan(cnnopts.cnn_center[0])) {  // cnn_torch_scorer.cpp:137-140
+    centers.resize((size_t)B * 3);
+    for (int b = 0; b < B; b++)
+      for (int k = 0; k < 3; k++) centers[3 * b + k] = cnnopts.cnn_center[k];
+    cptr = centers.data();
+  }
+  pose.resize(B);
+  affinity.resize(B);
+  loss.resize(B);
+  variance.resize(B);
+  if (mi_scorer_score_batch(ensemble.get(), lig_xyz.data(), lt.data(), B, L, cptr, pose.data(), affinity.data(),
+                            loss.data(), variance.data()) != MI_OK)
+    throw internal_error(mi_last_error());
+}
+
+float HipCNNScorer::score(model &m, bool compute_gradient, float &affinity, float &loss, float &variance) {
+  if (!initialized()) return -1.0;  // cnn_torch_scorer.cpp:107-108
+  if (compute_gradient) throw internal_error("compute_gradient not supported by the HIP engine yet");
+  if (cnnopts.cnn_rotations > 0) throw internal_error("cnn_rotations not supported by the HIP engine yet");
+  setLigand(m);
+  m.clear_minus_forces();  // "ALERT: clears minus forces" (cnn_torch_scorer.cpp:115)
+  std::vector<float> xyz(ligand_coords.size() * 3);
+  std::memcpy(xyz.data(), ligand_coords.data(), xyz.size() * sizeof(float));
+  std::vector<float> p, a, l, v;
+  score_poses(m, xyz, 1, p, a, l, v);
+  affinity = a[0];
+  loss = l[0];
+  variance = v[0];
+  return p[0];
+}
+
+void HipCNNScorer::set_bounding_box(grid_dims &box) const {  // cnn_torch_scorer.cpp:230-242
+  vec center = get_center();
+  fl dim = get_grid_dim();
+  fl n = dim / get_grid_res();
+  fl half = dim / 2.0;
+  for (unsigned i = 0; i < 3; i++) {
+    box[i].begin = center[i] - half;
+    box[i].end = center[i] + half;
+    box[i].n = (sz)n;
+  }
+}
+
+fl HipCNNScorer::get_grid_dim() const {
+  if (models.empty()) throw internal_error("no models");
+  return models[0]->get_grid_dim();
+}
+fl HipCNNScorer::get_grid_res() const {
+  if (models.empty()) throw internal_error("no models");
+  return models[0]->get_grid_res();
+}
+
+}  // namespace gnina_amd

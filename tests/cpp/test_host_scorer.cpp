@@ -1,0 +1,102 @@
+// Drives the C++ host adapters (HipCNNScorer : DLScorer) the way gnina drives CNNTorchScorer:
+// builds a `model` from a typed-atom file written by the pytest harness, scores every pose with
+// score(model&, ...) one at a time (reference behaviour) and all at once with score_poses, and
+// prints the numbers for the harness to compare with the oracle / goldens.
+//
+// input file (little endian): int32 n_rec, n_lig, n_poses, n_models; n_models x (int32 len, chars);
+//   float rec_xyz[n_rec][3]; int32 rec_smt[n_rec]; int32 lig_smt[n_lig]; float poses[n_poses][n_lig][3]
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "../../gnina_amd/host/hip_cnn_scorer.h"
+
+template <typename T> static void rd(std::ifstream &f, T *p, size_t n) { f.read((char *)p, sizeof(T) * n); }
+
+int main(int argc, char **argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s atoms.bin weights_dir [--expect-invalid-name]\n", argv[0]);
+    return 2;
+  }
+  gnina_amd::set_builtin_model_dir(argv[2]);
+  if (argc > 3 && std::string(argv[3]) == "--names") {   // no GPU needed
+    for (auto &n : gnina_amd::builtin_model_names()) std::printf("%s\n", n.c_str());
+    return 0;
+  }
+  if (mi_gnina_init(0) != MI_OK) {
+    std::fprintf(stderr, "init failed: %s\n", mi_last_error());
+    return 3;
+  }
+  std::ifstream f(argv[1], std::ios::binary);
+  int32_t hdr[4];
+  rd(f, hdr, 4);
+  const int n_rec = hdr[0], n_lig = hdr[1], n_poses = hdr[2], n_models = hdr[3];
+  cnn_options opts;
+  for (int i = 0; i < n_models; i++) {
+    int32_t len;
+    rd(f, &len, 1);
+    std::string s(len, ' ');
+    f.read(&s[0], len);
+    opts.cnn_model_names.push_back(s);
+  }
+  std::vector<float> rec_xyz(3 * n_rec), poses((size_t)n_poses * n_lig * 3);
+  std::vector<int32_t> rec_smt(n_rec), lig_smt(n_lig);
+  rd(f, rec_xyz.data(), rec_xyz.size());
+  rd(f, rec_smt.data(), rec_smt.size());
+  rd(f, lig_smt.data(), lig_smt.size());
+  rd(f, poses.data(), poses.size());
+
+  try {
+    cnn_options bad = opts;
+    bad.cnn_model_names = {"no_such_model"};
+    gnina_amd::HipCNNScorer nope(bad);
+    std::printf("ERROR: invalid model name accepted\n");
+    return 1;
+  } catch (const usage_error &e) {
+    std::printf("usage_error_ok %s\n", e.what());
+  }
+
+  gnina_amd::HipCNNScorer scorer(opts);
+  // model: rigid receptor in grid_atoms, ligand as the only movable atoms (ligands[0].node.begin = 0)
+  model m;
+  for (int i = 0; i < n_rec; i++) {
+    atom a;
+    a.sm = rec_smt[i];
+    a.coords = vec(rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2]);
+    m.grid_atoms.push_back(a);
+  }
+  for (int i = 0; i < n_lig; i++) {
+    atom a;
+    a.sm = lig_smt[i];
+    m.atoms.push_back(a);
+    m.coords.push_back(vec());
+  }
+  m.m_num_movable_atoms = n_lig;
+  m.ligands.resize(1);
+  m.ligands[0].node.begin = 0;
+  m.ligands[0].node.end = n_lig;
+
+  std::printf("models %zu initialized %d has_affinity %d\n", scorer.num_models(), (int)scorer.initialized(),
+              (int)scorer.has_affinity());
+  auto copy = scorer.fresh_copy();
+  for (int b = 0; b < n_poses; b++) {
+    for (int i = 0; i < n_lig; i++)
+      m.coords[i] = vec(poses[((size_t)b * n_lig + i) * 3], poses[((size_t)b * n_lig + i) * 3 + 1],
+                        poses[((size_t)b * n_lig + i) * 3 + 2]);
+    float aff, loss, var;
+    float s = scorer.score(m, false, aff, loss, var);
+    float var2;
+    float s2 = copy->score(m, var2);   // a fresh copy must give identical numbers
+    std::printf("single %d %.9g %.9g %.9g %.9g copy %.9g\n", b, s, aff, loss, var, s2);
+  }
+  std::vector<float> p, a, l, v;
+  scorer.score_poses(m, poses, n_poses, p, a, l, v);
+  for (int b = 0; b < n_poses; b++) std::printf("batch %d %.9g %.9g %.9g %.9g\n", b, p[b], a[b], l[b], v[b]);
+  scorer.set_center_from_model(m);
+  grid_dims box;
+  scorer.set_bounding_box(box);
+  std::printf("box %.6g %.6g %zu center %.6g %.6g %.6g\n", box[0].begin, box[0].end, box[0].n,
+              scorer.get_center()[0], scorer.get_center()[1], scorer.get_center()[2]);
+  return 0;
+}
