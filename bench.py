@@ -50,8 +50,7 @@ def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
     from oracle import cnn_ref, voxel
     blob = cnn_ref.Blob(blob_path)
     rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
 
     def one(b):
         t0 = time.perf_counter()
@@ -63,6 +62,16 @@ def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, float(p[0]), float(a[0])
 
+    # gnina uses every hardware thread (torch::set_num_threads(settings.cpu), main.cpp:1374); at B=1
+    # that oversubscribes big hosts, so be generous to the CPU: try a few thread counts, keep the best.
+    best, cores = None, ncpu
+    for t in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16), min(ncpu, 8)}, reverse=True):
+        torch.set_num_threads(t)
+        one(0)
+        dt = min(sum(one(0)[:2]) for _ in range(2))
+        if best is None or dt < best:
+            best, cores = dt, t
+    torch.set_num_threads(cores)
     one(0)  # warm-up
     tv = tc = 0.0
     n = 0
@@ -78,6 +87,23 @@ def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
             "sample": f"{n} poses of the same workload, B=1 per call like the reference "
                       f"(torch_model.cpp:179); voxelize {1e3 * tv / n:.1f} ms/pose (C oracle, 1 thread) + "
                       f"CNN {1e3 * tc / n:.1f} ms/pose (PyTorch CPU fp32, {cores} threads)"}, scores
+
+
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/latest_pmc.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command; units/corrections per MI355X_MICROARCH.md).  bench.py
+    cannot collect PMCs itself; null when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        pm = json.load(open(path))
+        want = pm.get("roofline_kernel_map", {}).get(kernel_label)
+        k = pm["kernels"].get(want) if want else None
+        return k.get("hbm_bytes_per_launch") if k else None
+    except Exception:
+        return None
 
 
 def main():
@@ -187,7 +213,7 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(dom_conv["kernel"]),
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_flops_per_launch": dom_conv["flops"] / dom_conv["launches"],
                 "poses_per_launch": dom_conv["poses"] // dom_conv["launches"],
