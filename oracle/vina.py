@@ -1,0 +1,198 @@
+"""ctypes wrapper over oracle/vina_ref.c (CPU restatement of the smina/Vina scoring + BFGS path).
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import voxel as _voxel
+
+_f32p, _i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+
+class GridDims(C.Structure):
+    _fields_ = [("begin", C.c_float * 3), ("end", C.c_float * 3), ("n", C.c_int * 3)]
+
+    @property
+    def shape(self):  # (nz+1, ny+1, nx+1): x fastest in memory
+        return (self.n[2] + 1, self.n[1] + 1, self.n[0] + 1)
+
+
+class Ligand(C.Structure):
+    _fields_ = [("n_atoms", C.c_int), ("smt", _i32p), ("local_xyz", _f32p), ("n_nodes", C.c_int),
+                ("parent", _i32p), ("abeg", _i32p), ("aend", _i32p), ("rel_origin", _f32p), ("rel_axis", _f32p),
+                ("n_pairs", C.c_int), ("pairs", _i32p)]
+
+
+_configured = False
+
+
+def lib():
+    global _configured
+    L = _voxel.lib()
+    if not _configured:
+        vp = C.c_void_p
+        L.ora_vina_pair_energy.restype = C.c_float
+        L.ora_vina_pair_energy.argtypes = [_f32p, C.c_int, C.c_int, C.c_float]
+        L.ora_vina_tables_create.restype = vp
+        L.ora_vina_tables_create.argtypes = [_f32p, C.c_float, C.c_float]
+        L.ora_vina_tables_free.argtypes = [vp]
+        L.ora_vina_tables_n.restype = C.c_int
+        L.ora_vina_tables_n.argtypes = [vp]
+        L.ora_vina_tables_get.argtypes = [vp, C.c_int, C.c_int, _f32p, _f32p, _f32p]
+        L.ora_vina_eval_fast.restype = C.c_float
+        L.ora_vina_eval_fast.argtypes = [vp, C.c_int, C.c_int, C.c_float]
+        L.ora_vina_table_eval_deriv.restype = None
+        L.ora_vina_table_eval_deriv.argtypes = [vp, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+        L.ora_vina_setup_grid_dims.argtypes = [_f32p, _f32p, C.POINTER(GridDims)]
+        L.ora_vina_cache_populate.argtypes = [vp, C.POINTER(GridDims), _f32p, _i32p, C.c_int, C.c_int, _f32p]
+        L.ora_vina_grid_evaluate.restype = C.c_float
+        L.ora_vina_grid_evaluate.argtypes = [C.POINTER(GridDims), _f32p, _f32p, C.c_float, C.c_float, _f32p]
+        L.ora_vina_set_conf.argtypes = [C.POINTER(Ligand), _f32p, _f32p, _f32p, _f32p]
+        L.ora_vina_conf_increment.argtypes = [_f32p, _f32p, C.c_float, C.c_int]
+        _configured = True
+    return L
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Tables:
+    def __init__(self, weights=None, cutoff=8.0, factor=32.0):
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        self.h = lib().ora_vina_tables_create(_p(w) if w is not None else None, cutoff, factor)
+        self.n = lib().ora_vina_tables_n(self.h)
+
+    def get(self, t1, t2):
+        fast, se, sd = (np.empty(self.n, dtype=np.float32) for _ in range(3))
+        lib().ora_vina_tables_get(self.h, t1, t2, _p(fast), _p(se), _p(sd))
+        return fast, se, sd
+
+    def eval_fast(self, t1, t2, r2):
+        return lib().ora_vina_eval_fast(self.h, t1, t2, r2)
+
+    def eval_deriv(self, t1, t2, r2):
+        e, d = C.c_float(), C.c_float()
+        lib().ora_vina_table_eval_deriv(self.h, t1, t2, r2, C.byref(e), C.byref(d))
+        return e.value, d.value
+
+    def __del__(self):
+        try:
+            lib().ora_vina_tables_free(self.h)
+        except Exception:
+            pass
+
+
+def pair_energy(t1, t2, r, weights=None):
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+    return lib().ora_vina_pair_energy(_p(w) if w is not None else None, t1, t2, r)
+
+
+def setup_grid_dims(center, size):
+    gd = GridDims()
+    c = np.ascontiguousarray(center, dtype=np.float32)
+    s = np.ascontiguousarray(size, dtype=np.float32)
+    lib().ora_vina_setup_grid_dims(_p(c), _p(s), C.byref(gd))
+    return gd
+
+
+def cache_populate(tables, gd, rec_xyz, rec_smt, lig_type):
+    rec_xyz = np.ascontiguousarray(rec_xyz, dtype=np.float32)
+    rec_smt = np.ascontiguousarray(rec_smt, dtype=np.int32)
+    out = np.empty(gd.shape, dtype=np.float32)
+    lib().ora_vina_cache_populate(tables.h, C.byref(gd), _p(rec_xyz), _p(rec_smt, C.c_int32), len(rec_smt),
+                                  int(lig_type), _p(out))
+    return out
+
+
+def grid_evaluate(gd, data, loc, slope, v, deriv=True):
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    d = np.zeros(3, dtype=np.float32)
+    e = lib().ora_vina_grid_evaluate(C.byref(gd), _p(data), _p(loc), slope, v, _p(d) if deriv else None)
+    return e, d
+
+
+class LigandHandle:
+    """Keeps the numpy arrays alive behind the C struct."""
+
+    def __init__(self, lig):
+        self.arr = {k: np.ascontiguousarray(lig[k]) for k in
+                    ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs")}
+        a = self.arr
+        self.n_atoms, self.n_nodes = len(a["smt"]), len(a["parent"])
+        self.n_tors = self.n_nodes - 1
+        self.c = Ligand(self.n_atoms, _p(a["smt"], C.c_int32), _p(a["local_xyz"]), self.n_nodes,
+                        _p(a["parent"], C.c_int32), _p(a["abeg"], C.c_int32), _p(a["aend"], C.c_int32),
+                        _p(a["rel_origin"]), _p(a["rel_axis"]), len(a["pairs"]), _p(a["pairs"], C.c_int32))
+
+
+def set_conf(lig, conf):
+    conf = np.ascontiguousarray(conf, dtype=np.float32)
+    coords = np.empty((lig.n_atoms, 3), dtype=np.float32)
+    origin = np.empty((lig.n_nodes, 3), dtype=np.float32)
+    axis = np.empty((lig.n_nodes, 3), dtype=np.float32)
+    lib().ora_vina_set_conf(C.byref(lig.c), _p(conf), _p(coords), _p(origin), _p(axis))
+    return coords, origin, axis
+
+
+class Scene:
+    """tables + grid dims + per-type grids + ligand: everything model::eval_deriv needs."""
+
+    def __init__(self, tables, gd, grids_by_type, lig, slope=1e3):
+        self.tables, self.gd, self.lig, self.slope = tables, gd, lig, slope
+        self.grids = grids_by_type
+        self.ptrs = (_f32p * 28)()
+        for t in range(28):
+            self.ptrs[t] = _p(grids_by_type[t]) if t in grids_by_type else None
+        lib()
+
+    def eval_deriv(self, conf, v=(1000.0, 1000.0, 1000.0)):
+        """model::eval_deriv -> (energy, change[6+T], coords, forces)"""
+        conf = np.ascontiguousarray(conf, dtype=np.float32)
+        vv = np.ascontiguousarray(v, dtype=np.float32)
+        change = np.empty(6 + self.lig.n_tors, dtype=np.float32)
+        coords = np.empty((self.lig.n_atoms, 3), dtype=np.float32)
+        forces = np.empty((self.lig.n_atoms, 3), dtype=np.float32)
+        f = _model_eval_deriv()
+        e = f(self.tables.h, C.byref(self.gd), self.ptrs, self.slope, C.byref(self.lig.c), _p(conf), _p(vv),
+              _p(change), _p(coords), _p(forces))
+        return e, change, coords, forces
+
+    def eval(self, conf, v=(1000.0, 1000.0, 1000.0)):
+        conf = np.ascontiguousarray(conf, dtype=np.float32)
+        vv = np.ascontiguousarray(v, dtype=np.float32)
+        f = _voxel.lib().ora_vina_eval
+        f.restype = C.c_float
+        f.argtypes = [C.c_void_p, C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, _f32p]
+        return f(self.tables.h, C.byref(self.gd), self.ptrs, self.slope, C.byref(self.lig.c), _p(conf), _p(vv))
+
+    def bfgs(self, conf, v=(1000.0, 1000.0, 1000.0), max_iters=None):
+        """quasi_newton: returns (energy, conf_out, grad, n_evals)"""
+        if max_iters is None:
+            max_iters = (25 + self.lig.n_atoms) // 3  # main.cpp:454-456
+        conf = np.array(conf, dtype=np.float32, copy=True)
+        vv = np.ascontiguousarray(v, dtype=np.float32)
+        g = np.empty(6 + self.lig.n_tors, dtype=np.float32)
+        ev = C.c_long()
+        f = _voxel.lib().ora_vina_bfgs
+        f.restype = C.c_float
+        f.argtypes = [C.c_void_p, C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, _f32p,
+                      C.c_int, _f32p, C.POINTER(C.c_long)]
+        e = f(self.tables.h, C.byref(self.gd), self.ptrs, self.slope, C.byref(self.lig.c), _p(conf), _p(vv),
+              int(max_iters), _p(g), C.byref(ev))
+        return e, conf, g, ev.value
+
+
+def _model_eval_deriv():
+    f = _voxel.lib().ora_vina_model_eval_deriv
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, _f32p,
+                  _f32p, _f32p, _f32p]
+    return f
+
+
+def conf_increment(conf, p, alpha, n_tors):
+    conf = np.array(conf, dtype=np.float32, copy=True)
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    lib().ora_vina_conf_increment(_p(conf), _p(p), alpha, n_tors)
+    return conf

@@ -1,0 +1,704 @@
+/*
+ * oracle/vina_ref.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, scalar fp32 like gnina's `fl` = float, common.h:47; no FMA
+ * contraction) of the smina/Vina scoring + local optimisation path that gnina's Monte-Carlo
+ * docking loop runs, each function citing the reference file:line
+ * it follows under /root/reference/gninasrc/lib/.
+ *
+ * Parity status: "parity unpinned" by stored vectors -- the reference keeps NO golden numbers
+ * for this path; its own tests only assert CPU == CUDA within 0.01 on random
+ * molecules (test/gnina/test_gpucode.cpp:142-147, test_cache.cu:148-153, test_tree.cu:175-187)
+ * and a few inequalities.  The source cannot be compiled here (Boost, OpenBabel, CUDA headers),
+ * so this restatement of the cited lines is the oracle; tests/test_oracle_vina.py checks it
+ * against analytic identities (finite-difference gradients, rigid-motion invariance, table
+ * construction rules) and the parity tests hold the HIP kernels to it.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NT 28
+#define V_PI 3.14159265358979323846f /* common.h: const fl pi = fl(3.1415926535897931) */
+#define V_EPS 1.1920928955078125e-07f /* std::numeric_limits<float>::epsilon(), common.h:328 */
+#define V_MAXFL 3.402823466e+38f
+
+/* atom_constants.h:101-133: xs_radius and the xs_hydrophobe / xs_donor / xs_acceptor flags */
+static const float XS_R[NT] = {0.37f, 0.37f, 1.9f, 1.9f, 1.9f, 1.9f, 1.8f, 1.8f, 1.8f, 1.8f, 1.7f, 1.7f, 1.7f, 1.7f,
+                               2.0f,  2.0f,  2.1f, 1.5f, 1.8f, 2.0f, 2.2f, 1.2f, 1.2f, 1.2f, 1.2f, 1.2f, 1.2f, 1.92f};
+static const unsigned char XS_HYD[NT] = {0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1};
+static const unsigned char XS_DON[NT] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0};
+static const unsigned char XS_ACC[NT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+static inline int is_hydrogen(int t) { return t == 0 || t == 1; }
+
+/* default weights, main.cpp:1324-1328 (stored as fl) */
+static const float DEFAULT_W[5] = {-0.035579f, -0.005156f, 0.840245f, -0.035069f, -0.587439f};
+
+/* everything.h:207-216 */
+static float slope_step(float x_bad, float x_good, float x) {
+  if (x_bad < x_good) {
+    if (x <= x_bad) return 0;
+    if (x >= x_good) return 1;
+  } else {
+    if (x >= x_bad) return 0;
+    if (x <= x_good) return 1;
+  }
+  return (x - x_bad) / (x_good - x_bad);
+}
+
+/* everything.h:48-50 */
+static float gaussian(float x, float width) {
+  float q = x / width;
+  return expf(-(q * q));
+}
+
+/* weighted_terms::eval_fast (weighted_terms.cpp:54-68) with the five default terms:
+ * gauss(o=0,w=0.5) everything.h:153-179, gauss(o=3,w=2), repulsion(o=0) :181-205,
+ * hydrophobic(g=0.5,b=1.5) :218-247, non_dir_h_bond(g=-0.7,b=0) :480-506; all cutoff 8. */
+float ora_vina_pair_energy(const float *w, int t1, int t2, float r) {
+  if (!w) w = DEFAULT_W;
+  float opt = XS_R[t1] + XS_R[t2]; /* optimal_distance, everything.h:149-151 */
+  float acc = 0;
+  acc += w[0] * gaussian(r - (opt + 0.0f), 0.5f);
+  acc += w[1] * gaussian(r - (opt + 3.0f), 2.0f);
+  {
+    float d = r - (opt + 0.0f);
+    acc += w[2] * (d > 0 ? 0.0f : d * d);
+  }
+  acc += w[3] * ((XS_HYD[t1] && XS_HYD[t2]) ? slope_step(1.5f, 0.5f, r - opt) : 0.0f);
+  {
+    int hb = (XS_DON[t1] && XS_ACC[t2]) || (XS_DON[t2] && XS_ACC[t1]); /* atom_constants.h:195-201 */
+    acc += w[4] * (hb ? slope_step(0.0f, -0.7f, r - opt) : 0.0f);
+  }
+  return acc;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * precalculate_linear (precalculate.h:165-272, element :82-163)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n;            /* sz(factor * cutoff_sqr) + 3 */
+  float factor, cutoff_sqr;
+  float *rs;        /* [n+2] sqrt(i / factor), precalculate.h:266-271 */
+  float *fast;      /* [npairs][n] */
+  float *se, *sd;   /* smooth (E, dor) [npairs][n] */
+} ora_vina_tables;
+
+static inline int tri(int t1, int t2) { /* triangular_matrix index, i <= j */
+  if (t1 > t2) {
+    int t = t1;
+    t1 = t2;
+    t2 = t;
+  }
+  return t1 + t2 * (t2 + 1) / 2;
+}
+
+ora_vina_tables *ora_vina_tables_create(const float *w, float cutoff, float factor) {
+  ora_vina_tables *T = (ora_vina_tables *)calloc(1, sizeof(*T));
+  T->factor = factor;
+  T->cutoff_sqr = cutoff * cutoff;
+  T->n = (int)(factor * T->cutoff_sqr) + 3;
+  const int n = T->n, np = NT * (NT + 1) / 2;
+  T->rs = (float *)malloc(sizeof(float) * (n + 2));
+  for (int i = 0; i < n + 2; i++) T->rs[i] = sqrtf((float)i / factor);
+  T->fast = (float *)calloc((size_t)np * n, sizeof(float));
+  T->se = (float *)calloc((size_t)np * n, sizeof(float));
+  T->sd = (float *)calloc((size_t)np * n, sizeof(float));
+  for (int t1 = 0; t1 < NT; t1++)
+    for (int t2 = t1; t2 < NT; t2++) {
+      float *se = T->se + (size_t)tri(t1, t2) * n, *sd = T->sd + (size_t)tri(t1, t2) * n;
+      float *fa = T->fast + (size_t)tri(t1, t2) * n;
+      for (int i = 0; i < n; i++) se[i] = ora_vina_pair_energy(w, t1, t2, T->rs[i]);
+      /* init_from_smooth_fst, precalculate.h:135-158 */
+      for (int i = 0; i < n; i++) {
+        if (i == 0 || i == n - 1) {
+          sd[i] = 0;
+        } else {
+          float delta = T->rs[i + 1] - T->rs[i - 1];
+          float r = T->rs[i];
+          sd[i] = (se[i + 1] - se[i - 1]) / (delta * r);
+        }
+        float f1 = se[i];
+        float f2 = (i + 1 >= n) ? 0 : se[i + 1];
+        fa[i] = (f2 + f1) / 2;
+      }
+    }
+  return T;
+}
+
+void ora_vina_tables_free(ora_vina_tables *T) {
+  if (!T) return;
+  free(T->rs);
+  free(T->fast);
+  free(T->se);
+  free(T->sd);
+  free(T);
+}
+
+int ora_vina_tables_n(const ora_vina_tables *T) { return T->n; }
+
+void ora_vina_tables_get(const ora_vina_tables *T, int t1, int t2, float *fast, float *se, float *sd) {
+  size_t o = (size_t)tri(t1, t2) * T->n;
+  if (fast) memcpy(fast, T->fast + o, sizeof(float) * T->n);
+  if (se) memcpy(se, T->se + o, sizeof(float) * T->n);
+  if (sd) memcpy(sd, T->sd + o, sizeof(float) * T->n);
+}
+
+/* precalculate_linear_element::eval_fast, precalculate.h:90-95 */
+float ora_vina_eval_fast(const ora_vina_tables *T, int t1, int t2, float r2) {
+  int i = (int)(T->factor * r2);
+  return T->fast[(size_t)tri(t1, t2) * T->n + i];
+}
+
+/* precalculate_linear_element::eval_deriv, precalculate.h:97-133 (single component) */
+void ora_vina_table_eval_deriv(const ora_vina_tables *T, int t1, int t2, float r2, float *e, float *dor) {
+  float r2f = T->factor * r2;
+  int i1 = (int)r2f, i2 = i1 + 1;
+  float rem = r2f - (float)i1;
+  const float *se = T->se + (size_t)tri(t1, t2) * T->n, *sd = T->sd + (size_t)tri(t1, t2) * T->n;
+  float e1 = se[i1], e2 = se[i2], d1 = sd[i1], d2 = sd[i2];
+  *e = e1 + rem * (e2 - e1);
+  *dor = d1 + rem * (d2 - d1);
+}
+
+/* curl.h:29-42 */
+static void curl3(float *e, float *d, float v) {
+  if (*e > 0 && v < 0.1f * V_MAXFL) {
+    float tmp = (v < V_EPS) ? 0 : (v / (v + *e));
+    *e *= tmp;
+    float t2 = tmp * tmp;
+    d[0] *= t2;
+    d[1] *= t2;
+    d[2] *= t2;
+  }
+}
+static void curl1(float *e, float v) {
+  if (*e > 0 && v < 0.1f * V_MAXFL) {
+    float tmp = (v < V_EPS) ? 0 : (v / (v + *e));
+    *e *= tmp;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * receptor grids: cache::populate (cache.cpp:104-184), grid::init (grid.cpp:47-68),
+ * grid::evaluate_aux (grid.cpp:96-186); array3d is x-fastest (array3d.h:91-96)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  float begin[3], end[3];
+  int n[3]; /* intervals; points = n + 1 */
+} ora_grid_dims;
+
+/* setup_grid_dims, main.cpp:622-634 (box_granularity 0.375) */
+void ora_vina_setup_grid_dims(const float *center, const float *size, ora_grid_dims *gd) {
+  const float gran = 0.375f;
+  for (int i = 0; i < 3; i++) {
+    gd->n[i] = (int)ceilf(size[i] / gran);
+    float real_span = gran * (float)gd->n[i];
+    gd->begin[i] = center[i] - real_span / 2;
+    gd->end[i] = gd->begin[i] + real_span;
+  }
+}
+
+typedef struct {
+  float init[3], factor[3], factor_inv[3], dim_m1[3];
+  int dim[3];
+} grid_geom;
+
+static grid_geom geom_of(const ora_grid_dims *gd) {
+  grid_geom g;
+  for (int i = 0; i < 3; i++) {
+    g.dim[i] = gd->n[i] + 1;
+    g.init[i] = gd->begin[i];
+    float range = gd->end[i] - gd->begin[i];
+    g.dim_m1[i] = (float)g.dim[i] - 1.0f;
+    g.factor[i] = g.dim_m1[i] / range;
+    g.factor_inv[i] = 1 / g.factor[i];
+  }
+  return g;
+}
+
+/* One ligand-type grid.  data: [(nz+1)][(ny+1)][(nx+1)] with x fastest.  Sum over receptor atoms in
+ * index order (szv_grid possibilities are index ordered), r2 <= cutoff_sqr, hydrogens included as
+ * the reference does not filter grid_atoms here (cache.cpp:141-150; their table rows are just small). */
+void ora_vina_cache_populate(const ora_vina_tables *T, const ora_grid_dims *gd, const float *rec_xyz,
+                             const int32_t *rec_smt, int n_rec, int lig_type, float *data) {
+  grid_geom g = geom_of(gd);
+  for (int z = 0; z < g.dim[2]; z++)
+    for (int y = 0; y < g.dim[1]; y++)
+      for (int x = 0; x < g.dim[0]; x++) {
+        float px = g.init[0] + g.factor_inv[0] * (float)x; /* index_to_argument, grid.h:54-57 */
+        float py = g.init[1] + g.factor_inv[1] * (float)y;
+        float pz = g.init[2] + g.factor_inv[2] * (float)z;
+        float aff = 0;
+        for (int i = 0; i < n_rec; i++) {
+          float dx = rec_xyz[3 * i] - px, dy = rec_xyz[3 * i + 1] - py, dz = rec_xyz[3 * i + 2] - pz;
+          float r2 = dx * dx + dy * dy + dz * dz; /* vec_distance_sqr: sqr(x)+sqr(y)+sqr(z) */
+          if (r2 <= T->cutoff_sqr) aff += ora_vina_eval_fast(T, rec_smt[i], lig_type, r2);
+        }
+        data[(size_t)x + (size_t)g.dim[0] * ((size_t)y + (size_t)g.dim[1] * z)] = aff;
+      }
+}
+
+/* grid::evaluate_aux (grid.cpp:96-186). deriv may be NULL. */
+float ora_vina_grid_evaluate(const ora_grid_dims *gd, const float *data, const float *loc, float slope, float v,
+                             float *deriv) {
+  grid_geom g = geom_of(gd);
+  float s[3], miss[3] = {0, 0, 0};
+  int region[3], a[3];
+  for (int i = 0; i < 3; i++) {
+    s[i] = (loc[i] - g.init[i]) * g.factor[i];
+    if (s[i] < 0) {
+      miss[i] = -s[i];
+      region[i] = -1;
+      a[i] = 0;
+      s[i] = 0;
+    } else if (s[i] >= g.dim_m1[i]) {
+      miss[i] = s[i] - g.dim_m1[i];
+      region[i] = 1;
+      a[i] = g.dim[i] - 2;
+      s[i] = 1;
+    } else {
+      region[i] = 0;
+      a[i] = (int)s[i];
+      s[i] -= (float)a[i];
+    }
+  }
+  const float penalty = slope * (miss[0] * g.factor_inv[0] + miss[1] * g.factor_inv[1] + miss[2] * g.factor_inv[2]);
+#define D(X, Y, Z) data[(size_t)(X) + (size_t)g.dim[0] * ((size_t)(Y) + (size_t)g.dim[1] * (Z))]
+  const int x0 = a[0], y0 = a[1], z0 = a[2], x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  const float f000 = D(x0, y0, z0), f100 = D(x1, y0, z0), f010 = D(x0, y1, z0), f110 = D(x1, y1, z0);
+  const float f001 = D(x0, y0, z1), f101 = D(x1, y0, z1), f011 = D(x0, y1, z1), f111 = D(x1, y1, z1);
+#undef D
+  const float x = s[0], y = s[1], z = s[2], mx = 1 - x, my = 1 - y, mz = 1 - z;
+  float f = f000 * mx * my * mz + f100 * x * my * mz + f010 * mx * y * mz + f110 * x * y * mz + f001 * mx * my * z +
+            f101 * x * my * z + f011 * mx * y * z + f111 * x * y * z;
+  if (deriv) {
+    float gr[3];
+    gr[0] = f000 * (-1) * my * mz + f100 * 1 * my * mz + f010 * (-1) * y * mz + f110 * 1 * y * mz +
+            f001 * (-1) * my * z + f101 * 1 * my * z + f011 * (-1) * y * z + f111 * 1 * y * z;
+    gr[1] = f000 * mx * (-1) * mz + f100 * x * (-1) * mz + f010 * mx * 1 * mz + f110 * x * 1 * mz +
+            f001 * mx * (-1) * z + f101 * x * (-1) * z + f011 * mx * 1 * z + f111 * x * 1 * z;
+    gr[2] = f000 * mx * my * (-1) + f100 * x * my * (-1) + f010 * mx * y * (-1) + f110 * x * y * (-1) +
+            f001 * mx * my * 1 + f101 * x * my * 1 + f011 * mx * y * 1 + f111 * x * y * 1;
+    curl3(&f, gr, v);
+    for (int i = 0; i < 3; i++) {
+      float ge = (region[i] == 0) ? gr[i] : 0;
+      deriv[i] = g.factor[i] * ge + slope * (float)region[i];
+    }
+    return f + penalty;
+  }
+  curl1(&f, v);
+  return f + penalty;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ligand torsion tree: conf -> coordinates, forces -> change
+ * (tree.h:29-59,123-140,152-203,206-233,293-401; quaternion.h:243-257,284-303,327-364)
+ * Nodes are stored in DFS pre-order; node 0 is the rigid root, node k>0 owns torsion k-1
+ * (the iterator order of branches_set_conf / branches_derivative).
+ * conf   = [pos 3][quat a,b,c,d][torsion x (n_nodes-1)]
+ * change = [force 3][torque 3][torsion derivative x (n_nodes-1)]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_atoms;
+  const int32_t *smt;      /* [n_atoms] */
+  const float *local_xyz;  /* [n_atoms][3] coordinates in the owning node's frame */
+  int n_nodes;
+  const int32_t *parent;   /* [n_nodes], parent[0] = -1 */
+  const int32_t *abeg, *aend; /* atom range of each node */
+  const float *rel_origin; /* [n_nodes][3] (node 0 unused) */
+  const float *rel_axis;   /* [n_nodes][3] */
+  int n_pairs;
+  const int32_t *pairs;    /* [n_pairs][2] intramolecular interacting pairs (model.cpp:682-703) */
+} ora_ligand;
+
+static void g_normalize_angle(float *x) { /* quaternion.h:259-282 */
+  if (*x > 3 * V_PI) {
+    float n = (*x - V_PI) / (2 * V_PI);
+    *x -= 2 * V_PI * ceilf(n);
+    g_normalize_angle(x);
+  } else if (*x < -3 * V_PI) {
+    float n = (-*x - V_PI) / (2 * V_PI);
+    *x += 2 * V_PI * ceilf(n);
+    g_normalize_angle(x);
+  } else if (*x > V_PI) {
+    *x -= 2 * V_PI;
+  } else if (*x < -V_PI) {
+    *x += 2 * V_PI;
+  }
+}
+
+static void angle_to_quat(const float *axis, float angle, float *q) { /* quaternion.h:284-291 */
+  g_normalize_angle(&angle);
+  float c = cosf(angle / 2), s = sinf(angle / 2);
+  q[0] = c;
+  q[1] = s * axis[0];
+  q[2] = s * axis[1];
+  q[3] = s * axis[2];
+}
+
+static void quat_mul(const float *l, const float *r, float *o) { /* quaternion.h:293-303 */
+  const float a = l[0], b = l[1], c = l[2], d = l[3], ar = r[0], br = r[1], cr = r[2], dr = r[3];
+  o[0] = +a * ar - b * br - c * cr - d * dr;
+  o[1] = +a * br + b * ar + c * dr - d * cr;
+  o[2] = +a * cr - b * dr + c * ar + d * br;
+  o[3] = +a * dr + b * cr - c * br + d * ar;
+}
+
+static void quat_normalize_approx(float *q) { /* quaternion.h:243-257, tolerance 1e-6 */
+  const float s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (fabsf(s - 1) < 1e-6f) return;
+  const float a = sqrtf(s);
+  const float inv = 1 / a;
+  q[0] *= inv;
+  q[1] *= inv;
+  q[2] *= inv;
+  q[3] *= inv;
+}
+
+static void quat_to_r3(const float *q, float *m) { /* quaternion.h:327-364; m[i + 3 j] = M(i,j) */
+  const float a = q[0], b = q[1], c = q[2], d = q[3];
+  const float aa = a * a, ab = a * b, ac = a * c, ad = a * d, bb = b * b, bc = b * c, bd = b * d, cc = c * c,
+              cd = c * d, dd = d * d;
+  m[0] = (aa + bb - cc - dd);
+  m[3] = 2 * (-ad + bc);
+  m[6] = 2 * (ac + bd);
+  m[1] = 2 * (ad + bc);
+  m[4] = (aa - bb + cc - dd);
+  m[7] = 2 * (-ab + cd);
+  m[2] = 2 * (-ac + bd);
+  m[5] = 2 * (ab + cd);
+  m[8] = (aa - bb - cc + dd);
+}
+
+static void mat_vec(const float *m, const float *v, float *o) { /* common.h:243-246 */
+  o[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  o[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  o[2] = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+}
+
+/* heterotree<rigid_body>::set_conf (tree.h:361-367) -> rigid_body::set_conf (:152-156),
+ * segment::set_conf (:218-233), atom_frame::set_coords (:128-131).
+ * Outputs: coords [n_atoms][3], node origins [n_nodes][3], node axes [n_nodes][3]. */
+void ora_vina_set_conf(const ora_ligand *L, const float *conf, float *coords, float *origin, float *axis) {
+  float *q = (float *)malloc(sizeof(float) * 4 * L->n_nodes);
+  float *M = (float *)malloc(sizeof(float) * 9 * L->n_nodes);
+  for (int k = 0; k < L->n_nodes; k++) {
+    if (k == 0) {
+      origin[0] = conf[0];
+      origin[1] = conf[1];
+      origin[2] = conf[2];
+      memcpy(q, conf + 3, sizeof(float) * 4); /* set_orientation does not normalize (tree.h:53-56) */
+      axis[0] = axis[1] = axis[2] = 0;
+    } else {
+      int p = L->parent[k];
+      float t[3];
+      mat_vec(M + 9 * p, L->rel_origin + 3 * k, t); /* local_to_lab: origin + M * local (tree.h:34-38) */
+      origin[3 * k + 0] = origin[3 * p + 0] + t[0];
+      origin[3 * k + 1] = origin[3 * p + 1] + t[1];
+      origin[3 * k + 2] = origin[3 * p + 2] + t[2];
+      mat_vec(M + 9 * p, L->rel_axis + 3 * k, axis + 3 * k);
+      float rq[4];
+      angle_to_quat(axis + 3 * k, conf[7 + (k - 1)], rq);
+      quat_mul(rq, q + 4 * p, q + 4 * k);
+      quat_normalize_approx(q + 4 * k);
+    }
+    quat_to_r3(q + 4 * k, M + 9 * k);
+    for (int i = L->abeg[k]; i < L->aend[k]; i++) {
+      float t[3];
+      mat_vec(M + 9 * k, L->local_xyz + 3 * i, t);
+      coords[3 * i + 0] = origin[3 * k + 0] + t[0];
+      coords[3 * i + 1] = origin[3 * k + 1] + t[1];
+      coords[3 * i + 2] = origin[3 * k + 2] + t[2];
+    }
+  }
+  free(q);
+  free(M);
+}
+
+static void cross(const float *a, const float *b, float *o) { /* common.h:198-200 */
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* tree<segment>::derivative (tree.h:328-338) / branches_derivative (:301-311): returns the
+ * (force, torque) of node k's subtree about node k's origin, writes the torsion derivative. */
+static void node_derivative(const ora_ligand *L, int k, const float *coords, const float *forces,
+                            const float *origin, const float *axis, float *change, float *ft) {
+  float f[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
+  for (int i = L->abeg[k]; i < L->aend[k]; i++) { /* sum_force_and_torque, tree.h:133-140 */
+    float r[3] = {coords[3 * i] - origin[3 * k], coords[3 * i + 1] - origin[3 * k + 1],
+                  coords[3 * i + 2] - origin[3 * k + 2]};
+    float c[3];
+    cross(r, forces + 3 * i, c);
+    f[0] += forces[3 * i];
+    f[1] += forces[3 * i + 1];
+    f[2] += forces[3 * i + 2];
+    tq[0] += c[0];
+    tq[1] += c[1];
+    tq[2] += c[2];
+  }
+  for (int c = k + 1; c < L->n_nodes; c++) {
+    if (L->parent[c] != k) continue;
+    float cft[6];
+    node_derivative(L, c, coords, forces, origin, axis, change, cft);
+    f[0] += cft[0];
+    f[1] += cft[1];
+    f[2] += cft[2];
+    float r[3] = {origin[3 * c] - origin[3 * k], origin[3 * c + 1] - origin[3 * k + 1],
+                  origin[3 * c + 2] - origin[3 * k + 2]};
+    float cr[3];
+    cross(r, cft, cr);
+    tq[0] += cr[0] + cft[3];
+    tq[1] += cr[1] + cft[4];
+    tq[2] += cr[2] + cft[5];
+  }
+  if (k == 0) { /* rigid_body::set_derivative, tree.h:160-164 */
+    change[0] = f[0];
+    change[1] = f[1];
+    change[2] = f[2];
+    change[3] = tq[0];
+    change[4] = tq[1];
+    change[5] = tq[2];
+  } else { /* axis_frame::set_derivative: torque . axis, tree.h:188-190 */
+    change[6 + (k - 1)] = tq[0] * axis[3 * k] + tq[1] * axis[3 * k + 1] + tq[2] * axis[3 * k + 2];
+  }
+  ft[0] = f[0];
+  ft[1] = f[1];
+  ft[2] = f[2];
+  ft[3] = tq[0];
+  ft[4] = tq[1];
+  ft[5] = tq[2];
+}
+
+/* model::eval_deriv (model.cu:202-225) with ig = cache (cache.cpp:65-83):
+ *   set(c); e = sum over movable heavy atoms of grid::evaluate on its type's grid (v[1]);
+ *   e += eval_interacting_pairs_deriv(ligand pairs, v[0]) (model.cu:38-60);
+ *   ligands.derivative -> change.
+ * grids[t] = data pointer for smina type t (NULL when absent -> atom skipped like t >= nat).
+ * change may be NULL (energy only still uses the deriv-aware code path of the reference's
+ * eval_deriv; for model::eval see ora_vina_eval).  coords_out/forces_out optional. */
+float ora_vina_model_eval_deriv(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids,
+                                float slope, const ora_ligand *L, const float *conf, const float *v, float *change,
+                                float *coords_out, float *forces_out) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *forces = (float *)calloc(3 * (size_t)n, sizeof(float));
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  float e = 0;
+  for (int i = 0; i < n; i++) {
+    int t = L->smt[i];
+    if (is_hydrogen(t) || !grids[t]) continue; /* minus_forces[i] = 0 */
+    float d[3];
+    e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v[1], d);
+    forces[3 * i] = d[0];
+    forces[3 * i + 1] = d[1];
+    forces[3 * i + 2] = d[2];
+  }
+  float ie = 0;
+  for (int p = 0; p < L->n_pairs; p++) {
+    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+    float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
+                  coords[3 * b + 2] - coords[3 * a + 2]};
+    float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    if (r2 < T->cutoff_sqr) {
+      float pe, dor;
+      ora_vina_table_eval_deriv(T, L->smt[a], L->smt[b], r2, &pe, &dor);
+      float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
+      curl3(&pe, force, v[0]);
+      ie += pe;
+      for (int k = 0; k < 3; k++) {
+        forces[3 * a + k] -= force[k];
+        forces[3 * b + k] += force[k];
+      }
+    }
+  }
+  e += ie;
+  if (change) {
+    float ft[6];
+    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
+  }
+  if (coords_out) memcpy(coords_out, coords, sizeof(float) * 3 * n);
+  if (forces_out) memcpy(forces_out, forces, sizeof(float) * 3 * n);
+  free(coords);
+  free(forces);
+  free(origin);
+  free(axis);
+  return e;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * conf increment (conf.h:54-59,103-118; quaternion.cu:32-62,96-100)
+ * ------------------------------------------------------------------------------------------- */
+static float normalized_angle(float x) {
+  g_normalize_angle(&x);
+  return x;
+}
+
+void ora_vina_conf_increment(float *conf, const float *p, float alpha, int n_tors) {
+  conf[0] += alpha * p[0];
+  conf[1] += alpha * p[1];
+  conf[2] += alpha * p[2];
+  float rot[3] = {alpha * p[3], alpha * p[4], alpha * p[5]};
+  float angle = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+  float rq[4] = {1, 0, 0, 0};
+  if (angle > V_EPS) {
+    float inv = 1 / angle;
+    float ax[3] = {inv * rot[0], inv * rot[1], inv * rot[2]};
+    angle_to_quat(ax, angle, rq);
+  }
+  float nq[4];
+  quat_mul(rq, conf + 3, nq);
+  quat_normalize_approx(nq);
+  memcpy(conf + 3, nq, sizeof(nq));
+  for (int i = 0; i < n_tors; i++) {
+    conf[7 + i] += normalized_angle(alpha * p[6 + i]);
+    g_normalize_angle(&conf[7 + i]);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * BFGS with Vina's fast line search (bfgs.h:34-91,357-502; quasi_newton.cpp:49-83)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const ora_vina_tables *T;
+  const ora_grid_dims *gd;
+  const float *const *grids;
+  float slope;
+  const ora_ligand *L;
+  const float *v;
+  long evals;
+} bfgs_ctx;
+
+static float fx(bfgs_ctx *c, const float *conf, float *g) {
+  c->evals++;
+  return ora_vina_model_eval_deriv(c->T, c->gd, c->grids, c->slope, c->L, conf, c->v, g, NULL, NULL);
+}
+
+static inline int hidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
+
+static float dotn(const float *a, const float *b, int n) {
+  float t = 0;
+  for (int i = 0; i < n; i++) t += a[i] * b[i];
+  return t;
+}
+
+/* returns the final energy; conf is updated in place; change g receives the final gradient */
+float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                    const ora_ligand *L, float *conf, const float *v, int max_iters, float *g_out, long *evals_out) {
+  const int nt = L->n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0};
+  float *h = (float *)calloc((size_t)n * (n + 1) / 2, sizeof(float));
+  for (int i = 0; i < n; i++) h[hidx(i, i)] = 1;
+  float *g = (float *)malloc(sizeof(float) * n), *g_new = (float *)malloc(sizeof(float) * n);
+  float *p = (float *)malloc(sizeof(float) * n), *y = (float *)malloc(sizeof(float) * n);
+  float *mhy = (float *)malloc(sizeof(float) * n), *g_orig = (float *)malloc(sizeof(float) * n);
+  float *x_new = (float *)malloc(sizeof(float) * nc), *x_orig = (float *)malloc(sizeof(float) * nc);
+  float f0 = fx(&ctx, conf, g);
+  const float f_orig = f0;
+  memcpy(g_orig, g, sizeof(float) * n);
+  memcpy(x_orig, conf, sizeof(float) * nc);
+  memcpy(g_new, g, sizeof(float) * n);
+  for (int step = 0; step < max_iters; step++) {
+    for (int i = 0; i < n; i++) { /* minus_mat_vec_product, bfgs.h:34-43 */
+      float sum = 0;
+      for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
+      p[i] = -sum;
+    }
+    /* fast_line_search, bfgs.h:73-91 */
+    float f1 = 0, alpha = 1;
+    const float pg = dotn(p, g, n);
+    for (unsigned trial = 0; trial < 10; trial++) {
+      memcpy(x_new, conf, sizeof(float) * nc);
+      ora_vina_conf_increment(x_new, p, alpha, nt);
+      f1 = fx(&ctx, x_new, g_new);
+      if (f1 - f0 < 0.0001f * alpha * pg) break;
+      alpha *= 0.5f;
+    }
+    if (alpha == 0) break;
+    for (int i = 0; i < n; i++) y[i] = g_new[i] - g[i];
+    f0 = f1;
+    memcpy(conf, x_new, sizeof(float) * nc);
+    memcpy(g, g_new, sizeof(float) * n);
+    float gradnormsq = dotn(g, g, n);
+    if (!(gradnormsq >= 1e-4f)) break;
+    if (step == 0) {
+      const float yy = dotn(y, y, n);
+      if (fabsf(yy) > V_EPS) {
+        float dgl = alpha * dotn(y, p, n) / yy;
+        for (int i = 0; i < n; i++) h[hidx(i, i)] = dgl;
+      }
+    }
+    { /* bfgs_update, bfgs.h:52-66 */
+      const float yp = dotn(y, p, n);
+      if (!(alpha * yp < V_EPS)) {
+        for (int i = 0; i < n; i++) {
+          float sum = 0;
+          for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * y[j];
+          mhy[i] = -sum;
+        }
+        const float yhy = -dotn(y, mhy, n);
+        const float r = 1 / (alpha * yp);
+        for (int i = 0; i < n; i++)
+          for (int j = i; j < n; j++)
+            h[hidx(i, j)] += alpha * r * (mhy[i] * p[j] + mhy[j] * p[i]) + alpha * alpha * (r * r * yhy + r) * p[i] * p[j];
+      }
+    }
+  }
+  if (!(f0 <= f_orig)) {
+    f0 = f_orig;
+    memcpy(conf, x_orig, sizeof(float) * nc);
+    memcpy(g, g_orig, sizeof(float) * n);
+  }
+  if (g_out) memcpy(g_out, g, sizeof(float) * n);
+  if (evals_out) *evals_out = ctx.evals;
+  free(h);
+  free(g);
+  free(g_new);
+  free(p);
+  free(y);
+  free(mhy);
+  free(g_orig);
+  free(x_new);
+  free(x_orig);
+  return f0;
+}
+
+/* model::eval with ig = cache (cache.cpp:52-63 + model.cu:22-36): energy only, used by the
+ * Metropolis step (monte_carlo.cpp:44-47). */
+float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                    const ora_ligand *L, const float *conf, const float *v) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  float e = 0;
+  for (int i = 0; i < n; i++) {
+    int t = L->smt[i];
+    if (is_hydrogen(t) || !grids[t]) continue;
+    e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v[1], NULL);
+  }
+  for (int p = 0; p < L->n_pairs; p++) {
+    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+    float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
+          dz = coords[3 * a + 2] - coords[3 * b + 2];
+    float r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 < T->cutoff_sqr) {
+      /* p.eval = eval_fast(...) in the reference (precalculate.h:67-70): midpoint table */
+      float pe = ora_vina_eval_fast(T, L->smt[a], L->smt[b], r2);
+      curl1(&pe, v[0]);
+      e += pe;
+    }
+  }
+  free(coords);
+  free(origin);
+  free(axis);
+  return e;
+}
