@@ -23,9 +23,20 @@ SYMBOLS = [
     "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
+    "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_bfgs_batch", "mi_vina_stream",
 ]
 
 _lib = None
+
+
+class LigandDesc(C.Structure):
+    """mi_ligand_desc (include/mi_gnina.h)"""
+    _fields_ = [("n_atoms", C.c_int32), ("smt", C.c_void_p), ("local_xyz", C.c_void_p), ("n_nodes", C.c_int32),
+                ("node_parent", C.c_void_p), ("node_atom_begin", C.c_void_p), ("node_atom_end", C.c_void_p),
+                ("node_rel_origin", C.c_void_p), ("node_rel_axis", C.c_void_p), ("n_pairs", C.c_int32),
+                ("pairs", C.c_void_p)]
 
 
 class MiGninaError(RuntimeError):
@@ -92,6 +103,28 @@ def lib():
         L.mi_scorer_enable_profile.restype = C.c_int
         L.mi_scorer_profile_json.argtypes = [vp]
         L.mi_scorer_profile_json.restype = C.c_char_p
+        L.mi_vina_create.argtypes = [vp, C.c_float, C.c_float]
+        L.mi_vina_create.restype = vp
+        L.mi_vina_destroy.argtypes = [vp]
+        L.mi_vina_destroy.restype = None
+        L.mi_vina_table_size.argtypes = [vp]
+        L.mi_vina_table_size.restype = C.c_int
+        L.mi_vina_table.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+        L.mi_vina_table.restype = C.c_int
+        L.mi_vina_set_receptor.argtypes = [vp, vp, vp, C.c_int]
+        L.mi_vina_set_receptor.restype = C.c_int
+        L.mi_vina_build_cache.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float]
+        L.mi_vina_build_cache.restype = C.c_int
+        L.mi_vina_cache_grid.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.mi_vina_cache_grid.restype = C.c_int
+        L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
+        L.mi_vina_set_ligand.restype = C.c_int
+        L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.mi_vina_eval_batch.restype = C.c_int
+        L.mi_vina_bfgs_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.mi_vina_bfgs_batch.restype = C.c_int
+        L.mi_vina_stream.argtypes = [vp]
+        L.mi_vina_stream.restype = vp
         _lib = L
     return _lib
 
@@ -236,6 +269,77 @@ class Scorer:
     def __del__(self):
         if getattr(self, "handle", None) and _lib is not None:
             _lib.mi_scorer_destroy(self.handle)
+            self.handle = None
+
+
+class Vina:
+    """Vina/smina engine: pair tables + receptor cache grids + one prepared ligand
+    (mirror of precalculate_linear + cache + model::eval_deriv + quasi_newton)."""
+
+    def __init__(self, weights=None, cutoff=8.0, factor=32.0):
+        w = _f32(weights)
+        self.handle = lib().mi_vina_create(_ptr(w), cutoff, factor)
+        if not self.handle:
+            raise MiGninaError(lib().mi_last_error().decode())
+        self.n = lib().mi_vina_table_size(self.handle)
+        self.grid_shape = None
+        self.n_atoms = self.n_tors = 0
+
+    def table(self, t1, t2):
+        fast, se, sd = (np.empty(self.n, dtype=np.float32) for _ in range(3))
+        check(lib().mi_vina_table(self.handle, t1, t2, _ptr(fast), _ptr(se), _ptr(sd)))
+        return fast, se, sd
+
+    def set_receptor(self, xyz, smt):
+        xyz, smt = _f32(xyz).reshape(-1, 3), _i32(smt)
+        check(lib().mi_vina_set_receptor(self.handle, _ptr(xyz), _ptr(smt), len(smt)))
+
+    def build_cache(self, begin, end, n, lig_types, slope=1e3):
+        begin, end, n, lt = _f32(begin), _f32(end), _i32(n), _i32(lig_types)
+        check(lib().mi_vina_build_cache(self.handle, _ptr(begin), _ptr(end), _ptr(n), _ptr(lt), len(lt), slope))
+        self.grid_shape = (int(n[2]) + 1, int(n[1]) + 1, int(n[0]) + 1)
+
+    def cache_grid(self, smt):
+        out = np.empty(self.grid_shape, dtype=np.float32)
+        check(lib().mi_vina_cache_grid(self.handle, int(smt), _ptr(out), out.size))
+        return out
+
+    def set_ligand(self, lig):
+        a = {k: np.ascontiguousarray(lig[k]) for k in
+             ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs")}
+        self._keep = a
+        d = LigandDesc(len(a["smt"]), _ptr(a["smt"]), _ptr(a["local_xyz"]), len(a["parent"]), _ptr(a["parent"]),
+                       _ptr(a["abeg"]), _ptr(a["aend"]), _ptr(a["rel_origin"]), _ptr(a["rel_axis"]),
+                       len(a["pairs"]), _ptr(a["pairs"]))
+        check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
+        self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
+
+    def eval_batch(self, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False):
+        confs = _f32(confs).reshape(-1, 7 + self.n_tors)
+        B = len(confs)
+        vv = _f32(v)
+        e = np.empty(B, dtype=np.float32)
+        ch = np.empty((B, 6 + self.n_tors), dtype=np.float32) if deriv else None
+        co = np.empty((B, self.n_atoms, 3), dtype=np.float32) if want_coords else None
+        check(lib().mi_vina_eval_batch(self.handle, _ptr(confs), B, _ptr(vv), int(deriv), _ptr(e), _ptr(ch), _ptr(co)))
+        return e, ch, co
+
+    def bfgs_batch(self, confs, v=(1000.0, 1000.0, 1000.0), max_iters=None):
+        confs = np.array(_f32(confs).reshape(-1, 7 + self.n_tors), copy=True)
+        B = len(confs)
+        if max_iters is None:
+            max_iters = (25 + self.n_atoms) // 3
+        vv = _f32(v)
+        e = np.empty(B, dtype=np.float32)
+        g = np.empty((B, 6 + self.n_tors), dtype=np.float32)
+        ev = np.empty(B, dtype=np.int32)
+        check(lib().mi_vina_bfgs_batch(self.handle, _ptr(confs), B, _ptr(vv), int(max_iters), _ptr(e), _ptr(g),
+                                       _ptr(ev)))
+        return e, confs, g, ev
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.mi_vina_destroy(self.handle)
             self.handle = None
 
 

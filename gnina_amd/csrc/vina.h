@@ -1,0 +1,70 @@
+// vina.h -- device-side data model of the smina/Vina scoring + BFGS engine (vina.hip, vina_host.cpp).
+//
+// Reference rows: a11 precalculate_linear (precalculate.h:165-272), a12 cache::populate
+// (cache.cpp:104-184), a13 cache::eval_deriv -> grid::evaluate_aux (cache.cpp:65-83, grid.cpp:96-186),
+// a14 eval_interacting_pairs_deriv (model.cu:38-60), a15 model::set / tree (tree.h), a16 bfgs<>
+// (bfgs.h:357-502).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mig {
+
+constexpr int kVinaTypes = 28;
+
+struct VinaGridGeom {
+  float init[3], factor[3], factor_inv[3], dim_m1[3];
+  int dim[3];
+};
+
+struct VinaEnv {
+  // pair tables
+  const float2 *smooth;  // [npairs][n] (E, dor)
+  const float *fast;     // [npairs][n]
+  int n;
+  float factor, cutoff_sqr;
+  // receptor cache grids
+  VinaGridGeom geom;
+  const float *grid_data;       // all type grids back to back
+  long grid_off[kVinaTypes];    // float offset of type t's grid, -1 if absent
+  float slope;
+};
+
+struct VinaLigand {
+  int n_atoms, n_nodes, n_pairs;
+  const int *smt;            // [n_atoms]
+  const float *local_xyz;    // [n_atoms][3]
+  const int *node_of_atom;   // [n_atoms]
+  const int *parent;         // [n_nodes]
+  const int *abeg, *aend;    // [n_nodes]
+  const float *rel_origin;   // [n_nodes][3]
+  const float *rel_axis;     // [n_nodes][3]
+  const int *child_start;    // [n_nodes+1] CSR of children in increasing index order
+  const int *child_list;
+  const int2 *pairs;         // [n_pairs] (a, b), a < b
+  const int *atom_pair_start;  // [n_atoms+1] CSR: for every atom the pairs touching it, in pair order
+  const int *atom_pair_list;   // entry = pair index * 2 + (1 if the atom is `b`, else 0)
+};
+
+struct VinaPopulateArgs {
+  const float4 *rec;  // (x, y, z, smt as float bits)
+  int n_rec;
+  const float *fast;
+  int n;
+  float factor, cutoff_sqr;
+  VinaGridGeom geom;
+  int lig_type;
+  float *out;  // [(dimz)][(dimy)][(dimx)], x fastest
+};
+
+size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs);
+void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
+// confs [B][7+T]; energy [B]; change [B][6+T] or null; coords [B][n_atoms][3] or null
+void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
+                      float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);
+// in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
+void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+                      int max_iters, float *energy, float *grad, int *evals, hipStream_t s);
+
+}  // namespace mig

@@ -1,0 +1,601 @@
+// vina.hip -- smina/Vina scoring and BFGS local optimisation for gfx950 (MI355X).
+//
+// Replaces, behind the igrid / quasi_newton seam, the CPU loop nest
+//   quasi_newton::operator() (quasi_newton.cpp:49-83) -> bfgs<> (bfgs.h:357-502)
+//     -> model::eval_deriv (model.cu:202-225): set(conf) (tree.h:361-373), cache::eval_deriv
+//        (cache.cpp:65-83 -> grid.cpp:96-186), eval_interacting_pairs_deriv (model.cu:38-60),
+//        ligands.derivative (tree.h:374-382)
+// and cache::populate (cache.cpp:104-184).
+//
+// MI355X design (not the reference's experimental --gpu_docking layout, which runs one BFGS per
+// kernel launch in a single block with dynamic parallelism, bfgs.cu:229-337):
+//  * ONE 64-lane wavefront owns ONE conformation for its whole life -- evaluation, line search and
+//    the quasi-Newton update all stay inside one kernel, state lives in LDS (a few KB), nothing
+//    returns to the host between function evaluations.  A batch of B conformations (MC chains x
+//    ligands) is B independent wavefronts; 256 CUs x 8+ waves/SIMD keep thousands in flight, which
+//    is what hides the L2 gather latency of the grid and table look-ups.
+//  * Lanes map to atoms for the receptor-grid term (8-point trilinear gather per atom), to pairs for
+//    the intramolecular term, to tree nodes for the force/torque sums; pair forces are written to
+//    LDS and gathered per atom in pair order, so there are no atomics and results are
+//    deterministic.  The energy is a fixed-order butterfly reduction across the wave.
+//  * All arithmetic is fp32 in the reference's operation order (compiled with -ffp-contract=off);
+//    only sinf/cosf and the reduction order differ from the CPU oracle.
+#include "vina.h"
+
+namespace mig {
+
+#define VPI 3.14159265358979323846f
+#define VEPS 1.1920928955078125e-07f
+#define VMAXFL 3.402823466e+38f
+
+__device__ __forceinline__ int tri_idx(int t1, int t2) {
+  int a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+  return a + b * (b + 1) / 2;
+}
+
+// curl.h:29-42
+__device__ __forceinline__ void curl3(float &e, float &dx, float &dy, float &dz, float v) {
+  if (e > 0 && v < 0.1f * VMAXFL) {
+    float tmp = (v < VEPS) ? 0.f : (v / (v + e));
+    e *= tmp;
+    float t2 = tmp * tmp;
+    dx *= t2;
+    dy *= t2;
+    dz *= t2;
+  }
+}
+__device__ __forceinline__ void curl1(float &e, float v) {
+  if (e > 0 && v < 0.1f * VMAXFL) {
+    float tmp = (v < VEPS) ? 0.f : (v / (v + e));
+    e *= tmp;
+  }
+}
+
+// grid::evaluate_aux, grid.cpp:96-186
+template <bool DERIV>
+__device__ float grid_evaluate(const VinaGridGeom &g, const float *data, float lx, float ly, float lz, float slope,
+                               float v, float &ox, float &oy, float &oz) {
+  float s[3] = {(lx - g.init[0]) * g.factor[0], (ly - g.init[1]) * g.factor[1], (lz - g.init[2]) * g.factor[2]};
+  float miss[3] = {0.f, 0.f, 0.f};
+  int region[3], a[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (s[i] < 0) {
+      miss[i] = -s[i];
+      region[i] = -1;
+      a[i] = 0;
+      s[i] = 0;
+    } else if (s[i] >= g.dim_m1[i]) {
+      miss[i] = s[i] - g.dim_m1[i];
+      region[i] = 1;
+      a[i] = g.dim[i] - 2;
+      s[i] = 1;
+    } else {
+      region[i] = 0;
+      a[i] = (int)s[i];
+      s[i] -= (float)a[i];
+    }
+  }
+  const float penalty = slope * (miss[0] * g.factor_inv[0] + miss[1] * g.factor_inv[1] + miss[2] * g.factor_inv[2]);
+  const long sx = 1, sy = g.dim[0], sz = (long)g.dim[0] * g.dim[1];
+  const float *p = data + a[0] * sx + a[1] * sy + a[2] * sz;
+  const float f000 = p[0], f100 = p[sx], f010 = p[sy], f110 = p[sx + sy];
+  const float f001 = p[sz], f101 = p[sz + sx], f011 = p[sz + sy], f111 = p[sz + sx + sy];
+  const float x = s[0], y = s[1], z = s[2], mx = 1 - x, my = 1 - y, mz = 1 - z;
+  float f = f000 * mx * my * mz + f100 * x * my * mz + f010 * mx * y * mz + f110 * x * y * mz + f001 * mx * my * z +
+            f101 * x * my * z + f011 * mx * y * z + f111 * x * y * z;
+  if (DERIV) {
+    float gx = f000 * (-1) * my * mz + f100 * 1 * my * mz + f010 * (-1) * y * mz + f110 * 1 * y * mz +
+               f001 * (-1) * my * z + f101 * 1 * my * z + f011 * (-1) * y * z + f111 * 1 * y * z;
+    float gy = f000 * mx * (-1) * mz + f100 * x * (-1) * mz + f010 * mx * 1 * mz + f110 * x * 1 * mz +
+               f001 * mx * (-1) * z + f101 * x * (-1) * z + f011 * mx * 1 * z + f111 * x * 1 * z;
+    float gz = f000 * mx * my * (-1) + f100 * x * my * (-1) + f010 * mx * y * (-1) + f110 * x * y * (-1) +
+               f001 * mx * my * 1 + f101 * x * my * 1 + f011 * mx * y * 1 + f111 * x * y * 1;
+    curl3(f, gx, gy, gz, v);
+    ox = g.factor[0] * (region[0] == 0 ? gx : 0.f) + slope * (float)region[0];
+    oy = g.factor[1] * (region[1] == 0 ? gy : 0.f) + slope * (float)region[1];
+    oz = g.factor[2] * (region[2] == 0 ? gz : 0.f) + slope * (float)region[2];
+    return f + penalty;
+  }
+  curl1(f, v);
+  return f + penalty;
+}
+
+// ---- quaternion helpers (quaternion.h:243-303,327-364) ------------------------------------------
+__device__ __forceinline__ float norm_angle(float x) {  // g_normalize_angle, quaternion.h:259-282
+  while (x > 3 * VPI) {
+    float n = (x - VPI) / (2 * VPI);
+    x -= 2 * VPI * ceilf(n);
+  }
+  while (x < -3 * VPI) {
+    float n = (-x - VPI) / (2 * VPI);
+    x += 2 * VPI * ceilf(n);
+  }
+  if (x > VPI)
+    x -= 2 * VPI;
+  else if (x < -VPI)
+    x += 2 * VPI;
+  return x;
+}
+
+__device__ __forceinline__ void angle_to_quat(float ax, float ay, float az, float angle, float *q) {
+  angle = norm_angle(angle);
+  float c = cosf(angle / 2), s = sinf(angle / 2);
+  q[0] = c;
+  q[1] = s * ax;
+  q[2] = s * ay;
+  q[3] = s * az;
+}
+
+__device__ __forceinline__ void quat_mul(const float *l, const float *r, float *o) {
+  const float a = l[0], b = l[1], c = l[2], d = l[3], ar = r[0], br = r[1], cr = r[2], dr = r[3];
+  o[0] = +a * ar - b * br - c * cr - d * dr;
+  o[1] = +a * br + b * ar + c * dr - d * cr;
+  o[2] = +a * cr - b * dr + c * ar + d * br;
+  o[3] = +a * dr + b * cr - c * br + d * ar;
+}
+
+__device__ __forceinline__ void quat_norm_approx(float *q) {
+  const float s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (fabsf(s - 1) < 1e-6f) return;
+  const float inv = 1 / sqrtf(s);
+  q[0] *= inv;
+  q[1] *= inv;
+  q[2] *= inv;
+  q[3] *= inv;
+}
+
+__device__ __forceinline__ void quat_to_r3(const float *q, float *m) {  // m[i + 3 j] = M(i, j)
+  const float a = q[0], b = q[1], c = q[2], d = q[3];
+  const float aa = a * a, ab = a * b, ac = a * c, ad = a * d, bb = b * b, bc = b * c, bd = b * d, cc = c * c,
+              cd = c * d, dd = d * d;
+  m[0] = (aa + bb - cc - dd);
+  m[3] = 2 * (-ad + bc);
+  m[6] = 2 * (ac + bd);
+  m[1] = 2 * (ad + bc);
+  m[4] = (aa - bb + cc - dd);
+  m[7] = 2 * (-ab + cd);
+  m[2] = 2 * (-ac + bd);
+  m[5] = 2 * (ab + cd);
+  m[8] = (aa - bb - cc + dd);
+}
+
+__device__ __forceinline__ void mat_vec(const float *m, float vx, float vy, float vz, float &ox, float &oy,
+                                        float &oz) {
+  ox = m[0] * vx + m[3] * vy + m[6] * vz;
+  oy = m[1] * vx + m[4] * vy + m[7] * vz;
+  oz = m[2] * vx + m[5] * vy + m[8] * vz;
+}
+
+// ---- per-wave LDS workspace -----------------------------------------------------------------------
+struct WaveWork {
+  float *origin, *axis, *M, *q;  // node frames
+  float *coords, *forces;        // [3 n_atoms]
+  float *node_ft;                // [6 n_nodes]
+  float4 *pair_out;              // [n_pairs]
+};
+
+__device__ __forceinline__ float *carve(float *&p, int n) {
+  float *r = p;
+  p += (n + 3) & ~3;
+  return r;
+}
+
+__device__ WaveWork carve_work(float *&p, const VinaLigand &L) {
+  WaveWork w;
+  w.pair_out = reinterpret_cast<float4 *>(carve(p, 4 * L.n_pairs));
+  w.origin = carve(p, 3 * L.n_nodes);
+  w.axis = carve(p, 3 * L.n_nodes);
+  w.M = carve(p, 9 * L.n_nodes);
+  w.q = carve(p, 4 * L.n_nodes);
+  w.coords = carve(p, 3 * L.n_atoms);
+  w.forces = carve(p, 3 * L.n_atoms);
+  w.node_ft = carve(p, 6 * L.n_nodes);
+  return w;
+}
+
+static size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs) {
+  size_t f = pad4(4 * (size_t)n_pairs) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
+             pad4(4 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms) + pad4(6 * (size_t)n_nodes);
+  const size_t nt = n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  f += pad4(nc);  // conf being evaluated
+  f += pad4(n);   // change
+  if (bfgs) f += 2 * pad4(nc) + 6 * pad4(n) + pad4(n * (n + 1) / 2);
+  return f * sizeof(float);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// model::eval_deriv (DERIV) / model::eval (!DERIV) for the conformation in LDS at `conf`.
+// Returns the energy in every lane; DERIV writes change[6 + T] to LDS.
+template <bool DERIV>
+__device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float *conf, float v0, float v1, float v2,
+                           const WaveWork &w, float *change) {
+  const int lane = threadIdx.x;
+  // 1. node frames, sequential down the tree (tree.h:152-156, 218-233)
+  if (lane == 0) {
+    for (int k = 0; k < L.n_nodes; k++) {
+      float *q = w.q + 4 * k, *M = w.M + 9 * k;
+      if (k == 0) {
+        w.origin[0] = conf[0];
+        w.origin[1] = conf[1];
+        w.origin[2] = conf[2];
+        q[0] = conf[3];
+        q[1] = conf[4];
+        q[2] = conf[5];
+        q[3] = conf[6];
+        w.axis[0] = w.axis[1] = w.axis[2] = 0.f;
+      } else {
+        const int p = L.parent[k];
+        const float *Mp = w.M + 9 * p;
+        float tx, ty, tz;
+        mat_vec(Mp, L.rel_origin[3 * k], L.rel_origin[3 * k + 1], L.rel_origin[3 * k + 2], tx, ty, tz);
+        w.origin[3 * k] = w.origin[3 * p] + tx;
+        w.origin[3 * k + 1] = w.origin[3 * p + 1] + ty;
+        w.origin[3 * k + 2] = w.origin[3 * p + 2] + tz;
+        float ax, ay, az;
+        mat_vec(Mp, L.rel_axis[3 * k], L.rel_axis[3 * k + 1], L.rel_axis[3 * k + 2], ax, ay, az);
+        w.axis[3 * k] = ax;
+        w.axis[3 * k + 1] = ay;
+        w.axis[3 * k + 2] = az;
+        float rq[4];
+        angle_to_quat(ax, ay, az, conf[7 + (k - 1)], rq);
+        quat_mul(rq, w.q + 4 * p, q);
+        quat_norm_approx(q);
+      }
+      quat_to_r3(q, M);
+    }
+  }
+  __syncthreads();
+  // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor grid term
+  float e_part = 0.f;
+  for (int i = lane; i < L.n_atoms; i += 64) {
+    const int k = L.node_of_atom[i];
+    float tx, ty, tz;
+    mat_vec(w.M + 9 * k, L.local_xyz[3 * i], L.local_xyz[3 * i + 1], L.local_xyz[3 * i + 2], tx, ty, tz);
+    const float cx = w.origin[3 * k] + tx, cy = w.origin[3 * k + 1] + ty, cz = w.origin[3 * k + 2] + tz;
+    w.coords[3 * i] = cx;
+    w.coords[3 * i + 1] = cy;
+    w.coords[3 * i + 2] = cz;
+    const int t = L.smt[i];
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+      e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
+    }
+    if (DERIV) {
+      w.forces[3 * i] = fx;
+      w.forces[3 * i + 1] = fy;
+      w.forces[3 * i + 2] = fz;
+    }
+  }
+  __syncthreads();
+  // 4. intramolecular pairs (model.cu:38-60 / :22-36)
+  for (int p = lane; p < L.n_pairs; p += 64) {
+    const int2 ab = L.pairs[p];
+    const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
+                rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
+    const float r2 = rx * rx + ry * ry + rz * rz;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r2 < env.cutoff_sqr) {
+      const long base = (long)tri_idx(L.smt[ab.x], L.smt[ab.y]) * env.n;
+      if (DERIV) {
+        const float r2f = env.factor * r2;
+        const int i1 = (int)r2f;
+        const float rem = r2f - (float)i1;
+        const float2 s1 = env.smooth[base + i1], s2 = env.smooth[base + i1 + 1];
+        float pe = s1.x + rem * (s2.x - s1.x);
+        const float dor = s1.y + rem * (s2.y - s1.y);
+        float fx = dor * rx, fy = dor * ry, fz = dor * rz;
+        curl3(pe, fx, fy, fz, v0);
+        out = make_float4(fx, fy, fz, pe);
+        e_part += pe;
+      } else {
+        float pe = env.fast[base + (int)(env.factor * r2)];
+        curl1(pe, v0);
+        e_part += pe;
+      }
+    }
+    if (DERIV) w.pair_out[p] = out;
+  }
+  if (DERIV) {
+    __syncthreads();
+    // 5. gather pair forces per atom, in pair order (forces[a] -= f; forces[b] += f)
+    for (int i = lane; i < L.n_atoms; i += 64) {
+      float fx = w.forces[3 * i], fy = w.forces[3 * i + 1], fz = w.forces[3 * i + 2];
+      for (int e = L.atom_pair_start[i]; e < L.atom_pair_start[i + 1]; e++) {
+        const int code = L.atom_pair_list[e];
+        const float4 pf = w.pair_out[code >> 1];
+        if (code & 1) {
+          fx += pf.x;
+          fy += pf.y;
+          fz += pf.z;
+        } else {
+          fx -= pf.x;
+          fy -= pf.y;
+          fz -= pf.z;
+        }
+      }
+      w.forces[3 * i] = fx;
+      w.forces[3 * i + 1] = fy;
+      w.forces[3 * i + 2] = fz;
+    }
+    __syncthreads();
+    // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140)
+    for (int k = lane; k < L.n_nodes; k += 64) {
+      float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      const float ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
+      for (int i = L.abeg[k]; i < L.aend[k]; i++) {
+        const float rx = w.coords[3 * i] - ox, ry = w.coords[3 * i + 1] - oy, rz = w.coords[3 * i + 2] - oz;
+        const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
+        f0 += gx;
+        f1 += gy;
+        f2 += gz;
+        t0 += ry * gz - rz * gy;
+        t1 += rz * gx - rx * gz;
+        t2 += rx * gy - ry * gx;
+      }
+      float *ft = w.node_ft + 6 * k;
+      ft[0] = f0, ft[1] = f1, ft[2] = f2, ft[3] = t0, ft[4] = t1, ft[5] = t2;
+    }
+    __syncthreads();
+    // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311)
+    if (lane == 0) {
+      for (int k = L.n_nodes - 1; k >= 0; k--) {
+        float *ft = w.node_ft + 6 * k;
+        for (int e = L.child_start[k]; e < L.child_start[k + 1]; e++) {
+          const int c = L.child_list[e];
+          const float *cf = w.node_ft + 6 * c;
+          ft[0] += cf[0];
+          ft[1] += cf[1];
+          ft[2] += cf[2];
+          const float rx = w.origin[3 * c] - w.origin[3 * k], ry = w.origin[3 * c + 1] - w.origin[3 * k + 1],
+                      rz = w.origin[3 * c + 2] - w.origin[3 * k + 2];
+          ft[3] += (ry * cf[2] - rz * cf[1]) + cf[3];
+          ft[4] += (rz * cf[0] - rx * cf[2]) + cf[4];
+          ft[5] += (rx * cf[1] - ry * cf[0]) + cf[5];
+        }
+        if (k == 0) {
+          for (int j = 0; j < 6; j++) change[j] = ft[j];
+        } else {
+          change[6 + (k - 1)] = ft[3] * w.axis[3 * k] + ft[4] * w.axis[3 * k + 1] + ft[5] * w.axis[3 * k + 2];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return wave_sum(e_part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch evaluation kernel
+// ---------------------------------------------------------------------------------------------
+template <bool DERIV>
+__global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L, const float *confs, float v0,
+                                                       float v1, float v2, float *energy, float *change_out,
+                                                       float *coords_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *p = lds;
+  WaveWork w = carve_work(p, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  float *conf = carve(p, nc);
+  float *change = carve(p, n);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  const float e = eval_conf<DERIV>(env, L, conf, v0, v1, v2, w, change);
+  if (lane == 0) energy[b] = e;
+  if (DERIV && change_out)
+    for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
+  if (coords_out)
+    for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// BFGS kernel: quasi_newton / bfgs<> with fast_line_search (bfgs.h:73-91,357-502)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
+
+__device__ __forceinline__ float dot_seq(const float *a, const float *b, int n) {  // scalar_product, bfgs.h:45-50
+  float t = 0.f;
+  for (int i = 0; i < n; i++) t += a[i] * b[i];
+  return t;
+}
+
+// conf::increment (conf.h:54-59,113-118; quaternion.cu:32-62,96-100), executed by one lane
+__device__ void conf_increment(float *x, const float *p, float alpha, int nt) {
+  x[0] += alpha * p[0];
+  x[1] += alpha * p[1];
+  x[2] += alpha * p[2];
+  const float rx = alpha * p[3], ry = alpha * p[4], rz = alpha * p[5];
+  const float angle = sqrtf(rx * rx + ry * ry + rz * rz);
+  float rq[4] = {1.f, 0.f, 0.f, 0.f};
+  if (angle > VEPS) {
+    const float inv = 1 / angle;
+    angle_to_quat(inv * rx, inv * ry, inv * rz, angle, rq);
+  }
+  float nq[4];
+  quat_mul(rq, x + 3, nq);
+  quat_norm_approx(nq);
+  x[3] = nq[0], x[4] = nq[1], x[5] = nq[2], x[6] = nq[3];
+  for (int i = 0; i < nt; i++) {
+    float t = x[7 + i] + norm_angle(alpha * p[6 + i]);
+    x[7 + i] = norm_angle(t);
+  }
+}
+
+__global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
+                                                       float v2, int max_iters, float *energy, float *grad_out,
+                                                       int *evals_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *pp = lds;
+  WaveWork w = carve_work(pp, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  float *x_new = carve(pp, nc);   // the conformation handed to eval_conf
+  float *g_new = carve(pp, n);    // ... and the change it fills
+  float *x = carve(pp, nc), *x_orig = carve(pp, nc);
+  float *g = carve(pp, n), *g_orig = carve(pp, n), *p = carve(pp, n), *y = carve(pp, n), *mhy = carve(pp, n);
+  float *tmpn = carve(pp, n);
+  float *h = carve(pp, n * (n + 1) / 2);
+  (void)tmpn;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int evals = 0;
+
+  for (int i = lane; i < nc; i += 64) {
+    const float val = confs[(size_t)b * nc + i];
+    x[i] = val;
+    x_orig[i] = val;
+    x_new[i] = val;
+  }
+  for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) h[hidx(i, i)] = 1.f;
+  float f0 = eval_conf<true>(env, L, x_new, v0, v1, v2, w, g_new);
+  evals++;
+  for (int i = lane; i < n; i += 64) {
+    g[i] = g_new[i];
+    g_orig[i] = g_new[i];
+  }
+  const float f_orig = f0;
+  __syncthreads();
+
+  for (int step = 0; step < max_iters; step++) {
+    // p = -H g  (minus_mat_vec_product, bfgs.h:34-43): one row per lane, j ascending
+    for (int i = lane; i < n; i += 64) {
+      float sum = 0.f;
+      for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
+      p[i] = -sum;
+    }
+    __syncthreads();
+    // fast_line_search (bfgs.h:73-91)
+    float f1 = 0.f, alpha = 1.f;
+    const float pg = dot_seq(p, g, n);
+    for (unsigned trial = 0; trial < 10; trial++) {
+      if (lane == 0) {
+        for (int i = 0; i < nc; i++) x_new[i] = x[i];
+        conf_increment(x_new, p, alpha, nt);
+      }
+      __syncthreads();
+      f1 = eval_conf<true>(env, L, x_new, v0, v1, v2, w, g_new);
+      evals++;
+      if (f1 - f0 < 0.0001f * alpha * pg) break;
+      alpha *= 0.5f;
+    }
+    if (alpha == 0.f) break;
+    for (int i = lane; i < n; i += 64) y[i] = g_new[i] - g[i];
+    f0 = f1;
+    __syncthreads();
+    for (int i = lane; i < nc; i += 64) x[i] = x_new[i];
+    for (int i = lane; i < n; i += 64) g[i] = g_new[i];
+    __syncthreads();
+    const float gradnormsq = dot_seq(g, g, n);
+    if (!(gradnormsq >= 1e-4f)) break;
+    if (step == 0) {
+      const float yy = dot_seq(y, y, n);
+      if (fabsf(yy) > VEPS) {
+        const float dgl = alpha * dot_seq(y, p, n) / yy;
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) h[hidx(i, i)] = dgl;
+        __syncthreads();
+      }
+    }
+    // bfgs_update (bfgs.h:52-66)
+    const float yp = dot_seq(y, p, n);
+    if (!(alpha * yp < VEPS)) {
+      for (int i = lane; i < n; i += 64) {
+        float sum = 0.f;
+        for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * y[j];
+        mhy[i] = -sum;
+      }
+      __syncthreads();
+      const float yhy = -dot_seq(y, mhy, n);
+      const float r = 1 / (alpha * yp);
+      for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        if (j >= i)
+          h[hidx(i, j)] +=
+              alpha * r * (mhy[i] * p[j] + mhy[j] * p[i]) + alpha * alpha * (r * r * yhy + r) * p[i] * p[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (!(f0 <= f_orig)) {  // bfgs.h:491-495
+    f0 = f_orig;
+    __syncthreads();
+    for (int i = lane; i < nc; i += 64) x[i] = x_orig[i];
+    for (int i = lane; i < n; i += 64) g[i] = g_orig[i];
+  }
+  __syncthreads();
+  for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = x[i];
+  if (grad_out)
+    for (int i = lane; i < n; i += 64) grad_out[(size_t)b * n + i] = g[i];
+  if (lane == 0) {
+    energy[b] = f0;
+    if (evals_out) evals_out[b] = evals;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cache::populate (cache.cpp:104-184): one thread per grid point, receptor atoms staged through
+// LDS in tiles; per point the sum runs over receptor atoms in index order like the reference's
+// index-ordered `possibilities` list, so the fp32 result is the same sum.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) {
+  __shared__ float4 tile[256];
+  const long npts = (long)a.geom.dim[0] * a.geom.dim[1] * a.geom.dim[2];
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < npts;
+  const long ii = live ? idx : 0;
+  const int x = (int)(ii % a.geom.dim[0]), y = (int)((ii / a.geom.dim[0]) % a.geom.dim[1]),
+            z = (int)(ii / ((long)a.geom.dim[0] * a.geom.dim[1]));
+  const float px = a.geom.init[0] + a.geom.factor_inv[0] * (float)x;  // index_to_argument, grid.h:54-57
+  const float py = a.geom.init[1] + a.geom.factor_inv[1] * (float)y;
+  const float pz = a.geom.init[2] + a.geom.factor_inv[2] * (float)z;
+  float aff = 0.f;
+  for (int base = 0; base < a.n_rec; base += 256) {
+    __syncthreads();
+    if (base + (int)threadIdx.x < a.n_rec) tile[threadIdx.x] = a.rec[base + threadIdx.x];
+    __syncthreads();
+    const int cnt = min(256, a.n_rec - base);
+    for (int j = 0; j < cnt; j++) {
+      const float4 r = tile[j];
+      const float dx = r.x - px, dy = r.y - py, dz = r.z - pz;
+      const float r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 <= a.cutoff_sqr) {
+        const int t1 = __float_as_int(r.w);
+        aff += a.fast[(long)tri_idx(t1, a.lig_type) * a.n + (int)(a.factor * r2)];
+      }
+    }
+  }
+  if (live) a.out[idx] = aff;
+}
+
+void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s) {
+  const long npts = (long)a.geom.dim[0] * a.geom.dim[1] * a.geom.dim[2];
+  hipLaunchKernelGGL(vina_populate_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
+                      float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s) {
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false);
+  if (with_deriv)
+    hipLaunchKernelGGL(vina_eval_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
+                       coords);
+  else
+    hipLaunchKernelGGL(vina_eval_kernel<false>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy,
+                       change, coords);
+}
+
+void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+                      int max_iters, float *energy, float *grad, int *evals, hipStream_t s) {
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true);
+  hipLaunchKernelGGL(vina_bfgs_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy, grad,
+                     evals);
+}
+
+}  // namespace mig

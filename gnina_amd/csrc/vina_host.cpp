@@ -1,0 +1,411 @@
+// vina_host.cpp -- host side of the Vina engine: pair tables (precalculate_linear), receptor /
+// cache / ligand upload, and the mi_vina_* C ABI (include/mi_gnina.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/mi_gnina.h"
+#include "common.h"
+#include "typer.h"
+#include "vina.h"
+
+namespace mig {
+
+// atom_constants.h:101-133 (xs_hydrophobe / xs_donor / xs_acceptor columns)
+static const unsigned char kHyd[kVinaTypes] = {0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                               0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1};
+static const unsigned char kDon[kVinaTypes] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1, 0,
+                                               0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0};
+static const unsigned char kAcc[kVinaTypes] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1,
+                                               0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// main.cpp:1324-1328
+static const float kDefaultWeights[5] = {-0.035579f, -0.005156f, 0.840245f, -0.035069f, -0.587439f};
+
+static float slope_step(float x_bad, float x_good, float x) {  // everything.h:207-216
+  if (x_bad < x_good) {
+    if (x <= x_bad) return 0;
+    if (x >= x_good) return 1;
+  } else {
+    if (x >= x_bad) return 0;
+    if (x <= x_good) return 1;
+  }
+  return (x - x_bad) / (x_good - x_bad);
+}
+
+static float gaussian(float x, float width) {  // everything.h:48-50
+  volatile float q = x / width;
+  return expf(-(q * q));
+}
+
+// weighted_terms::eval_fast (weighted_terms.cpp:54-68) for the default Vina term set
+static float pair_energy(const float *w, int t1, int t2, float r) {
+  volatile float opt = smina_xs_radius(t1) + smina_xs_radius(t2);
+  volatile float acc = 0;
+  acc = acc + w[0] * gaussian(r - (opt + 0.0f), 0.5f);
+  acc = acc + w[1] * gaussian(r - (opt + 3.0f), 2.0f);
+  {
+    volatile float d = r - (opt + 0.0f);
+    acc = acc + w[2] * (d > 0 ? 0.0f : d * d);
+  }
+  acc = acc + w[3] * ((kHyd[t1] && kHyd[t2]) ? slope_step(1.5f, 0.5f, r - opt) : 0.0f);
+  const bool hb = (kDon[t1] && kAcc[t2]) || (kDon[t2] && kAcc[t1]);
+  acc = acc + w[4] * (hb ? slope_step(0.0f, -0.7f, r - opt) : 0.0f);
+  return acc;
+}
+
+struct Vina {
+  hipStream_t stream = nullptr;
+  // tables (host copies kept for mi_vina_table)
+  int n = 0;
+  float factor = 32.f, cutoff_sqr = 64.f;
+  std::vector<float> h_fast, h_se, h_sd;
+  DevBuf<float2> d_smooth;
+  DevBuf<float> d_fast;
+  // receptor
+  DevBuf<float4> d_rec;
+  int n_rec = 0;
+  // cache
+  bool have_cache = false;
+  VinaGridGeom geom{};
+  long grid_off[kVinaTypes];
+  size_t grid_pts = 0;
+  DevBuf<float> d_grids;
+  float slope = 1e3f;
+  // ligand
+  bool have_lig = false;
+  VinaLigand lig{};
+  DevBuf<int> d_int;
+  DevBuf<float> d_flt;
+  // scratch
+  DevBuf<float> d_confs, d_energy, d_change, d_coords;
+  DevBuf<int> d_evals;
+  ~Vina() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static int tri(int t1, int t2) {
+  if (t1 > t2) std::swap(t1, t2);
+  return t1 + t2 * (t2 + 1) / 2;
+}
+
+// precalculate_linear ctor (precalculate.h:184-210) + init_from_smooth_fst (:135-158)
+static void build_tables(Vina &v, const float *w, float cutoff, float factor) {
+  v.factor = factor;
+  v.cutoff_sqr = cutoff * cutoff;
+  v.n = (int)(factor * v.cutoff_sqr) + 3;
+  const int n = v.n, np = kVinaTypes * (kVinaTypes + 1) / 2;
+  std::vector<float> rs(n + 2);
+  for (int i = 0; i < n + 2; i++) rs[i] = sqrtf((float)i / factor);
+  v.h_fast.assign((size_t)np * n, 0.f);
+  v.h_se.assign((size_t)np * n, 0.f);
+  v.h_sd.assign((size_t)np * n, 0.f);
+  for (int t1 = 0; t1 < kVinaTypes; t1++)
+    for (int t2 = t1; t2 < kVinaTypes; t2++) {
+      float *se = &v.h_se[(size_t)tri(t1, t2) * n], *sd = &v.h_sd[(size_t)tri(t1, t2) * n];
+      float *fa = &v.h_fast[(size_t)tri(t1, t2) * n];
+      for (int i = 0; i < n; i++) se[i] = pair_energy(w, t1, t2, rs[i]);
+      for (int i = 0; i < n; i++) {
+        if (i == 0 || i == n - 1) {
+          sd[i] = 0;
+        } else {
+          volatile float delta = rs[i + 1] - rs[i - 1];
+          volatile float dr = delta * rs[i];
+          sd[i] = (se[i + 1] - se[i - 1]) / dr;
+        }
+        const float f2 = (i + 1 >= n) ? 0.f : se[i + 1];
+        volatile float s2 = f2 + se[i];
+        fa[i] = s2 / 2;
+      }
+    }
+  std::vector<float2> sm((size_t)np * n);
+  for (size_t i = 0; i < sm.size(); i++) sm[i] = make_float2(v.h_se[i], v.h_sd[i]);
+  v.d_smooth.upload(sm.data(), sm.size(), v.stream);
+  v.d_fast.upload(v.h_fast.data(), v.h_fast.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+}
+
+static VinaEnv make_env(const Vina &v) {
+  VinaEnv e{};
+  e.smooth = v.d_smooth.p;
+  e.fast = v.d_fast.p;
+  e.n = v.n;
+  e.factor = v.factor;
+  e.cutoff_sqr = v.cutoff_sqr;
+  e.geom = v.geom;
+  e.grid_data = v.d_grids.p;
+  for (int t = 0; t < kVinaTypes; t++) e.grid_off[t] = v.grid_off[t];
+  e.slope = v.slope;
+  return e;
+}
+
+}  // namespace mig
+
+using namespace mig;
+
+#define VTRY try {
+#define VCATCH_STATUS                        \
+  }                                          \
+  catch (const mig::Error &e) {              \
+    mig::set_last_error(e.what());           \
+    return e.code;                           \
+  }                                          \
+  catch (const std::exception &e) {          \
+    mig::set_last_error(e.what());           \
+    return MI_ERR_INVALID;                   \
+  }
+
+extern "C" {
+
+mi_vina *mi_vina_create(const float *weights5, float cutoff, float factor) {
+  try {
+    MIG_CHECK(cutoff > 0 && factor > 0 && factor * cutoff * cutoff < 1e6f, 1, "bad cutoff / factor");
+    std::unique_ptr<Vina> v(new Vina());
+    MIG_HIP(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    for (auto &o : v->grid_off) o = -1;
+    build_tables(*v, weights5 ? weights5 : kDefaultWeights, cutoff, factor);
+    return reinterpret_cast<mi_vina *>(v.release());
+  } catch (const std::exception &e) {
+    mig::set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+void mi_vina_destroy(mi_vina *v) { delete reinterpret_cast<Vina *>(v); }
+
+int mi_vina_table_size(const mi_vina *v) { return v ? reinterpret_cast<const Vina *>(v)->n : 0; }
+
+mi_status mi_vina_table(const mi_vina *vv, int t1, int t2, float *fast, float *smooth_e, float *smooth_dor) {
+  VTRY
+  MIG_CHECK(vv && t1 >= 0 && t1 < kVinaTypes && t2 >= 0 && t2 < kVinaTypes, 1, "bad arguments");
+  const Vina &v = *reinterpret_cast<const Vina *>(vv);
+  const size_t o = (size_t)tri(t1, t2) * v.n;
+  if (fast) std::memcpy(fast, &v.h_fast[o], sizeof(float) * v.n);
+  if (smooth_e) std::memcpy(smooth_e, &v.h_se[o], sizeof(float) * v.n);
+  if (smooth_dor) std::memcpy(smooth_dor, &v.h_sd[o], sizeof(float) * v.n);
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_set_receptor(mi_vina *vv, const float *xyz, const int32_t *smt, int n) {
+  VTRY
+  MIG_CHECK(vv && n >= 0 && (n == 0 || (xyz && smt)), 1, "bad receptor arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  std::vector<float4> rec(n);
+  for (int i = 0; i < n; i++) {
+    MIG_CHECK(smt[i] >= 0 && smt[i] < kVinaTypes, 1, "receptor smina type out of range");
+    float w;
+    int32_t t = smt[i];
+    std::memcpy(&w, &t, 4);
+    rec[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], w);
+  }
+  v.d_rec.upload(rec.data(), rec.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  v.n_rec = n;
+  v.have_cache = false;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end3, const int32_t *n3,
+                              const int32_t *lig_types, int n_types, float slope) {
+  VTRY
+  MIG_CHECK(vv && begin3 && end3 && n3 && lig_types && n_types > 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.n_rec > 0, 4, "mi_vina_set_receptor must be called first");
+  for (int i = 0; i < 3; i++) {  // grid::init, grid.cpp:47-68
+    MIG_CHECK(n3[i] > 0 && end3[i] > begin3[i], 1, "bad grid dims");
+    v.geom.dim[i] = n3[i] + 1;
+    v.geom.init[i] = begin3[i];
+    const float range = end3[i] - begin3[i];
+    v.geom.dim_m1[i] = (float)v.geom.dim[i] - 1.0f;
+    v.geom.factor[i] = v.geom.dim_m1[i] / range;
+    v.geom.factor_inv[i] = 1 / v.geom.factor[i];
+  }
+  v.grid_pts = (size_t)v.geom.dim[0] * v.geom.dim[1] * v.geom.dim[2];
+  for (auto &o : v.grid_off) o = -1;
+  int cnt = 0;
+  for (int j = 0; j < n_types; j++) {
+    const int t = lig_types[j];
+    MIG_CHECK(t >= 0 && t < kVinaTypes, 1, "ligand smina type out of range");
+    if (v.grid_off[t] < 0) v.grid_off[t] = (long)(cnt++) * (long)v.grid_pts;
+  }
+  v.d_grids.ensure((size_t)cnt * v.grid_pts);
+  v.slope = slope;
+  for (int t = 0; t < kVinaTypes; t++) {
+    if (v.grid_off[t] < 0) continue;
+    VinaPopulateArgs a{};
+    a.rec = v.d_rec.p;
+    a.n_rec = v.n_rec;
+    a.fast = v.d_fast.p;
+    a.n = v.n;
+    a.factor = v.factor;
+    a.cutoff_sqr = v.cutoff_sqr;
+    a.geom = v.geom;
+    a.lig_type = t;
+    a.out = v.d_grids.p + v.grid_off[t];
+    launch_vina_populate(a, v.stream);
+  }
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  v.have_cache = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_cache_grid(mi_vina *vv, int smt, float *out, size_t n_floats) {
+  VTRY
+  MIG_CHECK(vv && out, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && smt >= 0 && smt < kVinaTypes && v.grid_off[smt] >= 0, 4, "no grid for this type");
+  MIG_CHECK(n_floats == v.grid_pts, 1, "grid size mismatch");
+  MIG_HIP(hipMemcpy(out, v.d_grids.p + v.grid_off[smt], n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
+  VTRY
+  MIG_CHECK(vv && d && d->n_atoms > 0 && d->n_nodes > 0 && d->n_pairs >= 0, 1, "bad ligand description");
+  MIG_CHECK(d->smt && d->local_xyz && d->node_parent && d->node_atom_begin && d->node_atom_end &&
+                d->node_rel_origin && d->node_rel_axis && (d->n_pairs == 0 || d->pairs),
+            1, "NULL array in ligand description");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
+  MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
+  std::vector<int> node_of(na, -1);
+  for (int k = 0; k < nn; k++) {
+    MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : d->node_parent[k] >= 0), 1,
+              "nodes must be in DFS pre-order (parent index < node index, root first)");
+    MIG_CHECK(d->node_atom_begin[k] >= 0 && d->node_atom_begin[k] <= d->node_atom_end[k] && d->node_atom_end[k] <= na,
+              1, "bad node atom range");
+    for (int i = d->node_atom_begin[k]; i < d->node_atom_end[k]; i++) node_of[i] = k;
+  }
+  for (int i = 0; i < na; i++) {
+    MIG_CHECK(node_of[i] >= 0, 1, "atom not covered by any node");
+    MIG_CHECK(d->smt[i] >= 0 && d->smt[i] < kVinaTypes, 1, "ligand smina type out of range");
+  }
+  // CSR of children (increasing index) and of pairs per atom (pair order)
+  std::vector<int> child_start(nn + 1, 0), child_list;
+  for (int k = 0; k < nn; k++) {
+    child_start[k] = (int)child_list.size();
+    for (int c = k + 1; c < nn; c++)
+      if (d->node_parent[c] == k) child_list.push_back(c);
+  }
+  child_start[nn] = (int)child_list.size();
+  std::vector<std::vector<int>> per_atom(na);
+  for (int p = 0; p < np; p++) {
+    const int a = d->pairs[2 * p], b = d->pairs[2 * p + 1];
+    MIG_CHECK(a >= 0 && a < na && b >= 0 && b < na && a != b, 1, "bad pair");
+    per_atom[a].push_back(2 * p);
+    per_atom[b].push_back(2 * p + 1);
+  }
+  std::vector<int> aps(na + 1, 0), apl;
+  for (int i = 0; i < na; i++) {
+    aps[i] = (int)apl.size();
+    apl.insert(apl.end(), per_atom[i].begin(), per_atom[i].end());
+  }
+  aps[na] = (int)apl.size();
+  // pack ints: smt, node_of, parent, abeg, aend, child_start, child_list, pairs, aps, apl
+  std::vector<int> ints;
+  auto pushi = [&](const int *p, size_t n) {
+    size_t off = ints.size();
+    ints.insert(ints.end(), p, p + n);
+    while (ints.size() % 4) ints.push_back(0);
+    return off;
+  };
+  const size_t o_smt = pushi(d->smt, na), o_node = pushi(node_of.data(), na), o_par = pushi(d->node_parent, nn),
+               o_abeg = pushi(d->node_atom_begin, nn), o_aend = pushi(d->node_atom_end, nn),
+               o_cs = pushi(child_start.data(), nn + 1),
+               o_cl = pushi(child_list.empty() ? aps.data() : child_list.data(), child_list.size()),
+               o_pairs = pushi(np ? d->pairs : aps.data(), 2 * (size_t)np), o_aps = pushi(aps.data(), na + 1),
+               o_apl = pushi(apl.empty() ? aps.data() : apl.data(), apl.size());
+  std::vector<float> flts;
+  auto pushf = [&](const float *p, size_t n) {
+    size_t off = flts.size();
+    flts.insert(flts.end(), p, p + n);
+    while (flts.size() % 4) flts.push_back(0.f);
+    return off;
+  };
+  const size_t o_loc = pushf(d->local_xyz, 3 * (size_t)na), o_ro = pushf(d->node_rel_origin, 3 * (size_t)nn),
+               o_ra = pushf(d->node_rel_axis, 3 * (size_t)nn);
+  v.d_int.upload(ints.data(), ints.size(), v.stream);
+  v.d_flt.upload(flts.data(), flts.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  VinaLigand &L = v.lig;
+  L.n_atoms = na;
+  L.n_nodes = nn;
+  L.n_pairs = np;
+  L.smt = v.d_int.p + o_smt;
+  L.node_of_atom = v.d_int.p + o_node;
+  L.parent = v.d_int.p + o_par;
+  L.abeg = v.d_int.p + o_abeg;
+  L.aend = v.d_int.p + o_aend;
+  L.child_start = v.d_int.p + o_cs;
+  L.child_list = v.d_int.p + o_cl;
+  L.pairs = reinterpret_cast<const int2 *>(v.d_int.p + o_pairs);
+  L.atom_pair_start = v.d_int.p + o_aps;
+  L.atom_pair_list = v.d_int.p + o_apl;
+  L.local_xyz = v.d_flt.p + o_loc;
+  L.rel_origin = v.d_flt.p + o_ro;
+  L.rel_axis = v.d_flt.p + o_ra;
+  v.have_lig = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_eval_batch(mi_vina *vv, const float *confs, int B, const float *v3, int with_deriv, float *energy,
+                             float *change, float *coords) {
+  VTRY
+  MIG_CHECK(vv && confs && v3 && energy && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  v.d_confs.upload(confs, (size_t)B * nc, v.stream);
+  v.d_energy.ensure(B);
+  if (change) v.d_change.ensure((size_t)B * n);
+  if (coords) v.d_coords.ensure((size_t)B * 3 * v.lig.n_atoms);
+  launch_vina_eval(make_env(v), v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
+                   change ? v.d_change.p : nullptr, coords ? v.d_coords.p : nullptr, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (change && with_deriv)
+    MIG_HIP(hipMemcpyAsync(change, v.d_change.p, (size_t)B * n * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (coords)
+    MIG_HIP(hipMemcpyAsync(coords, v.d_coords.p, (size_t)B * 3 * v.lig.n_atoms * sizeof(float), hipMemcpyDeviceToHost,
+                           v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_bfgs_batch(mi_vina *vv, float *confs, int B, const float *v3, int max_iters, float *energy,
+                             float *grad, int32_t *evals) {
+  VTRY
+  MIG_CHECK(vv && confs && v3 && energy && B >= 0 && max_iters >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  v.d_confs.upload(confs, (size_t)B * nc, v.stream);
+  v.d_energy.ensure(B);
+  v.d_change.ensure((size_t)B * n);
+  v.d_evals.ensure(B);
+  launch_vina_bfgs(make_env(v), v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], max_iters, v.d_energy.p, v.d_change.p,
+                   v.d_evals.p, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(confs, v.d_confs.p, (size_t)B * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (grad) MIG_HIP(hipMemcpyAsync(grad, v.d_change.p, (size_t)B * n * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+void *mi_vina_stream(mi_vina *vv) { return vv ? (void *)reinterpret_cast<Vina *>(vv)->stream : nullptr; }
+
+}  // extern "C"

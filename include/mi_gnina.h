@@ -127,6 +127,59 @@ mi_status mi_scorer_set_chunk(mi_scorer *, int poses_per_chunk);
 mi_status mi_scorer_enable_timing(mi_scorer *, int on);
 mi_status mi_scorer_last_timing(mi_scorer *, float *ms3);
 
+/* ---- Vina / smina scoring + local optimisation (igrid / quasi_newton seam) -------------------------
+ * mi_vina owns: the pair tables of precalculate_linear(sf, factor) (gninasrc/lib/precalculate.h:165-272;
+ * selection main.cpp:1384-1391) for the default scoring function (main.cpp:1324-1329) or custom
+ * weights {gauss1, gauss2, repulsion, hydrophobic, h-bond}; the receptor atoms; the per-ligand-type
+ * affinity grids of `cache` (cache.cpp:104-184); and one prepared ligand (torsion tree + pairs). */
+mi_vina *mi_vina_create(const float *weights5 /* NULL = default Vina */, float cutoff /* 8 */, float factor /* 32 */);
+void mi_vina_destroy(mi_vina *);
+/* table points per type pair: sz(factor * cutoff^2) + 3 (precalculate.h:189) */
+int mi_vina_table_size(const mi_vina *);
+/* precalculate_linear_element data of one type pair: fast[n], smooth.first[n], smooth.second[n] */
+mi_status mi_vina_table(const mi_vina *, int t1, int t2, float *fast, float *smooth_e, float *smooth_dor);
+/* model.grid_atoms: the rigid receptor, all atoms with smina types (hydrogens included) */
+mi_status mi_vina_set_receptor(mi_vina *, const float *xyz, const int32_t *smt, int n_atoms);
+/* cache::populate(m, prec, atom_types_needed, ...) on the grid_dims {begin, end, n} of
+ * setup_grid_dims (main.cpp:625-634); slope = out-of-box penalty slope (main.cpp:466). */
+mi_status mi_vina_build_cache(mi_vina *, const float *begin3, const float *end3, const int32_t *n3,
+                              const int32_t *lig_types, int n_types, float slope);
+/* copy one type's grid back: float[(n3[2]+1)][(n3[1]+1)][(n3[0]+1)], x fastest (array3d.h:91-96) */
+mi_status mi_vina_cache_grid(mi_vina *, int smt, float *out, size_t n_floats);
+
+/* model.ligands[0] as the PDBQT parser lays it out (parse_pdbqt.cpp:343-380; tree.h:152-233):
+ * nodes in DFS pre-order, node 0 = rigid root, node k>0 = segment owning torsion k-1; atoms stored
+ * node by node with coordinates local to their node; interacting pairs per model::initialize_pairs
+ * (model.cpp:682-703).  conf = [position 3][orientation quaternion a,b,c,d][torsions n_nodes-1];
+ * change = [force 3][torque 3][torsion derivatives] (conf.h:244-359,361-518). */
+typedef struct mi_ligand_desc {
+  int32_t n_atoms;
+  const int32_t *smt;             /* [n_atoms] */
+  const float *local_xyz;         /* [n_atoms][3] */
+  int32_t n_nodes;
+  const int32_t *node_parent;     /* [n_nodes], -1 for the root */
+  const int32_t *node_atom_begin; /* [n_nodes] */
+  const int32_t *node_atom_end;   /* [n_nodes] */
+  const float *node_rel_origin;   /* [n_nodes][3] segment::relative_origin (root: unused) */
+  const float *node_rel_axis;     /* [n_nodes][3] segment::relative_axis */
+  int32_t n_pairs;
+  const int32_t *pairs;           /* [n_pairs][2] */
+} mi_ligand_desc;
+mi_status mi_vina_set_ligand(mi_vina *, const mi_ligand_desc *);
+/* model::eval_deriv(p, ig = cache, v, conf, change) (model.cu:202-225) [with_deriv = 1] or model::eval
+ * (energy only, the Metropolis energy of monte_carlo.cpp:44-47) for B conformations.
+ * v3 = per-term positive-energy caps {intramolecular, receptor grid, other} (curl.h:29-42; hunt cap
+ * (10,10,10) / authentic (1000,1000,1000), main.cpp:460, monte_carlo.cpp:102).
+ * confs [B][7+T]; energy [B]; change [B][6+T] or NULL; coords [B][n_atoms][3] or NULL. */
+mi_status mi_vina_eval_batch(mi_vina *, const float *confs, int B, const float *v3, int with_deriv, float *energy,
+                             float *change, float *coords);
+/* quasi_newton::operator() (quasi_newton.cpp:49-83) = bfgs<> with fast_line_search (bfgs.h:73-91,
+ * 357-502) for B conformations, in place; max_iters = (25 + n_movable_atoms) / 3 in gnina
+ * (main.cpp:454-456).  energy [B]; grad [B][6+T] or NULL; evals [B] or NULL. */
+mi_status mi_vina_bfgs_batch(mi_vina *, float *confs, int B, const float *v3, int max_iters, float *energy,
+                             float *grad, int32_t *evals);
+void *mi_vina_stream(mi_vina *);
+
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this
  * scorer is bracketed by HIP events on the scorer's stream.  mi_scorer_profile_json drains the
  * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes}], where
