@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
-    "mi_vina_bfgs_batch", "mi_vina_stream",
+    "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
 ]
 
 _lib = None
@@ -37,6 +37,18 @@ class LigandDesc(C.Structure):
                 ("node_parent", C.c_void_p), ("node_atom_begin", C.c_void_p), ("node_atom_end", C.c_void_p),
                 ("node_rel_origin", C.c_void_p), ("node_rel_axis", C.c_void_p), ("n_pairs", C.c_int32),
                 ("pairs", C.c_void_p)]
+
+
+class McParams(C.Structure):
+    """mi_mc_params (include/mi_gnina.h); defaults = gnina's (monte_carlo.h:38-40, main.cpp:441-463)"""
+    _fields_ = [("n_steps", C.c_int32), ("max_iters", C.c_int32), ("num_saved", C.c_int32),
+                ("temperature", C.c_float), ("mutation_amplitude", C.c_float), ("min_rmsd", C.c_float),
+                ("hunt_cap", C.c_float * 3), ("authentic_v", C.c_float * 3)]
+
+    @classmethod
+    def default(cls, n_steps, max_iters, num_saved=50):
+        return cls(n_steps, max_iters, num_saved, 1.2, 2.0, 1.0, (C.c_float * 3)(10, 10, 10),
+                   (C.c_float * 3)(1000, 1000, 1000))
 
 
 class MiGninaError(RuntimeError):
@@ -123,6 +135,10 @@ def lib():
         L.mi_vina_eval_batch.restype = C.c_int
         L.mi_vina_bfgs_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
         L.mi_vina_bfgs_batch.restype = C.c_int
+        L.mi_vina_mc_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(McParams), vp, vp, vp, vp, vp]
+        L.mi_vina_mc_batch.restype = C.c_int
+        L.mi_vina_ligand_heavy_atoms.argtypes = [vp]
+        L.mi_vina_ligand_heavy_atoms.restype = C.c_int
         L.mi_vina_stream.argtypes = [vp]
         L.mi_vina_stream.restype = vp
         _lib = L
@@ -314,15 +330,31 @@ class Vina:
         check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
         self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
 
-    def eval_batch(self, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False):
+    def eval_batch(self, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False, grid_only=False):
         confs = _f32(confs).reshape(-1, 7 + self.n_tors)
         B = len(confs)
         vv = _f32(v)
         e = np.empty(B, dtype=np.float32)
         ch = np.empty((B, 6 + self.n_tors), dtype=np.float32) if deriv else None
         co = np.empty((B, self.n_atoms, 3), dtype=np.float32) if want_coords else None
-        check(lib().mi_vina_eval_batch(self.handle, _ptr(confs), B, _ptr(vv), int(deriv), _ptr(e), _ptr(ch), _ptr(co)))
+        mode = 2 if grid_only else int(deriv)   # 1 model::eval_deriv, 0 model::eval, 2 cache::eval
+        check(lib().mi_vina_eval_batch(self.handle, _ptr(confs), B, _ptr(vv), mode, _ptr(e), _ptr(ch), _ptr(co)))
         return e, ch, co
+
+    def mc_batch(self, seeds, corner1, corner2, params):
+        """B Monte-Carlo chains -> (n_saved [B], energies [B,S], confs [B,S,7+T], coords [B,S,nh,3], evals [B])"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        B, S = len(seeds), params.num_saved
+        nh = lib().mi_vina_ligand_heavy_atoms(self.handle)
+        c1, c2 = _f32(corner1), _f32(corner2)
+        n = np.zeros(B, dtype=np.int32)
+        e = np.zeros((B, S), dtype=np.float32)
+        cf = np.zeros((B, S, 7 + self.n_tors), dtype=np.float32)
+        xyz = np.zeros((B, S, nh, 3), dtype=np.float32)
+        ev = np.zeros(B, dtype=np.int32)
+        check(lib().mi_vina_mc_batch(self.handle, B, _ptr(seeds), _ptr(c1), _ptr(c2), C.byref(params), _ptr(n),
+                                     _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev)))
+        return n, e, cf, xyz, ev
 
     def bfgs_batch(self, confs, v=(1000.0, 1000.0, 1000.0), max_iters=None):
         confs = np.array(_f32(confs).reshape(-1, 7 + self.n_tors), copy=True)

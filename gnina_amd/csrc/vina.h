@@ -45,6 +45,19 @@ struct VinaLigand {
   const int2 *pairs;         // [n_pairs] (a, b), a < b
   const int *atom_pair_start;  // [n_atoms+1] CSR: for every atom the pairs touching it, in pair order
   const int *atom_pair_list;   // entry = pair index * 2 + (1 if the atom is `b`, else 0)
+  int n_heavy;
+  const int *heavy_list;       // [n_heavy] indices of the non-hydrogen atoms
+};
+
+struct VinaMcArgs {
+  int n_steps, max_iters, num_saved;
+  float temperature, amplitude, min_rmsd;
+  float hunt[3], auth[3];
+  float c1[3], c2[3];            // search box corners
+  const unsigned long long *seeds;  // [B]
+  float *scratch_e, *scratch_conf, *scratch_coords;  // per-chain physical container
+  float *out_e, *out_conf, *out_coords;              // sorted output [B][num_saved]...
+  int *out_n, *evals;
 };
 
 struct VinaPopulateArgs {
@@ -64,6 +77,8 @@ void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
+size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved);
+void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s);
 

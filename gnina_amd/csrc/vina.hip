@@ -212,11 +212,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// model::eval_deriv (DERIV) / model::eval (!DERIV) for the conformation in LDS at `conf`.
-// Returns the energy in every lane; DERIV writes change[6 + T] to LDS.
-template <bool DERIV>
+// MODE 0: model::eval_deriv (model.cu:202-225); MODE 1: model::eval (energy only, midpoint pair table);
+// MODE 2: cache::eval (cache.cpp:52-63: receptor-grid term only -- the energy gnina's Metropolis step
+// uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates).  Returns the energy in every lane; MODE 0 writes change[6 + T] to LDS.
+template <int MODE>
 __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float *conf, float v0, float v1, float v2,
                            const WaveWork &w, float *change) {
+  constexpr bool DERIV = MODE == 0;
   const int lane = threadIdx.x;
   // 1. node frames, sequential down the tree (tree.h:152-156, 218-233)
   if (lane == 0) {
@@ -265,7 +267,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
     w.coords[3 * i + 2] = cz;
     const int t = L.smt[i];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+    if (MODE != 3 && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
       e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
     }
     if (DERIV) {
@@ -276,7 +278,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
   }
   __syncthreads();
   // 4. intramolecular pairs (model.cu:38-60 / :22-36)
-  for (int p = lane; p < L.n_pairs; p += 64) {
+  for (int p = lane; MODE < 2 && p < L.n_pairs; p += 64) {
     const int2 ab = L.pairs[p];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
@@ -375,7 +377,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
 // ---------------------------------------------------------------------------------------------
 // batch evaluation kernel
 // ---------------------------------------------------------------------------------------------
-template <bool DERIV>
+template <int MODE>
 __global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L, const float *confs, float v0,
                                                        float v1, float v2, float *energy, float *change_out,
                                                        float *coords_out) {
@@ -388,9 +390,9 @@ __global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L
   const int b = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
   __syncthreads();
-  const float e = eval_conf<DERIV>(env, L, conf, v0, v1, v2, w, change);
+  const float e = eval_conf<MODE>(env, L, conf, v0, v1, v2, w, change);
   if (lane == 0) energy[b] = e;
-  if (DERIV && change_out)
+  if (MODE == 0 && change_out)
     for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
   if (coords_out)
     for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
@@ -429,33 +431,43 @@ __device__ void conf_increment(float *x, const float *p, float alpha, int nt) {
   }
 }
 
-__global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
-                                                       float v2, int max_iters, float *energy, float *grad_out,
-                                                       int *evals_out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *pp = lds;
-  WaveWork w = carve_work(pp, L);
-  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
-  float *x_new = carve(pp, nc);   // the conformation handed to eval_conf
-  float *g_new = carve(pp, n);    // ... and the change it fills
-  float *x = carve(pp, nc), *x_orig = carve(pp, nc);
-  float *g = carve(pp, n), *g_orig = carve(pp, n), *p = carve(pp, n), *y = carve(pp, n), *mhy = carve(pp, n);
-  float *tmpn = carve(pp, n);
-  float *h = carve(pp, n * (n + 1) / 2);
-  (void)tmpn;
-  const int b = blockIdx.x, lane = threadIdx.x;
-  int evals = 0;
+struct BfgsWork {
+  float *x_new, *g_new;  // conformation handed to eval_conf and the change it fills
+  float *x, *x_orig, *g, *g_orig, *p, *y, *mhy, *h;
+};
 
+__device__ BfgsWork carve_bfgs(float *&pp, int n, int nc) {
+  BfgsWork k;
+  k.x_new = carve(pp, nc);
+  k.g_new = carve(pp, n);
+  k.x = carve(pp, nc);
+  k.x_orig = carve(pp, nc);
+  k.g = carve(pp, n);
+  k.g_orig = carve(pp, n);
+  k.p = carve(pp, n);
+  k.y = carve(pp, n);
+  k.mhy = carve(pp, n);
+  (void)carve(pp, n);
+  k.h = carve(pp, n * (n + 1) / 2);
+  return k;
+}
+
+// bfgs<> (bfgs.h:357-502) on the conformation in k.x (LDS, in/out); returns the final energy in every
+// lane, leaves the final gradient in k.g.  All control flow is wave-uniform.
+__device__ float bfgs_wave(const VinaEnv &env, const VinaLigand &L, const WaveWork &w, const BfgsWork &k, float v0,
+                           float v1, float v2, int max_iters, int &evals) {
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  const int lane = threadIdx.x;
+  float *x = k.x, *x_new = k.x_new, *x_orig = k.x_orig, *g = k.g, *g_new = k.g_new, *g_orig = k.g_orig, *p = k.p,
+        *y = k.y, *mhy = k.mhy, *h = k.h;
   for (int i = lane; i < nc; i += 64) {
-    const float val = confs[(size_t)b * nc + i];
-    x[i] = val;
-    x_orig[i] = val;
-    x_new[i] = val;
+    x_orig[i] = x[i];
+    x_new[i] = x[i];
   }
   for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
   __syncthreads();
   for (int i = lane; i < n; i += 64) h[hidx(i, i)] = 1.f;
-  float f0 = eval_conf<true>(env, L, x_new, v0, v1, v2, w, g_new);
+  float f0 = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
   evals++;
   for (int i = lane; i < n; i += 64) {
     g[i] = g_new[i];
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L
         conf_increment(x_new, p, alpha, nt);
       }
       __syncthreads();
-      f1 = eval_conf<true>(env, L, x_new, v0, v1, v2, w, g_new);
+      f1 = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
       evals++;
       if (f1 - f0 < 0.0001f * alpha * pg) break;
       alpha *= 0.5f;
@@ -531,13 +543,251 @@ __global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L
     for (int i = lane; i < n; i += 64) g[i] = g_orig[i];
   }
   __syncthreads();
-  for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = x[i];
+  return f0;
+}
+
+__global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
+                                                       float v2, int max_iters, float *energy, float *grad_out,
+                                                       int *evals_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *pp = lds;
+  WaveWork w = carve_work(pp, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  BfgsWork k = carve_bfgs(pp, n, nc);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int evals = 0;
+  for (int i = lane; i < nc; i += 64) k.x[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  const float f0 = bfgs_wave(env, L, w, k, v0, v1, v2, max_iters, evals);
+  for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = k.x[i];
   if (grad_out)
-    for (int i = lane; i < n; i += 64) grad_out[(size_t)b * n + i] = g[i];
+    for (int i = lane; i < n; i += 64) grad_out[(size_t)b * n + i] = k.g[i];
   if (lane == 0) {
     energy[b] = f0;
     if (evals_out) evals_out[b] = evals;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Monte-Carlo chain: monte_carlo::operator() (monte_carlo.cpp:99-148) -- one wavefront per chain for
+// the WHOLE chain (mutate -> BFGS(hunt cap) -> Metropolis -> BFGS(full cap) -> container insert),
+// no host round trip between steps.  RNG: a counter-based generator shared with the CPU oracle
+// (boost::mt19937 + boost distributions cannot be reproduced without the unvendored Boost; parity
+// for this row is statistical, SURVEY "Hard parts").
+// ---------------------------------------------------------------------------------------------
+struct McRng {
+  unsigned long long s;
+  __device__ unsigned u32() {
+    s += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+  }
+  __device__ float u01() { return (float)(u32() >> 8) * (1.0f / 16777216.0f); }
+  __device__ float fl(float a, float b) { return a + (b - a) * u01(); }
+  __device__ int irange(int a, int b) { return a + (int)(u32() % (unsigned)(b - a + 1)); }
+  __device__ float normal() {
+    float u1 = ((float)(u32() >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = u01();
+    return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * VPI * u2);
+  }
+  __device__ void inside_sphere(float &x, float &y, float &z) {  // random.cpp:66-75
+    for (;;) {
+      x = fl(-1, 1);
+      y = fl(-1, 1);
+      z = fl(-1, 1);
+      if (x * x + y * y + z * z < 1) return;
+    }
+  }
+};
+
+__global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *pp = lds;
+  WaveWork w = carve_work(pp, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt, nh = L.n_heavy;
+  BfgsWork k = carve_bfgs(pp, n, nc);
+  float *tmp = carve(pp, nc);
+  float *hc = carve(pp, 3 * nh);
+  float *rm = carve(pp, 64);                       // rmsd of the candidate to each saved pose
+  int *ord = reinterpret_cast<int *>(carve(pp, a.num_saved));  // sorted position -> physical slot
+  const int b = blockIdx.x, lane = threadIdx.x;
+  McRng rng{a.seeds[b]};
+  int evals = 0;
+  // scratch container of this chain (physical slots)
+  float *s_e = a.scratch_e + (size_t)b * a.num_saved;
+  float *s_conf = a.scratch_conf + (size_t)b * a.num_saved * nc;
+  float *s_xyz = a.scratch_coords + (size_t)b * a.num_saved * 3 * nh;
+
+  // conf::randomize (conf.h:119-122,189-192): every lane draws the same numbers
+  {
+    float px = rng.fl(a.c1[0], a.c2[0]), py = rng.fl(a.c1[1], a.c2[1]), pz = rng.fl(a.c1[2], a.c2[2]);
+    float q0, q1, q2, q3, nrm;
+    do {
+      q0 = rng.normal();
+      q1 = rng.normal();
+      q2 = rng.normal();
+      q3 = rng.normal();
+      nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    } while (!(nrm > VEPS));
+    if (lane == 0) {
+      tmp[0] = px, tmp[1] = py, tmp[2] = pz;
+      tmp[3] = q0 / nrm, tmp[4] = q1 / nrm, tmp[5] = q2 / nrm, tmp[6] = q3 / nrm;
+    }
+    for (int t = 0; t < nt; t++) {
+      float tv = rng.fl(-VPI, VPI);
+      if (lane == 0) tmp[7 + t] = tv;
+    }
+  }
+  __syncthreads();
+  float tmp_e = 0.f, best_e = VMAXFL;
+  int n_out = 0;
+
+  for (int step = 0; step < a.n_steps; step++) {
+    for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
+    __syncthreads();
+    // mutate_conf (mutate.cpp:35-73)
+    const int which = rng.irange(0, 2 + nt - 1);
+    if (which == 0) {
+      float dx, dy, dz;
+      rng.inside_sphere(dx, dy, dz);
+      if (lane == 0) {
+        k.x[0] += a.amplitude * dx;
+        k.x[1] += a.amplitude * dy;
+        k.x[2] += a.amplitude * dz;
+      }
+    } else if (which == 1) {
+      (void)eval_conf<3>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // coordinates of the candidate
+      float acc = 0.f;
+      for (int i = lane; i < L.n_atoms; i += 64)
+        if (L.smt[i] > 1) {
+          const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
+                      dz = w.coords[3 * i + 2] - w.origin[2];
+          acc += dx * dx + dy * dy + dz * dz;
+        }
+      acc = wave_sum(acc);
+      const float gr = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
+      if (gr > VEPS) {
+        float dx, dy, dz;
+        rng.inside_sphere(dx, dy, dz);
+        const float sc = a.amplitude / gr;
+        if (lane == 0) {
+          float rot[6] = {0.f, 0.f, 0.f, sc * dx, sc * dy, sc * dz};
+          conf_increment(k.x, rot, 1.0f, 0);
+        }
+      }
+    } else {
+      const float tv = rng.fl(-VPI, VPI);
+      if (lane == 0) k.x[7 + (which - 2)] = tv;
+    }
+    __syncthreads();
+    (void)bfgs_wave(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals);
+    const float cand_e = eval_conf<2>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // update_energy
+    bool accept = step == 0 || cand_e < tmp_e;
+    if (!accept) {  // metropolis_accept, monte_carlo.cpp:38-42
+      const float prob = expf((tmp_e - cand_e) / a.temperature);
+      accept = rng.u01() < prob;
+    }
+    if (accept) {
+      tmp_e = cand_e;
+      if (tmp_e < best_e || n_out < a.num_saved) {
+        (void)bfgs_wave(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals);
+        tmp_e = eval_conf<2>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // leaves coords of k.x in w.coords
+        for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
+        for (int h = lane; h < nh; h += 64) {
+          const int i = L.heavy_list[h];
+          hc[3 * h] = w.coords[3 * i];
+          hc[3 * h + 1] = w.coords[3 * i + 1];
+          hc[3 * h + 2] = w.coords[3 * i + 2];
+        }
+        __syncthreads();
+        // add_to_output_container (coords.cpp:25-56): rmsd to every saved pose, one pose per lane
+        for (int o = lane; o < n_out; o += 64) {
+          const float *ref = s_xyz + (size_t)ord[o] * 3 * nh;
+          float acc = 0.f;
+          for (int i = 0; i < 3 * nh; i++) {
+            const float d = hc[i] - ref[i];
+            acc += d * d;
+          }
+          rm[o & 63] = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;
+        }
+        __syncthreads();
+        int closest = n_out;
+        float closest_rmsd = VMAXFL;
+        for (int o = 0; o < n_out && o < 64; o++) {  // first minimum, like find_closest
+          const float r = rm[o];
+          if (o == 0 || r < closest_rmsd) {
+            closest = o;
+            closest_rmsd = r;
+          }
+        }
+        int pos = -1;
+        if (closest < n_out && closest_rmsd < a.min_rmsd) {
+          if (tmp_e < s_e[ord[closest]]) pos = closest;
+        } else if (n_out < a.num_saved) {
+          pos = n_out;
+          if (lane == 0) ord[pos] = n_out;
+          n_out++;
+        } else if (n_out > 0 && tmp_e < s_e[ord[n_out - 1]]) {
+          pos = n_out - 1;
+        }
+        __syncthreads();
+        if (pos >= 0) {
+          const int phys = ord[pos];
+          if (lane == 0) s_e[phys] = tmp_e;
+          for (int i = lane; i < nc; i += 64) s_conf[(size_t)phys * nc + i] = tmp[i];
+          for (int i = lane; i < 3 * nh; i += 64) s_xyz[(size_t)phys * 3 * nh + i] = hc[i];
+          __threadfence_block();
+          __syncthreads();
+          if (lane == 0) {  // out.sort(): keep `ord` ordered by energy
+            int o = pos;
+            while (o > 0 && s_e[ord[o]] < s_e[ord[o - 1]]) {
+              const int t = ord[o];
+              ord[o] = ord[o - 1];
+              ord[o - 1] = t;
+              o--;
+            }
+            while (o + 1 < n_out && s_e[ord[o + 1]] < s_e[ord[o]]) {
+              const int t = ord[o];
+              ord[o] = ord[o + 1];
+              ord[o + 1] = t;
+              o++;
+            }
+          }
+          __syncthreads();
+        }
+        if (tmp_e < best_e) best_e = tmp_e;
+      } else {
+        for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
+      }
+      __syncthreads();
+    }
+  }
+  // emit the container in sorted order
+  for (int o = 0; o < n_out; o++) {
+    const int phys = ord[o];
+    if (lane == 0) a.out_e[(size_t)b * a.num_saved + o] = s_e[phys];
+    for (int i = lane; i < nc; i += 64) a.out_conf[((size_t)b * a.num_saved + o) * nc + i] = s_conf[(size_t)phys * nc + i];
+    for (int i = lane; i < 3 * nh; i += 64)
+      a.out_coords[((size_t)b * a.num_saved + o) * 3 * nh + i] = s_xyz[(size_t)phys * 3 * nh + i];
+  }
+  if (lane == 0) {
+    a.out_n[b] = n_out;
+    if (a.evals) a.evals[b] = evals;
+  }
+}
+
+size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved) {
+  return vina_wave_lds_bytes(n_atoms, n_nodes, n_pairs, true) +
+         (pad4(7 + n_nodes - 1) + pad4(3 * (size_t)n_heavy) + 64 + pad4(num_saved)) * sizeof(float);
+}
+
+void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s) {
+  const size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved);
+  hipLaunchKernelGGL(vina_mc_kernel, dim3(B), dim3(64), lds, s, env, lig, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -583,12 +833,16 @@ void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s) {
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false);
-  if (with_deriv)
-    hipLaunchKernelGGL(vina_eval_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
+  // with_deriv: 1 = model::eval_deriv, 0 = model::eval, 2 = cache::eval (grid term only)
+  if (with_deriv == 1)
+    hipLaunchKernelGGL(vina_eval_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
+                       coords);
+  else if (with_deriv == 0)
+    hipLaunchKernelGGL(vina_eval_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
                        coords);
   else
-    hipLaunchKernelGGL(vina_eval_kernel<false>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy,
-                       change, coords);
+    hipLaunchKernelGGL(vina_eval_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
+                       coords);
 }
 
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,

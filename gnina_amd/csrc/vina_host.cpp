@@ -80,7 +80,9 @@ struct Vina {
   DevBuf<float> d_flt;
   // scratch
   DevBuf<float> d_confs, d_energy, d_change, d_coords;
-  DevBuf<int> d_evals;
+  DevBuf<int> d_evals, d_out_n;
+  DevBuf<unsigned long long> d_seeds;
+  DevBuf<float> d_mc_e, d_mc_conf, d_mc_xyz, d_sc_e, d_sc_conf, d_sc_xyz;
   ~Vina() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -316,6 +318,10 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
     while (ints.size() % 4) ints.push_back(0);
     return off;
   };
+  std::vector<int> heavy;
+  for (int i = 0; i < na; i++)
+    if (d->smt[i] > 1) heavy.push_back(i);
+  const size_t o_heavy = pushi(heavy.empty() ? aps.data() : heavy.data(), heavy.size());
   const size_t o_smt = pushi(d->smt, na), o_node = pushi(node_of.data(), na), o_par = pushi(d->node_parent, nn),
                o_abeg = pushi(d->node_atom_begin, nn), o_aend = pushi(d->node_atom_end, nn),
                o_cs = pushi(child_start.data(), nn + 1),
@@ -348,6 +354,8 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   L.pairs = reinterpret_cast<const int2 *>(v.d_int.p + o_pairs);
   L.atom_pair_start = v.d_int.p + o_aps;
   L.atom_pair_list = v.d_int.p + o_apl;
+  L.n_heavy = (int)heavy.size();
+  L.heavy_list = v.d_int.p + o_heavy;
   L.local_xyz = v.d_flt.p + o_loc;
   L.rel_origin = v.d_flt.p + o_ro;
   L.rel_axis = v.d_flt.p + o_ra;
@@ -400,6 +408,69 @@ mi_status mi_vina_bfgs_batch(mi_vina *vv, float *confs, int B, const float *v3, 
   MIG_HIP(hipMemcpyAsync(confs, v.d_confs.p, (size_t)B * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   if (grad) MIG_HIP(hipMemcpyAsync(grad, v.d_change.p, (size_t)B * n * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+int mi_vina_ligand_heavy_atoms(const mi_vina *vv) {
+  return vv && reinterpret_cast<const Vina *>(vv)->have_lig ? reinterpret_cast<const Vina *>(vv)->lig.n_heavy : 0;
+}
+
+mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const float *corner1, const float *corner2,
+                           const mi_mc_params *P, int32_t *out_n, float *out_e, float *out_conf, float *out_coords,
+                           int32_t *evals) {
+  VTRY
+  MIG_CHECK(vv && seeds && corner1 && corner2 && P && out_n && out_e && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  MIG_CHECK(P->num_saved > 0 && P->num_saved <= 64 && P->n_steps >= 0 && P->max_iters >= 0 && P->temperature > 0, 1,
+            "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, nc = 7 + nt, nh = v.lig.n_heavy, S = P->num_saved;
+  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S) <= 64 * 1024, 1,
+            "ligand too large for the per-wave LDS workspace");
+  v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
+  v.d_mc_e.ensure((size_t)B * S);
+  v.d_mc_conf.ensure((size_t)B * S * nc);
+  v.d_mc_xyz.ensure((size_t)B * S * 3 * nh + 1);
+  v.d_sc_e.ensure((size_t)B * S);
+  v.d_sc_conf.ensure((size_t)B * S * nc);
+  v.d_sc_xyz.ensure((size_t)B * S * 3 * nh + 1);
+  v.d_out_n.ensure(B);
+  v.d_evals.ensure(B);
+  VinaMcArgs a{};
+  a.n_steps = P->n_steps;
+  a.max_iters = P->max_iters;
+  a.num_saved = S;
+  a.temperature = P->temperature;
+  a.amplitude = P->mutation_amplitude;
+  a.min_rmsd = P->min_rmsd;
+  for (int i = 0; i < 3; i++) {
+    a.hunt[i] = P->hunt_cap[i];
+    a.auth[i] = P->authentic_v[i];
+    a.c1[i] = corner1[i];
+    a.c2[i] = corner2[i];
+  }
+  a.seeds = v.d_seeds.p;
+  a.scratch_e = v.d_sc_e.p;
+  a.scratch_conf = v.d_sc_conf.p;
+  a.scratch_coords = v.d_sc_xyz.p;
+  a.out_e = v.d_mc_e.p;
+  a.out_conf = v.d_mc_conf.p;
+  a.out_coords = v.d_mc_xyz.p;
+  a.out_n = v.d_out_n.p;
+  a.evals = v.d_evals.p;
+  launch_vina_mc(make_env(v), v.lig, a, B, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(out_n, v.d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(out_e, v.d_mc_e.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_conf)
+    MIG_HIP(hipMemcpyAsync(out_conf, v.d_mc_conf.p, (size_t)B * S * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_coords && nh > 0)
+    MIG_HIP(hipMemcpyAsync(out_coords, v.d_mc_xyz.p, (size_t)B * S * 3 * nh * sizeof(float), hipMemcpyDeviceToHost,
+                           v.stream));
   if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipStreamSynchronize(v.stream));
   return MI_OK;

@@ -178,6 +178,24 @@ mi_status mi_vina_eval_batch(mi_vina *, const float *confs, int B, const float *
  * (main.cpp:454-456).  energy [B]; grad [B][6+T] or NULL; evals [B] or NULL. */
 mi_status mi_vina_bfgs_batch(mi_vina *, float *confs, int B, const float *v3, int max_iters, float *energy,
                              float *grad, int32_t *evals);
+/* monte_carlo::operator() (monte_carlo.cpp:99-148) for B independent chains of the current ligand:
+ * random start in the box (conf.h:119-122), per step mutate_conf (mutate.cpp:35-73) -> BFGS with the
+ * hunt cap -> Metropolis on the receptor-grid energy (monte_carlo.cpp:38-47) -> BFGS with the full cap
+ * -> add_to_output_container (coords.cpp:43-56).  Defaults of gnina: temperature 1.2, amplitude 2,
+ * min_rmsd 1.0, num_saved 50, hunt_cap (10,10,10), authentic_v (1000,1000,1000), n_steps per
+ * main.cpp:441-463.  One seed per chain (parallel_mc.cpp:190-192).  The random stream is NOT
+ * boost::mt19937 (unvendored dependency): parity with the reference is statistical.
+ * Outputs per chain, sorted by energy: out_n [B]; out_e [B][num_saved]; out_conf [B][num_saved][7+T];
+ * out_coords [B][num_saved][n_heavy][3] (heavy-atom coordinates, model::get_heavy_atom_movable_coords). */
+typedef struct mi_mc_params {
+  int32_t n_steps, max_iters, num_saved;
+  float temperature, mutation_amplitude, min_rmsd;
+  float hunt_cap[3], authentic_v[3];
+} mi_mc_params;
+mi_status mi_vina_mc_batch(mi_vina *, int B, const uint64_t *seeds, const float *corner1, const float *corner2,
+                           const mi_mc_params *params, int32_t *out_n, float *out_e, float *out_conf,
+                           float *out_coords, int32_t *evals);
+int mi_vina_ligand_heavy_atoms(const mi_vina *);
 void *mi_vina_stream(mi_vina *);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this

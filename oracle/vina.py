@@ -183,6 +183,42 @@ class Scene:
         return e, conf, g, ev.value
 
 
+class McParams(C.Structure):
+    _fields_ = [("n_steps", C.c_int), ("max_iters", C.c_int), ("num_saved", C.c_int), ("temperature", C.c_float),
+                ("mutation_amplitude", C.c_float), ("min_rmsd", C.c_float), ("hunt_cap", C.c_float * 3),
+                ("authentic_v", C.c_float * 3)]
+
+
+def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, temperature=1.2, amplitude=2.0,
+             min_rmsd=1.0):
+    """monte_carlo::operator() for one chain -> (energies [n], confs [n,7+T], coords [n,nh,3], evals)"""
+    lig = scene.lig
+    nh = int((lig.arr["smt"] > 1).sum())
+    P = McParams(n_steps, max_iters, num_saved, temperature, amplitude, min_rmsd, (C.c_float * 3)(10, 10, 10),
+                 (C.c_float * 3)(1000, 1000, 1000))
+    e = np.zeros(num_saved, dtype=np.float32)
+    cf = np.zeros((num_saved, 7 + lig.n_tors), dtype=np.float32)
+    xyz = np.zeros((num_saved, nh, 3), dtype=np.float32)
+    c1 = np.ascontiguousarray(corner1, dtype=np.float32)
+    c2 = np.ascontiguousarray(corner2, dtype=np.float32)
+    ev = C.c_long()
+    f = _voxel.lib().ora_vina_mc_chain
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, _f32p,
+                  C.c_uint64, C.POINTER(McParams), _f32p, _f32p, _f32p, C.POINTER(C.c_long)]
+    n = f(scene.tables.h, C.byref(scene.gd), scene.ptrs, scene.slope, C.byref(lig.c), _p(c1), _p(c2), int(seed),
+          C.byref(P), _p(e), _p(cf), _p(xyz), C.byref(ev))
+    return e[:n], cf[:n], xyz[:n], ev.value
+
+
+def cache_eval(scene, conf, v1=1000.0):
+    conf = np.ascontiguousarray(conf, dtype=np.float32)
+    f = _voxel.lib().ora_vina_cache_eval
+    f.restype = C.c_float
+    f.argtypes = [C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, C.c_float]
+    return f(C.byref(scene.gd), scene.ptrs, scene.slope, C.byref(scene.lig.c), _p(conf), v1)
+
+
 def _model_eval_deriv():
     f = _voxel.lib().ora_vina_model_eval_deriv
     f.restype = C.c_float

@@ -702,3 +702,225 @@ float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
   free(axis);
   return e;
 }
+
+/* cache::eval (cache.cpp:52-63): receptor-grid term only, energy only -- what update_energy
+ * (monte_carlo.cpp:44-47) feeds the Metropolis criterion. */
+float ora_vina_cache_eval(const ora_grid_dims *gd, const float *const *grids, float slope, const ora_ligand *L,
+                          const float *conf, float v1) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  float e = 0;
+  for (int i = 0; i < n; i++) {
+    int t = L->smt[i];
+    if (is_hydrogen(t) || !grids[t]) continue;
+    e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v1, NULL);
+  }
+  free(coords);
+  free(origin);
+  free(axis);
+  return e;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Monte-Carlo chain: monte_carlo::operator() (monte_carlo.cpp:99-148), mutate_conf (mutate.cpp:35-73),
+ * metropolis_accept (monte_carlo.cpp:38-42), conf randomize (conf.h:119-122,189-192),
+ * add_to_output_container (coords.cpp:25-56).
+ *
+ * DEVIATION (documented, SURVEY "Hard parts"): the reference draws from boost::mt19937 through
+ * boost's uniform_real / uniform_int / normal_distribution, whose exact algorithms depend on the
+ * (unvendored) Boost version; trajectories cannot be reproduced without it.  The oracle and the
+ * HIP kernel therefore share this small counter-based generator instead; parity for the MC row
+ * is statistical.  Second deviation: gyration_radius and the Metropolis energy are taken at the
+ * chain's current conformation (the reference reads whatever coordinates the last evaluation left
+ * in `model`, identical except after a rejected BFGS).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t s;
+} ora_rng;
+
+static uint32_t rng_u32(ora_rng *r) { /* splitmix64, high half */
+  r->s += 0x9E3779B97F4A7C15ull;
+  uint64_t z = r->s;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+static float rng_u01(ora_rng *r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
+static float rng_fl(ora_rng *r, float a, float b) { return a + (b - a) * rng_u01(r); }
+static int rng_int(ora_rng *r, int a, int b) { return a + (int)(rng_u32(r) % (uint32_t)(b - a + 1)); }
+static float rng_normal(ora_rng *r) { /* Box-Muller */
+  float u1 = ((float)(rng_u32(r) >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  float u2 = rng_u01(r);
+  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * V_PI * u2);
+}
+static void rng_inside_sphere(ora_rng *r, float *o) { /* random.cpp:66-75 */
+  for (;;) {
+    o[0] = rng_fl(r, -1, 1);
+    o[1] = rng_fl(r, -1, 1);
+    o[2] = rng_fl(r, -1, 1);
+    if (o[0] * o[0] + o[1] * o[1] + o[2] * o[2] < 1) return;
+  }
+}
+
+typedef struct {
+  int n_steps, max_iters, num_saved;
+  float temperature, mutation_amplitude, min_rmsd;
+  float hunt_cap[3], authentic_v[3];
+} ora_mc_params;
+
+/* out arrays sized for num_saved entries: out_e[num_saved], out_conf[num_saved][7+T],
+ * out_coords[num_saved][n_heavy][3]; returns the number of saved poses (sorted by energy). */
+int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                      const ora_ligand *L, const float *corner1, const float *corner2, uint64_t seed,
+                      const ora_mc_params *P, float *out_e, float *out_conf, float *out_coords, long *evals_out) {
+  const int nt = L->n_nodes - 1, nc = 7 + nt, na = L->n_atoms;
+  int nh = 0;
+  for (int i = 0; i < na; i++) nh += !is_hydrogen(L->smt[i]);
+  ora_rng rng = {seed};
+  float *tmp = (float *)malloc(sizeof(float) * nc), *cand = (float *)malloc(sizeof(float) * nc);
+  float *coords = (float *)malloc(sizeof(float) * 3 * na), *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes),
+        *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *hc = (float *)malloc(sizeof(float) * 3 * nh);
+  long evals = 0, ev;
+  /* conf::randomize */
+  for (int k = 0; k < 3; k++) tmp[k] = rng_fl(&rng, corner1[k], corner2[k]);
+  for (;;) {
+    float q[4] = {rng_normal(&rng), rng_normal(&rng), rng_normal(&rng), rng_normal(&rng)};
+    float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (nrm > V_EPS) {
+      for (int k = 0; k < 4; k++) tmp[3 + k] = q[k] / nrm;
+      break;
+    }
+  }
+  for (int k = 0; k < nt; k++) tmp[7 + k] = rng_fl(&rng, -V_PI, V_PI);
+  float tmp_e = 0, best_e = V_MAXFL;
+  int n_out = 0;
+  for (int step = 0; step < P->n_steps; step++) {
+    memcpy(cand, tmp, sizeof(float) * nc);
+    /* mutate_conf */
+    int which = rng_int(&rng, 0, 2 + nt - 1);
+    if (which == 0) {
+      float d[3];
+      rng_inside_sphere(&rng, d);
+      for (int k = 0; k < 3; k++) cand[k] += P->mutation_amplitude * d[k];
+    } else if (which == 1) {
+      ora_vina_set_conf(L, cand, coords, origin, axis);
+      float acc = 0;
+      int cnt = 0;
+      for (int i = 0; i < na; i++)
+        if (!is_hydrogen(L->smt[i])) { /* model::gyration_radius, model.cpp:1002-1014 */
+          float dx = coords[3 * i] - origin[0], dy = coords[3 * i + 1] - origin[1], dz = coords[3 * i + 2] - origin[2];
+          acc += dx * dx + dy * dy + dz * dz;
+          cnt++;
+        }
+      float gr = cnt > 0 ? sqrtf(acc / (float)cnt) : 0;
+      if (gr > V_EPS) {
+        float d[3];
+        rng_inside_sphere(&rng, d);
+        float s = P->mutation_amplitude / gr;
+        float rot[6] = {0, 0, 0, s * d[0], s * d[1], s * d[2]};
+        ora_vina_conf_increment(cand, rot, 1.0f, 0); /* quaternion_increment(orientation, rotation) */
+      }
+    } else {
+      cand[7 + (which - 2)] = rng_fl(&rng, -V_PI, V_PI);
+    }
+    ora_vina_bfgs(T, gd, grids, slope, L, cand, P->hunt_cap, P->max_iters, NULL, &ev);
+    evals += ev;
+    float cand_e = ora_vina_cache_eval(gd, grids, slope, L, cand, P->authentic_v[1]);
+    int accept = step == 0 || cand_e < tmp_e;
+    if (!accept) { /* metropolis_accept */
+      float prob = expf((tmp_e - cand_e) / P->temperature);
+      accept = rng_u01(&rng) < prob;
+    }
+    if (accept) {
+      memcpy(tmp, cand, sizeof(float) * nc);
+      tmp_e = cand_e;
+      if (tmp_e < best_e || n_out < P->num_saved) {
+        ora_vina_bfgs(T, gd, grids, slope, L, tmp, P->authentic_v, P->max_iters, NULL, &ev);
+        evals += ev;
+        tmp_e = ora_vina_cache_eval(gd, grids, slope, L, tmp, P->authentic_v[1]);
+        ora_vina_set_conf(L, tmp, coords, origin, axis);
+        int h = 0;
+        for (int i = 0; i < na; i++)
+          if (!is_hydrogen(L->smt[i])) {
+            hc[3 * h] = coords[3 * i];
+            hc[3 * h + 1] = coords[3 * i + 1];
+            hc[3 * h + 2] = coords[3 * i + 2];
+            h++;
+          }
+        /* add_to_output_container (coords.cpp:43-56) */
+        int closest = n_out;
+        float closest_rmsd = V_MAXFL;
+        for (int o = 0; o < n_out; o++) {
+          float acc = 0;
+          for (int i = 0; i < 3 * nh; i++) {
+            float d = hc[i] - out_coords[(size_t)o * 3 * nh + i];
+            acc += d * d;
+          }
+          /* vec_distance_sqr sums per atom then accumulates; same value up to association */
+          float res = nh > 0 ? sqrtf(acc / (float)nh) : 0;
+          if (o == 0 || res < closest_rmsd) {
+            closest = o;
+            closest_rmsd = res;
+          }
+        }
+        int slot = -1;
+        if (closest < n_out && closest_rmsd < P->min_rmsd) {
+          if (tmp_e < out_e[closest]) slot = closest;
+        } else if (n_out < P->num_saved) {
+          slot = n_out++;
+        } else if (n_out > 0 && tmp_e < out_e[n_out - 1]) {
+          slot = n_out - 1;
+        }
+        if (slot >= 0) {
+          out_e[slot] = tmp_e;
+          memcpy(out_conf + (size_t)slot * nc, tmp, sizeof(float) * nc);
+          memcpy(out_coords + (size_t)slot * 3 * nh, hc, sizeof(float) * 3 * nh);
+          /* out.sort(): insertion keeps the container ordered by energy */
+          for (int o = slot; o > 0 && out_e[o] < out_e[o - 1]; o--) {
+            float te = out_e[o];
+            out_e[o] = out_e[o - 1];
+            out_e[o - 1] = te;
+            for (int k = 0; k < nc; k++) {
+              float t = out_conf[(size_t)o * nc + k];
+              out_conf[(size_t)o * nc + k] = out_conf[(size_t)(o - 1) * nc + k];
+              out_conf[(size_t)(o - 1) * nc + k] = t;
+            }
+            for (int k = 0; k < 3 * nh; k++) {
+              float t = out_coords[(size_t)o * 3 * nh + k];
+              out_coords[(size_t)o * 3 * nh + k] = out_coords[(size_t)(o - 1) * 3 * nh + k];
+              out_coords[(size_t)(o - 1) * 3 * nh + k] = t;
+            }
+          }
+          for (int o = slot; o + 1 < n_out && out_e[o + 1] < out_e[o]; o++) {
+            float te = out_e[o];
+            out_e[o] = out_e[o + 1];
+            out_e[o + 1] = te;
+            for (int k = 0; k < nc; k++) {
+              float t = out_conf[(size_t)o * nc + k];
+              out_conf[(size_t)o * nc + k] = out_conf[(size_t)(o + 1) * nc + k];
+              out_conf[(size_t)(o + 1) * nc + k] = t;
+            }
+            for (int k = 0; k < 3 * nh; k++) {
+              float t = out_coords[(size_t)o * 3 * nh + k];
+              out_coords[(size_t)o * 3 * nh + k] = out_coords[(size_t)(o + 1) * 3 * nh + k];
+              out_coords[(size_t)(o + 1) * 3 * nh + k] = t;
+            }
+          }
+        }
+        if (tmp_e < best_e) best_e = tmp_e;
+      }
+    }
+  }
+  if (evals_out) *evals_out = evals;
+  free(tmp);
+  free(cand);
+  free(coords);
+  free(origin);
+  free(axis);
+  free(hc);
+  return n_out;
+}

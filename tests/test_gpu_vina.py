@@ -123,3 +123,48 @@ def test_vina_error_paths(capi):
     v.n_tors = 0
     with pytest.raises(capi.MiGninaError):
         v.eval_batch(np.zeros((1, 7), dtype=np.float32))            # no ligand yet
+
+
+def test_mc_chain_first_step_matches_oracle_and_statistics(setup, capi):
+    """Row a17.  Same counter-based RNG on both sides: a 1-step chain with a short BFGS must agree
+    closely (identical random start / mutation, step-exact BFGS); full chains are chaotic, so they
+    are compared statistically over 48 chains.  Structural invariants of the output container
+    (coords.cpp:43-56) are checked exactly."""
+    vina, S, sc, gd, types, grids = setup
+    c1, c2 = list(gd.begin), list(gd.end)
+    seeds = np.arange(100, 148, dtype=np.uint64)
+    # (a) one step, two BFGS iterations
+    P = capi.McParams.default(1, 2, 8)
+    n, e, cf, xyz, ev = vina.mc_batch(seeds, c1, c2, P)
+    close = 0
+    for b in range(len(seeds)):
+        e0, cf0, xyz0, ev0 = V.mc_chain(S, c1, c2, int(seeds[b]), 1, 2, 8)
+        assert n[b] == len(e0) == 1
+        if abs(e[b, 0] - e0[0]) <= 1e-3 * max(1.0, abs(e0[0])) and np.abs(cf[b, 0] - cf0[0]).max() < 1e-2:
+            close += 1
+    assert close >= 0.9 * len(seeds), close
+    # (b) longer chains: invariants + statistics
+    steps, iters, saved = 120, (25 + vina.n_atoms) // 3, 20
+    P = capi.McParams.default(steps, iters, saved)
+    n, e, cf, xyz, ev = vina.mc_batch(seeds, c1, c2, P)
+    assert (n >= 1).all() and (n <= saved).all() and (ev > steps).all()
+    for b in range(0, len(seeds), 5):
+        eb = e[b, :n[b]]
+        assert np.all(np.diff(eb) >= 0)                                   # container sorted by energy
+        chk = vina.eval_batch(cf[b, :n[b]], grid_only=True, deriv=False)[0]
+        assert np.abs(chk - eb).max() <= 1e-4 * max(1.0, np.abs(eb).max())  # stored e = cache::eval(conf)
+        co = vina.eval_batch(cf[b, :n[b]], want_coords=True)[2]
+        heavy = np.nonzero(sc["lig"]["smt"] > 1)[0]
+        assert np.abs(co[:, heavy] - xyz[b, :n[b]]).max() < 1e-3           # stored coords = heavy atoms of conf
+    best_dev = e[:, 0]
+    orc = [V.mc_chain(S, c1, c2, int(s), steps, iters, saved) for s in seeds]
+    best_orc = np.array([o[0][0] for o in orc])
+    ev_orc = np.array([o[3] for o in orc])
+    sem = np.sqrt(best_dev.var() / len(seeds) + best_orc.var() / len(seeds))
+    assert abs(best_dev.mean() - best_orc.mean()) <= 4 * sem + 0.05 * abs(best_orc.mean()), (best_dev.mean(), best_orc.mean(), sem)
+    assert abs(ev.mean() - ev_orc.mean()) <= 0.15 * ev_orc.mean()          # same amount of optimisation work
+    # (c) determinism: same seeds -> same bits; different seeds -> different chains
+    n2, e2, _, _, _ = vina.mc_batch(seeds[:4], c1, c2, P)
+    assert np.array_equal(e2[:, 0], e[:4, 0])
+    n3, e3, _, _, _ = vina.mc_batch(seeds[:4] + np.uint64(1000), c1, c2, P)
+    assert not np.array_equal(e3[:, 0], e[:4, 0])
