@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_model_supports_gradient", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -95,6 +95,10 @@ def lib():
         L.mi_scorer_score_batch.restype = C.c_int
         L.mi_scorer_score_batch_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint]
         L.mi_scorer_score_batch_ex.restype = C.c_int
+        L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.mi_scorer_score_grad.restype = C.c_int
+        L.mi_model_supports_gradient.argtypes = [vp]
+        L.mi_model_supports_gradient.restype = C.c_int
         L.mi_scorer_last_model_outputs.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         L.mi_scorer_last_model_outputs.restype = C.c_int
         L.mi_voxelize_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_uint]
@@ -227,6 +231,18 @@ class Scorer:
         check(lib().mi_scorer_score_batch_ex(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers),
                                              _ptr(pose), _ptr(aff), _ptr(loss), _ptr(var), flags))
         return {"pose": pose, "affinity": aff, "loss": loss, "variance": var}
+
+    def score_grad(self, lig_xyz, lig_smt, centers=None):
+        """Scores + d loss / d ligand coordinates [B][L][3] (refinement path)."""
+        lig_xyz = _f32(lig_xyz)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        lig_smt = _i32(lig_smt)
+        centers = _f32(centers)
+        pose, aff, loss, var = (np.empty(B, dtype=np.float32) for _ in range(4))
+        grad = np.empty((B, L, 3), dtype=np.float32)
+        check(lib().mi_scorer_score_grad(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(pose),
+                                         _ptr(aff), _ptr(loss), _ptr(var), _ptr(grad)))
+        return {"pose": pose, "affinity": aff, "loss": loss, "variance": var, "lig_grad": grad}
 
     def last_model_outputs(self, m, B):
         pose, aff, loss = (np.empty(B, dtype=np.float32) for _ in range(3))

@@ -20,6 +20,16 @@ struct ConvArgs {
   int relu, pool;    // pool: 0 none, 1 max, 2 avg (2x2x2 after ReLU)
   int tcx, tcy, tcz; // workgroup tile in 2x2x2 cells
   int ntx, nty, ntz; // tiles per axis
+  // backward-data support (the same kernel runs the transposed convolution):
+  //   in_mode 0: plain input
+  //   in_mode 1: input masked by (in_act > 0) at the same voxel      (ReLU backward)
+  //   in_mode 2: max-unpool on load: `in`, `in_argmax`, `in_act` are at S/2; a voxel receives the pooled
+  //              gradient iff it was the arg-max of its 2x2x2 cell and the pooled activation was > 0
+  int in_mode;
+  const unsigned char *in_argmax;  // [B][S/2]^3[in_cs] (in_mode 2)
+  const float *in_act;             // mask source; stride in_act_cs
+  int in_act_cs;
+  unsigned char *argmax_out;       // pool == 1: arg-max index (x*4+y*2+z) per pooled output, or nullptr
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;
@@ -37,6 +47,9 @@ void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int ou
 void launch_gmax(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
 void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
                      int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s);
+void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s);
+void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
+                       hipStream_t s);
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
                             float *pose, float *aff, float *loss, float *var, hipStream_t s);
 

@@ -103,14 +103,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S) {
         const int c = c_base + c4 * 4;
-        val = *reinterpret_cast<const float4 *>(in_b + (((size_t)x * S + y) * S + z) * p.in_cs + c);
-        if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
-          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
-          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
-          val.x = val.x * sc.x + sh.x;
-          val.y = val.y * sc.y + sh.y;
-          val.z = val.z * sc.z + sh.z;
-          val.w = val.w * sc.w + sh.w;
+        if (p.in_mode == 2) {
+          // transposed conv fed by a max-pooled gradient: un-pool while staging (no full-size tensor in HBM)
+          const int Sh = S >> 1;
+          const size_t cell = (((size_t)b * Sh + (x >> 1)) * Sh + (y >> 1)) * Sh + (z >> 1);
+          const int r = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+          const float4 g = *reinterpret_cast<const float4 *>(p.in + cell * p.in_cs + c);
+          const uchar4 am = *reinterpret_cast<const uchar4 *>(p.in_argmax + cell * p.in_cs + c);
+          const float4 act = *reinterpret_cast<const float4 *>(p.in_act + cell * p.in_act_cs + c);
+          val.x = (am.x == r && act.x > 0.f) ? g.x : 0.f;
+          val.y = (am.y == r && act.y > 0.f) ? g.y : 0.f;
+          val.z = (am.z == r && act.z > 0.f) ? g.z : 0.f;
+          val.w = (am.w == r && act.w > 0.f) ? g.w : 0.f;
+        } else {
+          const size_t vox = ((size_t)x * S + y) * S + z;
+          val = *reinterpret_cast<const float4 *>(in_b + vox * p.in_cs + c);
+          if (p.in_mode == 1) {  // ReLU backward: gradient passes where the forward activation was > 0
+            const float4 act =
+                *reinterpret_cast<const float4 *>(p.in_act + ((size_t)b * S * S * S + vox) * p.in_act_cs + c);
+            val.x = act.x > 0.f ? val.x : 0.f;
+            val.y = act.y > 0.f ? val.y : 0.f;
+            val.z = act.z > 0.f ? val.z : 0.f;
+            val.w = act.w > 0.f ? val.w : 0.f;
+          }
+          if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
+            const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
+            val.x = val.x * sc.x + sh.x;
+            val.y = val.y * sc.y + sh.y;
+            val.z = val.z * sc.z + sh.z;
+            val.w = val.w * sc.w + sh.w;
+          }
         }
       }
       *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
@@ -167,9 +190,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
         }
         if (p.pool == 1) {
           float mx = v[0];
+          int am = 0;
 #pragma unroll
-          for (int r = 1; r < 8; r++) mx = fmaxf(mx, v[r]);
-          out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = mx;
+          for (int r = 1; r < 8; r++)
+            if (v[r] > mx) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
+              mx = v[r];
+              am = r;
+            }
+          const size_t o = (((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch;
+          out_b[o] = mx;
+          if (p.argmax_out) p.argmax_out[(size_t)b * So * So * So * p.out_cs + p.out_c0 + o] = (unsigned char)am;
         } else if (p.pool == 2) {
           float s = v[0];
 #pragma unroll
@@ -385,6 +415,52 @@ void launch_fc_heads(const float *in, const float *w, const float *bias, int n_i
                      int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s) {
   hipLaunchKernelGGL(fc_heads_kernel, dim3(B), dim3(256), 0, s, in, w, bias, n_in, skip_softmax, logistic_loss,
                      pose, aff, loss, raw3);
+}
+
+// ---- gradient pass helpers --------------------------------------------------------------------
+// d loss / d (fc input).  loss = cross_entropy(log_softmax(z), 1) (torch_model.cpp:192-195) so
+// dz = softmax(z) - onehot(1) = (exp(lp0), exp(lp1) - 1); the affinity head does not enter the loss.
+__global__ void fc_backward_kernel(const float *raw3, const float *w, int n_in, float *g_in) {
+  const int b = blockIdx.y;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n_in) return;
+  const float dz0 = expf(raw3[3 * b + 0]), dz1 = expf(raw3[3 * b + 1]) - 1.0f;
+  const float4 w0 = *reinterpret_cast<const float4 *>(w + i), w1 = *reinterpret_cast<const float4 *>(w + n_in + i);
+  float4 g;
+  g.x = w0.x * dz0 + w1.x * dz1;
+  g.y = w0.y * dz0 + w1.y * dz1;
+  g.z = w0.z * dz0 + w1.z * dz1;
+  g.w = w0.w * dz0 + w1.w * dz1;
+  *reinterpret_cast<float4 *>(g_in + (size_t)b * n_in + i) = g;
+}
+
+void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s) {
+  hipLaunchKernelGGL(fc_backward_kernel, dim3((n_in / 4 + 255) / 256, B), dim3(256), 0, s, raw3, w, n_in, g_in);
+}
+
+// avg_pool3d(2) backward: every voxel of a cell receives 1/8 of the pooled gradient
+__global__ void unpool_avg_kernel(const float *g_pooled, float *g_full, int C, int in_cs, int out_cs, int S,
+                                  long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  long r = i / C;
+  int z = r % S;
+  r /= S;
+  int y = r % S;
+  r /= S;
+  int x = r % S;
+  long b = r / S;
+  const int Sh = S / 2;
+  g_full[((((size_t)b * S + x) * S + y) * S + z) * out_cs + c] =
+      g_pooled[((((size_t)b * Sh + (x >> 1)) * Sh + (y >> 1)) * Sh + (z >> 1)) * in_cs + c] * 0.125f;
+}
+
+void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
+                       hipStream_t s) {
+  long total = (long)B * S * S * S * C;
+  hipLaunchKernelGGL(unpool_avg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_pooled, g_full, C,
+                     in_cs, out_cs, S, total);
 }
 
 // ensemble mean / variance over models (cnn_torch_scorer.cpp:177-191)

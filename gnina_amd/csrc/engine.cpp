@@ -41,6 +41,9 @@ struct ConvPlan {
 struct Step {
   OpKind kind;
   ConvPlan conv;         // Conv
+  ConvPlan bwd;          // Conv: transposed twin for the gradient pass (grad program only)
+  bool has_bwd = false;
+  bool has_bn = false;
   int src = -1, dst = -1;
   int pool_mode = 0;     // Pool
   int C = 0;             // channels moved by Pool/GMax
@@ -57,6 +60,9 @@ struct Model {
   int input_dst = -1;    // buffer receiving the pooled grid
   std::vector<int> buf_cp;          // padded channel stride per buffer (0 = never materialised)
   std::vector<Step> steps;          // executable program after fusion
+  std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
+  bool grad_supported = false;
+  std::string grad_unsupported_reason;
   DevBuf<float> dev_data;           // fc weights, biases, bn params (canonical payload)
   std::vector<std::unique_ptr<DevBuf<float>>> packed;  // packed conv weights / padded bias / bn
   float qa, qb, qc;                 // quadratic tail coefficients
@@ -73,7 +79,19 @@ static const float *push_dev(Model &m, const std::vector<float> &host) {
   return buf.p;
 }
 
-static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0) {
+// Transposed ("backward-data") twin of a forward conv: same geometry, channels swapped, taps flipped.
+static Op make_bwd_op(const Op &o) {
+  Op b = o;
+  b.cin = o.cout;
+  b.cout = o.cin;
+  b.relu = 0;
+  b.bn_scale_off = b.bn_shift_off = -1;
+  b.dst_c0 = 0;
+  return b;
+}
+
+static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0,
+                      bool backward = false) {
   const int S = m.d.bufs[o.src].S;
   MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
   const int cells = S / 2;
@@ -105,7 +123,8 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.ntz = cdiv(cells, a.tcz);
   // K chunking: largest divisor of cin4 whose halo tile fits the LDS budget
   const int cin4 = cdiv(o.cin, 4);
-  MIG_CHECK(cin4 * 4 <= round_up(m.d.bufs[o.src].C, 4), 2, "conv input channels exceed buffer");
+  if (!backward) MIG_CHECK(cin4 * 4 <= round_up(m.d.bufs[o.src].C, 4), 2, "conv input channels exceed buffer");
+  if (backward) MIG_CHECK(o.cin % 4 == 0, 2, "backward conv needs the forward Cout to be a multiple of 4");
   const int halo = o.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
   const size_t budget = 72 * 1024;
@@ -122,7 +141,18 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   const int taps = o.ksize * o.ksize * o.ksize;
   const int Q = taps * a.cc4, P = (Q + 1) / 2;
   std::vector<float> wp((size_t)a.nchunks * P * 2 * a.coutp * 4, 0.f);
-  const float *w = m.d.data.data() + o.w_off;  // [tap][cin][cout]
+  // forward: canonical [tap][cin][cout]; backward: W'[tap][co][ci] = W[taps-1-tap][ci][co] (flipped, transposed)
+  std::vector<float> wT;
+  const float *w = m.d.data.data() + o.w_off;
+  if (backward) {
+    const int fci = o.cout, fco = o.cin;  // forward cin / cout
+    wT.resize((size_t)taps * o.cin * o.cout);
+    for (int t = 0; t < taps; t++)
+      for (int ci = 0; ci < fci; ci++)
+        for (int co = 0; co < fco; co++)
+          wT[((size_t)t * fco + co) * fci + ci] = w[((size_t)(taps - 1 - t) * fci + ci) * fco + co];
+    w = wT.data();
+  }
   for (int ch = 0; ch < a.nchunks; ch++)
     for (int pr = 0; pr < P; pr++)
       for (int kh = 0; kh < 2; kh++) {
@@ -138,9 +168,14 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
       }
   a.wp = push_dev(m, wp);
   std::vector<float> bias(a.coutp, 0.f);
-  std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
+  if (!backward) std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
   a.bias = push_dev(m, bias);
   a.bn_scale = a.bn_shift = nullptr;
+  a.in_mode = 0;
+  a.in_argmax = nullptr;
+  a.in_act = nullptr;
+  a.in_act_cs = 0;
+  a.argmax_out = nullptr;
   if (o.bn_scale_off >= 0) {
     std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
     std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -174,47 +209,79 @@ static Model *build_model(ModelDesc &&desc) {
   m->input_pool = d.ops[0].pool_mode;
   m->input_dst = d.ops[0].dst;
   m->buf_cp[m->input_dst] = round_up(d.bufs[m->input_dst].C, 4);
-  for (size_t i = 1; i < d.ops.size(); i++) {
-    const Op &o = d.ops[i];
-    Step st;
-    st.kind = o.kind;
-    if (o.kind == OpKind::Conv) {
-      // fuse "conv -> pool" when the pool directly consumes this conv's private output
-      int pool_mode = 0, dst = o.dst, dst_c0 = o.dst_c0;
-      if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == o.dst &&
-          o.src != o.dst && o.dst_c0 == 0 && o.cout == d.bufs[o.dst].C) {
-        bool used_elsewhere = false;
-        for (size_t j = i + 2; j < d.ops.size(); j++)
-          if (d.ops[j].src == o.dst) used_elsewhere = true;
-        if (!used_elsewhere) {
-          pool_mode = d.ops[i + 1].pool_mode;
-          dst = d.ops[i + 1].dst;
-          i++;  // swallow the pool
+  auto build_steps = [&](bool grad) {
+    std::vector<Step> out;
+    for (size_t i = 1; i < d.ops.size(); i++) {
+      const Op &o = d.ops[i];
+      Step st;
+      st.kind = o.kind;
+      if (o.kind == OpKind::Conv) {
+        // fuse "conv -> pool" when the pool directly consumes this conv's private output
+        // (gradient program: only max pools are fused -- their arg-max is saved; avg pools keep the
+        // pre-pool activation, which the ReLU backward needs)
+        int pool_mode = 0, dst = o.dst, dst_c0 = o.dst_c0;
+        if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == o.dst &&
+            o.src != o.dst && o.dst_c0 == 0 && o.cout == d.bufs[o.dst].C && !(grad && d.ops[i + 1].pool_mode == 2)) {
+          bool used_elsewhere = false;
+          for (size_t j = i + 2; j < d.ops.size(); j++)
+            if (d.ops[j].src == o.dst) used_elsewhere = true;
+          if (!used_elsewhere) {
+            pool_mode = d.ops[i + 1].pool_mode;
+            dst = d.ops[i + 1].dst;
+            i++;  // swallow the pool
+          }
         }
+        plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
+        st.has_bn = o.bn_scale_off >= 0;
+        if (grad && !st.has_bn && o.src != o.dst && o.cout % 4 == 0) {
+          plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
+          st.has_bwd = true;
+        }
+        m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
+      } else if (o.kind == OpKind::Pool) {
+        st.src = o.src;
+        st.dst = o.dst;
+        st.pool_mode = o.pool_mode;
+        st.C = d.bufs[o.src].C;
+        m->buf_cp[o.dst] = round_up(d.bufs[o.dst].C, 4);
+      } else if (o.kind == OpKind::GMax) {
+        st.src = o.src;
+        st.dst = o.dst;
+        st.C = d.bufs[o.src].C;
+        m->buf_cp[o.dst] = d.bufs[o.dst].C;
+      } else {
+        st.src = o.src;
+        st.w_off = o.w_off;
+        st.b_off = o.b_off;
+        st.n_in = o.n_in;
+        MIG_CHECK(m->buf_cp[o.src] == d.bufs[o.src].C, 2, "fc input buffer must not be channel padded");
+        MIG_CHECK(o.n_in % 4 == 0, 2, "fc input size must be a multiple of 4");
       }
-      plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
-      m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
-    } else if (o.kind == OpKind::Pool) {
-      st.src = o.src;
-      st.dst = o.dst;
-      st.pool_mode = o.pool_mode;
-      st.C = d.bufs[o.src].C;
-      m->buf_cp[o.dst] = round_up(d.bufs[o.dst].C, 4);
-    } else if (o.kind == OpKind::GMax) {
-      st.src = o.src;
-      st.dst = o.dst;
-      st.C = d.bufs[o.src].C;
-      m->buf_cp[o.dst] = d.bufs[o.dst].C;
-    } else {
-      st.src = o.src;
-      st.w_off = o.w_off;
-      st.b_off = o.b_off;
-      st.n_in = o.n_in;
-      MIG_CHECK(m->buf_cp[o.src] == d.bufs[o.src].C, 2, "fc input buffer must not be channel padded");
-      MIG_CHECK(o.n_in % 4 == 0, 2, "fc input size must be a multiple of 4");
+      out.push_back(st);
     }
-    m->steps.push_back(st);
+    return out;
+  };
+  m->steps = build_steps(false);
+  // gradient program: supported for plain conv/pool stacks (Default2017 / Default2018 families)
+  m->grad_supported = !d.skip_softmax && !d.apply_logistic_loss;
+  if (!m->grad_supported) m->grad_unsupported_reason = "skip_softmax / apply_logistic_loss models";
+  for (const Op &o : d.ops) {
+    if (o.kind == OpKind::GMax || (o.kind == OpKind::Conv && (o.bn_scale_off >= 0 || o.src == o.dst))) {
+      m->grad_supported = false;
+      m->grad_unsupported_reason = "Dense family (BatchNorm / concat / global max pooling)";
+    }
+    if (o.kind == OpKind::Pool && o.pool_mode == 1 && &o != &d.ops[0]) {
+      // a max pool must be fusable into the conv that feeds it
+      bool fed_by_conv = false;
+      for (const Op &c : d.ops)
+        if (c.kind == OpKind::Conv && c.dst == o.src && c.src != c.dst) fed_by_conv = true;
+      if (!fed_by_conv) {
+        m->grad_supported = false;
+        m->grad_unsupported_reason = "stand-alone max pooling layer";
+      }
+    }
   }
+  if (m->grad_supported) m->gsteps = build_steps(true);
   for (const Step &st : m->steps) {
     int s = st.kind == OpKind::Conv ? st.conv.src : st.src;
     MIG_CHECK(s >= 0 && m->buf_cp[s] > 0, 2, "layer program reads a buffer nothing produced");
@@ -257,6 +324,9 @@ struct Scorer {
   DevBuf<AtomRec> d_cand;
   // activations: one set of buffers sized for `chunk` poses, shared by all models (max size per id)
   std::vector<std::unique_ptr<DevBuf<float>>> act;
+  std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
+  std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
+  DevBuf<float> d_raw3, d_lig_grad;
   // outputs per model [n_models][B] and reduced
   DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var;
   int last_B = 0;
@@ -328,6 +398,20 @@ static float *act_buf(Scorer &s, size_t id, size_t floats) {
   if (!s.act[id]) s.act[id].reset(new DevBuf<float>());
   s.act[id]->ensure(floats);
   return s.act[id]->p;
+}
+
+static float *gact_buf(Scorer &s, size_t id, size_t floats) {
+  if (s.gact.size() <= id) s.gact.resize(id + 1);
+  if (!s.gact[id]) s.gact[id].reset(new DevBuf<float>());
+  s.gact[id]->ensure(floats);
+  return s.gact[id]->p;
+}
+
+static unsigned char *argm_buf(Scorer &s, size_t id, size_t n) {
+  if (s.argm.size() <= id) s.argm.resize(id + 1);
+  if (!s.argm[id]) s.argm[id].reset(new DevBuf<unsigned char>());
+  s.argm[id]->ensure(n);
+  return s.argm[id]->p;
 }
 
 static void build_groups(Scorer &s) {
@@ -436,7 +520,8 @@ static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_sm
 
 // gather + voxelize poses [b0, b0+nb) of the batch for one group. mode: 0 full grid, 1/2 pooled.
 static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, const float *d_lig_xyz, int L,
-                           const float *d_centers_in, unsigned flags, int b0, int nb, int mode, float *out) {
+                           const float *d_centers_in, unsigned flags, int b0, int nb, int mode, float *out,
+                           unsigned char *argmax_out = nullptr) {
   Model *m = s.models[g.first_model];
   TypedReceptor &tr = *s.receptors[g.rec_idx];
   const int cap = tr.n + ls.n_lig + 1;
@@ -482,6 +567,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   va.qb = m->qb;
   va.qc = m->qc;
   va.out = out;
+  va.argmax_out = argmax_out;
   {
     // algorithmic bytes: the un-fused figure C*N^3*4 written once per pose
     ProfScope ps(s, mode == 0 ? "voxelize_tiles<full>" : "voxelize_tiles<pooled>", 0.0,
@@ -493,15 +579,21 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
 
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
 // act[input_dst]; writes pose/aff/loss at out offsets.
-static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss) {
+static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false) {
   Model *m = s.models[mi];
+  const std::vector<Step> &steps = grad ? m->gsteps : m->steps;
+  auto arg_ptr = [&](int id) -> unsigned char * {
+    const BufDecl &bd = m->d.bufs[id];
+    const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
+    return argm_buf(s, slot, (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id]);
+  };
   auto buf_ptr = [&](int id) -> float * {
     const BufDecl &bd = m->d.bufs[id];
     // the pooled voxel grid lives in a dedicated slot shared by all models of a voxelization group
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
     return act_buf(s, slot, (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id]);
   };
-  for (const Step &st : m->steps) {
+  for (const Step &st : steps) {
     switch (st.kind) {
       case OpKind::Conv: {
         ConvArgs a = st.conv.a;
@@ -509,6 +601,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.in_cs = m->buf_cp[st.conv.src];
         a.out = buf_ptr(st.conv.dst);
         a.out_cs = m->buf_cp[st.conv.dst];
+        if (grad && a.pool == 1) a.argmax_out = arg_ptr(st.conv.dst);
         {
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
@@ -532,12 +625,154 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
       case OpKind::Fc: {
         ProfScope ps(s, "fc_heads", 2.0 * nb * 3.0 * st.n_in, (double)nb * st.n_in * 4.0, nb);
         launch_fc_heads(buf_ptr(st.src), m->dev_data.p + st.w_off, m->dev_data.p + st.b_off, st.n_in,
-                        m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss, nullptr, nb, s.stream);
+                        m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss,
+                        grad ? (s.d_raw3.ensure((size_t)3 * s.chunk), s.d_raw3.p) : nullptr, nb, s.stream);
         break;
       }
     }
   }
   MIG_HIP(hipGetLastError());
+}
+
+// Gradient of the loss w.r.t. the pooled voxel grid for `nb` poses whose forward pass (gradient
+// program) has just run: fc backward -> transposed convs (max-unpool / ReLU mask applied while
+// staging) -> avg un-pool.  Returns the device pointer of dL/d(pooled grid).
+static float *run_backward(Scorer &s, int mi, int nb) {
+  Model *m = s.models[mi];
+  auto slot_of = [&](int id) { return id == m->input_dst ? kPooledSlot : (size_t)id; };
+  auto count_of = [&](int id) {
+    const BufDecl &bd = m->d.bufs[id];
+    return (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id];
+  };
+  auto act_ptr = [&](int id) { return act_buf(s, slot_of(id), count_of(id)); };
+  auto g_ptr = [&](int id) { return gact_buf(s, slot_of(id), count_of(id)); };
+  for (int i = (int)m->gsteps.size() - 1; i >= 0; i--) {
+    const Step &st = m->gsteps[i];
+    switch (st.kind) {
+      case OpKind::Fc: {
+        ProfScope ps(s, "fc_backward", 2.0 * nb * 2.0 * st.n_in, 0.0, nb);
+        launch_fc_backward(s.d_raw3.p, m->dev_data.p + st.w_off, st.n_in, g_ptr(st.src), nb, s.stream);
+        break;
+      }
+      case OpKind::Conv: {
+        MIG_CHECK(st.has_bwd, 1, "gradient not supported for this layer");
+        ConvArgs a = st.bwd.a;
+        const int dst = st.conv.dst, src = st.conv.src;
+        a.in = g_ptr(dst);
+        a.in_cs = m->buf_cp[dst];
+        a.in_act = act_ptr(dst);
+        a.in_act_cs = m->buf_cp[dst];
+        if (st.conv.a.pool == 1) {
+          a.in_mode = 2;
+          a.in_argmax = argm_buf(s, slot_of(dst), count_of(dst));
+        } else {
+          a.in_mode = st.conv.a.relu ? 1 : 0;
+        }
+        a.out = g_ptr(src);
+        a.out_cs = m->buf_cp[src];
+        char nm[96];
+        snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d", a.ksize, a.S, st.conv.a.cout, st.conv.cin);
+        const double S3 = (double)a.S * a.S * a.S;
+        ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * st.conv.cin * st.conv.a.cout, 0.0, nb);
+        launch_conv(a, st.bwd.cfg, nb, s.stream);
+        break;
+      }
+      case OpKind::Pool: {
+        MIG_CHECK(st.pool_mode == 2, 1, "gradient of a stand-alone max pool is not supported");
+        ProfScope ps(s, "unpool_avg", 0.0, 0.0, nb);
+        launch_unpool_avg(g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.dst], m->buf_cp[st.src],
+                          m->d.bufs[st.src].S, s.stream);
+        break;
+      }
+      default:
+        throw Error(1, "gradient not supported for this model family");
+    }
+  }
+  MIG_HIP(hipGetLastError());
+  return g_ptr(m->input_dst);
+}
+
+// CNNTorchScorer::score(m, compute_gradient = true, ...) (cnn_torch_scorer.cpp:105-198): forward,
+// loss.backward() and GridMaker::backward (torch_model.cpp:197-221) for B poses; ligand-atom
+// gradients are averaged over the ensemble like m.scale_minus_forces(1 / cnt).
+static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                             const float *centers, float *pose, float *aff, float *loss, float *var,
+                             float *lig_grad, unsigned flags) {
+  MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
+  MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
+  MIG_CHECK(pose && aff && loss && lig_grad, 1, "output arrays must not be NULL");
+  MIG_CHECK(!(flags & (MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE)), 1, "score_grad takes host pointers");
+  for (Model *m : s.models)
+    MIG_CHECK(m->grad_supported, 1, "gradient not supported for model " + m->d.name + ": " + m->grad_unsupported_reason);
+  if (B == 0) return;
+  const int nm = (int)s.models.size();
+  s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
+  const float *d_lig = s.d_lig.p, *d_cen = nullptr;
+  if (centers) {
+    s.d_centers_in.upload(centers, (size_t)B * 3, s.stream);
+    d_cen = s.d_centers_in.p;
+  }
+  s.d_centers.ensure((size_t)B * 3);
+  s.d_pose_m.ensure((size_t)nm * B);
+  s.d_aff_m.ensure((size_t)nm * B);
+  s.d_loss_m.ensure((size_t)nm * B);
+  s.d_lig_grad.ensure((size_t)B * L * 3);
+  MIG_HIP(hipMemsetAsync(s.d_lig_grad.p, 0, (size_t)B * L * 3 * sizeof(float), s.stream));
+  for (const VoxGroup &g : s.groups) {
+    Model *m0 = s.models[g.first_model];
+    LigSetup ls = setup_ligand(s, g, lig_smt, L);
+    const BufDecl &ib = m0->d.bufs[m0->input_dst];
+    const size_t pooled_n = (size_t)s.chunk * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
+    for (int b0 = 0; b0 < B; b0 += s.chunk) {
+      const int nb = std::min(s.chunk, B - b0);
+      float *pooled = act_buf(s, kPooledSlot, pooled_n);
+      unsigned char *am0 = m0->input_pool == 1 ? argm_buf(s, kPooledSlot, pooled_n) : nullptr;
+      voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, am0);
+      for (int mi : g.models) {
+        Model *m = s.models[mi];
+        run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
+                    s.d_loss_m.p + (size_t)mi * B + b0, true);
+        float *g0 = run_backward(s, mi, nb);
+        VoxBackArgs vb{};
+        vb.lig_xyz = d_lig + (size_t)b0 * L * 3;
+        vb.L = L;
+        vb.lig_perm = s.d_lig_perm.p;
+        vb.lig_consts = s.d_lig_consts.p;
+        vb.lig_chan = s.d_lig_chan.p;
+        vb.n_lig = ls.n_lig;
+        vb.centers = s.d_centers.p + (size_t)b0 * 3;
+        vb.grad_pooled = g0;
+        vb.argmax = am0;
+        vb.N = m->N;
+        vb.Cp = m->Cp;
+        vb.res = m->d.resolution;
+        vb.half_dim = m->d.dimension / 2.0f;
+        vb.qa = m->qa;
+        vb.qb = m->qb;
+        vb.lig_grad = s.d_lig_grad.p + (size_t)b0 * L * 3;
+        vb.scale = 1.0f / (float)nm;
+        vb.accumulate = 1;
+        {
+          ProfScope ps(s, "voxel_backward", 0.0, 0.0, nb);
+          launch_voxel_backward(vb, nb, m->input_pool, s.stream);
+        }
+        MIG_HIP(hipGetLastError());
+      }
+    }
+  }
+  s.d_pose.ensure(B);
+  s.d_aff.ensure(B);
+  s.d_loss.ensure(B);
+  s.d_var.ensure(B);
+  launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, s.d_pose.p, s.d_aff.p, s.d_loss.p, s.d_var.p,
+                         s.stream);
+  s.last_B = B;
+  MIG_HIP(hipMemcpyAsync(pose, s.d_pose.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipMemcpyAsync(aff, s.d_aff.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipMemcpyAsync(loss, s.d_loss.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  if (var) MIG_HIP(hipMemcpyAsync(var, s.d_var.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipMemcpyAsync(lig_grad, s.d_lig_grad.p, (size_t)B * L * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipStreamSynchronize(s.stream));
 }
 
 static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
@@ -747,6 +982,21 @@ mi_status mi_scorer_score_batch(mi_scorer *sc, const float *lig_xyz, const int32
   return mi_scorer_score_batch_ex(sc, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, MI_MEM_HOST);
 }
 
+mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                               const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
+                               float *lig_grad) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  score_batch_grad(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var,
+                   lig_grad, MI_MEM_HOST);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+int mi_model_supports_gradient(const mi_model *m) {
+  return m && reinterpret_cast<const Model *>(m)->grad_supported ? 1 : 0;
+}
+
 mi_status mi_scorer_last_model_outputs(mi_scorer *sc, int m, float *pose, float *affinity, float *loss, int B) {
   MI_TRY
   MIG_CHECK(sc, 1, "NULL scorer");
@@ -852,6 +1102,8 @@ mi_status mi_scorer_set_chunk(mi_scorer *sc, int poses_per_chunk) {
   MIG_HIP(hipStreamSynchronize(s.stream));
   s.chunk = poses_per_chunk;
   s.act.clear();
+  s.gact.clear();
+  s.argm.clear();
   return MI_OK;
   MI_CATCH_STATUS
 }

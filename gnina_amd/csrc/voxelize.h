@@ -50,11 +50,30 @@ struct VoxArgs {
   float res, half_dim;
   float qa, qb, qc;      // quadratic tail coefficients (4 e^-2, -12 e^-2, 9 e^-2)
   float *out;
+  unsigned char *argmax_out;  // pooled max mode: arg-max voxel (x*4+y*2+z) per (cell, channel), or nullptr
+};
+
+struct VoxBackArgs {
+  const float *lig_xyz;  // [B][L][3]
+  int L;
+  const int *lig_perm;   // typed ligand atoms (sorted by channel)
+  const LigConsts *lig_consts;
+  const int *lig_chan;
+  int n_lig;
+  const float *centers;  // [B][3]
+  const float *grad_pooled;     // [B][N/2]^3[Cp] gradient w.r.t. the pooled grid
+  const unsigned char *argmax;  // [B][N/2]^3[Cp] (max pooling) or nullptr
+  int N, Cp;
+  float res, half_dim, qa, qb;
+  float *lig_grad;  // [B][L][3]
+  float scale;      // e.g. 1 / n_models
+  int accumulate;   // add into lig_grad instead of overwriting
 };
 
 void launch_gather(const GatherArgs &g, int B, hipStream_t s);
 // mode 0: full grid [B][C][N][N][N] (out must be pre-zeroed); 1: max-pooled; 2: avg-pooled
 // ([B][N/2]^3[Cp], fully written).
 void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s);
+void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream_t s);
 
 }  // namespace mig

@@ -161,10 +161,13 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   const int tz = blockIdx.x % ntile, ty = (blockIdx.x / ntile) % ntile, tx = blockIdx.x / (ntile * ntile);
   const int cx = tx * 4 + (lane >> 4), cy = ty * 4 + ((lane >> 2) & 3), cz = tz * 4 + (lane & 3);
 
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // MODE != 0: [64][Cp]
+  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // MODE != 0: [64][Cp] (+ arg-max bytes)
   const int Cp = v.Cp;
+  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_stage + 64 * Cp);  // [64][Cp], only if argmax_out
   if (MODE != 0) {
     for (int i = lane; i < 64 * Cp; i += 64) s_stage[i] = 0.f;
+    if (MODE == 1 && v.argmax_out)
+      for (int i = lane; i < 16 * Cp; i += 64) reinterpret_cast<unsigned *>(s_arg)[i] = 0u;
   }
 
   const float ctrx = v.centers[3 * b + 0], ctry = v.centers[3 * b + 1], ctrz = v.centers[3 * b + 2];
@@ -206,9 +209,15 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
           }
     } else if (MODE == 1) {
       float m = acc[0];
+      int am = 0;
 #pragma unroll
-      for (int i = 1; i < 8; i++) m = fmaxf(m, acc[i]);
+      for (int i = 1; i < 8; i++)
+        if (acc[i] > m) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
+          m = acc[i];
+          am = i;
+        }
       s_stage[lane * Cp + c] = m;
+      if (v.argmax_out) s_arg[lane * Cp + c] = (unsigned char)am;
     } else {
       float s = acc[0];
 #pragma unroll
@@ -286,9 +295,101 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
         float4 val = *reinterpret_cast<const float4 *>(&s_stage[(row * 4) * Cp + 4 * w]);
         float *dst = v.out + ((((size_t)b * S + rx) * S + ry) * S + rz0) * Cp + 4 * w;
         *reinterpret_cast<float4 *>(dst) = val;
+        if (MODE == 1 && v.argmax_out) {
+          const unsigned word = *reinterpret_cast<const unsigned *>(&s_arg[(row * 4) * Cp + 4 * w]);
+          unsigned char *ad = v.argmax_out + ((((size_t)b * S + rx) * S + ry) * S + rz0) * Cp + 4 * w;
+          *reinterpret_cast<unsigned *>(ad) = word;
+        }
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// voxel_backward: GridMaker::backward (called torch_model.cpp:203; semantics SURVEY App. A.4) fused
+// with the backward of the network's first 2x2x2 pooling layer.  One wavefront per (pose, typed
+// ligand atom): lanes sweep the atom's bounding cube of fine voxels; the gradient of a fine voxel is
+// recovered from the pooled-grid gradient (max: only the arg-max voxel of a cell; avg: 1/8 of it).
+//   dL/dx_a = sum_v g[c][v] * rho'(d) * (x_a - p_v) / d
+//   rho'(d) = -4 d / r^2 exp(-2 d^2 / r^2)  (d <= r);  (2 A d/r + B) / r  (r < d < 1.5 r);  0 otherwise
+// ---------------------------------------------------------------------------------------------
+template <int POOL>  // 1 max, 2 avg
+__global__ __launch_bounds__(64) void voxel_backward_kernel(VoxBackArgs a) {
+  const int b = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+  const int src = a.lig_perm[j];
+  const LigConsts lc = a.lig_consts[j];
+  const int c = a.lig_chan[j];
+  const float ax = a.lig_xyz[((size_t)b * a.L + src) * 3], ay = a.lig_xyz[((size_t)b * a.L + src) * 3 + 1],
+              az = a.lig_xyz[((size_t)b * a.L + src) * 3 + 2];
+  const float ox = a.centers[3 * b] - a.half_dim, oy = a.centers[3 * b + 1] - a.half_dim,
+              oz = a.centers[3 * b + 2] - a.half_dim;
+  const float maxr = lc.ar * 1.5f;
+  const int N = a.N, S = N / 2, Cp = a.Cp;
+  const int i0 = max(0, (int)floorf((ax - maxr - ox) / a.res)), i1 = min(2 * S - 1, (int)ceilf((ax + maxr - ox) / a.res));
+  const int j0 = max(0, (int)floorf((ay - maxr - oy) / a.res)), j1 = min(2 * S - 1, (int)ceilf((ay + maxr - oy) / a.res));
+  const int k0 = max(0, (int)floorf((az - maxr - oz) / a.res)), k1 = min(2 * S - 1, (int)ceilf((az + maxr - oz) / a.res));
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (i1 >= i0 && j1 >= j0 && k1 >= k0) {
+    const int ni = i1 - i0 + 1, nj = j1 - j0 + 1, nk = k1 - k0 + 1;
+    const int total = ni * nj * nk;
+    const float *G = a.grad_pooled + (size_t)b * S * S * S * Cp;
+    const unsigned char *AM = POOL == 1 ? a.argmax + (size_t)b * S * S * S * Cp : nullptr;
+    const float inv_ar2 = 1.0f / (lc.ar * lc.ar);
+    for (int t = lane; t < total; t += 64) {
+      const int k = k0 + t % nk, jj = j0 + (t / nk) % nj, i = i0 + t / (nk * nj);
+      const size_t cell = (((size_t)(i >> 1) * S + (jj >> 1)) * S + (k >> 1)) * Cp + c;
+      float g = G[cell];
+      if (POOL == 1) {
+        const int r = ((i & 1) << 2) | ((jj & 1) << 1) | (k & 1);
+        if (AM[cell] != r) g = 0.f;
+      } else {
+        g *= 0.125f;
+      }
+      if (g == 0.f) continue;
+      const float px = ox + (float)i * a.res, py = oy + (float)jj * a.res, pz = oz + (float)k * a.res;
+      const float dx = ax - px, dy = ay - py, dz = az - pz;
+      const float rsq = (dx * dx + dy * dy) + dz * dz;
+      if (!(rsq < lc.t2) || rsq == 0.f) continue;
+      const float dist = sqrtf(rsq);
+      float d;
+      if (rsq <= lc.g2)
+        d = (-4.0f * dist * inv_ar2) * __expf(-2.0f * rsq * inv_ar2);
+      else
+        d = (2.0f * a.qa * (dist * lc.inv_ar) + a.qb) * lc.inv_ar;
+      const float gv = g * d / dist;
+      gx += gv * dx;
+      gy += gv * dy;
+      gz += gv * dz;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    gx += __shfl_xor(gx, off);
+    gy += __shfl_xor(gy, off);
+    gz += __shfl_xor(gz, off);
+  }
+  if (lane == 0) {
+    float *o = a.lig_grad + ((size_t)b * a.L + src) * 3;
+    if (a.accumulate) {
+      o[0] += gx * a.scale;
+      o[1] += gy * a.scale;
+      o[2] += gz * a.scale;
+    } else {
+      o[0] = gx * a.scale;
+      o[1] = gy * a.scale;
+      o[2] = gz * a.scale;
+    }
+  }
+}
+
+void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream_t s) {
+  if (a.n_lig == 0) return;
+  dim3 grid(a.n_lig, B), block(64);
+  if (pool_mode == 1)
+    hipLaunchKernelGGL(voxel_backward_kernel<1>, grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL(voxel_backward_kernel<2>, grid, block, 0, s, a);
 }
 
 void launch_gather(const GatherArgs &g, int B, hipStream_t s) {
@@ -301,7 +402,7 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
-    size_t lds = (size_t)64 * v.Cp * sizeof(float);
+    size_t lds = (size_t)64 * v.Cp * sizeof(float) + (v.argmax_out ? (size_t)64 * v.Cp : 0);
     if (mode == 1)
       hipLaunchKernelGGL(voxelize_tiles<1>, grid, block, lds, s, v);
     else

@@ -100,6 +100,17 @@ mi_status mi_scorer_score_batch(mi_scorer *, const float *lig_xyz, const int32_t
 mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                    const float *centers, float *pose, float *affinity, float *loss,
                                    float *aff_var, unsigned flags);
+/* CNNTorchScorer::score(model&, compute_gradient = true, ...) for B poses: forward, loss.backward()
+ * through the network and GridMaker::backward (torch_model.cpp:197-221; cnn_torch_scorer.cpp:164-175).
+ * lig_grad [B][L][3] = d loss / d x for every ligand row (0 for untyped rows such as hydrogens), mean
+ * over the ensemble -- what getGradient + add_minus_forces + scale_minus_forces(1/cnt) leave in
+ * model::minus_forces.  Host pointers.  Supported for the Default2017 / Default2018 families
+ * (mi_model_supports_gradient); the Dense family returns MI_ERR_INVALID. */
+mi_status mi_scorer_score_grad(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                               const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
+                               float *lig_grad);
+int mi_model_supports_gradient(const mi_model *);
+
 /* Per-model raw outputs of the last mi_scorer_score_batch* call: TorchModel::forward's
  * {pose, affinity, loss} for model `m` (host arrays [B]); used by the parity tests. */
 mi_status mi_scorer_last_model_outputs(mi_scorer *, int m, float *pose, float *affinity, float *loss, int B);

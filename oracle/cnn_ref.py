@@ -123,3 +123,14 @@ def scores(blob, grid, dtype=torch.float32):
     else:
         loss = F.cross_entropy(logp, torch.ones(logp.shape[0], dtype=torch.long), reduction="none")
     return pose, aff, loss
+
+
+def loss_and_grid_gradient(blob, grid, dtype=torch.float32):
+    """What TorchModel::forward does with compute_gradient (torch_model.cpp:192-199): loss =
+    cross_entropy(log_softmax(z), 1); loss.backward(); returns (loss [B], d loss / d grid [B,C,N,N,N])."""
+    x = torch.as_tensor(grid).to(dtype).clone().requires_grad_(True)
+    logits, _ = forward_logits(blob, x, dtype)
+    logp = torch.log_softmax(logits, 1)
+    loss = F.cross_entropy(logp, torch.ones(logp.shape[0], dtype=torch.long), reduction="none")
+    loss.sum().backward()
+    return loss.detach(), x.grad.detach()

@@ -1,0 +1,97 @@
+"""Rows a9/a10: the gradient path (refinement).  HIP: mi_scorer_score_grad = forward + transposed
+convolutions + fused un-pooling + GridMaker::backward.  Oracle: autograd through oracle/cnn_ref.py on
+the oracle grid (what loss.backward() does in torch_model.cpp:197-199), then ora_grid_backward
+(SURVEY App. A.4).  The oracle itself is checked against finite differences of its own loss."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref, voxel
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHTS = os.path.join(ROOT, "gnina_amd", "weights")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import capi as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def CG(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+
+
+def oracle_lig_gradient(blob, rec_xyz, rec_smt, pose, lig_smt):
+    rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
+    grid, cen = voxel.voxelize_pose(rec_xyz, rec_smt, pose, lig_smt, rmap, lmap)
+    loss, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None])
+    ch, rad = voxel.type_atoms(lig_smt, lmap[0])
+    ch = np.where(ch >= 0, ch + rmap[1], -1)
+    g = voxel.grid_backward(cen, pose, ch, rad, rmap[1] + lmap[1], gg[0].numpy(), blob.resolution, blob.dimension,
+                            blob.radius_scaling)
+    return float(loss[0]), g
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "crossdock_default2018_KD_4"])
+def test_ligand_gradient_matches_oracle(capi, CG, name):
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    out = s.score_grad(poses, lig_smt)
+    fwd = s.score_batch(poses, lig_smt)
+    assert np.abs(out["pose"] - fwd["pose"]).max() < 1e-6 and np.abs(out["loss"] - fwd["loss"]).max() < 1e-5
+    assert np.abs(out["pose"] - CG[name + "/pose"]).max() < 1e-4
+    for b in range(len(poses)):
+        loss0, g0 = oracle_lig_gradient(blob, rec_xyz, rec_smt, poses[b], lig_smt)
+        scale = max(np.abs(g0).max(), 1e-6)
+        assert abs(out["loss"][b] - loss0) < 1e-3 * max(1.0, abs(loss0))
+        assert np.abs(out["lig_grad"][b] - g0).max() < 2e-3 * scale, (b, np.abs(out["lig_grad"][b] - g0).max(), scale)
+
+
+def test_gradient_with_hydrogens_and_ensemble(capi, CG):
+    names = ["default2017", "crossdock_default2018"]
+    base = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{base}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    lig_smt = lig_smt.copy()
+    lig_smt[[1, 5]] = 1          # polar hydrogens: untyped rows, gradient must be exactly zero
+    s = capi.Scorer(names)
+    s.set_receptor(rec_xyz, rec_smt)
+    out = s.score_grad(poses[:2], lig_smt)
+    assert not out["lig_grad"][:, [1, 5]].any()
+    acc = np.zeros((2, len(lig_smt), 3))
+    for n in names:
+        blob = cnn_ref.Blob(os.path.join(WEIGHTS, n + ".mgw"))
+        for b in range(2):
+            acc[b] += oracle_lig_gradient(blob, rec_xyz, rec_smt, poses[b], lig_smt)[1] / len(names)
+    assert np.abs(out["lig_grad"] - acc).max() < 2e-3 * np.abs(acc).max()
+
+
+def test_gradient_descends_the_loss(capi, CG):
+    """A small step against the gradient must lower the CNN loss (what refinement relies on,
+    test/gnina/test_cnn.py:56-59)."""
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    out = s.score_grad(poses, lig_smt)
+    g = out["lig_grad"]
+    step = 0.02 / max(np.abs(g).max(), 1e-9)
+    out2 = s.score_batch(poses - step * g, lig_smt)
+    assert (out2["loss"] < out["loss"] + 1e-7).all() and (out2["loss"] < out["loss"]).any()
+
+
+def test_dense_family_reports_unsupported(capi, CG):
+    name = "dense"
+    s = capi.Scorer([name])
+    s.set_receptor(CG[name + "/rec_xyz"], CG[name + "/rec_smt"])
+    with pytest.raises(capi.MiGninaError) as ei:
+        s.score_grad(CG[name + "/poses"][:1], CG[name + "/lig_smt"])
+    assert "Dense" in str(ei.value)

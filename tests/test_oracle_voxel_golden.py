@@ -135,3 +135,36 @@ def test_backward_matches_finite_difference():
             fp = (V.grid_forward(cen, p, chan, rad, 2, 0.5, 12.0).astype(np.float64) * w).sum()
             fm = (V.grid_forward(cen, m, chan, rad, 2, 0.5, 12.0).astype(np.float64) * w).sum()
             assert abs((fp - fm) / (2 * h) - ana[a, d]) < 2e-2 * max(1.0, abs(ana[a, d]))
+
+
+def test_end_to_end_loss_gradient_matches_finite_differences():
+    """Oracle self-check for the gradient rows: d loss / d ligand coordinate (autograd through the CNN
+    oracle + ora_grid_backward) against central differences of the oracle's own loss."""
+    import os
+    import torch
+    from oracle import cnn_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = cnn_ref.Blob(os.path.join(root, "gnina_amd", "weights", "default2017.mgw"))
+    G = np.load(os.path.join(root, "tests", "golden", "cnn_goldens.npz"))
+    rec_xyz, rec_smt, lig_smt, pose = (G["default2017/" + k] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    pose = pose[1]
+    rmap, lmap = V.typer_parse(blob.recmap_text()), V.typer_parse(blob.ligmap_text())
+    cen = V.center(pose)
+
+    def loss_of(p):
+        grid, _ = V.voxelize_pose(rec_xyz, rec_smt, p, lig_smt, rmap, lmap, cen)   # fixed centre
+        with torch.no_grad():
+            return float(cnn_ref.scores(blob, grid[None], torch.float64)[2][0])
+
+    grid, _ = V.voxelize_pose(rec_xyz, rec_smt, pose, lig_smt, rmap, lmap, cen)
+    _, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None], torch.float64)
+    ch, rad = V.type_atoms(lig_smt, lmap[0])
+    ch = np.where(ch >= 0, ch + rmap[1], -1)
+    g = V.grid_backward(cen, pose, ch, rad, rmap[1] + lmap[1], gg[0].numpy().astype(np.float32))
+    scale = np.abs(g).max()
+    for a, d in ((0, 0), (3, 1), (7, 2), (12, 0)):
+        p, m = pose.copy(), pose.copy()
+        p[a, d] += 1e-2
+        m[a, d] -= 1e-2
+        fd = (loss_of(p) - loss_of(m)) / 2e-2
+        assert abs(fd - g[a, d]) < 0.05 * scale + 1e-4, (a, d, fd, g[a, d])
