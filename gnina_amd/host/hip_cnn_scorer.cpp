@@ -219,14 +219,39 @@ void HipCNNScorer::score_poses(model &m, const std::vector<float> &lig_xyz, int 
 
 float HipCNNScorer::score(model &m, bool compute_gradient, float &affinity, float &loss, float &variance) {
   if (!initialized()) return -1.0;  // cnn_torch_scorer.cpp:107-108
-  if (compute_gradient) throw internal_error("compute_gradient not supported by the HIP engine yet");
   if (cnnopts.cnn_rotations > 0) throw internal_error("cnn_rotations not supported by the HIP engine yet");
   setLigand(m);
   m.clear_minus_forces();  // "ALERT: clears minus forces" (cnn_torch_scorer.cpp:115)
   std::vector<float> xyz(ligand_coords.size() * 3);
   std::memcpy(xyz.data(), ligand_coords.data(), xyz.size() * sizeof(float));
   std::vector<float> p, a, l, v;
-  score_poses(m, xyz, 1, p, a, l, v);
+  if (!compute_gradient) {
+    score_poses(m, xyz, 1, p, a, l, v);
+  } else {
+    // forward + loss.backward() + GridMaker::backward on the device (torch_model.cpp:197-221); the
+    // ensemble mean of the atom gradients is what add_minus_forces + scale_minus_forces(1/cnt) produce
+    setReceptor(m);
+    if (!receptor_uploaded) {
+      std::vector<int32_t> t(receptor_smtypes.begin(), receptor_smtypes.end());
+      if (mi_scorer_set_receptor(ensemble.get(), &receptor_coords[0].x, t.data(), (int)t.size()) != MI_OK)
+        throw internal_error(mi_last_error());
+      receptor_uploaded = true;
+    }
+    const int L = (int)ligand_smtypes.size();
+    std::vector<int32_t> lt(ligand_smtypes.begin(), ligand_smtypes.end());
+    float c[3] = {cnnopts.cnn_center[0], cnnopts.cnn_center[1], cnnopts.cnn_center[2]};
+    p.resize(1), a.resize(1), l.resize(1), v.resize(1);
+    std::vector<float> lg((size_t)L * 3);
+    if (mi_scorer_score_grad(ensemble.get(), xyz.data(), lt.data(), 1, L, std::isnan(c[0]) ? nullptr : c, p.data(),
+                             a.data(), l.data(), v.data(), lg.data()) != MI_OK)
+      throw internal_error(mi_last_error());
+    // getGradient (cnn_torch_scorer.cpp:208-228): scatter by movable-atom index, then the model adds
+    // them to minus_forces (flexible-receptor gradients are not produced by the engine yet)
+    std::vector<gfloat3> gradient(receptor_map.size() + ligand_map.size(), gfloat3{0, 0, 0});
+    if (gradient.size() < (size_t)m.m_num_movable_atoms) gradient.resize(m.m_num_movable_atoms, gfloat3{0, 0, 0});
+    for (sz i = 0; i < ligand_map.size(); i++) gradient[ligand_map[i]] = gfloat3{lg[3 * i], lg[3 * i + 1], lg[3 * i + 2]};
+    m.add_minus_forces(gradient);
+  }
   affinity = a[0];
   loss = l[0];
   variance = v[0];

@@ -5,6 +5,7 @@
 //
 // input file (little endian): int32 n_rec, n_lig, n_poses, n_models; n_models x (int32 len, chars);
 //   float rec_xyz[n_rec][3]; int32 rec_smt[n_rec]; int32 lig_smt[n_lig]; float poses[n_poses][n_lig][3]
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -89,6 +90,19 @@ int main(int argc, char **argv) {
     float var2;
     float s2 = copy->score(m, var2);   // a fresh copy must give identical numbers
     std::printf("single %d %.9g %.9g %.9g %.9g copy %.9g\n", b, s, aff, loss, var, s2);
+  }
+  {  // compute_gradient = true (refinement): minus_forces receive d loss / d x of the heavy ligand atoms
+    for (int i = 0; i < n_lig; i++)
+      m.coords[i] = vec(poses[(size_t)i * 3], poses[(size_t)i * 3 + 1], poses[(size_t)i * 3 + 2]);
+    float aff, loss, var;
+    try {
+      float s = scorer.score(m, true, aff, loss, var);
+      double nrm = 0;
+      for (auto &f : m.minus_forces) nrm += f[0] * f[0] + f[1] * f[1] + f[2] * f[2];
+      std::printf("grad %.9g %.9g %.9g\n", s, loss, std::sqrt(nrm));
+    } catch (const internal_error &e) {
+      std::printf("grad_unsupported %s\n", e.what());
+    }
   }
   std::vector<float> p, a, l, v;
   scorer.score_poses(m, poses, n_poses, p, a, l, v);
