@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi_gnina.so")
+LIB_PATH = os.environ.get("MI_GNINA_LIB", os.path.join(_HERE, "lib", "libmi_gnina.so"))
 
 MI_OK = 0
 MI_LIG_ON_DEVICE = 1

@@ -30,6 +30,7 @@ struct ConvArgs {
   const float *in_act;             // mask source; stride in_act_cs
   int in_act_cs;
   unsigned char *argmax_out;       // pool == 1: arg-max index (x*4+y*2+z) per pooled output, or nullptr
+  int sparse;        // skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients)
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;

@@ -28,7 +28,7 @@ namespace mig {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool SPARSE>
 __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   constexpr int NWAVES = WM * WN;
   constexpr int NTHREADS = 64 * NWAVES;
@@ -58,6 +58,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_tile = smem;                                  // [HV][CCs]
   int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);  // [Q]
+  int *s_jq = s_qoff + Q;                                // [Q] compacted list of the non-zero quads of a chunk
+  int *s_flag = s_jq + Q;                                // [nchunks][CC4] "this channel quad is non-zero in the tile"
+
+  for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = 0;
 
   for (int q = tid; q < Q; q += NTHREADS) {
     int tap = q / CC4, c4 = q - tap * CC4;
@@ -137,30 +141,90 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
         }
       }
       *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
+      if (SPARSE && (val.x != 0.f || val.y != 0.f || val.z != 0.f || val.w != 0.f)) s_flag[chunk * CC4 + c4] = 1;
     }
     __syncthreads();
 
-    // ---- K loop over quad pairs of this chunk ----
-    const float *wchunk = wq + (size_t)chunk * P * 2 * wstride + (size_t)kh * wstride;
-    for (int pr = 0; pr < P; pr++) {
-      int q = 2 * pr + kh;
-      q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
-      const int qo = s_qoff[q];
-      float4 a[TM], w[TN];
-#pragma unroll
-      for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-#pragma unroll
-      for (int n = 0; n < TN; n++)
-        w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
-#pragma unroll
-      for (int m = 0; m < TM; m++)
-#pragma unroll
-        for (int n = 0; n < TN; n++) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
+    // ---- input sparsity (the pooled voxel grid is ~12 % dense, SURVEY "Hard parts"): channel quads
+    // that are entirely zero inside this halo tile contribute exact zeros, so their 27 taps are
+    // skipped.  The surviving quads keep their original order -> the fp32 sum is bit-identical.
+    int J = Q;
+    if (SPARSE) {
+      int n_act = 0;
+      for (int c = 0; c < CC4; c++) n_act += s_flag[chunk * CC4 + c];
+      if (n_act == 0) continue;
+      J = taps * n_act;
+      if (n_act == CC4) {
+        for (int j = tid; j < J; j += NTHREADS) s_jq[j] = j;
+      } else {
+        for (int j = tid; j < J; j += NTHREADS) {
+          const int tap = j / n_act, a = j - tap * n_act;
+          int c4 = 0, seen = -1;
+          for (int c = 0; c < CC4; c++) {
+            seen += s_flag[chunk * CC4 + c];
+            if (seen == a) {
+              c4 = c;
+              break;
+            }
+          }
+          s_jq[j] = tap * CC4 + c4;
         }
+      }
+      __syncthreads();
+    }
+
+    if (!SPARSE) {
+      // ---- dense K loop over quad pairs of this chunk (affine addressing: the weight loads of the
+      // next pairs can be issued ahead of the MFMAs) ----
+      const float *wchunk = wq + (size_t)chunk * P * 2 * wstride + (size_t)kh * wstride;
+      for (int pr = 0; pr < P; pr++) {
+        int q = 2 * pr + kh;
+        q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
+        const int qo = s_qoff[q];
+        float4 a[TM], w[TN];
+#pragma unroll
+        for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+#pragma unroll
+        for (int n = 0; n < TN; n++)
+          w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
+#pragma unroll
+        for (int m = 0; m < TM; m++)
+#pragma unroll
+          for (int n = 0; n < TN; n++) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
+    } else {
+      // ---- K loop over pairs of surviving quads (compacted list) ----
+      const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
+      const int PJ = (J + 1) >> 1;
+      for (int pr = 0; pr < PJ; pr++) {
+        const int j = 2 * pr + kh;
+        const bool live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
+        const int q = s_jq[live ? j : J - 1];
+        const int qo = s_qoff[q];
+        float4 a[TM], w[TN];
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+          if (!live) a[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; n++)
+          w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)q * wstride + (size_t)n * 32 * 4);
+#pragma unroll
+        for (int m = 0; m < TM; m++)
+#pragma unroll
+          for (int n = 0; n < TN; n++) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
     }
   }
 
@@ -221,20 +285,27 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  return HV * p.ccs * sizeof(float) + (size_t)Q * sizeof(int);
+  return HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4) * sizeof(int);
 }
 
-template <int WM, int WN, int TM, int TN> static void launch_cfg(const ConvArgs &p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool SPARSE> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN>), grid, block, lds, s, p);
+  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE>), grid, block, lds, s, p);
+}
+
+template <int WM, int WN, int TM, int TN> static void launch_cfg(const ConvArgs &p, int B, hipStream_t s) {
+  if (p.sparse)
+    launch_one<WM, WN, TM, TN, true>(p, B, s);
+  else
+    launch_one<WM, WN, TM, TN, false>(p, B, s);
 }
 
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {

@@ -172,6 +172,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.bias = push_dev(m, bias);
   a.bn_scale = a.bn_shift = nullptr;
   a.in_mode = 0;
+  a.sparse = 0;
   a.in_argmax = nullptr;
   a.in_act = nullptr;
   a.in_act_cs = 0;
@@ -602,6 +603,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.out = buf_ptr(st.conv.dst);
         a.out_cs = m->buf_cp[st.conv.dst];
         if (grad && a.pool == 1) a.argmax_out = arg_ptr(st.conv.dst);
+        a.sparse = (st.conv.src == m->input_dst && !st.has_bn) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
         {
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
@@ -663,6 +665,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         a.in_act = act_ptr(dst);
         a.in_act_cs = m->buf_cp[dst];
         if (st.conv.a.pool == 1) {
+          a.sparse = 1;  // un-pooled gradient: at most 1 of 8 voxels per cell is non-zero
           a.in_mode = 2;
           a.in_argmax = argm_buf(s, slot_of(dst), count_of(dst));
         } else {
