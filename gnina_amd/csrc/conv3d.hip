@@ -177,16 +177,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       // ---- dense K loop over quad pairs of this chunk (affine addressing: the weight loads of the
       // next pairs can be issued ahead of the MFMAs) ----
       const float *wchunk = wq + (size_t)chunk * P * 2 * wstride + (size_t)kh * wstride;
+      float4 w[TN], wn[TN];  // weights of the current / next pair: the L2 latency hides behind 4*TM*TN MFMAs
+#pragma unroll
+      for (int n = 0; n < TN; n++) w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)n * 32 * 4);
       for (int pr = 0; pr < P; pr++) {
         int q = 2 * pr + kh;
         q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
         const int qo = s_qoff[q];
-        float4 a[TM], w[TN];
+        float4 a[TM];
 #pragma unroll
         for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+        const int prn = pr + 1 < P ? pr + 1 : pr;
 #pragma unroll
         for (int n = 0; n < TN; n++)
-          w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
+          wn[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)prn * 2 * wstride + (size_t)n * 32 * 4);
 #pragma unroll
         for (int m = 0; m < TM; m++)
 #pragma unroll
@@ -196,6 +200,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
           }
+#pragma unroll
+        for (int n = 0; n < TN; n++) w[n] = wn[n];
       }
     } else {
       // ---- K loop over pairs of surviving quads (compacted list) ----
