@@ -34,6 +34,7 @@ struct ConvArgs {
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;
+  int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
 };
 
 enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_3x2_2x1 = 1, CONV_CFG_1x4_7x1 = 2 };

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
       int x = x0 + hx, y = y0 + hy, z = z0 + hz;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S) {
+      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S &&
+          chunk * CC4 + c4 < p.cin4) {
         const int c = c_base + c4 * 4;
         if (p.in_mode == 2) {
           // transposed conv fed by a max-pooled gradient: un-pool while staging (no full-size tensor in HBM)

@@ -128,16 +128,20 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   if (backward) MIG_CHECK(o.cin % 4 == 0, 2, "backward conv needs the forward Cout to be a multiple of 4");
   const int halo = o.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
-  const size_t budget = 72 * 1024;
+  // K chunking over input-channel quads: the halo tile of one chunk must fit the LDS budget.  Convs that
+  // read the sparse pooled voxel grid get a small budget (more workgroups per CU, finer zero-skipping);
+  // the last chunk may be partial (its missing quads are zero-filled and, on the sparse path, skipped).
+  const size_t budget = (o.src == m.input_dst && !backward && o.bn_scale_off < 0) ? 40 * 1024 : 72 * 1024;
   int best = 1;
   for (int c = 1; c <= cin4; c++) {
-    if (cin4 % c) continue;
+    if (budget == 72 * 1024 && cin4 % c) continue;  // dense layers: equal chunks only (no wasted MFMAs)
     int ccs = 4 * (c | 1);
     if (HV * ccs * 4 + 27 * c * 4 <= budget) best = c;
   }
   a.cc4 = best;
   a.ccs = 4 * (best | 1);  // odd quad stride: consecutive voxels land on different 16-byte LDS slots
-  a.nchunks = cin4 / best;
+  a.nchunks = cdiv(cin4, best);
+  a.cin4 = cin4;
   // pack weights [chunk][pair][2][coutp][4]
   const int taps = o.ksize * o.ksize * o.ksize;
   const int Q = taps * a.cc4, P = (Q + 1) / 2;
