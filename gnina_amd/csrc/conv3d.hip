@@ -205,15 +205,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
         for (int n = 0; n < TN; n++) w[n] = wn[n];
       }
     } else {
-      // ---- K loop over pairs of surviving quads (compacted list) ----
+      // ---- K loop over pairs of surviving quads (compacted list), software pipelined: the list entry,
+      // LDS operand and weight row of pair pr+1 are fetched before the MFMAs of pair pr ----
       const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
       const int PJ = (J + 1) >> 1;
-      for (int pr = 0; pr < PJ; pr++) {
-        const int j = 2 * pr + kh;
-        const bool live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
-        const int q = s_jq[live ? j : J - 1];
+      float4 a[TM], w[TN], an[TM], wn[TN];
+      {
+        const bool live = kh < J;
+        const int q = s_jq[live ? kh : J - 1];
         const int qo = s_qoff[q];
-        float4 a[TM], w[TN];
 #pragma unroll
         for (int m = 0; m < TM; m++) {
           a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
@@ -222,6 +222,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int n = 0; n < TN; n++)
           w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)q * wstride + (size_t)n * 32 * 4);
+      }
+      for (int pr = 0; pr < PJ; pr++) {
+        {
+          const int j = 2 * (pr + 1) + kh;
+          const bool live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
+          const int q = s_jq[live ? j : J - 1];
+          const int qo = s_qoff[q];
+#pragma unroll
+          for (int m = 0; m < TM; m++) {
+            an[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+            if (!live) an[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int n = 0; n < TN; n++)
+            wn[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)q * wstride + (size_t)n * 32 * 4);
+        }
 #pragma unroll
         for (int m = 0; m < TM; m++)
 #pragma unroll
@@ -231,6 +247,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
           }
+#pragma unroll
+        for (int m = 0; m < TM; m++) a[m] = an[m];
+#pragma unroll
+        for (int n = 0; n < TN; n++) w[n] = wn[n];
       }
     }
   }
