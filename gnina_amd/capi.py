@@ -26,6 +26,7 @@ SYMBOLS = [
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
+    "mi_vina_refine_batch", "mi_vina_final_energies",
 ]
 
 _lib = None
@@ -143,6 +144,10 @@ def lib():
         L.mi_vina_mc_batch.restype = C.c_int
         L.mi_vina_ligand_heavy_atoms.argtypes = [vp]
         L.mi_vina_ligand_heavy_atoms.restype = C.c_int
+        L.mi_vina_refine_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp]
+        L.mi_vina_refine_batch.restype = C.c_int
+        L.mi_vina_final_energies.argtypes = [vp, vp, C.c_int, vp, C.c_float, vp, vp]
+        L.mi_vina_final_energies.restype = C.c_int
         L.mi_vina_stream.argtypes = [vp]
         L.mi_vina_stream.restype = vp
         _lib = L
@@ -346,14 +351,36 @@ class Vina:
         check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
         self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
 
-    def eval_batch(self, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False, grid_only=False):
+    def refine_batch(self, confs, v=(1000.0, 1000.0, 1000.0), max_iters=None):
+        """refine_structure: BFGS on the direct receptor term with the slope ladder -> (e, confs, tries)"""
+        confs = np.array(_f32(confs).reshape(-1, 7 + self.n_tors), copy=True)
+        B = len(confs)
+        if max_iters is None:
+            max_iters = (25 + self.n_atoms) // 3
+        vv = _f32(v)
+        e = np.empty(B, dtype=np.float32)
+        tries = np.empty(B, dtype=np.int32)
+        check(lib().mi_vina_refine_batch(self.handle, _ptr(confs), B, _ptr(vv), int(max_iters), _ptr(e), _ptr(tries)))
+        return e, confs, tries
+
+    def final_energies(self, confs, num_tors, v=(1000.0, 1000.0, 1000.0)):
+        confs = _f32(confs).reshape(-1, 7 + self.n_tors)
+        B = len(confs)
+        vv = _f32(v)
+        e, intra = np.empty(B, dtype=np.float32), np.empty(B, dtype=np.float32)
+        check(lib().mi_vina_final_energies(self.handle, _ptr(confs), B, _ptr(vv), float(num_tors), _ptr(e), _ptr(intra)))
+        return e, intra
+
+    def eval_batch(self, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False, grid_only=False,
+                   direct=False, exact=False, pairs_only=False):
         confs = _f32(confs).reshape(-1, 7 + self.n_tors)
         B = len(confs)
         vv = _f32(v)
         e = np.empty(B, dtype=np.float32)
-        ch = np.empty((B, 6 + self.n_tors), dtype=np.float32) if deriv else None
+        ch = np.empty((B, 6 + self.n_tors), dtype=np.float32) if (deriv and not grid_only and not pairs_only) else None
         co = np.empty((B, self.n_atoms, 3), dtype=np.float32) if want_coords else None
-        mode = 2 if grid_only else int(deriv)   # 1 model::eval_deriv, 0 model::eval, 2 cache::eval
+        mode = 4 if pairs_only else (2 if grid_only else int(deriv))   # 1 eval_deriv, 0 eval, 2 receptor only, 4 pairs only
+        mode |= (16 if direct else 0) | (32 if exact else 0)
         check(lib().mi_vina_eval_batch(self.handle, _ptr(confs), B, _ptr(vv), mode, _ptr(e), _ptr(ch), _ptr(co)))
         return e, ch, co
 

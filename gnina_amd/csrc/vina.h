@@ -29,6 +29,13 @@ struct VinaEnv {
   const float *grid_data;       // all type grids back to back
   long grid_off[kVinaTypes];    // float offset of type t's grid, -1 if absent
   float slope;
+  // direct (grid-free) receptor term = the non_cache igrid (non_cache.cpp:52-83,125-179), and the
+  // exact pair functions = precalculate_exact (precalculate.h:452-494)
+  int direct, exact;
+  const float4 *rec;  // (x, y, z, smt bits)
+  int n_rec;
+  float w5[5];
+  float box_begin[3], box_end[3];
 };
 
 struct VinaLigand {
@@ -81,5 +88,8 @@ size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s);
+// refine_structure (main.cpp:131-171): BFGS on the direct receptor term with the slope ladder 10, 100, ...
+void launch_vina_refine(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+                        int max_iters, float *energy, int *tries, hipStream_t s);
 
 }  // namespace mig

@@ -51,6 +51,73 @@ __device__ __forceinline__ void curl1(float &e, float v) {
   }
 }
 
+// atom_constants.h:101-133 (xs_radius, xs_hydrophobe / xs_donor / xs_acceptor)
+__constant__ float c_xs_radius[kVinaTypes] = {0.37f, 0.37f, 1.9f, 1.9f, 1.9f, 1.9f, 1.8f, 1.8f, 1.8f, 1.8f,
+                                              1.7f,  1.7f,  1.7f, 1.7f, 2.0f, 2.0f, 2.1f, 1.5f, 1.8f, 2.0f,
+                                              2.2f,  1.2f,  1.2f, 1.2f, 1.2f, 1.2f, 1.2f, 1.92f};
+__constant__ unsigned char c_hyd[kVinaTypes] = {0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1};
+__constant__ unsigned char c_don[kVinaTypes] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1, 0,
+                                                0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0};
+__constant__ unsigned char c_acc[kVinaTypes] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 1,
+                                                0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ float slope_step_d(float x_bad, float x_good, float x) {  // everything.h:207-216
+  if (x_bad < x_good) {
+    if (x <= x_bad) return 0.f;
+    if (x >= x_good) return 1.f;
+  } else {
+    if (x >= x_bad) return 0.f;
+    if (x <= x_good) return 1.f;
+  }
+  return (x - x_bad) / (x_good - x_bad);
+}
+
+// weighted_terms::eval_fast for the default Vina term set (weighted_terms.cpp:54-68; everything.h)
+__device__ float pair_energy_exact(const float *w, int t1, int t2, float r) {
+  const float opt = c_xs_radius[t1] + c_xs_radius[t2];
+  float acc = 0.f;
+  float q = (r - (opt + 0.0f)) / 0.5f;
+  acc += w[0] * expf(-(q * q));
+  q = (r - (opt + 3.0f)) / 2.0f;
+  acc += w[1] * expf(-(q * q));
+  const float d = r - (opt + 0.0f);
+  acc += w[2] * (d > 0 ? 0.0f : d * d);
+  acc += w[3] * ((c_hyd[t1] && c_hyd[t2]) ? slope_step_d(1.5f, 0.5f, r - opt) : 0.0f);
+  const bool hb = (c_don[t1] && c_acc[t2]) || (c_don[t2] && c_acc[t1]);
+  acc += w[4] * (hb ? slope_step_d(0.0f, -0.7f, r - opt) : 0.0f);
+  return acc;
+}
+
+// precalculate::eval_deriv: interpolated table (precalculate.h:97-133) or numeric exact (:467-490)
+__device__ __forceinline__ void prec_eval_deriv(const VinaEnv &env, int t1, int t2, float r2, float &e, float &dor) {
+  if (env.exact) {
+    const float delta = 0.000005f;
+    const float r = sqrtf(r2);
+    const float X = pair_energy_exact(env.w5, t1, t2, r);
+    const float rhi = r + delta;
+    float rlo = r - delta;
+    if (rlo < 0) rlo = 0;
+    const float W = pair_energy_exact(env.w5, t1, t2, rlo), Y = pair_energy_exact(env.w5, t1, t2, rhi);
+    e = X;
+    dor = ((Y - W) / (rhi - rlo)) / r;
+  } else {
+    const long base = (long)tri_idx(t1, t2) * env.n;
+    const float r2f = env.factor * r2;
+    const int i1 = (int)r2f;
+    const float rem = r2f - (float)i1;
+    const float2 s1 = env.smooth[base + i1], s2 = env.smooth[base + i1 + 1];
+    e = s1.x + rem * (s2.x - s1.x);
+    dor = s1.y + rem * (s2.y - s1.y);
+  }
+}
+
+// precalculate::eval = eval_fast: midpoint table (precalculate.h:90-95) or exact E(r)
+__device__ __forceinline__ float prec_eval(const VinaEnv &env, int t1, int t2, float r2) {
+  if (env.exact) return pair_energy_exact(env.w5, t1, t2, sqrtf(r2));
+  return env.fast[(long)tri_idx(t1, t2) * env.n + (int)(env.factor * r2)];
+}
+
 // grid::evaluate_aux, grid.cpp:96-186
 template <bool DERIV>
 __device__ float grid_evaluate(const VinaGridGeom &g, const float *data, float lx, float ly, float lz, float slope,
@@ -214,7 +281,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // MODE 0: model::eval_deriv (model.cu:202-225); MODE 1: model::eval (energy only, midpoint pair table);
 // MODE 2: cache::eval (cache.cpp:52-63: receptor-grid term only -- the energy gnina's Metropolis step
-// uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates).  Returns the energy in every lane; MODE 0 writes change[6 + T] to LDS.
+// uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates); MODE 4: eval_intramolecular
+// (model.cu:352-399: ligand pairs only, energy only).  Returns the energy in every lane; MODE 0 writes change[6 + T] to LDS.
 template <int MODE>
 __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float *conf, float v0, float v1, float v2,
                            const WaveWork &w, float *change) {
@@ -255,7 +323,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
     }
   }
   __syncthreads();
-  // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor grid term
+  // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor term
   float e_part = 0.f;
   for (int i = lane; i < L.n_atoms; i += 64) {
     const int k = L.node_of_atom[i];
@@ -267,7 +335,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
     w.coords[3 * i + 2] = cz;
     const int t = L.smt[i];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (MODE != 3 && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+    if (MODE != 3 && MODE != 4 && !env.direct && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
       e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
     }
     if (DERIV) {
@@ -277,28 +345,82 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
     }
   }
   __syncthreads();
+  if (MODE != 3 && MODE != 4 && env.direct) {
+    // non_cache::eval / eval_deriv (non_cache.cpp:52-83,125-179): every ligand heavy atom against every
+    // receptor atom within the cutoff -- the 64 lanes stride over the receptor, one ligand atom at a time
+    for (int i = 0; i < L.n_atoms; i++) {
+      const int t1 = L.smt[i];
+      if (t1 <= 1) continue;
+      float adj[3], oobd[3] = {0.f, 0.f, 0.f}, oob = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {  // check_bounds(_deriv), non_cache.cpp:32-50,102-123
+        const float c = w.coords[3 * i + k];
+        adj[k] = c;
+        if (c < env.box_begin[k]) {
+          adj[k] = env.box_begin[k];
+          oobd[k] = -1.f;
+          oob += fabsf(c - env.box_begin[k]);
+        } else if (c > env.box_end[k]) {
+          adj[k] = env.box_end[k];
+          oobd[k] = 1.f;
+          oob += fabsf(c - env.box_end[k]);
+        }
+      }
+      oob *= env.slope;
+      float pe = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+      for (int j = lane; j < env.n_rec; j += 64) {
+        const float4 r = env.rec[j];
+        const float rx = adj[0] - r.x, ry = adj[1] - r.y, rz = adj[2] - r.z;
+        const float r2 = rx * rx + ry * ry + rz * rz;
+        if (r2 < env.cutoff_sqr) {
+          const int t2 = __float_as_int(r.w);
+          if (DERIV) {
+            float e1, dor;
+            prec_eval_deriv(env, t1, t2, r2, e1, dor);
+            pe += e1;
+            dx += dor * rx;
+            dy += dor * ry;
+            dz += dor * rz;
+          } else {
+            pe += prec_eval(env, t1, t2, r2);
+          }
+        }
+      }
+      pe = wave_sum(pe);
+      if (DERIV) {
+        dx = wave_sum(dx);
+        dy = wave_sum(dy);
+        dz = wave_sum(dz);
+        curl3(pe, dx, dy, dz, v1);
+        if (lane == 0) {
+          w.forces[3 * i] = dx + env.slope * oobd[0];
+          w.forces[3 * i + 1] = dy + env.slope * oobd[1];
+          w.forces[3 * i + 2] = dz + env.slope * oobd[2];
+        }
+      } else {
+        curl1(pe, v1);
+      }
+      if (lane == 0) e_part += pe + oob;
+    }
+    __syncthreads();
+  }
   // 4. intramolecular pairs (model.cu:38-60 / :22-36)
-  for (int p = lane; MODE < 2 && p < L.n_pairs; p += 64) {
+  for (int p = lane; (MODE < 2 || MODE == 4) && p < L.n_pairs; p += 64) {
     const int2 ab = L.pairs[p];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
     const float r2 = rx * rx + ry * ry + rz * rz;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r2 < env.cutoff_sqr) {
-      const long base = (long)tri_idx(L.smt[ab.x], L.smt[ab.y]) * env.n;
       if (DERIV) {
-        const float r2f = env.factor * r2;
-        const int i1 = (int)r2f;
-        const float rem = r2f - (float)i1;
-        const float2 s1 = env.smooth[base + i1], s2 = env.smooth[base + i1 + 1];
-        float pe = s1.x + rem * (s2.x - s1.x);
-        const float dor = s1.y + rem * (s2.y - s1.y);
+        float pe, dor;
+        prec_eval_deriv(env, L.smt[ab.x], L.smt[ab.y], r2, pe, dor);
         float fx = dor * rx, fy = dor * ry, fz = dor * rz;
         curl3(pe, fx, fy, fz, v0);
         out = make_float4(fx, fy, fz, pe);
         e_part += pe;
       } else {
-        float pe = env.fast[base + (int)(env.factor * r2)];
+        float pe = prec_eval(env, L.smt[ab.x], L.smt[ab.y], r2);
         curl1(pe, v0);
         e_part += pe;
       }
@@ -568,6 +690,53 @@ __global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L
   }
 }
 
+
+// refine_structure (main.cpp:131-171): BFGS on the direct receptor term; the out-of-box slope starts at
+// 10 and is raised 10x per try (at most 5) until every heavy atom is inside the box (non_cache::within,
+// non_cache.cpp:84-101); a pose that never gets in reports max_fl.
+__global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
+                                                         float v2, int max_iters, float *energy, int *tries_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *pp = lds;
+  WaveWork w = carve_work(pp, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  BfgsWork k = carve_bfgs(pp, n, nc);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int evals = 0;
+  for (int i = lane; i < nc; i += 64) k.x[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  env.direct = 1;
+  float slope = 10.f, e = 0.f;
+  int tries = 0;
+  bool inside = false;
+  for (int p = 0; p < 5 && !inside; p++) {
+    env.slope = slope;
+    e = bfgs_wave(env, L, w, k, v0, v1, v2, max_iters, evals);
+    (void)eval_conf<3>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // m.set(out.c)
+    int bad = 0;
+    for (int i = lane; i < L.n_atoms; i += 64)
+      if (L.smt[i] > 1)
+        for (int d = 0; d < 3; d++)
+          if (w.coords[3 * i + d] < env.box_begin[d] - 0.0001f || w.coords[3 * i + d] > env.box_end[d] + 0.0001f) bad = 1;
+    inside = !__any(bad);
+    tries++;
+    slope *= 10.f;
+    __syncthreads();
+  }
+  if (!inside) e = VMAXFL;
+  for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = k.x[i];
+  if (lane == 0) {
+    energy[b] = e;
+    if (tries_out) tries_out[b] = tries;
+  }
+}
+
+void launch_vina_refine(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+                        int max_iters, float *energy, int *tries, hipStream_t s) {
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true);
+  hipLaunchKernelGGL(vina_refine_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
+                     tries);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Monte-Carlo chain: monte_carlo::operator() (monte_carlo.cpp:99-148) -- one wavefront per chain for
@@ -839,6 +1008,9 @@ void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *co
                        coords);
   else if (with_deriv == 0)
     hipLaunchKernelGGL(vina_eval_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
+                       coords);
+  else if (with_deriv == 4)
+    hipLaunchKernelGGL(vina_eval_kernel<4>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
                        coords);
   else
     hipLaunchKernelGGL(vina_eval_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,

@@ -73,6 +73,8 @@ struct Vina {
   size_t grid_pts = 0;
   DevBuf<float> d_grids;
   float slope = 1e3f;
+  float box_begin[3] = {0, 0, 0}, box_end[3] = {0, 0, 0};
+  float w5[5];
   // ligand
   bool have_lig = false;
   VinaLigand lig{};
@@ -140,6 +142,15 @@ static VinaEnv make_env(const Vina &v) {
   e.grid_data = v.d_grids.p;
   for (int t = 0; t < kVinaTypes; t++) e.grid_off[t] = v.grid_off[t];
   e.slope = v.slope;
+  e.direct = 0;
+  e.exact = 0;
+  e.rec = v.d_rec.p;
+  e.n_rec = v.n_rec;
+  for (int i = 0; i < 5; i++) e.w5[i] = v.w5[i];
+  for (int i = 0; i < 3; i++) {
+    e.box_begin[i] = v.box_begin[i];
+    e.box_end[i] = v.box_end[i];
+  }
   return e;
 }
 
@@ -167,7 +178,8 @@ mi_vina *mi_vina_create(const float *weights5, float cutoff, float factor) {
     std::unique_ptr<Vina> v(new Vina());
     MIG_HIP(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
     for (auto &o : v->grid_off) o = -1;
-    build_tables(*v, weights5 ? weights5 : kDefaultWeights, cutoff, factor);
+    for (int i = 0; i < 5; i++) v->w5[i] = (weights5 ? weights5 : kDefaultWeights)[i];
+    build_tables(*v, v->w5, cutoff, factor);
     return reinterpret_cast<mi_vina *>(v.release());
   } catch (const std::exception &e) {
     mig::set_last_error(e.what());
@@ -221,6 +233,8 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
     MIG_CHECK(n3[i] > 0 && end3[i] > begin3[i], 1, "bad grid dims");
     v.geom.dim[i] = n3[i] + 1;
     v.geom.init[i] = begin3[i];
+    v.box_begin[i] = begin3[i];
+    v.box_end[i] = end3[i];
     const float range = end3[i] - begin3[i];
     v.geom.dim_m1[i] = (float)v.geom.dim[i] - 1.0f;
     v.geom.factor[i] = v.geom.dim_m1[i] / range;
@@ -376,11 +390,15 @@ mi_status mi_vina_eval_batch(mi_vina *vv, const float *confs, int B, const float
   v.d_energy.ensure(B);
   if (change) v.d_change.ensure((size_t)B * n);
   if (coords) v.d_coords.ensure((size_t)B * 3 * v.lig.n_atoms);
-  launch_vina_eval(make_env(v), v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
+  VinaEnv env = make_env(v);
+  env.direct = (with_deriv & MI_VINA_DIRECT) ? 1 : 0;
+  env.exact = (with_deriv & MI_VINA_EXACT) ? 1 : 0;
+  with_deriv &= 7;
+  launch_vina_eval(env, v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
                    change ? v.d_change.p : nullptr, coords ? v.d_coords.p : nullptr, v.stream);
   MIG_HIP(hipGetLastError());
   MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
-  if (change && with_deriv)
+  if (change && with_deriv == 1)
     MIG_HIP(hipMemcpyAsync(change, v.d_change.p, (size_t)B * n * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   if (coords)
     MIG_HIP(hipMemcpyAsync(coords, v.d_coords.p, (size_t)B * 3 * v.lig.n_atoms * sizeof(float), hipMemcpyDeviceToHost,
@@ -473,6 +491,56 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
                            v.stream));
   if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_refine_batch(mi_vina *vv, float *confs, int B, const float *v3, int max_iters, float *energy,
+                               int32_t *tries) {
+  VTRY
+  MIG_CHECK(vv && confs && v3 && energy && B >= 0 && max_iters >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache (it defines the search box) and set the ligand first");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, nc = 7 + nt;
+  v.d_confs.upload(confs, (size_t)B * nc, v.stream);
+  v.d_energy.ensure(B);
+  v.d_evals.ensure(B);
+  launch_vina_refine(make_env(v), v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], max_iters, v.d_energy.p, v.d_evals.p,
+                     v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(confs, v.d_confs.p, (size_t)B * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (tries) MIG_HIP(hipMemcpyAsync(tries, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// do_search's final energies (main.cpp:339-344): intramolecular = eval_intramolecular(exact_prec) and
+// e = conf_independent(eval(exact_prec, non_cache) - intramolecular) with num_tors_div (everything.h:796-814)
+mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const float *v3, float num_tors,
+                                 float *e_final, float *intramolecular) {
+  VTRY
+  MIG_CHECK(vv && confs && v3 && e_final && B >= 0, 1, "bad arguments");
+  if (B == 0) return MI_OK;
+  std::vector<float> total(B), intra(B);
+  mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 0 | MI_VINA_DIRECT | MI_VINA_EXACT, total.data(), nullptr, nullptr);
+  if (st != MI_OK) return st;
+  st = mi_vina_eval_batch(vv, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
+  if (st != MI_OK) return st;
+  const float weight = (float)(5 * 0.05846 / 0.1 - 1);  // main.cpp:1329
+  const float w = 0.1f * (weight + 1);
+  for (int b = 0; b < B; b++) {
+    const float x = total[b] - intra[b];
+    const float y = 1 + w * num_tors / 5.0f;
+    float r;  // smooth_div, everything.h:52-56
+    if (std::fabs(x) < 1.1920928955078125e-07f) r = 0;
+    else if (std::fabs(y) < 1.1920928955078125e-07f) r = (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;
+    else r = x / y;
+    e_final[b] = r;
+    if (intramolecular) intramolecular[b] = intra[b];
+  }
   return MI_OK;
   VCATCH_STATUS
 }

@@ -184,6 +184,21 @@ mi_status mi_vina_set_ligand(mi_vina *, const mi_ligand_desc *);
  * confs [B][7+T]; energy [B]; change [B][6+T] or NULL; coords [B][n_atoms][3] or NULL. */
 mi_status mi_vina_eval_batch(mi_vina *, const float *confs, int B, const float *v3, int with_deriv, float *energy,
                              float *change, float *coords);
+/* with_deriv values: 1 model::eval_deriv, 0 model::eval, 2 receptor term only (cache::eval / non_cache::eval),
+ * 4 eval_intramolecular (ligand pairs only, model.cu:352-399); OR-able flags: */
+enum {
+  MI_VINA_DIRECT = 16, /* receptor term from the atoms, no grids: the non_cache igrid (non_cache.cpp:52-83,125-179) */
+  MI_VINA_EXACT = 32   /* precalculate_exact instead of the linear tables (precalculate.h:452-494) */
+};
+/* refine_structure (main.cpp:131-171): BFGS on non_cache, out-of-box slope 10 -> x10 per try (<= 5) until
+ * non_cache::within; energy = max_fl when the pose never gets inside.  In place; tries [B] optional. */
+mi_status mi_vina_refine_batch(mi_vina *, float *confs, int B, const float *v3, int max_iters, float *energy,
+                               int32_t *tries);
+/* The energies do_search reports (main.cpp:339-344): intramolecular = eval_intramolecular(exact_prec);
+ * e_final = conf_independent(eval(exact_prec, non_cache) - intramolecular) with the default num_tors_div
+ * weight (everything.h:796-814, main.cpp:1329).  num_tors = conf_independent_inputs::num_tors (terms.cpp:74-106). */
+mi_status mi_vina_final_energies(mi_vina *, const float *confs, int B, const float *v3, float num_tors,
+                                 float *e_final, float *intramolecular);
 /* quasi_newton::operator() (quasi_newton.cpp:49-83) = bfgs<> with fast_line_search (bfgs.h:73-91,
  * 357-502) for B conformations, in place; max_iters = (25 + n_movable_atoms) / 3 in gnina
  * (main.cpp:454-456).  energy [B]; grad [B][6+T] or NULL; evals [B] or NULL. */

@@ -211,6 +211,49 @@ def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, te
     return e[:n], cf[:n], xyz[:n], ev.value
 
 
+def noncache_eval(scene, rec_xyz, rec_smt, conf, v=(1000.0, 1000.0, 1000.0), deriv=True, exact=False, slope=None):
+    """model::eval_deriv / model::eval with ig = non_cache -> (total, change, inter, intra)"""
+    conf = np.ascontiguousarray(conf, dtype=np.float32)
+    vv = np.ascontiguousarray(v, dtype=np.float32)
+    rec_xyz = np.ascontiguousarray(rec_xyz, dtype=np.float32)
+    rec_smt = np.ascontiguousarray(rec_smt, dtype=np.int32)
+    change = np.zeros(6 + scene.lig.n_tors, dtype=np.float32)
+    inter, intra = C.c_float(), C.c_float()
+    f = _voxel.lib().ora_vina_noncache_eval
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(GridDims), C.c_float, _f32p, _i32p, C.c_int,
+                  C.POINTER(Ligand), _f32p, _f32p, C.c_int, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    e = f(scene.tables.h, None, int(exact), C.byref(scene.gd), scene.slope if slope is None else slope, _p(rec_xyz),
+          _p(rec_smt, C.c_int32), len(rec_smt), C.byref(scene.lig.c), _p(conf), _p(vv), int(deriv), _p(change),
+          C.byref(inter), C.byref(intra))
+    return e, change, inter.value, intra.value
+
+
+def refine(scene, rec_xyz, rec_smt, conf, v=(1000.0, 1000.0, 1000.0), max_iters=None):
+    """refine_structure -> (energy, conf, tries)"""
+    conf = np.array(conf, dtype=np.float32, copy=True)
+    vv = np.ascontiguousarray(v, dtype=np.float32)
+    rec_xyz = np.ascontiguousarray(rec_xyz, dtype=np.float32)
+    rec_smt = np.ascontiguousarray(rec_smt, dtype=np.int32)
+    if max_iters is None:
+        max_iters = (25 + scene.lig.n_atoms) // 3
+    tries = C.c_int()
+    f = _voxel.lib().ora_vina_refine
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, C.POINTER(GridDims), _f32p, _i32p, C.c_int, C.POINTER(Ligand), _f32p, _f32p, C.c_int,
+                  C.POINTER(C.c_int)]
+    e = f(scene.tables.h, C.byref(scene.gd), _p(rec_xyz), _p(rec_smt, C.c_int32), len(rec_smt), C.byref(scene.lig.c),
+          _p(conf), _p(vv), int(max_iters), C.byref(tries))
+    return e, conf, tries.value
+
+
+def conf_independent(e, num_tors):
+    f = _voxel.lib().ora_vina_conf_independent
+    f.restype = C.c_float
+    f.argtypes = [C.c_float, C.c_float]
+    return f(e, num_tors)
+
+
 def cache_eval(scene, conf, v1=1000.0):
     conf = np.ascontiguousarray(conf, dtype=np.float32)
     f = _voxel.lib().ora_vina_cache_eval

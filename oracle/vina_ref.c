@@ -574,12 +574,27 @@ typedef struct {
   const ora_ligand *L;
   const float *v;
   long evals;
+  /* direct (non_cache) evaluation instead of the cache grids */
+  int direct;
+  const float *rec_xyz;
+  const int32_t *rec_smt;
+  int n_rec;
 } bfgs_ctx;
+
+float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact, const ora_grid_dims *gd, float slope,
+                             const float *rec_xyz, const int32_t *rec_smt, int n_rec, const ora_ligand *L,
+                             const float *conf, const float *v, int deriv, float *change, float *inter_out,
+                             float *intra_out);
 
 static float fx(bfgs_ctx *c, const float *conf, float *g) {
   c->evals++;
+  if (c->direct)
+    return ora_vina_noncache_eval(c->T, NULL, 0, c->gd, c->slope, c->rec_xyz, c->rec_smt, c->n_rec, c->L, conf, c->v, 1,
+                                  g, NULL, NULL);
   return ora_vina_model_eval_deriv(c->T, c->gd, c->grids, c->slope, c->L, conf, c->v, g, NULL, NULL);
 }
+
+static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out);
 
 static inline int hidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
 
@@ -592,8 +607,34 @@ static float dotn(const float *a, const float *b, int n) {
 /* returns the final energy; conf is updated in place; change g receives the final gradient */
 float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
                     const ora_ligand *L, float *conf, const float *v, int max_iters, float *g_out, long *evals_out) {
+  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0};
+  float f = bfgs_run(&ctx, conf, max_iters, g_out);
+  if (evals_out) *evals_out = ctx.evals;
+  return f;
+}
+
+/* refine_structure (main.cpp:131-171): BFGS on non_cache with the out-of-box slope raised 10x per try
+ * until every heavy atom is inside the box (at most 5 tries); energy = max_fl if it never gets in. */
+float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const float *rec_xyz, const int32_t *rec_smt,
+                      int n_rec, const ora_ligand *L, float *conf, const float *v, int max_iters, int *tries_out) {
+  int ora_vina_within(const ora_grid_dims *gd, const ora_ligand *L, const float *conf);
+  float slope = 10, e = 0;
+  int p = 0;
+  for (; p < 5; p++) {
+    bfgs_ctx ctx = {T, gd, NULL, slope, L, v, 0, 1, rec_xyz, rec_smt, n_rec};
+    e = bfgs_run(&ctx, conf, max_iters, NULL);
+    if (ora_vina_within(gd, L, conf)) break;
+    slope *= 10;
+  }
+  if (tries_out) *tries_out = p < 5 ? p + 1 : 5;
+  if (!ora_vina_within(gd, L, conf)) e = V_MAXFL;
+  return e;
+}
+
+static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) {
+  const ora_ligand *L = ctxp->L;
   const int nt = L->n_nodes - 1, n = 6 + nt, nc = 7 + nt;
-  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0};
+#define ctx (*ctxp)
   float *h = (float *)calloc((size_t)n * (n + 1) / 2, sizeof(float));
   for (int i = 0; i < n; i++) h[hidx(i, i)] = 1;
   float *g = (float *)malloc(sizeof(float) * n), *g_new = (float *)malloc(sizeof(float) * n);
@@ -657,7 +698,7 @@ float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
     memcpy(g, g_orig, sizeof(float) * n);
   }
   if (g_out) memcpy(g_out, g, sizeof(float) * n);
-  if (evals_out) *evals_out = ctx.evals;
+#undef ctx
   free(h);
   free(g);
   free(g_new);
@@ -923,4 +964,155 @@ int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const f
   free(axis);
   free(hc);
   return n_out;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Direct (grid-free) receptor term and exact pair functions: rows "Direct pair evaluators" /
+ * a18 of SURVEY 8a -- non_cache::eval (non_cache.cpp:52-83), non_cache::eval_deriv (:125-179),
+ * check_bounds(_deriv) (:32-50,102-123), within (:84-101), precalculate_exact (precalculate.h:452-494),
+ * refine_structure (main.cpp:131-171), conf-independent num_tors_div (everything.h:796-814).
+ * prec_mode 0 = precalculate_linear tables, 1 = precalculate_exact.
+ * ------------------------------------------------------------------------------------------- */
+static float prec_eval(const ora_vina_tables *T, const float *w, int exact, int t1, int t2, float r2) {
+  if (exact) return ora_vina_pair_energy(w, t1, t2, sqrtf(r2)); /* precalculate_exact::eval_fast */
+  return ora_vina_eval_fast(T, t1, t2, r2);
+}
+
+static void prec_eval_deriv(const ora_vina_tables *T, const float *w, int exact, int t1, int t2, float r2, float *e,
+                            float *dor) {
+  if (!exact) {
+    ora_vina_table_eval_deriv(T, t1, t2, r2, e, dor);
+    return;
+  }
+  const float delta = 0.000005f; /* precalculate.h:457 */
+  float r = sqrtf(r2);
+  float X = ora_vina_pair_energy(w, t1, t2, r);
+  float rhi = r + delta, rlo = r - delta;
+  if (rlo < 0) rlo = 0;
+  float W = ora_vina_pair_energy(w, t1, t2, rlo), Y = ora_vina_pair_energy(w, t1, t2, rhi);
+  float dx = (Y - W) / (rhi - rlo);
+  *e = X;
+  *dor = dx / r;
+}
+
+/* model::eval_deriv / model::eval with ig = non_cache.  deriv != 0 -> eval_deriv semantics (interpolated
+ * tables / numeric exact derivative, change written); deriv == 0 -> eval semantics (p.eval = eval_fast). */
+float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact, const ora_grid_dims *gd, float slope,
+                             const float *rec_xyz, const int32_t *rec_smt, int n_rec, const ora_ligand *L,
+                             const float *conf, const float *v, int deriv, float *change, float *inter_out,
+                             float *intra_out) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n), *forces = (float *)calloc(3 * (size_t)n, sizeof(float));
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  float e = 0;
+  for (int i = 0; i < n; i++) {
+    int t1 = L->smt[i];
+    if (is_hydrogen(t1)) continue;
+    float adj[3], oob_d[3] = {0, 0, 0}, oob = 0;
+    for (int k = 0; k < 3; k++) { /* check_bounds_deriv */
+      float c = coords[3 * i + k];
+      adj[k] = c;
+      if (gd->n[k] > 0) {
+        if (c < gd->begin[k]) {
+          adj[k] = gd->begin[k];
+          oob_d[k] = -1;
+          oob += fabsf(c - gd->begin[k]);
+        } else if (c > gd->end[k]) {
+          adj[k] = gd->end[k];
+          oob_d[k] = 1;
+          oob += fabsf(c - gd->end[k]);
+        }
+      }
+    }
+    oob *= slope;
+    float this_e = 0, d[3] = {0, 0, 0};
+    for (int j = 0; j < n_rec; j++) {
+      float rx = adj[0] - rec_xyz[3 * j], ry = adj[1] - rec_xyz[3 * j + 1], rz = adj[2] - rec_xyz[3 * j + 2];
+      float r2 = rx * rx + ry * ry + rz * rz;
+      if (r2 < T->cutoff_sqr) {
+        if (deriv) {
+          float pe, dor;
+          prec_eval_deriv(T, w, exact, t1, rec_smt[j], r2, &pe, &dor);
+          this_e += pe;
+          d[0] += dor * rx;
+          d[1] += dor * ry;
+          d[2] += dor * rz;
+        } else {
+          this_e += prec_eval(T, w, exact, t1, rec_smt[j], r2);
+        }
+      }
+    }
+    if (deriv) {
+      curl3(&this_e, d, v[1]);
+      for (int k = 0; k < 3; k++) forces[3 * i + k] = d[k] + slope * oob_d[k];
+    } else {
+      curl1(&this_e, v[1]);
+    }
+    e += this_e + oob;
+  }
+  float ie = 0;
+  for (int p = 0; p < L->n_pairs; p++) {
+    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+    float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
+                  coords[3 * b + 2] - coords[3 * a + 2]};
+    float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    if (r2 < T->cutoff_sqr) {
+      if (deriv) {
+        float pe, dor;
+        prec_eval_deriv(T, w, exact, L->smt[a], L->smt[b], r2, &pe, &dor);
+        float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
+        curl3(&pe, force, v[0]);
+        ie += pe;
+        for (int k = 0; k < 3; k++) {
+          forces[3 * a + k] -= force[k];
+          forces[3 * b + k] += force[k];
+        }
+      } else {
+        float pe = prec_eval(T, w, exact, L->smt[a], L->smt[b], r2);
+        curl1(&pe, v[0]);
+        ie += pe;
+      }
+    }
+  }
+  if (deriv && change) {
+    float ft[6];
+    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
+  }
+  if (inter_out) *inter_out = e;
+  if (intra_out) *intra_out = ie;
+  free(coords);
+  free(forces);
+  free(origin);
+  free(axis);
+  return e + ie;
+}
+
+/* non_cache::within (non_cache.cpp:84-101), margin 0.0001 */
+int ora_vina_within(const ora_grid_dims *gd, const ora_ligand *L, const float *conf) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  int ok = 1;
+  for (int i = 0; i < n && ok; i++) {
+    if (is_hydrogen(L->smt[i])) continue;
+    for (int k = 0; k < 3; k++)
+      if (gd->n[k] > 0 && (coords[3 * i + k] < gd->begin[k] - 0.0001f || coords[3 * i + k] > gd->end[k] + 0.0001f)) ok = 0;
+  }
+  free(coords);
+  free(origin);
+  free(axis);
+  return ok;
+}
+
+/* num_tors_div (everything.h:796-814) with the default weight 5*0.05846/0.1 - 1 (main.cpp:1329):
+ * e / (1 + w * num_tors / 5), w = 0.1 * (weight + 1) */
+float ora_vina_conf_independent(float e, float num_tors) {
+  const float weight = (float)(5 * 0.05846 / 0.1 - 1);
+  float w = 0.1f * (weight + 1);
+  float y = 1 + w * num_tors / 5.0f;
+  if (fabsf(e) < V_EPS) return 0;
+  if (fabsf(y) < V_EPS) return (e * y > 0) ? V_MAXFL : -V_MAXFL;
+  return e / y;
 }

@@ -168,3 +168,50 @@ def test_mc_chain_first_step_matches_oracle_and_statistics(setup, capi):
     assert np.array_equal(e2[:, 0], e[:4, 0])
     n3, e3, _, _, _ = vina.mc_batch(seeds[:4] + np.uint64(1000), c1, c2, P)
     assert not np.array_equal(e3[:, 0], e[:4, 0])
+
+
+def test_noncache_exact_and_refine_match_oracle(setup):
+    """Row a18 pieces: the direct (non_cache) receptor term, precalculate_exact, refine_structure's
+    slope ladder and the final reported energies (main.cpp:131-171,339-344)."""
+    vina, S, sc, gd, types, grids = setup
+    rng = np.random.RandomState(21)
+    lig = sc["lig"]
+    confs = np.stack([synth.random_conf(rng, lig, sc["center"], spread=1.0) for _ in range(10)] + [lig["conf0"]])
+    out = confs[2].copy()
+    out[:3] += (np.array(gd.end[:]) - np.array(gd.begin[:])) * 0.55
+    confs = np.vstack([confs, out[None]])
+    v = (1000.0, 1000.0, 1000.0)
+    for exact in (False, True):
+        e, ch, _ = vina.eval_batch(confs, v, deriv=True, direct=True, exact=exact)
+        e0s = []
+        for b in range(len(confs)):
+            e0, g0, inter, intra = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=True, exact=exact)
+            assert abs(e[b] - e0) <= 2e-4 * max(1.0, abs(e0)), (exact, b, e[b], e0)
+            # the exact derivative is a difference over 1e-5 A in fp32: noisy by construction
+            tol = (5e-2 if exact else 1e-3) * max(1.0, np.abs(g0).max())
+            assert np.abs(ch[b] - g0).max() <= tol, (exact, b)
+        e_only = vina.eval_batch(confs, v, deriv=False, direct=True, exact=exact)[0]
+        for b in range(0, len(confs), 3):
+            e0 = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=exact)[0]
+            assert abs(e_only[b] - e0) <= 2e-4 * max(1.0, abs(e0))
+    # final energies: conf_independent(inter_exact) and the exact intramolecular term
+    num_tors = 6.0
+    ef, intra = vina.final_energies(confs, num_tors, v)
+    for b in range(len(confs)):
+        tot, _, inter0, intra0 = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=True)
+        assert abs(intra[b] - intra0) <= 2e-4 * max(1.0, abs(intra0))
+        ref = V.conf_independent(np.float32(tot) - np.float32(intra0), num_tors)
+        assert abs(ef[b] - ref) <= 5e-4 * max(1.0, abs(ref))
+    # refine_structure: everything ends inside the box (or reports max_fl), energies never increase
+    e_start = vina.eval_batch(confs, v, deriv=False, direct=True)[0]
+    er, cr, tries = vina.refine_batch(confs, v)
+    assert ((tries >= 1) & (tries <= 5)).all()
+    co = vina.eval_batch(cr, v, want_coords=True)[2]
+    heavy = lig["smt"] > 1
+    for b in range(len(confs)):
+        inside = ((co[b][heavy] >= np.array(gd.begin[:]) - 1e-3) & (co[b][heavy] <= np.array(gd.end[:]) + 1e-3)).all()
+        assert inside == (er[b] < 1e30)
+    assert tries[-1] >= 1 and er[-1] < 1e30            # the out-of-box pose was pulled back in
+    e_orc = np.array([V.refine(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v)[0] for b in range(len(confs))])
+    fin = (er < 1e30) & (e_orc < 1e30)
+    assert abs(np.median(er[fin]) - np.median(e_orc[fin])) <= 0.25 * abs(np.median(e_orc[fin])) + 1.0

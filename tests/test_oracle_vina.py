@@ -181,3 +181,45 @@ def test_bfgs_descends_and_is_idempotent_at_a_minimum(scene):
         assert e2 <= e1 + 1e-6
     # quaternion stays normalised through many increments
     assert abs(np.linalg.norm(c1[3:7]) - 1) < 1e-3
+
+
+def test_noncache_agrees_with_cache_inside_the_box(scene):
+    """The cache grid is a trilinear interpolation of the same pair sum non_cache evaluates directly:
+    inside the box the two receptor terms agree to grid resolution (this is why gnina can dock on the
+    grids and refine / report on non_cache)."""
+    S, sc = scene
+    rng = np.random.RandomState(8)
+    v = (1000.0, 1000.0, 1000.0)
+    diffs = []
+    for _ in range(6):
+        conf = synth.random_conf(rng, sc["lig"], sc["center"], spread=0.5)
+        e_cache = S.eval_deriv(conf, v)[0]
+        e_nc, g_nc, inter, intra = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], conf, v)
+        assert abs(inter + intra - e_nc) < 1e-3 * max(1.0, abs(e_nc))
+        diffs.append(abs(e_cache - e_nc) / max(1.0, abs(e_nc)))
+    assert np.median(diffs) < 0.15
+
+
+def test_exact_precalculate_is_close_to_tables_and_gradient_consistent(scene):
+    S, sc = scene
+    conf = synth.random_conf(np.random.RandomState(9), sc["lig"], sc["center"], spread=0.5)
+    v = (1000.0, 1000.0, 1000.0)
+    e_t, g_t, _, _ = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], conf, v, exact=False)
+    e_x, g_x, _, _ = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], conf, v, exact=True)
+    assert abs(e_t - e_x) < 0.02 * max(1.0, abs(e_x))
+    assert np.abs(g_t - g_x).max() < 0.1 * max(1.0, np.abs(g_x).max())
+    # num_tors_div: e / (1 + 0.05846 * num_tors)  (SURVEY App. D)
+    assert V.conf_independent(-10.0, 6.0) == pytest.approx(-10.0 / (1 + 0.05846 * 6), rel=1e-5)
+
+
+def test_refine_structure_pulls_a_pose_back_into_the_box(scene):
+    S, sc = scene
+    gd = S.gd
+    conf = sc["lig"]["conf0"].copy()
+    conf[:3] += (np.array(gd.end[:]) - np.array(gd.begin[:])) * 0.55      # mostly outside the box
+    e, c1, tries = V.refine(S, sc["rec_xyz"], sc["rec_smt"], conf)
+    assert 1 <= tries <= 5
+    coords, _, _ = V.set_conf(S.lig, c1)
+    heavy = sc["lig"]["smt"] > 1
+    inside = ((coords[heavy] >= np.array(gd.begin[:]) - 1e-3) & (coords[heavy] <= np.array(gd.end[:]) + 1e-3)).all()
+    assert inside == (e < 1e30)
