@@ -26,7 +26,7 @@ SYMBOLS = [
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
-    "mi_vina_refine_batch", "mi_vina_final_energies",
+    "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs",
 ]
 
 _lib = None
@@ -148,6 +148,11 @@ def lib():
         L.mi_vina_refine_batch.restype = C.c_int
         L.mi_vina_final_energies.argtypes = [vp, vp, C.c_int, vp, C.c_float, vp, vp]
         L.mi_vina_final_energies.restype = C.c_int
+        L.mi_rank_poses.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+        L.mi_rank_poses.restype = C.c_int
+        L.mi_merge_mc_outputs.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp,
+                                          vp, vp]
+        L.mi_merge_mc_outputs.restype = C.c_int
         L.mi_vina_stream.argtypes = [vp]
         L.mi_vina_stream.restype = vp
         _lib = L
@@ -416,6 +421,34 @@ class Vina:
         if getattr(self, "handle", None) and _lib is not None:
             _lib.mi_vina_destroy(self.handle)
             self.handle = None
+
+
+def merge_mc_outputs(n, e, conf, coords, min_rmsd=2.0, max_size=50):
+    """parallel_mc's merge of the per-chain containers -> (energies [m], confs [m,nc], coords [m,nh,3])"""
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    e, conf, coords = _f32(e), _f32(conf), _f32(coords)
+    B, S = e.shape
+    nc, nh = conf.shape[2], coords.shape[2]
+    on = C.c_int32()
+    oe = np.empty(max_size, dtype=np.float32)
+    ocf = np.empty((max_size, nc), dtype=np.float32)
+    oxyz = np.empty((max_size, nh, 3), dtype=np.float32)
+    check(lib().mi_merge_mc_outputs(_ptr(n), _ptr(e), _ptr(conf), _ptr(coords), B, S, nc, nh, min_rmsd, max_size,
+                                    C.byref(on), _ptr(oe), _ptr(ocf), _ptr(oxyz)))
+    m = on.value
+    return oe[:m].copy(), ocf[:m].copy(), oxyz[:m].copy()
+
+
+def rank_poses(cnnscore, cnnaffinity, energy, coords, sort_order=0, min_rmsd=1.0):
+    """do_search's sort + remove_redundant (host only): returns the kept pose indices, best first."""
+    coords = _f32(coords)
+    n, nh = coords.shape[0], coords.shape[1]
+    cs, ca, en = _f32(cnnscore), _f32(cnnaffinity), _f32(energy)
+    order = np.empty(max(n, 1), dtype=np.int32)
+    n_out = C.c_int32()
+    check(lib().mi_rank_poses(_ptr(cs), _ptr(ca), _ptr(en), _ptr(coords), n, nh, sort_order, min_rmsd, _ptr(order),
+                              C.byref(n_out)))
+    return order[:n_out.value].copy()
 
 
 def init(device=0):

@@ -545,6 +545,102 @@ mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const f
   VCATCH_STATUS
 }
 
+// do_search's ranking tail (main.cpp:348-361): sort by CNNscore (descending, default), CNNaffinity
+// (descending) or Energy (ascending), then remove_redundant (main.cpp:182-192): keep a pose only if its
+// RMSD (rmsd_upper_bound over heavy atoms, coords.cpp:25-32) to every pose kept so far exceeds min_rmsd.
+// Host only.  order_out receives the indices of the kept poses, best first.
+mi_status mi_rank_poses(const float *cnnscore, const float *cnnaffinity, const float *energy, const float *coords,
+                        int n_poses, int n_heavy, int sort_order, float min_rmsd, int32_t *order_out,
+                        int32_t *n_out) {
+  VTRY
+  MIG_CHECK(n_poses >= 0 && n_heavy >= 0 && order_out && n_out && (n_poses == 0 || coords), 1, "bad arguments");
+  const float *key = sort_order == MI_SORT_ENERGY ? energy : (sort_order == MI_SORT_CNNAFFINITY ? cnnaffinity : cnnscore);
+  MIG_CHECK(n_poses == 0 || key, 1, "the array of the requested sort key is NULL");
+  std::vector<int> idx(n_poses);
+  for (int i = 0; i < n_poses; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    return sort_order == MI_SORT_ENERGY ? key[a] < key[b] : key[a] > key[b];
+  });
+  std::vector<int> kept;
+  for (int i : idx) {
+    int closest = (int)kept.size();
+    float best = 3.402823466e+38f;
+    for (size_t k = 0; k < kept.size(); k++) {  // find_closest, coords.cpp:34-41
+      float acc = 0;
+      const float *a = coords + (size_t)i * n_heavy * 3, *b = coords + (size_t)kept[k] * n_heavy * 3;
+      for (int h = 0; h < n_heavy; h++) {
+        const float dx = a[3 * h] - b[3 * h], dy = a[3 * h + 1] - b[3 * h + 1], dz = a[3 * h + 2] - b[3 * h + 2];
+        acc += dx * dx + dy * dy + dz * dz;
+      }
+      const float r = n_heavy > 0 ? std::sqrt(acc / n_heavy) : 0;
+      if (k == 0 || r < best) {
+        closest = (int)k;
+        best = r;
+      }
+    }
+    if (closest >= (int)kept.size() || best > min_rmsd) kept.push_back(i);
+  }
+  for (size_t k = 0; k < kept.size(); k++) order_out[k] = kept[k];
+  *n_out = (int)kept.size();
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// merge_output_containers (parallel_mc.cpp:165-181): fold the per-chain containers into one with
+// add_to_output_container (coords.cpp:43-56) at min_rmsd (gnina: 2.0) and max_size, then sort.  Host only.
+// in_*: [B][S]... as produced by mi_vina_mc_batch; out arrays sized max_size.
+mi_status mi_merge_mc_outputs(const int32_t *in_n, const float *in_e, const float *in_conf, const float *in_coords,
+                              int B, int S, int conf_len, int n_heavy, float min_rmsd, int max_size, int32_t *out_n,
+                              float *out_e, float *out_conf, float *out_coords) {
+  VTRY
+  MIG_CHECK(in_n && in_e && in_conf && in_coords && out_n && out_e && out_conf && out_coords && B >= 0 && S > 0 &&
+                max_size > 0,
+            1, "bad arguments");
+  struct Ent {
+    float e;
+    const float *conf, *xyz;
+  };
+  std::vector<Ent> out;
+  auto rmsd = [&](const float *a, const float *b) {
+    float acc = 0;
+    for (int i = 0; i < 3 * n_heavy; i++) {
+      const float d = a[i] - b[i];
+      acc += d * d;
+    }
+    return n_heavy > 0 ? std::sqrt(acc / n_heavy) : 0.f;
+  };
+  for (int b = 0; b < B; b++)
+    for (int o = 0; o < in_n[b]; o++) {
+      Ent t{in_e[(size_t)b * S + o], in_conf + ((size_t)b * S + o) * conf_len,
+            in_coords + ((size_t)b * S + o) * 3 * n_heavy};
+      size_t closest = out.size();
+      float best = 3.402823466e+38f;
+      for (size_t k = 0; k < out.size(); k++) {
+        const float r = rmsd(t.xyz, out[k].xyz);
+        if (k == 0 || r < best) {
+          closest = k;
+          best = r;
+        }
+      }
+      if (closest < out.size() && best < min_rmsd) {
+        if (t.e < out[closest].e) out[closest] = t;
+      } else if ((int)out.size() < max_size) {
+        out.push_back(t);
+      } else if (!out.empty() && t.e < out.back().e) {
+        out.back() = t;
+      }
+      std::stable_sort(out.begin(), out.end(), [](const Ent &x, const Ent &y) { return x.e < y.e; });
+    }
+  *out_n = (int)out.size();
+  for (size_t k = 0; k < out.size(); k++) {
+    out_e[k] = out[k].e;
+    std::memcpy(out_conf + k * conf_len, out[k].conf, sizeof(float) * conf_len);
+    std::memcpy(out_coords + k * 3 * n_heavy, out[k].xyz, sizeof(float) * 3 * n_heavy);
+  }
+  return MI_OK;
+  VCATCH_STATUS
+}
+
 void *mi_vina_stream(mi_vina *vv) { return vv ? (void *)reinterpret_cast<Vina *>(vv)->stream : nullptr; }
 
 }  // extern "C"

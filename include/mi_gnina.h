@@ -222,6 +222,18 @@ mi_status mi_vina_mc_batch(mi_vina *, int B, const uint64_t *seeds, const float 
                            const mi_mc_params *params, int32_t *out_n, float *out_e, float *out_conf,
                            float *out_coords, int32_t *evals);
 int mi_vina_ligand_heavy_atoms(const mi_vina *);
+/* do_search's ranking tail (main.cpp:348-361): sort (pose_sort_order: CNNscore / CNNaffinity descending,
+ * Energy ascending) then remove_redundant(out_cont, out_min_rmsd) (main.cpp:182-192).  Host only.
+ * coords [n_poses][n_heavy][3]; order_out [n_poses] receives the kept pose indices, best first. */
+/* merge_output_containers (parallel_mc.cpp:165-181): fold the per-chain containers of mi_vina_mc_batch
+ * into one (add_to_output_container with min_rmsd, gnina uses 2.0, and max_size), sorted by energy.  Host only. */
+mi_status mi_merge_mc_outputs(const int32_t *in_n, const float *in_e, const float *in_conf, const float *in_coords,
+                              int B, int S, int conf_len, int n_heavy, float min_rmsd, int max_size, int32_t *out_n,
+                              float *out_e, float *out_conf, float *out_coords);
+enum { MI_SORT_CNNSCORE = 0, MI_SORT_CNNAFFINITY = 1, MI_SORT_ENERGY = 2 };
+mi_status mi_rank_poses(const float *cnnscore, const float *cnnaffinity, const float *energy, const float *coords,
+                        int n_poses, int n_heavy, int sort_order, float min_rmsd, int32_t *order_out,
+                        int32_t *n_out);
 void *mi_vina_stream(mi_vina *);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this

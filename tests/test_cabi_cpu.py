@@ -90,3 +90,19 @@ def test_synth_generator_is_deterministic_and_in_spec():
     d0 = np.linalg.norm(poses[0][:, None] - poses[0][None], axis=-1)
     d3 = np.linalg.norm(poses[3][:, None] - poses[3][None], axis=-1)
     assert np.abs(d0 - d3).max() < 1e-4
+
+
+def test_rank_poses_sort_and_remove_redundant(capi):
+    """do_search's tail (main.cpp:182-192,348-361) is host logic: runs without a GPU."""
+    rng = np.random.RandomState(0)
+    base = rng.normal(size=(6, 10, 3)).astype(np.float32) * 5
+    coords = np.concatenate([base, base[:2] + 0.1], axis=0)             # poses 6,7 are near-duplicates of 0,1
+    score = np.array([0.9, 0.2, 0.5, 0.7, 0.1, 0.3, 0.95, 0.15], dtype=np.float32)
+    aff = np.arange(8, dtype=np.float32)
+    energy = -score
+    keep = capi.rank_poses(score, aff, energy, coords, 0, 1.0)
+    assert list(keep) == [6, 3, 2, 5, 1, 4]          # 0 dropped (dup of 6, lower score); 7 dropped (dup of 1)
+    assert list(capi.rank_poses(score, aff, energy, coords, 2, 1.0)) == [6, 3, 2, 5, 1, 4]   # by energy ascending
+    assert list(capi.rank_poses(score, aff, energy, coords, 1, 1.0)) == [7, 6, 5, 4, 3, 2]   # by affinity descending
+    assert len(capi.rank_poses(score, aff, energy, coords, 0, 0.0)) == 8                      # nothing is redundant
+    assert len(capi.rank_poses(score[:0], aff[:0], energy[:0], coords[:0], 0, 1.0)) == 0
