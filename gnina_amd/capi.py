@@ -26,7 +26,7 @@ SYMBOLS = [
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
-    "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs",
+    "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs", "mi_vina_eval_latency",
 ]
 
 _lib = None
@@ -153,6 +153,8 @@ def lib():
         L.mi_merge_mc_outputs.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp,
                                           vp, vp]
         L.mi_merge_mc_outputs.restype = C.c_int
+        L.mi_vina_eval_latency.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.mi_vina_eval_latency.restype = C.c_int
         L.mi_vina_stream.argtypes = [vp]
         L.mi_vina_stream.restype = vp
         _lib = L
@@ -355,6 +357,12 @@ class Vina:
                        len(a["pairs"]), _ptr(a["pairs"]))
         check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
         self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
+
+    def eval_latency_us(self, confs, mode, reps=200):
+        confs = _f32(confs).reshape(-1, 7 + self.n_tors)
+        ms = C.c_float()
+        check(lib().mi_vina_eval_latency(self.handle, _ptr(confs), len(confs), mode, reps, C.byref(ms)))
+        return 1e3 * ms.value / reps
 
     def refine_batch(self, confs, v=(1000.0, 1000.0, 1000.0), max_iters=None):
         """refine_structure: BFGS on the direct receptor term with the slope ladder -> (e, confs, tries)"""

@@ -32,6 +32,7 @@ struct VinaEnv {
   // direct (grid-free) receptor term = the non_cache igrid (non_cache.cpp:52-83,125-179), and the
   // exact pair functions = precalculate_exact (precalculate.h:452-494)
   int direct, exact;
+  int stage;  // copy the ligand description into LDS (set by the launchers)
   const float4 *rec;  // (x, y, z, smt bits)
   int n_rec;
   float w5[5];
@@ -78,17 +79,19 @@ struct VinaPopulateArgs {
   float *out;  // [(dimz)][(dimy)][(dimx)], x fastest
 };
 
-size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs);
+size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage);
 void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
 // confs [B][7+T]; energy [B]; change [B][6+T] or null; coords [B][n_atoms][3] or null
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
-size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved);
+size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage);
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s);
 // refine_structure (main.cpp:131-171): BFGS on the direct receptor term with the slope ladder 10, 100, ...
+void launch_vina_eval_repeat(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, int mode, int reps,
+                             float *energy, hipStream_t s);
 void launch_vina_refine(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                         int max_iters, float *energy, int *tries, hipStream_t s);
 

@@ -187,7 +187,13 @@ __device__ __forceinline__ float norm_angle(float x) {  // g_normalize_angle, qu
 
 __device__ __forceinline__ void angle_to_quat(float ax, float ay, float az, float angle, float *q) {
   angle = norm_angle(angle);
-  float c = cosf(angle / 2), s = sinf(angle / 2);
+  float c, s;
+#ifdef MIG_FAST_SINCOS
+  s = __sinf(angle / 2);
+  c = __cosf(angle / 2);
+#else
+  sincosf(angle / 2, &s, &c);  // one shared argument reduction; same values as sinf / cosf
+#endif
   q[0] = c;
   q[1] = s * ax;
   q[2] = s * ay;
@@ -237,6 +243,7 @@ __device__ __forceinline__ void mat_vec(const float *m, float vx, float vy, floa
 // ---- per-wave LDS workspace -----------------------------------------------------------------------
 struct WaveWork {
   float *origin, *axis, *M, *q;  // node frames
+  float *cs;                     // [2 n_nodes] cos / sin of every half torsion angle
   float *coords, *forces;        // [3 n_atoms]
   float *node_ft;                // [6 n_nodes]
   float4 *pair_out;              // [n_pairs]
@@ -255,21 +262,67 @@ __device__ WaveWork carve_work(float *&p, const VinaLigand &L) {
   w.axis = carve(p, 3 * L.n_nodes);
   w.M = carve(p, 9 * L.n_nodes);
   w.q = carve(p, 4 * L.n_nodes);
+  w.cs = carve(p, 2 * L.n_nodes);
   w.coords = carve(p, 3 * L.n_atoms);
   w.forces = carve(p, 3 * L.n_atoms);
   w.node_ft = carve(p, 6 * L.n_nodes);
   return w;
 }
 
+// Copy the (small, read-many) ligand description from global memory into LDS so that the sequential
+// tree walk and the per-pair / per-atom index look-ups of every evaluation hit LDS (~64 cycles) instead of
+// L2 (~200-500 cycles).  Returns a VinaLigand whose pointers address the LDS copies.
+__device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
+  const int lane = threadIdx.x;
+  VinaLigand L = G;
+  auto cp_i = [&](const int *src, int n) -> const int * {
+    int *dst = reinterpret_cast<int *>(carve(p, n));
+    for (int i = lane; i < n; i += 64) dst[i] = src[i];
+    return dst;
+  };
+  auto cp_f = [&](const float *src, int n) -> const float * {
+    float *dst = carve(p, n);
+    for (int i = lane; i < n; i += 64) dst[i] = src[i];
+    return dst;
+  };
+  L.smt = cp_i(G.smt, G.n_atoms);
+  L.node_of_atom = cp_i(G.node_of_atom, G.n_atoms);
+  L.parent = cp_i(G.parent, G.n_nodes);
+  L.abeg = cp_i(G.abeg, G.n_nodes);
+  L.aend = cp_i(G.aend, G.n_nodes);
+  L.child_start = cp_i(G.child_start, G.n_nodes + 1);
+  L.child_list = cp_i(G.child_list, G.n_nodes);  // a tree has n_nodes - 1 edges
+  L.pairs = reinterpret_cast<const int2 *>(cp_i(reinterpret_cast<const int *>(G.pairs), 2 * G.n_pairs));
+  L.atom_pair_start = cp_i(G.atom_pair_start, G.n_atoms + 1);
+  L.atom_pair_list = cp_i(G.atom_pair_list, 2 * G.n_pairs);
+  L.heavy_list = cp_i(G.heavy_list, G.n_heavy);
+  L.local_xyz = cp_f(G.local_xyz, 3 * G.n_atoms);
+  L.rel_origin = cp_f(G.rel_origin, 3 * G.n_nodes);
+  L.rel_axis = cp_f(G.rel_axis, 3 * G.n_nodes);
+  __syncthreads();
+  return L;
+}
+
 static size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
-size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs) {
+// Few chains (a single docking job) are latency bound: keep the ligand description in LDS.  Many chains
+// (screening) are throughput bound: spend the LDS on occupancy instead.
+static bool want_stage(int B) { return B <= 2048; }
+
+static size_t ligand_lds_floats(int na, int nn, int np, int nh) {
+  return 2 * pad4(na) + 3 * pad4(nn) + pad4(nn + 1) + pad4(nn) + 2 * pad4(2 * (size_t)np) + pad4(na + 1) + pad4(nh) +
+         pad4(3 * (size_t)na) + 2 * pad4(3 * (size_t)nn);
+}
+
+size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage) {
   size_t f = pad4(4 * (size_t)n_pairs) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
-             pad4(4 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms) + pad4(6 * (size_t)n_nodes);
+             pad4(4 * (size_t)n_nodes) + pad4(2 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms) +
+             pad4(6 * (size_t)n_nodes);
   const size_t nt = n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   f += pad4(nc);  // conf being evaluated
   f += pad4(n);   // change
   if (bfgs) f += 2 * pad4(nc) + 6 * pad4(n) + pad4(n * (n + 1) / 2);
+  if (stage) f += ligand_lds_floats(n_atoms, n_nodes, n_pairs, n_atoms);  // LDS copy of the ligand description
   return f * sizeof(float);
 }
 
@@ -288,38 +341,58 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
                            const WaveWork &w, float *change) {
   constexpr bool DERIV = MODE == 0;
   const int lane = threadIdx.x;
-  // 1. node frames, sequential down the tree (tree.h:152-156, 218-233)
+  // 1. node frames, sequential down the tree (tree.h:152-156, 218-233).  The frame of the previous
+  // node stays in registers: in DFS order the parent is usually the node just computed, so the
+  // dependent chain runs register to register and LDS is only written (for the atom / derivative
+  // stages), read back only at branch points.
+  // (the trigonometry of all torsions is evaluated once, one node per lane: a single wave issues about
+  // one instruction every four cycles, so the serial tree walk below is kept as short as possible)
+  for (int k = 1 + lane; k < L.n_nodes; k += 64) {
+    const float angle = norm_angle(conf[7 + (k - 1)]);  // angle_to_quaternion, quaternion.h:284-291
+    float sn, cn;
+    sincosf(angle / 2, &sn, &cn);
+    w.cs[2 * k] = cn;
+    w.cs[2 * k + 1] = sn;
+  }
+  __syncthreads();
   if (lane == 0) {
+    float q[4], M[9], o[3];
+    int prev = -1;
     for (int k = 0; k < L.n_nodes; k++) {
-      float *q = w.q + 4 * k, *M = w.M + 9 * k;
+      float ax = 0.f, ay = 0.f, az = 0.f;
       if (k == 0) {
-        w.origin[0] = conf[0];
-        w.origin[1] = conf[1];
-        w.origin[2] = conf[2];
-        q[0] = conf[3];
-        q[1] = conf[4];
-        q[2] = conf[5];
-        q[3] = conf[6];
-        w.axis[0] = w.axis[1] = w.axis[2] = 0.f;
+        o[0] = conf[0], o[1] = conf[1], o[2] = conf[2];
+        q[0] = conf[3], q[1] = conf[4], q[2] = conf[5], q[3] = conf[6];
       } else {
         const int p = L.parent[k];
-        const float *Mp = w.M + 9 * p;
+        if (p != prev) {  // branch point: reload the parent's frame
+#pragma unroll
+          for (int i = 0; i < 9; i++) M[i] = w.M[9 * p + i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) q[i] = w.q[4 * p + i];
+#pragma unroll
+          for (int i = 0; i < 3; i++) o[i] = w.origin[3 * p + i];
+        }
         float tx, ty, tz;
-        mat_vec(Mp, L.rel_origin[3 * k], L.rel_origin[3 * k + 1], L.rel_origin[3 * k + 2], tx, ty, tz);
-        w.origin[3 * k] = w.origin[3 * p] + tx;
-        w.origin[3 * k + 1] = w.origin[3 * p + 1] + ty;
-        w.origin[3 * k + 2] = w.origin[3 * p + 2] + tz;
-        float ax, ay, az;
-        mat_vec(Mp, L.rel_axis[3 * k], L.rel_axis[3 * k + 1], L.rel_axis[3 * k + 2], ax, ay, az);
-        w.axis[3 * k] = ax;
-        w.axis[3 * k + 1] = ay;
-        w.axis[3 * k + 2] = az;
-        float rq[4];
-        angle_to_quat(ax, ay, az, conf[7 + (k - 1)], rq);
-        quat_mul(rq, w.q + 4 * p, q);
-        quat_norm_approx(q);
+        mat_vec(M, L.rel_origin[3 * k], L.rel_origin[3 * k + 1], L.rel_origin[3 * k + 2], tx, ty, tz);
+        o[0] = o[0] + tx;
+        o[1] = o[1] + ty;
+        o[2] = o[2] + tz;
+        mat_vec(M, L.rel_axis[3 * k], L.rel_axis[3 * k + 1], L.rel_axis[3 * k + 2], ax, ay, az);
+        const float cn = w.cs[2 * k], sn = w.cs[2 * k + 1];
+        float rq[4] = {cn, sn * ax, sn * ay, sn * az}, nq[4];
+        quat_mul(rq, q, nq);
+        quat_norm_approx(nq);
+        q[0] = nq[0], q[1] = nq[1], q[2] = nq[2], q[3] = nq[3];
       }
       quat_to_r3(q, M);
+#pragma unroll
+      for (int i = 0; i < 9; i++) w.M[9 * k + i] = M[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w.q[4 * k + i] = q[i];
+      w.origin[3 * k] = o[0], w.origin[3 * k + 1] = o[1], w.origin[3 * k + 2] = o[2];
+      w.axis[3 * k] = ax, w.axis[3 * k + 1] = ay, w.axis[3 * k + 2] = az;
+      prev = k;
     }
   }
   __syncthreads();
@@ -520,6 +593,43 @@ __global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L
     for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
 }
 
+// latency probe (tools/bench_vina.py): `reps` back-to-back evaluations of one conformation per wave
+template <int MODE>
+__global__ __launch_bounds__(64) void vina_eval_repeat_kernel(VinaEnv env, VinaLigand L, const float *confs, float v0,
+                                                              float v1, float v2, int reps, float *energy) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *p = lds;
+  L = stage_ligand(L, p);
+  WaveWork w = carve_work(p, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  float *conf = carve(p, nc);
+  float *change = carve(p, n);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  float e = 0.f;
+  for (int r = 0; r < reps; r++) {
+    e += eval_conf<MODE>(env, L, conf, v0, v1, v2, w, change);
+    if (lane == 0) conf[0] += 1e-7f * e;  // keep the iterations dependent
+    __syncthreads();
+  }
+  if (lane == 0) energy[b] = e;
+}
+
+void launch_vina_eval_repeat(const VinaEnv &env0, const VinaLigand &lig, const float *confs, int B, int mode, int reps,
+                             float *energy, hipStream_t s) {
+  VinaEnv env = env0;
+  env.stage = 1;
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, true);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(vina_eval_repeat_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 1: hipLaunchKernelGGL(vina_eval_repeat_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 2: hipLaunchKernelGGL(vina_eval_repeat_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 3: hipLaunchKernelGGL(vina_eval_repeat_kernel<3>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    default: hipLaunchKernelGGL(vina_eval_repeat_kernel<4>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BFGS kernel: quasi_newton / bfgs<> with fast_line_search (bfgs.h:73-91,357-502)
 // ---------------------------------------------------------------------------------------------
@@ -673,6 +783,7 @@ __global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L
                                                        int *evals_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  if (env.stage) L = stage_ligand(L, pp);
   WaveWork w = carve_work(pp, L);
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   BfgsWork k = carve_bfgs(pp, n, nc);
@@ -698,6 +809,7 @@ __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand
                                                          float v2, int max_iters, float *energy, int *tries_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  if (env.stage) L = stage_ligand(L, pp);
   WaveWork w = carve_work(pp, L);
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   BfgsWork k = carve_bfgs(pp, n, nc);
@@ -731,9 +843,11 @@ __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand
   }
 }
 
-void launch_vina_refine(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+void launch_vina_refine(const VinaEnv &env0, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                         int max_iters, float *energy, int *tries, hipStream_t s) {
-  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true);
+  VinaEnv env = env0;
+  env.stage = want_stage(B) ? 1 : 0;
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
   hipLaunchKernelGGL(vina_refine_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
                      tries);
 }
@@ -776,6 +890,7 @@ struct McRng {
 __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  if (env.stage) L = stage_ligand(L, pp);
   WaveWork w = carve_work(pp, L);
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt, nh = L.n_heavy;
   BfgsWork k = carve_bfgs(pp, n, nc);
@@ -949,13 +1064,15 @@ __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, 
   }
 }
 
-size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved) {
-  return vina_wave_lds_bytes(n_atoms, n_nodes, n_pairs, true) +
+size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage) {
+  return vina_wave_lds_bytes(n_atoms, n_nodes, n_pairs, true, stage) +
          (pad4(7 + n_nodes - 1) + pad4(3 * (size_t)n_heavy) + 64 + pad4(num_saved)) * sizeof(float);
 }
 
-void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s) {
-  const size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved);
+void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s) {
+  VinaEnv env = env0;
+  env.stage = want_stage(B) ? 1 : 0;
+  const size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage);
   hipLaunchKernelGGL(vina_mc_kernel, dim3(B), dim3(64), lds, s, env, lig, a);
 }
 
@@ -1001,7 +1118,7 @@ void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s) {
 
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s) {
-  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false);
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
   // with_deriv: 1 = model::eval_deriv, 0 = model::eval, 2 = cache::eval (grid term only)
   if (with_deriv == 1)
     hipLaunchKernelGGL(vina_eval_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
@@ -1017,9 +1134,11 @@ void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *co
                        coords);
 }
 
-void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
+void launch_vina_bfgs(const VinaEnv &env0, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s) {
-  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true);
+  VinaEnv env = env0;
+  env.stage = want_stage(B) ? 1 : 0;
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
   hipLaunchKernelGGL(vina_bfgs_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy, grad,
                      evals);
 }

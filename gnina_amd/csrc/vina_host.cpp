@@ -144,6 +144,7 @@ static VinaEnv make_env(const Vina &v) {
   e.slope = v.slope;
   e.direct = 0;
   e.exact = 0;
+  e.stage = 0;
   e.rec = v.d_rec.p;
   e.n_rec = v.n_rec;
   for (int i = 0; i < 5; i++) e.w5[i] = v.w5[i];
@@ -290,7 +291,7 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
             1, "NULL array in ligand description");
   Vina &v = *reinterpret_cast<Vina *>(vv);
   const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
-  MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
+  MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
   std::vector<int> node_of(na, -1);
   for (int k = 0; k < nn; k++) {
     MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : d->node_parent[k] >= 0), 1,
@@ -447,7 +448,7 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
             "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
   if (B == 0) return MI_OK;
   const int nt = v.lig.n_nodes - 1, nc = 7 + nt, nh = v.lig.n_heavy, S = P->num_saved;
-  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S) <= 64 * 1024, 1,
+  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true) <= 64 * 1024, 1,
             "ligand too large for the per-wave LDS workspace");
   v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
   v.d_mc_e.ensure((size_t)B * S);
@@ -637,6 +638,31 @@ mi_status mi_merge_mc_outputs(const int32_t *in_n, const float *in_e, const floa
     std::memcpy(out_conf + k * conf_len, out[k].conf, sizeof(float) * conf_len);
     std::memcpy(out_coords + k * 3 * n_heavy, out[k].xyz, sizeof(float) * 3 * n_heavy);
   }
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// latency probe: ms for `reps` dependent evaluations (mode as in mi_vina_eval_batch, 3 = coordinates only)
+mi_status mi_vina_eval_latency(mi_vina *vv, const float *confs, int B, int mode, int reps, float *ms_out) {
+  VTRY
+  MIG_CHECK(vv && confs && B > 0 && reps > 0 && ms_out, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  const int nc = 7 + v.lig.n_nodes - 1;
+  v.d_confs.upload(confs, (size_t)B * nc, v.stream);
+  v.d_energy.ensure(B);
+  const int tmode = mode == 1 ? 0 : (mode == 0 ? 1 : mode);  // ABI mode -> kernel template mode
+  hipEvent_t e0, e1;
+  MIG_HIP(hipEventCreate(&e0));
+  MIG_HIP(hipEventCreate(&e1));
+  launch_vina_eval_repeat(make_env(v), v.lig, v.d_confs.p, B, tmode, 2, v.d_energy.p, v.stream);  // warm-up
+  MIG_HIP(hipEventRecord(e0, v.stream));
+  launch_vina_eval_repeat(make_env(v), v.lig, v.d_confs.p, B, tmode, reps, v.d_energy.p, v.stream);
+  MIG_HIP(hipEventRecord(e1, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  MIG_HIP(hipEventElapsedTime(ms_out, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return MI_OK;
   VCATCH_STATUS
 }

@@ -234,6 +234,8 @@ enum { MI_SORT_CNNSCORE = 0, MI_SORT_CNNAFFINITY = 1, MI_SORT_ENERGY = 2 };
 mi_status mi_rank_poses(const float *cnnscore, const float *cnnaffinity, const float *energy, const float *coords,
                         int n_poses, int n_heavy, int sort_order, float min_rmsd, int32_t *order_out,
                         int32_t *n_out);
+/* Latency probe for tools/bench_vina.py: device time (ms) of `reps` dependent evaluations per wave. */
+mi_status mi_vina_eval_latency(mi_vina *, const float *confs, int B, int mode, int reps, float *ms_out);
 void *mi_vina_stream(mi_vina *);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this

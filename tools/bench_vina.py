@@ -52,6 +52,10 @@ def main():
         dt = time.perf_counter() - t0
         res["bfgs"].append({"B": B, "ms": round(1e3 * dt, 2), "evals": int(ev.sum()), "evals_per_s": round(ev.sum() / dt),
                             "us_per_eval_per_chain": round(1e6 * dt / ev.max(), 2)})
+    c64 = np.stack([synth.random_conf(rng, lig, sc["center"], 1.0) for _ in range(64)])
+    res["eval_latency_us_B64"] = {name: round(vina.eval_latency_us(c64, mode), 2) for name, mode in
+                                  (("coords_only", 3), ("receptor_grid_only", 2), ("pairs_only", 4),
+                                   ("energy", 0), ("energy_and_gradient", 1))}
     # CPU oracle, one core
     T = V.Tables()
     grids = {t: V.cache_populate(T, gd, sc["rec_xyz"], sc["rec_smt"], t) for t in types[:1]}
