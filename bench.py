@@ -89,6 +89,16 @@ def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
                       f"CNN {1e3 * tc / n:.1f} ms/pose (PyTorch CPU fp32, {cores} threads)"}, scores
 
 
+def pmc_entry(kernel_label):
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        pm = json.load(open(path))
+        want = pm.get("roofline_kernel_map", {}).get(kernel_label)
+        return pm["kernels"].get(want) if want else None
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/latest_pmc.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
@@ -217,6 +227,13 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_flops_per_launch": dom_conv["flops"] / dom_conv["launches"],
                 "poses_per_launch": dom_conv["poses"] // dom_conv["launches"],
+                "note": "achieved = ALGORITHMIC (dense) FLOPs / launch time; the kernel skips channel quads that are "
+                        "all-zero inside a tile (exact zeros, bit-identical sum), so the MFMA pipe executes fewer: see "
+                        "mfma_executed_*",
+                "mfma_executed_flops_per_launch": (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch"),
+                "mfma_executed_tflops": (round((pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch", 0)
+                                               / (avg_ms * 1e-3) / 1e12, 2)
+                                         if (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch") else None),
             },
             "kernels": [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
                          "ms_per_step": round(r["ms_total"] / args.steps, 4),
