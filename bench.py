@@ -123,7 +123,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
