@@ -308,6 +308,143 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-output-channel variant for the Dense blocks (Cout = 16): v_mfma_f32_16x16x4_f32.
+// A 32-wide tile would run half empty; here N = 16 exactly.  An M-tile is 16 voxels = two 2x2x2
+// cells (row = cell*8 + x*4 + y*2 + z); the four k of one instruction are channel j of FOUR
+// different quads (lane group l>>4 picks the quad), so one ds_read_b128 per lane still feeds four
+// MFMAs.  TM independent accumulators per wave cover the 40-cycle dependent latency of the 16x16x4
+// form.  Dense-block convs have eval-BN on their input (folded into the staging), ReLU, no pooling,
+// and write at a channel offset of the concat buffer.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TM>
+__global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
+  constexpr int NTHREADS = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wm = tid >> 6;
+  const int kq = lane >> 4;   // which of the four quads of a step this lane feeds
+  const int row = lane & 15;  // A row / B column
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int b = blockIdx.x / tiles_per_pose;
+  int t = blockIdx.x - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const int HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo;
+  const int HV = HX * HY * HZ;
+  const int CC4 = p.cc4, CCs = p.ccs;
+  const int taps = p.ksize == 3 ? 27 : 1;
+  const int Q = taps * CC4;       // quads per chunk
+  const int P4 = (Q + 3) >> 2;    // quad quartets per chunk
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_tile = smem;
+  int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);
+  for (int q = tid; q < Q; q += NTHREADS) {
+    int tap = q / CC4, c4 = q - tap * CC4;
+    int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = (p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 2) & 1, cell_in_mt = row >> 3;
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cell = (wm * TM + m) * 2 + cell_in_mt;
+    if (cell >= NC) cell = 0;
+    int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs;
+  }
+  f32x4 acc[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) acc[m] = {0.f, 0.f, 0.f, 0.f};
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
+  const size_t wstride = (size_t)p.coutp * 4;  // 16 * 4 floats per quad row
+  const float *wq = p.wp + (size_t)row * 4;
+
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    __syncthreads();
+    const int c_base = chunk * CC4 * 4;
+    for (int it = tid; it < HV * CC4; it += NTHREADS) {
+      int hv = it / CC4, c4 = it - hv * CC4;
+      int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+      int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S &&
+          chunk * CC4 + c4 < p.cin4) {
+        const int c = c_base + c4 * 4;
+        val = *reinterpret_cast<const float4 *>(in_b + (((size_t)x * S + y) * S + z) * p.in_cs + c);
+        if (p.bn_scale) {
+          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
+          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
+          val.x = val.x * sc.x + sh.x;
+          val.y = val.y * sc.y + sh.y;
+          val.z = val.z * sc.z + sh.z;
+          val.w = val.w * sc.w + sh.w;
+        }
+      }
+      *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
+    }
+    __syncthreads();
+
+    // K loop over quad quartets; weights packed [chunk][quartet][4][16][4], pad quads have zero weights
+    const float *wchunk = wq + (size_t)chunk * P4 * 4 * wstride + (size_t)kq * wstride;
+    float4 w = *reinterpret_cast<const float4 *>(wchunk), wn;
+    for (int pr = 0; pr < P4; pr++) {
+      int q = 4 * pr + kq;
+      q = q < Q ? q : Q - 1;
+      const int qo = s_qoff[q];
+      float4 a[TM];
+#pragma unroll
+      for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+      const int prn = pr + 1 < P4 ? pr + 1 : pr;
+      wn = *reinterpret_cast<const float4 *>(wchunk + (size_t)prn * 4 * wstride);
+#pragma unroll
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, w.x, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, w.y, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, w.z, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, w.w, acc[m], 0, 0, 0);
+      w = wn;
+    }
+  }
+
+  // epilogue: accumulator row = 4 * (lane >> 4) + reg, column = lane & 15
+  float *out_b = p.out + (size_t)b * S * S * S * p.out_cs + p.out_c0;
+  const int ncx = S / 2;
+  const int ch = row;
+  if (ch < p.cout) {
+    const float bias = p.bias[ch];
+#pragma unroll
+    for (int m = 0; m < TM; m++) {
+      const int cell = (wm * TM + m) * 2 + (kq >> 1);
+      if (cell >= NC) continue;
+      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int vx = 2 * gcx + (kq & 1), vy = 2 * gcy + (r >> 1), vz = 2 * gcz + (r & 1);
+        float v = acc[m][r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        out_b[(((size_t)vx * S + vy) * S + vz) * p.out_cs + ch] = v;
+      }
+    }
+  }
+}
+
 size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
@@ -340,6 +477,24 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1>(p, B, s); break;
     case CONV_CFG_3x2_2x1: launch_cfg<3, 2, 2, 1>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
+    case CONV_CFG_N16_TM4:
+    case CONV_CFG_N16_TM3: {
+      dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
+      const size_t lds = conv_lds_bytes(p);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma16_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma16_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      if (cfg == CONV_CFG_N16_TM4)
+        hipLaunchKernelGGL(conv3d_mfma16_kernel<4>, grid, block, lds, s, p);
+      else
+        hipLaunchKernelGGL(conv3d_mfma16_kernel<3>, grid, block, lds, s, p);
+      break;
+    }
     default: break;
   }
 }
@@ -348,6 +503,8 @@ void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
     case CONV_CFG_3x2_2x1: *wm = 3, *wn = 2, *tm = 2, *tn = 1; break;
+    case CONV_CFG_N16_TM4: *wm = 4, *wn = 1, *tm = 4, *tn = 1; break;
+    case CONV_CFG_N16_TM3: *wm = 4, *wn = 1, *tm = 3, *tn = 1; break;
     default: *wm = 1, *wn = 4, *tm = 7, *tn = 1; break;
   }
 }

@@ -106,7 +106,18 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.pool = pool_mode;
   a.out_c0 = dst_c0;
   // workgroup shape
-  if (cells == 3 && NT % 4 == 0) {
+  const bool n16 = o.cout == 16 && pool_mode == 0 && !backward;  // Dense-block convs: 16-wide MFMA tiles
+  if (n16) {
+    a.coutp = 16;
+    if (cells == 6) {
+      cp.cfg = CONV_CFG_N16_TM3;  // 4 waves x 3 M-tiles x 2 cells = 24 cells = 2x2x6
+      a.tcx = 2, a.tcy = 2, a.tcz = 6;
+    } else {
+      cp.cfg = CONV_CFG_N16_TM4;  // 4 waves x 4 M-tiles x 2 cells = 32 cells
+      if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
+      else a.tcx = 2, a.tcy = 4, a.tcz = 4;
+    }
+  } else if (cells == 3 && NT % 4 == 0) {
     cp.cfg = CONV_CFG_1x4_7x1;
     a.tcx = a.tcy = a.tcz = 3;
   } else if (cells == 6 && NT % 2 == 0) {
@@ -144,8 +155,9 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.cin4 = cin4;
   // pack weights [chunk][pair][2][coutp][4]
   const int taps = o.ksize * o.ksize * o.ksize;
-  const int Q = taps * a.cc4, P = (Q + 1) / 2;
-  std::vector<float> wp((size_t)a.nchunks * P * 2 * a.coutp * 4, 0.f);
+  const int kstep = n16 ? 4 : 2;  // quads per MFMA step: pairs for 32x32x2, quartets for 16x16x4
+  const int Q = taps * a.cc4, P = (Q + kstep - 1) / kstep;
+  std::vector<float> wp((size_t)a.nchunks * P * kstep * a.coutp * 4, 0.f);
   // forward: canonical [tap][cin][cout]; backward: W'[tap][co][ci] = W[taps-1-tap][ci][co] (flipped, transposed)
   std::vector<float> wT;
   const float *w = m.d.data.data() + o.w_off;
@@ -160,15 +172,15 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
   for (int ch = 0; ch < a.nchunks; ch++)
     for (int pr = 0; pr < P; pr++)
-      for (int kh = 0; kh < 2; kh++) {
-        int q = 2 * pr + kh;
+      for (int kh = 0; kh < kstep; kh++) {
+        int q = kstep * pr + kh;
         if (q >= Q) continue;
         int tap = q / a.cc4, c4 = q % a.cc4;
         for (int j = 0; j < 4; j++) {
           int c = (ch * a.cc4 + c4) * 4 + j;
           if (c >= o.cin) continue;
           for (int n = 0; n < o.cout; n++)
-            wp[((((size_t)ch * P + pr) * 2 + kh) * a.coutp + n) * 4 + j] = w[((size_t)tap * o.cin + c) * o.cout + n];
+            wp[((((size_t)ch * P + pr) * kstep + kh) * a.coutp + n) * 4 + j] = w[((size_t)tap * o.cin + c) * o.cout + n];
         }
       }
   a.wp = push_dev(m, wp);
