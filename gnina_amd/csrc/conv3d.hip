@@ -477,6 +477,8 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1>(p, B, s); break;
     case CONV_CFG_3x2_2x1: launch_cfg<3, 2, 2, 1>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
+    case CONV_CFG_4x1_2x3: launch_cfg<4, 1, 2, 3>(p, B, s); break;
+    case CONV_CFG_4x1_1x5: launch_cfg<4, 1, 1, 5>(p, B, s); break;
     case CONV_CFG_N16_TM4:
     case CONV_CFG_N16_TM3: {
       dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
@@ -503,6 +505,8 @@ void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
     case CONV_CFG_3x2_2x1: *wm = 3, *wn = 2, *tm = 2, *tn = 1; break;
+    case CONV_CFG_4x1_2x3: *wm = 4, *wn = 1, *tm = 2, *tn = 3; break;
+    case CONV_CFG_4x1_1x5: *wm = 4, *wn = 1, *tm = 1, *tn = 5; break;
     case CONV_CFG_N16_TM4: *wm = 4, *wn = 1, *tm = 4, *tn = 1; break;
     case CONV_CFG_N16_TM3: *wm = 4, *wn = 1, *tm = 3, *tn = 1; break;
     default: *wm = 1, *wn = 4, *tm = 7, *tn = 1; break;

@@ -117,6 +117,13 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
       if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
       else a.tcx = 2, a.tcy = 4, a.tcz = 4;
     }
+  } else if (o.ksize == 1 && NT == 3 && cells % 4 == 0 && !backward) {
+    cp.cfg = CONV_CFG_4x1_2x3;  // 1x1 bottleneck 96 -> 96: all output channels in one workgroup (input read once)
+    a.tcx = 2, a.tcy = 4, a.tcz = 4;
+  } else if (o.ksize == 1 && NT == 5 && !backward) {
+    cp.cfg = CONV_CFG_4x1_1x5;  // 1x1 bottleneck 160 -> 160: 4 waves x 1 M-tile = 16 cells
+    if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 3;  // 12 cells used of 16
+    else a.tcx = 2, a.tcy = 2, a.tcz = 4;
   } else if (cells == 3 && NT % 4 == 0) {
     cp.cfg = CONV_CFG_1x4_7x1;
     a.tcx = a.tcy = a.tcz = 3;
