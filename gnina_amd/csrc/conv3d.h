@@ -30,6 +30,10 @@ struct ConvArgs {
   const float *in_act;             // mask source; stride in_act_cs
   int in_act_cs;
   unsigned char *argmax_out;       // pool == 1: arg-max index (x*4+y*2+z) per pooled output, or nullptr
+  // Dense-block backward (pool == 0 only): out[ch] (+)= acc * out_scale[ch].  out_scale is the eval-BatchNorm
+  // scale of the forward layer's input (d(BN x)/dx); accumulate adds into the concat buffer's gradient.
+  const float *out_scale;          // [coutp] or nullptr
+  int accumulate;
   int sparse;        // skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients)
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
@@ -48,6 +52,9 @@ void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N,
 void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,
                     hipStream_t s);
 void launch_gmax(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
+// global max pool backward: g_in [B][S]^3[in_cs] = g_out[b][c] at the first arg-max voxel of channel c, 0 elsewhere
+void launch_gmax_backward(const float *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
+                          int S, hipStream_t s);
 void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
                      int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s);
 void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s);

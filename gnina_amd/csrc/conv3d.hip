@@ -297,10 +297,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
           for (int r = 1; r < 8; r++) s = s + v[r];  // r = x*4 + y*2 + z: avg_pool3d's (kd,kh,kw) order
           out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
         } else {
+          const float osc = p.out_scale ? p.out_scale[ch] : 1.0f;
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-            out_b[(((size_t)vx * So + vy) * So + vz) * p.out_cs + ch] = v[r];
+            float *dst = out_b + (((size_t)vx * So + vy) * So + vz) * p.out_cs + ch;
+            float val = p.out_scale ? v[r] * osc : v[r];
+            if (p.accumulate) val = *dst + val;
+            *dst = val;
           }
         }
       }
@@ -607,6 +611,29 @@ __global__ void gmax_kernel(const float *in, float *out, int C, int in_cs, int o
 
 void launch_gmax(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s) {
   hipLaunchKernelGGL(gmax_kernel, dim3(B), dim3(256), 0, s, in, out, C, in_cs, out_cs, S * S * S);
+}
+
+// max_pool3d(kernel = whole grid) backward: the gradient goes to the first maximum in (x, y, z) scan order
+__global__ void gmax_backward_kernel(const float *act, const float *g_out, float *g_in, int C, int in_cs, int out_cs,
+                                     int S3) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float *src = act + (size_t)b * S3 * in_cs + c;
+    float m = src[0];
+    int am = 0;
+    for (int v = 1; v < S3; v++) {
+      const float t = src[(size_t)v * in_cs];
+      if (t > m) m = t, am = v;
+    }
+    float *dst = g_in + (size_t)b * S3 * in_cs + c;
+    const float g = g_out[(size_t)b * out_cs + c];
+    for (int v = 0; v < S3; v++) dst[(size_t)v * in_cs] = v == am ? g : 0.f;
+  }
+}
+
+void launch_gmax_backward(const float *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
+                          int S, hipStream_t s) {
+  hipLaunchKernelGGL(gmax_backward_kernel, dim3(B), dim3(256), 0, s, act, g_out, g_in, C, in_cs, out_cs, S * S * S);
 }
 
 // ---------------------------------------------------------------------------------------------

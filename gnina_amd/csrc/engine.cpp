@@ -201,6 +201,8 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.in_act = nullptr;
   a.in_act_cs = 0;
   a.argmax_out = nullptr;
+  a.out_scale = nullptr;
+  a.accumulate = 0;
   if (o.bn_scale_off >= 0) {
     std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
     std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -258,9 +260,16 @@ static Model *build_model(ModelDesc &&desc) {
         }
         plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
         st.has_bn = o.bn_scale_off >= 0;
-        if (grad && !st.has_bn && o.src != o.dst && o.cout % 4 == 0) {
+        if (grad && o.cout % 4 == 0) {
           plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
           st.has_bwd = true;
+          if (st.has_bn) {  // d(BN x)/dx: the transposed conv's output is scaled per (forward-input) channel
+            std::vector<float> sc(st.bwd.a.coutp, 0.f);
+            std::copy(d.data.begin() + o.bn_scale_off, d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+            st.bwd.a.out_scale = push_dev(*m, sc);
+          }
+          // a Dense-block layer reads and extends the same concat buffer: its input gradient accumulates
+          st.bwd.a.accumulate = o.src == o.dst ? 1 : 0;
         }
         m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
       } else if (o.kind == OpKind::Pool) {
@@ -287,13 +296,14 @@ static Model *build_model(ModelDesc &&desc) {
     return out;
   };
   m->steps = build_steps(false);
-  // gradient program: supported for plain conv/pool stacks (Default2017 / Default2018 families)
+  // gradient program: conv / pool stacks (Default2017 / Default2018 families) and the Dense family
+  // (BatchNorm-on-input convs growing a concat buffer, global max pool)
   m->grad_supported = !d.skip_softmax && !d.apply_logistic_loss;
   if (!m->grad_supported) m->grad_unsupported_reason = "skip_softmax / apply_logistic_loss models";
   for (const Op &o : d.ops) {
-    if (o.kind == OpKind::GMax || (o.kind == OpKind::Conv && (o.bn_scale_off >= 0 || o.src == o.dst))) {
+    if (o.kind == OpKind::Conv && o.cout % 4 != 0) {
       m->grad_supported = false;
-      m->grad_unsupported_reason = "Dense family (BatchNorm / concat / global max pooling)";
+      m->grad_unsupported_reason = "conv output channels not a multiple of 4";
     }
     if (o.kind == OpKind::Pool && o.pool_mode == 1 && &o != &d.ops[0]) {
       // a max pool must be fusable into the conv that feeds it
@@ -702,9 +712,9 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         MIG_CHECK(st.has_bwd, 1, "gradient not supported for this layer");
         ConvArgs a = st.bwd.a;
         const int dst = st.conv.dst, src = st.conv.src;
-        a.in = g_ptr(dst);
+        a.in = g_ptr(dst) + st.conv.a.out_c0;  // Dense layers: the 16-channel slice this conv produced
         a.in_cs = m->buf_cp[dst];
-        a.in_act = act_ptr(dst);
+        a.in_act = act_ptr(dst) + st.conv.a.out_c0;
         a.in_act_cs = m->buf_cp[dst];
         if (st.conv.a.pool == 1) {
           a.sparse = 1;  // un-pooled gradient: at most 1 of 8 voxels per cell is non-zero
@@ -720,6 +730,12 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         const double S3 = (double)a.S * a.S * a.S;
         ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * st.conv.cin * st.conv.a.cout, 0.0, nb);
         launch_conv(a, st.bwd.cfg, nb, s.stream);
+        break;
+      }
+      case OpKind::GMax: {
+        ProfScope ps(s, "gmax_backward", 0.0, 0.0, nb);
+        launch_gmax_backward(act_ptr(st.src), g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.src],
+                             m->buf_cp[st.dst], m->d.bufs[st.src].S, s.stream);
         break;
       }
       case OpKind::Pool: {

@@ -39,7 +39,8 @@ def oracle_lig_gradient(blob, rec_xyz, rec_smt, pose, lig_smt):
     return float(loss[0]), g
 
 
-@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "crossdock_default2018_KD_4"])
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "crossdock_default2018_KD_4", "dense",
+                                  "dense_1_3", "dense_1_3_PT_KD_3"])
 def test_ligand_gradient_matches_oracle(capi, CG, name):
     blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
     rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
@@ -88,10 +89,18 @@ def test_gradient_descends_the_loss(capi, CG):
     assert (out2["loss"] < out["loss"] + 1e-7).all() and (out2["loss"] < out["loss"]).any()
 
 
-def test_dense_family_reports_unsupported(capi, CG):
-    name = "dense"
-    s = capi.Scorer([name])
-    s.set_receptor(CG[name + "/rec_xyz"], CG[name + "/rec_smt"])
-    with pytest.raises(capi.MiGninaError) as ei:
-        s.score_grad(CG[name + "/poses"][:1], CG[name + "/lig_smt"])
-    assert "Dense" in str(ei.value)
+def test_default_ensemble_gradient(capi, CG):
+    """gnina's default ensemble (cnn_torch_scorer.cpp:33-35): two Dense models + one Default2018 model; the
+    ligand gradient is the ensemble mean (m.scale_minus_forces(1 / cnt), cnn_torch_scorer.cpp:172-175)."""
+    names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]
+    base = "dense_1_3"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{base}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer(names)
+    s.set_receptor(rec_xyz, rec_smt)
+    out = s.score_grad(poses[:2], lig_smt)
+    acc = np.zeros((2, len(lig_smt), 3))
+    for n in names:
+        blob = cnn_ref.Blob(os.path.join(WEIGHTS, n + ".mgw"))
+        for b in range(2):
+            acc[b] += oracle_lig_gradient(blob, rec_xyz, rec_smt, poses[b], lig_smt)[1] / len(names)
+    assert np.abs(out["lig_grad"] - acc).max() < 2e-3 * np.abs(acc).max()
