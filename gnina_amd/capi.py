@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_model_supports_gradient", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_model_supports_gradient", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -98,6 +98,8 @@ def lib():
         L.mi_scorer_score_batch_ex.restype = C.c_int
         L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mi_scorer_score_grad.restype = C.c_int
+        L.mi_scorer_set_flex.argtypes = [vp, vp, C.c_int]
+        L.mi_scorer_score_flex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mi_model_supports_gradient.argtypes = [vp]
         L.mi_model_supports_gradient.restype = C.c_int
         L.mi_scorer_last_model_outputs.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
@@ -255,6 +257,28 @@ class Scorer:
         check(lib().mi_scorer_score_grad(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(pose),
                                          _ptr(aff), _ptr(loss), _ptr(var), _ptr(grad)))
         return {"pose": pose, "affinity": aff, "loss": loss, "variance": var, "lig_grad": grad}
+
+    def set_flex(self, rec_rows):
+        """Receptor rows (of set_receptor's arrays) whose coordinates are supplied per pose."""
+        rec_rows = _i32(rec_rows)
+        self._n_flex = len(rec_rows)
+        check(lib().mi_scorer_set_flex(self.handle, _ptr(rec_rows), len(rec_rows)))
+
+    def score_flex(self, lig_xyz, lig_smt, flex_xyz, centers=None, grad=True):
+        """Scores with per-pose flexible-residue coordinates [B][n_flex][3]; with grad also
+        d loss / d ligand and d loss / d flexible-atom coordinates."""
+        lig_xyz = _f32(lig_xyz)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        lig_smt = _i32(lig_smt)
+        centers = _f32(centers)
+        flex_xyz = _f32(flex_xyz)
+        nf = flex_xyz.shape[1]
+        pose, aff, loss, var = (np.empty(B, dtype=np.float32) for _ in range(4))
+        lg = np.empty((B, L, 3), dtype=np.float32) if grad else None
+        fg = np.empty((B, nf, 3), dtype=np.float32) if grad else None
+        check(lib().mi_scorer_score_flex(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(flex_xyz),
+                                         _ptr(pose), _ptr(aff), _ptr(loss), _ptr(var), _ptr(lg), _ptr(fg)))
+        return {"pose": pose, "affinity": aff, "loss": loss, "variance": var, "lig_grad": lg, "flex_grad": fg}
 
     def last_model_outputs(self, m, B):
         pose, aff, loss = (np.empty(B, dtype=np.float32) for _ in range(3))

@@ -335,6 +335,13 @@ struct TypedReceptor {  // one per distinct (recmap, radius_scaling)
   int n = 0;
   DevBuf<AtomRec> rec;
   DevBuf<int> chan;
+  std::vector<int> row;       // input row of every typed atom (same order as rec)
+  std::vector<int> smt_of;    // its smina type
+  // flexible rows (mi_scorer_set_flex): slot per typed atom for the gather kernel, and the typed flexible
+  // atoms as an (index, constants, channel) list for the voxelizer backward
+  int n_flex_typed = 0;
+  DevBuf<int> flex_slot, flex_perm, flex_chan;
+  DevBuf<LigConsts> flex_consts;
 };
 
 struct VoxGroup {  // models sharing one voxelization: same maps, geometry, radius scale, input pool
@@ -366,6 +373,9 @@ struct Scorer {
   std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
   std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
   DevBuf<float> d_raw3, d_lig_grad;
+  std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
+  DevBuf<float> d_flex, d_flex_grad;    // [B][n_flex][3]
+  const float *cur_flex = nullptr;      // device flex coordinates of the call in flight (or nullptr)
   // outputs per model [n_models][B] and reduced
   DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var;
   int last_B = 0;
@@ -516,6 +526,9 @@ static void set_receptor(Scorer &s, const float *xyz, const int32_t *smt, int n)
         chans[k] = tr->map.chan_of_smt[smt[i]];
       }
       tr->n = (int)idx.size();
+      tr->row = idx;
+      tr->smt_of.resize(idx.size());
+      for (size_t k = 0; k < idx.size(); k++) tr->smt_of[k] = smt[idx[k]];
       tr->rec.upload(recs.data(), recs.size(), s.stream);
       tr->chan.upload(chans.data(), chans.size(), s.stream);
       MIG_HIP(hipStreamSynchronize(s.stream));
@@ -526,6 +539,43 @@ static void set_receptor(Scorer &s, const float *xyz, const int32_t *smt, int n)
   }
   s.have_receptor = true;
   s.n_rec_atoms_in = n;
+  s.flex_rows.clear();
+}
+
+// Declare the receptor rows that move with every pose (flexible side chains).  In the reference these are
+// the first num_flex rows of receptor_coords (dl_scorer.cpp:150-193) and receptor_map sends their
+// gradients back to the model (cnn_torch_scorer.cpp:216-224).
+static void set_flex(Scorer &s, const int32_t *rows, int n_flex) {
+  MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before mi_scorer_set_flex");
+  MIG_CHECK(n_flex >= 0 && (n_flex == 0 || rows), 1, "bad flex arguments");
+  std::vector<int> slot_of_row(s.n_rec_atoms_in, -1);
+  for (int j = 0; j < n_flex; j++) {
+    MIG_CHECK(rows[j] >= 0 && rows[j] < s.n_rec_atoms_in, 1, "flex row out of range");
+    MIG_CHECK(slot_of_row[rows[j]] < 0, 1, "duplicate flex row");
+    slot_of_row[rows[j]] = j;
+  }
+  for (auto &g : s.groups) {
+    TypedReceptor &tr = *s.receptors[g.rec_idx];
+    Model *m = s.models[g.first_model];
+    std::vector<int> slot(tr.n, -1), perm, chan;
+    std::vector<LigConsts> lc;
+    for (int k = 0; k < tr.n; k++) {
+      const int fs = slot_of_row[tr.row[k]];
+      slot[k] = fs;
+      if (fs < 0) continue;
+      const DensityConsts &dc = m->dens[tr.smt_of[k]];
+      perm.push_back(fs);
+      lc.push_back(LigConsts{dc.ar, dc.t2, dc.g2, dc.kexp, dc.inv_ar});
+      chan.push_back(tr.map.chan_of_smt[tr.smt_of[k]]);
+    }
+    tr.n_flex_typed = (int)perm.size();
+    tr.flex_slot.upload(slot.data(), slot.size(), s.stream);
+    tr.flex_perm.upload(perm.data(), perm.size(), s.stream);
+    tr.flex_chan.upload(chan.data(), chan.size(), s.stream);
+    tr.flex_consts.upload(lc.data(), lc.size(), s.stream);
+    MIG_HIP(hipStreamSynchronize(s.stream));
+  }
+  s.flex_rows.assign(rows, rows + n_flex);
 }
 
 struct LigSetup {
@@ -584,6 +634,11 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.rec = tr.rec.p;
   ga.rec_chan = tr.chan.p;
   ga.n_rec = tr.n;
+  if (s.cur_flex && !s.flex_rows.empty()) {
+    ga.rec_flex_slot = tr.flex_slot.p;
+    ga.n_flex = (int)s.flex_rows.size();
+    ga.flex_xyz = s.cur_flex + (size_t)b0 * ga.n_flex * 3;
+  }
   ga.lig_xyz = d_lig_xyz + (size_t)b0 * L * 3;
   ga.L = L;
   ga.lig_perm = s.d_lig_perm.p;
@@ -758,10 +813,11 @@ static float *run_backward(Scorer &s, int mi, int nb) {
 // gradients are averaged over the ensemble like m.scale_minus_forces(1 / cnt).
 static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                              const float *centers, float *pose, float *aff, float *loss, float *var,
-                             float *lig_grad, unsigned flags) {
+                             float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
+                             float *flex_grad = nullptr) {
   MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
-  MIG_CHECK(pose && aff && loss && lig_grad, 1, "output arrays must not be NULL");
+  MIG_CHECK(pose && aff && loss && (lig_grad || flex_grad), 1, "output arrays must not be NULL");
   MIG_CHECK(!(flags & (MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE)), 1, "score_grad takes host pointers");
   for (Model *m : s.models)
     MIG_CHECK(m->grad_supported, 1, "gradient not supported for model " + m->d.name + ": " + m->grad_unsupported_reason);
@@ -779,6 +835,19 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   s.d_loss_m.ensure((size_t)nm * B);
   s.d_lig_grad.ensure((size_t)B * L * 3);
   MIG_HIP(hipMemsetAsync(s.d_lig_grad.p, 0, (size_t)B * L * 3 * sizeof(float), s.stream));
+  const int n_flex = (int)s.flex_rows.size();
+  MIG_CHECK(!flex_xyz || n_flex > 0, 1, "flex coordinates given but mi_scorer_set_flex declared no flexible rows");
+  MIG_CHECK(!flex_grad || flex_xyz, 1, "flex gradient without flex coordinates");
+  struct FlexGuard {  // cur_flex never outlives the call
+    Scorer &s;
+    ~FlexGuard() { s.cur_flex = nullptr; }
+  } flex_guard{s};
+  if (flex_xyz) {
+    s.d_flex.upload(flex_xyz, (size_t)B * n_flex * 3, s.stream);
+    s.cur_flex = s.d_flex.p;
+    s.d_flex_grad.ensure((size_t)B * n_flex * 3);
+    MIG_HIP(hipMemsetAsync(s.d_flex_grad.p, 0, (size_t)B * n_flex * 3 * sizeof(float), s.stream));
+  }
   for (const VoxGroup &g : s.groups) {
     Model *m0 = s.models[g.first_model];
     LigSetup ls = setup_ligand(s, g, lig_smt, L);
@@ -817,6 +886,18 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
           ProfScope ps(s, "voxel_backward", 0.0, 0.0, nb);
           launch_voxel_backward(vb, nb, m->input_pool, s.stream);
         }
+        TypedReceptor &tr = *s.receptors[g.rec_idx];
+        if (flex_grad && tr.n_flex_typed > 0) {  // getReceptorGradient: the same backward over the flexible atoms
+          vb.lig_xyz = s.cur_flex + (size_t)b0 * n_flex * 3;
+          vb.L = n_flex;
+          vb.lig_perm = tr.flex_perm.p;
+          vb.lig_consts = tr.flex_consts.p;
+          vb.lig_chan = tr.flex_chan.p;
+          vb.n_lig = tr.n_flex_typed;
+          vb.lig_grad = s.d_flex_grad.p + (size_t)b0 * n_flex * 3;
+          ProfScope ps(s, "voxel_backward_flex", 0.0, 0.0, nb);
+          launch_voxel_backward(vb, nb, m->input_pool, s.stream);
+        }
         MIG_HIP(hipGetLastError());
       }
     }
@@ -828,11 +909,15 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, s.d_pose.p, s.d_aff.p, s.d_loss.p, s.d_var.p,
                          s.stream);
   s.last_B = B;
+  if (flex_grad)
+    MIG_HIP(hipMemcpyAsync(flex_grad, s.d_flex_grad.p, (size_t)B * n_flex * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                           s.stream));
   MIG_HIP(hipMemcpyAsync(pose, s.d_pose.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   MIG_HIP(hipMemcpyAsync(aff, s.d_aff.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   MIG_HIP(hipMemcpyAsync(loss, s.d_loss.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   if (var) MIG_HIP(hipMemcpyAsync(var, s.d_var.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipMemcpyAsync(lig_grad, s.d_lig_grad.p, (size_t)B * L * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  if (lig_grad)
+    MIG_HIP(hipMemcpyAsync(lig_grad, s.d_lig_grad.p, (size_t)B * L * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   MIG_HIP(hipStreamSynchronize(s.stream));
 }
 
@@ -1077,6 +1162,40 @@ mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_
   MIG_CHECK(sc, 1, "NULL scorer");
   score_batch_grad(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var,
                    lig_grad, MI_MEM_HOST);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_set_flex(mi_scorer *sc, const int32_t *rec_rows, int n_flex) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  set_flex(*reinterpret_cast<Scorer *>(sc), rec_rows, n_flex);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_score_flex(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                               const float *centers, const float *flex_xyz, float *pose, float *affinity, float *loss,
+                               float *aff_var, float *lig_grad, float *flex_grad) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  if (lig_grad || flex_grad) {
+    score_batch_grad(s, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, lig_grad, MI_MEM_HOST, flex_xyz,
+                     flex_grad);
+  } else {
+    const int n_flex = (int)s.flex_rows.size();
+    MIG_CHECK(!flex_xyz || n_flex > 0, 1, "flex coordinates given but mi_scorer_set_flex declared no flexible rows");
+    struct FlexGuard {
+      Scorer &s;
+      ~FlexGuard() { s.cur_flex = nullptr; }
+    } guard{s};
+    if (flex_xyz && B > 0) {
+      s.d_flex.upload(flex_xyz, (size_t)B * n_flex * 3, s.stream);
+      s.cur_flex = s.d_flex.p;
+    }
+    score_batch(s, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, MI_MEM_HOST);
+  }
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -20,6 +20,11 @@ struct GatherArgs {
   const AtomRec *rec;      // typed receptor atoms, sorted by channel (stable)
   const int *rec_chan;     // their channel in the combined set
   int n_rec;
+  // flexible-residue atoms (DLScorer::setReceptor refreshes their coordinates on every call,
+  // dl_scorer.cpp:181-192): per-pose coordinates replace the stored ones
+  const int *rec_flex_slot;  // [n_rec] index into the flex rows, -1 = rigid; nullptr = no flexible atoms
+  const float *flex_xyz;     // [B][n_flex][3]
+  int n_flex;
   const float *lig_xyz;    // [B][L][3]
   int L;
   const int *lig_perm;     // [n_lig] index into the L ligand rows (typed atoms, sorted by channel)

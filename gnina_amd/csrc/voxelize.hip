@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
       if (i < g.n_rec) {
         a = g.rec[i];
         ch = g.rec_chan[i];
+        if (g.rec_flex_slot) {
+          const int fs = g.rec_flex_slot[i];
+          if (fs >= 0) {
+            const float *f = g.flex_xyz + ((size_t)b * g.n_flex + fs) * 3;
+            a.x = f[0], a.y = f[1], a.z = f[2];
+          }
+        }
       } else {
         int j = i - g.n_rec;
         int src = g.lig_perm[j];

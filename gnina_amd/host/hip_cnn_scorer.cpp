@@ -180,6 +180,23 @@ std::shared_ptr<DLScorer> HipCNNScorer::fresh_copy() const {
   return c;
 }
 
+// Types and coordinates go to the device once (the receptor is assumed constant, dl_scorer.cpp:112,150);
+// the flexible-residue rows -- the first receptor_map.size() rows -- are declared so that every call can
+// pass their current coordinates (dl_scorer.cpp:181-192).
+void HipCNNScorer::upload_receptor() {
+  if (receptor_uploaded) return;
+  std::vector<int32_t> t(receptor_smtypes.begin(), receptor_smtypes.end());
+  if (mi_scorer_set_receptor(ensemble.get(), &receptor_coords[0].x, t.data(), (int)t.size()) != MI_OK)
+    throw internal_error(mi_last_error());
+  if (!receptor_map.empty()) {
+    std::vector<int32_t> rows(receptor_map.size());
+    for (size_t i = 0; i < rows.size(); i++) rows[i] = (int32_t)i;
+    if (mi_scorer_set_flex(ensemble.get(), rows.data(), (int)rows.size()) != MI_OK)
+      throw internal_error(mi_last_error());
+  }
+  receptor_uploaded = true;
+}
+
 float HipCNNScorer::score(model &m, float &variance) {
   float aff = 0, loss = 0;
   return score(m, false, aff, loss, variance);
@@ -191,12 +208,7 @@ void HipCNNScorer::score_poses(model &m, const std::vector<float> &lig_xyz, int 
   if (!initialized()) throw internal_error("scorer not initialised");
   setLigand(m);
   setReceptor(m);
-  if (!receptor_uploaded) {
-    std::vector<int32_t> t(receptor_smtypes.begin(), receptor_smtypes.end());
-    if (mi_scorer_set_receptor(ensemble.get(), &receptor_coords[0].x, t.data(), (int)t.size()) != MI_OK)
-      throw internal_error(mi_last_error());
-    receptor_uploaded = true;
-  }
+  upload_receptor();
   const int L = (int)ligand_smtypes.size();
   if ((size_t)B * L * 3 != lig_xyz.size()) throw internal_error("Shape mismatch");
   std::vector<int32_t> lt(ligand_smtypes.begin(), ligand_smtypes.end());
@@ -212,9 +224,18 @@ void HipCNNScorer::score_poses(model &m, const std::vector<float> &lig_xyz, int 
   affinity.resize(B);
   loss.resize(B);
   variance.resize(B);
-  if (mi_scorer_score_batch(ensemble.get(), lig_xyz.data(), lt.data(), B, L, cptr, pose.data(), affinity.data(),
-                            loss.data(), variance.data()) != MI_OK)
-    throw internal_error(mi_last_error());
+  mi_status st;
+  if (receptor_map.empty()) {
+    st = mi_scorer_score_batch(ensemble.get(), lig_xyz.data(), lt.data(), B, L, cptr, pose.data(), affinity.data(),
+                               loss.data(), variance.data());
+  } else {  // every pose sees the flexible residues where the model has them now
+    const size_t nf = receptor_map.size();
+    std::vector<float> flex((size_t)B * nf * 3);
+    for (int b = 0; b < B; b++) std::memcpy(&flex[(size_t)b * nf * 3], receptor_coords.data(), nf * 3 * sizeof(float));
+    st = mi_scorer_score_flex(ensemble.get(), lig_xyz.data(), lt.data(), B, L, cptr, flex.data(), pose.data(),
+                              affinity.data(), loss.data(), variance.data(), nullptr, nullptr);
+  }
+  if (st != MI_OK) throw internal_error(mi_last_error());
 }
 
 float HipCNNScorer::score(model &m, bool compute_gradient, float &affinity, float &loss, float &variance) {
@@ -231,25 +252,23 @@ float HipCNNScorer::score(model &m, bool compute_gradient, float &affinity, floa
     // forward + loss.backward() + GridMaker::backward on the device (torch_model.cpp:197-221); the
     // ensemble mean of the atom gradients is what add_minus_forces + scale_minus_forces(1/cnt) produce
     setReceptor(m);
-    if (!receptor_uploaded) {
-      std::vector<int32_t> t(receptor_smtypes.begin(), receptor_smtypes.end());
-      if (mi_scorer_set_receptor(ensemble.get(), &receptor_coords[0].x, t.data(), (int)t.size()) != MI_OK)
-        throw internal_error(mi_last_error());
-      receptor_uploaded = true;
-    }
+    upload_receptor();
     const int L = (int)ligand_smtypes.size();
     std::vector<int32_t> lt(ligand_smtypes.begin(), ligand_smtypes.end());
     float c[3] = {cnnopts.cnn_center[0], cnnopts.cnn_center[1], cnnopts.cnn_center[2]};
     p.resize(1), a.resize(1), l.resize(1), v.resize(1);
-    std::vector<float> lg((size_t)L * 3);
-    if (mi_scorer_score_grad(ensemble.get(), xyz.data(), lt.data(), 1, L, std::isnan(c[0]) ? nullptr : c, p.data(),
-                             a.data(), l.data(), v.data(), lg.data()) != MI_OK)
+    const size_t nf = receptor_map.size();
+    std::vector<float> lg((size_t)L * 3), fg(nf * 3);
+    if (mi_scorer_score_flex(ensemble.get(), xyz.data(), lt.data(), 1, L, std::isnan(c[0]) ? nullptr : c,
+                             nf ? &receptor_coords[0].x : nullptr, p.data(), a.data(), l.data(), v.data(), lg.data(),
+                             nf ? fg.data() : nullptr) != MI_OK)
       throw internal_error(mi_last_error());
-    // getGradient (cnn_torch_scorer.cpp:208-228): scatter by movable-atom index, then the model adds
-    // them to minus_forces (flexible-receptor gradients are not produced by the engine yet)
+    // getGradient (cnn_torch_scorer.cpp:208-228): ligand and flexible-residue gradients scattered by
+    // movable-atom index, then the model adds them to minus_forces
     std::vector<gfloat3> gradient(receptor_map.size() + ligand_map.size(), gfloat3{0, 0, 0});
     if (gradient.size() < (size_t)m.m_num_movable_atoms) gradient.resize(m.m_num_movable_atoms, gfloat3{0, 0, 0});
     for (sz i = 0; i < ligand_map.size(); i++) gradient[ligand_map[i]] = gfloat3{lg[3 * i], lg[3 * i + 1], lg[3 * i + 2]};
+    for (sz i = 0; i < nf; i++) gradient[receptor_map[i]] = gfloat3{fg[3 * i], fg[3 * i + 1], fg[3 * i + 2]};
     m.add_minus_forces(gradient);
   }
   affinity = a[0];

@@ -49,6 +49,7 @@ class HipCNNScorer : public DLScorer {
   std::vector<std::shared_ptr<HipTorchModel>> models;
   std::shared_ptr<mi_scorer> ensemble;   // all models behind one batched scorer
   bool receptor_uploaded = false;
+  void upload_receptor();
 
  public:
   HipCNNScorer() {}

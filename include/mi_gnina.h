@@ -104,12 +104,25 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * through the network and GridMaker::backward (torch_model.cpp:197-221; cnn_torch_scorer.cpp:164-175).
  * lig_grad [B][L][3] = d loss / d x for every ligand row (0 for untyped rows such as hydrogens), mean
  * over the ensemble -- what getGradient + add_minus_forces + scale_minus_forces(1/cnt) leave in
- * model::minus_forces.  Host pointers.  Supported for the Default2017 / Default2018 families
- * (mi_model_supports_gradient); the Dense family returns MI_ERR_INVALID. */
+ * model::minus_forces.  Host pointers.  Supported for the Default2017 / Default2018 / Dense families
+ * (mi_model_supports_gradient); skip_softmax / apply_logistic_loss test models return MI_ERR_INVALID. */
 mi_status mi_scorer_score_grad(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
                                float *lig_grad);
 int mi_model_supports_gradient(const mi_model *);
+
+/* Flexible receptor residues.  DLScorer::setReceptor keeps the movable receptor atoms in the first rows of
+ * receptor_coords and refreshes them from the model on every call (dl_scorer.cpp:150-193); their gradient
+ * travels back through receptor_map (getReceptorGradient, cnn_torch_scorer.cpp:216-224).
+ * mi_scorer_set_flex names the rows of mi_scorer_set_receptor's arrays that move (any rows, n_flex >= 0;
+ * a later mi_scorer_set_receptor clears the declaration).  mi_scorer_score_flex scores B poses with
+ * per-pose coordinates flex_xyz [B][n_flex][3] for those rows (NULL: the stored coordinates); lig_grad
+ * [B][L][3] and flex_grad [B][n_flex][3] are optional outputs (both NULL: forward only).  Gradients of
+ * untyped rows are 0.  Host pointers. */
+mi_status mi_scorer_set_flex(mi_scorer *, const int32_t *rec_rows, int n_flex);
+mi_status mi_scorer_score_flex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                               const float *centers, const float *flex_xyz, float *pose, float *affinity,
+                               float *loss, float *aff_var, float *lig_grad, float *flex_grad);
 
 /* Per-model raw outputs of the last mi_scorer_score_batch* call: TorchModel::forward's
  * {pose, affinity, loss} for model `m` (host arrays [B]); used by the parity tests. */

@@ -58,6 +58,41 @@ int main(int argc, char **argv) {
     std::printf("usage_error_ok %s\n", e.what());
   }
 
+  if (argc > 4 && std::string(argv[3]) == "--flex") {
+    // flexible residues: the first K receptor atoms are movable atoms in front of the ligand
+    // (model.h: movable = [flex residues ..., ligand ...]); they are displaced by +0.25 A in x before
+    // scoring, and score(compute_gradient = true) must return forces on them as well
+    const int K = std::atoi(argv[4]);
+    gnina_amd::HipCNNScorer scorer(opts);
+    model m;
+    for (int i = 0; i < K + n_lig; i++) {
+      atom a;
+      a.sm = i < K ? rec_smt[i] : lig_smt[i - K];
+      m.atoms.push_back(a);
+      m.coords.push_back(i < K ? vec(rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2])
+                               : vec(poses[(size_t)(i - K) * 3], poses[(size_t)(i - K) * 3 + 1], poses[(size_t)(i - K) * 3 + 2]));
+    }
+    for (int i = K; i < n_rec; i++) {
+      atom a;
+      a.sm = rec_smt[i];
+      a.coords = vec(rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2]);
+      m.grid_atoms.push_back(a);
+    }
+    m.m_num_movable_atoms = K + n_lig;
+    m.ligands.resize(1);
+    m.ligands[0].node.begin = K;
+    m.ligands[0].node.end = K + n_lig;
+    float aff, loss, var;
+    float s0 = scorer.score(m, false, aff, loss, var);
+    std::printf("flex_rest %.9g %.9g\n", s0, aff);
+    for (int i = 0; i < K; i++) m.coords[i][0] += 0.25f;
+    float s1 = scorer.score(m, true, aff, loss, var);
+    std::printf("flex_moved %.9g %.9g %.9g\n", s1, aff, loss);
+    for (int i = 0; i < K + n_lig; i++)
+      std::printf("force %d %.9g %.9g %.9g\n", i, m.minus_forces[i][0], m.minus_forces[i][1], m.minus_forces[i][2]);
+    return 0;
+  }
+
   gnina_amd::HipCNNScorer scorer(opts);
   // model: rigid receptor in grid_atoms, ligand as the only movable atoms (ligands[0].node.begin = 0)
   model m;

@@ -104,3 +104,45 @@ def test_default_ensemble_gradient(capi, CG):
         for b in range(2):
             acc[b] += oracle_lig_gradient(blob, rec_xyz, rec_smt, poses[b], lig_smt)[1] / len(names)
     assert np.abs(out["lig_grad"] - acc).max() < 2e-3 * np.abs(acc).max()
+
+
+@pytest.mark.parametrize("name", ["crossdock_default2018", "dense_1_3"])
+def test_flexible_receptor_rows(capi, CG, name):
+    """flexible-residue atoms get per-pose coordinates (dl_scorer.cpp:181-192) and their own
+    gradient (getReceptorGradient, cnn_torch_scorer.cpp:216-224)."""
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    poses = poses[:2]
+    cen = poses.mean(axis=1)
+    near = np.argsort(np.linalg.norm(rec_xyz - cen[0], axis=1))[:14]
+    rows = np.sort(near)[::-1].copy()            # deliberately not ascending
+    rng = np.random.default_rng(5)
+    flex = rec_xyz[rows][None] + rng.normal(0, 0.3, (2, len(rows), 3)).astype(np.float32)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    s.set_flex(rows)
+    out = s.score_flex(poses, lig_smt, flex)
+    fwd = s.score_flex(poses, lig_smt, flex, grad=False)
+    assert np.abs(out["pose"] - fwd["pose"]).max() < 1e-6
+    rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
+    for b in range(2):
+        rx = rec_xyz.copy()
+        rx[rows] = flex[b]
+        # the same pose through a scorer whose receptor simply has the moved coordinates
+        s2 = capi.Scorer([name])
+        s2.set_receptor(rx, rec_smt)
+        ref = s2.score_batch(poses[b:b + 1], lig_smt)
+        assert out["pose"][b] == ref["pose"][0] and out["affinity"][b] == ref["affinity"][0]
+        grid, c = voxel.voxelize_pose(rx, rec_smt, poses[b], lig_smt, rmap, lmap)
+        loss, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None])
+        ch, rad = voxel.type_atoms(rec_smt[rows], rmap[0])
+        g0 = voxel.grid_backward(c, flex[b], ch, rad, rmap[1] + lmap[1], gg[0].numpy(), blob.resolution,
+                                 blob.dimension, blob.radius_scaling)
+        scale = max(np.abs(g0).max(), 1e-6)
+        assert np.abs(out["flex_grad"][b] - g0).max() < 2e-3 * scale
+        _, gl = oracle_lig_gradient(blob, rx, rec_smt, poses[b], lig_smt)
+        assert np.abs(out["lig_grad"][b] - gl).max() < 2e-3 * max(np.abs(gl).max(), 1e-6)
+    # rows that do not move keep working after the declaration is cleared
+    s.set_flex(np.zeros(0, np.int32))
+    plain = s.score_batch(poses, lig_smt)
+    assert np.abs(plain["pose"] - CG[name + "/pose"][:2]).max() < 1e-4

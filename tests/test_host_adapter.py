@@ -53,3 +53,45 @@ def test_dlscorer_adapter_matches_goldens(exe, golden_dir, tmp_path):
         assert float(batch[b][2]) == s and float(batch[b][3]) == a   # batched == one at a time, bitwise
     box = [l for l in lines if l.startswith("box")][0].split()
     assert abs((float(box[2]) - float(box[1])) - 23.5) < 1e-4 and box[3] == "47"
+
+
+@pytest.mark.gpu
+def test_dlscorer_adapter_flexible_residues(exe, golden_dir, tmp_path):
+    """Flexible-residue atoms in front of the ligand (dl_scorer.cpp:93-193): refreshed coordinates are scored
+    and score(compute_gradient=true) leaves their forces in minus_forces (cnn_torch_scorer.cpp:216-224)."""
+    from gnina_amd import capi
+    G = np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+    name = "crossdock_default2018"
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    # put the receptor atoms closest to the ligand first: they become the flexible rows; no hydrogens, so
+    # add_minus_forces' heavy-atom counter (model.cu:247-259) walks the gradient one to one
+    order = np.argsort(np.linalg.norm(rec_xyz - poses[0].mean(axis=0), axis=1), kind="stable")
+    rec_xyz, rec_smt = rec_xyz[order], rec_smt[order]
+    K = 10
+    assert (rec_smt[:K] > 1).all() and (lig_smt > 1).all()
+    path = tmp_path / "atoms.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", len(rec_smt), len(lig_smt), 1, 1))
+        f.write(struct.pack("<i", len(name)) + name.encode())
+        f.write(rec_xyz.astype("<f4").tobytes())
+        f.write(rec_smt.astype("<i4").tobytes())
+        f.write(lig_smt.astype("<i4").tobytes())
+        f.write(poses[:1].astype("<f4").tobytes())
+    r = subprocess.run([exe, str(path), WEIGHTS, "--flex", str(K)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n")]
+    rest = [l for l in lines if l[0] == "flex_rest"][0]
+    moved = [l for l in lines if l[0] == "flex_moved"][0]
+    forces = np.array([[float(x) for x in l[2:5]] for l in lines if l[0] == "force"])
+    capi.init(0)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    assert abs(float(rest[1]) - s.score_batch(poses[:1], lig_smt)["pose"][0]) < 1e-6
+    s.set_flex(np.arange(K))
+    flex = rec_xyz[:K].copy()
+    flex[:, 0] += 0.25
+    out = s.score_flex(poses[:1], lig_smt, flex[None])
+    assert float(moved[1]) == out["pose"][0] and float(moved[1]) != float(rest[1])
+    assert np.abs(forces[:K] - out["flex_grad"][0]).max() < 1e-7
+    assert np.abs(forces[K:] - out["lig_grad"][0]).max() < 1e-7
+    assert np.abs(forces[:K]).max() > 0
