@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_model_supports_gradient", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -38,6 +38,19 @@ class LigandDesc(C.Structure):
                 ("node_parent", C.c_void_p), ("node_atom_begin", C.c_void_p), ("node_atom_end", C.c_void_p),
                 ("node_rel_origin", C.c_void_p), ("node_rel_axis", C.c_void_p), ("n_pairs", C.c_int32),
                 ("pairs", C.c_void_p)]
+
+
+class CnnBox(C.Structure):
+    """mi_cnn_box (include/mi_gnina.h): the two out-of-box penalty regions of non_cache_cnn"""
+    _fields_ = [("use_search_box", C.c_int32), ("box_begin", C.c_float * 3), ("box_end", C.c_float * 3),
+                ("cnn_dimension", C.c_float), ("slope", C.c_float)]
+
+    @classmethod
+    def make(cls, cnn_dimension, box_begin=None, box_end=None, slope=10.0):
+        use = box_begin is not None
+        bb = (C.c_float * 3)(*(box_begin if use else (0, 0, 0)))
+        be = (C.c_float * 3)(*(box_end if use else (0, 0, 0)))
+        return cls(1 if use else 0, bb, be, cnn_dimension, slope)
 
 
 class McParams(C.Structure):
@@ -99,6 +112,9 @@ def lib():
         L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mi_scorer_score_grad.restype = C.c_int
         L.mi_scorer_set_flex.argtypes = [vp, vp, C.c_int]
+        L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
+        L.mi_cnn_eval_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]
+        L.mi_cnn_refine_batch.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
         L.mi_scorer_score_flex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mi_model_supports_gradient.argtypes = [vp]
         L.mi_model_supports_gradient.restype = C.c_int
@@ -399,6 +415,36 @@ class Vina:
         tries = np.empty(B, dtype=np.int32)
         check(lib().mi_vina_refine_batch(self.handle, _ptr(confs), B, _ptr(vv), int(max_iters), _ptr(e), _ptr(tries)))
         return e, confs, tries
+
+    def coords_batch(self, confs):
+        """model::set(conf): coords [B, n_atoms, 3]"""
+        confs = _f32(confs).reshape(-1, 7 + self.n_tors)
+        out = np.empty((len(confs), self.n_atoms, 3), dtype=np.float32)
+        check(lib().mi_vina_coords_batch(self.handle, _ptr(confs), len(confs), _ptr(out)))
+        return out
+
+    def cnn_eval_batch(self, scorer, confs, box, cnn_centers=None, deriv=True):
+        """non_cache_cnn::eval_deriv / eval -> (energy [B], change [B, 6+T] or None)"""
+        confs = _f32(confs).reshape(-1, 7 + self.n_tors)
+        B = len(confs)
+        cen = _f32(cnn_centers)
+        e = np.empty(B, dtype=np.float32)
+        ch = np.empty((B, 6 + self.n_tors), dtype=np.float32) if deriv else None
+        check(lib().mi_cnn_eval_batch(self.handle, scorer.handle, _ptr(confs), B, C.byref(box), _ptr(cen),
+                                      1 if deriv else 0, _ptr(e), _ptr(ch)))
+        return e, ch
+
+    def cnn_refine_batch(self, scorer, confs, box, max_iters=None):
+        """refine_structure with non_cache_cnn -> (energy, confs, tries, evals)"""
+        confs = np.array(_f32(confs).reshape(-1, 7 + self.n_tors), copy=True)
+        B = len(confs)
+        if max_iters is None:
+            max_iters = (25 + self.n_atoms) // 3
+        e = np.empty(B, dtype=np.float32)
+        tries, evals = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        check(lib().mi_cnn_refine_batch(self.handle, scorer.handle, _ptr(confs), B, C.byref(box), int(max_iters),
+                                        _ptr(e), _ptr(tries), _ptr(evals)))
+        return e, confs, tries, evals
 
     def final_energies(self, confs, num_tors, v=(1000.0, 1000.0, 1000.0)):
         confs = _f32(confs).reshape(-1, 7 + self.n_tors)

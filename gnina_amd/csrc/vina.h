@@ -68,6 +68,16 @@ struct VinaMcArgs {
   int *out_n, *evals;
 };
 
+struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN loss + per-atom gradient)
+  const float *forces;      // [B][n_atoms][3] or nullptr (energy only)
+  const float *e_in;        // [B] or nullptr
+  int use_box;              // search box gd active
+  float box_begin[3], box_end[3];
+  const float *cnn_center;  // [B][3] centre of the CNN cube cnn_gd, or nullptr (cube inactive)
+  float cnn_half;           // half its side
+  float slope;
+};
+
 struct VinaPopulateArgs {
   const float4 *rec;  // (x, y, z, smt as float bits)
   int n_rec;
@@ -84,6 +94,12 @@ void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
 // confs [B][7+T]; energy [B]; change [B][6+T] or null; coords [B][n_atoms][3] or null
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);
+// model::set(conf) only: coords [B][n_atoms][3]
+void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float *coords,
+                        hipStream_t s);
+// energy [B] = e_in + box penalties; change [B][6+T] (optional) from the external forces + penalty forces
+void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, const VinaExtArgs &a,
+                          float *energy, float *change, hipStream_t s);
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
 size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage);
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);

@@ -332,6 +332,53 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ligands.derivative(coords, minus_forces, g) (model.cu:223; tree.h:133-140,293-401): per-atom forces in
+// w.forces + the node frames of the conformation just set -> change[6 + T].
+__device__ void fold_forces(const VinaLigand &L, const WaveWork &w, float *change) {
+  const int lane = threadIdx.x;
+  // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140)
+  for (int k = lane; k < L.n_nodes; k += 64) {
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    const float ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
+    for (int i = L.abeg[k]; i < L.aend[k]; i++) {
+      const float rx = w.coords[3 * i] - ox, ry = w.coords[3 * i + 1] - oy, rz = w.coords[3 * i + 2] - oz;
+      const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
+      f0 += gx;
+      f1 += gy;
+      f2 += gz;
+      t0 += ry * gz - rz * gy;
+      t1 += rz * gx - rx * gz;
+      t2 += rx * gy - ry * gx;
+    }
+    float *ft = w.node_ft + 6 * k;
+    ft[0] = f0, ft[1] = f1, ft[2] = f2, ft[3] = t0, ft[4] = t1, ft[5] = t2;
+  }
+  __syncthreads();
+  // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311)
+  if (lane == 0) {
+    for (int k = L.n_nodes - 1; k >= 0; k--) {
+      float *ft = w.node_ft + 6 * k;
+      for (int e = L.child_start[k]; e < L.child_start[k + 1]; e++) {
+        const int c = L.child_list[e];
+        const float *cf = w.node_ft + 6 * c;
+        ft[0] += cf[0];
+        ft[1] += cf[1];
+        ft[2] += cf[2];
+        const float rx = w.origin[3 * c] - w.origin[3 * k], ry = w.origin[3 * c + 1] - w.origin[3 * k + 1],
+                    rz = w.origin[3 * c + 2] - w.origin[3 * k + 2];
+        ft[3] += (ry * cf[2] - rz * cf[1]) + cf[3];
+        ft[4] += (rz * cf[0] - rx * cf[2]) + cf[4];
+        ft[5] += (rx * cf[1] - ry * cf[0]) + cf[5];
+      }
+      if (k == 0) {
+        for (int j = 0; j < 6; j++) change[j] = ft[j];
+      } else {
+        change[6 + (k - 1)] = ft[3] * w.axis[3 * k] + ft[4] * w.axis[3 * k + 1] + ft[5] * w.axis[3 * k + 2];
+      }
+    }
+  }
+}
+
 // MODE 0: model::eval_deriv (model.cu:202-225); MODE 1: model::eval (energy only, midpoint pair table);
 // MODE 2: cache::eval (cache.cpp:52-63: receptor-grid term only -- the energy gnina's Metropolis step
 // uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates); MODE 4: eval_intramolecular
@@ -523,47 +570,7 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
       w.forces[3 * i + 2] = fz;
     }
     __syncthreads();
-    // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140)
-    for (int k = lane; k < L.n_nodes; k += 64) {
-      float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
-      const float ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
-      for (int i = L.abeg[k]; i < L.aend[k]; i++) {
-        const float rx = w.coords[3 * i] - ox, ry = w.coords[3 * i + 1] - oy, rz = w.coords[3 * i + 2] - oz;
-        const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
-        f0 += gx;
-        f1 += gy;
-        f2 += gz;
-        t0 += ry * gz - rz * gy;
-        t1 += rz * gx - rx * gz;
-        t2 += rx * gy - ry * gx;
-      }
-      float *ft = w.node_ft + 6 * k;
-      ft[0] = f0, ft[1] = f1, ft[2] = f2, ft[3] = t0, ft[4] = t1, ft[5] = t2;
-    }
-    __syncthreads();
-    // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311)
-    if (lane == 0) {
-      for (int k = L.n_nodes - 1; k >= 0; k--) {
-        float *ft = w.node_ft + 6 * k;
-        for (int e = L.child_start[k]; e < L.child_start[k + 1]; e++) {
-          const int c = L.child_list[e];
-          const float *cf = w.node_ft + 6 * c;
-          ft[0] += cf[0];
-          ft[1] += cf[1];
-          ft[2] += cf[2];
-          const float rx = w.origin[3 * c] - w.origin[3 * k], ry = w.origin[3 * c + 1] - w.origin[3 * k + 1],
-                      rz = w.origin[3 * c + 2] - w.origin[3 * k + 2];
-          ft[3] += (ry * cf[2] - rz * cf[1]) + cf[3];
-          ft[4] += (rz * cf[0] - rx * cf[2]) + cf[4];
-          ft[5] += (rx * cf[1] - ry * cf[0]) + cf[5];
-        }
-        if (k == 0) {
-          for (int j = 0; j < 6; j++) change[j] = ft[j];
-        } else {
-          change[6 + (k - 1)] = ft[3] * w.axis[3 * k] + ft[4] * w.axis[3 * k + 1] + ft[5] * w.axis[3 * k + 2];
-        }
-      }
-    }
+    fold_forces(L, w, change);
   }
   __syncthreads();
   return wave_sum(e_part);
@@ -591,6 +598,100 @@ __global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L
     for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
   if (coords_out)
     for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// non_cache_cnn as the igrid (non_cache_cnn.cpp:33-54,79-169): the receptor term is the CNN loss, computed
+// by the CNN engine for the coordinates of launch A; launch B adds the out-of-box penalties of the search
+// box `gd` and of the CNN cube `cnn_gd` to the CNN's per-atom gradient (hydrogens: zero force) and folds
+// the forces into change[6 + T].  skip_interacting_pairs() is true for this igrid: no intramolecular term.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vina_coords_kernel(VinaEnv env, VinaLigand L, const float *confs,
+                                                         float *coords_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *p = lds;
+  WaveWork w = carve_work(p, L);
+  const int nc = 7 + L.n_nodes - 1;
+  float *conf = carve(p, nc);
+  float *change = carve(p, 6 + L.n_nodes - 1);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  eval_conf<3>(env, L, conf, 0.f, 0.f, 0.f, w, change);
+  for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
+}
+
+__global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLigand L, const float *confs,
+                                                           VinaExtArgs a, float *energy, float *change_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *p = lds;
+  WaveWork w = carve_work(p, L);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  float *conf = carve(p, nc);
+  float *change = carve(p, n);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
+  __syncthreads();
+  eval_conf<3>(env, L, conf, 0.f, 0.f, 0.f, w, change);
+  float pen = 0.f;
+  for (int i = lane; i < L.n_atoms; i += 64) {
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (L.smt[i] > 1) {  // hydrogens: minus_forces = 0, no penalty (non_cache_cnn.cpp:92-96)
+      float f[3] = {0.f, 0.f, 0.f}, dist = 0.f;
+      if (a.forces) {
+        const float *g = a.forces + ((size_t)b * L.n_atoms + i) * 3;
+        f[0] = g[0], f[1] = g[1], f[2] = g[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {  // check_bounds_deriv on gd, then on cnn_gd (non_cache.cpp:102-123)
+        const float c = w.coords[3 * i + k];
+        if (a.use_box) {
+          if (c < a.box_begin[k]) {
+            f[k] += -a.slope;
+            dist += fabsf(c - a.box_begin[k]);
+          } else if (c > a.box_end[k]) {
+            f[k] += a.slope;
+            dist += fabsf(c - a.box_end[k]);
+          }
+        }
+        if (a.cnn_center) {
+          const float lo = a.cnn_center[3 * b + k] - a.cnn_half, hi = a.cnn_center[3 * b + k] + a.cnn_half;
+          if (c < lo) {
+            f[k] += -a.slope;
+            dist += fabsf(c - lo);
+          } else if (c > hi) {
+            f[k] += a.slope;
+            dist += fabsf(c - hi);
+          }
+        }
+      }
+      pen += dist * a.slope;
+      fx = f[0], fy = f[1], fz = f[2];
+    }
+    w.forces[3 * i] = fx;
+    w.forces[3 * i + 1] = fy;
+    w.forces[3 * i + 2] = fz;
+  }
+  __syncthreads();
+  if (change_out) {
+    fold_forces(L, w, change);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
+  }
+  pen = wave_sum(pen);
+  if (lane == 0) energy[b] = (a.e_in ? a.e_in[b] : 0.f) + pen;
+}
+
+void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float *coords,
+                        hipStream_t s) {
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
+  hipLaunchKernelGGL(vina_coords_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, coords);
+}
+
+void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, const VinaExtArgs &a,
+                          float *energy, float *change, hipStream_t s) {
+  const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
+  hipLaunchKernelGGL(vina_extforce_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, a, energy, change);
 }
 
 // latency probe (tools/bench_vina.py): `reps` back-to-back evaluations of one conformation per wave

@@ -78,10 +78,12 @@ struct Vina {
   // ligand
   bool have_lig = false;
   VinaLigand lig{};
+  std::vector<int32_t> h_lig_smt;  // host copy of the ligand atom types (CNN-in-the-loop calls type the ligand with them)
   DevBuf<int> d_int;
   DevBuf<float> d_flt;
   // scratch
   DevBuf<float> d_confs, d_energy, d_change, d_coords;
+  DevBuf<float> d_ext_forces, d_ext_e, d_ext_centers;
   DevBuf<int> d_evals, d_out_n;
   DevBuf<unsigned long long> d_seeds;
   DevBuf<float> d_mc_e, d_mc_conf, d_mc_xyz, d_sc_e, d_sc_conf, d_sc_xyz;
@@ -355,6 +357,7 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   v.d_int.upload(ints.data(), ints.size(), v.stream);
   v.d_flt.upload(flts.data(), flts.size(), v.stream);
   MIG_HIP(hipStreamSynchronize(v.stream));
+  v.h_lig_smt.assign(d->smt, d->smt + na);
   VinaLigand &L = v.lig;
   L.n_atoms = na;
   L.n_nodes = nn;
@@ -514,6 +517,365 @@ mi_status mi_vina_refine_batch(mi_vina *vv, float *confs, int B, const float *v3
   MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   if (tries) MIG_HIP(hipMemcpyAsync(tries, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// ---------------------------------------------------------------------------------------------
+// CNN in the optimisation loop: non_cache_cnn as quasi_newton's igrid (non_cache_cnn.cpp:33-54,79-169;
+// selected at main.cpp:475-476 for --cnn_scoring refinement and above).
+// ---------------------------------------------------------------------------------------------
+mi_status mi_vina_coords_batch(mi_vina *vv, const float *confs, int B, float *coords) {
+  VTRY
+  MIG_CHECK(vv && confs && coords && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_lig, 4, "set the ligand first");
+  if (B == 0) return MI_OK;
+  const int nc = 7 + v.lig.n_nodes - 1;
+  v.d_confs.upload(confs, (size_t)B * nc, v.stream);
+  v.d_coords.ensure((size_t)B * 3 * v.lig.n_atoms);
+  launch_vina_coords(make_env(v), v.lig, v.d_confs.p, B, v.d_coords.p, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(coords, v.d_coords.p, (size_t)B * 3 * v.lig.n_atoms * sizeof(float), hipMemcpyDeviceToHost,
+                         v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+namespace {
+
+// One batched evaluation of non_cache_cnn::eval_deriv (with_deriv) / eval for the conformations in `confs`:
+// coordinates on the device -> CNN forward(+backward) for all of them in one launch sequence -> penalties and
+// the fold into change.  Scratch vectors live in the caller so the refinement loop does not reallocate.
+struct CnnEvalScratch {
+  std::vector<float> coords, lig_grad, pose, aff, loss, var;
+};
+
+mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_cnn_box *box, const float *cnn_centers,
+                   float slope, int with_deriv, float *energy, float *change, CnnEvalScratch &s) {
+  const int na = v.lig.n_atoms, nt = v.lig.n_nodes - 1, n = 6 + nt;
+  s.coords.resize((size_t)B * na * 3);
+  s.pose.resize(B), s.aff.resize(B), s.loss.resize(B), s.var.resize(B);
+  mi_status st = mi_vina_coords_batch(reinterpret_cast<mi_vina *>(&v), confs, B, s.coords.data());
+  if (st != MI_OK) return st;
+  // grid centre = NaN -> recomputed from the ligand on every forward (cnn_torch_scorer.cpp:137-142)
+  if (with_deriv) {
+    s.lig_grad.resize((size_t)B * na * 3);
+    st = mi_scorer_score_grad(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
+                              s.loss.data(), s.var.data(), s.lig_grad.data());
+  } else {
+    st = mi_scorer_score_batch(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
+                               s.loss.data(), s.var.data());
+  }
+  if (st != MI_OK) return st;
+  // penalties + fold (confs are still in v.d_confs from the coordinate launch)
+  DevBuf<float> &d_f = v.d_ext_forces, &d_e = v.d_ext_e, &d_c = v.d_ext_centers;
+  VinaExtArgs a{};
+  if (with_deriv) {
+    d_f.upload(s.lig_grad.data(), s.lig_grad.size(), v.stream);
+    a.forces = d_f.p;
+  }
+  d_e.upload(s.loss.data(), B, v.stream);
+  a.e_in = d_e.p;
+  a.use_box = box && box->use_search_box ? 1 : 0;
+  for (int k = 0; k < 3; k++) {
+    a.box_begin[k] = box ? box->box_begin[k] : 0.f;
+    a.box_end[k] = box ? box->box_end[k] : 0.f;
+  }
+  if (cnn_centers) {
+    d_c.upload(cnn_centers, (size_t)B * 3, v.stream);
+    a.cnn_center = d_c.p;
+    a.cnn_half = box->cnn_dimension / 2.0f;
+  }
+  a.slope = slope;
+  v.d_energy.ensure(B);
+  if (with_deriv) v.d_change.ensure((size_t)B * n);
+  launch_vina_extforce(make_env(v), v.lig, v.d_confs.p, B, a, v.d_energy.p, with_deriv ? v.d_change.p : nullptr,
+                       v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (with_deriv)
+    MIG_HIP(hipMemcpyAsync(change, v.d_change.p, (size_t)B * n * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+}
+
+// --- host restatement of the optimiser state (bfgs.h:34-91,357-502) as a resumable state machine: every
+// chain asks for one (energy, change) evaluation at a time, so that the evaluations of all chains of a
+// round go to the device as one batch. ---
+inline int hidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
+
+inline float dot_seq(const float *a, const float *b, int n) {  // scalar_product, bfgs.h:45-50
+  float t = 0;
+  for (int i = 0; i < n; i++) t += a[i] * b[i];
+  return t;
+}
+
+constexpr float kPi = 3.14159265358979323846f, kEps = 1.1920928955078125e-07f;
+
+void normalize_angle(float &x) {  // quaternion.h:259-282
+  if (x > 3 * kPi) {
+    float n = (x - kPi) / (2 * kPi);
+    x -= 2 * kPi * std::ceil(n);
+    normalize_angle(x);
+  } else if (x < -3 * kPi) {
+    float n = (-x - kPi) / (2 * kPi);
+    x += 2 * kPi * std::ceil(n);
+    normalize_angle(x);
+  } else if (x > kPi) {
+    x -= 2 * kPi;
+  } else if (x < -kPi) {
+    x += 2 * kPi;
+  }
+}
+
+void conf_increment(float *x, const float *p, float alpha, int nt) {  // conf.h:54-59,103-118; quaternion.cu:32-62,96-100
+  x[0] += alpha * p[0], x[1] += alpha * p[1], x[2] += alpha * p[2];
+  const float rx = alpha * p[3], ry = alpha * p[4], rz = alpha * p[5];
+  const float angle = std::sqrt(rx * rx + ry * ry + rz * rz);
+  float rq[4] = {1, 0, 0, 0};
+  if (angle > kEps) {
+    const float inv = 1 / angle;
+    float a = angle;
+    normalize_angle(a);
+    const float c = std::cos(a / 2), s = std::sin(a / 2);
+    rq[0] = c, rq[1] = s * (inv * rx), rq[2] = s * (inv * ry), rq[3] = s * (inv * rz);
+  }
+  const float *q = x + 3;
+  float nq[4] = {rq[0] * q[0] - rq[1] * q[1] - rq[2] * q[2] - rq[3] * q[3],
+                 rq[0] * q[1] + rq[1] * q[0] + rq[2] * q[3] - rq[3] * q[2],
+                 rq[0] * q[2] - rq[1] * q[3] + rq[2] * q[0] + rq[3] * q[1],
+                 rq[0] * q[3] + rq[1] * q[2] - rq[2] * q[1] + rq[3] * q[0]};
+  const float s2 = nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3];
+  if (!(std::fabs(s2 - 1) < 1e-6f)) {  // quaternion_normalize_approx, quaternion.h:327-343
+    const float inv = 1 / std::sqrt(s2);
+    for (float &c : nq) c *= inv;
+  }
+  x[3] = nq[0], x[4] = nq[1], x[5] = nq[2], x[6] = nq[3];
+  for (int i = 0; i < nt; i++) {
+    float d = alpha * p[6 + i];
+    normalize_angle(d);
+    x[7 + i] += d;
+    normalize_angle(x[7 + i]);
+  }
+}
+
+struct BfgsChain {
+  int n = 0, nt = 0, nc = 0, max_iters = 0;
+  std::vector<float> x, x_new, x_orig, g, g_new, g_orig, p, y, mhy, h;
+  float f0 = 0, f_orig = 0, alpha = 1, pg = 0;
+  int step = 0, trial = 0;
+  long evals = 0;
+  enum { Init, Line, Done } state = Init;
+
+  void start(const float *conf, int nt_, int max_iters_) {
+    nt = nt_, n = 6 + nt_, nc = 7 + nt_, max_iters = max_iters_;
+    x.assign(conf, conf + nc);
+    x_new = x;
+    g.assign(n, 0), g_new.assign(n, 0), p.assign(n, 0), y.assign(n, 0), mhy.assign(n, 0);
+    h.assign((size_t)n * (n + 1) / 2, 0.f);
+    for (int i = 0; i < n; i++) h[hidx(i, i)] = 1;
+    step = 0;
+    state = Init;
+  }
+  const float *request() const { return state == Init ? x.data() : x_new.data(); }  // conformation to evaluate next
+
+  void begin_step() {
+    if (step >= max_iters) {
+      finish();
+      return;
+    }
+    for (int i = 0; i < n; i++) {  // minus_mat_vec_product, bfgs.h:34-43
+      float sum = 0;
+      for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
+      p[i] = -sum;
+    }
+    alpha = 1;
+    trial = 0;
+    pg = dot_seq(p.data(), g.data(), n);
+    x_new = x;
+    conf_increment(x_new.data(), p.data(), alpha, nt);
+    state = Line;
+  }
+  void finish() {
+    if (!(f0 <= f_orig)) {  // bfgs.h:493-497
+      f0 = f_orig;
+      x = x_orig;
+      g = g_orig;
+    }
+    state = Done;
+  }
+  void feed(float f, const float *grad) {  // the evaluation of request() has arrived
+    evals++;
+    if (state == Init) {
+      f0 = f_orig = f;
+      g.assign(grad, grad + n);
+      g_orig = g;
+      x_orig = x;
+      g_new = g;
+      begin_step();
+      return;
+    }
+    // fast_line_search, bfgs.h:73-91
+    g_new.assign(grad, grad + n);
+    const float f1 = f;
+    bool leave = f1 - f0 < 0.0001f * alpha * pg;
+    if (!leave) {
+      alpha *= 0.5f;
+      if (++trial < 10) {
+        x_new = x;
+        conf_increment(x_new.data(), p.data(), alpha, nt);
+        return;  // next trial
+      }
+    }
+    if (alpha == 0) {
+      finish();
+      return;
+    }
+    for (int i = 0; i < n; i++) y[i] = g_new[i] - g[i];
+    f0 = f1;
+    x = x_new;
+    g = g_new;
+    if (!(dot_seq(g.data(), g.data(), n) >= 1e-4f)) {  // bfgs.h:474
+      finish();
+      return;
+    }
+    if (step == 0) {  // initial Hessian scaling, bfgs.h:478-483
+      const float yy = dot_seq(y.data(), y.data(), n);
+      if (std::fabs(yy) > kEps) {
+        const float dgl = alpha * dot_seq(y.data(), p.data(), n) / yy;
+        for (int i = 0; i < n; i++) h[hidx(i, i)] = dgl;
+      }
+    }
+    const float yp = dot_seq(y.data(), p.data(), n);  // bfgs_update, bfgs.h:52-66
+    if (!(alpha * yp < kEps)) {
+      for (int i = 0; i < n; i++) {
+        float sum = 0;
+        for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * y[j];
+        mhy[i] = -sum;
+      }
+      const float yhy = -dot_seq(y.data(), mhy.data(), n);
+      const float r = 1 / (alpha * yp);
+      for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++)
+          h[hidx(i, j)] += alpha * r * (mhy[i] * p[j] + mhy[j] * p[i]) + alpha * alpha * (r * r * yhy + r) * p[i] * p[j];
+    }
+    step++;
+    begin_step();
+  }
+};
+
+}  // namespace
+
+mi_status mi_cnn_eval_batch(mi_vina *vv, mi_scorer *sc, const float *confs, int B, const mi_cnn_box *box,
+                            const float *cnn_centers, int with_deriv, float *energy, float *change) {
+  VTRY
+  MIG_CHECK(vv && sc && confs && energy && B >= 0 && (!with_deriv || change), 1, "bad arguments");
+  MIG_CHECK(!cnn_centers || (box && box->cnn_dimension > 0), 1, "cnn_centers needs box->cnn_dimension");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_lig, 4, "set the ligand first");
+  if (B == 0) return MI_OK;
+  CnnEvalScratch s;
+  return cnn_eval(v, sc, confs, B, box, cnn_centers, box ? box->slope : 0.f, with_deriv, energy, change, s);
+  VCATCH_STATUS
+}
+
+mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, const mi_cnn_box *box, int max_iters,
+                              float *energy, int32_t *tries, int32_t *evals) {
+  VTRY
+  MIG_CHECK(vv && sc && confs && energy && box && B >= 0 && max_iters >= 0, 1, "bad arguments");
+  MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_lig, 4, "set the ligand first");
+  if (B == 0) return MI_OK;
+  const int na = v.lig.n_atoms, nt = v.lig.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  CnnEvalScratch scratch;
+  // adjust_center (non_cache_cnn.cpp:57-67): the CNN cube is centred on the heavy movable atoms of the
+  // starting pose (DLScorer::set_center_from_model, dl_scorer.cpp:197-217) and stays there
+  std::vector<float> coords((size_t)B * na * 3), centers((size_t)B * 3);
+  mi_status st = mi_vina_coords_batch(vv, confs, B, coords.data());
+  if (st != MI_OK) return st;
+  auto heavy_center = [&](const float *xyz, float *c) {
+    float s0 = 0, s1 = 0, s2 = 0;
+    unsigned cnt = 0;
+    for (int i = 0; i < na; i++)
+      if (v.h_lig_smt[i] > 1) s0 += xyz[3 * i], s1 += xyz[3 * i + 1], s2 += xyz[3 * i + 2], cnt++;
+    c[0] = s0 / (float)cnt, c[1] = s1 / (float)cnt, c[2] = s2 / (float)cnt;
+  };
+  for (int b = 0; b < B; b++) heavy_center(&coords[(size_t)b * na * 3], &centers[3 * b]);
+  const float margin = 0.0001f, half = box->cnn_dimension / 2.0f;
+  auto within = [&](const float *xyz, const float *cen) {  // non_cache_cnn::within = cube OR search box (:74-76)
+    bool in_cnn = true, in_box = true;
+    for (int i = 0; i < na; i++) {
+      if (v.h_lig_smt[i] <= 1) continue;
+      for (int k = 0; k < 3; k++) {
+        const float c = xyz[3 * i + k];
+        if (c < cen[k] - half - margin || c > cen[k] + half + margin) in_cnn = false;
+        if (box->use_search_box && (c < box->box_begin[k] - margin || c > box->box_end[k] + margin)) in_box = false;
+      }
+    }
+    return in_cnn || in_box;
+  };
+  // refine_structure (main.cpp:131-171): slope 10, x10 per try, at most 5 tries, until within
+  std::vector<BfgsChain> chain(B);
+  std::vector<float> slope(B, 10.f);
+  std::vector<int> n_try(B, 0), active;
+  std::vector<char> done(B, 0);
+  std::vector<long> total_evals(B, 0);
+  for (int b = 0; b < B; b++) chain[b].start(confs + (size_t)b * nc, nt, max_iters);
+  std::vector<float> req, req_centers, e_out, g_out;
+  for (;;) {
+    // chains sharing a slope value are evaluated together (the slope is a kernel argument)
+    active.clear();
+    float cur_slope = 0;
+    for (int b = 0; b < B; b++)
+      if (!done[b]) {
+        if (active.empty()) cur_slope = slope[b];
+        if (slope[b] == cur_slope) active.push_back(b);
+      }
+    if (active.empty()) break;
+    const int nb = (int)active.size();
+    req.resize((size_t)nb * nc), req_centers.resize((size_t)nb * 3), e_out.resize(nb), g_out.resize((size_t)nb * n);
+    for (int i = 0; i < nb; i++) {
+      std::copy(chain[active[i]].request(), chain[active[i]].request() + nc, req.begin() + (size_t)i * nc);
+      std::copy(&centers[3 * active[i]], &centers[3 * active[i]] + 3, req_centers.begin() + (size_t)i * 3);
+    }
+    st = cnn_eval(v, sc, req.data(), nb, box, req_centers.data(), cur_slope, 1, e_out.data(), g_out.data(), scratch);
+    if (st != MI_OK) return st;
+    std::vector<int> finished;
+    for (int i = 0; i < nb; i++) {
+      const int b = active[i];
+      chain[b].feed(e_out[i], &g_out[(size_t)i * n]);
+      if (chain[b].state == BfgsChain::Done) finished.push_back(b);
+    }
+    if (finished.empty()) continue;
+    // the chains whose BFGS just ended: inside the box? (needs the coordinates of the final conformation)
+    std::vector<float> fc((size_t)finished.size() * nc), fxyz((size_t)finished.size() * na * 3);
+    for (size_t i = 0; i < finished.size(); i++)
+      std::copy(chain[finished[i]].x.begin(), chain[finished[i]].x.end(), fc.begin() + i * nc);
+    st = mi_vina_coords_batch(vv, fc.data(), (int)finished.size(), fxyz.data());
+    if (st != MI_OK) return st;
+    for (size_t i = 0; i < finished.size(); i++) {
+      const int b = finished[i];
+      total_evals[b] += chain[b].evals;
+      n_try[b]++;
+      const bool in = within(&fxyz[i * na * 3], &centers[3 * b]);
+      if (in || n_try[b] >= 5) {
+        done[b] = 1;
+        std::copy(chain[b].x.begin(), chain[b].x.end(), confs + (size_t)b * nc);
+        energy[b] = in ? chain[b].f0 : 3.402823466e+38f;  // out.e = max_fl (main.cpp:160-161)
+      } else {
+        slope[b] *= 10;
+        std::vector<float> x = chain[b].x;
+        chain[b].start(x.data(), nt, max_iters);
+      }
+    }
+  }
+  for (int b = 0; b < B; b++) {
+    if (tries) tries[b] = n_try[b];
+    if (evals) evals[b] = (int32_t)total_evals[b];
+  }
   return MI_OK;
   VCATCH_STATUS
 }

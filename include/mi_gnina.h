@@ -247,6 +247,33 @@ enum { MI_SORT_CNNSCORE = 0, MI_SORT_CNNAFFINITY = 1, MI_SORT_ENERGY = 2 };
 mi_status mi_rank_poses(const float *cnnscore, const float *cnnaffinity, const float *energy, const float *coords,
                         int n_poses, int n_heavy, int sort_order, float min_rmsd, int32_t *order_out,
                         int32_t *n_out);
+/* ---- CNN in the optimisation loop (--cnn_scoring refinement and above) ---------------------------------
+ * non_cache_cnn (non_cache_cnn.cpp:33-54,79-169) is the igrid quasi_newton minimises on (main.cpp:475-476):
+ *   E(conf) = CNN loss of the ensemble + slope * (distance of every heavy movable atom outside the search
+ *             box gd + outside the CNN cube cnn_gd);   no intramolecular term (skip_interacting_pairs()),
+ *   minus_forces = ensemble-mean d loss / d x of the heavy atoms + the penalty forces; hydrogens 0.
+ * The ligand of mi_vina_set_ligand supplies the torsion tree; ALL of its atoms (hydrogens included, as
+ * DLScorer::setLigand does) go to the CNN with their smina types; the receptor is the scorer's.
+ * Every evaluation re-centres the CNN grid on the ligand (cnn_torch_scorer.cpp:137-142); the penalty cube
+ * cnn_gd is given by cnn_centers [B][3] (NULL: inactive, as before adjust_center) and box->cnn_dimension. */
+typedef struct mi_cnn_box {
+  int32_t use_search_box;        /* gd[j].n > 0 */
+  float box_begin[3], box_end[3];
+  float cnn_dimension;           /* DLScorer::set_bounding_box: the model's grid dimension (23.5) */
+  float slope;                   /* mi_cnn_eval_batch only; mi_cnn_refine_batch runs refine_structure's ladder */
+} mi_cnn_box;
+/* model::set(conf) for B conformations: coords [B][n_atoms][3]. */
+mi_status mi_vina_coords_batch(mi_vina *, const float *confs, int B, float *coords);
+/* non_cache_cnn::eval_deriv (with_deriv = 1: energy [B], change [B][6+T]) / ::eval (0: energy only). */
+mi_status mi_cnn_eval_batch(mi_vina *, mi_scorer *, const float *confs, int B, const mi_cnn_box *box,
+                            const float *cnn_centers, int with_deriv, float *energy, float *change);
+/* refine_structure (main.cpp:131-171) with nc = non_cache_cnn for B poses at once: adjust_center (cube
+ * centred on the heavy atoms of the starting pose), then quasi_newton with the slope ladder 10, 100, ...
+ * (<= 5 tries) until non_cache_cnn::within; energy = max_fl if the pose never gets inside.  The optimiser
+ * state (bfgs.h:357-502) advances on the host; the evaluations of all poses of a round are one device
+ * batch.  confs in place; tries / evals [B] optional. */
+mi_status mi_cnn_refine_batch(mi_vina *, mi_scorer *, float *confs, int B, const mi_cnn_box *box, int max_iters,
+                              float *energy, int32_t *tries, int32_t *evals);
 /* Latency probe for tools/bench_vina.py: device time (ms) of `reps` dependent evaluations per wave. */
 mi_status mi_vina_eval_latency(mi_vina *, const float *confs, int B, int mode, int reps, float *ms_out);
 void *mi_vina_stream(mi_vina *);

@@ -275,3 +275,40 @@ def conf_increment(conf, p, alpha, n_tors):
     p = np.ascontiguousarray(p, dtype=np.float32)
     lib().ora_vina_conf_increment(_p(conf), _p(p), alpha, n_tors)
     return conf
+
+
+def forces_to_change(lig, conf, forces):
+    """ligands.derivative on given per-atom forces -> (change [6+T], coords [n_atoms, 3])"""
+    conf = np.ascontiguousarray(conf, dtype=np.float32)
+    forces = np.ascontiguousarray(forces, dtype=np.float32)
+    change = np.zeros(6 + lig.n_tors, dtype=np.float32)
+    coords = np.empty((lig.n_atoms, 3), dtype=np.float32)
+    f = _voxel.lib().ora_vina_forces_to_change
+    f.restype = None
+    f.argtypes = [C.POINTER(Ligand), _f32p, _f32p, _f32p, _f32p]
+    f(C.byref(lig.c), _p(conf), _p(forces), _p(change), _p(coords))
+    return change, coords
+
+
+_FX = C.CFUNCTYPE(C.c_float, _f32p, _f32p, C.c_void_p)
+
+
+def bfgs_callback(lig, conf, fx, max_iters):
+    """quasi_newton on a Python objective fx(conf) -> (energy, change): (energy, conf, grad, evals)"""
+    conf = np.array(conf, dtype=np.float32, copy=True)
+    n, nc = 6 + lig.n_tors, 7 + lig.n_tors
+
+    def cb(cp, gp, _user):
+        c = np.ctypeslib.as_array(cp, shape=(nc,)).copy()
+        e, g = fx(c)
+        np.ctypeslib.as_array(gp, shape=(n,))[:] = np.asarray(g, dtype=np.float32)
+        return float(e)
+
+    g = np.empty(n, dtype=np.float32)
+    ev = C.c_long()
+    f = _voxel.lib().ora_vina_bfgs_cb
+    f.restype = C.c_float
+    f.argtypes = [C.POINTER(Ligand), _f32p, C.c_int, _FX, C.c_void_p, _f32p, C.POINTER(C.c_long)]
+    keep = _FX(cb)
+    e = f(C.byref(lig.c), _p(conf), int(max_iters), keep, None, _p(g), C.byref(ev))
+    return e, conf, g, ev.value

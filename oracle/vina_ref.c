@@ -579,6 +579,9 @@ typedef struct {
   const float *rec_xyz;
   const int32_t *rec_smt;
   int n_rec;
+  /* any other igrid (non_cache_cnn: the CNN loss + box penalties): the objective comes from a callback */
+  float (*cb)(const float *conf, float *change, void *user);
+  void *user;
 } bfgs_ctx;
 
 float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact, const ora_grid_dims *gd, float slope,
@@ -588,6 +591,7 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
 
 static float fx(bfgs_ctx *c, const float *conf, float *g) {
   c->evals++;
+  if (c->cb) return c->cb(conf, g, c->user);
   if (c->direct)
     return ora_vina_noncache_eval(c->T, NULL, 0, c->gd, c->slope, c->rec_xyz, c->rec_smt, c->n_rec, c->L, conf, c->v, 1,
                                   g, NULL, NULL);
@@ -607,10 +611,41 @@ static float dotn(const float *a, const float *b, int n) {
 /* returns the final energy; conf is updated in place; change g receives the final gradient */
 float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
                     const ora_ligand *L, float *conf, const float *v, int max_iters, float *g_out, long *evals_out) {
-  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0};
+  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0, NULL, NULL};
   float f = bfgs_run(&ctx, conf, max_iters, g_out);
   if (evals_out) *evals_out = ctx.evals;
   return f;
+}
+
+/* quasi_newton on a caller-supplied objective (conf -> energy, change): the same bfgs<> + fast_line_search,
+ * used by the tests to restate refinement on non_cache_cnn (non_cache_cnn.cpp:79-169), whose energy is the
+ * CNN loss and lives in Python (oracle/cnn_ref.py). */
+typedef float (*ora_fx_cb)(const float *conf, float *change, void *user);
+float ora_vina_bfgs_cb(const ora_ligand *L, float *conf, int max_iters, ora_fx_cb cb, void *user, float *g_out,
+                       long *evals_out) {
+  bfgs_ctx ctx = {NULL, NULL, NULL, 0, L, NULL, 0, 0, NULL, NULL, 0, cb, user};
+  float f = bfgs_run(&ctx, conf, max_iters, g_out);
+  if (evals_out) *evals_out = ctx.evals;
+  return f;
+}
+
+/* ligands.derivative(coords, minus_forces, g.ligands) (model.cu:223; tree.h:293-401) on given forces:
+ * sets the conformation, folds per-atom forces into change[6 + T]; coords_out optional */
+void ora_vina_forces_to_change(const ora_ligand *L, const float *conf, const float *forces, float *change,
+                               float *coords_out) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  if (forces && change) {
+    float ft[6];
+    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
+  }
+  if (coords_out) memcpy(coords_out, coords, sizeof(float) * 3 * n);
+  free(coords);
+  free(origin);
+  free(axis);
 }
 
 /* refine_structure (main.cpp:131-171): BFGS on non_cache with the out-of-box slope raised 10x per try
@@ -621,7 +656,7 @@ float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const f
   float slope = 10, e = 0;
   int p = 0;
   for (; p < 5; p++) {
-    bfgs_ctx ctx = {T, gd, NULL, slope, L, v, 0, 1, rec_xyz, rec_smt, n_rec};
+    bfgs_ctx ctx = {T, gd, NULL, slope, L, v, 0, 1, rec_xyz, rec_smt, n_rec, NULL, NULL};
     e = bfgs_run(&ctx, conf, max_iters, NULL);
     if (ora_vina_within(gd, L, conf)) break;
     slope *= 10;

@@ -1,0 +1,128 @@
+"""Row a10: the CNN inside the optimisation loop.  HIP: mi_cnn_eval_batch (non_cache_cnn::eval / eval_deriv,
+non_cache_cnn.cpp:33-54,79-169) and mi_cnn_refine_batch (refine_structure on it, main.cpp:131-171).
+Oracle: oracle/cnn_refine.py (voxelizer + CNN autograd + torsion-tree fold + the same bfgs<>)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cnn_ref, cnn_refine, vina as ovina
+from tests import vina_scene
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHTS = os.path.join(ROOT, "gnina_amd", "weights")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from gnina_amd import capi
+    capi.init(0)
+    sc = vina_scene.build(seed=3)
+    lig = sc["lig"]
+    lig["smt"] = lig["smt"].copy()
+    lig["smt"][[5, 20]] = 1          # two polar hydrogens: go to the CNN untyped, get zero force
+    v = capi.Vina()
+    v.set_ligand(lig)
+    olig = ovina.LigandHandle(lig)
+    return capi, sc, lig, v, olig
+
+
+def random_confs(lig, rng, n, trans=0.6, rot=0.25, tors=0.5):
+    """conf0 perturbed: translation U(-trans, trans), a rotation of up to `rot` rad, torsion offsets"""
+    out = []
+    for _ in range(n):
+        c = lig["conf0"].astype(np.float32).copy()
+        c[:3] += rng.uniform(-trans, trans, 3)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(-rot, rot)
+        r = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+        q = c[3:7]
+        c[3:7] = [r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3],
+                  r[0] * q[1] + r[1] * q[0] + r[2] * q[3] - r[3] * q[2],
+                  r[0] * q[2] - r[1] * q[3] + r[2] * q[0] + r[3] * q[1],
+                  r[0] * q[3] + r[1] * q[2] - r[2] * q[1] + r[3] * q[0]]
+        c[7:] += rng.uniform(-tors, tors, len(c) - 7)
+        out.append(c)
+    return np.stack(out).astype(np.float32)
+
+
+def heavy_center(coords, smt):
+    c = np.zeros(3, dtype=np.float32)
+    for i in range(len(smt)):
+        if smt[i] > 1:
+            c = (c + coords[i]).astype(np.float32)
+    return c / np.float32((smt > 1).sum())
+
+
+@pytest.mark.parametrize("names", [["crossdock_default2018"], ["default2017", "crossdock_default2018_KD_4"]])
+def test_cnn_eval_deriv_matches_oracle(setup, names):
+    capi, sc, lig, v, olig = setup
+    s = capi.Scorer(names)
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(11)
+    confs = random_confs(lig, rng, 3)
+    confs[2, :3] += [9.0, 0.0, -7.5]   # far enough to leave both the search box and the CNN cube
+    coords = v.coords_batch(confs)
+    for b in range(3):
+        assert np.abs(coords[b] - ovina.set_conf(olig, confs[b])[0]).max() < 2e-5
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    cen = np.stack([heavy_center(ovina.set_conf(olig, lig["conf0"])[0], lig["smt"])] * 3)
+    box = capi.CnnBox.make(23.5, lo, hi, slope=10.0)
+    e, ch = v.cnn_eval_batch(s, confs, box, cen, deriv=True)
+    e0, _ = v.cnn_eval_batch(s, confs, box, cen, deriv=False)
+    assert np.abs(e - e0).max() < 1e-4 * np.abs(e).max()
+    blobs = [cnn_ref.Blob(os.path.join(WEIGHTS, n + ".mgw")) for n in names]
+    nc = cnn_refine.NonCacheCnn(blobs, sc["rec_xyz"], sc["rec_smt"], olig, (lo, hi), 23.5)
+    nc.cnn_center = cen[0]
+    nc.slope = 10.0
+    for b in range(3):
+        eo, cho = nc.eval_deriv(confs[b])
+        assert abs(e[b] - eo) < 2e-4 * max(1.0, abs(eo)), (b, e[b], eo)
+        assert np.abs(ch[b] - cho).max() < 3e-3 * max(np.abs(cho).max(), 1e-3), (b, ch[b], cho)
+        assert abs(nc.eval(confs[b]) - eo) < 1e-4 * max(1.0, abs(eo))
+    assert e[2] > e[0] + 10.0          # the displaced pose pays the out-of-box penalties
+
+
+def test_cnn_refine_first_iterations_match_oracle(setup):
+    capi, sc, lig, v, olig = setup
+    name = "crossdock_default2018"
+    s = capi.Scorer([name])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(5)
+    confs = random_confs(lig, rng, 3, trans=0.4, rot=0.15, tors=0.3)
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    box = capi.CnnBox.make(23.5, lo, hi)
+    e, out, tries, evals = v.cnn_refine_batch(s, confs, box, max_iters=2)
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    close = 0
+    for b in range(3):
+        nc = cnn_refine.NonCacheCnn([blob], sc["rec_xyz"], sc["rec_smt"], olig, (lo, hi), 23.5)
+        eo, co, to = cnn_refine.refine_structure(nc, confs[b], 2)
+        assert to == tries[b] == 1
+        if abs(e[b] - eo) < 1e-3 * max(1.0, abs(eo)) and np.abs(out[b] - co).max() < 5e-3 and nc.evals == evals[b]:
+            close += 1
+    assert close >= 2
+
+
+def test_cnn_refine_lowers_the_loss(setup):
+    """--cnn_scoring refinement must end at a lower CNN loss than it started from (what test_min.py /
+    test_cnn.py:56-59 check qualitatively), stay inside the box, and be reproducible."""
+    capi, sc, lig, v, olig = setup
+    names = ["crossdock_default2018", "dense_1_3"]
+    s = capi.Scorer(names)
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(7)
+    confs = random_confs(lig, rng, 16, trans=0.5, rot=0.2, tors=0.4)
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    box = capi.CnnBox.make(23.5, lo, hi)
+    start, _ = v.cnn_eval_batch(s, confs, box, None, deriv=False)
+    e, out, tries, evals = v.cnn_refine_batch(s, confs, box)
+    assert (e <= start + 1e-6).all() and (e < start - 1e-3).sum() >= 12
+    assert (tries == 1).all() and (evals >= 2).all()
+    after, _ = v.cnn_eval_batch(s, out, box, None, deriv=False)
+    assert np.abs(after - e).max() < 1e-4
+    e2, out2, _, _ = v.cnn_refine_batch(s, confs, box)
+    assert np.array_equal(e, e2) and np.array_equal(out, out2)
