@@ -16,7 +16,7 @@ MI_CENTER_TYPED_ONLY = 4
 # every function include/mi_gnina.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "mi_gnina_init", "mi_gnina_device_count", "mi_gnina_abi_version", "mi_last_error",
-    "mi_model_load", "mi_model_load_file", "mi_model_retain", "mi_model_release", "mi_model_info",
+    "mi_model_load", "mi_model_load_file", "mi_model_load_file_ex", "mi_model_retain", "mi_model_release", "mi_model_info",
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
@@ -87,6 +87,8 @@ def lib():
         L.mi_model_load.restype = vp
         L.mi_model_load_file.argtypes = [C.c_char_p]
         L.mi_model_load_file.restype = vp
+        L.mi_model_load_file_ex.argtypes = [C.c_char_p, C.c_float, C.c_float]
+        L.mi_model_load_file_ex.restype = vp
         L.mi_model_retain.argtypes = [vp]
         L.mi_model_retain.restype = None
         L.mi_model_release.argtypes = [vp]
@@ -202,11 +204,14 @@ WEIGHTS_DIR = os.path.join(_HERE, "weights")
 class Model:
     """One network (mirror of TorchModel's constructor, gninasrc/lib/torch_model.cpp:49-118)."""
 
-    def __init__(self, path_or_name):
+    def __init__(self, path_or_name, resolution=None, dimension=None):
         path = path_or_name
         if not os.path.exists(path):
             path = os.path.join(WEIGHTS_DIR, path_or_name.replace(".", "_") + ".mgw")
-        self.handle = lib().mi_model_load_file(path.encode())
+        if resolution is None and dimension is None:
+            self.handle = lib().mi_model_load_file(path.encode())
+        else:  # the same weights on another grid (dynamic-pool Dense family only)
+            self.handle = lib().mi_model_load_file_ex(path.encode(), float(resolution or 0), float(dimension or 0))
         if not self.handle:
             raise MiGninaError(f"could not load model {path_or_name}: {lib().mi_last_error().decode()}")
         res, dim = C.c_float(), C.c_float()

@@ -353,6 +353,7 @@ struct VoxGroup {  // models sharing one voxelization: same maps, geometry, radi
 struct Scorer {
   std::vector<Model *> models;
   hipStream_t stream = nullptr;
+  int cap = 1024;    // poses per launch of the call in flight: min(chunk, B, what the activation budget allows)
   int chunk = 1024;  // poses per launch: fewer, larger launches win (93.6k vs 87.1k poses/s at 256); 2.4 MB/pose of HBM
   bool have_receptor = false;
   int n_rec_atoms_in = 0;
@@ -450,6 +451,32 @@ struct ProfScope {
 
 constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
 constexpr size_t kPooledSlot2 = 4096;  // second pooled-grid buffer of the two-stream pipeline
+
+// Poses per launch for a call on B poses: the user's chunk, clipped to B and to an activation-memory budget
+// (96 GB of the 288 GB by default, MI_GNINA_ACT_GB overrides) -- a 96^3 Dense pose keeps ~110 MB of
+// activations (x2.25 with gradients), a 48^3 Default2017 pose 2.4 MB.
+static void set_call_capacity(Scorer &s, int B, bool grad) {
+  double per_pose = 0;
+  size_t max_bufs = 0;
+  for (Model *m : s.models) max_bufs = std::max(max_bufs, m->d.bufs.size());
+  for (size_t id = 0; id < max_bufs; id++) {
+    double worst = 0;
+    for (Model *m : s.models)
+      if (id < m->d.bufs.size() && m->buf_cp[id] > 0) {
+        const BufDecl &bd = m->d.bufs[id];
+        worst = std::max(worst, (double)bd.S * bd.S * bd.S * m->buf_cp[id] * 4.0);
+      }
+    per_pose += worst;
+  }
+  if (grad) per_pose *= 2.25;  // gradient buffers + arg-max bytes
+  double budget_gb = 96.0;
+  if (const char *ev = getenv("MI_GNINA_ACT_GB"))
+    if (atof(ev) > 0) budget_gb = atof(ev);
+  const double fit = budget_gb * 1073741824.0 / std::max(per_pose, 1.0);
+  int cap = std::min(s.chunk, std::max(B, 1));
+  if ((double)cap > fit) cap = std::max(1, (int)fit);
+  s.cap = cap;
+}
 
 static float *act_buf(Scorer &s, size_t id, size_t floats) {
   if (s.act.size() <= id) s.act.resize(id + 1);
@@ -627,9 +654,9 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   Model *m = s.models[g.first_model];
   TypedReceptor &tr = *s.receptors[g.rec_idx];
   const int cap = tr.n + ls.n_lig + 1;
-  cand.ensure((size_t)s.chunk * cap);
-  cand_chan.ensure((size_t)s.chunk * cap);
-  cand_n.ensure(s.chunk);
+  cand.ensure((size_t)s.cap * cap);
+  cand_chan.ensure((size_t)s.cap * cap);
+  cand_n.ensure(s.cap);
   GatherArgs ga{};
   ga.rec = tr.rec.p;
   ga.rec_chan = tr.chan.p;
@@ -693,13 +720,13 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
-    return argm_buf(s, slot, (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id]);
+    return argm_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id]);
   };
   auto buf_ptr = [&](int id) -> float * {
     const BufDecl &bd = m->d.bufs[id];
     // the pooled voxel grid lives in a dedicated slot shared by all models of a voxelization group
     const size_t slot = id == m->input_dst ? pooled_slot : (size_t)id;
-    return act_buf(s, slot, (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id]);
+    return act_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id]);
   };
   for (const Step &st : steps) {
     switch (st.kind) {
@@ -735,7 +762,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         ProfScope ps(s, "fc_heads", 2.0 * nb * 3.0 * st.n_in, (double)nb * st.n_in * 4.0, nb);
         launch_fc_heads(buf_ptr(st.src), m->dev_data.p + st.w_off, m->dev_data.p + st.b_off, st.n_in,
                         m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss,
-                        grad ? (s.d_raw3.ensure((size_t)3 * s.chunk), s.d_raw3.p) : nullptr, nb, s.stream);
+                        grad ? (s.d_raw3.ensure((size_t)3 * s.cap), s.d_raw3.p) : nullptr, nb, s.stream);
         break;
       }
     }
@@ -751,7 +778,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   auto slot_of = [&](int id) { return id == m->input_dst ? kPooledSlot : (size_t)id; };
   auto count_of = [&](int id) {
     const BufDecl &bd = m->d.bufs[id];
-    return (size_t)s.chunk * bd.S * bd.S * bd.S * m->buf_cp[id];
+    return (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id];
   };
   auto act_ptr = [&](int id) { return act_buf(s, slot_of(id), count_of(id)); };
   auto g_ptr = [&](int id) { return gact_buf(s, slot_of(id), count_of(id)); };
@@ -822,6 +849,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   for (Model *m : s.models)
     MIG_CHECK(m->grad_supported, 1, "gradient not supported for model " + m->d.name + ": " + m->grad_unsupported_reason);
   if (B == 0) return;
+  set_call_capacity(s, B, true);
   const int nm = (int)s.models.size();
   s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
   const float *d_lig = s.d_lig.p, *d_cen = nullptr;
@@ -852,9 +880,9 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
     Model *m0 = s.models[g.first_model];
     LigSetup ls = setup_ligand(s, g, lig_smt, L);
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
-    const size_t pooled_n = (size_t)s.chunk * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
-    for (int b0 = 0; b0 < B; b0 += s.chunk) {
-      const int nb = std::min(s.chunk, B - b0);
+    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
+    for (int b0 = 0; b0 < B; b0 += s.cap) {
+      const int nb = std::min(s.cap, B - b0);
       float *pooled = act_buf(s, kPooledSlot, pooled_n);
       unsigned char *am0 = m0->input_pool == 1 ? argm_buf(s, kPooledSlot, pooled_n) : nullptr;
       voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, am0);
@@ -927,6 +955,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
   MIG_CHECK(pose && aff && loss, 1, "output arrays must not be NULL");
   if (B == 0) return;
+  set_call_capacity(s, B, false);
   const int nm = (int)s.models.size();
   const float *d_lig = lig_xyz;
   const float *d_cen = centers;
@@ -954,15 +983,15 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
     // Two-stream pipeline: chunk i+1 is voxelized (VALU-bound) on vox_stream while the CNN of chunk i
     // (MFMA-bound) runs on the main stream; the pooled grid and candidate lists are double buffered.
-    const size_t pooled_n = (size_t)s.chunk * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
-    const bool ov = s.overlap && B > s.chunk;
+    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
+    const bool ov = s.overlap && B > s.cap;
     if (ov) {
       MIG_HIP(hipEventRecord(s.ev_inputs, s.stream));  // ligand / centre uploads are visible to vox_stream
       MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_inputs, 0));
     }
     int ci = 0;
-    for (int b0 = 0; b0 < B; b0 += s.chunk, ci++) {
-      const int nb = std::min(s.chunk, B - b0);
+    for (int b0 = 0; b0 < B; b0 += s.cap, ci++) {
+      const int nb = std::min(s.cap, B - b0);
       const int set = ov ? (ci & 1) : 0;
       const size_t slot = set ? kPooledSlot2 : kPooledSlot;
       float *pooled = act_buf(s, slot, pooled_n);
@@ -1068,6 +1097,18 @@ mi_model *mi_model_load_file(const char *path) {
   MIG_CHECK((bool)f, 2, std::string("could not open model file ") + path);  // usage_error, cnn_torch_scorer.cpp:87
   std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   ModelDesc d = parse_blob(raw.data(), raw.size(), nullptr);
+  return reinterpret_cast<mi_model *>(build_model(std::move(d)));
+  MI_CATCH_NULL
+}
+
+mi_model *mi_model_load_file_ex(const char *path, float resolution, float dimension) {
+  MI_TRY
+  MIG_CHECK(path, 1, "NULL path");
+  std::ifstream f(path, std::ios::binary);
+  MIG_CHECK((bool)f, 2, std::string("could not open model file ") + path);
+  std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  ModelDesc d = parse_blob(raw.data(), raw.size(), nullptr);
+  regrid(d, resolution > 0 ? resolution : d.resolution, dimension > 0 ? dimension : d.dimension);
   return reinterpret_cast<mi_model *>(build_model(std::move(d)));
   MI_CATCH_NULL
 }
@@ -1243,11 +1284,13 @@ mi_status mi_voxelize_batch(mi_scorer *sc, int mi, const float *lig_xyz, const i
   s.d_centers.ensure((size_t)B * 3);
   LigSetup ls = setup_ligand(s, *grp, lig_smt, L);
   const size_t per_pose = (size_t)m->C * m->N * m->N * m->N;
+  set_call_capacity(s, B, false);
+  s.cap = std::max(1, std::min(s.cap, (int)(((size_t)16 << 30) / (per_pose * 4))));  // <= 16 GB of staging
   const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
   DevBuf<float> tmp;
-  for (int b0 = 0; b0 < B; b0 += s.chunk) {
-    const int nb = std::min(s.chunk, B - b0);
-    float *dst = out_dev ? grid_out + (size_t)b0 * per_pose : (tmp.ensure((size_t)s.chunk * per_pose), tmp.p);
+  for (int b0 = 0; b0 < B; b0 += s.cap) {
+    const int nb = std::min(s.cap, B - b0);
+    float *dst = out_dev ? grid_out + (size_t)b0 * per_pose : (tmp.ensure((size_t)s.cap * per_pose), tmp.p);
     MIG_HIP(hipMemsetAsync(dst, 0, (size_t)nb * per_pose * sizeof(float), s.stream));  // torch::zeros, torch_model.cpp:179
     voxelize_chunk(s, *grp, ls, d_lig, L, d_cen, flags, b0, nb, 0, dst);
     if (!out_dev)
@@ -1271,14 +1314,16 @@ mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int 
   Model *m = s.models[mi];
   const size_t per_pose = (size_t)m->C * m->N * m->N * m->N;
   DevBuf<float> d_grid, d_out;
-  d_grid.ensure((size_t)std::min(B, s.chunk) * per_pose);
+  set_call_capacity(s, B, false);
+  s.cap = std::max(1, std::min(s.cap, (int)(((size_t)16 << 30) / (per_pose * 4))));
+  d_grid.ensure((size_t)std::min(B, s.cap) * per_pose);
   d_out.ensure((size_t)3 * B);
   const BufDecl &ib = m->d.bufs[m->input_dst];
-  for (int b0 = 0; b0 < B; b0 += s.chunk) {
-    const int nb = std::min(s.chunk, B - b0);
+  for (int b0 = 0; b0 < B; b0 += s.cap) {
+    const int nb = std::min(s.cap, B - b0);
     MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
                            hipMemcpyHostToDevice, s.stream));
-    float *pooled = act_buf(s, kPooledSlot, (size_t)s.chunk * ib.S * ib.S * ib.S * m->buf_cp[m->input_dst]);
+    float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * m->buf_cp[m->input_dst]);
     launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
     run_program(s, mi, nb, d_out.p + b0, d_out.p + B + b0, d_out.p + 2 * (size_t)B + b0);
   }

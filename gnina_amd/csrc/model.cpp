@@ -144,4 +144,30 @@ ModelDesc parse_blob(const void *blob, size_t nbytes, const char *name_override)
   return m;
 }
 
+// Same network on a different grid (metadata "resolution" / "dimension" of a user-supplied model file,
+// torch_model.cpp:73-84): only networks whose head does not depend on the spatial size qualify -- the
+// dynamic-global-pool Dense family; Default2017/2018 heads are fixed at 128 * 6^3 inputs and
+// `dense.pt` hard-codes max_pool3d(6).
+void regrid(ModelDesc &m, float resolution, float dimension) {
+  MIG_CHECK(resolution > 0 && dimension > 0, 2, "resolution and dimension must be positive");
+  const int old_n = m.grid_points();
+  m.resolution = resolution;
+  m.dimension = dimension;
+  const int new_n = m.grid_points();
+  if (new_n == old_n) return;
+  MIG_CHECK(m.family == "Dense", 2,
+            "model " + m.name + " (" + m.family + ") has a fixed-size head and cannot run on a " +
+                std::to_string(new_n) + "^3 grid");
+  MIG_CHECK(new_n % 8 == 0, 2, "grid points per side must be a multiple of 8 (three 2x2x2 pools)");
+  for (const Op &o : m.ops)
+    MIG_CHECK(o.kind != OpKind::Fc || m.bufs[o.src].S == 1, 2, "fc head depends on the spatial size");
+  for (BufDecl &b : m.bufs) {
+    if (b.S == 1) continue;  // global pool output
+    MIG_CHECK(old_n % b.S == 0, 2, "unexpected buffer size");
+    const int div = old_n / b.S;
+    MIG_CHECK(new_n % div == 0, 2, "grid does not divide through the pooling stack");
+    b.S = new_n / div;
+  }
+}
+
 }  // namespace mig

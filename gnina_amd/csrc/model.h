@@ -47,4 +47,7 @@ struct ModelDesc {
 // Throws mig::Error(MI_ERR_MODEL) on malformed input.
 ModelDesc parse_blob(const void *blob, size_t nbytes, const char *name_override);
 
+// Re-target a parsed model to another grid resolution / dimension (dynamic-pool families only).
+void regrid(ModelDesc &m, float resolution, float dimension);
+
 }  // namespace mig

@@ -59,6 +59,11 @@ const char *mi_last_error(void);
  * output for one .pt of gninasrc/lib/models/).  Returns NULL on failure (see mi_last_error). */
 mi_model *mi_model_load(const void *blob, size_t nbytes, const char *name);
 mi_model *mi_model_load_file(const char *path);
+/* The same weights on another grid: "resolution" / "dimension" as the metadata of a user-supplied model
+ * file would give them (torch_model.cpp:73-84); <= 0 keeps the blob's value.  Only networks with a
+ * size-independent head qualify (family Dense: dynamic global max pool, e.g. dense_1_3 at 0.25 A / 23.75 A =
+ * 96^3); others return NULL (MI_ERR_MODEL). */
+mi_model *mi_model_load_file_ex(const char *path, float resolution, float dimension);
 void mi_model_retain(mi_model *);
 void mi_model_release(mi_model *);
 /* TorchModel::get_grid_res / get_grid_dim (torch_model.h:42-43) + channel counts of the two
