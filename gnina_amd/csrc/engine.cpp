@@ -361,7 +361,7 @@ struct Scorer {
   std::vector<VoxGroup> groups;
   // per-call ligand staging
   DevBuf<float> d_lig, d_centers_in, d_centers;
-  DevBuf<int> d_lig_perm, d_lig_chan, d_cand_chan, d_cand_n;
+  DevBuf<int> d_lig_perm, d_lig_chan, d_cand_chan, d_cand_n, d_pose_rows, d_pose_nlig;
   DevBuf<LigConsts> d_lig_consts;
   DevBuf<unsigned char> d_lig_typed;
   DevBuf<AtomRec> d_cand, d_cand2;
@@ -606,8 +606,57 @@ static void set_flex(Scorer &s, const int32_t *rows, int n_flex) {
 }
 
 struct LigSetup {
-  int n_lig = 0;  // typed ligand atoms
+  int n_lig = 0;  // typed ligand atoms (ragged: the largest count of any pose)
+  bool ragged = false;
 };
+
+// Ragged batch (virtual screening): pose b has its own ligand -- rows [0, rows_b) of
+// lig_smt[b][0..L) are real atoms (smt >= 0), the rest padding (-1).  Same typing / stable channel sort as
+// setup_ligand, per pose.
+static LigSetup setup_ligand_ragged(Scorer &s, const VoxGroup &g, const int32_t *lig_smt, int B, int L) {
+  Model *m = s.models[g.first_model];
+  std::vector<int> perm((size_t)B * L, 0), chan((size_t)B * L, 0), rows(B), nl(B);
+  std::vector<LigConsts> lc((size_t)B * L);
+  std::vector<unsigned char> typed((size_t)B * L, 0);
+  std::vector<int> idx;
+  int max_n = 0;
+  for (int b = 0; b < B; b++) {
+    const int32_t *t = lig_smt + (size_t)b * L;
+    int r = 0;
+    while (r < L && t[r] >= 0) r++;
+    for (int i = r; i < L; i++) MIG_CHECK(t[i] < 0, 1, "ragged ligand rows: padding (-1) must follow the real atoms");
+    rows[b] = r;
+    idx.clear();
+    for (int i = 0; i < r; i++) {
+      MIG_CHECK(t[i] < kNumSminaTypes, 1, "ligand smina type out of range");
+      if (m->d.ligmap.chan_of_smt[t[i]] >= 0) {
+        idx.push_back(i);
+        typed[(size_t)b * L + i] = 1;
+      }
+    }
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](int a, int c) { return m->d.ligmap.chan_of_smt[t[a]] < m->d.ligmap.chan_of_smt[t[c]]; });
+    nl[b] = (int)idx.size();
+    max_n = std::max(max_n, nl[b]);
+    for (size_t k = 0; k < idx.size(); k++) {
+      const DensityConsts &dc = m->dens[t[idx[k]]];
+      perm[(size_t)b * L + k] = idx[k];
+      lc[(size_t)b * L + k] = LigConsts{dc.ar, dc.t2, dc.g2, dc.kexp, dc.inv_ar};
+      chan[(size_t)b * L + k] = m->d.ligmap.chan_of_smt[t[idx[k]]] + m->d.recmap.n_channels;
+    }
+  }
+  s.d_lig_perm.upload(perm.data(), perm.size(), s.stream);
+  s.d_lig_chan.upload(chan.data(), chan.size(), s.stream);
+  s.d_lig_consts.upload(lc.data(), lc.size(), s.stream);
+  s.d_lig_typed.upload(typed.data(), typed.size(), s.stream);
+  s.d_pose_rows.upload(rows.data(), rows.size(), s.stream);
+  s.d_pose_nlig.upload(nl.data(), nl.size(), s.stream);
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  LigSetup ls;
+  ls.n_lig = max_n;
+  ls.ragged = true;
+  return ls;
+}
 
 // Type the ligand rows with the group's ligand map, upload permutation / constants.
 static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_smt, int L) {
@@ -673,6 +722,14 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.lig_chan = s.d_lig_chan.p;
   ga.n_lig = ls.n_lig;
   ga.lig_typed = s.d_lig_typed.p;
+  if (ls.ragged) {  // per-pose ligand descriptions
+    ga.lig_perm += (size_t)b0 * L;
+    ga.lig_consts += (size_t)b0 * L;
+    ga.lig_chan += (size_t)b0 * L;
+    ga.lig_typed += (size_t)b0 * L;
+    ga.pose_rows = s.d_pose_rows.p + b0;
+    ga.pose_n_lig = s.d_pose_nlig.p + b0;
+  }
   ga.centers_in = d_centers_in ? d_centers_in + (size_t)b0 * 3 : nullptr;
   ga.center_typed_only = (flags & MI_CENTER_TYPED_ONLY) ? 1 : 0;
   ga.half_dim = m->d.dimension / 2.0f;
@@ -950,7 +1007,8 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
 }
 
 static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
-                        const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags) {
+                        const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags,
+                        bool ragged = false) {
   MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
   MIG_CHECK(pose && aff && loss, 1, "output arrays must not be NULL");
@@ -979,7 +1037,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   }
   for (const VoxGroup &g : s.groups) {
     Model *m0 = s.models[g.first_model];
-    LigSetup ls = setup_ligand(s, g, lig_smt, L);
+    LigSetup ls = ragged ? setup_ligand_ragged(s, g, lig_smt, B, L) : setup_ligand(s, g, lig_smt, L);
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
     // Two-stream pipeline: chunk i+1 is voxelized (VALU-bound) on vox_stream while the CNN of chunk i
     // (MFMA-bound) runs on the main stream; the pooled grid and candidate lists are double buffered.
@@ -1194,6 +1252,16 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *sc, const float *lig_xyz, const in
 mi_status mi_scorer_score_batch(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                 const float *centers, float *pose, float *affinity, float *loss, float *aff_var) {
   return mi_scorer_score_batch_ex(sc, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, MI_MEM_HOST);
+}
+
+mi_status mi_scorer_score_ragged(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                 const float *centers, float *pose, float *affinity, float *loss, float *aff_var) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  score_batch(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var,
+              MI_MEM_HOST, true);
+  return MI_OK;
+  MI_CATCH_STATUS
 }
 
 mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int B, int L,

@@ -32,6 +32,10 @@ struct GatherArgs {
   const int *lig_chan;     // [n_lig] channel in the combined set (already offset by n_rec_channels)
   int n_lig;
   const unsigned char *lig_typed;  // [L] 1 if the row has a channel (for the typed-only centre switch)
+  // ragged batches (virtual screening: every pose may belong to a different ligand): the four ligand arrays
+  // above are then per pose, [B][L], and these give the per-pose counts
+  const int *pose_rows;     // [B] real ligand rows of pose b (<= L), or nullptr = one ligand for the whole batch
+  const int *pose_n_lig;    // [B] typed atoms of pose b
   const float *centers_in;  // [B][3] or nullptr; non-finite x -> ligand mean
   int center_typed_only;
   float half_dim;

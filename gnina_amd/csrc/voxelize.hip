@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
   __shared__ int s_base;
 
   const float *lig = g.lig_xyz + (size_t)b * g.L * 3;
+  const size_t po = g.pose_rows ? (size_t)b * g.L : 0;  // offset of this pose's ligand description
+  const int rows = g.pose_rows ? g.pose_rows[b] : g.L;
+  const int n_lig = g.pose_rows ? g.pose_n_lig[b] : g.n_lig;
   if (tid == 0) {
     float cx, cy, cz;
     bool given = false;
@@ -58,8 +61,8 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
       // CoordinateSet::center(): fp32 sum in index order, one divide per axis (oracle ora_center)
       float sx = 0.f, sy = 0.f, sz = 0.f;
       int cnt = 0;
-      for (int i = 0; i < g.L; i++) {
-        if (g.center_typed_only && g.lig_typed[i] == 0) continue;
+      for (int i = 0; i < rows; i++) {
+        if (g.center_typed_only && g.lig_typed[po + i] == 0) continue;
         sx = sx + lig[3 * i + 0];
         sy = sy + lig[3 * i + 1];
         sz = sz + lig[3 * i + 2];
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
   AtomRec *cand = g.cand + (size_t)b * g.cap;
   int *cand_chan = g.cand_chan + (size_t)b * g.cap;
 
-  const int total = g.n_rec + g.n_lig;
+  const int total = g.n_rec + n_lig;
   for (int base = 0; base < total; base += 256) {
     int i = base + tid;
     bool keep = false;
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
         }
       } else {
         int j = i - g.n_rec;
-        int src = g.lig_perm[j];
-        const LigConsts lc = g.lig_consts[j];
+        int src = g.lig_perm[po + j];
+        const LigConsts lc = g.lig_consts[po + j];
         a.x = lig[3 * src + 0];
         a.y = lig[3 * src + 1];
         a.z = lig[3 * src + 2];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
         a.g2 = lc.g2;
         a.kexp = lc.kexp;
         a.inv_ar = lc.inv_ar;
-        ch = g.lig_chan[j];
+        ch = g.lig_chan[po + j];
       }
       float reach = g.half_dim + a.ar * 1.5f + 0.01f;
       keep = fabsf(a.x - cx) <= reach && fabsf(a.y - cy) <= reach && fabsf(a.z - cz) <= reach;

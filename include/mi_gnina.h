@@ -105,6 +105,13 @@ mi_status mi_scorer_score_batch(mi_scorer *, const float *lig_xyz, const int32_t
 mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                    const float *centers, float *pose, float *affinity, float *loss,
                                    float *aff_var, unsigned flags);
+/* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
+ * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
+ * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as
+ * mi_scorer_score_batch (one DLScorer::setLigand + score per pose in the reference, main.cpp:1438-1466).
+ * Host pointers. */
+mi_status mi_scorer_score_ragged(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int Lmax,
+                                 const float *centers, float *pose, float *affinity, float *loss, float *aff_var);
 /* CNNTorchScorer::score(model&, compute_gradient = true, ...) for B poses: forward, loss.backward()
  * through the network and GridMaker::backward (torch_model.cpp:197-221; cnn_torch_scorer.cpp:164-175).
  * lig_grad [B][L][3] = d loss / d x for every ligand row (0 for untyped rows such as hydrogens), mean

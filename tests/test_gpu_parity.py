@@ -205,3 +205,38 @@ def test_error_paths(capi):
     s.set_receptor(np.zeros((1, 3), dtype=np.float32), np.array([2]))
     with pytest.raises(capi.MiGninaError):      # smina type out of range
         s.score_batch(np.zeros((1, 1, 3), dtype=np.float32), np.array([99]))
+
+
+def test_ragged_batch_equals_per_ligand_calls(capi, CG):
+    """Virtual-screening batches: poses of different ligands, padded to Lmax, in one call --
+    bit-identical to scoring every ligand on its own."""
+    from gnina_amd import synth
+    names = ["crossdock_default2018", "crossdock_default2018_KD_4", "default2017"]
+    base = "crossdock_default2018"
+    rec_xyz, rec_smt = CG[base + "/rec_xyz"], CG[base + "/rec_smt"]
+    s = capi.Scorer(names)
+    s.set_receptor(rec_xyz, rec_smt)
+    rng = np.random.RandomState(3)
+    types = np.array([2, 3, 4, 5, 6, 8, 10, 12, 14, 1, 16], dtype=np.int32)   # includes polar H (untyped)
+    Lmax, P = 48, 3
+    xyz = np.zeros((0, Lmax, 3), dtype=np.float32)
+    smt = np.zeros((0, Lmax), dtype=np.int32)
+    single = {k: [] for k in ("pose", "affinity", "loss", "variance")}
+    for L in (16, 48, 1, 33):
+        lig_xyz, lig_smt = synth.make_ligand(rng, L, types)
+        poses = synth.make_poses(rng, lig_xyz, P)
+        out = s.score_batch(poses, lig_smt)
+        for k in single:
+            single[k].append(out[k])
+        pad_xyz = np.full((P, Lmax, 3), 1e30, dtype=np.float32)     # padding coordinates must be ignored
+        pad_xyz[:, :L] = poses
+        pad_smt = np.full((P, Lmax), -1, dtype=np.int32)
+        pad_smt[:, :L] = lig_smt
+        xyz, smt = np.concatenate([xyz, pad_xyz]), np.concatenate([smt, pad_smt])
+    out = s.score_ragged(xyz, smt)
+    for k in single:
+        assert np.array_equal(out[k], np.concatenate(single[k])), k
+    bad = smt.copy()
+    bad[0, 3] = -1                       # a hole in the middle of a ligand
+    with pytest.raises(capi.MiGninaError):
+        s.score_ragged(xyz, bad)
