@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -114,6 +114,7 @@ def lib():
         L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mi_scorer_score_grad.restype = C.c_int
         L.mi_scorer_set_flex.argtypes = [vp, vp, C.c_int]
+        L.mi_scorer_set_precision.argtypes = [vp, C.c_int]
         L.mi_scorer_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
         L.mi_cnn_eval_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]
@@ -291,6 +292,10 @@ class Scorer:
         check(lib().mi_scorer_score_grad(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(pose),
                                          _ptr(aff), _ptr(loss), _ptr(var), _ptr(grad)))
         return {"pose": pose, "affinity": aff, "loss": loss, "variance": var, "lig_grad": grad}
+
+    def set_precision(self, bf16):
+        """False: exact fp32 (parity path); True: bf16-MFMA convolutions (forward only)."""
+        check(lib().mi_scorer_set_precision(self.handle, 1 if bf16 else 0))
 
     def set_flex(self, rec_rows):
         """Receptor rows (of set_receptor's arrays) whose coordinates are supplied per pose."""

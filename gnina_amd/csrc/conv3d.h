@@ -34,6 +34,9 @@ struct ConvArgs {
   // scale of the forward layer's input (d(BN x)/dx); accumulate adds into the concat buffer's gradient.
   const float *out_scale;          // [coutp] or nullptr
   int accumulate;
+  // bf16 kernels (conv3d_bf16.hip) only: element type of the tensors behind in / out / in_act
+  // (1 = fp32, 0 = bf16; cc4 / ccs / cin4 then count OCTETS of 8 channels and wp is a packed bf16 array)
+  int in_f32, out_f32, act_f32;
   int sparse;        // skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients)
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
@@ -47,6 +50,10 @@ enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_3x2_2x1 = 1, CONV_CFG_1x4_7x1 = 2, CONV_CF
 size_t conv_lds_bytes(const ConvArgs &p);
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn);
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s);
+
+size_t conv_bf16_lds_bytes(const ConvArgs &p);
+void launch_conv_bf16(const ConvArgs &p, int cfg, int B, hipStream_t s);
+void launch_gmax_bf16(const void *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
 
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);
 void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,

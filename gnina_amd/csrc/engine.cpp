@@ -50,6 +50,7 @@ struct Step {
   int C = 0;             // channels moved by Pool/GMax
   long w_off = 0, b_off = 0;  // Fc (offsets into dev_data)
   int n_in = 0;
+  bool src_bf16 = false;  // bf16 program: GMax reads a bf16 tensor
 };
 
 struct Model {
@@ -62,6 +63,9 @@ struct Model {
   std::vector<int> buf_cp;          // padded channel stride per buffer (0 = never materialised)
   std::vector<Step> steps;          // executable program after fusion
   std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
+  std::vector<Step> hsteps;         // bf16-MFMA forward program (built on first use, mi_scorer_set_precision)
+  std::once_flag hsteps_once;
+  std::string hsteps_error;
   bool grad_supported = false;
   std::string grad_unsupported_reason;
   DevBuf<float> dev_data;           // fc weights, biases, bn params (canonical payload)
@@ -216,6 +220,155 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   MIG_CHECK(conv_lds_bytes(a) <= 160 * 1024, 2, "conv tile exceeds LDS");
 }
 
+// ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
+static unsigned short host_f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0) {
+  const int S = m.d.bufs[o.src].S;
+  MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
+  const int cells = S / 2;
+  const int NT = cdiv(o.cout, 32);
+  ConvArgs &a = cp.a;
+  a = ConvArgs{};
+  a.S = S;
+  a.cout = o.cout;
+  a.coutp = NT * 32;
+  a.ksize = o.ksize;
+  a.relu = o.relu;
+  a.pool = pool_mode;
+  a.out_c0 = dst_c0;
+  if (o.ksize == 1 && NT == 3 && cells % 4 == 0) {
+    cp.cfg = CONV_CFG_4x1_2x3;
+    a.tcx = 2, a.tcy = 4, a.tcz = 4;
+  } else if (o.ksize == 1 && NT == 5) {
+    cp.cfg = CONV_CFG_4x1_1x5;
+    if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 3;
+    else a.tcx = 2, a.tcy = 2, a.tcz = 4;
+  } else if (cells == 3 && NT % 4 == 0) {
+    cp.cfg = CONV_CFG_1x4_7x1;
+    a.tcx = a.tcy = a.tcz = 3;
+  } else if (cells == 6 && NT % 2 == 0) {
+    cp.cfg = CONV_CFG_3x2_2x1;
+    a.tcx = 2, a.tcy = 2, a.tcz = 6;
+  } else {
+    cp.cfg = CONV_CFG_4x1_2x1;
+    if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
+    else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
+    else if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
+    else a.tcx = 2, a.tcy = 4, a.tcz = 4;
+  }
+  a.ntx = cdiv(cells, a.tcx);
+  a.nty = cdiv(cells, a.tcy);
+  a.ntz = cdiv(cells, a.tcz);
+  const int cin8 = (cdiv(o.cin, 8) + 1) & ~1;  // octets, rounded up to even: the two k-halves of an MFMA share a tap
+  const int halo = o.ksize == 3 ? 1 : 0;
+  const size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
+  const int taps = o.ksize * o.ksize * o.ksize;
+  size_t budget = 36 * 1024;  // small tiles, 4 workgroups per CU: staging and MFMA phases of different workgroups overlap (measured best of 24..72 KB)
+  if (const char *ev = getenv("MI_GNINA_BF16_LDS_KB"))
+    if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
+  int best = 2;
+  for (int c = 2; c <= cin8; c += 2) {
+    if (cin8 % c) continue;
+    if (HV * 8 * (c | 1) * 2 + (size_t)taps * c * 4 + 64 * c + HV * 4 <= budget) best = c;
+  }
+  a.cc4 = best;             // octets per chunk
+  a.ccs = 8 * (best | 1);   // odd octet stride: consecutive voxels land on different 16-byte LDS slots
+  a.nchunks = cin8 / best;
+  a.cin4 = cin8;
+  const int Q = taps * a.cc4, P = (Q + 1) / 2;
+  std::vector<unsigned short> wp((size_t)a.nchunks * P * 2 * a.coutp * 8, 0);
+  const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
+  for (int ch = 0; ch < a.nchunks; ch++)
+    for (int pr = 0; pr < P; pr++)
+      for (int kh = 0; kh < 2; kh++) {
+        const int q = 2 * pr + kh;
+        if (q >= Q) continue;
+        const int tap = q / a.cc4, c8 = q % a.cc4;
+        for (int j = 0; j < 8; j++) {
+          const int c = (ch * a.cc4 + c8) * 8 + j;
+          if (c >= o.cin) continue;
+          for (int n = 0; n < o.cout; n++)
+            wp[((((size_t)ch * P + pr) * 2 + kh) * a.coutp + n) * 8 + j] =
+                host_f2bf(w[((size_t)tap * o.cin + c) * o.cout + n]);
+        }
+      }
+  std::vector<float> wpf((wp.size() + 1) / 2, 0.f);
+  memcpy(wpf.data(), wp.data(), wp.size() * sizeof(unsigned short));
+  a.wp = push_dev(m, wpf);
+  std::vector<float> bias(a.coutp, 0.f);
+  std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
+  a.bias = push_dev(m, bias);
+  if (o.bn_scale_off >= 0) {
+    std::vector<float> sc(cin8 * 8, 0.f), sh(cin8 * 8, 0.f);
+    std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+    std::copy(m.d.data.begin() + o.bn_shift_off, m.d.data.begin() + o.bn_shift_off + o.cin, sh.begin());
+    a.bn_scale = push_dev(m, sc);
+    a.bn_shift = push_dev(m, sh);
+  }
+  cp.src = o.src;
+  cp.dst = dst_buf;
+  cp.cin = o.cin;
+  MIG_CHECK(conv_bf16_lds_bytes(a) <= 160 * 1024, 2, "bf16 conv tile exceeds LDS");
+}
+
+// The forward program on the bf16 kernels.  Tensors that stay fp32: the pooled voxel grid (written by the
+// voxelizer), whatever feeds the fully connected heads, the global-max output.
+static void build_bf16_program(Model &m) {
+  const ModelDesc &d = m.d;
+  std::vector<char> f32(d.bufs.size(), 0);
+  f32[m.input_dst] = 1;
+  for (const Op &o : d.ops) {
+    if (o.kind == OpKind::Fc) f32[o.src] = 1;
+    if (o.kind == OpKind::GMax) f32[o.dst] = 1;
+  }
+  std::vector<Step> out;
+  for (size_t i = 1; i < d.ops.size(); i++) {
+    const Op &o = d.ops[i];
+    Step st;
+    st.kind = o.kind;
+    if (o.kind == OpKind::Conv) {
+      int pool_mode = 0, dst = o.dst;
+      if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == o.dst && o.src != o.dst &&
+          o.dst_c0 == 0 && o.cout == d.bufs[o.dst].C) {
+        bool used_elsewhere = false;
+        for (size_t j = i + 2; j < d.ops.size(); j++)
+          if (d.ops[j].src == o.dst) used_elsewhere = true;
+        if (!used_elsewhere) {
+          pool_mode = d.ops[i + 1].pool_mode;
+          dst = d.ops[i + 1].dst;
+          i++;
+        }
+      }
+      MIG_CHECK(f32[o.src] || m.buf_cp[o.src] % 8 == 0, 2, "bf16 path: channel stride must be a multiple of 8");
+      MIG_CHECK(f32[dst] || (m.buf_cp[dst] % 8 == 0 && o.dst_c0 % 8 == 0), 2, "bf16 path: unaligned output slice");
+      plan_conv_bf16(m, o, st.conv, pool_mode, dst, o.dst_c0);
+      st.conv.a.in_f32 = f32[o.src];
+      st.conv.a.out_f32 = f32[dst];
+      st.has_bn = o.bn_scale_off >= 0;
+    } else if (o.kind == OpKind::GMax) {
+      st.src = o.src;
+      st.dst = o.dst;
+      st.C = d.bufs[o.src].C;
+      st.src_bf16 = !f32[o.src];
+    } else if (o.kind == OpKind::Fc) {
+      st.src = o.src;
+      st.w_off = o.w_off;
+      st.b_off = o.b_off;
+      st.n_in = o.n_in;
+    } else {
+      throw Error(2, "bf16 path: stand-alone pooling layers are not supported");
+    }
+    out.push_back(st);
+  }
+  m.hsteps = std::move(out);
+}
+
 static Model *build_model(ModelDesc &&desc) {
   std::unique_ptr<Model> m(new Model());
   m->d = std::move(desc);
@@ -353,6 +506,7 @@ struct VoxGroup {  // models sharing one voxelization: same maps, geometry, radi
 struct Scorer {
   std::vector<Model *> models;
   hipStream_t stream = nullptr;
+  int precision = 0;  // 0 = fp32 (parity path), 1 = bf16-MFMA forward (mi_scorer_set_precision)
   int cap = 1024;    // poses per launch of the call in flight: min(chunk, B, what the activation budget allows)
   int chunk = 1024;  // poses per launch: fewer, larger launches win (93.6k vs 87.1k poses/s at 256); 2.4 MB/pose of HBM
   bool have_receptor = false;
@@ -773,7 +927,18 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
                         size_t pooled_slot = 0) {
   Model *m = s.models[mi];
-  const std::vector<Step> &steps = grad ? m->gsteps : m->steps;
+  const bool bf16 = s.precision == 1 && !grad;  // the gradient program is fp32 only
+  if (bf16) {
+    std::call_once(m->hsteps_once, [&] {
+      try {
+        build_bf16_program(*m);
+      } catch (const std::exception &e) {
+        m->hsteps_error = e.what();
+      }
+    });
+    MIG_CHECK(m->hsteps_error.empty(), 2, "bf16 program of " + m->d.name + ": " + m->hsteps_error);
+  }
+  const std::vector<Step> &steps = bf16 ? m->hsteps : (grad ? m->gsteps : m->steps);
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
@@ -794,16 +959,18 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.out = buf_ptr(st.conv.dst);
         a.out_cs = m->buf_cp[st.conv.dst];
         if (grad && a.pool == 1) a.argmax_out = arg_ptr(st.conv.dst);
-        a.sparse = (st.conv.src == m->input_dst && !st.has_bn) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
+        a.sparse = (st.conv.src == m->input_dst && !st.has_bn && !bf16) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
         {
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
           char nm[96];
           snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s", a.ksize, a.S, st.conv.cin, a.cout,
                    a.pool ? "_pool" : "");
+          if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
           ProfScope ps(s, nm, 2.0 * nb * S3 * taps * st.conv.cin * a.cout,
                        (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
-          launch_conv(a, st.conv.cfg, nb, s.stream);
+          if (bf16) launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
+          else launch_conv(a, st.conv.cfg, nb, s.stream);
         }
         break;
       }
@@ -812,8 +979,12 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                        m->d.bufs[st.src].S, st.pool_mode, s.stream);
         break;
       case OpKind::GMax:
-        launch_gmax(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
-                    m->d.bufs[st.src].S, s.stream);
+        if (st.src_bf16)
+          launch_gmax_bf16(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
+                           m->d.bufs[st.src].S, s.stream);
+        else
+          launch_gmax(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
+                      m->d.bufs[st.src].S, s.stream);
         break;
       case OpKind::Fc: {
         ProfScope ps(s, "fc_heads", 2.0 * nb * 3.0 * st.n_in, (double)nb * st.n_in * 4.0, nb);
@@ -1271,6 +1442,15 @@ mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_
   MIG_CHECK(sc, 1, "NULL scorer");
   score_batch_grad(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var,
                    lig_grad, MI_MEM_HOST);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_set_precision(mi_scorer *sc, int precision) {
+  MI_TRY
+  MIG_CHECK(sc, 1, "NULL scorer");
+  MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16, 1, "unknown precision");
+  reinterpret_cast<Scorer *>(sc)->precision = precision;
   return MI_OK;
   MI_CATCH_STATUS
 }

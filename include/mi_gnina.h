@@ -105,6 +105,13 @@ mi_status mi_scorer_score_batch(mi_scorer *, const float *lig_xyz, const int32_t
 mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                    const float *centers, float *pose, float *affinity, float *loss,
                                    float *aff_var, unsigned flags);
+/* Arithmetic of the CNN forward pass.  MI_PRECISION_FP32 (default) is the parity path: exact fp32 MFMA,
+ * scores within 1e-4 of the reference.  MI_PRECISION_BF16 (BASELINE config 5, "bf16 MFMA path") runs the
+ * convolutions on v_mfma_f32_32x32x16_bf16 with bf16 activations / weights and fp32 accumulation; voxelization,
+ * the fully connected heads and the score post-processing stay fp32.  Its deviation from the fp32 path is a
+ * measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.  Gradient calls always run in fp32. */
+enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1 };
+mi_status mi_scorer_set_precision(mi_scorer *, int precision);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
  * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as

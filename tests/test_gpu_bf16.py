@@ -1,0 +1,84 @@
+"""BASELINE config 5, "bf16 MFMA path": mi_scorer_set_precision(MI_PRECISION_BF16) runs the convolutions on
+v_mfma_f32_32x32x16_bf16 with bf16 activations and weights.  It is NOT the parity path; this file MEASURES
+its deviation from the exact-fp32 path on the golden complexes and pins the measured tolerance (bf16 has 8
+mantissa bits: relative rounding 2^-9 per activation / weight, accumulated in fp32)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["default2017", "crossdock_default2018", "crossdock_default2018_KD_4", "dense", "dense_1_3",
+          "dense_1_3_PT_KD_3"]
+# measured on MI355X (round 1): max |d pose| 0.040 (dense), max |d affinity| 0.062 (crossdock_default2018_KD_4)
+POSE_TOL, AFF_TOL = 0.08, 0.12
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import capi as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def CG(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_bf16_forward_within_measured_tolerance(capi, CG, name):
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    f32 = s.score_batch(poses, lig_smt)
+    s.set_precision(True)
+    b16 = s.score_batch(poses, lig_smt)
+    dp, da = np.abs(b16["pose"] - f32["pose"]).max(), np.abs(b16["affinity"] - f32["affinity"]).max()
+    print(f"{name}: bf16 vs fp32 max|dpose| {dp:.2e} max|daffinity| {da:.2e}")
+    assert dp < POSE_TOL and da < AFF_TOL
+    assert dp > 0 or da > 0                       # really a different arithmetic, not a silent fp32 run
+    # affinity keeps its meaning: relative error well under a percent of the predicted pK
+    assert (np.abs(b16["affinity"] - f32["affinity"]) < 0.02 * np.abs(f32["affinity"]) + 0.02).all()
+    # the fp32 path is untouched: switching back reproduces the first result bit for bit
+    s.set_precision(False)
+    again = s.score_batch(poses, lig_smt)
+    assert np.array_equal(again["pose"], f32["pose"]) and np.array_equal(again["affinity"], f32["affinity"])
+    assert np.abs(f32["pose"] - CG[name + "/pose"]).max() < 1e-4
+
+
+def test_bf16_ranking_and_statistics_on_a_large_batch(capi, CG):
+    """On 512 random poses the bf16 scores must rank like the fp32 ones.  The deviation is mostly a constant
+    offset (rounded weights are a fixed perturbation of the network: measured +0.030 pK for this ensemble) with
+    a small pose-dependent part."""
+    from gnina_amd import synth
+    name = "dense_1_3"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = synth.make_poses(np.random.RandomState(9), poses[0] - poses[0].mean(0), 512)
+    s = capi.Scorer([name, "crossdock_default2018_KD_4"])
+    s.set_receptor(rec_xyz, rec_smt)
+    f32 = s.score_batch(many, lig_smt)
+    s.set_precision(True)
+    b16 = s.score_batch(many, lig_smt)
+    d = b16["affinity"] - f32["affinity"]
+    print(f"affinity bf16 - fp32: mean {d.mean():+.4f} std {d.std():.4f} max {np.abs(d).max():.4f}")
+    assert np.abs(d).max() < AFF_TOL and abs(d.mean()) < 0.06 and d.std() < 0.02
+    assert np.corrcoef(b16["affinity"], f32["affinity"])[0, 1] > 0.999
+    assert np.corrcoef(b16["pose"], f32["pose"])[0, 1] > 0.995
+    assert (np.abs(b16["variance"] - f32["variance"]) < 0.03 * f32["variance"] + 0.05).all()
+
+
+def test_bf16_at_96_and_gradient_stays_fp32(capi, CG):
+    name = "dense_1_3"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    s = capi.Scorer([capi.Model(name, resolution=0.25, dimension=23.75)])
+    s.set_receptor(rec_xyz, rec_smt)
+    f32 = s.score_batch(poses, lig_smt)
+    g32 = s.score_grad(poses[:1], lig_smt)
+    s.set_precision(True)
+    b16 = s.score_batch(poses, lig_smt)
+    assert np.abs(b16["pose"] - f32["pose"]).max() < POSE_TOL
+    assert np.abs(b16["affinity"] - f32["affinity"]).max() < AFF_TOL
+    g16 = s.score_grad(poses[:1], lig_smt)         # gradient calls run the fp32 program regardless
+    assert np.array_equal(g16["lig_grad"], g32["lig_grad"]) and np.array_equal(g16["loss"], g32["loss"])
