@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);  // [Q]
   int *s_jq = s_qoff + Q;                                // [Q] compacted list of the non-zero quads of a chunk
   int *s_flag = s_jq + Q;                                // [nchunks][CC4] "this channel quad is non-zero in the tile"
+  int *s_vox = s_flag + p.nchunks * CC4;                 // [HV] voxel index of every halo position inside the pose, -1 = padding
 
   for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = 0;
 
@@ -92,6 +93,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  // halo position -> voxel, once per workgroup: the per-chunk staging loops then run without integer divisions
+  for (int hv = tid; hv < HV; hv += NTHREADS) {
+    const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    int v = -1;
+    if (in)
+      v = p.in_mode == 2 ? (((x >> 1) * (S >> 1) + (y >> 1)) * (S >> 1) + (z >> 1)) | ((((x & 1) << 2) | ((y & 1) << 1) | (z & 1)) << 28)
+                         : (x * S + y) * S + z;
+    s_vox[hv] = v;
+  }
+  const unsigned inv_cc4 = ((1u << 20) + CC4 - 1) / CC4;  // it / CC4 == (it * inv_cc4) >> 20 for it < 2^20 / CC4
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
   const float *wq = p.wp + (size_t)(n_base + row) * 4;  // + ((pair*2 + kh) * coutp) * 4
   const size_t wstride = (size_t)p.coutp * 4;           // floats per quad row of packed weights
@@ -100,49 +113,77 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     __syncthreads();  // previous chunk's reads done (and s_qoff visible on the first pass)
     // ---- stage the halo tile of this channel chunk into LDS (zero padded; BN folded in) ----
     const int c_base = chunk * CC4 * 4;
-    for (int it = tid; it < HV * CC4; it += NTHREADS) {
-      int hv = it / CC4, c4 = it - hv * CC4;
-      int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
-      int x = x0 + hx, y = y0 + hy, z = z0 + hz;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S &&
-          chunk * CC4 + c4 < p.cin4) {
-        const int c = c_base + c4 * 4;
-        if (p.in_mode == 2) {
-          // transposed conv fed by a max-pooled gradient: un-pool while staging (no full-size tensor in HBM)
-          const int Sh = S >> 1;
-          const size_t cell = (((size_t)b * Sh + (x >> 1)) * Sh + (y >> 1)) * Sh + (z >> 1);
-          const int r = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
-          const float4 g = *reinterpret_cast<const float4 *>(p.in + cell * p.in_cs + c);
-          const uchar4 am = *reinterpret_cast<const uchar4 *>(p.in_argmax + cell * p.in_cs + c);
-          const float4 act = *reinterpret_cast<const float4 *>(p.in_act + cell * p.in_act_cs + c);
-          val.x = (am.x == r && act.x > 0.f) ? g.x : 0.f;
-          val.y = (am.y == r && act.y > 0.f) ? g.y : 0.f;
-          val.z = (am.z == r && act.z > 0.f) ? g.z : 0.f;
-          val.w = (am.w == r && act.w > 0.f) ? g.w : 0.f;
-        } else {
-          const size_t vox = ((size_t)x * S + y) * S + z;
-          val = *reinterpret_cast<const float4 *>(in_b + vox * p.in_cs + c);
-          if (p.in_mode == 1) {  // ReLU backward: gradient passes where the forward activation was > 0
-            const float4 act =
-                *reinterpret_cast<const float4 *>(p.in_act + ((size_t)b * S * S * S + vox) * p.in_act_cs + c);
-            val.x = act.x > 0.f ? val.x : 0.f;
-            val.y = act.y > 0.f ? val.y : 0.f;
-            val.z = act.z > 0.f ? val.z : 0.f;
-            val.w = act.w > 0.f ? val.w : 0.f;
-          }
-          if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
-            const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
-            const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
-            val.x = val.x * sc.x + sh.x;
-            val.y = val.y * sc.y + sh.y;
-            val.z = val.z * sc.z + sh.z;
-            val.w = val.w * sc.w + sh.w;
+    // All global loads of a batch of U items per thread are issued before the first one is consumed: a
+    // dependent load -> (mask, BN) -> ds_write chain per item would serialise one L2/HBM latency per iteration.
+    const int total_items = HV * CC4;
+    constexpr int U = 4;
+    for (int base = 0; base < total_items; base += NTHREADS * U) {
+      float4 val[U], act[U];
+      uchar4 am[U];
+      int dst[U], cq[U], rr[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int it = base + u * NTHREADS + tid;
+        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        act[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        am[u] = make_uchar4(0, 0, 0, 0);
+        dst[u] = -1;
+        cq[u] = -1;
+        rr[u] = 0;
+        if (it < total_items) {
+          const int hv = (int)(((unsigned)it * inv_cc4) >> 20), c4 = it - hv * CC4;
+          const int vi = s_vox[hv];
+          dst[u] = hv * CCs + c4 * 4;
+          if (vi >= 0 && chunk * CC4 + c4 < p.cin4) {
+            const int c = c_base + c4 * 4;
+            cq[u] = c4;
+            if (p.in_mode == 2) {
+              // transposed conv fed by a max-pooled gradient: un-pool while staging (no full-size tensor in HBM)
+              const int Sh = S >> 1;
+              const size_t cell = (size_t)b * Sh * Sh * Sh + (vi & 0x0fffffff);
+              rr[u] = vi >> 28;
+              val[u] = *reinterpret_cast<const float4 *>(p.in + cell * p.in_cs + c);
+              am[u] = *reinterpret_cast<const uchar4 *>(p.in_argmax + cell * p.in_cs + c);
+              act[u] = *reinterpret_cast<const float4 *>(p.in_act + cell * p.in_act_cs + c);
+            } else {
+              val[u] = *reinterpret_cast<const float4 *>(in_b + (size_t)vi * p.in_cs + c);
+              if (p.in_mode == 1)  // ReLU backward: gradient passes where the forward activation was > 0
+                act[u] = *reinterpret_cast<const float4 *>(p.in_act + ((size_t)b * S * S * S + vi) * p.in_act_cs + c);
+            }
           }
         }
       }
-      *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
-      if (SPARSE && (val.x != 0.f || val.y != 0.f || val.z != 0.f || val.w != 0.f)) s_flag[chunk * CC4 + c4] = 1;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (dst[u] < 0) continue;
+        float4 v = val[u];
+        if (cq[u] >= 0) {
+          if (p.in_mode == 2) {
+            v.x = (am[u].x == rr[u] && act[u].x > 0.f) ? v.x : 0.f;
+            v.y = (am[u].y == rr[u] && act[u].y > 0.f) ? v.y : 0.f;
+            v.z = (am[u].z == rr[u] && act[u].z > 0.f) ? v.z : 0.f;
+            v.w = (am[u].w == rr[u] && act[u].w > 0.f) ? v.w : 0.f;
+          } else {
+            if (p.in_mode == 1) {
+              v.x = act[u].x > 0.f ? v.x : 0.f;
+              v.y = act[u].y > 0.f ? v.y : 0.f;
+              v.z = act[u].z > 0.f ? v.z : 0.f;
+              v.w = act[u].w > 0.f ? v.w : 0.f;
+            }
+            if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
+              const int c = c_base + cq[u] * 4;
+              const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
+              const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
+              v.x = v.x * sc.x + sh.x;
+              v.y = v.y * sc.y + sh.y;
+              v.z = v.z * sc.z + sh.z;
+              v.w = v.w * sc.w + sh.w;
+            }
+          }
+        }
+        *reinterpret_cast<float4 *>(s_tile + dst[u]) = v;
+        if (SPARSE && cq[u] >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) s_flag[chunk * CC4 + cq[u]] = 1;
+      }
     }
     __syncthreads();
 
@@ -174,85 +215,56 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       __syncthreads();
     }
 
-    if (!SPARSE) {
-      // ---- dense K loop over quad pairs of this chunk (affine addressing: the weight loads of the
-      // next pairs can be issued ahead of the MFMAs) ----
-      const float *wchunk = wq + (size_t)chunk * P * 2 * wstride + (size_t)kh * wstride;
-      float4 w[TN], wn[TN];  // weights of the current / next pair: the L2 latency hides behind 4*TM*TN MFMAs
-#pragma unroll
-      for (int n = 0; n < TN; n++) w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)n * 32 * 4);
-      for (int pr = 0; pr < P; pr++) {
-        int q = 2 * pr + kh;
+    // ---- K loop over quad pairs, unrolled by two with two operand register sets (ping-pong): the LDS
+    // operands and the L2-resident weight rows of pair pr + 1 are in flight while the eight MFMAs per
+    // (M-tile, N-tile) of pair pr run.  A single-set "fetch next, then copy" loop gets folded back by the
+    // compiler into load -> s_waitcnt vmcnt(0) -> MFMA, which exposes the L2 latency once per pair.
+    // Dense: pair pr = quads (2 pr, 2 pr + 1), affine addressing.  Sparse: pairs of the compacted list
+    // of surviving quads, in their original order (the fp32 sum stays bit-identical).
+    const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
+    const int NP = SPARSE ? (J + 1) >> 1 : P;
+    auto load_pair = [&](int pr, float4 *aa, float4 *ww) {
+      int q;
+      bool live = true;
+      if (SPARSE) {
+        const int j = 2 * pr + kh;
+        live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
+        q = s_jq[live ? j : J - 1];
+      } else {
+        q = 2 * pr + kh;
         q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
-        const int qo = s_qoff[q];
-        float4 a[TM];
-#pragma unroll
-        for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-        const int prn = pr + 1 < P ? pr + 1 : pr;
-#pragma unroll
-        for (int n = 0; n < TN; n++)
-          wn[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)prn * 2 * wstride + (size_t)n * 32 * 4);
-#pragma unroll
-        for (int m = 0; m < TM; m++)
-#pragma unroll
-          for (int n = 0; n < TN; n++) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
-          }
-#pragma unroll
-        for (int n = 0; n < TN; n++) w[n] = wn[n];
       }
-    } else {
-      // ---- K loop over pairs of surviving quads (compacted list), software pipelined: the list entry,
-      // LDS operand and weight row of pair pr+1 are fetched before the MFMAs of pair pr ----
-      const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
-      const int PJ = (J + 1) >> 1;
-      float4 a[TM], w[TN], an[TM], wn[TN];
-      {
-        const bool live = kh < J;
-        const int q = s_jq[live ? kh : J - 1];
-        const int qo = s_qoff[q];
+      const int qo = s_qoff[q];
 #pragma unroll
-        for (int m = 0; m < TM; m++) {
-          a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-          if (!live) a[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < TM; m++) {
+        aa[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+        if (SPARSE && !live) aa[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float *wrow = SPARSE ? wchunk + (size_t)q * wstride : wchunk + (size_t)(2 * pr + kh) * wstride;
+#pragma unroll
+      for (int n = 0; n < TN; n++) ww[n] = *reinterpret_cast<const float4 *>(wrow + (size_t)n * 32 * 4);
+    };
+    auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].x, ww[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].y, ww[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].z, ww[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].w, ww[n].w, acc[m][n], 0, 0, 0);
         }
-#pragma unroll
-        for (int n = 0; n < TN; n++)
-          w[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)q * wstride + (size_t)n * 32 * 4);
-      }
-      for (int pr = 0; pr < PJ; pr++) {
-        {
-          const int j = 2 * (pr + 1) + kh;
-          const bool live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
-          const int q = s_jq[live ? j : J - 1];
-          const int qo = s_qoff[q];
-#pragma unroll
-          for (int m = 0; m < TM; m++) {
-            an[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-            if (!live) an[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int n = 0; n < TN; n++)
-            wn[n] = *reinterpret_cast<const float4 *>(wchunk + (size_t)q * wstride + (size_t)n * 32 * 4);
-        }
-#pragma unroll
-        for (int m = 0; m < TM; m++)
-#pragma unroll
-          for (int n = 0; n < TN; n++) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, w[n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, w[n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, w[n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, w[n].w, acc[m][n], 0, 0, 0);
-          }
-#pragma unroll
-        for (int m = 0; m < TM; m++) a[m] = an[m];
-#pragma unroll
-        for (int n = 0; n < TN; n++) w[n] = wn[n];
-      }
+    };
+    float4 a0[TM], a1[TM], w0[TN], w1[TN];
+    load_pair(0, a0, w0);
+    int pr = 0;
+    for (; pr + 1 < NP; pr += 2) {
+      load_pair(pr + 1, a1, w1);
+      mfma_pair(a0, w0);
+      if (pr + 2 < NP) load_pair(pr + 2, a0, w0);
+      mfma_pair(a1, w1);
     }
+    if (NP & 1) mfma_pair(a0, w0);
   }
 
   // ---- epilogue: bias, ReLU, optional 2x2x2 pool, store channels-last ----
@@ -453,7 +465,7 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  return HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4) * sizeof(int);
+  return HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4 + HV) * sizeof(int);
 }
 
 template <int WM, int WN, int TM, int TN, bool SPARSE> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
