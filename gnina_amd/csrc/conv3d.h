@@ -44,8 +44,8 @@ struct ConvArgs {
   int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
 };
 
-enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_3x2_2x1 = 1, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
-       CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6 };
+enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
+       CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6, CONV_CFG_2x2_3x1 = 7 };
 
 size_t conv_lds_bytes(const ConvArgs &p);
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn);

@@ -491,9 +491,9 @@ template <int WM, int WN, int TM, int TN> static void launch_cfg(const ConvArgs 
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1>(p, B, s); break;
-    case CONV_CFG_3x2_2x1: launch_cfg<3, 2, 2, 1>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
     case CONV_CFG_4x1_2x3: launch_cfg<4, 1, 2, 3>(p, B, s); break;
+    case CONV_CFG_2x2_3x1: launch_cfg<2, 2, 3, 1>(p, B, s); break;
     case CONV_CFG_4x1_1x5: launch_cfg<4, 1, 1, 5>(p, B, s); break;
     case CONV_CFG_N16_TM4:
     case CONV_CFG_N16_TM3: {
@@ -520,8 +520,8 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
-    case CONV_CFG_3x2_2x1: *wm = 3, *wn = 2, *tm = 2, *tn = 1; break;
     case CONV_CFG_4x1_2x3: *wm = 4, *wn = 1, *tm = 2, *tn = 3; break;
+    case CONV_CFG_2x2_3x1: *wm = 2, *wn = 2, *tm = 3, *tn = 1; break;
     case CONV_CFG_4x1_1x5: *wm = 4, *wn = 1, *tm = 1, *tn = 5; break;
     case CONV_CFG_N16_TM4: *wm = 4, *wn = 1, *tm = 4, *tn = 1; break;
     case CONV_CFG_N16_TM3: *wm = 4, *wn = 1, *tm = 3, *tn = 1; break;

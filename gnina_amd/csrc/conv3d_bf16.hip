@@ -350,7 +350,7 @@ template <int WM, int WN, int TM, int TN> static void launch_bf16(const ConvArgs
 void launch_conv_bf16(const ConvArgs &p, int cfg, int B, hipStream_t s) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: launch_bf16<4, 1, 2, 1>(p, B, s); break;
-    case CONV_CFG_3x2_2x1: launch_bf16<3, 2, 2, 1>(p, B, s); break;
+    case CONV_CFG_2x2_3x1: launch_bf16<2, 2, 3, 1>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_bf16<1, 4, 7, 1>(p, B, s); break;
     case CONV_CFG_4x1_2x3: launch_bf16<4, 1, 2, 3>(p, B, s); break;
     case CONV_CFG_4x1_1x5: launch_bf16<4, 1, 1, 5>(p, B, s); break;

@@ -132,7 +132,8 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     cp.cfg = CONV_CFG_1x4_7x1;
     a.tcx = a.tcy = a.tcz = 3;
   } else if (cells == 6 && NT % 2 == 0) {
-    cp.cfg = CONV_CFG_3x2_2x1;
+    cp.cfg = CONV_CFG_2x2_3x1;  // 24 cells = 6 M-tiles: 2 x 2 waves x 3 M-tiles, one wave per SIMD (a 3 x 2 = 6-wave
+                                // workgroup loads two SIMDs twice as much as the other two: measured 2.08 -> 1.71 ms)
     a.tcx = 2, a.tcy = 2, a.tcz = 6;
   } else {
     cp.cfg = CONV_CFG_4x1_2x1;  // 8 M-tiles = 32 cells
@@ -253,7 +254,7 @@ static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, i
     cp.cfg = CONV_CFG_1x4_7x1;
     a.tcx = a.tcy = a.tcz = 3;
   } else if (cells == 6 && NT % 2 == 0) {
-    cp.cfg = CONV_CFG_3x2_2x1;
+    cp.cfg = CONV_CFG_2x2_3x1;
     a.tcx = 2, a.tcy = 2, a.tcz = 6;
   } else {
     cp.cfg = CONV_CFG_4x1_2x1;
