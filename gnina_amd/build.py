@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi_gnina.so")
-SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "vina.hip", "vina_host.cpp"]
+SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "vina.hip", "vina_host.cpp",
+           "../host/typed_atoms.cpp"]
 # -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
 # bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -31,11 +32,12 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mi_gnina.h"))
+    headers.append(os.path.join(HERE, "host", "typed_atoms.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
     objs, rebuilt = [], False
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(objdir, src + ".o")
+        op = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_mtime):
             cmd = [hipcc()] + FLAGS + ["-c", sp, "-o", op]

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -114,6 +114,9 @@ def lib():
         L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mi_scorer_score_grad.restype = C.c_int
         L.mi_scorer_set_flex.argtypes = [vp, vp, C.c_int]
+        L.mi_read_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.mi_write_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int]
+        L.mi_io_last_error.restype = C.c_char_p
         L.mi_scorer_set_precision.argtypes = [vp, C.c_int]
         L.mi_scorer_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
@@ -201,6 +204,23 @@ def _i32(a):
 
 
 WEIGHTS_DIR = os.path.join(_HERE, "weights")
+
+
+def read_gninatypes(path):
+    """`.gninatypes` (gninatyper.cpp:30-36) -> (xyz [n,3] float32, smt [n] int32)"""
+    n = C.c_int()
+    if lib().mi_read_gninatypes(path.encode(), None, None, 0, C.byref(n)) != MI_OK:
+        raise MiGninaError(lib().mi_io_last_error().decode())
+    xyz, smt = np.empty((n.value, 3), dtype=np.float32), np.empty(n.value, dtype=np.int32)
+    if lib().mi_read_gninatypes(path.encode(), _ptr(xyz), _ptr(smt), n.value, C.byref(n)) != MI_OK:
+        raise MiGninaError(lib().mi_io_last_error().decode())
+    return xyz, smt
+
+
+def write_gninatypes(path, xyz, smt):
+    xyz, smt = _f32(xyz).reshape(-1, 3), _i32(smt)
+    if lib().mi_write_gninatypes(path.encode(), _ptr(xyz), _ptr(smt), len(smt)) != MI_OK:
+        raise MiGninaError(lib().mi_io_last_error().decode())
 
 
 class Model:

@@ -297,6 +297,16 @@ mi_status mi_cnn_refine_batch(mi_vina *, mi_scorer *, float *confs, int B, const
 mi_status mi_vina_eval_latency(mi_vina *, const float *confs, int B, int mode, int reps, float *ms_out);
 void *mi_vina_stream(mi_vina *);
 
+/* ---- typed-atom files ------------------------------------------------------------
+ * `.gninatypes` = headerless array of struct { float x, y, z; int type; } (gninasrc/gninatyper/
+ * gninatyper.cpp:30-36,65-75), type = smina type index 0..27: what gnina's `gninatyper` writes and
+ * libmolgrid's providers read.  mi_read_gninatypes fills xyz [capacity][3] / smt [capacity] and *n_atoms
+ * (call with xyz = smt = NULL to get the count).  Errors: MI_ERR_INVALID + mi_io_last_error().  Host only;
+ * the C++ form is gnina_amd/host/typed_atoms.h. */
+mi_status mi_read_gninatypes(const char *path, float *xyz, int32_t *smt, int capacity, int *n_atoms);
+mi_status mi_write_gninatypes(const char *path, const float *xyz, const int32_t *smt, int n_atoms);
+const char *mi_io_last_error(void);
+
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this
  * scorer is bracketed by HIP events on the scorer's stream.  mi_scorer_profile_json drains the
  * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes}], where

@@ -106,3 +106,38 @@ def test_rank_poses_sort_and_remove_redundant(capi):
     assert list(capi.rank_poses(score, aff, energy, coords, 1, 1.0)) == [7, 6, 5, 4, 3, 2]   # by affinity descending
     assert len(capi.rank_poses(score, aff, energy, coords, 0, 0.0)) == 8                      # nothing is redundant
     assert len(capi.rank_poses(score[:0], aff[:0], energy[:0], coords[:0], 0, 1.0)) == 0
+
+
+def test_gninatypes_round_trip_and_errors(capi, tmp_path):
+    """`.gninatypes` reader/writer (gninatyper.cpp:30-36: struct {float x, y, z; int type;} records)."""
+    import struct
+    rng = np.random.RandomState(0)
+    xyz = rng.normal(0, 10, (57, 3)).astype(np.float32)
+    smt = rng.randint(0, 28, 57).astype(np.int32)
+    # a file written the way gninatyper writes it
+    p = tmp_path / "lig.gninatypes"
+    with open(p, "wb") as f:
+        for i in range(57):
+            f.write(struct.pack("<fffi", *xyz[i], smt[i]))
+    x2, s2 = capi.read_gninatypes(str(p))
+    assert np.array_equal(x2, xyz) and np.array_equal(s2, smt)
+    # our writer produces the same bytes
+    q = tmp_path / "out.gninatypes"
+    capi.write_gninatypes(str(q), xyz, smt)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    # empty file = zero atoms
+    e = tmp_path / "empty.gninatypes"
+    e.write_bytes(b"")
+    x0, s0 = capi.read_gninatypes(str(e))
+    assert x0.shape == (0, 3) and s0.shape == (0,)
+    # truncated record, bad type index, missing file
+    t = tmp_path / "trunc.gninatypes"
+    t.write_bytes(open(p, "rb").read()[:-5])
+    with pytest.raises(capi.MiGninaError, match="multiple of the 16-byte"):
+        capi.read_gninatypes(str(t))
+    b = tmp_path / "bad.gninatypes"
+    b.write_bytes(struct.pack("<fffi", 0, 0, 0, 28))
+    with pytest.raises(capi.MiGninaError, match="outside 0..27"):
+        capi.read_gninatypes(str(b))
+    with pytest.raises(capi.MiGninaError, match="could not open"):
+        capi.read_gninatypes(str(tmp_path / "nope.gninatypes"))
