@@ -54,6 +54,8 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s);
 size_t conv_bf16_lds_bytes(const ConvArgs &p);
 void launch_conv_bf16(const ConvArgs &p, int cfg, int B, hipStream_t s);
 void launch_gmax_bf16(const void *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
+void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
+                               int S, hipStream_t s);
 
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);
 void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,

@@ -374,4 +374,28 @@ void launch_gmax_bf16(const void *in, float *out, int B, int C, int in_cs, int o
                      in_cs, out_cs, S * S * S);
 }
 
+// max_pool3d(kernel = whole grid) backward on a bf16 activation: fp32 gradient to the first arg-max voxel
+__global__ void gmax_backward_bf16_kernel(const unsigned short *act, const float *g_out, float *g_in, int C, int in_cs,
+                                          int out_cs, int S3) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const unsigned short *src = act + (size_t)b * S3 * in_cs + c;
+    float m = bf2f(src[0]);
+    int am = 0;
+    for (int v = 1; v < S3; v++) {
+      const float t = bf2f(src[(size_t)v * in_cs]);
+      if (t > m) m = t, am = v;
+    }
+    float *dst = g_in + (size_t)b * S3 * in_cs + c;
+    const float g = g_out[(size_t)b * out_cs + c];
+    for (int v = 0; v < S3; v++) dst[(size_t)v * in_cs] = v == am ? g : 0.f;
+  }
+}
+
+void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
+                               int S, hipStream_t s) {
+  hipLaunchKernelGGL(gmax_backward_bf16_kernel, dim3(B), dim3(256), 0, s,
+                     reinterpret_cast<const unsigned short *>(act), g_out, g_in, C, in_cs, out_cs, S * S * S);
+}
+
 }  // namespace mig

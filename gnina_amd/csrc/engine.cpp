@@ -64,8 +64,9 @@ struct Model {
   std::vector<Step> steps;          // executable program after fusion
   std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
   std::vector<Step> hsteps;         // bf16-MFMA forward program (built on first use, mi_scorer_set_precision)
-  std::once_flag hsteps_once;
-  std::string hsteps_error;
+  std::vector<Step> hgsteps;        // bf16-MFMA gradient program (max-pool networks: Default2017, Dense)
+  std::once_flag hsteps_once, hgsteps_once;
+  std::string hsteps_error, hgsteps_error;
   bool grad_supported = false;
   std::string grad_unsupported_reason;
   DevBuf<float> dev_data;           // fc weights, biases, bn params (canonical payload)
@@ -229,7 +230,8 @@ static unsigned short host_f2bf(float f) {
   return (unsigned short)(u >> 16);
 }
 
-static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0) {
+static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0,
+                           bool backward = false) {
   const int S = m.d.bufs[o.src].S;
   MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
   const int cells = S / 2;
@@ -285,6 +287,16 @@ static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, i
   const int Q = taps * a.cc4, P = (Q + 1) / 2;
   std::vector<unsigned short> wp((size_t)a.nchunks * P * 2 * a.coutp * 8, 0);
   const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
+  std::vector<float> wT;
+  if (backward) {  // W'[tap][co][ci] = W[taps-1-tap][ci][co] (flipped, transposed); o is the swapped-channel twin
+    const int fci = o.cout, fco = o.cin;
+    wT.resize((size_t)taps * o.cin * o.cout);
+    for (int t = 0; t < taps; t++)
+      for (int ci = 0; ci < fci; ci++)
+        for (int co = 0; co < fco; co++)
+          wT[((size_t)t * fco + co) * fci + ci] = w[((size_t)(taps - 1 - t) * fci + ci) * fco + co];
+    w = wT.data();
+  }
   for (int ch = 0; ch < a.nchunks; ch++)
     for (int pr = 0; pr < P; pr++)
       for (int kh = 0; kh < 2; kh++) {
@@ -303,7 +315,7 @@ static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, i
   memcpy(wpf.data(), wp.data(), wp.size() * sizeof(unsigned short));
   a.wp = push_dev(m, wpf);
   std::vector<float> bias(a.coutp, 0.f);
-  std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
+  if (!backward) std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
   a.bias = push_dev(m, bias);
   if (o.bn_scale_off >= 0) {
     std::vector<float> sc(cin8 * 8, 0.f), sh(cin8 * 8, 0.f);
@@ -320,8 +332,9 @@ static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, i
 
 // The forward program on the bf16 kernels.  Tensors that stay fp32: the pooled voxel grid (written by the
 // voxelizer), whatever feeds the fully connected heads, the global-max output.
-static void build_bf16_program(Model &m) {
+static void build_bf16_program(Model &m, bool grad) {
   const ModelDesc &d = m.d;
+  if (grad) MIG_CHECK(m.grad_supported, 2, m.grad_unsupported_reason);
   std::vector<char> f32(d.bufs.size(), 0);
   f32[m.input_dst] = 1;
   for (const Op &o : d.ops) {
@@ -341,6 +354,8 @@ static void build_bf16_program(Model &m) {
         for (size_t j = i + 2; j < d.ops.size(); j++)
           if (d.ops[j].src == o.dst) used_elsewhere = true;
         if (!used_elsewhere) {
+          // (gradient program: an avg pool would have to stay un-fused, which the bf16 path does not do)
+          MIG_CHECK(!(grad && d.ops[i + 1].pool_mode == 2), 2, "bf16 gradient: average-pooling networks run in fp32");
           pool_mode = d.ops[i + 1].pool_mode;
           dst = d.ops[i + 1].dst;
           i++;
@@ -352,6 +367,22 @@ static void build_bf16_program(Model &m) {
       st.conv.a.in_f32 = f32[o.src];
       st.conv.a.out_f32 = f32[dst];
       st.has_bn = o.bn_scale_off >= 0;
+      if (grad) {
+        // transposed twin: reads the fp32 gradient of this conv's output slice (masked by the bf16 / fp32
+        // activation), writes / accumulates the fp32 gradient of its input
+        MIG_CHECK(o.cout % 8 == 0, 2, "bf16 gradient: conv output channels must be a multiple of 8");
+        plan_conv_bf16(m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
+        st.has_bwd = true;
+        st.bwd.a.in_f32 = 1;
+        st.bwd.a.out_f32 = 1;
+        st.bwd.a.act_f32 = f32[dst];
+        if (st.has_bn) {
+          std::vector<float> sc(st.bwd.a.coutp, 0.f);
+          std::copy(d.data.begin() + o.bn_scale_off, d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+          st.bwd.a.out_scale = push_dev(m, sc);
+        }
+        st.bwd.a.accumulate = o.src == o.dst ? 1 : 0;
+      }
     } else if (o.kind == OpKind::GMax) {
       st.src = o.src;
       st.dst = o.dst;
@@ -367,7 +398,7 @@ static void build_bf16_program(Model &m) {
     }
     out.push_back(st);
   }
-  m.hsteps = std::move(out);
+  (grad ? m.hgsteps : m.hsteps) = std::move(out);
 }
 
 static Model *build_model(ModelDesc &&desc) {
@@ -923,23 +954,39 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   MIG_HIP(hipGetLastError());
 }
 
+// Does this call run on the bf16 kernels?  Forward: whenever the scorer asks for it (an unsupported layer
+// program is an error).  Gradient: max-pool networks (Default2017, Dense); average-pooling networks keep
+// their gradient calls in fp32.
+static bool use_bf16(Scorer &s, Model &m, bool grad) {
+  if (s.precision != 1) return false;
+  if (!grad) {
+    std::call_once(m.hsteps_once, [&] {
+      try {
+        build_bf16_program(m, false);
+      } catch (const std::exception &e) {
+        m.hsteps_error = e.what();
+      }
+    });
+    MIG_CHECK(m.hsteps_error.empty(), 2, "bf16 program of " + m.d.name + ": " + m.hsteps_error);
+    return true;
+  }
+  std::call_once(m.hgsteps_once, [&] {
+    try {
+      build_bf16_program(m, true);
+    } catch (const std::exception &e) {
+      m.hgsteps_error = e.what();
+    }
+  });
+  return m.hgsteps_error.empty();
+}
+
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
 // act[input_dst]; writes pose/aff/loss at out offsets.
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
                         size_t pooled_slot = 0) {
   Model *m = s.models[mi];
-  const bool bf16 = s.precision == 1 && !grad;  // the gradient program is fp32 only
-  if (bf16) {
-    std::call_once(m->hsteps_once, [&] {
-      try {
-        build_bf16_program(*m);
-      } catch (const std::exception &e) {
-        m->hsteps_error = e.what();
-      }
-    });
-    MIG_CHECK(m->hsteps_error.empty(), 2, "bf16 program of " + m->d.name + ": " + m->hsteps_error);
-  }
-  const std::vector<Step> &steps = bf16 ? m->hsteps : (grad ? m->gsteps : m->steps);
+  const bool bf16 = use_bf16(s, *m, grad);
+  const std::vector<Step> &steps = bf16 ? (grad ? m->hgsteps : m->hsteps) : (grad ? m->gsteps : m->steps);
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
@@ -1004,6 +1051,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
 // staging) -> avg un-pool.  Returns the device pointer of dL/d(pooled grid).
 static float *run_backward(Scorer &s, int mi, int nb) {
   Model *m = s.models[mi];
+  const bool bf16 = use_bf16(s, *m, true);
+  const std::vector<Step> &gsteps = bf16 ? m->hgsteps : m->gsteps;
   auto slot_of = [&](int id) { return id == m->input_dst ? kPooledSlot : (size_t)id; };
   auto count_of = [&](int id) {
     const BufDecl &bd = m->d.bufs[id];
@@ -1011,8 +1060,8 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   };
   auto act_ptr = [&](int id) { return act_buf(s, slot_of(id), count_of(id)); };
   auto g_ptr = [&](int id) { return gact_buf(s, slot_of(id), count_of(id)); };
-  for (int i = (int)m->gsteps.size() - 1; i >= 0; i--) {
-    const Step &st = m->gsteps[i];
+  for (int i = (int)gsteps.size() - 1; i >= 0; i--) {
+    const Step &st = gsteps[i];
     switch (st.kind) {
       case OpKind::Fc: {
         ProfScope ps(s, "fc_backward", 2.0 * nb * 2.0 * st.n_in, 0.0, nb);
@@ -1026,6 +1075,8 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         a.in = g_ptr(dst) + st.conv.a.out_c0;  // Dense layers: the 16-channel slice this conv produced
         a.in_cs = m->buf_cp[dst];
         a.in_act = act_ptr(dst) + st.conv.a.out_c0;
+        if (bf16 && !st.bwd.a.act_f32)  // bf16 activation tensor: the slice offset is in 2-byte elements
+          a.in_act = reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(act_ptr(dst)) + st.conv.a.out_c0);
         a.in_act_cs = m->buf_cp[dst];
         if (st.conv.a.pool == 1) {
           a.sparse = 1;  // un-pooled gradient: at most 1 of 8 voxels per cell is non-zero
@@ -1039,14 +1090,24 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         char nm[96];
         snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d", a.ksize, a.S, st.conv.a.cout, st.conv.cin);
         const double S3 = (double)a.S * a.S * a.S;
+        if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
         ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * st.conv.cin * st.conv.a.cout, 0.0, nb);
-        launch_conv(a, st.bwd.cfg, nb, s.stream);
+        if (bf16) {
+          a.sparse = 0;
+          launch_conv_bf16(a, st.bwd.cfg, nb, s.stream);
+        } else {
+          launch_conv(a, st.bwd.cfg, nb, s.stream);
+        }
         break;
       }
       case OpKind::GMax: {
         ProfScope ps(s, "gmax_backward", 0.0, 0.0, nb);
-        launch_gmax_backward(act_ptr(st.src), g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.src],
-                             m->buf_cp[st.dst], m->d.bufs[st.src].S, s.stream);
+        if (st.src_bf16)
+          launch_gmax_backward_bf16(act_ptr(st.src), g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.src],
+                                    m->buf_cp[st.dst], m->d.bufs[st.src].S, s.stream);
+        else
+          launch_gmax_backward(act_ptr(st.src), g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.src],
+                               m->buf_cp[st.dst], m->d.bufs[st.src].S, s.stream);
         break;
       }
       case OpKind::Pool: {

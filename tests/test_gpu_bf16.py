@@ -69,16 +69,40 @@ def test_bf16_ranking_and_statistics_on_a_large_batch(capi, CG):
     assert (np.abs(b16["variance"] - f32["variance"]) < 0.03 * f32["variance"] + 0.05).all()
 
 
-def test_bf16_at_96_and_gradient_stays_fp32(capi, CG):
+def test_bf16_at_96_and_gradients(capi, CG):
+    """Forward and gradient (refinement) calls on the bf16 kernels for the max-pool families; networks with
+    average pooling keep their gradient calls in fp32."""
     name = "dense_1_3"
     rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
     s = capi.Scorer([capi.Model(name, resolution=0.25, dimension=23.75)])
     s.set_receptor(rec_xyz, rec_smt)
     f32 = s.score_batch(poses, lig_smt)
-    g32 = s.score_grad(poses[:1], lig_smt)
+    g32 = s.score_grad(poses[:2], lig_smt)
     s.set_precision(True)
     b16 = s.score_batch(poses, lig_smt)
     assert np.abs(b16["pose"] - f32["pose"]).max() < POSE_TOL
     assert np.abs(b16["affinity"] - f32["affinity"]).max() < AFF_TOL
-    g16 = s.score_grad(poses[:1], lig_smt)         # gradient calls run the fp32 program regardless
-    assert np.array_equal(g16["lig_grad"], g32["lig_grad"]) and np.array_equal(g16["loss"], g32["loss"])
+    g16 = s.score_grad(poses[:2], lig_smt)
+    scale = np.abs(g32["lig_grad"]).max()
+    rel = np.abs(g16["lig_grad"] - g32["lig_grad"]).max() / scale
+    cos = (g16["lig_grad"] * g32["lig_grad"]).sum() / np.linalg.norm(g16["lig_grad"]) / np.linalg.norm(g32["lig_grad"])
+    print(f"dense_1_3@96 bf16 gradient: max rel deviation {rel:.3e}, cosine {cos:.6f}")
+    # measured (round 1): Default2017 deviates by 2-11 % of max|g| (cosine >= 0.998), the Dense family by
+    # 5-22 % (cosine 0.991-0.998): arg-max and ReLU decisions flip where bf16 activations nearly tie
+    assert rel < 0.35 and cos > 0.985 and not np.array_equal(g16["lig_grad"], g32["lig_grad"])
+    assert np.abs(g16["loss"] - g32["loss"]).max() < 0.05 * np.abs(g32["loss"]).max()
+    for fam, bf16_grad in (("default2017", True), ("dense", True), ("crossdock_default2018", False)):
+        rx, rs, ls, ps = (CG[f"{fam}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+        s2 = capi.Scorer([fam])
+        s2.set_receptor(rx, rs)
+        a = s2.score_grad(ps, ls)
+        s2.set_precision(True)
+        b = s2.score_grad(ps, ls)
+        if bf16_grad:
+            sc = np.abs(a["lig_grad"]).max()
+            assert 0 < np.abs(a["lig_grad"] - b["lig_grad"]).max() < 0.35 * sc, fam
+            for i in range(len(ps)):
+                ga, gb = a["lig_grad"][i], b["lig_grad"][i]
+                assert (ga * gb).sum() / np.linalg.norm(ga) / np.linalg.norm(gb) > 0.985, (fam, i)
+        else:                                   # average pooling: gradient calls stay on the fp32 program
+            assert np.array_equal(a["lig_grad"], b["lig_grad"]) and np.array_equal(a["loss"], b["loss"])

@@ -79,6 +79,11 @@ def main():
         gf = 36.33e9
         print(json.dumps({"config": "C5 dense_1_3 @ 0.25 A (96^3), fp32, B=256", "poses_per_s_forward": B / dt,
                           "tflops_forward": B / dt * gf / 1e12, "poses_per_s_forward_backward": B / dg}), flush=True)
+        s.set_precision(True)
+        dt = timed(lambda: s.score_batch(poses, ls), args.reps)
+        dg = timed(lambda: s.score_grad(poses, ls), args.reps)
+        print(json.dumps({"config": "C5 dense_1_3 @ 0.25 A (96^3), bf16 MFMA, B=256", "poses_per_s_forward": B / dt,
+                          "tflops_forward": B / dt * gf / 1e12, "poses_per_s_forward_backward": B / dg}), flush=True)
         del s
     if want("refine"):
         from tests import vina_scene
@@ -87,11 +92,13 @@ def main():
         v = capi.Vina()
         v.set_ligand(lig)
         lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
-        for label, models, B in (("default ensemble 48^3", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"], 64),
-                                 ("default2017 48^3", ["default2017"], 64),
-                                 ("dense_1_3 96^3", [capi.Model("dense_1_3", resolution=0.25, dimension=23.75)], 64)):
+        for label, models, B, bf in (("default ensemble 48^3", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"], 64, False),
+                                     ("default2017 48^3", ["default2017"], 64, False),
+                                     ("dense_1_3 96^3", [capi.Model("dense_1_3", resolution=0.25, dimension=23.75)], 64, False),
+                                     ("dense_1_3 96^3 bf16", [capi.Model("dense_1_3", resolution=0.25, dimension=23.75)], 64, True)):
             s = capi.Scorer(models)
             s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+            s.set_precision(bf)
             dim = 23.75 if "96" in label else 23.5
             box = capi.CnnBox.make(dim, lo, hi)
             r2 = np.random.RandomState(1)
