@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_tile = smem;
   int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);
+  int *s_vox = s_qoff + Q;  // [HV] voxel index of every halo position inside the pose, -1 = padding
   for (int q = tid; q < Q; q += NTHREADS) {
     int tap = q / CC4, c4 = q - tap * CC4;
     int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
@@ -384,6 +385,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  for (int hv = tid; hv < HV; hv += NTHREADS) {
+    const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    s_vox[hv] = in ? (x * S + y) * S + z : -1;
+  }
+  const unsigned inv_cc4 = ((1u << 20) + CC4 - 1) / CC4;  // it / CC4 == (it * inv_cc4) >> 20 for it < 2^20 / CC4
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
   const size_t wstride = (size_t)p.coutp * 4;  // 16 * 4 floats per quad row
   const float *wq = p.wp + (size_t)row * 4;
@@ -391,50 +399,77 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     __syncthreads();
     const int c_base = chunk * CC4 * 4;
-    for (int it = tid; it < HV * CC4; it += NTHREADS) {
-      int hv = it / CC4, c4 = it - hv * CC4;
-      int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
-      int x = x0 + hx, y = y0 + hy, z = z0 + hz;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S &&
-          chunk * CC4 + c4 < p.cin4) {
-        const int c = c_base + c4 * 4;
-        val = *reinterpret_cast<const float4 *>(in_b + (((size_t)x * S + y) * S + z) * p.in_cs + c);
-        if (p.bn_scale) {
-          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
-          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
-          val.x = val.x * sc.x + sh.x;
-          val.y = val.y * sc.y + sh.y;
-          val.z = val.z * sc.z + sh.z;
-          val.w = val.w * sc.w + sh.w;
+    // batched, division-free staging (see conv3d_mfma_kernel)
+    const int total_items = HV * CC4;
+    constexpr int U = 4;
+    for (int base = 0; base < total_items; base += NTHREADS * U) {
+      float4 val[U];
+      int dst[U], cq[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int it = base + u * NTHREADS + tid;
+        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[u] = -1;
+        cq[u] = -1;
+        if (it < total_items) {
+          const int hv = (int)(((unsigned)it * inv_cc4) >> 20), c4 = it - hv * CC4;
+          const int vi = s_vox[hv];
+          dst[u] = hv * CCs + c4 * 4;
+          if (vi >= 0 && chunk * CC4 + c4 < p.cin4) {
+            cq[u] = c4;
+            val[u] = *reinterpret_cast<const float4 *>(in_b + (size_t)vi * p.in_cs + c_base + c4 * 4);
+          }
         }
       }
-      *reinterpret_cast<float4 *>(s_tile + (size_t)hv * CCs + c4 * 4) = val;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (dst[u] < 0) continue;
+        float4 v = val[u];
+        if (p.bn_scale && cq[u] >= 0) {  // eval BatchNorm on the conv input; padding stays exactly 0
+          const int c = c_base + cq[u] * 4;
+          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
+          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
+          v.x = v.x * sc.x + sh.x;
+          v.y = v.y * sc.y + sh.y;
+          v.z = v.z * sc.z + sh.z;
+          v.w = v.w * sc.w + sh.w;
+        }
+        *reinterpret_cast<float4 *>(s_tile + dst[u]) = v;
+      }
     }
     __syncthreads();
 
-    // K loop over quad quartets; weights packed [chunk][quartet][4][16][4], pad quads have zero weights
+    // K loop over quad quartets, ping-pong operand sets (see conv3d_mfma_kernel); weights packed
+    // [chunk][quartet][4][16][4], pad quads have zero weights
     const float *wchunk = wq + (size_t)chunk * P4 * 4 * wstride + (size_t)kq * wstride;
-    float4 w = *reinterpret_cast<const float4 *>(wchunk), wn;
-    for (int pr = 0; pr < P4; pr++) {
+    auto load_step = [&](int pr, float4 *aa, float4 &ww) {
       int q = 4 * pr + kq;
       q = q < Q ? q : Q - 1;
       const int qo = s_qoff[q];
-      float4 a[TM];
 #pragma unroll
-      for (int m = 0; m < TM; m++) a[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-      const int prn = pr + 1 < P4 ? pr + 1 : pr;
-      wn = *reinterpret_cast<const float4 *>(wchunk + (size_t)prn * 4 * wstride);
+      for (int m = 0; m < TM; m++) aa[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
+      ww = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 4 * wstride);
+    };
+    auto mfma_step = [&](const float4 *aa, const float4 &ww) {
 #pragma unroll
-      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, w.x, acc[m], 0, 0, 0);
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m].x, ww.x, acc[m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, w.y, acc[m], 0, 0, 0);
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m].y, ww.y, acc[m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, w.z, acc[m], 0, 0, 0);
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m].z, ww.z, acc[m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, w.w, acc[m], 0, 0, 0);
-      w = wn;
+      for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m].w, ww.w, acc[m], 0, 0, 0);
+    };
+    float4 a0[TM], a1[TM], w0, w1;
+    load_step(0, a0, w0);
+    int pr = 0;
+    for (; pr + 1 < P4; pr += 2) {
+      load_step(pr + 1, a1, w1);
+      mfma_step(a0, w0);
+      if (pr + 2 < P4) load_step(pr + 2, a0, w0);
+      mfma_step(a1, w1);
     }
+    if (P4 & 1) mfma_step(a0, w0);
   }
 
   // epilogue: accumulator row = 4 * (lane >> 4) + reg, column = lane & 15
