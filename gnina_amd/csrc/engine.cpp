@@ -155,10 +155,15 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   // K chunking over input-channel quads: the halo tile of one chunk must fit the LDS budget.  Convs that
   // read the sparse pooled voxel grid get a small budget (more workgroups per CU, finer zero-skipping);
   // the last chunk may be partial (its missing quads are zero-filled and, on the sparse path, skipped).
-  const size_t budget = (o.src == m.input_dst && !backward && o.bn_scale_off < 0) ? 40 * 1024 : 72 * 1024;
+  // 40 KB per workgroup = 3-4 workgroups per CU whose staging and MFMA phases overlap (measured on the dense
+  // layers: 72 KB 20.3k, 52 KB 20.8k, 36 KB 20.8k poses/s; MI_GNINA_LDS_KB overrides for tuning)
+  const bool sparse_budget = o.src == m.input_dst && !backward && o.bn_scale_off < 0;
+  size_t budget = 40 * 1024;
+  if (!sparse_budget && getenv("MI_GNINA_LDS_KB") && atoi(getenv("MI_GNINA_LDS_KB")) > 0)
+    budget = (size_t)atoi(getenv("MI_GNINA_LDS_KB")) * 1024;
   int best = 1;
   for (int c = 1; c <= cin4; c++) {
-    if (budget == 72 * 1024 && cin4 % c) continue;  // dense layers: equal chunks only (no wasted MFMAs)
+    if (!sparse_budget && cin4 % c) continue;  // dense layers: equal chunks only (no wasted MFMAs)
     int ccs = 4 * (c | 1);
     if (HV * ccs * 4 + 27 * c * 4 <= budget) best = c;
   }
