@@ -529,9 +529,12 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
     case CONV_CFG_4x1_2x3: launch_cfg<4, 1, 2, 3>(p, B, s); break;
     case CONV_CFG_2x2_3x1: launch_cfg<2, 2, 3, 1>(p, B, s); break;
+    case CONV_CFG_4x1_1x1: launch_cfg<4, 1, 1, 1>(p, B, s); break;
     case CONV_CFG_4x1_1x5: launch_cfg<4, 1, 1, 5>(p, B, s); break;
     case CONV_CFG_N16_TM4:
-    case CONV_CFG_N16_TM3: {
+    case CONV_CFG_N16_TM3:
+    case CONV_CFG_N16_TM2:
+    case CONV_CFG_N16_TM1: {
       dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
       const size_t lds = conv_lds_bytes(p);
       static bool attr_set = false;
@@ -544,8 +547,12 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
       }
       if (cfg == CONV_CFG_N16_TM4)
         hipLaunchKernelGGL(conv3d_mfma16_kernel<4>, grid, block, lds, s, p);
-      else
+      else if (cfg == CONV_CFG_N16_TM3)
         hipLaunchKernelGGL(conv3d_mfma16_kernel<3>, grid, block, lds, s, p);
+      else if (cfg == CONV_CFG_N16_TM2)
+        hipLaunchKernelGGL(conv3d_mfma16_kernel<2>, grid, block, lds, s, p);
+      else
+        hipLaunchKernelGGL(conv3d_mfma16_kernel<1>, grid, block, lds, s, p);
       break;
     }
     default: break;
@@ -557,6 +564,9 @@ void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
     case CONV_CFG_4x1_2x3: *wm = 4, *wn = 1, *tm = 2, *tn = 3; break;
     case CONV_CFG_2x2_3x1: *wm = 2, *wn = 2, *tm = 3, *tn = 1; break;
+    case CONV_CFG_4x1_1x1: *wm = 4, *wn = 1, *tm = 1, *tn = 1; break;
+    case CONV_CFG_N16_TM1: *wm = 4, *wn = 1, *tm = 1, *tn = 1; break;
+    case CONV_CFG_N16_TM2: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
     case CONV_CFG_4x1_1x5: *wm = 4, *wn = 1, *tm = 1, *tn = 5; break;
     case CONV_CFG_N16_TM4: *wm = 4, *wn = 1, *tm = 4, *tn = 1; break;
     case CONV_CFG_N16_TM3: *wm = 4, *wn = 1, *tm = 3, *tn = 1; break;

@@ -37,7 +37,31 @@ struct ConvPlan {
   int cin = 0;           // real (unpadded) input channels, for FLOP accounting
   ConvArgs a{};          // device pointers to weights filled at load; in/out patched per run
   int src = -1, dst = -1;
+  // latency variant for small batches (a per-pose DLScorer::score call is B = 1): same K chunking and packed
+  // weights, smaller spatial tiles and one M-tile per wave, so that one pose still spreads over the chip
+  bool has_lat = false;
+  int lat_cfg = 0;
+  int lat_tc[3] = {0, 0, 0};
 };
+
+// Tile geometry of a launch of `nb` poses: the throughput plan, or the latency variant when the throughput
+// plan would leave most of the 256 CUs idle.
+static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
+  cfg = cp.cfg;
+  if (!cp.has_lat) return;
+  int wm, wn, tm, tn;
+  conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
+  const long groups = cdiv(a.coutp / (cp.cfg == CONV_CFG_N16_TM4 || cp.cfg == CONV_CFG_N16_TM3 ? 16 : 32), wn * tn);
+  const long blocks = (long)nb * a.ntx * a.nty * a.ntz * groups;
+  if (blocks >= 512 || getenv("MI_GNINA_NO_LAT")) return;
+  if (a.sparse) return;  // the zero-quad skipping pairs up surviving quads per tile: keep one tiling so results do not depend on the batch size
+  cfg = cp.lat_cfg;
+  a.tcx = cp.lat_tc[0], a.tcy = cp.lat_tc[1], a.tcz = cp.lat_tc[2];
+  const int cells = a.S / 2;
+  a.ntx = cdiv(cells, a.tcx);
+  a.nty = cdiv(cells, a.tcy);
+  a.ntz = cdiv(cells, a.tcz);
+}
 
 struct Step {
   OpKind kind;
@@ -225,6 +249,23 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   cp.dst = dst_buf;
   cp.cin = o.cin;
   MIG_CHECK(conv_lds_bytes(a) <= 160 * 1024, 2, "conv tile exceeds LDS");
+  // latency variant: 4 waves x 1 M-tile (32-wide kernel: 16 cells; 16-wide kernel: 8 cells, or 16 at 6^3)
+  cp.has_lat = true;
+  if (n16) {
+    if (cells % 2 == 0) {
+      cp.lat_cfg = CONV_CFG_N16_TM1;
+      cp.lat_tc[0] = 2, cp.lat_tc[1] = 2, cp.lat_tc[2] = 2;
+    } else {
+      cp.lat_cfg = CONV_CFG_N16_TM2;  // 4 waves x 2 M-tiles x 2 cells = 16 cells >= 1 x 3 x 3
+      cp.lat_tc[0] = 1, cp.lat_tc[1] = cells == 3 ? 3 : 2, cp.lat_tc[2] = cells == 3 ? 3 : 4;
+    }
+  } else {
+    cp.lat_cfg = CONV_CFG_4x1_1x1;  // 4 M-tiles = 16 cells, one 32-wide N tile per workgroup
+    if (cells % 4 == 0) cp.lat_tc[0] = 2, cp.lat_tc[1] = 2, cp.lat_tc[2] = 4;
+    else if (cells == 6) cp.lat_tc[0] = 2, cp.lat_tc[1] = 2, cp.lat_tc[2] = 3;
+    else if (cells == 3) cp.lat_tc[0] = 1, cp.lat_tc[1] = 3, cp.lat_tc[2] = 3;
+    else cp.lat_tc[0] = 2, cp.lat_tc[1] = 2, cp.lat_tc[2] = 4;
+  }
 }
 
 // ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
@@ -1013,6 +1054,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.out_cs = m->buf_cp[st.conv.dst];
         if (grad && a.pool == 1) a.argmax_out = arg_ptr(st.conv.dst);
         a.sparse = (st.conv.src == m->input_dst && !st.has_bn && !bf16) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
+        if (getenv("MI_GNINA_NO_SPARSE")) a.sparse = 0;
         {
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
@@ -1022,8 +1064,13 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
           ProfScope ps(s, nm, 2.0 * nb * S3 * taps * st.conv.cin * a.cout,
                        (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
-          if (bf16) launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
-          else launch_conv(a, st.conv.cfg, nb, s.stream);
+          if (bf16) {
+            launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
+          } else {
+            int cfg;
+            pick_tile(st.conv, nb, a, cfg);
+            launch_conv(a, cfg, nb, s.stream);
+          }
         }
         break;
       }
@@ -1101,7 +1148,9 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           a.sparse = 0;
           launch_conv_bf16(a, st.bwd.cfg, nb, s.stream);
         } else {
-          launch_conv(a, st.bwd.cfg, nb, s.stream);
+          int cfg;
+          pick_tile(st.bwd, nb, a, cfg);
+          launch_conv(a, cfg, nb, s.stream);
         }
         break;
       }
