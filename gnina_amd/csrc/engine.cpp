@@ -606,11 +606,15 @@ struct Scorer {
   std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
   std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
   DevBuf<float> d_raw3, d_lig_grad;
+  int lig_cache_group = -1, lig_cache_n = 0;  // setup_ligand cache: group / ligand types the device arrays describe
+  std::vector<int32_t> lig_cache_smt;
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
   DevBuf<float> d_flex, d_flex_grad;    // [B][n_flex][3]
   const float *cur_flex = nullptr;      // device flex coordinates of the call in flight (or nullptr)
   // outputs per model [n_models][B] and reduced
-  DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var;
+  DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var, d_out4;
+  float *h_out4 = nullptr;  // pinned staging of the four output arrays
+  size_t h_out4_n = 0;
   int last_B = 0;
   // per-kernel profiling (mi_scorer_enable_profile): HIP events around every launch on `stream`
   struct ProfRec {
@@ -641,6 +645,7 @@ struct Scorer {
     for (auto &e : ev_cnn_done)
       if (e) (void)hipEventDestroy(e);
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
+    if (h_out4) (void)hipHostFree(h_out4);
     if (vox_stream) (void)hipStreamDestroy(vox_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -881,6 +886,7 @@ static LigSetup setup_ligand_ragged(Scorer &s, const VoxGroup &g, const int32_t 
   s.d_lig_chan.upload(chan.data(), chan.size(), s.stream);
   s.d_lig_consts.upload(lc.data(), lc.size(), s.stream);
   s.d_lig_typed.upload(typed.data(), typed.size(), s.stream);
+  s.lig_cache_group = -1;  // the per-pose arrays overwrite the cached single-ligand description
   s.d_pose_rows.upload(rows.data(), rows.size(), s.stream);
   s.d_pose_nlig.upload(nl.data(), nl.size(), s.stream);
   MIG_HIP(hipStreamSynchronize(s.stream));
@@ -893,6 +899,14 @@ static LigSetup setup_ligand_ragged(Scorer &s, const VoxGroup &g, const int32_t 
 // Type the ligand rows with the group's ligand map, upload permutation / constants.
 static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_smt, int L) {
   Model *m = s.models[g.first_model];
+  // the same ligand is scored call after call (poses of one docking run): keep its device-side description
+  if (s.lig_cache_group == g.first_model && (int)s.lig_cache_smt.size() == L &&
+      std::equal(s.lig_cache_smt.begin(), s.lig_cache_smt.end(), lig_smt)) {
+    LigSetup ls;
+    ls.n_lig = s.lig_cache_n;
+    return ls;
+  }
+  s.lig_cache_group = -1;
   std::vector<int> idx;
   std::vector<unsigned char> typed(L, 0);
   for (int i = 0; i < L; i++) {
@@ -921,6 +935,9 @@ static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_sm
   MIG_HIP(hipStreamSynchronize(s.stream));
   LigSetup ls;
   ls.n_lig = (int)idx.size();
+  s.lig_cache_group = g.first_model;
+  s.lig_cache_smt.assign(lig_smt, lig_smt + L);
+  s.lig_cache_n = ls.n_lig;
   return ls;
 }
 
@@ -1359,22 +1376,26 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   }
   const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
   float *o_pose = pose, *o_aff = aff, *o_loss = loss, *o_var = var;
-  if (!out_dev) {
-    s.d_pose.ensure(B);
-    s.d_aff.ensure(B);
-    s.d_loss.ensure(B);
-    s.d_var.ensure(B);
-    o_pose = s.d_pose.p, o_aff = s.d_aff.p, o_loss = s.d_loss.p, o_var = s.d_var.p;
+  if (!out_dev) {  // one [4][B] device block -> one copy into pinned host memory -> the caller's four arrays
+    s.d_out4.ensure((size_t)4 * B);
+    o_pose = s.d_out4.p, o_aff = s.d_out4.p + B, o_loss = s.d_out4.p + 2 * (size_t)B, o_var = s.d_out4.p + 3 * (size_t)B;
   }
   launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, o_pose, o_aff, o_loss, o_var, s.stream);
   if (s.timing) MIG_HIP(hipEventRecord(s.ev[2], s.stream));
   s.last_B = B;
   if (!out_dev) {
-    MIG_HIP(hipMemcpyAsync(pose, o_pose, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    MIG_HIP(hipMemcpyAsync(aff, o_aff, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    MIG_HIP(hipMemcpyAsync(loss, o_loss, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    if (var) MIG_HIP(hipMemcpyAsync(var, o_var, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    if (s.h_out4_n < (size_t)4 * B) {
+      if (s.h_out4) (void)hipHostFree(s.h_out4);
+      s.h_out4 = nullptr;
+      MIG_HIP(hipHostMalloc((void **)&s.h_out4, (size_t)4 * B * sizeof(float), hipHostMallocDefault));
+      s.h_out4_n = (size_t)4 * B;
+    }
+    MIG_HIP(hipMemcpyAsync(s.h_out4, s.d_out4.p, (size_t)4 * B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
     MIG_HIP(hipStreamSynchronize(s.stream));
+    memcpy(pose, s.h_out4, B * sizeof(float));
+    memcpy(aff, s.h_out4 + B, B * sizeof(float));
+    memcpy(loss, s.h_out4 + 2 * (size_t)B, B * sizeof(float));
+    if (var) memcpy(var, s.h_out4 + 3 * (size_t)B, B * sizeof(float));
     if (s.timing) MIG_HIP(hipEventElapsedTime(&s.last_ms[2], s.ev[0], s.ev[2]));
   }
 }
