@@ -43,8 +43,18 @@ def to_json(d, out):
         e = {c: sum(v) / len(v) for c, v in cs.items()}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+        if e.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
+            # one MOP = 512 FLOP (a 32x32x2 fp32 MFMA = 4096 FLOP = 8 MOPs)
+            e["mfma_executed_flops_per_launch"] = e["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
         res[k] = e
-    json.dump({"source": d, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    # bench.py's label of the dominant kernel -> profiler kernel name (first conv of the default workload)
+    kmap = {}
+    first = [k for k in res if k.startswith("conv3d_mfma_kernel<4, 1, 2, 1")]
+    if first:
+        kmap["conv3_s24_35to32_pool"] = first[0]
+        kmap["conv3_s24_28to32"] = first[0]
+    json.dump({"source": d, "command": "tools/profile_gpu.sh (bench.py --steps 3 --warmup 1 --no-cpu-baseline)",
+               "roofline_kernel_map": kmap, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
