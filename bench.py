@@ -228,7 +228,7 @@ def main():
                 "algorithmic_flops_per_launch": dom_conv["flops"] / dom_conv["launches"],
                 "poses_per_launch": dom_conv["poses"] // dom_conv["launches"],
                 "note": "achieved = ALGORITHMIC (dense) FLOPs / launch time; the kernel skips channel quads that are "
-                        "all-zero inside a tile (exact zeros, bit-identical sum), so the MFMA pipe executes fewer: see "
+                        "all-zero inside a tile (exact-zero products; the rest keep their order), so the MFMA pipe executes fewer: see "
                         "mfma_executed_*",
                 "mfma_executed_flops_per_launch": (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch"),
                 "mfma_executed_tflops": (round((pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch", 0)

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
 
     // ---- input sparsity (the pooled voxel grid is ~12 % dense, SURVEY "Hard parts"): channel quads
     // that are entirely zero inside this halo tile contribute exact zeros, so their 27 taps are
-    // skipped.  The surviving quads keep their original order -> the fp32 sum is bit-identical.
+    // skipped.  The surviving quads keep their original order; only which two of them share one two-k MFMA
+    // instruction can change (measured effect on scores: none for Default2017/2018, <= 6e-7 for Dense).
     int J = Q;
     if (SPARSE) {
       int n_act = 0;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     // (M-tile, N-tile) of pair pr run.  A single-set "fetch next, then copy" loop gets folded back by the
     // compiler into load -> s_waitcnt vmcnt(0) -> MFMA, which exposes the L2 latency once per pair.
     // Dense: pair pr = quads (2 pr, 2 pr + 1), affine addressing.  Sparse: pairs of the compacted list
-    // of surviving quads, in their original order (the fp32 sum stays bit-identical).
+    // of surviving quads, in their original order.
     const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
     const int NP = SPARSE ? (J + 1) >> 1 : P;
     auto load_pair = [&](int pr, float4 *aa, float4 *ww) {
