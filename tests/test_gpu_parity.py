@@ -240,3 +240,39 @@ def test_ragged_batch_equals_per_ligand_calls(capi, CG):
     bad[0, 3] = -1                       # a hole in the middle of a ligand
     with pytest.raises(capi.MiGninaError):
         s.score_ragged(xyz, bad)
+
+
+def test_full_size_batch_properties(capi, CG):
+    """BASELINE config C2 at full size (1,024 poses): the oracle cannot run that many in seconds, so the batch
+    is checked through size-independent properties -- run-to-run determinism, permutation equivariance,
+    independence of the internal chunking, and agreement of a 16-pose sample with the oracle."""
+    from gnina_amd import synth
+    name = "default2017"
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rng = np.random.RandomState(0)
+    rec_xyz, rec_smt = synth.make_receptor(rng, 2500, synth.mapped_types(rmap[0]))
+    lig_xyz, lig_smt = synth.make_ligand(rng, 32, synth.mapped_types(lmap[0]))
+    poses = synth.make_poses(np.random.RandomState(1000), lig_xyz, 1024)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    a = s.score_batch(poses, lig_smt)
+    b = s.score_batch(poses, lig_smt)
+    for k in ("pose", "affinity", "loss"):
+        assert np.array_equal(a[k], b[k]), k                     # deterministic
+    perm = np.random.RandomState(3).permutation(1024)
+    c = s.score_batch(poses[perm], lig_smt)
+    for k in ("pose", "affinity", "loss"):
+        assert np.array_equal(c[k], a[k][perm]), k               # poses are independent of their neighbours
+    s.set_chunk(37)
+    d = s.score_batch(poses, lig_smt)
+    for k in ("pose", "affinity", "loss"):
+        assert np.array_equal(d[k], a[k]), k                     # ... and of the chunking / launch plan
+    assert np.isfinite(a["pose"]).all() and (a["pose"] >= 0).all() and (a["pose"] <= 1).all()
+    assert np.allclose(a["loss"], -np.log(np.maximum(a["pose"], 1e-30)), rtol=2e-4, atol=2e-6)  # CE(logp, 1) = -log p1
+    sample = np.random.RandomState(5).choice(1024, 16, replace=False)
+    grids = np.stack([voxel.voxelize_pose(rec_xyz, rec_smt, poses[i], lig_smt, rmap, lmap)[0] for i in sample])
+    with torch.no_grad():
+        p, aff, _ = cnn_ref.scores(blob, grids)
+    assert np.abs(a["pose"][sample] - p.numpy()).max() < 1e-4
+    assert np.abs(a["affinity"][sample] - aff.numpy()).max() < 1e-4
