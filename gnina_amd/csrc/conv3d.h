@@ -48,6 +48,17 @@ enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CF
        CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6, CONV_CFG_2x2_3x1 = 7,
        CONV_CFG_4x1_1x1 = 8, CONV_CFG_N16_TM1 = 9, CONV_CFG_N16_TM2 = 10 /* latency variants: one M-tile per wave */ };
 
+// MI355X dispatches workgroups round-robin over its 8 XCDs (workgroup i -> XCD i % 8), each with a private
+// 4 MB L2.  Tiles of one pose share halo voxels, K chunks and the candidate list, so a launch re-numbers its
+// workgroups such that every XCD works on a CONTIGUOUS range of (pose, tile) ids: XCD x gets ids
+// [x * n/8, (x+1) * n/8).  Ids past the last multiple of 8 keep their number.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_contiguous_id(int wg, int n) {
+  const int per = n >> 3;
+  return wg >= (per << 3) ? wg : (wg & 7) * per + (wg >> 3);
+}
+#endif
+
 size_t conv_lds_bytes(const ConvArgs &p);
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn);
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s);

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   const int row = lane & 31;  // A row / B column
 
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
-  const int b = blockIdx.x / tiles_per_pose;
-  int t = blockIdx.x - b * tiles_per_pose;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
   const int tz = t % p.ntz;
   t /= p.ntz;
   const int ty = t % p.nty, tx = t / p.nty;
@@ -346,8 +347,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   const int row = lane & 15;  // A row / B column
 
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
-  const int b = blockIdx.x / tiles_per_pose;
-  int t = blockIdx.x - b * tiles_per_pose;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
   const int tz = t % p.ntz;
   t /= p.ntz;
   const int ty = t % p.nty, tx = t / p.nty;

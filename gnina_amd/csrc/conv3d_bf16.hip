@@ -59,8 +59,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_bf16_kernel(ConvArgs p) {
   const int row = lane & 31;
 
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
-  const int b = blockIdx.x / tiles_per_pose;
-  int t = blockIdx.x - b * tiles_per_pose;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
   const int tz = t % p.ntz;
   t /= p.ntz;
   const int ty = t % p.nty, tx = t / p.nty;

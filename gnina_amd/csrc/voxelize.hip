@@ -27,6 +27,8 @@
 //    bit-identical to the sqrtf-based reference arithmetic.
 #include "voxelize.h"
 
+#include "conv3d.h"  // xcd_contiguous_id
+
 namespace mig {
 
 __device__ __forceinline__ float rl_f(float v, int lane) {
@@ -165,10 +167,14 @@ __device__ __forceinline__ float density(float rsq, float t2, float g2, float ke
 
 template <int MODE>  // 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last
 __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
-  const int b = blockIdx.y;
   const int lane = threadIdx.x;
   const int ntile = v.tiles_per_axis;
-  const int tz = blockIdx.x % ntile, ty = (blockIdx.x / ntile) % ntile, tx = blockIdx.x / (ntile * ntile);
+  // 1-D grid of B * tiles workgroups, re-numbered so that an XCD (private L2) sees whole poses: the 216 tile
+  // wavefronts of a pose all read that pose's candidate list
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / (ntile * ntile * ntile);
+  const int tile_id = wg - b * (ntile * ntile * ntile);
+  const int tz = tile_id % ntile, ty = (tile_id / ntile) % ntile, tx = tile_id / (ntile * ntile);
   const int cx = tx * 4 + (lane >> 4), cy = ty * 4 + ((lane >> 2) & 3), cz = tz * 4 + (lane & 3);
 
   extern __shared__ __attribute__((aligned(16))) float s_stage[];  // MODE != 0: [64][Cp] (+ arg-max bytes)
@@ -408,7 +414,7 @@ void launch_gather(const GatherArgs &g, int B, hipStream_t s) {
 
 void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   const int nt = v.tiles_per_axis;
-  dim3 grid(nt * nt * nt, B), block(64);
+  dim3 grid(nt * nt * nt * B), block(64);
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
