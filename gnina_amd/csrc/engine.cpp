@@ -952,9 +952,11 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   Model *m = s.models[g.first_model];
   TypedReceptor &tr = *s.receptors[g.rec_idx];
   const int cap = tr.n + ls.n_lig + 1;
-  cand.ensure((size_t)s.cap * cap);
-  cand_chan.ensure((size_t)s.cap * cap);
-  cand_n.ensure(s.cap);
+  const int nt_axis = cdiv(cdiv(m->N, 2), 4);
+  const int n_slab = nt_axis <= kMaxSlabs ? nt_axis : 1;  // one candidate list per x-slab of tiles
+  cand.ensure((size_t)s.cap * n_slab * cap);
+  cand_chan.ensure((size_t)s.cap * n_slab * cap);
+  cand_n.ensure((size_t)s.cap * n_slab);
   GatherArgs ga{};
   ga.rec = tr.rec.p;
   ga.rec_chan = tr.chan.p;
@@ -987,6 +989,8 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.cand_chan = cand_chan.p;
   ga.cand_n = cand_n.p;
   ga.cap = cap;
+  ga.n_slab = n_slab;
+  ga.res = m->d.resolution;
   {
     ProfScope ps(s, "gather_pose_atoms", 0.0, (double)nb * (tr.n + ls.n_lig) * 36.0, nb, vs);
     launch_gather(ga, nb, vs);
@@ -996,6 +1000,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   va.cand_chan = cand_chan.p;
   va.cand_n = cand_n.p;
   va.cap = cap;
+  va.n_slab = n_slab;
   va.centers = ga.centers_out;
   va.N = m->N;
   va.tiles_per_axis = cdiv(cdiv(m->N, 2), 4);

@@ -40,17 +40,25 @@ struct GatherArgs {
   int center_typed_only;
   float half_dim;
   float *centers_out;  // [B][3]
-  AtomRec *cand;       // [B][cap]
-  int *cand_chan;      // [B][cap]
-  int *cand_n;         // [B]
+  // Candidate lists, one per x-slab of 8 voxels (= one per tile index tx): the atoms whose support can reach
+  // the slab, order preserving.  A tile wavefront scans only its slab's list (~2.4/6 of the pose's candidates
+  // at 48^3) with the full sphere/box test; the slab test is the x part of that test, so nothing is lost.
+  AtomRec *cand;       // [B][n_slab][cap]
+  int *cand_chan;      // [B][n_slab][cap]
+  int *cand_n;         // [B][n_slab]
   int cap;
+  int n_slab;          // tiles per axis (<= kMaxSlabs), or 1 = a single list for the whole grid
+  float res;
 };
+
+constexpr int kMaxSlabs = 16;
 
 struct VoxArgs {
   const AtomRec *cand;
   const int *cand_chan;
   const int *cand_n;
   int cap;
+  int n_slab;            // as in GatherArgs
   const float *centers;  // [B][3]
   int N;                 // grid points per side
   int tiles_per_axis;    // ceil(ceil(N/2) / 4)

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   __shared__ float s_center[3];
-  __shared__ int s_wave_cnt[4];
-  __shared__ int s_base;
+  __shared__ int s_wave_cnt[kMaxSlabs][4];
+  __shared__ int s_base[kMaxSlabs];
 
   const float *lig = g.lig_xyz + (size_t)b * g.L * 3;
   const size_t po = g.pose_rows ? (size_t)b * g.L : 0;  // offset of this pose's ligand description
@@ -81,12 +81,10 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
     g.centers_out[3 * b + 0] = cx;
     g.centers_out[3 * b + 1] = cy;
     g.centers_out[3 * b + 2] = cz;
-    s_base = 0;
   }
+  if (tid < kMaxSlabs) s_base[tid] = 0;
   __syncthreads();
   const float cx = s_center[0], cy = s_center[1], cz = s_center[2];
-  AtomRec *cand = g.cand + (size_t)b * g.cap;
-  int *cand_chan = g.cand_chan + (size_t)b * g.cap;
 
   const int total = g.n_rec + n_lig;
   for (int base = 0; base < total; base += 256) {
@@ -122,21 +120,41 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
       float reach = g.half_dim + a.ar * 1.5f + 0.01f;
       keep = fabsf(a.x - cx) <= reach && fabsf(a.y - cy) <= reach && fabsf(a.z - cz) <= reach;
     }
-    unsigned long long m = __ballot(keep);
-    int prefix = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave_cnt[wid] = __builtin_popcountll(m);
-    __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wid; w++) off += s_wave_cnt[w];
+    // per slab: does the atom's support reach it?  (the x part of voxelize_tiles' sphere/box test, same floats)
+    unsigned slab_mask = 0u;
     if (keep) {
-      cand[off + prefix] = a;
-      cand_chan[off + prefix] = ch;
+      if (g.n_slab == 1) {
+        slab_mask = 1u;
+      } else {
+        const float ox = cx - g.half_dim, lim = a.t2 * 1.0001f + 1e-4f;
+        for (int sl = 0; sl < g.n_slab; sl++) {
+          const float tlox = ox + (float)(8 * sl) * g.res, thix = ox + (float)(8 * sl + 7) * g.res;
+          const float ddx = fmaxf(0.f, fmaxf(tlox - a.x, a.x - thix));
+          if (ddx * ddx <= lim) slab_mask |= 1u << sl;
+        }
+      }
+    }
+    int prefix[kMaxSlabs];
+#pragma unroll 1
+    for (int sl = 0; sl < g.n_slab; sl++) {
+      const unsigned long long m = __ballot((slab_mask >> sl) & 1u);
+      prefix[sl] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave_cnt[sl][wid] = __builtin_popcountll(m);
     }
     __syncthreads();
-    if (tid == 0) s_base += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    for (int sl = 0; sl < g.n_slab; sl++) {
+      if (!((slab_mask >> sl) & 1u)) continue;
+      int off = s_base[sl];
+      for (int w = 0; w < wid; w++) off += s_wave_cnt[sl][w];
+      const size_t o = ((size_t)b * g.n_slab + sl) * g.cap + off + prefix[sl];
+      g.cand[o] = a;
+      g.cand_chan[o] = ch;
+    }
+    __syncthreads();
+    if (tid < g.n_slab) s_base[tid] += s_wave_cnt[tid][0] + s_wave_cnt[tid][1] + s_wave_cnt[tid][2] + s_wave_cnt[tid][3];
     __syncthreads();
   }
-  if (tid == 0) g.cand_n[b] = s_base;
+  if (tid < g.n_slab) g.cand_n[(size_t)b * g.n_slab + tid] = s_base[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,9 +219,10 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   const float tloy = oy + (float)(8 * ty) * v.res, thiy = oy + (float)(8 * ty + 7) * v.res;
   const float tloz = oz + (float)(8 * tz) * v.res, thiz = oz + (float)(8 * tz + 7) * v.res;
 
-  const AtomRec *cand = v.cand + (size_t)b * v.cap;
-  const int *cand_chan = v.cand_chan + (size_t)b * v.cap;
-  const int n = v.cand_n[b];
+  const int slab = v.n_slab > 1 ? tx : 0;
+  const AtomRec *cand = v.cand + ((size_t)b * v.n_slab + slab) * v.cap;
+  const int *cand_chan = v.cand_chan + ((size_t)b * v.n_slab + slab) * v.cap;
+  const int n = v.cand_n[(size_t)b * v.n_slab + slab];
 
   float acc[8];
 #pragma unroll
