@@ -334,12 +334,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ligands.derivative(coords, minus_forces, g) (model.cu:223; tree.h:133-140,293-401): per-atom forces in
 // w.forces + the node frames of the conformation just set -> change[6 + T].
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 __device__ void fold_forces(const VinaLigand &L, const WaveWork &w, float *change) {
   const int lane = threadIdx.x;
-  // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140)
-  for (int k = lane; k < L.n_nodes; k += 64) {
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
-    const float ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
+  // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140): lane k owns
+  // node k and keeps the six sums and the node origin in registers
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+  int cs = 0, ce = 0, cl = 0;
+  if (lane < L.n_nodes) {
+    const int k = lane;
+    ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
     for (int i = L.abeg[k]; i < L.aend[k]; i++) {
       const float rx = w.coords[3 * i] - ox, ry = w.coords[3 * i + 1] - oy, rz = w.coords[3 * i + 2] - oz;
       const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
@@ -350,32 +357,33 @@ __device__ void fold_forces(const VinaLigand &L, const WaveWork &w, float *chang
       t1 += rz * gx - rx * gz;
       t2 += rx * gy - ry * gx;
     }
-    float *ft = w.node_ft + 6 * k;
-    ft[0] = f0, ft[1] = f1, ft[2] = f2, ft[3] = t0, ft[4] = t1, ft[5] = t2;
+    cs = L.child_start[k];
+    ce = L.child_start[k + 1];
+    if (k < L.n_nodes - 1) cl = L.child_list[k];  // entry k of the child list (a tree has n_nodes - 1 edges)
   }
-  __syncthreads();
-  // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311)
-  if (lane == 0) {
-    for (int k = L.n_nodes - 1; k >= 0; k--) {
-      float *ft = w.node_ft + 6 * k;
-      for (int e = L.child_start[k]; e < L.child_start[k + 1]; e++) {
-        const int c = L.child_list[e];
-        const float *cf = w.node_ft + 6 * c;
-        ft[0] += cf[0];
-        ft[1] += cf[1];
-        ft[2] += cf[2];
-        const float rx = w.origin[3 * c] - w.origin[3 * k], ry = w.origin[3 * c + 1] - w.origin[3 * k + 1],
-                    rz = w.origin[3 * c + 2] - w.origin[3 * k + 2];
-        ft[3] += (ry * cf[2] - rz * cf[1]) + cf[3];
-        ft[4] += (rz * cf[0] - rx * cf[2]) + cf[4];
-        ft[5] += (rx * cf[1] - ry * cf[0]) + cf[5];
-      }
-      if (k == 0) {
-        for (int j = 0; j < 6; j++) change[j] = ft[j];
-      } else {
-        change[6 + (k - 1)] = ft[3] * w.axis[3 * k] + ft[4] * w.axis[3 * k + 1] + ft[5] * w.axis[3 * k + 2];
+  // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311).  The
+  // dependent chain runs register to register: a child's sums reach its parent's lane through v_readlane
+  // (wave-uniform lane indices), not through LDS round trips of a single active lane.
+  for (int k = L.n_nodes - 1; k >= 0; k--) {
+    const int s = __builtin_amdgcn_readlane(cs, k), e_end = __builtin_amdgcn_readlane(ce, k);
+    for (int e = s; e < e_end; e++) {
+      const int c = __builtin_amdgcn_readlane(cl, e);
+      const float c0 = rl(f0, c), c1 = rl(f1, c), c2 = rl(f2, c), c3 = rl(t0, c), c4 = rl(t1, c), c5 = rl(t2, c);
+      const float rx = rl(ox, c) - ox, ry = rl(oy, c) - oy, rz = rl(oz, c) - oz;
+      if (lane == k) {
+        f0 += c0;
+        f1 += c1;
+        f2 += c2;
+        t0 += (ry * c2 - rz * c1) + c3;
+        t1 += (rz * c0 - rx * c2) + c4;
+        t2 += (rx * c1 - ry * c0) + c5;
       }
     }
+  }
+  if (lane == 0) {
+    change[0] = f0, change[1] = f1, change[2] = f2, change[3] = t0, change[4] = t1, change[5] = t2;
+  } else if (lane < L.n_nodes) {
+    change[6 + (lane - 1)] = t0 * w.axis[3 * lane] + t1 * w.axis[3 * lane + 1] + t2 * w.axis[3 * lane + 2];
   }
 }
 

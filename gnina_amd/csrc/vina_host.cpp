@@ -294,6 +294,7 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   Vina &v = *reinterpret_cast<Vina *>(vv);
   const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
   MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
+  MIG_CHECK(nn <= 64, 1, "more than 63 rotatable bonds: the force fold keeps one tree node per lane");
   std::vector<int> node_of(na, -1);
   for (int k = 0; k < nn; k++) {
     MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : d->node_parent[k] >= 0), 1,
