@@ -74,6 +74,18 @@ def test_null_and_error_paths_do_not_crash(capi):
     L.mi_model_release(None)
     L.mi_scorer_destroy(None)
     assert L.mi_model_type_channel(None, 0, 2, None) == -1
+    # every handle-taking entry point added later refuses NULL handles with a status, not a crash
+    import ctypes as C
+    one = (C.c_float * 8)()
+    assert L.mi_scorer_set_flex(None, None, 0) != capi.MI_OK
+    assert L.mi_scorer_set_precision(None, 1) != capi.MI_OK
+    assert L.mi_scorer_score_ragged(None, one, None, 1, 1, None, one, one, one, None) != capi.MI_OK
+    assert L.mi_scorer_score_flex(None, one, None, 1, 1, None, None, one, one, one, None, None, None) != capi.MI_OK
+    assert L.mi_vina_coords_batch(None, one, 1, one) != capi.MI_OK
+    assert L.mi_cnn_eval_batch(None, None, one, 1, None, None, 0, one, None) != capi.MI_OK
+    assert L.mi_cnn_refine_batch(None, None, one, 1, None, 3, one, None, None) != capi.MI_OK
+    assert L.mi_model_load_file_ex(b"/nonexistent.mgw", C.c_float(0.25), C.c_float(23.75)) is None
+    assert L.mi_read_gninatypes(None, None, None, 0, None) != capi.MI_OK
 
 
 def test_synth_generator_is_deterministic_and_in_spec():
