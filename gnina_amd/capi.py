@@ -43,14 +43,17 @@ class LigandDesc(C.Structure):
 class CnnBox(C.Structure):
     """mi_cnn_box (include/mi_gnina.h): the two out-of-box penalty regions of non_cache_cnn"""
     _fields_ = [("use_search_box", C.c_int32), ("box_begin", C.c_float * 3), ("box_end", C.c_float * 3),
-                ("cnn_dimension", C.c_float), ("slope", C.c_float)]
+                ("cnn_dimension", C.c_float), ("slope", C.c_float), ("mix_emp_force", C.c_int32),
+                ("mix_emp_energy", C.c_int32), ("empirical_weight", C.c_float), ("v", C.c_float)]
 
     @classmethod
-    def make(cls, cnn_dimension, box_begin=None, box_end=None, slope=10.0):
+    def make(cls, cnn_dimension, box_begin=None, box_end=None, slope=10.0, mix_emp_force=False,
+             mix_emp_energy=False, empirical_weight=1.0, v=1000.0):
         use = box_begin is not None
         bb = (C.c_float * 3)(*(box_begin if use else (0, 0, 0)))
         be = (C.c_float * 3)(*(box_end if use else (0, 0, 0)))
-        return cls(1 if use else 0, bb, be, cnn_dimension, slope)
+        return cls(1 if use else 0, bb, be, cnn_dimension, slope, int(mix_emp_force), int(mix_emp_energy),
+                   empirical_weight, v)
 
 
 class McParams(C.Structure):

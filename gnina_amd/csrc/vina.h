@@ -76,6 +76,9 @@ struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN l
   const float *cnn_center;  // [B][3] centre of the CNN cube cnn_gd, or nullptr (cube inactive)
   float cnn_half;           // half its side
   float slope;
+  // cnn_options::mix_emp_force / mix_emp_energy / empirical_weight (user_opts.h:46-51); v = curl cap
+  int mix_force, mix_energy;
+  float weight, v;
 };
 
 struct VinaPopulateArgs {

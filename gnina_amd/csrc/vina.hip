@@ -681,13 +681,65 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
     w.forces[3 * i + 2] = fz;
   }
   __syncthreads();
+  float emp_total = 0.f;
+  if (a.mix_force) {
+    // mix_emp_force (non_cache_cnn.cpp:113-137,151-156): the empirical receptor term of every heavy atom, taken at
+    // its coordinates clamped to the search box, curl-capped, is blended into the CNN force:
+    //   minus_forces = (cnn + penalties + w (emp_deriv + search-box penalty force)) / (1 + w)
+    // The 64 lanes stride the receptor for one ligand atom at a time (like the non_cache igrid).
+    for (int i = 0; i < L.n_atoms; i++) {
+      const int t1 = L.smt[i];
+      if (t1 <= 1) continue;
+      float adj[3], oobd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float c = w.coords[3 * i + k];
+        adj[k] = c;
+        if (a.use_box) {
+          if (c < a.box_begin[k]) adj[k] = a.box_begin[k], oobd[k] = -1.f;
+          else if (c > a.box_end[k]) adj[k] = a.box_end[k], oobd[k] = 1.f;
+        }
+      }
+      float pe = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+      for (int j = lane; j < env.n_rec; j += 64) {
+        const float4 r = env.rec[j];
+        const float rx = adj[0] - r.x, ry = adj[1] - r.y, rz = adj[2] - r.z;
+        const float r2 = rx * rx + ry * ry + rz * rz;
+        if (r2 < env.cutoff_sqr) {
+          float e1, dor;
+          prec_eval_deriv(env, t1, __float_as_int(r.w), r2, e1, dor);
+          pe += e1;
+          dx += dor * rx;
+          dy += dor * ry;
+          dz += dor * rz;
+        }
+      }
+      pe = wave_sum(pe);
+      dx = wave_sum(dx);
+      dy = wave_sum(dy);
+      dz = wave_sum(dz);
+      curl3(pe, dx, dy, dz, a.v);
+      if (lane == 0) {
+        const float den = 1.0f + a.weight;
+        w.forces[3 * i] = (w.forces[3 * i] + a.weight * (dx + a.slope * oobd[0])) / den;
+        w.forces[3 * i + 1] = (w.forces[3 * i + 1] + a.weight * (dy + a.slope * oobd[1])) / den;
+        w.forces[3 * i + 2] = (w.forces[3 * i + 2] + a.weight * (dz + a.slope * oobd[2])) / den;
+        emp_total += pe;
+      }
+    }
+    __syncthreads();
+  }
   if (change_out) {
     fold_forces(L, w, change);
     __syncthreads();
     for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
   }
   pen = wave_sum(pen);
-  if (lane == 0) energy[b] = (a.e_in ? a.e_in[b] : 0.f) + pen;
+  if (lane == 0) {
+    float e = (a.e_in ? a.e_in[b] : 0.f) + pen;
+    if (a.mix_energy) e = (e + a.weight * emp_total) / (1.0f + a.weight);  // non_cache_cnn.cpp:160-166
+    energy[b] = e;
+  }
 }
 
 void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float *coords,

@@ -590,6 +590,13 @@ mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_c
     a.cnn_half = box->cnn_dimension / 2.0f;
   }
   a.slope = slope;
+  if (box && with_deriv && (box->mix_emp_force || box->mix_emp_energy)) {
+    MIG_CHECK(v.n_rec > 0, 4, "mix_emp_force / mix_emp_energy need the receptor (mi_vina_set_receptor)");
+    a.mix_force = box->mix_emp_force ? 1 : 0;
+    a.mix_energy = box->mix_emp_energy ? 1 : 0;
+    a.weight = box->empirical_weight;
+    a.v = box->v;
+  }
   v.d_energy.ensure(B);
   if (with_deriv) v.d_change.ensure((size_t)B * n);
   launch_vina_extforce(make_env(v), v.lig, v.d_confs.p, B, a, v.d_energy.p, with_deriv ? v.d_change.p : nullptr,

@@ -280,6 +280,13 @@ typedef struct mi_cnn_box {
   float box_begin[3], box_end[3];
   float cnn_dimension;           /* DLScorer::set_bounding_box: the model's grid dimension (23.5) */
   float slope;                   /* mi_cnn_eval_batch only; mi_cnn_refine_batch runs refine_structure's ladder */
+  /* cnn_options::mix_emp_force / mix_emp_energy / empirical_weight (user_opts.h:46-51; non_cache_cnn.cpp:113-166):
+   * blend the empirical receptor term (precalculate_linear pair tables vs the mi_vina receptor, at the atom's
+   * coordinates clamped to the search box, curl cap v) into the force and / or the energy.  As in the reference
+   * the empirical term is only evaluated when mix_emp_force is set, and ::eval (with_deriv = 0) ignores both. */
+  int32_t mix_emp_force, mix_emp_energy;
+  float empirical_weight;        /* default 1 */
+  float v;                       /* authentic_v[1] = 1000 */
 } mi_cnn_box;
 /* model::set(conf) for B conformations: coords [B][n_atoms][3]. */
 mi_status mi_vina_coords_batch(mi_vina *, const float *confs, int B, float *coords);

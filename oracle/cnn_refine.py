@@ -12,8 +12,11 @@ MAX_FL = np.float32(3.402823466e+38)
 class NonCacheCnn:
     """dl_scorer + the two penalty boxes.  blobs: list of cnn_ref.Blob (the ensemble)."""
 
-    def __init__(self, blobs, rec_xyz, rec_smt, lig, search_box=None, cnn_dimension=23.5):
+    def __init__(self, blobs, rec_xyz, rec_smt, lig, search_box=None, cnn_dimension=23.5, mix_emp_force=False,
+                 mix_emp_energy=False, empirical_weight=1.0, tables=None, v=1000.0):
         self.blobs, self.rec_xyz, self.rec_smt, self.lig = blobs, rec_xyz, rec_smt, lig
+        self.mix_emp_force, self.mix_emp_energy, self.weight = mix_emp_force, mix_emp_energy, empirical_weight
+        self.tables, self.v = tables, v       # precalculate_linear tables (oracle.vina.Tables) for the empirical term
         self.smt = lig.arr["smt"]
         self.search_box = search_box          # (begin[3], end[3]) or None
         self.cnn_dimension = cnn_dimension
@@ -70,18 +73,50 @@ class NonCacheCnn:
             pen += dist * np.float32(self.slope)
         return pen, f
 
+    def _empirical(self, i, c):
+        """non_cache_cnn.cpp:113-137: sum over receptor atoms within the cutoff of the atom clamped to the search
+        box -> (energy, derivative, search-box penalty direction * slope), before curl"""
+        adj, oob = np.array(c, dtype=np.float32), np.zeros(3, dtype=np.float32)
+        if self.search_box is not None:
+            lo, hi = self.search_box
+            for k in range(3):
+                if c[k] < lo[k]:
+                    adj[k], oob[k] = lo[k], -self.slope
+                elif c[k] > hi[k]:
+                    adj[k], oob[k] = hi[k], self.slope
+        r = adj[None, :] - self.rec_xyz
+        r2 = (r * r).sum(1, dtype=np.float32)
+        e, d = np.float32(0), np.zeros(3, dtype=np.float32)
+        for j in np.nonzero(r2 < 64.0)[0]:
+            ej, dor = self.tables.eval_deriv(int(self.smt[i]), int(self.rec_smt[j]), float(r2[j]))
+            e += np.float32(ej)
+            d += np.float32(dor) * r[j]
+        return e, d, oob
+
     def eval_deriv(self, conf):
         self.evals += 1
         coords, _, _ = vina.set_conf(self.lig, conf)
         loss, grad = self._cnn(coords, True)
         e = np.float32(loss)
         forces = np.zeros_like(coords)
+        w = np.float32(self.weight)
         for i in range(len(self.smt)):
             if self.smt[i] <= 1:
                 continue                       # hydrogens: minus_forces = 0
             pen, f = self._bounds(coords[i])
             forces[i] = grad[i] + f
+            emp_e = np.float32(0)
+            if self.mix_emp_force:
+                emp_e, emp_d, oob = self._empirical(i, coords[i])
+                if emp_e > 0 and self.v < 0.1 * MAX_FL:          # curl (curl.h:29-42)
+                    tmp = np.float32(self.v / (self.v + emp_e))
+                    emp_e, emp_d = emp_e * tmp, emp_d * tmp * tmp
+                forces[i] = (forces[i] + w * (emp_d + oob)) / (np.float32(1) + w)
             e += pen
+            if self.mix_emp_energy:
+                e += w * emp_e
+        if self.mix_emp_energy:
+            e /= (np.float32(1) + w)
         change, _ = vina.forces_to_change(self.lig, conf, forces)
         return float(e), change
 

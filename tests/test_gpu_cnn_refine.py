@@ -126,3 +126,39 @@ def test_cnn_refine_lowers_the_loss(setup):
     assert np.abs(after - e).max() < 1e-4
     e2, out2, _, _ = v.cnn_refine_batch(s, confs, box)
     assert np.array_equal(e, e2) and np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("mix_force,mix_energy", [(True, False), (True, True), (False, True)])
+def test_cnn_eval_deriv_with_empirical_mix(setup, mix_force, mix_energy):
+    """cnn_options::mix_emp_force / mix_emp_energy / empirical_weight (non_cache_cnn.cpp:113-166)."""
+    capi, sc, lig, v, olig = setup
+    name = "crossdock_default2018"
+    s = capi.Scorer([name])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(21)
+    confs = random_confs(lig, rng, 2)
+    confs[1, :3] += [6.0, 0.0, 0.0]                 # partly outside the search box
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    cen = np.stack([heavy_center(ovina.set_conf(olig, lig["conf0"])[0], lig["smt"])] * 2)
+    wgt = 0.7
+    box = capi.CnnBox.make(23.5, lo, hi, slope=10.0, mix_emp_force=mix_force, mix_emp_energy=mix_energy,
+                           empirical_weight=wgt, v=1000.0)
+    e, ch = v.cnn_eval_batch(s, confs, box, cen, deriv=True)
+    plain = capi.CnnBox.make(23.5, lo, hi, slope=10.0)
+    e_plain, ch_plain = v.cnn_eval_batch(s, confs, plain, cen, deriv=True)
+    e0, _ = v.cnn_eval_batch(s, confs, box, cen, deriv=False)
+    assert np.abs(e0 - e_plain).max() < 1e-4 * np.abs(e_plain).max()     # ::eval ignores the mix options
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    nc = cnn_refine.NonCacheCnn([blob], sc["rec_xyz"], sc["rec_smt"], olig, (lo, hi), 23.5, mix_emp_force=mix_force,
+                                mix_emp_energy=mix_energy, empirical_weight=wgt, tables=ovina.Tables(), v=1000.0)
+    nc.cnn_center = cen[0]
+    nc.slope = 10.0
+    for b in range(2):
+        eo, cho = nc.eval_deriv(confs[b])
+        assert abs(e[b] - eo) < 3e-4 * max(1.0, abs(eo)), (b, e[b], eo)
+        assert np.abs(ch[b] - cho).max() < 3e-3 * max(np.abs(cho).max(), 1e-3), (b, ch[b], cho)
+    if mix_force:
+        assert np.abs(ch - ch_plain).max() > 1e-3     # the blend really changed the forces
+    else:
+        assert np.abs(ch - ch_plain).max() < 1e-6 and np.abs(e - e_plain / (1 + wgt)).max() < 1e-4 * np.abs(e_plain).max()
