@@ -66,10 +66,26 @@ std::vector<float> HipTorchModel::forward(const std::vector<float3> &rec_coords,
 }  // namespace gnina_amd
 
 // Ligand = movable atoms from the first ligand's root to m_num_movable_atoms, hydrogens included
-// (dl_scorer.cpp:71-87).  The covalent-docking branch (:43-69) is not restated.
+// (dl_scorer.cpp:71-87); without a ligand (covalent docking, :43-69) the atoms flagged `iscov` among the
+// flexible-residue and inflex atoms play the ligand's role.
 void DLScorer::setLigand(const model &m) {
   num_atoms = m.atoms.size();
-  if (m.ligands.empty()) return;
+  if (m.ligands.empty() && m.coords.empty()) return;
+  if (m.ligands.empty()) {
+    ligand_smtypes.clear();
+    ligand_coords.clear();
+    ligand_map.clear();
+    auto take = [&](sz i) {
+      if (!m.atoms[i].iscov) return;
+      const vec &c = m.coords[i];
+      ligand_smtypes.push_back(m.atoms[i].sm);
+      ligand_coords.push_back(float3{c[0], c[1], c[2]});
+      ligand_map.push_back((int)i);
+    };
+    for (sz i = 0; i < m.m_num_movable_atoms; i++) take(i);
+    for (sz i = m.m_num_movable_atoms; i < m.coords.size(); i++) take(i);
+    return;
+  }
   const sz off = m.ligands[0].node.begin;
   const sz n = m.m_num_movable_atoms - off;
   ligand_smtypes.resize(n);
@@ -83,27 +99,32 @@ void DLScorer::setLigand(const model &m) {
   }
 }
 
-// Receptor = flexible-residue movable atoms (before the ligand), then inflex atoms, then fixed
-// atoms; types cached on the first call, flexible coordinates refreshed afterwards (dl_scorer.cpp:93-193).
+// Receptor = flexible-residue movable atoms (before the ligand), then inflex atoms, then fixed atoms, covalent
+// (`iscov`) atoms left out; types cached on the first call, flexible coordinates refreshed afterwards
+// (dl_scorer.cpp:93-193).
 void DLScorer::setReceptor(const model &m) {
   num_atoms = m.atoms.size();
   const sz n_flex = m.ligands.empty() ? m.m_num_movable_atoms : m.ligands[0].node.begin;
   const sz n_total = n_flex + (m.atoms.size() - m.m_num_movable_atoms) + m.grid_atoms.size();
   if (receptor_smtypes.empty()) {
-    for (sz i = 0; i < n_flex; i++) receptor_smtypes.push_back(m.atoms[i].sm);
-    for (sz i = m.m_num_movable_atoms; i < m.atoms.size(); i++) receptor_smtypes.push_back(m.atoms[i].sm);
+    for (sz i = 0; i < n_flex; i++)
+      if (!m.atoms[i].iscov) receptor_smtypes.push_back(m.atoms[i].sm);
+    for (sz i = m.m_num_movable_atoms; i < m.atoms.size(); i++)
+      if (!m.atoms[i].iscov) receptor_smtypes.push_back(m.atoms[i].sm);
     for (const atom &a : m.grid_atoms) receptor_smtypes.push_back(a.sm);
   }
   if (receptor_coords.empty()) {
-    for (sz i = 0; i < n_flex; i++) {
-      receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
-      receptor_map.push_back((int)i);
-    }
+    for (sz i = 0; i < n_flex; i++)
+      if (!m.atoms[i].iscov) {
+        receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
+        receptor_map.push_back((int)i);
+      }
     for (sz i = m.m_num_movable_atoms; i < m.coords.size(); i++)
-      receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
+      if (!m.atoms[i].iscov) receptor_coords.push_back(float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]});
     for (const atom &a : m.grid_atoms) receptor_coords.push_back(float3{a.coords[0], a.coords[1], a.coords[2]});
-  } else if (receptor_coords.size() == n_total) {
-    for (sz i = 0; i < n_flex; i++) receptor_coords[i] = float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]};
+  } else if (receptor_coords.size() == n_total) {  // (as in the reference: only when no atom was left out)
+    for (sz i = 0; i < n_flex; i++)
+      if (!m.atoms[i].iscov) receptor_coords[i] = float3{m.coords[i][0], m.coords[i][1], m.coords[i][2]};
   }
 }
 

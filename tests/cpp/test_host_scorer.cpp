@@ -93,6 +93,30 @@ int main(int argc, char **argv) {
     return 0;
   }
 
+  if (argc > 3 && std::string(argv[3]) == "--cov") {
+    // covalent docking: no ligand in the model, the atoms flagged `iscov` are what the CNN sees as the ligand
+    gnina_amd::HipCNNScorer scorer(opts);
+    model m;
+    for (int i = 0; i < n_rec; i++) {
+      atom a;
+      a.sm = rec_smt[i];
+      a.coords = vec(rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2]);
+      m.grid_atoms.push_back(a);
+    }
+    for (int i = 0; i < n_lig; i++) {
+      atom a;
+      a.sm = lig_smt[i];
+      a.iscov = true;
+      m.atoms.push_back(a);
+      m.coords.push_back(vec(poses[(size_t)i * 3], poses[(size_t)i * 3 + 1], poses[(size_t)i * 3 + 2]));
+    }
+    m.m_num_movable_atoms = n_lig;
+    float aff, loss, var;
+    float s0 = scorer.score(m, false, aff, loss, var);
+    std::printf("cov %.9g %.9g %.9g\n", s0, aff, loss);
+    return 0;
+  }
+
   gnina_amd::HipCNNScorer scorer(opts);
   // model: rigid receptor in grid_atoms, ligand as the only movable atoms (ligands[0].node.begin = 0)
   model m;

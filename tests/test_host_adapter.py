@@ -95,3 +95,23 @@ def test_dlscorer_adapter_flexible_residues(exe, golden_dir, tmp_path):
     assert np.abs(forces[:K] - out["flex_grad"][0]).max() < 1e-7
     assert np.abs(forces[K:] - out["lig_grad"][0]).max() < 1e-7
     assert np.abs(forces[:K]).max() > 0
+
+
+@pytest.mark.gpu
+def test_dlscorer_adapter_covalent_branch(exe, golden_dir, tmp_path):
+    """Without a ligand the `iscov` atoms are the CNN's ligand (DLScorer::setLigand, dl_scorer.cpp:43-69)."""
+    G = np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    path = tmp_path / "atoms.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", len(rec_smt), len(lig_smt), 1, 1))
+        f.write(struct.pack("<i", len(name)) + name.encode())
+        f.write(rec_xyz.astype("<f4").tobytes())
+        f.write(rec_smt.astype("<i4").tobytes())
+        f.write(lig_smt.astype("<i4").tobytes())
+        f.write(poses[:1].astype("<f4").tobytes())
+    r = subprocess.run([exe, str(path), WEIGHTS, "--cov"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cov = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("cov")][0]
+    assert abs(float(cov[1]) - G[name + "/pose"][0]) < 1e-4 and abs(float(cov[2]) - G[name + "/affinity"][0]) < 1e-4
