@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi_gnina.so")
 SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "vina.hip", "vina_host.cpp",
-           "../host/typed_atoms.cpp"]
+           "../host/typed_atoms.cpp", "../host/pdbqt.cpp"]
 # -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
 # bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -33,6 +33,7 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mi_gnina.h"))
     headers.append(os.path.join(HERE, "host", "typed_atoms.h"))
+    headers.append(os.path.join(HERE, "host", "pdbqt.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
     objs, rebuilt = [], False
     for src in SOURCES:

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -120,6 +120,14 @@ def lib():
         L.mi_read_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.mi_write_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int]
         L.mi_io_last_error.restype = C.c_char_p
+        L.mi_pdbqt_read_receptor.argtypes = [C.c_char_p, vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.mi_pdbqt_ligand_open.argtypes = [C.c_char_p, C.c_int]
+        L.mi_pdbqt_ligand_open.restype = vp
+        L.mi_pdbqt_ligand_close.argtypes = [vp]
+        L.mi_pdbqt_ligand_close.restype = None
+        L.mi_pdbqt_ligand_sizes.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+        L.mi_pdbqt_ligand_desc.argtypes = [vp, vp, vp, vp, vp]
+        L.mi_pdbqt_last_error.restype = C.c_char_p
         L.mi_scorer_set_precision.argtypes = [vp, C.c_int]
         L.mi_scorer_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
@@ -224,6 +232,48 @@ def write_gninatypes(path, xyz, smt):
     xyz, smt = _f32(xyz).reshape(-1, 3), _i32(smt)
     if lib().mi_write_gninatypes(path.encode(), _ptr(xyz), _ptr(smt), len(smt)) != MI_OK:
         raise MiGninaError(lib().mi_io_last_error().decode())
+
+
+def read_pdbqt_receptor(path):
+    """rigid receptor .pdbqt -> (xyz [n,3], smt [n]) with gnina's typing (parse_pdbqt_rigid + model::initialize)"""
+    n = C.c_int()
+    if lib().mi_pdbqt_read_receptor(path.encode(), None, None, 0, C.byref(n)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    xyz, smt = np.empty((n.value, 3), dtype=np.float32), np.empty(n.value, dtype=np.int32)
+    if lib().mi_pdbqt_read_receptor(path.encode(), _ptr(xyz), _ptr(smt), n.value, C.byref(n)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    return xyz, smt
+
+
+def read_pdbqt_ligand(path_or_text, is_text=False):
+    """ligand .pdbqt -> dict in the layout of gnina_amd.synth.make_ligand_tree (what Vina.set_ligand takes) plus
+    coords0 / conf0 / serial / torsdof"""
+    h = lib().mi_pdbqt_ligand_open(path_or_text.encode(), 1 if is_text else 0)
+    if not h:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    try:
+        d = LigandDesc()
+        pxyz, pser, pconf = C.POINTER(C.c_float)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+        na, nn, npairs, tors = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().mi_pdbqt_ligand_sizes(h, C.byref(na), C.byref(nn), C.byref(npairs), C.byref(tors)))
+        check(lib().mi_pdbqt_ligand_desc(h, C.byref(d), C.byref(pxyz), C.byref(pser), C.byref(pconf)))
+        na, nn, npairs = na.value, nn.value, npairs.value
+
+        def arr(p, shape, dt):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.zeros(shape, dtype=dt)
+            ct = C.c_float if dt == np.float32 else C.c_int32
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).reshape(shape).astype(dt, copy=True)
+
+        return {"smt": arr(d.smt, (na,), np.int32), "local_xyz": arr(d.local_xyz, (na, 3), np.float32),
+                "parent": arr(d.node_parent, (nn,), np.int32), "abeg": arr(d.node_atom_begin, (nn,), np.int32),
+                "aend": arr(d.node_atom_end, (nn,), np.int32), "rel_origin": arr(d.node_rel_origin, (nn, 3), np.float32),
+                "rel_axis": arr(d.node_rel_axis, (nn, 3), np.float32), "pairs": arr(d.pairs, (npairs, 2), np.int32),
+                "coords0": arr(pxyz, (na, 3), np.float32), "serial": arr(pser, (na,), np.int32),
+                "conf0": arr(pconf, (7 + nn - 1,), np.float32), "n_tors": nn - 1, "torsdof": tors.value}
+    finally:
+        lib().mi_pdbqt_ligand_close(h)
 
 
 class Model:

@@ -1,0 +1,590 @@
+#include "pdbqt.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../include/mi_gnina.h"
+
+namespace gnina_amd {
+namespace {
+
+// smina types (atom_constants.h:45-133): AutoDock name, covalent radius, "heteroatom" flag.  Index = smt.
+struct TypeRow {
+  const char *smina, *ad;
+  float covalent;
+  bool hetero;
+};
+const TypeRow kTypes[28] = {
+    {"Hydrogen", "H", 0.37f, false},
+    {"PolarHydrogen", "HD", 0.37f, false},
+    {"AliphaticCarbonXSHydrophobe", "C", 0.77f, false},
+    {"AliphaticCarbonXSNonHydrophobe", "C", 0.77f, false},
+    {"AromaticCarbonXSHydrophobe", "A", 0.77f, false},
+    {"AromaticCarbonXSNonHydrophobe", "A", 0.77f, false},
+    {"Nitrogen", "N", 0.75f, true},
+    {"NitrogenXSDonor", "N", 0.75f, true},
+    {"NitrogenXSDonorAcceptor", "NA", 0.75f, true},
+    {"NitrogenXSAcceptor", "NA", 0.75f, true},
+    {"Oxygen", "O", 0.73f, true},
+    {"OxygenXSDonor", "O", 0.73f, true},
+    {"OxygenXSDonorAcceptor", "OA", 0.73f, true},
+    {"OxygenXSAcceptor", "OA", 0.73f, true},
+    {"Sulfur", "S", 1.02f, true},
+    {"SulfurAcceptor", "SA", 1.02f, true},
+    {"Phosphorus", "P", 1.06f, true},
+    {"Fluorine", "F", 0.71f, true},
+    {"Chlorine", "Cl", 0.99f, true},
+    {"Bromine", "Br", 1.14f, true},
+    {"Iodine", "I", 1.33f, true},
+    {"Magnesium", "Mg", 1.30f, true},
+    {"Manganese", "Mn", 1.39f, true},
+    {"Zinc", "Zn", 1.31f, true},
+    {"Calcium", "Ca", 1.74f, true},
+    {"Iron", "Fe", 1.25f, true},
+    {"GenericMetal", "M", 1.75f, true},
+    {"Boron", "B", 0.90f, false},
+};
+enum { kH = 0, kHD = 1, kGenericMetal = 26, kNumTypes = 28 };
+
+float max_covalent_radius() {
+  float m = 0;
+  for (const TypeRow &r : kTypes) m = std::max(m, r.covalent);
+  return m;
+}
+
+// string_to_smina_type (atom_constants.h:227-253): <= 2 characters = AutoDock name (first row that carries it),
+// "Se" counts as "S", anything else short is a generic metal; longer strings are full smina names
+int string_to_smina_type(const std::string &name) {
+  if (name.empty()) return kNumTypes;
+  if (name.size() <= 2) {
+    for (int i = 0; i < kNumTypes; i++)
+      if (name == kTypes[i].ad) return i;
+    if (name == "Se") return string_to_smina_type("S");
+    return kGenericMetal;
+  }
+  for (int i = 0; i < kNumTypes; i++)
+    if (name == kTypes[i].smina) return i;
+  return kNumTypes;
+}
+
+// adjust_smina_type (atom_constants.h:280-309)
+int adjust_smina_type(int t, bool h_bonded, bool hetero_bonded) {
+  switch (t) {
+    case 2: case 3: return hetero_bonded ? 3 : 2;
+    case 4: case 5: return hetero_bonded ? 5 : 4;
+    case 6: case 7: return h_bonded ? 7 : 6;
+    case 8: case 9: return h_bonded ? 8 : 9;
+    case 10: case 11: return h_bonded ? 11 : 10;
+    case 12: case 13: return h_bonded ? 12 : 13;
+    default: return t;
+  }
+}
+
+struct PAtom {
+  unsigned number = 0;
+  float c[3] = {0, 0, 0};
+  int sm = 0;
+};
+
+[[noreturn]] void fail(const std::string &name, unsigned line, const std::string &what) {
+  throw std::runtime_error(name + ":" + std::to_string(line) + ": " + what);
+}
+
+bool starts_with(const std::string &s, const char *p) { return s.compare(0, std::strlen(p), p) == 0; }
+
+// parse_pdbqt_atom_string (parse_pdbqt.cpp:103-122): 1-based columns 7-11 number, 31-38 / 39-46 / 47-54
+// coordinates, 78.. the AutoDock type (omit_whitespace(str, 78, 79) runs to the end of the line)
+template <typename T> T field(const std::string &name, unsigned line, const std::string &s, size_t i, size_t j, const char *what) {
+  if (j > s.size()) fail(name, line, "ATOM syntax incorrect: The line is too short");
+  std::istringstream is(s.substr(i - 1, j - i + 1));
+  T v;
+  is >> v;
+  std::string rest;
+  if (!is || (is >> rest)) fail(name, line, std::string("ATOM syntax incorrect: \"") + s.substr(i - 1, j - i + 1) + "\" is not a valid " + what);
+  return v;
+}
+
+PAtom parse_atom(const std::string &name, unsigned line, const std::string &s) {
+  PAtom a;
+  const long num = field<long>(name, line, s, 7, 11, "atom number");
+  if (num < 0) fail(name, line, "ATOM syntax incorrect: negative atom number");
+  a.number = (unsigned)num;
+  a.c[0] = field<float>(name, line, s, 31, 38, "coordinate");
+  a.c[1] = field<float>(name, line, s, 39, 46, "coordinate");
+  a.c[2] = field<float>(name, line, s, 47, 54, "coordinate");
+  if (s.size() < 78) fail(name, line, "ATOM syntax incorrect: The line is too short");
+  size_t b = 77, e = s.size();
+  while (b < e && std::isspace((unsigned char)s[b])) b++;
+  while (e > b && std::isspace((unsigned char)s[e - 1])) e--;
+  const std::string ad = s.substr(b, e - b);
+  a.sm = string_to_smina_type(ad);
+  if (a.sm >= kNumTypes)
+    fail(name, line, "ATOM syntax incorrect: \"" + ad + "\" is not a valid AutoDock type. Note that AutoDock atom types are case-sensitive.");
+  return a;
+}
+
+bool ignorable(const std::string &s) {
+  return s.empty() || starts_with(s, "WARNING") || starts_with(s, "REMARK") || starts_with(s, "USER") || starts_with(s, "TER");
+}
+
+// ---- covalent bonds + type adjustment (model::assign_bonds / assign_types, model.cpp:560-655) -----------------
+// mob(i, j): 0 variable, 1 fixed, 2 rotor.  A cell list replaces the reference's "beads" (same candidate set:
+// every atom within the cut-off is seen).
+template <typename Mob>
+void bonds_and_types(const std::vector<PAtom> &atoms, Mob mob, std::vector<std::vector<int>> &bonds, std::vector<int> &sm_out) {
+  const int n = (int)atoms.size();
+  const float allow = 1.1f, maxcov = max_covalent_radius();
+  const float cell = allow * 2 * maxcov;
+  bonds.assign(n, {});
+  // cell list
+  float lo[3] = {1e30f, 1e30f, 1e30f};
+  for (const PAtom &a : atoms)
+    for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], a.c[k]);
+  auto key = [&](const float *c, int *q) {
+    for (int k = 0; k < 3; k++) q[k] = (int)std::floor((c[k] - lo[k]) / cell);
+  };
+  struct Entry {
+    long long h;
+    int i;
+  };
+  auto hash = [](const int *q) { return ((long long)q[0] * 2097152 + q[1]) * 2097152 + q[2]; };
+  std::vector<Entry> ent(n);
+  for (int i = 0; i < n; i++) {
+    int q[3];
+    key(atoms[i].c, q);
+    ent[i] = {hash(q), i};
+  }
+  std::sort(ent.begin(), ent.end(), [](const Entry &a, const Entry &b) { return a.h < b.h || (a.h == b.h && a.i < b.i); });
+  auto d2 = [&](int a, int b) {
+    float s = 0;
+    for (int k = 0; k < 3; k++) s += (atoms[a].c[k] - atoms[b].c[k]) * (atoms[a].c[k] - atoms[b].c[k]);
+    return s;
+  };
+  std::vector<int> rel;
+  for (int i = 0; i < n; i++) {
+    const float ci = kTypes[atoms[i].sm].covalent;
+    const float cut = allow * (ci + maxcov);
+    // relevant atoms: not variable relative to i and within the generous cut-off, ascending index
+    rel.clear();
+    int q[3];
+    key(atoms[i].c, q);
+    for (int dx = -1; dx <= 1; dx++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dz = -1; dz <= 1; dz++) {
+          const int qq[3] = {q[0] + dx, q[1] + dy, q[2] + dz};
+          const long long h = hash(qq);
+          auto it = std::lower_bound(ent.begin(), ent.end(), h, [](const Entry &e, long long v) { return e.h < v; });
+          for (; it != ent.end() && it->h == h; ++it) {
+            const int j = it->i;
+            if (j != i && mob(i, j) != 0 && d2(i, j) < cut * cut) rel.push_back(j);
+          }
+        }
+    std::sort(rel.begin(), rel.end());
+    for (int j : rel) {
+      if (j <= i) continue;
+      const float len = ci + kTypes[atoms[j].sm].covalent;  // optimal_covalent_bond_length
+      const float r2 = d2(i, j);
+      if (!(r2 < (allow * len) * (allow * len))) continue;
+      // atom_exists_between: a heavy atom, immobile relative to both, closer to both than they are to each other
+      bool blocked = false;
+      for (int c : rel) {
+        if (c == i || c == j || atoms[c].sm <= kHD) continue;
+        if (mob(i, c) != 0 && mob(j, c) != 0 && d2(i, c) < r2 && d2(j, c) < r2) {
+          blocked = true;
+          break;
+        }
+      }
+      if (!blocked) {
+        bonds[i].push_back(j);
+        bonds[j].push_back(i);
+      }
+    }
+  }
+  sm_out.resize(n);
+  for (int i = 0; i < n; i++) {
+    bool hd = false, het = false;
+    for (int j : bonds[i]) {
+      if (atoms[j].sm == kHD) hd = true;
+      if (kTypes[atoms[j].sm].hetero) het = true;
+    }
+    sm_out[i] = adjust_smina_type(atoms[i].sm, hd, het);
+  }
+}
+
+// ---- ligand structure ---------------------------------------------------------------------------------------
+struct PS;
+struct Node {
+  PAtom a;
+  std::vector<PS> ps;
+};
+struct PS {
+  int immobile = -1;                  // which of `atoms` is the branch's first ("immobile") atom
+  int axis_begin = -1, axis_end = -1; // model indices of the rotatable bond's two atoms
+  std::vector<Node> atoms;
+  bool essentially_empty() const {    // parsing.h:204-211
+    for (size_t i = 0; i < atoms.size(); i++) {
+      if (immobile >= 0 && (size_t)immobile != i) return false;
+      if (!atoms[i].ps.empty()) return false;
+    }
+    return true;
+  }
+};
+
+struct LineReader {
+  std::istringstream in;
+  unsigned count = 0;
+  const std::string &name;
+  LineReader(const std::string &n, const std::string &text) : in(text), name(n) {}
+  bool next(std::string &s) {
+    if (!std::getline(in, s)) return false;
+    if (!s.empty() && s.back() == '\r') s.pop_back();
+    count++;
+    return true;
+  }
+};
+
+void two_unsigneds(LineReader &r, const std::string &s, const char *tag, unsigned &a, unsigned &b) {
+  std::istringstream is(s.substr(std::strlen(tag)));
+  long x, y;
+  is >> x >> y;
+  if (!is || x < 0 || y < 0) fail(r.name, r.count, "Syntax error");
+  a = (unsigned)x, b = (unsigned)y;
+}
+
+void parse_branch(LineReader &r, PS &p, unsigned from, unsigned to);
+
+void branch_aux(LineReader &r, const std::string &s, PS &p) {  // parse_pdbqt.cpp:249-271
+  unsigned first, second;
+  two_unsigneds(r, s, "BRANCH", first, second);
+  for (Node &nd : p.atoms)
+    if (nd.a.number == first) {
+      PS branch;
+      parse_branch(r, branch, first, second);
+      nd.ps.push_back(std::move(branch));  // (fix_hydrogens is off: hydrogen-only branches stay branches)
+      return;
+    }
+  fail(r.name, r.count, "No atom number " + std::to_string(first) + " in this branch");
+}
+
+void parse_branch(LineReader &r, PS &p, unsigned from, unsigned to) {  // parse_pdbqt.cpp:481-523
+  std::string s;
+  while (r.next(s)) {
+    if (ignorable(s)) continue;
+    if (starts_with(s, "BRANCH")) {
+      branch_aux(r, s, p);
+    } else if (starts_with(s, "ENDBRANCH")) {
+      unsigned a, b;
+      two_unsigneds(r, s, "ENDBRANCH", a, b);
+      if (a != from || b != to) fail(r.name, r.count, "Inconsistent branch numbers");
+      if (p.immobile < 0) fail(r.name, r.count, "Atom " + std::to_string(to) + " has not been found in this branch");
+      return;
+    } else if (starts_with(s, "ATOM  ") || starts_with(s, "HETATM")) {
+      Node nd;
+      nd.a = parse_atom(r.name, r.count, s);
+      if (nd.a.number == to) p.immobile = (int)p.atoms.size();
+      p.atoms.push_back(std::move(nd));
+    } else if (starts_with(s, "MODEL")) {
+      fail(r.name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+    } else {
+      fail(r.name, r.count, "Unknown or inappropriate tag");
+    }
+  }
+}
+
+struct Builder {
+  std::vector<PAtom> atoms;           // model order
+  std::vector<float> local;           // [n][3]
+  std::vector<int> node_of;
+  std::vector<int> parent, abeg, aend;
+  std::vector<float> rel_origin, rel_axis, origin;  // per node
+  std::vector<std::vector<unsigned char>> fixed;    // sparse notes applied after the atom count is known
+  struct Mark {
+    int a, b;
+    unsigned char t;
+  };
+  std::vector<Mark> marks;
+
+  void insert(Node &nd, const float *frame_origin, int node) {  // parsing.h:151-158
+    for (PS &c : nd.ps) c.axis_begin = (int)atoms.size();
+    atoms.push_back(nd.a);
+    for (int k = 0; k < 3; k++) local.push_back(nd.a.c[k] - frame_origin[k]);
+    node_of.push_back(node);
+  }
+  void insert_immobiles(Node &nd, const float *frame_origin, int node) {  // parsing.h:159-163,194-202
+    for (PS &c : nd.ps)
+      if (!c.atoms.empty()) {
+        c.axis_end = (int)atoms.size();
+        insert(c.atoms[c.immobile], frame_origin, node);
+      }
+  }
+  // postprocess_branch (parse_pdbqt.cpp:346-382)
+  void branch(PS &p, int node) {
+    const float *org = &origin[3 * node];
+    abeg[node] = (int)atoms.size();
+    for (size_t i = 0; i < p.atoms.size(); i++) {
+      Node &nd = p.atoms[i];
+      if (!(p.immobile >= 0 && (size_t)p.immobile == i)) insert(nd, org, node);
+      insert_immobiles(nd, org, node);
+    }
+    aend[node] = (int)atoms.size();
+    for (int i = abeg[node]; i < aend[node]; i++) {
+      if (p.axis_begin >= 0) marks.push_back({p.axis_begin, i, 1});
+      if (p.axis_end >= 0) marks.push_back({p.axis_end, i, 1});
+      for (int j = i + 1; j < aend[node]; j++) marks.push_back({i, j, 1});
+    }
+    if (p.axis_begin >= 0 && p.axis_end >= 0) marks.push_back({p.axis_begin, p.axis_end, 2});
+    for (Node &nd : p.atoms)
+      for (PS &c : nd.ps)
+        if (!c.essentially_empty()) {
+          // segment(origin = the branch's immobile atom, axis root = the parent-side atom): tree.h:152-203
+          const float *o = c.atoms[c.immobile].a.c, *root = nd.a.c;
+          float ax[3] = {o[0] - root[0], o[1] - root[1], o[2] - root[2]};
+          const float nrm = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+          if (!(nrm >= 1.1920928955078125e-07f)) throw std::runtime_error("rotatable bond of zero length");
+          const int k = (int)parent.size();
+          parent.push_back(node);
+          abeg.push_back(0);
+          aend.push_back(0);
+          for (int d = 0; d < 3; d++) {
+            origin.push_back(o[d]);
+            rel_origin.push_back(o[d] - origin[3 * node + d]);
+            rel_axis.push_back((1 / nrm) * ax[d]);
+          }
+          branch(c, k);
+        }
+  }
+};
+
+}  // namespace
+
+PdbqtReceptor parse_pdbqt_receptor(const std::string &name, const std::string &text) {  // parse_pdbqt_rigid, :145-183
+  LineReader r(name, text);
+  std::vector<PAtom> atoms;
+  std::string s;
+  while (r.next(s)) {
+    if (starts_with(s, "ATOM  ") || starts_with(s, "HETATM")) atoms.push_back(parse_atom(name, r.count, s));
+    else if (starts_with(s, "MODEL")) fail(name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+    // everything else is ignored ("let's be forgiving")
+  }
+  std::vector<std::vector<int>> bonds;
+  std::vector<int> sm;
+  bonds_and_types(atoms, [](int, int) { return 1; }, bonds, sm);  // rigid: every distance is fixed
+  PdbqtReceptor out;
+  for (size_t i = 0; i < atoms.size(); i++) {
+    out.xyz.insert(out.xyz.end(), atoms[i].c, atoms[i].c + 3);
+    out.smt.push_back(sm[i]);
+  }
+  return out;
+}
+
+PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text) {
+  LineReader r(name, text);
+  PS root;
+  std::string s;
+  // parse_pdbqt_root (:219-244)
+  bool have_root = false;
+  while (!have_root && r.next(s)) {
+    if (ignorable(s)) continue;
+    if (starts_with(s, "ROOT")) {
+      while (r.next(s)) {
+        if (ignorable(s)) continue;
+        if (starts_with(s, "ATOM  ") || starts_with(s, "HETATM")) {
+          Node nd;
+          nd.a = parse_atom(name, r.count, s);
+          root.atoms.push_back(std::move(nd));
+        } else if (starts_with(s, "ENDROOT")) {
+          have_root = true;
+          break;
+        } else if (starts_with(s, "MODEL")) {
+          fail(name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+        } else {
+          fail(name, r.count, "Unknown or inappropriate tag");
+        }
+      }
+    } else if (starts_with(s, "MODEL")) {
+      fail(name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+    } else {
+      fail(name, r.count, "Unknown or inappropriate tag");
+    }
+  }
+  // parse_pdbqt_aux (:273-305)
+  int torsdof = -1;
+  while (r.next(s)) {
+    if (ignorable(s)) continue;
+    if (starts_with(s, "BRANCH")) {
+      branch_aux(r, s, root);
+    } else if (starts_with(s, "TORSDOF")) {
+      if (torsdof >= 0) fail(name, r.count, "TORSDOF can occur only once");
+      std::istringstream is(s.substr(7));
+      long t;
+      is >> t;
+      if (!is || t < 0) fail(name, r.count, "Syntax error");
+      torsdof = (int)t;
+    } else if (starts_with(s, "MODEL")) {
+      fail(name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+    } else {
+      fail(name, r.count, "Unknown or inappropriate tag");
+    }
+  }
+  if (root.atoms.empty()) fail(name, r.count, "No atoms in the ligand");
+  if (torsdof < 0) fail(name, r.count, "Missing TORSDOF");
+
+  // postprocess_ligand (:384-391): root frame at the first root atom
+  Builder b;
+  b.parent.push_back(-1);
+  b.abeg.push_back(0);
+  b.aend.push_back(0);
+  for (int d = 0; d < 3; d++) {
+    b.origin.push_back(root.atoms[0].a.c[d]);
+    b.rel_origin.push_back(0.f);
+    b.rel_axis.push_back(0.f);
+  }
+  b.branch(root, 0);
+  const int n = (int)b.atoms.size();
+  std::vector<unsigned char> mobm((size_t)n * n, 0);
+  for (const Builder::Mark &m : b.marks) {
+    const int lo = std::min(m.a, m.b), hi = std::max(m.a, m.b);
+    mobm[(size_t)lo * n + hi] = m.t;  // later marks overwrite earlier ones, like the reference's assignments
+  }
+  auto mob = [&](int i, int j) -> int { return i == j ? 1 : mobm[(size_t)std::min(i, j) * n + std::max(i, j)]; };
+  std::vector<std::vector<int>> bonds;
+  std::vector<int> sm;
+  bonds_and_types(b.atoms, mob, bonds, sm);
+
+  PdbqtLigand L;
+  L.torsdof = torsdof;
+  for (int i = 0; i < n; i++) {
+    L.xyz.insert(L.xyz.end(), b.atoms[i].c, b.atoms[i].c + 3);
+    L.smt.push_back(sm[i]);
+    L.serial.push_back((int32_t)b.atoms[i].number);
+  }
+  L.local_xyz = b.local;
+  L.node_parent.assign(b.parent.begin(), b.parent.end());
+  L.node_atom_begin.assign(b.abeg.begin(), b.abeg.end());
+  L.node_atom_end.assign(b.aend.begin(), b.aend.end());
+  L.node_rel_origin = b.rel_origin;
+  L.node_rel_axis = b.rel_axis;
+  // initialize_pairs (model.cpp:682-703): variable distance, not within 3 bonds, both heavy
+  for (int i = 0; i < n; i++) {
+    // model::bonded_to(i, 3) (model.cpp:664-680): depth-first, an atom already listed is not expanded again
+    struct Rec {
+      static void go(int a, int depth, const std::vector<std::vector<int>> &bonds, std::vector<int> &out) {
+        if (std::find(out.begin(), out.end(), a) != out.end()) return;
+        out.push_back(a);
+        if (depth > 0)
+          for (int nb : bonds[a]) go(nb, depth - 1, bonds, out);
+      }
+    };
+    std::vector<int> near;
+    Rec::go(i, 3, bonds, near);
+    for (int j = i + 1; j < n; j++) {
+      if (mob(i, j) != 0) continue;
+      if (std::find(near.begin(), near.end(), j) != near.end()) continue;
+      if (sm[i] <= kHD || sm[j] <= kHD) continue;
+      L.pairs.push_back(i);
+      L.pairs.push_back(j);
+    }
+  }
+  const int nt = (int)b.parent.size() - 1;
+  L.conf0.assign(7 + nt, 0.f);
+  for (int d = 0; d < 3; d++) L.conf0[d] = b.origin[d];
+  L.conf0[3] = 1.f;
+  return L;
+}
+
+static std::string slurp(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("could not open " + path);
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+PdbqtReceptor read_pdbqt_receptor(const std::string &path) { return parse_pdbqt_receptor(path, slurp(path)); }
+PdbqtLigand read_pdbqt_ligand(const std::string &path) { return parse_pdbqt_ligand(path, slurp(path)); }
+
+}  // namespace gnina_amd
+
+// ---- C entry points ------------------------------------------------------------------------------------------
+namespace {
+thread_local std::string g_pdbqt_error;
+}
+
+struct mi_pdbqt_ligand {
+  gnina_amd::PdbqtLigand L;
+};
+
+extern "C" {
+
+const char *mi_pdbqt_last_error(void) { return g_pdbqt_error.c_str(); }
+
+mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int capacity, int *n_atoms) {
+  try {
+    if (!path || !n_atoms) throw std::runtime_error("NULL argument");
+    gnina_amd::PdbqtReceptor r = gnina_amd::read_pdbqt_receptor(path);
+    *n_atoms = (int)r.smt.size();
+    if (xyz && smt) {
+      if ((int)r.smt.size() > capacity) throw std::runtime_error("capacity too small");
+      if (!r.smt.empty()) {
+        std::memcpy(xyz, r.xyz.data(), r.xyz.size() * sizeof(float));
+        std::memcpy(smt, r.smt.data(), r.smt.size() * sizeof(int32_t));
+      }
+    }
+    return MI_OK;
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return MI_ERR_INVALID;
+  }
+}
+
+mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text) {
+  try {
+    if (!path_or_text) throw std::runtime_error("NULL argument");
+    auto *h = new mi_pdbqt_ligand();
+    h->L = is_text ? gnina_amd::parse_pdbqt_ligand("<text>", path_or_text) : gnina_amd::read_pdbqt_ligand(path_or_text);
+    return h;
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return nullptr;
+  }
+}
+
+void mi_pdbqt_ligand_close(mi_pdbqt_ligand *h) { delete h; }
+
+mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *h, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof) {
+  if (!h) return MI_ERR_INVALID;
+  if (n_atoms) *n_atoms = (int)h->L.smt.size();
+  if (n_nodes) *n_nodes = (int)h->L.node_parent.size();
+  if (n_pairs) *n_pairs = (int)h->L.pairs.size() / 2;
+  if (torsdof) *torsdof = h->L.torsdof;
+  return MI_OK;
+}
+
+// The arrays of a mi_ligand_desc (pointers stay valid until mi_pdbqt_ligand_close), plus the input coordinates,
+// the PDBQT serial numbers and the conformation that reproduces the input pose.
+mi_status mi_pdbqt_ligand_desc(const mi_pdbqt_ligand *h, mi_ligand_desc *desc, const float **xyz, const int32_t **serial,
+                               const float **conf0) {
+  if (!h || !desc) return MI_ERR_INVALID;
+  const gnina_amd::PdbqtLigand &L = h->L;
+  desc->n_atoms = (int32_t)L.smt.size();
+  desc->smt = L.smt.data();
+  desc->local_xyz = L.local_xyz.data();
+  desc->n_nodes = (int32_t)L.node_parent.size();
+  desc->node_parent = L.node_parent.data();
+  desc->node_atom_begin = L.node_atom_begin.data();
+  desc->node_atom_end = L.node_atom_end.data();
+  desc->node_rel_origin = L.node_rel_origin.data();
+  desc->node_rel_axis = L.node_rel_axis.data();
+  desc->n_pairs = (int32_t)(L.pairs.size() / 2);
+  desc->pairs = L.pairs.data();
+  if (xyz) *xyz = L.xyz.data();
+  if (serial) *serial = L.serial.data();
+  if (conf0) *conf0 = L.conf0.data();
+  return MI_OK;
+}
+}

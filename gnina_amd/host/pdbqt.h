@@ -1,0 +1,50 @@
+// pdbqt.h -- native PDBQT reader for the hot path's inputs, no OpenBabel.
+//
+// Restates what gnina does between a .pdbqt file and the arrays the scoring path consumes:
+//   * parse_pdbqt_rigid / parse_pdbqt_ligand_stream (gninasrc/lib/parse_pdbqt.cpp:145-183,185-305,419-435,
+//     481-527): ATOM/HETATM columns, ROOT / BRANCH a b / ENDBRANCH / TORSDOF structure;
+//   * postprocess_ligand / postprocess_branch (parse_pdbqt.cpp:346-391; parsing.h:122-212): atom order
+//     (a branch's first atom -- its "immobile atom" -- is stored in the PARENT segment), segment frames
+//     (tree.h:152-203: origin = immobile atom, axis = unit vector from the parent-side atom), the relative
+//     mobility matrix (fixed / rotor / variable);
+//   * model::initialize (model.cpp:560-720): covalent bonds from distances (assign_bonds), X-Score type
+//     adjustment from bonded hydrogens / heteroatoms (adjust_smina_type, atom_constants.h:280-309), interacting
+//     pairs (initialize_pairs: variable distance, more than 3 bonds apart, heavy atoms).
+// The output is exactly what mi_scorer_set_receptor / mi_vina_set_receptor and mi_vina_set_ligand take.
+//
+// Not restated: flexible residues (BEGIN_RES), the `fix_hydrogens` option (off by default in gnina), multi-MODEL
+// files.  Parity: "unpinned" -- the reference ships no ligand .pdbqt fixture with expected types or pairs, so
+// the tests check hand-derived small molecules and structural invariants (tests/test_pdbqt_cpu.py).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gnina_amd {
+
+struct PdbqtReceptor {
+  std::vector<float> xyz;     // [n][3]
+  std::vector<int32_t> smt;   // [n] smina types after adjust_smina_type
+};
+
+struct PdbqtLigand {
+  // atoms in model order (node by node, DFS pre-order of the torsion tree)
+  std::vector<float> xyz;        // [n][3] input coordinates
+  std::vector<int32_t> smt;      // [n]
+  std::vector<int32_t> serial;   // [n] PDBQT atom numbers
+  std::vector<float> local_xyz;  // [n][3] relative to the owning node's origin
+  // nodes: 0 = rigid root, k > 0 = segment of torsion k-1
+  std::vector<int32_t> node_parent, node_atom_begin, node_atom_end;
+  std::vector<float> node_rel_origin, node_rel_axis;  // [n_nodes][3]
+  std::vector<int32_t> pairs;    // [n_pairs][2], a < b
+  std::vector<float> conf0;      // [7 + T]: root origin, identity quaternion, zero torsions = the input pose
+  int torsdof = 0;               // TORSDOF record
+};
+
+// Throw std::runtime_error("<name>:<line>: <what>") on malformed input, like parse_error.
+PdbqtReceptor read_pdbqt_receptor(const std::string &path);
+PdbqtLigand read_pdbqt_ligand(const std::string &path);
+PdbqtReceptor parse_pdbqt_receptor(const std::string &name, const std::string &text);
+PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text);
+
+}  // namespace gnina_amd

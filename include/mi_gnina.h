@@ -314,6 +314,23 @@ mi_status mi_read_gninatypes(const char *path, float *xyz, int32_t *smt, int cap
 mi_status mi_write_gninatypes(const char *path, const float *xyz, const int32_t *smt, int n_atoms);
 const char *mi_io_last_error(void);
 
+/* ---- PDBQT files, no OpenBabel: gnina_amd/host/pdbqt.h restates parse_pdbqt.cpp
+ * (ATOM columns, ROOT / BRANCH / ENDBRANCH / TORSDOF), postprocess_ligand (atom order, segment frames, mobility)
+ * and model::initialize (distance-based bonds, adjust_smina_type, interacting pairs; model.cpp:560-720).
+ * Receptor: rigid .pdbqt -> coordinates + smina types, ready for mi_scorer_set_receptor / mi_vina_set_receptor.
+ * Ligand: handle whose mi_ligand_desc is what mi_vina_set_ligand takes; xyz = input coordinates in model order
+ * (what mi_scorer_score_batch takes with desc.smt), serial = PDBQT atom numbers, conf0 [7+T] = the conformation
+ * that reproduces the input pose.  is_text != 0: the first argument is the file's text.  Flexible residues
+ * (BEGIN_RES) are not read.  Errors: NULL / MI_ERR_INVALID + mi_pdbqt_last_error() ("file:line: what"). */
+typedef struct mi_pdbqt_ligand mi_pdbqt_ligand;
+mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int capacity, int *n_atoms);
+mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text);
+void mi_pdbqt_ligand_close(mi_pdbqt_ligand *);
+mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof);
+mi_status mi_pdbqt_ligand_desc(const mi_pdbqt_ligand *, mi_ligand_desc *desc, const float **xyz,
+                               const int32_t **serial, const float **conf0);
+const char *mi_pdbqt_last_error(void);
+
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this
  * scorer is bracketed by HIP events on the scorer's stream.  mi_scorer_profile_json drains the
  * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes}], where

@@ -215,3 +215,37 @@ def test_noncache_exact_and_refine_match_oracle(setup):
     e_orc = np.array([V.refine(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v)[0] for b in range(len(confs))])
     fin = (er < 1e30) & (e_orc < 1e30)
     assert abs(np.median(er[fin]) - np.median(e_orc[fin])) <= 0.25 * abs(np.median(e_orc[fin])) + 1.0
+
+
+def test_pdbqt_ligand_through_the_engine(capi, T):
+    """A ligand read by the native PDBQT reader (torsion tree, types, pairs) drives the Vina kernels and the CNN
+    exactly like the synthetic generator's ligands: device == oracle on the same description."""
+    from tests.test_pdbqt_cpu import chain_pdbqt
+    lig = capi.read_pdbqt_ligand(chain_pdbqt(), is_text=True)
+    sc = vina_scene.build(seed=2)
+    shift = sc["center"] - lig["coords0"].mean(0)
+    conf = lig["conf0"].copy()
+    conf[:3] += shift
+    gd = V.setup_grid_dims(sc["center"], sc["size"])
+    types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+    v = capi.Vina()
+    v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    v.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+    v.set_ligand(lig)
+    rng = np.random.RandomState(4)
+    confs = np.stack([conf] * 4).astype(np.float32)
+    confs[1:, 7:] += rng.uniform(-2, 2, (3, lig["n_tors"])).astype(np.float32)
+    confs[1:, :3] += rng.uniform(-1, 1, (3, 3)).astype(np.float32)
+    e, ch, coords = v.eval_batch(confs, (1000.0, 1000.0, 1000.0), deriv=True, want_coords=True)
+    grids = {t: V.cache_populate(T, gd, sc["rec_xyz"], sc["rec_smt"], t) for t in types}
+    S = V.Scene(T, gd, grids, V.LigandHandle(lig))
+    for b in range(4):
+        eo, cho, co, _ = S.eval_deriv(confs[b])
+        assert np.abs(coords[b] - co).max() < 1e-4
+        assert abs(e[b] - eo) < 1e-4 * max(1.0, abs(eo))
+        assert np.abs(ch[b] - cho).max() < 2e-3 * max(np.abs(cho).max(), 1e-2)
+    assert np.abs(coords[0] - (lig["coords0"] + shift)).max() < 1e-4      # conf0 reproduces the file's pose
+    s = capi.Scorer(["crossdock_default2018"])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    out = s.score_batch(coords, lig["smt"])
+    assert np.isfinite(out["pose"]).all() and np.isfinite(out["affinity"]).all()

@@ -1,0 +1,140 @@
+"""Native PDBQT reader (gnina_amd/host/pdbqt.{h,cpp}).  The reference ships no ligand .pdbqt
+with expected types / pairs ("parity unpinned"): the expectations below are derived by hand from
+parse_pdbqt.cpp / parsing.h / model.cpp for small molecules, plus structural invariants checked with the
+torsion-tree oracle (oracle/vina.py: set_conf must reproduce the file's coordinates)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vina as ovina
+
+REF_DATA = "/root/reference/test/gnina/data"
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import build, capi as c
+    build.build()
+    return c
+
+
+def atom_line(serial, name, x, y, z, adtype, q=0.0, het=False):
+    rec = "HETATM" if het else "ATOM  "
+    return f"{rec}{serial:5d} {name:<4s} LIG A   1    {x:8.3f}{y:8.3f}{z:8.3f}{1.0:6.2f}{0.0:6.2f}    {q:6.3f} {adtype:<2s}"
+
+
+# zig-zag chain C1-C2-C3-C4-O5-H6, three rotatable bonds
+CHAIN = [(0.000, 0.000, 0.0), (1.520, 0.000, 0.0), (2.280, 1.316, 0.0), (3.800, 1.316, 0.0), (4.510, 2.546, 0.0),
+         (5.470, 2.546, 0.0)]
+
+
+def chain_pdbqt():
+    a = [atom_line(i + 1, n, *CHAIN[i], t) for i, (n, t) in
+         enumerate([("C1", "C"), ("C2", "C"), ("C3", "C"), ("C4", "C"), ("O5", "OA"), ("H6", "HD")])]
+    return "\n".join(["REMARK  hand-made test ligand", "ROOT", a[0], a[1], "ENDROOT", "BRANCH   2   3", a[2],
+                      "BRANCH   3   4", a[3], "BRANCH   4   5", a[4], a[5], "ENDBRANCH   4   5", "ENDBRANCH   3   4",
+                      "ENDBRANCH   2   3", "TORSDOF 3", ""])
+
+
+def test_ligand_structure_matches_hand_derivation(capi):
+    lig = capi.read_pdbqt_ligand(chain_pdbqt(), is_text=True)
+    # atom order: a branch's first ("immobile") atom is stored in the parent segment (parsing.h:151-202)
+    assert lig["serial"].tolist() == [1, 2, 3, 4, 5, 6]
+    assert lig["parent"].tolist() == [-1, 0, 1, 2]
+    assert lig["abeg"].tolist() == [0, 3, 4, 5] and lig["aend"].tolist() == [3, 4, 5, 6]
+    assert lig["n_tors"] == 3 and lig["torsdof"] == 3
+    xyz = np.array(CHAIN, dtype=np.float32)
+    np.testing.assert_allclose(lig["coords0"], xyz, atol=1e-6)
+    # frames: root origin = first root atom; segment origin = immobile atom, axis from the parent-side atom (tree.h:152-203)
+    np.testing.assert_allclose(lig["rel_origin"][1], xyz[2] - xyz[0], atol=1e-6)
+    np.testing.assert_allclose(lig["rel_origin"][2], xyz[3] - xyz[2], atol=1e-6)
+    np.testing.assert_allclose(lig["rel_origin"][3], xyz[4] - xyz[3], atol=1e-6)
+    for k, (a, b) in enumerate([(1, 2), (2, 3), (3, 4)], start=1):
+        ax = (xyz[b] - xyz[a]) / np.linalg.norm(xyz[b] - xyz[a])
+        np.testing.assert_allclose(lig["rel_axis"][k], ax, atol=1e-6)
+    np.testing.assert_allclose(lig["local_xyz"][:3], xyz[:3] - xyz[0], atol=1e-6)
+    np.testing.assert_allclose(lig["local_xyz"][3], xyz[3] - xyz[2], atol=1e-6)   # C4 lives in the C3-origin segment
+    np.testing.assert_allclose(lig["local_xyz"][4], xyz[4] - xyz[3], atol=1e-6)
+    np.testing.assert_allclose(lig["local_xyz"][5], xyz[5] - xyz[4], atol=1e-6)
+    # types (adjust_smina_type): C bonded only to C -> hydrophobe 2; C4 bonded to O -> 3; OA with a polar H -> 12
+    assert lig["smt"].tolist() == [2, 2, 2, 3, 12, 1]
+    # pairs (initialize_pairs): heavy, variable distance, more than 3 bonds apart -> only C1..O5
+    assert lig["pairs"].tolist() == [[0, 4]]
+    np.testing.assert_allclose(lig["conf0"], [0, 0, 0, 1, 0, 0, 0, 0, 0, 0], atol=1e-7)
+
+
+def test_tree_reproduces_the_file_and_torsions_preserve_bonds(capi):
+    lig = capi.read_pdbqt_ligand(chain_pdbqt(), is_text=True)
+    h = ovina.LigandHandle(lig)
+    coords, _, _ = ovina.set_conf(h, lig["conf0"])
+    assert np.abs(coords - lig["coords0"]).max() < 1e-5
+    rng = np.random.RandomState(0)
+    conf = lig["conf0"].copy()
+    conf[7:] = rng.uniform(-3, 3, 3)
+    moved, _, _ = ovina.set_conf(h, conf)
+    bonds = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+    for a, b in bonds:
+        d0 = np.linalg.norm(lig["coords0"][a] - lig["coords0"][b])
+        assert abs(np.linalg.norm(moved[a] - moved[b]) - d0) < 1e-4
+    # bond angles survive too (rotation about the bond axis only); end-to-end distance changes
+    for a, b, c in [(0, 1, 2), (1, 2, 3), (2, 3, 4), (3, 4, 5)]:
+        d0 = np.linalg.norm(lig["coords0"][a] - lig["coords0"][c])
+        assert abs(np.linalg.norm(moved[a] - moved[c]) - d0) < 1e-4
+    assert abs(np.linalg.norm(moved[0] - moved[4]) - np.linalg.norm(lig["coords0"][0] - lig["coords0"][4])) > 1e-3
+    assert np.abs(moved[:3] - lig["coords0"][:3]).max() < 1e-5            # the root did not move
+
+
+def test_single_atom_branch_makes_no_torsion_and_typing_rules(capi):
+    # methylamine-like: N (root) - C, the C as a one-atom branch: "essentially empty" -> no segment (parsing.h:204-211)
+    lines = ["ROOT", atom_line(1, "N1", 0, 0, 0, "N"), atom_line(2, "H1", 0.0, 0.95, 0.3, "HD"), "ENDROOT",
+             "BRANCH   1   3", atom_line(3, "C1", 1.47, 0, 0, "C"), "ENDBRANCH   1   3", "TORSDOF 0", ""]
+    lig = capi.read_pdbqt_ligand("\n".join(lines), is_text=True)
+    assert lig["n_tors"] == 0 and lig["serial"].tolist() == [1, 3, 2]     # the branch atom follows its parent atom
+    # N with a polar hydrogen -> NitrogenXSDonor (7); the carbon next to N -> non-hydrophobe (3)
+    assert lig["smt"].tolist() == [7, 3, 1]
+    assert lig["pairs"].shape == (0, 2)
+
+
+def test_receptor_typing_and_reference_file(capi, tmp_path):
+    # water (OA + 2 HD) -> donor/acceptor 12; a lone carbonyl-like OA -> acceptor 13; NA without H -> 9; N with H -> 7;
+    # an aromatic carbon next to N -> 5, far from everything -> 4; zinc and an unknown two-letter metal -> 23 / 26
+    atoms = [(1, "O", 0, 0, 0, "OA"), (2, "H1", 0.96, 0, 0, "HD"), (3, "H2", -0.24, 0.93, 0, "HD"),
+             (4, "O2", 10, 0, 0, "OA"), (5, "N1", 20, 0, 0, "NA"), (6, "N2", 30, 0, 0, "N"), (7, "H3", 30.9, 0.4, 0, "HD"),
+             (8, "CA", 31.0 - 2.3, 0.0, 0.9, "A"), (9, "CB", 50, 0, 0, "A"), (10, "ZN", 60, 0, 0, "Zn"),
+             (11, "CU", 70, 0, 0, "Cu")]
+    atoms[7] = (8, "CA", 30.0, -1.35, 0.0, "A")
+    text = "\n".join(["REMARK receptor"] + [atom_line(*a) for a in atoms] + ["TER", "END", ""])
+    p = tmp_path / "rec.pdbqt"
+    p.write_text(text)
+    xyz, smt = capi.read_pdbqt_receptor(str(p))
+    assert len(smt) == 11 and np.allclose(xyz[3], [10, 0, 0])
+    assert smt.tolist() == [12, 1, 1, 13, 9, 7, 1, 5, 4, 23, 26]
+    ref = os.path.join(REF_DATA, "GSK3B_DFG_out_35-388-processed_rigid.pdbqt")
+    if os.path.exists(ref):   # the reference's own rigid-receptor fixture (only in the build container)
+        xyz, smt = capi.read_pdbqt_receptor(ref)
+        n_lines = sum(1 for l in open(ref) if l.startswith("ATOM  ") or l.startswith("HETATM"))
+        assert len(smt) == n_lines > 1000 and ((smt >= 0) & (smt < 28)).all()
+        # a protein has backbone N-H donors, carbonyl acceptors, both kinds of carbon and polar hydrogens
+        for t in (1, 2, 3, 7, 13):
+            assert (smt == t).sum() > 20, t
+        assert (smt == 0).sum() == 0          # PDBQT receptors carry polar hydrogens only
+        # every polar hydrogen sits on a donor: count of donors (N 7/8, O 11/12) is between #HD/3 and #HD
+        donors = np.isin(smt, [7, 8, 11, 12]).sum()
+        assert (smt == 1).sum() / 3 <= donors <= (smt == 1).sum()
+
+
+def test_errors_carry_file_and_line(capi, tmp_path):
+    bad = chain_pdbqt().replace("ENDBRANCH   3   4", "ENDBRANCH   3   9")
+    with pytest.raises(capi.MiGninaError, match=r"<text>:\d+: Inconsistent branch numbers"):
+        capi.read_pdbqt_ligand(bad, is_text=True)
+    with pytest.raises(capi.MiGninaError, match="Missing TORSDOF"):
+        capi.read_pdbqt_ligand(chain_pdbqt().replace("TORSDOF 3", ""), is_text=True)
+    with pytest.raises(capi.MiGninaError, match="not a valid AutoDock type|GenericMetal|valid"):
+        capi.read_pdbqt_ligand(chain_pdbqt().replace(" OA", " Qx7"), is_text=True)
+    with pytest.raises(capi.MiGninaError, match="No atom number 7"):
+        capi.read_pdbqt_ligand(chain_pdbqt().replace("BRANCH   2   3", "BRANCH   7   3", 1), is_text=True)
+    with pytest.raises(capi.MiGninaError, match="could not open"):
+        capi.read_pdbqt_receptor(str(tmp_path / "none.pdbqt"))
+    with pytest.raises(capi.MiGninaError, match="MODEL"):
+        capi.read_pdbqt_ligand("MODEL 1\n" + chain_pdbqt(), is_text=True)
