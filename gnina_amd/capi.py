@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -128,6 +128,8 @@ def lib():
         L.mi_pdbqt_ligand_sizes.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
         L.mi_pdbqt_ligand_desc.argtypes = [vp, vp, vp, vp, vp]
         L.mi_pdbqt_last_error.restype = C.c_char_p
+        L.mi_pdbqt_write_pose.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
         L.mi_scorer_set_precision.argtypes = [vp, C.c_int]
         L.mi_scorer_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
@@ -272,6 +274,29 @@ def read_pdbqt_ligand(path_or_text, is_text=False):
                 "rel_axis": arr(d.node_rel_axis, (nn, 3), np.float32), "pairs": arr(d.pairs, (npairs, 2), np.int32),
                 "coords0": arr(pxyz, (na, 3), np.float32), "serial": arr(pser, (na,), np.int32),
                 "conf0": arr(pconf, (7 + nn - 1,), np.float32), "n_tors": nn - 1, "torsdof": tors.value}
+    finally:
+        lib().mi_pdbqt_ligand_close(h)
+
+
+def pdbqt_poses_text(path_or_text, poses, energies, cnnscores=None, cnnaffinities=None, rmsds=None, is_text=False):
+    """Poses [n, n_atoms, 3] (model order) -> gnina's multi-MODEL .pdbqt text (result_info::write)"""
+    h = lib().mi_pdbqt_ligand_open(path_or_text.encode(), 1 if is_text else 0)
+    if not h:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    try:
+        out = []
+        for i in range(len(poses)):
+            xyz = _f32(poses[i])
+            need = C.c_size_t()
+            args = (int(i + 1), float(energies[i]), float(-1 if rmsds is None else rmsds[i]),
+                    float(-1 if cnnscores is None else cnnscores[i]), float(0 if cnnaffinities is None else cnnaffinities[i]))
+            if lib().mi_pdbqt_write_pose(h, _ptr(xyz), *args, None, 0, C.byref(need)) != MI_OK:
+                raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+            buf = C.create_string_buffer(need.value)
+            if lib().mi_pdbqt_write_pose(h, _ptr(xyz), *args, buf, need.value, C.byref(need)) != MI_OK:
+                raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+            out.append(buf.value.decode())
+        return "".join(out)
     finally:
         lib().mi_pdbqt_ligand_close(h)
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -89,6 +90,7 @@ struct PAtom {
   unsigned number = 0;
   float c[3] = {0, 0, 0};
   int sm = 0;
+  unsigned line = 0;  // 1-based line of the ATOM record in the input
 };
 
 [[noreturn]] void fail(const std::string &name, unsigned line, const std::string &what) {
@@ -111,6 +113,7 @@ template <typename T> T field(const std::string &name, unsigned line, const std:
 
 PAtom parse_atom(const std::string &name, unsigned line, const std::string &s) {
   PAtom a;
+  a.line = line;
   const long num = field<long>(name, line, s, 7, 11, "atom number");
   if (num < 0) fail(name, line, "ATOM syntax incorrect: negative atom number");
   a.number = (unsigned)num;
@@ -240,10 +243,12 @@ struct LineReader {
   unsigned count = 0;
   const std::string &name;
   LineReader(const std::string &n, const std::string &text) : in(text), name(n) {}
+  std::vector<std::string> lines;
   bool next(std::string &s) {
     if (!std::getline(in, s)) return false;
     if (!s.empty() && s.back() == '\r') s.pop_back();
     count++;
+    lines.push_back(s);
     return true;
   }
 };
@@ -490,11 +495,45 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
       L.pairs.push_back(j);
     }
   }
+  L.lines = r.lines;
+  L.line_atom.assign(L.lines.size(), -1);
+  for (int i = 0; i < n; i++) L.line_atom[b.atoms[i].line - 1] = i;
   const int nt = (int)b.parent.size() - 1;
   L.conf0.assign(7 + nt, 0.f);
   for (int d = 0; d < 3; d++) L.conf0[d] = b.origin[d];
   L.conf0[3] = 1.f;
   return L;
+}
+
+static std::string num9(float v) {  // boost::lexical_cast<std::string>(float): up to 9 significant digits
+  char buf[48];
+  snprintf(buf, sizeof buf, "%.9g", (double)v);
+  return buf;
+}
+
+std::string write_pdbqt_pose(const PdbqtLigand &lig, const float *coords, int modelnum, float energy, float rmsd,
+                             float cnnscore, float cnnaffinity) {
+  std::ostringstream out;
+  out << "MODEL " << modelnum << "\n";
+  out << "REMARK minimizedAffinity " << num9(energy) << "\n";
+  if (rmsd >= 0) out << "REMARK minimizedRMSD " << num9(rmsd) << "\n";
+  if (cnnscore >= 0) out << "REMARK CNNscore " << num9(cnnscore) << "\n";
+  if (cnnaffinity != 0) out << "REMARK CNNaffinity " << num9(cnnaffinity) << "\n";
+  for (size_t i = 0; i < lig.lines.size(); i++) {
+    std::string s = lig.lines[i];
+    const int a = lig.line_atom[i];
+    if (a >= 0) {  // coords_to_pdbqt_string: columns 31, 39, 47, width 8, 3 decimals
+      for (int k = 0; k < 3; k++) {
+        char buf[32];
+        snprintf(buf, sizeof buf, "%8.3f", (double)coords[3 * a + k]);
+        if (std::strlen(buf) != 8) throw std::runtime_error("coordinate does not fit the 8-column PDBQT field");
+        s.replace(30 + 8 * k, 8, buf);
+      }
+    }
+    out << s << "\n";
+  }
+  out << "ENDMDL\n";
+  return out.str();
 }
 
 static std::string slurp(const std::string &path) {
@@ -563,6 +602,23 @@ mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *h, int *n_atoms, int *n_n
   if (n_pairs) *n_pairs = (int)h->L.pairs.size() / 2;
   if (torsdof) *torsdof = h->L.torsdof;
   return MI_OK;
+}
+
+mi_status mi_pdbqt_write_pose(const mi_pdbqt_ligand *h, const float *coords, int modelnum, float energy, float rmsd,
+                              float cnnscore, float cnnaffinity, char *out, size_t capacity, size_t *needed) {
+  try {
+    if (!h || !coords || !needed) throw std::runtime_error("NULL argument");
+    const std::string s = gnina_amd::write_pdbqt_pose(h->L, coords, modelnum, energy, rmsd, cnnscore, cnnaffinity);
+    *needed = s.size() + 1;
+    if (out) {
+      if (capacity < s.size() + 1) throw std::runtime_error("capacity too small");
+      std::memcpy(out, s.c_str(), s.size() + 1);
+    }
+    return MI_OK;
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return MI_ERR_INVALID;
+  }
 }
 
 // The arrays of a mi_ligand_desc (pointers stay valid until mi_pdbqt_ligand_close), plus the input coordinates,

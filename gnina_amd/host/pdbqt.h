@@ -39,7 +39,18 @@ struct PdbqtLigand {
   std::vector<int32_t> pairs;    // [n_pairs][2], a < b
   std::vector<float> conf0;      // [7 + T]: root origin, identity quaternion, zero torsions = the input pose
   int torsdof = 0;               // TORSDOF record
+  // the file's lines and, for ATOM/HETATM lines, the model index of the atom (-1 otherwise): gnina's `context`
+  // (model.h:205-230), used to write poses back in the input's own format
+  std::vector<std::string> lines;
+  std::vector<int32_t> line_atom;
 };
+
+// One docked pose as gnina writes it to a .pdbqt (result_info::write, result_info.cpp:151-164 +
+// context::writePDBQT / coords_to_pdbqt_string, model.cpp:779-810): MODEL n, REMARK minimizedAffinity /
+// [minimizedRMSD] / [CNNscore] / [CNNaffinity], the input lines with columns 31-54 rewritten (%8.3f), ENDMDL.
+// coords [n_atoms][3] in model order; rmsd < 0 and cnnscore < 0 omit their remarks, cnnaffinity == 0 omits its.
+std::string write_pdbqt_pose(const PdbqtLigand &lig, const float *coords, int modelnum, float energy, float rmsd,
+                             float cnnscore, float cnnaffinity);
 
 // Throw std::runtime_error("<name>:<line>: <what>") on malformed input, like parse_error.
 PdbqtReceptor read_pdbqt_receptor(const std::string &path);

@@ -329,6 +329,12 @@ void mi_pdbqt_ligand_close(mi_pdbqt_ligand *);
 mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof);
 mi_status mi_pdbqt_ligand_desc(const mi_pdbqt_ligand *, mi_ligand_desc *desc, const float **xyz,
                                const int32_t **serial, const float **conf0);
+/* One pose in gnina's .pdbqt output format (result_info::write, result_info.cpp:151-164; coordinates written back
+ * into the input's own lines like context::writePDBQT, model.cpp:779-810): MODEL n / REMARK minimizedAffinity,
+ * [minimizedRMSD if rmsd >= 0], [CNNscore if >= 0], [CNNaffinity if != 0] / ATOM lines / ENDMDL.  coords
+ * [n_atoms][3] in model order.  Call with out = NULL to get the size (*needed, incl. the terminating 0). */
+mi_status mi_pdbqt_write_pose(const mi_pdbqt_ligand *, const float *coords, int modelnum, float energy, float rmsd,
+                              float cnnscore, float cnnaffinity, char *out, size_t capacity, size_t *needed);
 const char *mi_pdbqt_last_error(void);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this

@@ -138,3 +138,33 @@ def test_errors_carry_file_and_line(capi, tmp_path):
         capi.read_pdbqt_receptor(str(tmp_path / "none.pdbqt"))
     with pytest.raises(capi.MiGninaError, match="MODEL"):
         capi.read_pdbqt_ligand("MODEL 1\n" + chain_pdbqt(), is_text=True)
+
+
+def test_pose_writer_round_trip(capi):
+    """gnina's .pdbqt output (result_info.cpp:151-164, model.cpp:779-810): the written poses parse back to the
+    written coordinates, remarks follow the reference's rules, non-ATOM lines survive untouched."""
+    text = chain_pdbqt()
+    lig = capi.read_pdbqt_ligand(text, is_text=True)
+    h = ovina.LigandHandle(lig)
+    rng = np.random.RandomState(1)
+    poses = []
+    for _ in range(3):
+        conf = lig["conf0"].copy()
+        conf[:3] += rng.uniform(-5, 5, 3)
+        conf[7:] = rng.uniform(-3, 3, 3)
+        poses.append(ovina.set_conf(h, conf)[0])
+    poses = np.stack(poses)
+    out = capi.pdbqt_poses_text(text, poses, energies=[-7.25, -6.5, 1e3], cnnscores=[0.91, 0.5, -1.0],
+                                cnnaffinities=[6.75, 0.0, 5.5], is_text=True)
+    models = out.split("ENDMDL\n")[:-1]
+    assert len(models) == 3 and models[0].startswith("MODEL 1\nREMARK minimizedAffinity -7.25\nREMARK CNNscore 0.910000026\nREMARK CNNaffinity 6.75\n")
+    assert "CNNaffinity" not in models[1] and "REMARK CNNscore 0.5\n" in models[1]       # affinity 0 -> omitted
+    assert "CNNscore" not in models[2] and "REMARK CNNaffinity 5.5\n" in models[2]       # score < 0 -> omitted
+    for k, m in enumerate(models):
+        body = "\n".join(l for l in m.split("\n") if not l.startswith(("MODEL", "REMARK minimized", "REMARK CNN")))
+        back = capi.read_pdbqt_ligand(body, is_text=True)
+        assert np.abs(back["coords0"] - np.round(poses[k].astype(np.float64), 3)).max() < 2e-3
+        assert back["smt"].tolist() == lig["smt"].tolist() and back["pairs"].tolist() == lig["pairs"].tolist()
+        assert "REMARK  hand-made test ligand" in m and "TORSDOF 3" in m and "BRANCH   3   4" in m
+    with pytest.raises(capi.MiGninaError, match="8-column"):
+        capi.pdbqt_poses_text(text, poses * 1e5, energies=[0, 0, 0], is_text=True)
