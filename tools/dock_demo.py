@@ -30,10 +30,19 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="MC steps per chain (0 = gnina's heuristic)")
     ap.add_argument("--models", default="default2017")
     ap.add_argument("--ligands", type=int, default=1, help="dock this many copies concurrently (screening mode)")
+    ap.add_argument("--receptor", default="", help="rigid receptor .pdbqt (default: the synthetic C3 complex)")
+    ap.add_argument("--ligand", default="", help="ligand .pdbqt; the search box is its bounding box + 4 A (autobox)")
+    ap.add_argument("--out", default="", help="write the ranked poses as a multi-MODEL .pdbqt (needs --ligand)")
     args = ap.parse_args()
     capi.init(0)
-    sc = vina_scene.build(0)
-    lig = sc["lig"]
+    if args.receptor and args.ligand:   # real files through the native PDBQT reader (no OpenBabel)
+        rec_xyz, rec_smt = capi.read_pdbqt_receptor(args.receptor)
+        lig = capi.read_pdbqt_ligand(args.ligand)
+        lo, hi = lig["coords0"].min(0) - 4.0, lig["coords0"].max(0) + 4.0   # --autobox_ligand, autobox_add 4 (main.cpp:1470-1490)
+        sc = {"rec_xyz": rec_xyz, "rec_smt": rec_smt, "lig": lig, "center": (lo + hi) / 2, "size": hi - lo}
+    else:
+        sc = vina_scene.build(0)
+        lig = sc["lig"]
     T = lig["n_tors"]
     begin, end, n = setup_grid_dims(sc["center"], sc["size"])
     types = sorted(set(int(t) for t in lig["smt"] if t > 1))
@@ -77,6 +86,11 @@ def main():
            "poses_merged": int(len(me)), "poses_reported": int(len(keep)),
            "best": {"cnnscore": float(out["pose"][keep[0]]), "cnnaffinity": float(out["affinity"][keep[0]]),
                     "vina_affinity": float(ef[keep[0]]), "intramol": float(intra[keep[0]])}}
+    if args.out and args.ligand:
+        order = list(keep)
+        text = capi.pdbqt_poses_text(args.ligand, co[order], ef[order], out["pose"][order], out["affinity"][order])
+        open(args.out, "w").write(text)
+        res["written"] = {"file": args.out, "poses": len(order)}
     print(json.dumps(res))
 
 
