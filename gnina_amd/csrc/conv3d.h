@@ -34,6 +34,12 @@ struct ConvArgs {
   // scale of the forward layer's input (d(BN x)/dx); accumulate adds into the concat buffer's gradient.
   const float *out_scale;          // [coutp] or nullptr
   int accumulate;
+  // fused 1x1x1 conv after this one (Default2018: conv3 -> ReLU -> conv1 -> ReLU -> pool): the ReLU'd tile goes
+  // through LDS into a second MFMA pass (cout -> cout channels), then the usual epilogue.  fp32 kernel only.
+  const float *post_w;             // packed [pair][2][coutp][4] weights of the 1x1 conv, or nullptr
+  const float *post_bias;          // [coutp]
+  int post_relu;
+  int post_rows;                   // WM * TM * 32: voxel rows of a workgroup (LDS sizing)
   // bf16 kernels (conv3d_bf16.hip) only: element type of the tensors behind in / out / in_act
   // (1 = fp32, 0 = bf16; cc4 / ccs / cin4 then count OCTETS of 8 channels and wp is a packed bf16 array)
   int in_f32, out_f32, act_f32;

@@ -269,6 +269,54 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     if (NP & 1) mfma_pair(a0, w0);
   }
 
+  // ---- fused 1x1x1 conv (conv -> ReLU -> conv1 -> ...): the activated tile is transposed through LDS from the
+  // accumulator layout (lane = channel, registers = voxels) into A-operand layout (lane = voxel, four
+  // consecutive channels), every wave then runs its (M-tile, N-tile) block of the cout x cout GEMM ----
+  const float *bias_ptr = p.bias;
+  int relu_flag = p.relu;
+  if (p.post_w) {
+    __syncthreads();  // the halo tile and its index tables are dead: reuse the LDS
+    const int stride = p.coutp + 4;  // odd multiple of 16 bytes per voxel row (coutp = 32 or 64)
+    float *s_mid = smem;
+#pragma unroll
+    for (int m = 0; m < TM; m++)
+#pragma unroll
+      for (int n = 0; n < TN; n++) {
+        const int ch = n_base + n * 32 + row;
+        const float b1 = p.bias[ch];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * kh;  // accumulator row of register r
+          float v = acc[m][n][r] + b1;
+          if (p.relu) v = fmaxf(v, 0.f);
+          s_mid[((wm * TM + m) * 32 + i) * stride + ch] = v;
+          acc[m][n][r] = 0.f;
+        }
+      }
+    __syncthreads();
+    const int P2 = p.coutp >> 3;  // quad pairs of the 1x1 conv's K = coutp channels
+    const float *w2 = p.post_w + (size_t)(n_base + row) * 4 + (size_t)kh * wstride;
+    for (int pr = 0; pr < P2; pr++) {
+      float4 a2[TM], b2[TN];
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        a2[m] = *reinterpret_cast<const float4 *>(s_mid + ((wm * TM + m) * 32 + row) * stride + (2 * pr + kh) * 4);
+#pragma unroll
+      for (int n = 0; n < TN; n++) b2[n] = *reinterpret_cast<const float4 *>(w2 + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].x, b2[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].y, b2[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].z, b2[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].w, b2[n].w, acc[m][n], 0, 0, 0);
+        }
+    }
+    bias_ptr = p.post_bias;
+    relu_flag = p.post_relu;
+  }
+
   // ---- epilogue: bias, ReLU, optional 2x2x2 pool, store channels-last ----
   const int So = p.pool ? S / 2 : S;
   float *out_b = p.out + (size_t)b * So * So * So * p.out_cs + p.out_c0;
@@ -286,12 +334,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       for (int n = 0; n < TN; n++) {
         const int ch = n_base + n * 32 + row;
         if (ch >= p.cout) continue;
-        const float bias = p.bias[ch];
+        const float bias = bias_ptr[ch];
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           float t = acc[m][n][half * 8 + r] + bias;
-          v[r] = p.relu ? fmaxf(t, 0.f) : t;
+          v[r] = relu_flag ? fmaxf(t, 0.f) : t;
         }
         if (p.pool == 1) {
           float mx = v[0];
@@ -503,7 +551,9 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  return HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4 + HV) * sizeof(int);
+  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4 + HV) * sizeof(int);
+  const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (p.coutp + 4) * sizeof(float) : 0;
+  return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }
 
 template <int WM, int WN, int TM, int TN, bool SPARSE> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {

@@ -55,6 +55,12 @@ static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
   const long blocks = (long)nb * a.ntx * a.nty * a.ntz * groups;
   if (blocks >= 512 || getenv("MI_GNINA_NO_LAT")) return;
   if (a.sparse) return;  // the zero-quad skipping pairs up surviving quads per tile: keep one tiling so results do not depend on the batch size
+  if (a.post_w) {  // the fused 1x1 conv needs every mid channel inside one workgroup
+    int lwm, lwn, ltm, ltn;
+    conv_cfg_shape(cp.lat_cfg, &lwm, &lwn, &ltm, &ltn);
+    if (a.coutp / 32 > lwn * ltn) return;
+    a.post_rows = lwm * ltm * 32;
+  }
   cfg = cp.lat_cfg;
   a.tcx = cp.lat_tc[0], a.tcy = cp.lat_tc[1], a.tcz = cp.lat_tc[2];
   const int cells = a.S / 2;
@@ -74,6 +80,7 @@ struct Step {
   int C = 0;             // channels moved by Pool/GMax
   long w_off = 0, b_off = 0;  // Fc (offsets into dev_data)
   int n_in = 0;
+  int post_cout = 0;      // Conv with a fused 1x1x1 conv behind it: that conv's output channels
   bool src_bf16 = false;  // bf16 program: GMax reads a bf16 tensor
 };
 
@@ -238,6 +245,10 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.argmax_out = nullptr;
   a.out_scale = nullptr;
   a.accumulate = 0;
+  a.post_w = nullptr;
+  a.post_bias = nullptr;
+  a.post_relu = 0;
+  a.post_rows = 0;
   if (o.bn_scale_off >= 0) {
     std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
     std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -478,11 +489,31 @@ static Model *build_model(ModelDesc &&desc) {
         // (gradient program: only max pools are fused -- their arg-max is saved; avg pools keep the
         // pre-pool activation, which the ReLU backward needs)
         int pool_mode = 0, dst = o.dst, dst_c0 = o.dst_c0;
-        if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == o.dst &&
-            o.src != o.dst && o.dst_c0 == 0 && o.cout == d.bufs[o.dst].C && !(grad && d.ops[i + 1].pool_mode == 2)) {
+        // fuse "conv3 -> ReLU -> conv1 (same width) -> ..." (Default2018's unit pairs): the 1x1x1 conv runs as a
+        // second MFMA pass on the LDS-transposed tile inside the first conv's kernel (forward program only --
+        // the gradient program needs the intermediate activation)
+        const Op *post = nullptr;
+        if (!grad && o.ksize == 3 && i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Conv) {
+          const Op &o2 = d.ops[i + 1];
           bool used_elsewhere = false;
           for (size_t j = i + 2; j < d.ops.size(); j++)
-            if (d.ops[j].src == o.dst) used_elsewhere = true;
+            if (d.ops[j].src == o.dst || (d.ops[j].kind == OpKind::Conv && d.ops[j].dst == o.dst)) used_elsewhere = true;
+          if (o2.ksize == 1 && o2.src == o.dst && o2.dst != o.dst && o.src != o.dst && o.dst_c0 == 0 && o2.dst_c0 == 0 &&
+              o.cout == d.bufs[o.dst].C && o2.cin == o.cout && o2.cout == o.cout && o.cout % 32 == 0 && o.cout <= 64 &&
+              o2.bn_scale_off < 0 && !used_elsewhere && !getenv("MI_GNINA_NO_FUSE1X1")) {
+            post = &o2;
+            dst = o2.dst;
+            dst_c0 = 0;
+            i++;  // swallow the 1x1 conv
+          }
+        }
+        const Op &last = post ? *post : o;  // the op whose output a following pool would consume
+        if (i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Pool && d.ops[i + 1].src == last.dst &&
+            last.src != last.dst && last.dst_c0 == 0 && last.cout == d.bufs[last.dst].C &&
+            !(grad && d.ops[i + 1].pool_mode == 2)) {
+          bool used_elsewhere = false;
+          for (size_t j = i + 2; j < d.ops.size(); j++)
+            if (d.ops[j].src == last.dst) used_elsewhere = true;
           if (!used_elsewhere) {
             pool_mode = d.ops[i + 1].pool_mode;
             dst = d.ops[i + 1].dst;
@@ -490,6 +521,18 @@ static Model *build_model(ModelDesc &&desc) {
           }
         }
         plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
+        if (post) {
+          ConvPlan p2;
+          plan_conv(*m, *post, p2, 0, post->dst, 0);  // for its packed weights [pair][2][coutp][4] (K chunks are contiguous)
+          st.conv.a.post_w = p2.a.wp;
+          st.conv.a.post_bias = p2.a.bias;
+          st.conv.a.post_relu = post->relu;
+          st.post_cout = post->cout;
+          int wm_, wn_, tm_, tn_;
+          conv_cfg_shape(st.conv.cfg, &wm_, &wn_, &tm_, &tn_);
+          st.conv.a.post_rows = wm_ * tm_ * 32;
+          MIG_CHECK(conv_lds_bytes(st.conv.a) <= 160 * 1024, 2, "fused conv tile exceeds LDS");
+        }
         st.has_bn = o.bn_scale_off >= 0;
         if (grad && o.cout % 4 == 0) {
           plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
@@ -1081,10 +1124,10 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
           char nm[96];
-          snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s", a.ksize, a.S, st.conv.cin, a.cout,
-                   a.pool ? "_pool" : "");
+          snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s%s", a.ksize, a.S, st.conv.cin, a.cout,
+                   a.post_w ? "+conv1" : "", a.pool ? "_pool" : "");
           if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
-          ProfScope ps(s, nm, 2.0 * nb * S3 * taps * st.conv.cin * a.cout,
+          ProfScope ps(s, nm, 2.0 * nb * S3 * (taps * st.conv.cin * a.cout + (a.post_w ? (double)a.cout * st.post_cout : 0.0)),
                        (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
           if (bf16) {
             launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
