@@ -84,6 +84,9 @@ void launch_gmax_backward(const float *act, const float *g_out, float *g_in, int
                           int S, hipStream_t s);
 void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
                      int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s);
+void launch_overlap_forward(const float *grid, int B, long N3, float *pose, float *aff, float *loss, float *ave_out,
+                            hipStream_t s);
+void launch_overlap_backward(const float *grid, const float *ave, int B, long N3, float *gg, hipStream_t s);
 void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s);
 void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
                        hipStream_t s);

@@ -813,6 +813,52 @@ void launch_fc_heads(const float *in, const float *w, const float *bias, int n_i
                      pose, aff, loss, raw3);
 }
 
+// ---- the Overlap toy model (test/gnina/data/overlap*.pt, the model of the reference's test_min.py) -----------
+// grid [B][2][N3] (reference layout): ave = mean_v rec[v] * lig[v]; module output = [0, ave > 0 ? ave : 1e-20],
+// affinity 0; with skip_softmax + apply_logistic_loss (torch_model.cpp:188-195): pose = ave0, loss = -log(ave0).
+__global__ __launch_bounds__(256) void overlap_forward_kernel(const float *grid, long N3, float *pose, float *aff,
+                                                              float *loss, float *ave_out) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *rec = grid + (size_t)b * 2 * N3, *lig = rec + N3;
+  float s = 0.f;
+  for (long v = tid; v < N3; v += 256) s += rec[v] * lig[v];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ float red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float ave = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N3;
+    const float ave0 = ave > 0.f ? ave : 9.9999999999999995e-21f;
+    pose[b] = ave0;
+    aff[b] = 0.f;
+    loss[b] = -logf(ave0);
+    if (ave_out) ave_out[b] = ave;
+  }
+}
+
+void launch_overlap_forward(const float *grid, int B, long N3, float *pose, float *aff, float *loss, float *ave_out,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(overlap_forward_kernel, dim3(B), dim3(256), 0, s, grid, N3, pose, aff, loss, ave_out);
+}
+
+// d loss / d grid = -(1 / ave) * d ave / d grid for ave > 0 (the where() branch has no gradient otherwise):
+// gg[rec][v] = -(lig[v] / N3) / ave, gg[lig][v] = -(rec[v] / N3) / ave
+__global__ void overlap_backward_kernel(const float *grid, const float *ave, long N3, float *gg, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / (2 * N3), r = i - b * 2 * N3;
+  const long v = r >= N3 ? r - N3 : r;
+  const float other = grid[(size_t)b * 2 * N3 + (r >= N3 ? v : N3 + v)];
+  const float a = ave[b];
+  gg[i] = a > 0.f ? -(other / (float)N3) / a : 0.f;
+}
+
+void launch_overlap_backward(const float *grid, const float *ave, int B, long N3, float *gg, hipStream_t s) {
+  const long total = (long)B * 2 * N3;
+  hipLaunchKernelGGL(overlap_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, grid, ave, N3, gg,
+                     total);
+}
+
 // ---- gradient pass helpers --------------------------------------------------------------------
 // d loss / d (fc input).  loss = cross_entropy(log_softmax(z), 1) (torch_model.cpp:192-195) so
 // dz = softmax(z) - onehot(1) = (exp(lp0), exp(lp1) - 1); the affinity head does not enter the loss.

@@ -100,6 +100,7 @@ struct Model {
   std::string hsteps_error, hgsteps_error;
   bool grad_supported = false;
   std::string grad_unsupported_reason;
+  bool overlap = false;             // the parameter-free Overlap toy (mean of rec * lig density over the full grid)
   DevBuf<float> dev_data;           // fc weights, biases, bn params (canonical payload)
   std::vector<std::unique_ptr<DevBuf<float>>> packed;  // packed conv weights / padded bias / bn
   float qa, qb, qc;                 // quadratic tail coefficients
@@ -474,6 +475,15 @@ static Model *build_model(ModelDesc &&desc) {
     for (int t = 0; t < kNumSminaTypes; t++) m->dens[t] = density_consts(smina_xs_radius(t), d.radius_scaling);
   }
   m->buf_cp.assign(d.bufs.size(), 0);
+  if (d.ops[0].kind == OpKind::Overlap) {
+    // no layer program: the full-resolution two-channel grid [B][2][N^3] (reference layout) is the input
+    m->overlap = true;
+    m->input_pool = 0;
+    m->input_dst = 0;
+    m->buf_cp[0] = 2;
+    m->grad_supported = true;
+    return m.release();
+  }
   // op 0 = pool of the voxel grid -> fused into the voxelizer
   m->input_pool = d.ops[0].pool_mode;
   m->input_dst = d.ops[0].dst;
@@ -648,7 +658,7 @@ struct Scorer {
   std::vector<std::unique_ptr<DevBuf<float>>> act;
   std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
   std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
-  DevBuf<float> d_raw3, d_lig_grad;
+  DevBuf<float> d_raw3, d_lig_grad, d_ave;
   int lig_cache_group = -1, lig_cache_n = 0;  // setup_ligand cache: group / ligand types the device arrays describe
   std::vector<int32_t> lig_cache_smt;
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
@@ -1096,6 +1106,15 @@ static bool use_bf16(Scorer &s, Model &m, bool grad) {
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
                         size_t pooled_slot = 0) {
   Model *m = s.models[mi];
+  if (m->overlap) {
+    const long N3 = (long)m->N * m->N * m->N;
+    const float *grid = act_buf(s, pooled_slot, (size_t)s.cap * 2 * N3);
+    s.d_ave.ensure(s.cap);
+    ProfScope ps(s, "overlap_forward", 2.0 * nb * N3, (double)nb * 2 * N3 * 4.0, nb);
+    launch_overlap_forward(grid, nb, N3, pose, aff, loss, s.d_ave.p, s.stream);
+    MIG_HIP(hipGetLastError());
+    return;
+  }
   const bool bf16 = use_bf16(s, *m, grad);
   const std::vector<Step> &steps = bf16 ? (grad ? m->hgsteps : m->hsteps) : (grad ? m->gsteps : m->steps);
   auto arg_ptr = [&](int id) -> unsigned char * {
@@ -1158,6 +1177,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                         grad ? (s.d_raw3.ensure((size_t)3 * s.cap), s.d_raw3.p) : nullptr, nb, s.stream);
         break;
       }
+      case OpKind::Overlap:  // handled above: the Overlap model has no layer program
+        break;
     }
   }
   MIG_HIP(hipGetLastError());
@@ -1168,6 +1189,15 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
 // staging) -> avg un-pool.  Returns the device pointer of dL/d(pooled grid).
 static float *run_backward(Scorer &s, int mi, int nb) {
   Model *m = s.models[mi];
+  if (m->overlap) {  // d loss / d (full grid) from the grid itself and the mean run_program left in d_ave
+    const long N3 = (long)m->N * m->N * m->N;
+    const float *grid = act_buf(s, kPooledSlot, (size_t)s.cap * 2 * N3);
+    float *gg = gact_buf(s, kPooledSlot, (size_t)s.cap * 2 * N3);
+    ProfScope ps(s, "overlap_backward", 0.0, 0.0, nb);
+    launch_overlap_backward(grid, s.d_ave.p, nb, N3, gg, s.stream);
+    MIG_HIP(hipGetLastError());
+    return gg;
+  }
   const bool bf16 = use_bf16(s, *m, true);
   const std::vector<Step> &gsteps = bf16 ? m->hgsteps : m->gsteps;
   auto slot_of = [&](int id) { return id == m->input_dst ? kPooledSlot : (size_t)id; };
@@ -1294,6 +1324,8 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
       const int nb = std::min(s.cap, B - b0);
       float *pooled = act_buf(s, kPooledSlot, pooled_n);
       unsigned char *am0 = m0->input_pool == 1 ? argm_buf(s, kPooledSlot, pooled_n) : nullptr;
+      if (m0->input_pool == 0)  // full-resolution grid (Overlap model): the tile kernel only writes touched voxels
+        MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
       voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, am0);
       for (int mi : g.models) {
         Model *m = s.models[mi];
@@ -1311,7 +1343,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
         vb.grad_pooled = g0;
         vb.argmax = am0;
         vb.N = m->N;
-        vb.Cp = m->Cp;
+        vb.Cp = m->overlap ? m->C : m->Cp;
         vb.res = m->d.resolution;
         vb.half_dim = m->d.dimension / 2.0f;
         vb.qa = m->qa;
@@ -1411,6 +1443,8 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
         MIG_HIP(hipEventRecord(s.ev_vox_done[set], s.vox_stream));
         MIG_HIP(hipStreamWaitEvent(s.stream, s.ev_vox_done[set], 0));
       } else {
+        if (m0->input_pool == 0)
+          MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
         voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled);
       }
       for (int mi : g.models)
@@ -1757,7 +1791,10 @@ mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int 
     MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
                            hipMemcpyHostToDevice, s.stream));
     float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * m->buf_cp[m->input_dst]);
-    launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
+    if (m->overlap)  // the full grid is the network input
+      MIG_HIP(hipMemcpyAsync(pooled, d_grid.p, (size_t)nb * per_pose * sizeof(float), hipMemcpyDeviceToDevice, s.stream));
+    else
+      launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
     run_program(s, mi, nb, d_out.p + b0, d_out.p + B + b0, d_out.p + 2 * (size_t)B + b0);
   }
   MIG_HIP(hipMemcpyAsync(pose, d_out.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));

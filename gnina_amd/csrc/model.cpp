@@ -86,6 +86,11 @@ ModelDesc parse_blob(const void *blob, size_t nbytes, const char *name_override)
         o.src = std::stoi(t.at(1));
         o.dst = std::stoi(t.at(2));
         m.ops.push_back(o);
+      } else if (k == "overlap") {  // test/gnina/data/overlap*.pt: mean over the grid of rec * lig density
+        Op o;
+        o.kind = OpKind::Overlap;
+        o.src = o.dst = std::stoi(t.at(1));
+        m.ops.push_back(o);
       } else if (k == "fc") {
         Op o;
         o.kind = OpKind::Fc;
@@ -137,6 +142,10 @@ ModelDesc parse_blob(const void *blob, size_t nbytes, const char *name_override)
       MIG_CHECK(o.w_off >= 0 && o.w_off + 3L * o.n_in <= ndata && o.b_off >= 0 && o.b_off + 3 <= ndata, 2,
                 "fc weights out of range");
     }
+  }
+  if (m.ops.size() == 1 && m.ops[0].kind == OpKind::Overlap) {
+    MIG_CHECK(m.ops[0].src == 0 && m.bufs[0].C == 2, 2, "the overlap model takes the two-channel voxel grid");
+    return m;
   }
   MIG_CHECK(m.ops.back().kind == OpKind::Fc, 2, "program must end with the fc heads");
   MIG_CHECK(m.ops.front().kind == OpKind::Pool && m.ops.front().src == 0, 2,

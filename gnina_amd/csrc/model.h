@@ -13,7 +13,7 @@
 
 namespace mig {
 
-enum class OpKind { Pool, Conv, GMax, Fc };
+enum class OpKind { Pool, Conv, GMax, Fc, Overlap };
 
 struct BufDecl {
   int S = 0;  // spatial points per side

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
 //   dL/dx_a = sum_v g[c][v] * rho'(d) * (x_a - p_v) / d
 //   rho'(d) = -4 d / r^2 exp(-2 d^2 / r^2)  (d <= r);  (2 A d/r + B) / r  (r < d < 1.5 r);  0 otherwise
 // ---------------------------------------------------------------------------------------------
-template <int POOL>  // 1 max, 2 avg
+template <int POOL>  // 1 max, 2 avg; 0 = no pooling: grad_pooled is a full-resolution gradient [B][C][N][N][N] (Cp = C)
 __global__ __launch_bounds__(64) void voxel_backward_kernel(VoxBackArgs a) {
   const int b = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
   const int src = a.lig_perm[j];
@@ -368,18 +368,21 @@ __global__ __launch_bounds__(64) void voxel_backward_kernel(VoxBackArgs a) {
   if (i1 >= i0 && j1 >= j0 && k1 >= k0) {
     const int ni = i1 - i0 + 1, nj = j1 - j0 + 1, nk = k1 - k0 + 1;
     const int total = ni * nj * nk;
-    const float *G = a.grad_pooled + (size_t)b * S * S * S * Cp;
+    const float *G = POOL == 0 ? a.grad_pooled + ((size_t)b * Cp + c) * N * N * N : a.grad_pooled + (size_t)b * S * S * S * Cp;
     const unsigned char *AM = POOL == 1 ? a.argmax + (size_t)b * S * S * S * Cp : nullptr;
     const float inv_ar2 = 1.0f / (lc.ar * lc.ar);
     for (int t = lane; t < total; t += 64) {
       const int k = k0 + t % nk, jj = j0 + (t / nk) % nj, i = i0 + t / (nk * nj);
       const size_t cell = (((size_t)(i >> 1) * S + (jj >> 1)) * S + (k >> 1)) * Cp + c;
-      float g = G[cell];
-      if (POOL == 1) {
+      float g;
+      if (POOL == 0) {
+        g = G[((size_t)i * N + jj) * N + k];
+      } else if (POOL == 1) {
+        g = G[cell];
         const int r = ((i & 1) << 2) | ((jj & 1) << 1) | (k & 1);
         if (AM[cell] != r) g = 0.f;
       } else {
-        g *= 0.125f;
+        g = G[cell] * 0.125f;
       }
       if (g == 0.f) continue;
       const float px = ox + (float)i * a.res, py = oy + (float)jj * a.res, pz = oz + (float)k * a.res;
@@ -423,8 +426,10 @@ void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream
   dim3 grid(a.n_lig, B), block(64);
   if (pool_mode == 1)
     hipLaunchKernelGGL(voxel_backward_kernel<1>, grid, block, 0, s, a);
-  else
+  else if (pool_mode == 2)
     hipLaunchKernelGGL(voxel_backward_kernel<2>, grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL(voxel_backward_kernel<0>, grid, block, 0, s, a);
 }
 
 void launch_gather(const GatherArgs &g, int B, hipStream_t s) {

@@ -215,13 +215,18 @@ def convert(pt_path, name=None):
         pose = [k for k in keys if k.endswith("pose_output.weight")][0][:-7]
         aff = [k for k in keys if k.endswith("affinity_output.weight")][0][:-7]
         blob.fc(sd, pose, aff, g, 1, cin)
+    elif family == "Overlap" and not keys:  # test toy: mean(rec * lig) over the grid, no parameters
+        assert C0 == 2
+        b_in = blob.buf(N, C0)
+        L.append(f"overlap {b_in}")
     else:
         raise ValueError(f"unsupported model family {family} in {pt_path}")
     L.append(f"ndata {blob.n}")
     header = ("\n".join(L) + "\n").encode()
     pre = MAGIC + struct.pack("<I", len(header)) + header
     pre += b"\0" * ((-len(pre)) % 64)
-    return pre + np.concatenate(blob.data).astype("<f4").tobytes(), name
+    payload = np.concatenate(blob.data).astype("<f4").tobytes() if blob.data else b""
+    return pre + payload, name
 
 
 def main(argv):

@@ -42,7 +42,7 @@ class Blob:
                 self.ligmap.append(t[1:])
             elif k == "buf":
                 self.bufs[int(t[1])] = (int(t[2]), int(t[3]))
-            elif k in ("pool", "conv", "gmax", "fc"):
+            elif k in ("pool", "conv", "gmax", "fc", "overlap"):
                 self.ops.append(t)
             else:
                 self.meta[k] = t[1] if len(t) > 1 else ""
@@ -53,6 +53,7 @@ class Blob:
         self.skip_softmax = bool(int(self.meta["skip_softmax"]))
         self.apply_logistic_loss = bool(int(self.meta["apply_logistic_loss"]))
         self.n_rec_ch, self.n_lig_ch = len(self.recmap), len(self.ligmap)
+        self.family = self.meta.get("family", "")
 
     def recmap_text(self):
         return "\n".join(" ".join(l) for l in self.recmap) + "\n"
@@ -95,6 +96,13 @@ def forward_logits(blob, grid, dtype=torch.float32):
             else:
                 assert c0 == 0
                 bufs[dst] = y
+        elif t[0] == "overlap":  # test/gnina/data/overlap*.pt (toy model of test_min.py): returns the module's
+            # output itself, not logits -- hstack([0, where(mean(rec * lig) > 0, mean, 1e-20)]) and a zero affinity
+            src = int(t[1])
+            g = bufs[src]
+            ave = F.avg_pool3d(g[:, 0:1] * g[:, 1:2], g.shape[-1]).flatten(1)
+            ave0 = torch.where(ave > 0, ave, torch.full_like(ave, 9.9999999999999995e-21))
+            return torch.cat([torch.zeros_like(ave0), ave0], 1), torch.zeros(g.shape[0], dtype=dtype)
         elif t[0] == "gmax":
             src, dst = int(t[1]), int(t[2])
             bufs[dst] = torch.amax(bufs[src], dim=(2, 3, 4), keepdim=True)
@@ -110,10 +118,18 @@ def forward_logits(blob, grid, dtype=torch.float32):
     return out[:, :2], out[:, 2]
 
 
+def module_output(blob, grid, dtype=torch.float32):
+    """What the TorchScript module returns: (log_softmax(pose logits), affinity) for the CNN families; the
+    Overlap toy returns its [0, ave] tensor as is."""
+    out, aff = forward_logits(blob, grid, dtype)
+    if blob.family == "Overlap":
+        return out, aff
+    return torch.log_softmax(out, 1), aff
+
+
 def scores(blob, grid, dtype=torch.float32):
     """(pose, affinity, loss) per pose exactly as TorchModel::forward reports them."""
-    logits, aff = forward_logits(blob, grid, dtype)
-    logp = torch.log_softmax(logits, 1)
+    logp, aff = module_output(blob, grid, dtype)
     if blob.skip_softmax:
         pose = logp[:, 1]
     else:
@@ -129,8 +145,10 @@ def loss_and_grid_gradient(blob, grid, dtype=torch.float32):
     """What TorchModel::forward does with compute_gradient (torch_model.cpp:192-199): loss =
     cross_entropy(log_softmax(z), 1); loss.backward(); returns (loss [B], d loss / d grid [B,C,N,N,N])."""
     x = torch.as_tensor(grid).to(dtype).clone().requires_grad_(True)
-    logits, _ = forward_logits(blob, x, dtype)
-    logp = torch.log_softmax(logits, 1)
-    loss = F.cross_entropy(logp, torch.ones(logp.shape[0], dtype=torch.long), reduction="none")
+    logp, _ = module_output(blob, x, dtype)
+    if blob.apply_logistic_loss:
+        loss = -torch.log(logp[:, 1])
+    else:
+        loss = F.cross_entropy(logp, torch.ones(logp.shape[0], dtype=torch.long), reduction="none")
     loss.sum().backward()
     return loss.detach(), x.grad.detach()

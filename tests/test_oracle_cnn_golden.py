@@ -80,3 +80,26 @@ def test_oracle_vs_reference_torchscript_live():
             lg, a2 = cnn_ref.forward_logits(blob, x)
         assert (torch.log_softmax(lg, 1) - logp).abs().max() < 2e-4 * max(1.0, logp.abs().max().item())
         assert (aff - a2).abs().max() < 1e-4 * max(1.0, aff.abs().max().item())
+
+
+def test_overlap_toy_models_match_reference_goldens(golden_dir):
+    """test/gnina/data/overlap*.pt (skip_softmax + apply_logistic_loss): oracle vs the reference modules' outputs."""
+    import os
+    import numpy as np
+    from oracle import cnn_ref, voxel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    OG = np.load(os.path.join(golden_dir, "overlap_goldens.npz"))
+    for name in ("overlap", "overlap_smallr"):
+        blob = cnn_ref.Blob(os.path.join(root, "gnina_amd", "weights", name + ".mgw"))
+        assert blob.skip_softmax and blob.apply_logistic_loss and blob.family == "Overlap"
+        rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
+        assert rmap[1] == 1 and lmap[1] == 1            # every heavy type on one line -> one channel each
+        for case in ("C_C1", "CC_CC2", "rand8", "far"):
+            k = f"{name}/{case}/"
+            rec, lig = OG[k + "rec"], OG[k + "lig"]
+            t = np.full(len(rec), 2, np.int32), np.full(len(lig), 2, np.int32)
+            grid, _ = voxel.voxelize_pose(rec, t[0], lig, t[1], rmap, lmap, None, blob.resolution, blob.dimension,
+                                          blob.radius_scaling)
+            p, a, l = cnn_ref.scores(blob, grid[None])
+            assert abs(float(p[0]) - OG[k + "pose"]) <= 1e-5 * OG[k + "pose"] + 1e-30
+            assert abs(float(l[0]) - OG[k + "loss"]) < 1e-4 and float(a[0]) == 0.0
