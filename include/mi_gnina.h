@@ -123,8 +123,8 @@ mi_status mi_scorer_score_ragged(mi_scorer *, const float *lig_xyz, const int32_
  * through the network and GridMaker::backward (torch_model.cpp:197-221; cnn_torch_scorer.cpp:164-175).
  * lig_grad [B][L][3] = d loss / d x for every ligand row (0 for untyped rows such as hydrogens), mean
  * over the ensemble -- what getGradient + add_minus_forces + scale_minus_forces(1/cnt) leave in
- * model::minus_forces.  Host pointers.  Supported for the Default2017 / Default2018 / Dense families
- * (mi_model_supports_gradient); skip_softmax / apply_logistic_loss test models return MI_ERR_INVALID. */
+ * model::minus_forces.  Host pointers.  Supported for the Default2017 / Default2018 / Dense families and the
+ * Overlap test model (mi_model_supports_gradient). */
 mi_status mi_scorer_score_grad(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
                                float *lig_grad);
