@@ -96,3 +96,71 @@ def test_min_overlap_converges_onto_the_receptor(capi, rec, lig):
     final = v.coords_batch(out)[0]
     assert e[0] < e0[0] - 0.3 and tries[0] == 1
     assert are_similar(rec, final), (final, e, evals)
+
+
+C8FLAT = [[-4.41300, -0.17760, 0.43050], [-3.15750, -0.17690, -0.43680], [-1.89220, -0.05930, 0.42040],
+          [-0.63310, -0.05880, -0.45450], [0.63310, 0.05880, 0.40230], [1.89220, 0.05930, -0.47270],
+          [3.15750, 0.17690, 0.38460], [4.41300, 0.17760, -0.48280]]                 # test/gnina/data/C8flat.xyz
+C8BENT = [[-3.5067, 1.1289, -0.0582], [-2.5909, -0.0810, -0.2192], [-1.3522, 0.0393, 0.6810], [-0.4171, -1.1759, 0.5481],
+          [0.4521, -1.1392, -0.7293], [1.9062, -0.7109, -0.4693], [2.0237, 0.7561, -0.0346], [3.4849, 1.1827, 0.0726]]  # C8bent.sdf
+
+
+def test_min_fully_flexible_octane(capi):
+    """test_min.py:87-104: `-r C8flat.xyz -l C8bent.sdf --cnn_scoring all --cnn_model overlap_smallr.pt --minimize`:
+    the bent octane must unfold onto the flat one.  The torsion tree (5 rotatable C-C bonds, root = C4) is written
+    as PDBQT and read back by the native reader, so reader, tree kernels and CNN refinement are exercised together."""
+    from tests.test_pdbqt_cpu import atom_line
+    a = [atom_line(i + 1, f"C{i + 1}", *C8BENT[i], "C") for i in range(8)]
+    text = "\n".join(["ROOT", a[3], "ENDROOT",
+                      "BRANCH   4   5", a[4], "BRANCH   5   6", a[5], "BRANCH   6   7", a[6], a[7],
+                      "ENDBRANCH   6   7", "ENDBRANCH   5   6", "ENDBRANCH   4   5",
+                      "BRANCH   4   3", a[2], "BRANCH   3   2", a[1], a[0], "ENDBRANCH   3   2", "ENDBRANCH   4   3",
+                      "TORSDOF 5", ""])
+    lig = capi.read_pdbqt_ligand(text, is_text=True)
+    assert lig["n_tors"] == 5 and (lig["smt"] == 2).all()
+    rec = np.asarray(C8FLAT, np.float32)
+    s = capi.Scorer(["overlap_smallr"])
+    s.set_receptor(rec, np.full(8, C, np.int32))
+    v = capi.Vina()
+    v.set_ligand(lig)
+    box = capi.CnnBox.make(23.5)
+    start = lig["conf0"][None]
+    assert not are_similar(rec, v.coords_batch(start)[0])
+    e0, _ = v.cnn_eval_batch(s, start, box, None, deriv=False)
+    e, out, tries, evals = v.cnn_refine_batch(s, start, box, max_iters=10000)
+    final = v.coords_batch(out)[0]
+    assert e[0] < e0[0] and are_similar(rec, final), (e0, e, evals, final)
+
+
+@pytest.mark.parametrize("weight", [1.0, 0.7])
+def test_min_cnn_plus_empirical_energy_identity(capi, weight):
+    """test_min.py:112-140: with --cnn_mix_emp_force --cnn_mix_emp_energy --cnn_empirical_weight w the minimised
+    octane does NOT land on the receptor (the empirical term repels), and the reported total energy obeys
+    total = (-log(CNNscore) + w * empirical) / (1 + w)   (validate_energies, tolerance 1e-3)."""
+    from tests.test_pdbqt_cpu import atom_line
+    a = [atom_line(i + 1, f"C{i + 1}", *C8BENT[i], "C") for i in range(8)]
+    text = "\n".join(["ROOT", a[3], "ENDROOT", "BRANCH   4   5", a[4], "BRANCH   5   6", a[5], "BRANCH   6   7", a[6], a[7],
+                      "ENDBRANCH   6   7", "ENDBRANCH   5   6", "ENDBRANCH   4   5", "BRANCH   4   3", a[2],
+                      "BRANCH   3   2", a[1], a[0], "ENDBRANCH   3   2", "ENDBRANCH   4   3", "TORSDOF 5", ""])
+    lig = capi.read_pdbqt_ligand(text, is_text=True)
+    rec = np.asarray(C8FLAT, np.float32)
+    rs = np.full(8, C, np.int32)
+    s = capi.Scorer(["overlap_smallr"])
+    s.set_receptor(rec, rs)
+    v = capi.Vina()
+    v.set_receptor(rec, rs)
+    lo, hi = rec.min(0) - 30.0, rec.max(0) + 30.0   # wide enough to hold wherever the repulsion sends the ligand
+    n = np.ceil((hi - lo) / 0.375).astype(np.int32)
+    v.build_cache(lo, lo + 0.375 * n, n, [C], 1e3)       # only so that the direct (non_cache) evaluation has a box
+    v.set_ligand(lig)
+    box = capi.CnnBox.make(23.5, mix_emp_force=True, mix_emp_energy=True, empirical_weight=weight, v=1000.0)
+    start = lig["conf0"][None]
+    e, out, tries, evals = v.cnn_refine_batch(s, start, box, max_iters=10000)
+    final = v.coords_batch(out)[0]
+    assert not are_similar(rec, final)
+    total, _ = v.cnn_eval_batch(s, out, box, None, deriv=True)           # "Total energy after refinement"
+    score = s.score_batch(final[None], lig["smt"])                       # CNNscore of the output pose
+    emp, _, _ = v.eval_batch(out, (1000.0, 1000.0, 1000.0), deriv=False, grid_only=True, direct=True)  # nc_new.eval
+    calc = (-np.log(score["pose"][0]) + weight * emp[0]) / (1 + weight)
+    assert abs(total[0] - calc) < 1e-3, (total, calc, emp, score["pose"])
+    assert abs(e[0] - total[0]) < 1e-4 * max(1.0, abs(total[0]))
