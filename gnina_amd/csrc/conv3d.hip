@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   // consecutive channels), every wave then runs its (M-tile, N-tile) block of the cout x cout GEMM ----
   const float *bias_ptr = p.bias;
   int relu_flag = p.relu;
-  if (p.post_w) {
+  constexpr bool kPostCapable = TM <= 3 && TN == 1;  // (compiled out of the register-heavy shapes; engine.cpp checks)
+  if (kPostCapable && p.post_w) {
     __syncthreads();  // the halo tile and its index tables are dead: reuse the LDS
     const int stride = p.coutp + 4;  // odd multiple of 16 bytes per voxel row (coutp = 32 or 64)
     float *s_mid = smem;

@@ -532,6 +532,11 @@ static Model *build_model(ModelDesc &&desc) {
         }
         plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
         if (post) {
+          {
+            int wm_, wn_, tm_, tn_;
+            conv_cfg_shape(st.conv.cfg, &wm_, &wn_, &tm_, &tn_);
+            MIG_CHECK(tm_ <= 3 && tn_ == 1, 2, "fused 1x1 conv planned on a kernel shape that does not carry it");
+          }
           ConvPlan p2;
           plan_conv(*m, *post, p2, 0, post->dst, 0);  // for its packed weights [pair][2][coutp][4] (K chunks are contiguous)
           st.conv.a.post_w = p2.a.wp;
