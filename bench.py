@@ -116,6 +116,44 @@ def pmc_traffic(kernel_label):
         return None
 
 
+def other_models(args, capi, synth, torch, dev):
+    """The same C2 workload through the other shipped single models, outside the headline's timed region
+    (BASELINE.json quotes "48^3 x 28ch": crossdock_default2018 is the shipped 28-channel network; default2017
+    as shipped has 35 channels).  Same step/fence structure, same batch, a handful of steps each."""
+    out = {}
+    for name in ("crossdock_default2018", "dense"):
+        if name == args.model:
+            continue
+        try:
+            m = capi.Model(name)
+            sc = capi.Scorer([m])
+            rng = np.random.RandomState(0)
+            rx, rs = synth.make_receptor(rng, args.n_rec, synth.mapped_types(m.chan_of_smt(False)))
+            lx, ls = synth.make_ligand(rng, args.n_lig, synth.mapped_types(m.chan_of_smt(True)))
+            poses = synth.make_poses(np.random.RandomState(1000), lx, args.batch)
+            sc.set_receptor(rx, rs)
+            d_lig = torch.from_numpy(poses).to(dev)
+            d_o = torch.empty(4, args.batch, dtype=torch.float32, device=dev)
+            def step():
+                sc.score_batch_device(d_lig.data_ptr(), ls, args.batch, args.n_lig, d_o[0].data_ptr(),
+                                      d_o[1].data_ptr(), d_o[2].data_ptr(), d_o[3].data_ptr())
+            for _ in range(2):
+                step()
+            sc.synchronize()
+            k = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sc.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"poses_per_s": round(args.batch * k / dt, 1), "channels": m.n_channels,
+                         "grid": m.grid_points, "steps": k, "dtype": "f32"}
+            del sc, m
+        except Exception as e:  # the headline line must still print
+            out[name] = {"error": str(e)}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -248,6 +286,8 @@ def main():
             "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
             "dominant_kernel_overall": dom["kernel"],
         }
+        if world == 1:
+            res["also"] = other_models(args, capi, synth, torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(args, os.path.join(ROOT, "gnina_amd", "weights", args.model + ".mgw"),
                                           rec_xyz, rec_smt, lig_smt, poses, args.cpu_seconds)

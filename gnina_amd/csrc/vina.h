@@ -51,8 +51,11 @@ struct VinaLigand {
   const int *child_start;    // [n_nodes+1] CSR of children in increasing index order
   const int *child_list;
   const int2 *pairs;         // [n_pairs] (a, b), a < b
-  const int *atom_pair_start;  // [n_atoms+1] CSR: for every atom the pairs touching it, in pair order
-  const int *atom_pair_list;   // entry = pair index * 2 + (1 if the atom is `b`, else 0)
+  // per-atom lists of pair-force contributions: atom i owns slots [slot_start[i], slot_start[i+1]) (both
+  // multiples of 4; the tail of a list is zero padding), its pairs in pair order; pair p writes -f to
+  // pair_slots[p].x (atom a's list) and +f to pair_slots[p].y (atom b's list)
+  const int *slot_start;       // [n_atoms+1]
+  const int2 *pair_slots;      // [n_pairs]
   int n_heavy;
   const int *heavy_list;       // [n_heavy] indices of the non-hydrogen atoms
 };
@@ -66,6 +69,7 @@ struct VinaMcArgs {
   float *scratch_e, *scratch_conf, *scratch_coords;  // per-chain physical container
   float *out_e, *out_conf, *out_coords;              // sorted output [B][num_saved]...
   int *out_n, *evals;
+  long long *prof;  // optional [B][8] phase timing, see vina_mc_kernel
 };
 
 struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN loss + per-atom gradient)

@@ -246,7 +246,8 @@ struct WaveWork {
   float *cs;                     // [2 n_nodes] cos / sin of every half torsion angle
   float *coords, *forces;        // [3 n_atoms]
   float *node_ft;                // [6 n_nodes]
-  float4 *pair_out;              // [n_pairs]
+  float4 *contrib;               // [n_slots] per-atom lists of pair-force contributions (see eval_conf stage 4/5)
+  float4 *ft;                    // [2 n_atoms] per-atom force and torque about its node origin (fold_forces)
 };
 
 __device__ __forceinline__ float *carve(float *&p, int n) {
@@ -257,7 +258,8 @@ __device__ __forceinline__ float *carve(float *&p, int n) {
 
 __device__ WaveWork carve_work(float *&p, const VinaLigand &L) {
   WaveWork w;
-  w.pair_out = reinterpret_cast<float4 *>(carve(p, 4 * L.n_pairs));
+  w.contrib = reinterpret_cast<float4 *>(carve(p, 4 * (2 * L.n_pairs + 3 * L.n_atoms)));
+  w.ft = reinterpret_cast<float4 *>(carve(p, 8 * L.n_atoms));
   w.origin = carve(p, 3 * L.n_nodes);
   w.axis = carve(p, 3 * L.n_nodes);
   w.M = carve(p, 9 * L.n_nodes);
@@ -266,6 +268,8 @@ __device__ WaveWork carve_work(float *&p, const VinaLigand &L) {
   w.coords = carve(p, 3 * L.n_atoms);
   w.forces = carve(p, 3 * L.n_atoms);
   w.node_ft = carve(p, 6 * L.n_nodes);
+  for (int i = threadIdx.x; i < 2 * L.n_pairs + 3 * L.n_atoms; i += 64) w.contrib[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
   return w;
 }
 
@@ -293,8 +297,8 @@ __device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
   L.child_start = cp_i(G.child_start, G.n_nodes + 1);
   L.child_list = cp_i(G.child_list, G.n_nodes);  // a tree has n_nodes - 1 edges
   L.pairs = reinterpret_cast<const int2 *>(cp_i(reinterpret_cast<const int *>(G.pairs), 2 * G.n_pairs));
-  L.atom_pair_start = cp_i(G.atom_pair_start, G.n_atoms + 1);
-  L.atom_pair_list = cp_i(G.atom_pair_list, 2 * G.n_pairs);
+  L.slot_start = cp_i(G.slot_start, G.n_atoms + 1);
+  L.pair_slots = reinterpret_cast<const int2 *>(cp_i(reinterpret_cast<const int *>(G.pair_slots), 2 * G.n_pairs));
   L.heavy_list = cp_i(G.heavy_list, G.n_heavy);
   L.local_xyz = cp_f(G.local_xyz, 3 * G.n_atoms);
   L.rel_origin = cp_f(G.rel_origin, 3 * G.n_nodes);
@@ -315,13 +319,13 @@ static size_t ligand_lds_floats(int na, int nn, int np, int nh) {
 }
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage) {
-  size_t f = pad4(4 * (size_t)n_pairs) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
+  size_t f = pad4(4 * (2 * (size_t)n_pairs + 3 * (size_t)n_atoms)) + pad4(8 * (size_t)n_atoms) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
              pad4(4 * (size_t)n_nodes) + pad4(2 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms) +
              pad4(6 * (size_t)n_nodes);
   const size_t nt = n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   f += pad4(nc);  // conf being evaluated
   f += pad4(n);   // change
-  if (bfgs) f += 2 * pad4(nc) + 6 * pad4(n) + pad4(n * (n + 1) / 2);
+  if (bfgs) f += pad4(nc) + pad4(n) + pad4(n * (n + 1) / 2);
   if (stage) f += ligand_lds_floats(n_atoms, n_nodes, n_pairs, n_atoms);  // LDS copy of the ligand description
   return f * sizeof(float);
 }
@@ -340,22 +344,41 @@ __device__ __forceinline__ float rl(float v, int lane) {
 
 __device__ void fold_forces(const VinaLigand &L, const WaveWork &w, float *change) {
   const int lane = threadIdx.x;
-  // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140): lane k owns
-  // node k and keeps the six sums and the node origin in registers
+  // 6. per-node force / torque about the node origin, atoms in index order (tree.h:133-140).  The cross
+  // products are formed one atom per lane first; lane k then owns node k and only adds, four atoms per LDS
+  // latency, keeping the six sums and the node origin in registers.
+  for (int i = lane; i < L.n_atoms; i += 64) {
+    const int k = L.node_of_atom[i];
+    const float rx = w.coords[3 * i] - w.origin[3 * k], ry = w.coords[3 * i + 1] - w.origin[3 * k + 1],
+                rz = w.coords[3 * i + 2] - w.origin[3 * k + 2];
+    const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
+    w.ft[2 * i] = make_float4(gx, gy, gz, 0.f);
+    w.ft[2 * i + 1] = make_float4(ry * gz - rz * gy, rz * gx - rx * gz, rx * gy - ry * gx, 0.f);
+  }
+  __syncthreads();
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
   int cs = 0, ce = 0, cl = 0;
   if (lane < L.n_nodes) {
     const int k = lane;
     ox = w.origin[3 * k], oy = w.origin[3 * k + 1], oz = w.origin[3 * k + 2];
-    for (int i = L.abeg[k]; i < L.aend[k]; i++) {
-      const float rx = w.coords[3 * i] - ox, ry = w.coords[3 * i + 1] - oy, rz = w.coords[3 * i + 2] - oz;
-      const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
-      f0 += gx;
-      f1 += gy;
-      f2 += gz;
-      t0 += ry * gz - rz * gy;
-      t1 += rz * gx - rx * gz;
-      t2 += rx * gy - ry * gx;
+    const int a_end = L.aend[k];
+    for (int i0 = L.abeg[k]; i0 < a_end; i0 += 4) {
+      float4 g[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u < a_end ? i0 + u : i0;
+        g[u] = w.ft[2 * i], t[u] = w.ft[2 * i + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool on = i0 + u < a_end;
+        f0 += on ? g[u].x : 0.f;
+        f1 += on ? g[u].y : 0.f;
+        f2 += on ? g[u].z : 0.f;
+        t0 += on ? t[u].x : 0.f;
+        t1 += on ? t[u].y : 0.f;
+        t2 += on ? t[u].z : 0.f;
+      }
     }
     cs = L.child_start[k];
     ce = L.child_start[k + 1];
@@ -402,15 +425,22 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
   // stages), read back only at branch points.
   // (the trigonometry of all torsions is evaluated once, one node per lane: a single wave issues about
   // one instruction every four cycles, so the serial tree walk below is kept as short as possible)
-  for (int k = 1 + lane; k < L.n_nodes; k += 64) {
-    const float angle = norm_angle(conf[7 + (k - 1)]);  // angle_to_quaternion, quaternion.h:284-291
-    float sn, cn;
-    sincosf(angle / 2, &sn, &cn);
-    w.cs[2 * k] = cn;
-    w.cs[2 * k + 1] = sn;
+  // Lane k keeps node k's constant description (relative origin / axis, parent) and the cos / sin of its half
+  // torsion angle in registers; the serial walk below reads them with v_readlane, so the dependent chain has no
+  // LDS round trip except at branch points.  Every lane runs the (wave-uniform) walk; lane 0 stores the frames.
+  float ro0 = 0.f, ro1 = 0.f, ro2 = 0.f, ra0 = 0.f, ra1 = 0.f, ra2 = 0.f, cn_r = 1.f, sn_r = 0.f;
+  int par_r = -1;
+  if (lane < L.n_nodes) {
+    const int k = lane;
+    ro0 = L.rel_origin[3 * k], ro1 = L.rel_origin[3 * k + 1], ro2 = L.rel_origin[3 * k + 2];
+    ra0 = L.rel_axis[3 * k], ra1 = L.rel_axis[3 * k + 1], ra2 = L.rel_axis[3 * k + 2];
+    par_r = L.parent[k];
+    if (k > 0) {
+      const float angle = norm_angle(conf[7 + (k - 1)]);  // angle_to_quaternion, quaternion.h:284-291
+      sincosf(angle / 2, &sn_r, &cn_r);
+    }
   }
-  __syncthreads();
-  if (lane == 0) {
+  {
     float q[4], M[9], o[3];
     int prev = -1;
     for (int k = 0; k < L.n_nodes; k++) {
@@ -419,8 +449,8 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
         o[0] = conf[0], o[1] = conf[1], o[2] = conf[2];
         q[0] = conf[3], q[1] = conf[4], q[2] = conf[5], q[3] = conf[6];
       } else {
-        const int p = L.parent[k];
-        if (p != prev) {  // branch point: reload the parent's frame
+        const int p = __builtin_amdgcn_readlane(par_r, k);
+        if (p != prev) {  // branch point: reload the parent's frame (stored earlier in this walk by lane 0)
 #pragma unroll
           for (int i = 0; i < 9; i++) M[i] = w.M[9 * p + i];
 #pragma unroll
@@ -429,24 +459,26 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
           for (int i = 0; i < 3; i++) o[i] = w.origin[3 * p + i];
         }
         float tx, ty, tz;
-        mat_vec(M, L.rel_origin[3 * k], L.rel_origin[3 * k + 1], L.rel_origin[3 * k + 2], tx, ty, tz);
+        mat_vec(M, rl(ro0, k), rl(ro1, k), rl(ro2, k), tx, ty, tz);
         o[0] = o[0] + tx;
         o[1] = o[1] + ty;
         o[2] = o[2] + tz;
-        mat_vec(M, L.rel_axis[3 * k], L.rel_axis[3 * k + 1], L.rel_axis[3 * k + 2], ax, ay, az);
-        const float cn = w.cs[2 * k], sn = w.cs[2 * k + 1];
+        mat_vec(M, rl(ra0, k), rl(ra1, k), rl(ra2, k), ax, ay, az);
+        const float cn = rl(cn_r, k), sn = rl(sn_r, k);
         float rq[4] = {cn, sn * ax, sn * ay, sn * az}, nq[4];
         quat_mul(rq, q, nq);
         quat_norm_approx(nq);
         q[0] = nq[0], q[1] = nq[1], q[2] = nq[2], q[3] = nq[3];
       }
       quat_to_r3(q, M);
+      if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; i++) w.M[9 * k + i] = M[i];
+        for (int i = 0; i < 9; i++) w.M[9 * k + i] = M[i];
 #pragma unroll
-      for (int i = 0; i < 4; i++) w.q[4 * k + i] = q[i];
-      w.origin[3 * k] = o[0], w.origin[3 * k + 1] = o[1], w.origin[3 * k + 2] = o[2];
-      w.axis[3 * k] = ax, w.axis[3 * k + 1] = ay, w.axis[3 * k + 2] = az;
+        for (int i = 0; i < 4; i++) w.q[4 * k + i] = q[i];
+        w.origin[3 * k] = o[0], w.origin[3 * k + 1] = o[1], w.origin[3 * k + 2] = o[2];
+        w.axis[3 * k] = ax, w.axis[3 * k + 1] = ay, w.axis[3 * k + 2] = az;
+      }
       prev = k;
     }
   }
@@ -532,8 +564,65 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
     }
     __syncthreads();
   }
-  // 4. intramolecular pairs (model.cu:38-60 / :22-36)
-  for (int p = lane; (MODE < 2 || MODE == 4) && p < L.n_pairs; p += 64) {
+  // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs four at a time and
+  // issues the four table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
+  // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
+  if ((MODE < 2 || MODE == 4) && !env.exact) {
+    for (int p0 = lane; p0 < L.n_pairs; p0 += 256) {
+      float rx[4], ry[4], rz[4], rem[4];
+      float2 s1[4], s2[4];
+      float fastv[4];
+      int2 sl[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = p0 + 64 * u;
+        const bool valid = p < L.n_pairs;
+        const int2 ab = L.pairs[valid ? p : 0];
+        if (DERIV) sl[u] = L.pair_slots[valid ? p : 0];
+        rx[u] = w.coords[3 * ab.y] - w.coords[3 * ab.x];
+        ry[u] = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1];
+        rz[u] = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
+        const float r2 = rx[u] * rx[u] + ry[u] * ry[u] + rz[u] * rz[u];
+        in[u] = valid && r2 < env.cutoff_sqr;
+        const long base = (long)tri_idx(L.smt[ab.x], L.smt[ab.y]) * env.n;
+        const float r2f = env.factor * r2;
+        const int i1 = (int)r2f;
+        rem[u] = r2f - (float)i1;
+        const long at = in[u] ? base + i1 : 0;
+        if (DERIV) {
+          s1[u] = env.smooth[at];
+          s2[u] = env.smooth[at + 1];
+        } else {
+          fastv[u] = env.fast[at];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = p0 + 64 * u;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[u]) {
+          if (DERIV) {
+            float pe = s1[u].x + rem[u] * (s2[u].x - s1[u].x);
+            const float dor = s1[u].y + rem[u] * (s2[u].y - s1[u].y);
+            float fx = dor * rx[u], fy = dor * ry[u], fz = dor * rz[u];
+            curl3(pe, fx, fy, fz, v0);
+            out = make_float4(fx, fy, fz, pe);
+            e_part += pe;
+          } else {
+            float pe = fastv[u];
+            curl1(pe, v0);
+            e_part += pe;
+          }
+        }
+        if (DERIV && p < L.n_pairs) {  // forces[a] -= f; forces[b] += f, as entries of the two atoms' lists
+          w.contrib[sl[u].x] = make_float4(-out.x, -out.y, -out.z, 0.f);
+          w.contrib[sl[u].y] = out;
+        }
+      }
+    }
+  }
+  for (int p = lane; (MODE < 2 || MODE == 4) && env.exact && p < L.n_pairs; p += 64) {
     const int2 ab = L.pairs[p];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
@@ -553,25 +642,26 @@ __device__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float 
         e_part += pe;
       }
     }
-    if (DERIV) w.pair_out[p] = out;
+    if (DERIV) {
+      const int2 sl = L.pair_slots[p];
+      w.contrib[sl.x] = make_float4(-out.x, -out.y, -out.z, 0.f);
+      w.contrib[sl.y] = out;
+    }
   }
   if (DERIV) {
     __syncthreads();
     // 5. gather pair forces per atom, in pair order (forces[a] -= f; forces[b] += f)
     for (int i = lane; i < L.n_atoms; i += 64) {
       float fx = w.forces[3 * i], fy = w.forces[3 * i + 1], fz = w.forces[3 * i + 2];
-      for (int e = L.atom_pair_start[i]; e < L.atom_pair_start[i + 1]; e++) {
-        const int code = L.atom_pair_list[e];
-        const float4 pf = w.pair_out[code >> 1];
-        if (code & 1) {
-          fx += pf.x;
-          fy += pf.y;
-          fz += pf.z;
-        } else {
-          fx -= pf.x;
-          fy -= pf.y;
-          fz -= pf.z;
-        }
+      // the atom's list of contributions (pair order, zero padded to a multiple of four) is contiguous: four
+      // 16-byte reads per LDS latency, no index indirection; the additions keep the pair order
+      const int e_end = L.slot_start[i + 1];
+      for (int e = L.slot_start[i]; e < e_end; e += 4) {
+        const float4 c0 = w.contrib[e], c1 = w.contrib[e + 1], c2 = w.contrib[e + 2], c3 = w.contrib[e + 3];
+        fx += c0.x, fy += c0.y, fz += c0.z;
+        fx += c1.x, fy += c1.y, fz += c1.z;
+        fx += c2.x, fy += c2.y, fz += c2.z;
+        fx += c3.x, fy += c3.y, fz += c3.z;
       }
       w.forces[3 * i] = fx;
       w.forces[3 * i + 1] = fy;
@@ -796,12 +886,6 @@ void launch_vina_eval_repeat(const VinaEnv &env0, const VinaLigand &lig, const f
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int hidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
 
-__device__ __forceinline__ float dot_seq(const float *a, const float *b, int n) {  // scalar_product, bfgs.h:45-50
-  float t = 0.f;
-  for (int i = 0; i < n; i++) t += a[i] * b[i];
-  return t;
-}
-
 // conf::increment (conf.h:54-59,113-118; quaternion.cu:32-62,96-100), executed by one lane
 __device__ void conf_increment(float *x, const float *p, float alpha, int nt) {
   x[0] += alpha * p[0];
@@ -826,7 +910,7 @@ __device__ void conf_increment(float *x, const float *p, float alpha, int nt) {
 
 struct BfgsWork {
   float *x_new, *g_new;  // conformation handed to eval_conf and the change it fills
-  float *x, *x_orig, *g, *g_orig, *p, *y, *mhy, *h;
+  float *x, *g, *h;      // in/out conformation, final gradient, triangular inverse-Hessian estimate
 };
 
 __device__ BfgsWork carve_bfgs(float *&pp, int n, int nc) {
@@ -834,107 +918,155 @@ __device__ BfgsWork carve_bfgs(float *&pp, int n, int nc) {
   k.x_new = carve(pp, nc);
   k.g_new = carve(pp, n);
   k.x = carve(pp, nc);
-  k.x_orig = carve(pp, nc);
   k.g = carve(pp, n);
-  k.g_orig = carve(pp, n);
-  k.p = carve(pp, n);
-  k.y = carve(pp, n);
-  k.mhy = carve(pp, n);
-  (void)carve(pp, n);
   k.h = carve(pp, n * (n + 1) / 2);
   return k;
 }
 
+// Sequential dot product of two vectors held one element per lane (scalar_product, bfgs.h:45-50): the products
+// are formed in parallel, the additions run in index order through v_readlane -- the same roundings as the
+// reference's loop (the build has FMA contraction off), without an LDS round trip per element.
+__device__ __forceinline__ float dot_lanes(float a, float b, int n) {
+  const float prod = a * b;
+  float t = 0.f;
+  for (int i = 0; i < n; i++) t += rl(prod, i);
+  return t;
+}
+
+// -(H v)[lane] with H triangular in LDS and v one element per lane (minus_mat_vec_product, bfgs.h:34-43):
+// j ascending; four H entries are fetched per LDS latency.
+__device__ __forceinline__ float minus_h_times(const float *h, float v, int n, int row) {
+  float sum = 0.f;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    const float h0 = h[hidx(row, j)], h1 = h[hidx(row, j + 1)], h2 = h[hidx(row, j + 2)], h3 = h[hidx(row, j + 3)];
+    sum += h0 * rl(v, j);
+    sum += h1 * rl(v, j + 1);
+    sum += h2 * rl(v, j + 2);
+    sum += h3 * rl(v, j + 3);
+  }
+  for (; j < n; j++) sum += h[hidx(row, j)] * rl(v, j);
+  return -sum;
+}
+
+// conf::increment (conf.h:54-59,113-118) with the conformation one element per lane: lanes 0-2 position, 3-6
+// orientation (every lane forms the same quaternion and keeps its component), 7.. torsions.  p_r holds the
+// direction one element per lane, p_up the same shifted up by one lane (torsion i: x[7+i], p[6+i]).
+__device__ __forceinline__ float increment_lanes(float x_r, float p_r, float p_up, float alpha, int nt, int lane) {
+  const float rx = alpha * rl(p_r, 3), ry = alpha * rl(p_r, 4), rz = alpha * rl(p_r, 5);
+  const float angle = sqrtf(rx * rx + ry * ry + rz * rz);
+  float rq[4] = {1.f, 0.f, 0.f, 0.f};
+  if (angle > VEPS) {
+    const float inv = 1 / angle;
+    angle_to_quat(inv * rx, inv * ry, inv * rz, angle, rq);
+  }
+  const float xq[4] = {rl(x_r, 3), rl(x_r, 4), rl(x_r, 5), rl(x_r, 6)};
+  float nq[4];
+  quat_mul(rq, xq, nq);
+  quat_norm_approx(nq);
+  float out = x_r;
+  if (lane < 3) {
+    out = x_r + alpha * p_r;
+  } else if (lane < 7) {
+    out = lane == 3 ? nq[0] : lane == 4 ? nq[1] : lane == 5 ? nq[2] : nq[3];
+  } else if (lane < 7 + nt) {
+    const float t = x_r + norm_angle(alpha * p_up);
+    out = norm_angle(t);
+  }
+  return out;
+}
+
 // bfgs<> (bfgs.h:357-502) on the conformation in k.x (LDS, in/out); returns the final energy in every
-// lane, leaves the final gradient in k.g.  All control flow is wave-uniform.
+// lane, leaves the final gradient in k.g.  All control flow is wave-uniform.  The vectors (x, g, p, y, -Hy)
+// live one element per lane in registers (6 + T <= 63 elements); only the conformation handed to eval_conf,
+// the change it returns and H are in LDS.
 __device__ float bfgs_wave(const VinaEnv &env, const VinaLigand &L, const WaveWork &w, const BfgsWork &k, float v0,
-                           float v1, float v2, int max_iters, int &evals) {
+                           float v1, float v2, int max_iters, int &evals, long long *eval_ticks = nullptr) {
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   const int lane = threadIdx.x;
-  float *x = k.x, *x_new = k.x_new, *x_orig = k.x_orig, *g = k.g, *g_new = k.g_new, *g_orig = k.g_orig, *p = k.p,
-        *y = k.y, *mhy = k.mhy, *h = k.h;
-  for (int i = lane; i < nc; i += 64) {
-    x_orig[i] = x[i];
-    x_new[i] = x[i];
-  }
+  const int row = lane < n ? lane : n - 1;
+  float *x = k.x, *x_new = k.x_new, *g_new = k.g_new, *h = k.h;
+  float x_r = lane < nc ? x[lane] : 0.f;
+  const float x_orig = x_r;
+  if (lane < nc) x_new[lane] = x_r;
   for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
   __syncthreads();
-  for (int i = lane; i < n; i += 64) h[hidx(i, i)] = 1.f;
+  if (lane < n) h[hidx(lane, lane)] = 1.f;
+  long long tk = eval_ticks ? wall_clock64() : 0;
   float f0 = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
+  if (eval_ticks) *eval_ticks += wall_clock64() - tk;
   evals++;
-  for (int i = lane; i < n; i += 64) {
-    g[i] = g_new[i];
-    g_orig[i] = g_new[i];
-  }
-  const float f_orig = f0;
+  float g_r = lane < n ? g_new[lane] : 0.f;
+  const float g_orig = g_r, f_orig = f0;
   __syncthreads();
 
   for (int step = 0; step < max_iters; step++) {
-    // p = -H g  (minus_mat_vec_product, bfgs.h:34-43): one row per lane, j ascending
-    for (int i = lane; i < n; i += 64) {
-      float sum = 0.f;
-      for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
-      p[i] = -sum;
-    }
-    __syncthreads();
+    const float p_r = lane < n ? minus_h_times(h, g_r, n, row) : 0.f;
+    const float p_up = __shfl_up(p_r, 1);
     // fast_line_search (bfgs.h:73-91)
-    float f1 = 0.f, alpha = 1.f;
-    const float pg = dot_seq(p, g, n);
+    float f1 = 0.f, alpha = 1.f, xn_r = x_r;
+    const float pg = dot_lanes(p_r, g_r, n);
     for (unsigned trial = 0; trial < 10; trial++) {
-      if (lane == 0) {
-        for (int i = 0; i < nc; i++) x_new[i] = x[i];
-        conf_increment(x_new, p, alpha, nt);
-      }
+      xn_r = increment_lanes(x_r, p_r, p_up, alpha, nt, lane);
+      if (lane < nc) x_new[lane] = xn_r;
       __syncthreads();
+      if (eval_ticks) tk = wall_clock64();
       f1 = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
+      if (eval_ticks) *eval_ticks += wall_clock64() - tk;
       evals++;
       if (f1 - f0 < 0.0001f * alpha * pg) break;
       alpha *= 0.5f;
     }
     if (alpha == 0.f) break;
-    for (int i = lane; i < n; i += 64) y[i] = g_new[i] - g[i];
+    const float gn_r = lane < n ? g_new[lane] : 0.f;
+    const float y_r = gn_r - g_r;
     f0 = f1;
-    __syncthreads();
-    for (int i = lane; i < nc; i += 64) x[i] = x_new[i];
-    for (int i = lane; i < n; i += 64) g[i] = g_new[i];
-    __syncthreads();
-    const float gradnormsq = dot_seq(g, g, n);
+    x_r = xn_r;
+    g_r = gn_r;
+    const float gradnormsq = dot_lanes(g_r, g_r, n);
     if (!(gradnormsq >= 1e-4f)) break;
     if (step == 0) {
-      const float yy = dot_seq(y, y, n);
+      const float yy = dot_lanes(y_r, y_r, n);
       if (fabsf(yy) > VEPS) {
-        const float dgl = alpha * dot_seq(y, p, n) / yy;
-        __syncthreads();
-        for (int i = lane; i < n; i += 64) h[hidx(i, i)] = dgl;
+        const float dgl = alpha * dot_lanes(y_r, p_r, n) / yy;
+        if (lane < n) h[hidx(lane, lane)] = dgl;
         __syncthreads();
       }
     }
     // bfgs_update (bfgs.h:52-66)
-    const float yp = dot_seq(y, p, n);
+    const float yp = dot_lanes(y_r, p_r, n);
     if (!(alpha * yp < VEPS)) {
-      for (int i = lane; i < n; i += 64) {
-        float sum = 0.f;
-        for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * y[j];
-        mhy[i] = -sum;
-      }
-      __syncthreads();
-      const float yhy = -dot_seq(y, mhy, n);
+      const float mhy_r = lane < n ? minus_h_times(h, y_r, n, row) : 0.f;
+      const float yhy = -dot_lanes(y_r, mhy_r, n);
       const float r = 1 / (alpha * yp);
-      for (int idx = lane; idx < n * n; idx += 64) {
-        const int i = idx / n, j = idx - i * n;
-        if (j >= i)
-          h[hidx(i, j)] +=
-              alpha * r * (mhy[i] * p[j] + mhy[j] * p[i]) + alpha * alpha * (r * r * yhy + r) * p[i] * p[j];
+      // row i of the upper triangle per pass, lane j >= i owns H(i, j); four rows per LDS latency
+      for (int i0 = 0; i0 < n; i0 += 4) {
+        float hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u;
+          hv[u] = (i < n && lane >= i && lane < n) ? h[hidx(i, lane)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u;
+          if (i < n) {
+            const float mi = rl(mhy_r, i), pi = rl(p_r, i);
+            const float upd = alpha * r * (mi * p_r + mhy_r * pi) + alpha * alpha * (r * r * yhy + r) * pi * p_r;
+            if (lane >= i && lane < n) h[hidx(i, lane)] = hv[u] + upd;
+          }
+        }
       }
     }
     __syncthreads();
   }
   if (!(f0 <= f_orig)) {  // bfgs.h:491-495
     f0 = f_orig;
-    __syncthreads();
-    for (int i = lane; i < nc; i += 64) x[i] = x_orig[i];
-    for (int i = lane; i < n; i += 64) g[i] = g_orig[i];
+    x_r = x_orig;
+    g_r = g_orig;
   }
+  if (lane < nc) x[lane] = x_r;
+  if (lane < n) k.g[lane] = g_r;
   __syncthreads();
   return f0;
 }
@@ -1090,6 +1222,17 @@ __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, 
   __syncthreads();
   float tmp_e = 0.f, best_e = VMAXFL;
   int n_out = 0;
+  // optional phase timing (MI_VINA_MC_PROFILE): 100 MHz ticks of [mutate, hunt BFGS, energy + Metropolis,
+  // second BFGS, energy + copy, container insert, evaluations inside both BFGS, accepted steps]
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = a.prof ? wall_clock64() : 0;
+  auto lap = [&](int ph) {
+    if (a.prof) {
+      const long long t = wall_clock64();
+      pt[ph] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  long long *evt = a.prof ? &pt[6] : nullptr;
 
   for (int step = 0; step < a.n_steps; step++) {
     for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
@@ -1129,17 +1272,22 @@ __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, 
       if (lane == 0) k.x[7 + (which - 2)] = tv;
     }
     __syncthreads();
-    (void)bfgs_wave(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals);
+    lap(0);
+    (void)bfgs_wave(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals, evt);
+    lap(1);
     const float cand_e = eval_conf<2>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // update_energy
     bool accept = step == 0 || cand_e < tmp_e;
     if (!accept) {  // metropolis_accept, monte_carlo.cpp:38-42
       const float prob = expf((tmp_e - cand_e) / a.temperature);
       accept = rng.u01() < prob;
     }
+    lap(2);
     if (accept) {
       tmp_e = cand_e;
+      pt[7] += a.prof ? 1 : 0;
       if (tmp_e < best_e || n_out < a.num_saved) {
-        (void)bfgs_wave(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals);
+        (void)bfgs_wave(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals, evt);
+        lap(3);
         tmp_e = eval_conf<2>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // leaves coords of k.x in w.coords
         for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
         for (int h = lane; h < nh; h += 64) {
@@ -1149,6 +1297,7 @@ __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, 
           hc[3 * h + 2] = w.coords[3 * i + 2];
         }
         __syncthreads();
+        lap(4);
         // add_to_output_container (coords.cpp:25-56): rmsd to every saved pose, one pose per lane
         for (int o = lane; o < n_out; o += 64) {
           const float *ref = s_xyz + (size_t)ord[o] * 3 * nh;
@@ -1205,12 +1354,15 @@ __global__ __launch_bounds__(64) void vina_mc_kernel(VinaEnv env, VinaLigand L, 
           __syncthreads();
         }
         if (tmp_e < best_e) best_e = tmp_e;
+        lap(5);
       } else {
         for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
       }
       __syncthreads();
     }
   }
+  if (a.prof && lane == 0)
+    for (int i = 0; i < 8; i++) a.prof[(size_t)b * 8 + i] = pt[i];
   // emit the container in sorted order
   for (int o = 0; o < n_out; o++) {
     const int phys = ord[o];

@@ -2,6 +2,8 @@
 // cache / ligand upload, and the mi_vina_* C ABI (include/mi_gnina.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -294,7 +296,7 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   Vina &v = *reinterpret_cast<Vina *>(vv);
   const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
   MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
-  MIG_CHECK(nn <= 64, 1, "more than 63 rotatable bonds: the force fold keeps one tree node per lane");
+  MIG_CHECK(nn <= 57, 1, "more than 56 rotatable bonds: the minimiser keeps the 7 + T conformation entries one per lane");
   std::vector<int> node_of(na, -1);
   for (int k = 0; k < nn; k++) {
     MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : d->node_parent[k] >= 0), 1,
@@ -315,19 +317,21 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
       if (d->node_parent[c] == k) child_list.push_back(c);
   }
   child_start[nn] = (int)child_list.size();
-  std::vector<std::vector<int>> per_atom(na);
+  std::vector<int> degree(na, 0);
   for (int p = 0; p < np; p++) {
     const int a = d->pairs[2 * p], b = d->pairs[2 * p + 1];
     MIG_CHECK(a >= 0 && a < na && b >= 0 && b < na && a != b, 1, "bad pair");
-    per_atom[a].push_back(2 * p);
-    per_atom[b].push_back(2 * p + 1);
+    degree[a]++;
+    degree[b]++;
   }
-  std::vector<int> aps(na + 1, 0), apl;
-  for (int i = 0; i < na; i++) {
-    aps[i] = (int)apl.size();
-    apl.insert(apl.end(), per_atom[i].begin(), per_atom[i].end());
+  // contribution slots: atom i's list, in pair order, padded to a multiple of four (vina.h: slot_start / pair_slots)
+  std::vector<int> aps(na + 1, 0), apl(2 * (size_t)np, 0), fill(na, 0);
+  for (int i = 0; i < na; i++) aps[i + 1] = aps[i] + ((degree[i] + 3) & ~3);
+  for (int p = 0; p < np; p++) {
+    const int a = d->pairs[2 * p], b = d->pairs[2 * p + 1];
+    apl[2 * p] = aps[a] + fill[a]++;
+    apl[2 * p + 1] = aps[b] + fill[b]++;
   }
-  aps[na] = (int)apl.size();
   // pack ints: smt, node_of, parent, abeg, aend, child_start, child_list, pairs, aps, apl
   std::vector<int> ints;
   auto pushi = [&](const int *p, size_t n) {
@@ -371,8 +375,8 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   L.child_start = v.d_int.p + o_cs;
   L.child_list = v.d_int.p + o_cl;
   L.pairs = reinterpret_cast<const int2 *>(v.d_int.p + o_pairs);
-  L.atom_pair_start = v.d_int.p + o_aps;
-  L.atom_pair_list = v.d_int.p + o_apl;
+  L.slot_start = v.d_int.p + o_aps;
+  L.pair_slots = reinterpret_cast<const int2 *>(v.d_int.p + o_apl);
   L.n_heavy = (int)heavy.size();
   L.heavy_list = v.d_int.p + o_heavy;
   L.local_xyz = v.d_flt.p + o_loc;
@@ -485,8 +489,27 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
   a.out_coords = v.d_mc_xyz.p;
   a.out_n = v.d_out_n.p;
   a.evals = v.d_evals.p;
+  const bool prof = getenv("MI_VINA_MC_PROFILE") != nullptr;
+  long long *d_prof = nullptr;
+  if (prof) {
+    MIG_HIP(hipMalloc(&d_prof, (size_t)B * 8 * sizeof(long long)));
+    a.prof = d_prof;
+  }
   launch_vina_mc(make_env(v), v.lig, a, B, v.stream);
   MIG_HIP(hipGetLastError());
+  if (prof) {  // diagnostic: mean per-chain time of each phase, 100 MHz ticks -> ms
+    std::vector<long long> hp((size_t)B * 8);
+    MIG_HIP(hipMemcpyAsync(hp.data(), d_prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, v.stream));
+    MIG_HIP(hipStreamSynchronize(v.stream));
+    MIG_HIP(hipFree(d_prof));
+    double m[8] = {0};
+    for (int b = 0; b < B; b++)
+      for (int i = 0; i < 8; i++) m[i] += (double)hp[(size_t)b * 8 + i] / B;
+    fprintf(stderr,
+            "[mi_vina_mc] B=%d steps=%d  per chain (ms): mutate %.2f  bfgs_hunt %.2f  energy+metropolis %.2f  "
+            "bfgs_auth %.2f  energy+copy %.2f  insert %.2f | evals inside bfgs %.2f | accepted %.0f\n",
+            B, a.n_steps, m[0] * 1e-5, m[1] * 1e-5, m[2] * 1e-5, m[3] * 1e-5, m[4] * 1e-5, m[5] * 1e-5, m[6] * 1e-5, m[7]);
+  }
   MIG_HIP(hipMemcpyAsync(out_n, v.d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipMemcpyAsync(out_e, v.d_mc_e.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   if (out_conf)

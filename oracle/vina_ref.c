@@ -666,6 +666,15 @@ float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const f
   return e;
 }
 
+/* instrumentation for the design notes: how many trials the line searches take (index = trials used, 0..10) */
+static long g_trial_hist[11];
+void ora_vina_trial_hist(long *out, int reset) {
+  for (int i = 0; i < 11; i++) {
+    out[i] = g_trial_hist[i];
+    if (reset) g_trial_hist[i] = 0;
+  }
+}
+
 static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) {
   const ora_ligand *L = ctxp->L;
   const int nt = L->n_nodes - 1, n = 6 + nt, nc = 7 + nt;
@@ -694,9 +703,13 @@ static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) 
       memcpy(x_new, conf, sizeof(float) * nc);
       ora_vina_conf_increment(x_new, p, alpha, nt);
       f1 = fx(&ctx, x_new, g_new);
-      if (f1 - f0 < 0.0001f * alpha * pg) break;
+      if (f1 - f0 < 0.0001f * alpha * pg) {
+        g_trial_hist[trial + 1]++;
+        break;
+      }
       alpha *= 0.5f;
     }
+    if (alpha < 0.001f) g_trial_hist[0]++; /* never accepted: 10 trials */
     if (alpha == 0) break;
     for (int i = 0; i < n; i++) y[i] = g_new[i] - g[i];
     f0 = f1;
