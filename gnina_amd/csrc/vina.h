@@ -108,7 +108,8 @@ void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *
 void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, const VinaExtArgs &a,
                           float *energy, float *change, hipStream_t s);
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
-size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage);
+size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage, int waves_per_chain);
+int vina_mc_team(int B);  // waves per chain the Monte-Carlo kernel uses for B chains
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s);

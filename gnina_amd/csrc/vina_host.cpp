@@ -456,7 +456,7 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
             "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
   if (B == 0) return MI_OK;
   const int nt = v.lig.n_nodes - 1, nc = 7 + nt, nh = v.lig.n_heavy, S = P->num_saved;
-  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true) <= 64 * 1024, 1,
+  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true, 1) <= 64 * 1024, 1,
             "ligand too large for the per-wave LDS workspace");
   v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
   v.d_mc_e.ensure((size_t)B * S);
