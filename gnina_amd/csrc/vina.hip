@@ -120,37 +120,53 @@ __device__ __forceinline__ float prec_eval(const VinaEnv &env, int t1, int t2, f
   return env.fast[(long)tri_idx(t1, t2) * env.n + (int)(env.factor * r2)];
 }
 
-// grid::evaluate_aux, grid.cpp:96-186
-template <bool DERIV>
-__device__ float grid_evaluate(const VinaGridGeom &g, const float *data, float lx, float ly, float lz, float slope,
-                               float v, float &ox, float &oy, float &oz) {
+// grid::evaluate_aux, grid.cpp:96-186, in two halves so that the eight corner loads (L2 latency) of an atom
+// can be in flight while the intramolecular pair stage runs: grid_fetch locates the cell and issues the loads,
+// grid_finish interpolates.
+struct GridTap {
+  float f[8];  // f000 f100 f010 f110 f001 f101 f011 f111
+  float s[3];
+  int region[3];
+  float penalty;
+};
+
+__device__ __forceinline__ void grid_fetch(const VinaGridGeom &g, const float *data, float lx, float ly, float lz,
+                                           float slope, GridTap &t) {
   float s[3] = {(lx - g.init[0]) * g.factor[0], (ly - g.init[1]) * g.factor[1], (lz - g.init[2]) * g.factor[2]};
   float miss[3] = {0.f, 0.f, 0.f};
-  int region[3], a[3];
+  int a[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     if (s[i] < 0) {
       miss[i] = -s[i];
-      region[i] = -1;
+      t.region[i] = -1;
       a[i] = 0;
       s[i] = 0;
     } else if (s[i] >= g.dim_m1[i]) {
       miss[i] = s[i] - g.dim_m1[i];
-      region[i] = 1;
+      t.region[i] = 1;
       a[i] = g.dim[i] - 2;
       s[i] = 1;
     } else {
-      region[i] = 0;
+      t.region[i] = 0;
       a[i] = (int)s[i];
       s[i] -= (float)a[i];
     }
+    t.s[i] = s[i];
   }
-  const float penalty = slope * (miss[0] * g.factor_inv[0] + miss[1] * g.factor_inv[1] + miss[2] * g.factor_inv[2]);
+  t.penalty = slope * (miss[0] * g.factor_inv[0] + miss[1] * g.factor_inv[1] + miss[2] * g.factor_inv[2]);
   const long sx = 1, sy = g.dim[0], sz = (long)g.dim[0] * g.dim[1];
   const float *p = data + a[0] * sx + a[1] * sy + a[2] * sz;
-  const float f000 = p[0], f100 = p[sx], f010 = p[sy], f110 = p[sx + sy];
-  const float f001 = p[sz], f101 = p[sz + sx], f011 = p[sz + sy], f111 = p[sz + sx + sy];
-  const float x = s[0], y = s[1], z = s[2], mx = 1 - x, my = 1 - y, mz = 1 - z;
+  t.f[0] = p[0], t.f[1] = p[sx], t.f[2] = p[sy], t.f[3] = p[sx + sy];
+  t.f[4] = p[sz], t.f[5] = p[sz + sx], t.f[6] = p[sz + sy], t.f[7] = p[sz + sx + sy];
+}
+
+template <bool DERIV>
+__device__ __forceinline__ float grid_finish(const VinaGridGeom &g, const GridTap &t, float slope, float v, float &ox,
+                                             float &oy, float &oz) {
+  const float f000 = t.f[0], f100 = t.f[1], f010 = t.f[2], f110 = t.f[3];
+  const float f001 = t.f[4], f101 = t.f[5], f011 = t.f[6], f111 = t.f[7];
+  const float x = t.s[0], y = t.s[1], z = t.s[2], mx = 1 - x, my = 1 - y, mz = 1 - z;
   float f = f000 * mx * my * mz + f100 * x * my * mz + f010 * mx * y * mz + f110 * x * y * mz + f001 * mx * my * z +
             f101 * x * my * z + f011 * mx * y * z + f111 * x * y * z;
   if (DERIV) {
@@ -161,13 +177,21 @@ __device__ float grid_evaluate(const VinaGridGeom &g, const float *data, float l
     float gz = f000 * mx * my * (-1) + f100 * x * my * (-1) + f010 * mx * y * (-1) + f110 * x * y * (-1) +
                f001 * mx * my * 1 + f101 * x * my * 1 + f011 * mx * y * 1 + f111 * x * y * 1;
     curl3(f, gx, gy, gz, v);
-    ox = g.factor[0] * (region[0] == 0 ? gx : 0.f) + slope * (float)region[0];
-    oy = g.factor[1] * (region[1] == 0 ? gy : 0.f) + slope * (float)region[1];
-    oz = g.factor[2] * (region[2] == 0 ? gz : 0.f) + slope * (float)region[2];
-    return f + penalty;
+    ox = g.factor[0] * (t.region[0] == 0 ? gx : 0.f) + slope * (float)t.region[0];
+    oy = g.factor[1] * (t.region[1] == 0 ? gy : 0.f) + slope * (float)t.region[1];
+    oz = g.factor[2] * (t.region[2] == 0 ? gz : 0.f) + slope * (float)t.region[2];
+    return f + t.penalty;
   }
   curl1(f, v);
-  return f + penalty;
+  return f + t.penalty;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ float grid_evaluate(const VinaGridGeom &g, const float *data, float lx, float ly, float lz,
+                                               float slope, float v, float &ox, float &oy, float &oz) {
+  GridTap t;
+  grid_fetch(g, data, lx, ly, lz, slope, t);
+  return grid_finish<DERIV>(g, t, slope, v, ox, oy, oz);
 }
 
 // ---- quaternion helpers (quaternion.h:243-303,327-364) ------------------------------------------
@@ -255,6 +279,8 @@ struct WaveWork {
 // Ordering point between the lanes of ONE wave (private LDS workspace): LDS instructions of a wave execute in
 // issue order, so no s_barrier and no counter drain is needed -- only the compiler must not move LDS accesses
 // across it.  Data shared between the waves of a workgroup still goes through __syncthreads().
+constexpr int kPairGroup = 6;
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -343,10 +369,24 @@ size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, boo
   return f * sizeof(float);
 }
 
+// Sum over the 64 lanes, returned in every lane.  The association is the xor butterfly's (1, 2, 4, 8, 16, 32):
+// quads, octets and rows are combined with DPP (quad_perm / row_half_mirror / row_mirror: after each step the
+// lanes of a group hold the same partial sum, so mirroring and xor pick the same partner value), rows with
+// row_bcast 15 / 31, and the total is read from lane 63 -- register to register, no ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ligands.derivative(coords, minus_forces, g) (model.cu:223; tree.h:133-140,293-401): per-atom forces in
@@ -496,21 +536,48 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
   }
   wave_sync();
-  // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor term
+  // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor term.  For the first
+  // kTapIt * 64 atoms the grid look-up is split: the corner loads are issued here and interpolated after the
+  // pair stage (3b below), so the two L2 round trips overlap.
+  constexpr bool GRID = MODE != 3 && MODE != 4;
+  constexpr int kTapIt = 2;
   float e_part = 0.f;
-  for (int i = lane; i < L.n_atoms; i += 64) {
+  GridTap tap[kTapIt];
+  bool tap_on[kTapIt];
+  auto place_atom = [&](int i, float &cx, float &cy, float &cz) {
     const int k = L.node_of_atom[i];
     float tx, ty, tz;
     mat_vec(w.M + 9 * k, L.local_xyz[3 * i], L.local_xyz[3 * i + 1], L.local_xyz[3 * i + 2], tx, ty, tz);
-    const float cx = w.origin[3 * k] + tx, cy = w.origin[3 * k + 1] + ty, cz = w.origin[3 * k + 2] + tz;
+    cx = w.origin[3 * k] + tx, cy = w.origin[3 * k + 1] + ty, cz = w.origin[3 * k + 2] + tz;
     w.coords[3 * i] = cx;
     w.coords[3 * i + 1] = cy;
     w.coords[3 * i + 2] = cz;
+  };
+#pragma unroll
+  for (int it = 0; it < kTapIt; it++) {
+    const int i = lane + 64 * it;
+    tap_on[it] = false;
+    if (i < L.n_atoms) {
+      float cx, cy, cz;
+      place_atom(i, cx, cy, cz);
+      const int t = L.smt[i];
+      if (GRID && !env.direct && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+        grid_fetch(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, tap[it]);
+        tap_on[it] = true;
+      } else if (DERIV) {
+        w.forces[3 * i] = 0.f;
+        w.forces[3 * i + 1] = 0.f;
+        w.forces[3 * i + 2] = 0.f;
+      }
+    }
+  }
+  for (int i = lane + 64 * kTapIt; i < L.n_atoms; i += 64) {
+    float cx, cy, cz;
+    place_atom(i, cx, cy, cz);
     const int t = L.smt[i];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (MODE != 3 && MODE != 4 && !env.direct && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+    if (GRID && !env.direct && t > 1 && env.grid_off[t] >= 0)
       e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
-    }
     if (DERIV) {
       w.forces[3 * i] = fx;
       w.forces[3 * i + 1] = fy;
@@ -577,18 +644,18 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
     wave_sync();
   }
-  // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs four at a time and
-  // issues the four table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
+  // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs kPairGroup at a time
+  // (one group covers 384 pairs, a typical drug-like ligand) and issues their table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
   // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
   if ((MODE < 2 || MODE == 4) && !env.exact) {
-    for (int p0 = lane; p0 < L.n_pairs; p0 += 256) {
-      float rx[4], ry[4], rz[4], rem[4];
-      float2 s1[4], s2[4];
-      float fastv[4];
-      int2 sl[4];
-      bool in[4];
+    for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * kPairGroup) {
+      float rx[kPairGroup], ry[kPairGroup], rz[kPairGroup], rem[kPairGroup];
+      float2 s1[kPairGroup], s2[kPairGroup];
+      float fastv[kPairGroup];
+      int2 sl[kPairGroup];
+      bool in[kPairGroup];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kPairGroup; u++) {
         const int p = p0 + 64 * u;
         const bool valid = p < L.n_pairs;
         const int2 ab = L.pairs[valid ? p : 0];
@@ -611,7 +678,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kPairGroup; u++) {
         const int p = p0 + 64 * u;
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in[u]) {
@@ -659,6 +726,20 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       const int2 sl = L.pair_slots[p];
       w.contrib[sl.x] = make_float4(-out.x, -out.y, -out.z, 0.f);
       w.contrib[sl.y] = out;
+    }
+  }
+  // 3b. interpolate the receptor grids whose corner loads were issued in stage 3
+#pragma unroll
+  for (int it = 0; it < kTapIt; it++) {
+    if (tap_on[it]) {
+      const int i = lane + 64 * it;
+      float fx = 0.f, fy = 0.f, fz = 0.f;
+      e_part += grid_finish<DERIV>(env.geom, tap[it], env.slope, v1, fx, fy, fz);
+      if (DERIV) {
+        w.forces[3 * i] = fx;
+        w.forces[3 * i + 1] = fy;
+        w.forces[3 * i + 2] = fz;
+      }
     }
   }
   if (DERIV) {
@@ -1032,11 +1113,20 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   for (int step = -1; step < max_iters; step++) {
     const bool start = step < 0;
     float p_r = 0.f, p_up = 0.f, pg = 0.f;
+    long long tb = eval_ticks ? wall_clock64() : 0;
+    auto lapb = [&](int slot) {
+      if (eval_ticks) {
+        const long long t = wall_clock64();
+        eval_ticks[slot] += t - tb;
+        tb = t;
+      }
+    };
     if (!start) {
       p_r = lane < n ? minus_h_times(h, g_r, n, row) : 0.f;
       p_up = __shfl_up(p_r, 1);
       pg = dot_lanes(p_r, g_r, n);
     }
+    lapb(2);
     // line search: trials t0 .. t0 + W - 1 in parallel
     float f1 = 0.f;
     int t_acc = -1, winner = 0;  // accepted trial (10 = none of the ten), wave that evaluated it
@@ -1046,9 +1136,9 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       const float xn = start ? x_r : increment_lanes(x_r, p_r, p_up, a_t, nt, lane);
       if (lane < nc) x_new[lane] = xn;
       wave_sync();
-      const long long tk = eval_ticks ? wall_clock64() : 0;
+      lapb(3);
       const float f_t = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
-      if (eval_ticks) *eval_ticks += wall_clock64() - tk;
+      lapb(0);
       if (start) {  // every wave evaluated the start point itself
         t_acc = 0;
         winner = wv;
@@ -1081,6 +1171,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         __syncthreads();
       }
     }
+    lapb(4);
     const float alpha = ldexpf(1.f, -t_acc);
     evals += t_acc < 10 ? t_acc + 1 : 10;
     // the accepted trial's conformation and gradient, from the workspace of the wave that evaluated it
@@ -1133,6 +1224,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       }
     }
     wave_sync();
+    lapb(5);
   }
   if (!(f0 <= f_orig)) {  // bfgs.h:491-495
     f0 = f_orig;
@@ -1325,7 +1417,7 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   int n_out = 0;
   // optional phase timing (MI_VINA_MC_PROFILE): 100 MHz ticks of [mutate, hunt BFGS, energy + Metropolis,
   // second BFGS, energy + copy, container insert, evaluations inside both BFGS, accepted steps]
-  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = a.prof ? wall_clock64() : 0;
+  long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = a.prof ? wall_clock64() : 0;
   auto lap = [&](int ph) {
     if (a.prof) {
       const long long t = wall_clock64();
@@ -1476,7 +1568,7 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   }
   if (wv != 0) return;
   if (a.prof && lane == 0)
-    for (int i = 0; i < 8; i++) a.prof[(size_t)b * 8 + i] = pt[i];
+    for (int i = 0; i < 12; i++) a.prof[(size_t)b * 12 + i] = pt[i];
   // emit the container in sorted order
   for (int o = 0; o < n_out; o++) {
     const int phys = ord[o];

@@ -492,23 +492,25 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
   const bool prof = getenv("MI_VINA_MC_PROFILE") != nullptr;
   long long *d_prof = nullptr;
   if (prof) {
-    MIG_HIP(hipMalloc(&d_prof, (size_t)B * 8 * sizeof(long long)));
+    MIG_HIP(hipMalloc(&d_prof, (size_t)B * 12 * sizeof(long long)));
     a.prof = d_prof;
   }
   launch_vina_mc(make_env(v), v.lig, a, B, v.stream);
   MIG_HIP(hipGetLastError());
   if (prof) {  // diagnostic: mean per-chain time of each phase, 100 MHz ticks -> ms
-    std::vector<long long> hp((size_t)B * 8);
+    std::vector<long long> hp((size_t)B * 12);
     MIG_HIP(hipMemcpyAsync(hp.data(), d_prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, v.stream));
     MIG_HIP(hipStreamSynchronize(v.stream));
     MIG_HIP(hipFree(d_prof));
-    double m[8] = {0};
+    double m[12] = {0};
     for (int b = 0; b < B; b++)
-      for (int i = 0; i < 8; i++) m[i] += (double)hp[(size_t)b * 8 + i] / B;
+      for (int i = 0; i < 12; i++) m[i] += (double)hp[(size_t)b * 12 + i] / B;
     fprintf(stderr,
             "[mi_vina_mc] B=%d steps=%d  per chain (ms): mutate %.2f  bfgs_hunt %.2f  energy+metropolis %.2f  "
-            "bfgs_auth %.2f  energy+copy %.2f  insert %.2f | evals inside bfgs %.2f | accepted %.0f\n",
-            B, a.n_steps, m[0] * 1e-5, m[1] * 1e-5, m[2] * 1e-5, m[3] * 1e-5, m[4] * 1e-5, m[5] * 1e-5, m[6] * 1e-5, m[7]);
+            "bfgs_auth %.2f  energy+copy %.2f  insert %.2f | inside bfgs: evals %.2f  direction %.2f  increment %.2f  "
+            "exchange %.2f  update %.2f | accepted %.0f\n",
+            B, a.n_steps, m[0] * 1e-5, m[1] * 1e-5, m[2] * 1e-5, m[3] * 1e-5, m[4] * 1e-5, m[5] * 1e-5, m[6] * 1e-5,
+            m[8] * 1e-5, m[9] * 1e-5, m[10] * 1e-5, m[11] * 1e-5, m[7]);
   }
   MIG_HIP(hipMemcpyAsync(out_n, v.d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipMemcpyAsync(out_e, v.d_mc_e.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost, v.stream));
