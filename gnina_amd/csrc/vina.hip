@@ -21,6 +21,8 @@
 //  * All arithmetic is fp32 in the reference's operation order (compiled with -ffp-contract=off);
 //    only sinf/cosf and the reduction order differ from the CPU oracle.
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 #include "vina.h"
 
@@ -346,6 +348,19 @@ __device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
   return L;
 }
 
+// Workspaces above the default 64 KB of dynamic LDS (large ligands; several waves per chain) need the kernel's
+// limit raised once; gfx950 has 160 KB per workgroup.
+constexpr size_t kVinaMaxLds = 160 * 1024;
+template <class K>
+static void big_lds(K kernel) {
+  static std::mutex mu;
+  static std::set<const void *> done;  // kernels of one signature share this instantiation: key by address
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert(fn).second)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVinaMaxLds);
+}
+
 static size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 // Few chains (a single docking job) are latency bound: keep the ligand description in LDS.  Many chains
@@ -437,22 +452,28 @@ __device__ __forceinline__ void fold_forces(const VinaLigand &L, const WaveWork 
     ce = L.child_start[k + 1];
     if (k < L.n_nodes - 1) cl = L.child_list[k];  // entry k of the child list (a tree has n_nodes - 1 edges)
   }
-  // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311).  The
-  // dependent chain runs register to register: a child's sums reach its parent's lane through v_readlane
-  // (wave-uniform lane indices), not through LDS round trips of a single active lane.
+  // 7. fold children into parents, children in increasing order (branches_derivative, tree.h:301-311): the parent
+  // adds (f_c, (o_c - o_parent) x f_c + t_c).  Every lane forms that contribution for its own node from its own
+  // registers (it is only read once the node is complete: children have larger indices and k runs downwards), so
+  // the dependent chain per edge is cross product -> six v_readlane -> six additions in the parent's lane.
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  if (lane > 0 && lane < L.n_nodes) {
+    const int pr = L.parent[lane];
+    rx = ox - w.origin[3 * pr], ry = oy - w.origin[3 * pr + 1], rz = oz - w.origin[3 * pr + 2];
+  }
   for (int k = L.n_nodes - 1; k >= 0; k--) {
     const int s = __builtin_amdgcn_readlane(cs, k), e_end = __builtin_amdgcn_readlane(ce, k);
     for (int e = s; e < e_end; e++) {
       const int c = __builtin_amdgcn_readlane(cl, e);
-      const float c0 = rl(f0, c), c1 = rl(f1, c), c2 = rl(f2, c), c3 = rl(t0, c), c4 = rl(t1, c), c5 = rl(t2, c);
-      const float rx = rl(ox, c) - ox, ry = rl(oy, c) - oy, rz = rl(oz, c) - oz;
+      const float u0 = (ry * f2 - rz * f1) + t0, u1 = (rz * f0 - rx * f2) + t1, u2 = (rx * f1 - ry * f0) + t2;
+      const float c0 = rl(f0, c), c1 = rl(f1, c), c2 = rl(f2, c), c3 = rl(u0, c), c4 = rl(u1, c), c5 = rl(u2, c);
       if (lane == k) {
         f0 += c0;
         f1 += c1;
         f2 += c2;
-        t0 += (ry * c2 - rz * c1) + c3;
-        t1 += (rz * c0 - rx * c2) + c4;
-        t2 += (rx * c1 - ry * c0) + c5;
+        t0 += c3;
+        t1 += c4;
+        t2 += c5;
       }
     }
   }
@@ -929,12 +950,14 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
 void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float *coords,
                         hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
+  big_lds(vina_coords_kernel);
   hipLaunchKernelGGL(vina_coords_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, coords);
 }
 
 void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, const VinaExtArgs &a,
                           float *energy, float *change, hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
+  big_lds(vina_extforce_kernel);
   hipLaunchKernelGGL(vina_extforce_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, a, energy, change);
 }
 
@@ -967,11 +990,11 @@ void launch_vina_eval_repeat(const VinaEnv &env0, const VinaLigand &lig, const f
   env.stage = 1;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, true);
   switch (mode) {
-    case 0: hipLaunchKernelGGL(vina_eval_repeat_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
-    case 1: hipLaunchKernelGGL(vina_eval_repeat_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
-    case 2: hipLaunchKernelGGL(vina_eval_repeat_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
-    case 3: hipLaunchKernelGGL(vina_eval_repeat_kernel<3>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
-    default: hipLaunchKernelGGL(vina_eval_repeat_kernel<4>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 0: big_lds(vina_eval_repeat_kernel<0>); hipLaunchKernelGGL(vina_eval_repeat_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 1: big_lds(vina_eval_repeat_kernel<1>); hipLaunchKernelGGL(vina_eval_repeat_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 2: big_lds(vina_eval_repeat_kernel<2>); hipLaunchKernelGGL(vina_eval_repeat_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    case 3: big_lds(vina_eval_repeat_kernel<3>); hipLaunchKernelGGL(vina_eval_repeat_kernel<3>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
+    default: big_lds(vina_eval_repeat_kernel<4>); hipLaunchKernelGGL(vina_eval_repeat_kernel<4>, dim3(B), dim3(64), lds, s, env, lig, confs, 10.f, 10.f, 10.f, reps, energy); break;
   }
 }
 
@@ -1105,9 +1128,30 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   float *x = k.x, *x_new = k.x_new, *g_new = k.g_new, *h = k.h;
   float x_r = lane < nc ? x[lane] : 0.f;
   const float x_orig = x_r;
-  for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
-  wave_sync();
-  if (lane < n) h[hidx(lane, lane)] = 1.f;
+  // H: up to kHReg variables, lane i keeps the full (symmetric) row i in registers -- both triangles are updated
+  // with the operands in the reference's order, so they stay bit-identical to the triangular update; larger
+  // problems keep the triangle in LDS.
+  constexpr int kHReg = 24;
+  const bool hreg = n <= kHReg;
+  float hrow[kHReg];
+#pragma unroll
+  for (int j = 0; j < kHReg; j++) hrow[j] = (j == lane && lane < n) ? 1.f : 0.f;
+  if (!hreg) {
+    for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
+    wave_sync();
+    if (lane < n) h[hidx(lane, lane)] = 1.f;
+  }
+  auto minus_hrow_times = [&](float v) {  // -(H v)[lane], j ascending
+    float sum = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < kHReg; j0 += 4) {
+      if (j0 < n) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum += hrow[j0 + u] * rl(v, j0 + u);
+      }
+    }
+    return -sum;
+  };
   float f0 = 0.f, f_orig = 0.f, g_r = 0.f, g_orig = 0.f;
 
   for (int step = -1; step < max_iters; step++) {
@@ -1122,7 +1166,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       }
     };
     if (!start) {
-      p_r = lane < n ? minus_h_times(h, g_r, n, row) : 0.f;
+      p_r = hreg ? minus_hrow_times(g_r) : (lane < n ? minus_h_times(h, g_r, n, row) : 0.f);
       p_up = __shfl_up(p_r, 1);
       pg = dot_lanes(p_r, g_r, n);
     }
@@ -1194,31 +1238,57 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       const float yy = dot_lanes(y_r, y_r, n);
       if (fabsf(yy) > VEPS) {
         const float dgl = alpha * dot_lanes(y_r, p_r, n) / yy;
-        if (lane < n) h[hidx(lane, lane)] = dgl;
-        wave_sync();
+        if (hreg) {
+#pragma unroll
+          for (int j = 0; j < kHReg; j++)
+            if (j == lane && lane < n) hrow[j] = dgl;
+        } else {
+          if (lane < n) h[hidx(lane, lane)] = dgl;
+          wave_sync();
+        }
       }
     }
     // bfgs_update (bfgs.h:52-66)
     const float yp = dot_lanes(y_r, p_r, n);
     if (!(alpha * yp < VEPS)) {
-      const float mhy_r = lane < n ? minus_h_times(h, y_r, n, row) : 0.f;
+      const float mhy_r = hreg ? minus_hrow_times(y_r) : (lane < n ? minus_h_times(h, y_r, n, row) : 0.f);
       const float yhy = -dot_lanes(y_r, mhy_r, n);
       const float r = 1 / (alpha * yp);
-      // row i of the upper triangle per pass, lane j >= i owns H(i, j); four rows per LDS latency
-      for (int i0 = 0; i0 < n; i0 += 4) {
-        float hv[4];
+      if (hreg) {
+        // H(i, j) += alpha r (mhy_i p_j + mhy_j p_i) + alpha alpha (r r yhy + r) p_lo p_hi, lo = min(i, j): lane i
+        // updates its whole row; the products keep the reference's operand order for the upper triangle
+        const float ar = alpha * r, c = alpha * alpha * (r * r * yhy + r);
+        const float cp_r = c * p_r;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u;
-          hv[u] = (i < n && lane >= i && lane < n) ? h[hidx(i, lane)] : 0.f;
+        for (int j0 = 0; j0 < kHReg; j0 += 4) {
+          if (j0 < n) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int j = j0 + u;
+              const float pj = rl(p_r, j), mj = rl(mhy_r, j), cpj = rl(cp_r, j);
+              const float t = mhy_r * pj + mj * p_r;
+              const float q = j >= lane ? cp_r * pj : cpj * p_r;
+              hrow[j] += ar * t + q;
+            }
+          }
         }
+      } else {
+        // row i of the upper triangle per pass, lane j >= i owns H(i, j); four rows per LDS latency
+        for (int i0 = 0; i0 < n; i0 += 4) {
+          float hv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u;
-          if (i < n) {
-            const float mi = rl(mhy_r, i), pi = rl(p_r, i);
-            const float upd = alpha * r * (mi * p_r + mhy_r * pi) + alpha * alpha * (r * r * yhy + r) * pi * p_r;
-            if (lane >= i && lane < n) h[hidx(i, lane)] = hv[u] + upd;
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            hv[u] = (i < n && lane >= i && lane < n) ? h[hidx(i, lane)] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            if (i < n) {
+              const float mi = rl(mhy_r, i), pi = rl(p_r, i);
+              const float upd = alpha * r * (mi * p_r + mhy_r * pi) + alpha * alpha * (r * r * yhy + r) * pi * p_r;
+              if (lane >= i && lane < n) h[hidx(i, lane)] = hv[u] + upd;
+            }
           }
         }
       }
@@ -1308,6 +1378,7 @@ void launch_vina_refine(const VinaEnv &env0, const VinaLigand &lig, float *confs
   VinaEnv env = env0;
   env.stage = want_stage(B) ? 1 : 0;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
+  big_lds(vina_refine_kernel);
   hipLaunchKernelGGL(vina_refine_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
                      tries);
 }
@@ -1606,16 +1677,11 @@ void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs
   env.stage = want_stage(B) ? 1 : 0;
   int W = vina_mc_team(B);
   size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, W);
-  while (W > 1 && lds > 144 * 1024) {  // very large ligands: fewer waves per chain
+  while (W > 1 && lds > kVinaMaxLds - 8 * 1024) {  // very large ligands: fewer waves per chain
     W /= 2;
     lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, W);
   }
-  static bool attr_set = false;
-  if (!attr_set) {  // more than the default 64 KB of dynamic LDS for large ligands at W = 4
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vina_mc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  big_lds(vina_mc_kernel);
   hipLaunchKernelGGL(vina_mc_kernel, dim3(B), dim3(64 * W), lds, s, env, lig, a);
 }
 
@@ -1663,18 +1729,18 @@ void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *co
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
   // with_deriv: 1 = model::eval_deriv, 0 = model::eval, 2 = cache::eval (grid term only)
+  auto go = [&](auto kernel) {
+    big_lds(kernel);
+    hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change, coords);
+  };
   if (with_deriv == 1)
-    hipLaunchKernelGGL(vina_eval_kernel<0>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
-                       coords);
+    go(vina_eval_kernel<0>);
   else if (with_deriv == 0)
-    hipLaunchKernelGGL(vina_eval_kernel<1>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
-                       coords);
+    go(vina_eval_kernel<1>);
   else if (with_deriv == 4)
-    hipLaunchKernelGGL(vina_eval_kernel<4>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
-                       coords);
+    go(vina_eval_kernel<4>);
   else
-    hipLaunchKernelGGL(vina_eval_kernel<2>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change,
-                       coords);
+    go(vina_eval_kernel<2>);
 }
 
 void launch_vina_bfgs(const VinaEnv &env0, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
@@ -1682,6 +1748,7 @@ void launch_vina_bfgs(const VinaEnv &env0, const VinaLigand &lig, float *confs, 
   VinaEnv env = env0;
   env.stage = want_stage(B) ? 1 : 0;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
+  big_lds(vina_bfgs_kernel);
   hipLaunchKernelGGL(vina_bfgs_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy, grad,
                      evals);
 }

@@ -295,7 +295,8 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
             1, "NULL array in ligand description");
   Vina &v = *reinterpret_cast<Vina *>(vv);
   const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
-  MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 64 * 1024, 1, "ligand too large for the per-wave LDS workspace");
+  MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 152 * 1024, 1,
+            "ligand too large for the per-wave LDS workspace (160 KB per workgroup)");
   MIG_CHECK(nn <= 57, 1, "more than 56 rotatable bonds: the minimiser keeps the 7 + T conformation entries one per lane");
   std::vector<int> node_of(na, -1);
   for (int k = 0; k < nn; k++) {
@@ -456,7 +457,7 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
             "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
   if (B == 0) return MI_OK;
   const int nt = v.lig.n_nodes - 1, nc = 7 + nt, nh = v.lig.n_heavy, S = P->num_saved;
-  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true, 1) <= 64 * 1024, 1,
+  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true, 1) <= 152 * 1024, 1,
             "ligand too large for the per-wave LDS workspace");
   v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
   v.d_mc_e.ensure((size_t)B * S);

@@ -249,3 +249,62 @@ def test_pdbqt_ligand_through_the_engine(capi, T):
     s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
     out = s.score_batch(coords, lig["smt"])
     assert np.isfinite(out["pose"]).all() and np.isfinite(out["affinity"]).all()
+
+
+def test_mc_output_is_independent_of_the_team_size(setup, capi, monkeypatch):
+    """The Monte-Carlo kernel runs W wavefronts per chain that evaluate the line-search trials of one search
+    at once and keep the first accepted trial in trial order (vina.hip, bfgs_wave): energies, conformations
+    and the reference-equivalent evaluation counts must be the same bits for W = 1, 2, 4."""
+    vina, S, sc, gd, types, grids = setup
+    c1, c2 = list(gd.begin), list(gd.end)
+    seeds = np.arange(500, 516, dtype=np.uint64)
+    P = capi.McParams.default(60, (25 + vina.n_atoms) // 3, 10)
+    ref = None
+    for w in ("1", "2", "4"):
+        monkeypatch.setenv("MI_VINA_MC_WAVES", w)
+        out = vina.mc_batch(seeds, c1, c2, P)
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), w
+    monkeypatch.delenv("MI_VINA_MC_WAVES")
+    assert (ref[4] > 60).all()
+
+
+@pytest.mark.parametrize("n_atoms,n_tors", [(60, 26), (140, 2)])
+def test_large_ligand_paths_match_oracle(capi, T, n_atoms, n_tors):
+    """Ligands past the register fast paths.  (60 atoms, 20 torsions): 6 + T = 26 > 24 variables, so the
+    inverse-Hessian estimate lives in LDS instead of registers, and ~1,500 interacting pairs = several groups of
+    pair look-ups per lane and a workspace above the default 64 KB of dynamic LDS.  (140 atoms, 2 torsions): the
+    grid look-ups of the atoms beyond the first 128 take the fused path, three atoms per lane."""
+    sc = vina_scene.build(3, n_rec=1500, n_atoms=n_atoms, n_tors=n_tors, pad=3.0)
+    lig = sc["lig"]
+    gd = V.setup_grid_dims(sc["center"], sc["size"])
+    types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+    grids = {t: V.cache_populate(T, gd, sc["rec_xyz"], sc["rec_smt"], t) for t in types}
+    S = V.Scene(T, gd, grids, V.LigandHandle(lig))
+    vina = capi.Vina()
+    vina.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    vina.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+    vina.set_ligand(lig)
+    assert len(lig["pairs"]) > 64 * 6 and (vina.n_tors >= 19 or n_atoms > 128)
+    rng = np.random.RandomState(5)
+    confs = np.stack([synth.random_conf(rng, lig, sc["center"], spread=0.5) for _ in range(6)] + [lig["conf0"]])
+    v = (10.0, 10.0, 10.0)
+    e, ch, co = vina.eval_batch(confs, v, deriv=True, want_coords=True)
+    for b in range(len(confs)):
+        e0, g0, c0, _ = S.eval_deriv(confs[b], v)
+        assert np.abs(co[b] - c0).max() < 2e-4
+        assert abs(e[b] - e0) <= 2e-4 * max(1.0, abs(e0)), (b, e[b], e0)
+        assert np.abs(ch[b] - g0).max() <= 2e-3 * max(1.0, np.abs(g0).max()), b
+    e1, cf1, g1, ev1 = vina.bfgs_batch(confs, v, max_iters=2)
+    same = 0
+    for b in range(len(confs)):
+        e0, c0, g0, ev0 = S.bfgs(confs[b], v, max_iters=2)
+        if ev1[b] == ev0 and abs(e1[b] - e0) <= 1e-3 * max(1.0, abs(e0)) and np.abs(cf1[b] - c0).max() < 1e-2:
+            same += 1
+    assert same >= len(confs) - 2, same
+    n, em, cfm, xyz, ev = vina.mc_batch(np.arange(3, dtype=np.uint64), list(gd.begin), list(gd.end),
+                                        capi.McParams.default(3, 4, 4))
+    assert (n >= 1).all() and np.isfinite(em[:, 0]).all()
