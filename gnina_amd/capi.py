@@ -26,6 +26,7 @@ SYMBOLS = [
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
+    "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs", "mi_vina_eval_latency",
 ]
 
@@ -180,6 +181,14 @@ def lib():
         L.mi_vina_bfgs_batch.restype = C.c_int
         L.mi_vina_mc_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(McParams), vp, vp, vp, vp, vp]
         L.mi_vina_mc_batch.restype = C.c_int
+        L.mi_vina_set_screen.argtypes = [vp, C.c_int, vp]
+        L.mi_vina_set_screen.restype = C.c_int
+        L.mi_vina_screen_size.argtypes = [vp]
+        L.mi_vina_screen_size.restype = C.c_int
+        L.mi_vina_screen_dims.argtypes = [vp, i32p, i32p]
+        L.mi_vina_screen_dims.restype = C.c_int
+        L.mi_vina_mc_screen.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.mi_vina_mc_screen.restype = C.c_int
         L.mi_vina_ligand_heavy_atoms.argtypes = [vp]
         L.mi_vina_ligand_heavy_atoms.restype = C.c_int
         L.mi_vina_refine_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp]
@@ -518,6 +527,41 @@ class Vina:
                        len(a["pairs"]), _ptr(a["pairs"]))
         check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
         self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
+
+    def set_screen(self, ligs):
+        """mi_vina_set_screen: the ligands of a screen, resident together (see mc_screen)"""
+        keep, descs = [], (LigandDesc * len(ligs))()
+        for i, lig in enumerate(ligs):
+            a = {k: np.ascontiguousarray(lig[k]) for k in
+                 ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs")}
+            keep.append(a)
+            descs[i] = LigandDesc(len(a["smt"]), _ptr(a["smt"]), _ptr(a["local_xyz"]), len(a["parent"]), _ptr(a["parent"]),
+                                  _ptr(a["abeg"]), _ptr(a["aend"]), _ptr(a["rel_origin"]), _ptr(a["rel_axis"]),
+                                  len(a["pairs"]), _ptr(a["pairs"]))
+        check(lib().mi_vina_set_screen(self.handle, len(ligs), C.cast(descs, C.c_void_p)))
+        mc, mh = C.c_int32(), C.c_int32()
+        check(lib().mi_vina_screen_dims(self.handle, C.byref(mc), C.byref(mh)))
+        self.screen_conf, self.screen_heavy = mc.value, mh.value
+        self.screen_tors = [len(a["parent"]) - 1 for a in keep]
+        self.screen_nheavy = [int((a["smt"] > 1).sum()) for a in keep]
+
+    def mc_screen(self, chain_ligand, seeds, corner1, corner2, params):
+        """mi_vina_mc_screen: chain b docks ligand chain_ligand[b]; params = one McParams per ligand.
+        -> (n [B], e [B,S], confs [B,S,max_conf], coords [B,S,max_heavy,3], evals [B]); a chain of ligand l fills
+        confs[..., :7+T_l] and coords[..., :3*n_heavy_l] of the flattened last two axes."""
+        chain_ligand = np.ascontiguousarray(chain_ligand, dtype=np.int32)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        B, S = len(seeds), params[0].num_saved
+        P = (McParams * len(params))(*params)
+        c1, c2 = _f32(corner1), _f32(corner2)
+        n = np.zeros(B, dtype=np.int32)
+        e = np.zeros((B, S), dtype=np.float32)
+        cf = np.zeros((B, S, self.screen_conf), dtype=np.float32)
+        xyz = np.zeros((B, S, self.screen_heavy * 3), dtype=np.float32)
+        ev = np.zeros(B, dtype=np.int32)
+        check(lib().mi_vina_mc_screen(self.handle, B, _ptr(chain_ligand), _ptr(seeds), _ptr(c1), _ptr(c2),
+                                      C.cast(P, C.c_void_p), _ptr(n), _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev)))
+        return n, e, cf, xyz, ev
 
     def eval_latency_us(self, confs, mode, reps=200):
         confs = _f32(confs).reshape(-1, 7 + self.n_tors)

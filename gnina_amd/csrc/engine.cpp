@@ -1526,6 +1526,10 @@ int mi_gnina_device_count(void) {
 
 mi_status mi_gnina_init(int device) {
   MI_TRY
+  // Scorers and mi_vina handles each own a HIP stream so that independent ligands overlap on the device.  The
+  // HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its
+  // kernels in order: ask for 16 unless the user chose (only effective before the first HIP call of the process).
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int n = 0;
   MIG_HIP(hipGetDeviceCount(&n));
   MIG_CHECK(n > 0, 3, "no HIP device visible");

@@ -69,7 +69,12 @@ struct VinaMcArgs {
   float *scratch_e, *scratch_conf, *scratch_coords;  // per-chain physical container
   float *out_e, *out_conf, *out_coords;              // sorted output [B][num_saved]...
   int *out_n, *evals;
-  long long *prof;  // optional [B][8] phase timing, see vina_mc_kernel
+  long long *prof;  // optional [B][12] phase timing, see vina_mc_kernel
+  // screen mode (mi_vina_mc_screen): chain b docks ligand chain_lig[b] of `ligs` with its own step / iteration
+  // counts; containers use the common strides below (floats per saved conformation / coordinate set)
+  const VinaLigand *ligs;
+  const int *chain_lig, *lig_steps, *lig_iters;
+  int conf_stride, coord_stride;
 };
 
 struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN loss + per-atom gradient)
@@ -110,6 +115,7 @@ void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
 size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage, int waves_per_chain);
 int vina_mc_team(int B);  // waves per chain the Monte-Carlo kernel uses for B chains
+// `lig` sizes the LDS workspace (screen mode: counts = the maxima over the set, pointers unused)
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);
 void launch_vina_bfgs(const VinaEnv &env, const VinaLigand &lig, float *confs, int B, float v0, float v1, float v2,
                       int max_iters, float *energy, float *grad, int *evals, hipStream_t s);

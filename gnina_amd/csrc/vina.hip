@@ -1430,6 +1430,12 @@ struct McRng {
 __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  if (a.ligs) {  // screen mode: this chain's ligand and search length
+    const int l = a.chain_lig[blockIdx.x];
+    L = a.ligs[l];
+    a.n_steps = a.lig_steps[l];
+    a.max_iters = a.lig_iters[l];
+  }
   if (env.stage) L = stage_ligand(L, pp);
   const int W = blockDim.x >> 6, wv = threadIdx.x >> 6;
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt, nh = L.n_heavy;
@@ -1460,8 +1466,9 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   int evals = 0;
   // scratch container of this chain (physical slots)
   float *s_e = a.scratch_e + (size_t)b * a.num_saved;
-  float *s_conf = a.scratch_conf + (size_t)b * a.num_saved * nc;
-  float *s_xyz = a.scratch_coords + (size_t)b * a.num_saved * 3 * nh;
+  const int cs_ = a.conf_stride, xs_ = a.coord_stride;  // >= nc, >= 3 nh
+  float *s_conf = a.scratch_conf + (size_t)b * a.num_saved * cs_;
+  float *s_xyz = a.scratch_coords + (size_t)b * a.num_saved * xs_;
 
   // conf::randomize (conf.h:119-122,189-192): every lane draws the same numbers
   {
@@ -1576,7 +1583,7 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
         if (wv == 0) {  // the container belongs to wave 0; wsync() orders its lanes' LDS / global accesses
           // add_to_output_container (coords.cpp:25-56): rmsd to every saved pose, one pose per lane
           for (int o = lane; o < n_out; o += 64) {
-            const float *ref = s_xyz + (size_t)ord[o] * 3 * nh;
+            const float *ref = s_xyz + (size_t)ord[o] * xs_;
             float acc = 0.f;
             for (int i = 0; i < 3 * nh; i++) {
               const float d = hc[i] - ref[i];
@@ -1608,8 +1615,8 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
           if (pos >= 0) {
             const int phys = ord[pos];
             if (lane == 0) s_e[phys] = tmp_e;
-            for (int i = lane; i < nc; i += 64) s_conf[(size_t)phys * nc + i] = tmp[i];
-            for (int i = lane; i < 3 * nh; i += 64) s_xyz[(size_t)phys * 3 * nh + i] = hc[i];
+            for (int i = lane; i < nc; i += 64) s_conf[(size_t)phys * cs_ + i] = tmp[i];
+            for (int i = lane; i < 3 * nh; i += 64) s_xyz[(size_t)phys * xs_ + i] = hc[i];
             wsync();
             if (lane == 0) {  // out.sort(): keep `ord` ordered by energy
               int o = pos;
@@ -1644,9 +1651,9 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   for (int o = 0; o < n_out; o++) {
     const int phys = ord[o];
     if (lane == 0) a.out_e[(size_t)b * a.num_saved + o] = s_e[phys];
-    for (int i = lane; i < nc; i += 64) a.out_conf[((size_t)b * a.num_saved + o) * nc + i] = s_conf[(size_t)phys * nc + i];
+    for (int i = lane; i < nc; i += 64) a.out_conf[((size_t)b * a.num_saved + o) * cs_ + i] = s_conf[(size_t)phys * cs_ + i];
     for (int i = lane; i < 3 * nh; i += 64)
-      a.out_coords[((size_t)b * a.num_saved + o) * 3 * nh + i] = s_xyz[(size_t)phys * 3 * nh + i];
+      a.out_coords[((size_t)b * a.num_saved + o) * xs_ + i] = s_xyz[(size_t)phys * xs_ + i];
   }
   if (lane == 0) {
     a.out_n[b] = n_out;
@@ -1672,9 +1679,15 @@ size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int
   return (ligand + 2 * pad4(W) + 4 + W * wave) * sizeof(float);
 }
 
-void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s) {
+void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs &a0, int B, hipStream_t s) {
   VinaEnv env = env0;
+  VinaMcArgs a = a0;
   env.stage = want_stage(B) ? 1 : 0;
+  if (!a.ligs) {
+    a.conf_stride = 7 + lig.n_nodes - 1;
+    a.coord_stride = 3 * lig.n_heavy;
+  }
+  // `lig` sizes the workspace (screen mode: a synthetic description holding the maxima of the set)
   int W = vina_mc_team(B);
   size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, W);
   while (W > 1 && lds > kVinaMaxLds - 8 * 1024) {  // very large ligands: fewer waves per chain

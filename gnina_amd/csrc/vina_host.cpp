@@ -57,6 +57,14 @@ static float pair_energy(const float *w, int t1, int t2, float r) {
   return acc;
 }
 
+// one ligand's description on the device (arrays + the struct of pointers the kernels take)
+struct LigandDev {
+  VinaLigand lig{};
+  std::vector<int32_t> h_smt;
+  DevBuf<int> d_int;
+  DevBuf<float> d_flt;
+};
+
 struct Vina {
   hipStream_t stream = nullptr;
   // tables (host copies kept for mi_vina_table)
@@ -81,8 +89,11 @@ struct Vina {
   bool have_lig = false;
   VinaLigand lig{};
   std::vector<int32_t> h_lig_smt;  // host copy of the ligand atom types (CNN-in-the-loop calls type the ligand with them)
-  DevBuf<int> d_int;
-  DevBuf<float> d_flt;
+  LigandDev one;                   // storage behind `lig` (mi_vina_set_ligand)
+  // screen: many ligands resident at once, docked by one launch (mi_vina_set_screen / mi_vina_mc_screen)
+  std::vector<std::unique_ptr<LigandDev>> screen;
+  DevBuf<VinaLigand> d_screen;
+  DevBuf<int> d_chain_lig, d_lig_steps, d_lig_iters;
   // scratch
   DevBuf<float> d_confs, d_energy, d_change, d_coords;
   DevBuf<float> d_ext_forces, d_ext_e, d_ext_centers;
@@ -287,13 +298,11 @@ mi_status mi_vina_cache_grid(mi_vina *vv, int smt, float *out, size_t n_floats) 
   VCATCH_STATUS
 }
 
-mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
-  VTRY
-  MIG_CHECK(vv && d && d->n_atoms > 0 && d->n_nodes > 0 && d->n_pairs >= 0, 1, "bad ligand description");
+static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t stream) {
+  MIG_CHECK(d && d->n_atoms > 0 && d->n_nodes > 0 && d->n_pairs >= 0, 1, "bad ligand description");
   MIG_CHECK(d->smt && d->local_xyz && d->node_parent && d->node_atom_begin && d->node_atom_end &&
                 d->node_rel_origin && d->node_rel_axis && (d->n_pairs == 0 || d->pairs),
             1, "NULL array in ligand description");
-  Vina &v = *reinterpret_cast<Vina *>(vv);
   const int na = d->n_atoms, nn = d->n_nodes, np = d->n_pairs;
   MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 152 * 1024, 1,
             "ligand too large for the per-wave LDS workspace (160 KB per workgroup)");
@@ -360,30 +369,74 @@ mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
   };
   const size_t o_loc = pushf(d->local_xyz, 3 * (size_t)na), o_ro = pushf(d->node_rel_origin, 3 * (size_t)nn),
                o_ra = pushf(d->node_rel_axis, 3 * (size_t)nn);
-  v.d_int.upload(ints.data(), ints.size(), v.stream);
-  v.d_flt.upload(flts.data(), flts.size(), v.stream);
-  MIG_HIP(hipStreamSynchronize(v.stream));
-  v.h_lig_smt.assign(d->smt, d->smt + na);
-  VinaLigand &L = v.lig;
+  out.d_int.upload(ints.data(), ints.size(), stream);
+  out.d_flt.upload(flts.data(), flts.size(), stream);
+  MIG_HIP(hipStreamSynchronize(stream));
+  out.h_smt.assign(d->smt, d->smt + na);
+  VinaLigand &L = out.lig;
   L.n_atoms = na;
   L.n_nodes = nn;
   L.n_pairs = np;
-  L.smt = v.d_int.p + o_smt;
-  L.node_of_atom = v.d_int.p + o_node;
-  L.parent = v.d_int.p + o_par;
-  L.abeg = v.d_int.p + o_abeg;
-  L.aend = v.d_int.p + o_aend;
-  L.child_start = v.d_int.p + o_cs;
-  L.child_list = v.d_int.p + o_cl;
-  L.pairs = reinterpret_cast<const int2 *>(v.d_int.p + o_pairs);
-  L.slot_start = v.d_int.p + o_aps;
-  L.pair_slots = reinterpret_cast<const int2 *>(v.d_int.p + o_apl);
+  L.smt = out.d_int.p + o_smt;
+  L.node_of_atom = out.d_int.p + o_node;
+  L.parent = out.d_int.p + o_par;
+  L.abeg = out.d_int.p + o_abeg;
+  L.aend = out.d_int.p + o_aend;
+  L.child_start = out.d_int.p + o_cs;
+  L.child_list = out.d_int.p + o_cl;
+  L.pairs = reinterpret_cast<const int2 *>(out.d_int.p + o_pairs);
+  L.slot_start = out.d_int.p + o_aps;
+  L.pair_slots = reinterpret_cast<const int2 *>(out.d_int.p + o_apl);
   L.n_heavy = (int)heavy.size();
-  L.heavy_list = v.d_int.p + o_heavy;
-  L.local_xyz = v.d_flt.p + o_loc;
-  L.rel_origin = v.d_flt.p + o_ro;
-  L.rel_axis = v.d_flt.p + o_ra;
+  L.heavy_list = out.d_int.p + o_heavy;
+  L.local_xyz = out.d_flt.p + o_loc;
+  L.rel_origin = out.d_flt.p + o_ro;
+  L.rel_axis = out.d_flt.p + o_ra;
+}
+
+
+mi_status mi_vina_set_ligand(mi_vina *vv, const mi_ligand_desc *d) {
+  VTRY
+  MIG_CHECK(vv && d, 1, "bad ligand description");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  build_ligand(d, v.one, v.stream);
+  v.lig = v.one.lig;
+  v.h_lig_smt = v.one.h_smt;
   v.have_lig = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_set_screen(mi_vina *vv, int n_lig, const mi_ligand_desc *descs) {
+  VTRY
+  MIG_CHECK(vv && n_lig >= 0 && (n_lig == 0 || descs), 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  v.screen.clear();
+  std::vector<VinaLigand> h(n_lig);
+  for (int l = 0; l < n_lig; l++) {
+    v.screen.emplace_back(new LigandDev());
+    build_ligand(descs + l, *v.screen.back(), v.stream);
+    h[l] = v.screen.back()->lig;
+  }
+  if (n_lig) v.d_screen.upload(h.data(), h.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+int mi_vina_screen_size(const mi_vina *vv) { return vv ? (int)reinterpret_cast<const Vina *>(vv)->screen.size() : 0; }
+
+mi_status mi_vina_screen_dims(const mi_vina *vv, int32_t *max_conf, int32_t *max_heavy) {
+  VTRY
+  MIG_CHECK(vv && max_conf && max_heavy, 1, "bad arguments");
+  const Vina &v = *reinterpret_cast<const Vina *>(vv);
+  int mc = 0, mh = 0;
+  for (const auto &l : v.screen) {
+    mc = std::max(mc, 7 + l->lig.n_nodes - 1);
+    mh = std::max(mh, l->lig.n_heavy);
+  }
+  *max_conf = mc;
+  *max_heavy = mh;
   return MI_OK;
   VCATCH_STATUS
 }
@@ -519,6 +572,87 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
     MIG_HIP(hipMemcpyAsync(out_conf, v.d_mc_conf.p, (size_t)B * S * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
   if (out_coords && nh > 0)
     MIG_HIP(hipMemcpyAsync(out_coords, v.d_mc_xyz.p, (size_t)B * S * 3 * nh * sizeof(float), hipMemcpyDeviceToHost,
+                           v.stream));
+  if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_mc_screen(mi_vina *vv, int B, const int32_t *chain_ligand, const uint64_t *seeds, const float *corner1,
+                            const float *corner2, const mi_mc_params *P, int32_t *out_n, float *out_e, float *out_conf,
+                            float *out_coords, int32_t *evals) {
+  VTRY
+  MIG_CHECK(vv && chain_ligand && seeds && corner1 && corner2 && P && out_n && out_e && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  const int nl = (int)v.screen.size();
+  MIG_CHECK(v.have_cache && nl > 0, 4, "build the cache and set the screen's ligands first");
+  const int S = P[0].num_saved;
+  MIG_CHECK(S > 0 && S <= 64 && P[0].temperature > 0, 1, "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
+  if (B == 0) return MI_OK;
+  VinaLigand big{};  // the maxima over the set size the LDS workspace and the container strides
+  std::vector<int> steps(nl), iters(nl);
+  for (int l = 0; l < nl; l++) {
+    const VinaLigand &L = v.screen[l]->lig;
+    big.n_atoms = std::max(big.n_atoms, L.n_atoms);
+    big.n_nodes = std::max(big.n_nodes, L.n_nodes);
+    big.n_pairs = std::max(big.n_pairs, L.n_pairs);
+    big.n_heavy = std::max(big.n_heavy, L.n_heavy);
+    MIG_CHECK(P[l].num_saved == S && P[l].n_steps >= 0 && P[l].max_iters >= 0, 1,
+              "every ligand of a screen uses the same num_saved");
+    steps[l] = P[l].n_steps;
+    iters[l] = P[l].max_iters;
+  }
+  for (int b = 0; b < B; b++) MIG_CHECK(chain_ligand[b] >= 0 && chain_ligand[b] < nl, 1, "chain_ligand out of range");
+  const int ncm = 7 + big.n_nodes - 1, nhm = big.n_heavy;
+  MIG_CHECK(vina_mc_lds_bytes(big.n_atoms, big.n_nodes, big.n_pairs, nhm, S, true, 1) <= 152 * 1024, 1,
+            "ligands too large for the per-wave LDS workspace");
+  v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
+  v.d_chain_lig.upload(chain_ligand, B, v.stream);
+  v.d_lig_steps.upload(steps.data(), nl, v.stream);
+  v.d_lig_iters.upload(iters.data(), nl, v.stream);
+  v.d_mc_e.ensure((size_t)B * S);
+  v.d_mc_conf.ensure((size_t)B * S * ncm);
+  v.d_mc_xyz.ensure((size_t)B * S * 3 * nhm + 1);
+  v.d_sc_e.ensure((size_t)B * S);
+  v.d_sc_conf.ensure((size_t)B * S * ncm);
+  v.d_sc_xyz.ensure((size_t)B * S * 3 * nhm + 1);
+  v.d_out_n.ensure(B);
+  v.d_evals.ensure(B);
+  VinaMcArgs a{};
+  a.num_saved = S;
+  a.temperature = P[0].temperature;
+  a.amplitude = P[0].mutation_amplitude;
+  a.min_rmsd = P[0].min_rmsd;
+  for (int i = 0; i < 3; i++) {
+    a.hunt[i] = P[0].hunt_cap[i];
+    a.auth[i] = P[0].authentic_v[i];
+    a.c1[i] = corner1[i];
+    a.c2[i] = corner2[i];
+  }
+  a.seeds = v.d_seeds.p;
+  a.scratch_e = v.d_sc_e.p;
+  a.scratch_conf = v.d_sc_conf.p;
+  a.scratch_coords = v.d_sc_xyz.p;
+  a.out_e = v.d_mc_e.p;
+  a.out_conf = v.d_mc_conf.p;
+  a.out_coords = v.d_mc_xyz.p;
+  a.out_n = v.d_out_n.p;
+  a.evals = v.d_evals.p;
+  a.ligs = v.d_screen.p;
+  a.chain_lig = v.d_chain_lig.p;
+  a.lig_steps = v.d_lig_steps.p;
+  a.lig_iters = v.d_lig_iters.p;
+  a.conf_stride = ncm;
+  a.coord_stride = 3 * nhm;
+  launch_vina_mc(make_env(v), big, a, B, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(out_n, v.d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(out_e, v.d_mc_e.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_conf)
+    MIG_HIP(hipMemcpyAsync(out_conf, v.d_mc_conf.p, (size_t)B * S * ncm * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_coords && nhm > 0)
+    MIG_HIP(hipMemcpyAsync(out_coords, v.d_mc_xyz.p, (size_t)B * S * 3 * nhm * sizeof(float), hipMemcpyDeviceToHost,
                            v.stream));
   if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
   MIG_HIP(hipStreamSynchronize(v.stream));

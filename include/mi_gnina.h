@@ -46,7 +46,10 @@ enum {
 
 /* ---- process / thread setup --------------------------------------------------------------
  * Replaces initializeCUDA(int device) (gninasrc/lib/dl_scorer.h:20-21, called main.cpp:753 and
- * parallel_mc.cpp:197): must be called in every host thread that uses the engine. */
+ * parallel_mc.cpp:197): must be called in every host thread that uses the engine.
+ * Every scorer / mi_vina handle owns a HIP stream; handles driven from different host threads overlap on the
+ * device as far as the runtime has hardware queues, so the first call also sets GPU_MAX_HW_QUEUES=16 (HIP's
+ * default is 4) unless the variable is already set -- effective only before the process's first HIP call. */
 mi_status mi_gnina_init(int device);
 int mi_gnina_device_count(void);
 int mi_gnina_abi_version(void);
@@ -254,6 +257,22 @@ mi_status mi_vina_mc_batch(mi_vina *, int B, const uint64_t *seeds, const float 
                            const mi_mc_params *params, int32_t *out_n, float *out_e, float *out_conf,
                            float *out_coords, int32_t *evals);
 int mi_vina_ligand_heavy_atoms(const mi_vina *);
+/* Virtual screening: MANY ligands docked by ONE launch.  gnina docks the ligands of a screen one after the other,
+ * `exhaustiveness` chains each on a thread pool (main.cpp:1001-1075 ligand loop, parallel_mc.cpp:183-214); one
+ * ligand's 8 chains occupy a sliver of the device and streams of different handles only overlap as far as the
+ * runtime has hardware queues, so the screen's chains are put into one grid instead: chain b docks ligand
+ * chain_ligand[b] of the set given to mi_vina_set_screen, with that ligand's own n_steps / max_iters
+ * (params[l], l < n_lig; num_saved must agree; temperature, amplitude, min_rmsd and the caps are taken from
+ * params[0]).  Same search box, receptor and cache grids for all (build the cache for the union of the ligands'
+ * atom types).  Outputs as mi_vina_mc_batch with common strides: out_conf [B][num_saved][max_conf], out_coords
+ * [B][num_saved][max_heavy][3] (mi_vina_screen_dims); a chain of ligand l fills the first 7+T_l / n_heavy_l*3
+ * floats of its rows.  A chain's result is bit-identical to mi_vina_mc_batch of that ligand with the same seed. */
+mi_status mi_vina_set_screen(mi_vina *, int n_lig, const mi_ligand_desc *descs);
+int mi_vina_screen_size(const mi_vina *);
+mi_status mi_vina_screen_dims(const mi_vina *, int32_t *max_conf, int32_t *max_heavy);
+mi_status mi_vina_mc_screen(mi_vina *, int B, const int32_t *chain_ligand, const uint64_t *seeds, const float *corner1,
+                            const float *corner2, const mi_mc_params *params, int32_t *out_n, float *out_e,
+                            float *out_conf, float *out_coords, int32_t *evals);
 /* do_search's ranking tail (main.cpp:348-361): sort (pose_sort_order: CNNscore / CNNaffinity descending,
  * Energy ascending) then remove_redundant(out_cont, out_min_rmsd) (main.cpp:182-192).  Host only.
  * coords [n_poses][n_heavy][3]; order_out [n_poses] receives the kept pose indices, best first. */

@@ -308,3 +308,43 @@ def test_large_ligand_paths_match_oracle(capi, T, n_atoms, n_tors):
     n, em, cfm, xyz, ev = vina.mc_batch(np.arange(3, dtype=np.uint64), list(gd.begin), list(gd.end),
                                         capi.McParams.default(3, 4, 4))
     assert (n >= 1).all() and np.isfinite(em[:, 0]).all()
+
+
+def test_screen_launch_matches_per_ligand_chains(capi, T):
+    """mi_vina_mc_screen docks the chains of several different ligands in ONE launch; every chain must give the
+    same bits as mi_vina_mc_batch of its ligand with the same seed (per-ligand step / iteration counts,
+    containers at the common strides)."""
+    sc = vina_scene.build(0)
+    rng = np.random.RandomState(3)
+    ligs = []
+    for na, nt in ((18, 2), (32, 6), (26, 9)):
+        lig = synth.make_ligand_tree(rng, na, nt)
+        shift = -lig["coords0"].mean(0)
+        lig["coords0"] = (lig["coords0"] + shift).astype(np.float32)
+        lig["conf0"][:3] += shift
+        ligs.append(lig)
+    gd = V.setup_grid_dims(np.zeros(3, np.float32), np.full(3, 18.0, np.float32))
+    types = sorted({int(t) for lig in ligs for t in lig["smt"] if t > 1})
+    vina = capi.Vina()
+    vina.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    vina.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+    c1, c2 = list(gd.begin), list(gd.end)
+    params = [capi.McParams.default(20 + 7 * l, (25 + len(lig["smt"])) // 3, 6) for l, lig in enumerate(ligs)]
+    chain_lig = np.array([0, 1, 2, 2, 1, 0, 1], dtype=np.int32)
+    seeds = np.arange(900, 900 + len(chain_lig), dtype=np.uint64)
+    vina.set_screen(ligs)
+    n, e, cf, xyz, ev = vina.mc_screen(chain_lig, seeds, c1, c2, params)
+    assert (n >= 1).all()
+    for l, lig in enumerate(ligs):
+        vina.set_ligand(lig)
+        idx = np.nonzero(chain_lig == l)[0]
+        n1, e1, cf1, xyz1, ev1 = vina.mc_batch(seeds[idx], c1, c2, params[l])
+        nc, nh3 = 7 + lig["n_tors"], 3 * int((lig["smt"] > 1).sum())
+        assert np.array_equal(n[idx], n1) and np.array_equal(ev[idx], ev1)
+        for k, b in enumerate(idx):                       # rows beyond n are unspecified
+            m = n1[k]
+            assert np.array_equal(e[b, :m], e1[k, :m])
+            assert np.array_equal(cf[b, :m, :nc], cf1[k, :m])
+            assert np.array_equal(xyz[b, :m, :nh3], xyz1[k, :m].reshape(m, nh3))
+    with pytest.raises(capi.MiGninaError):
+        vina.mc_screen(np.array([3], np.int32), seeds[:1], c1, c2, params)      # ligand index out of range
