@@ -27,6 +27,7 @@ SYMBOLS = [
     "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
+    "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
     "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs", "mi_vina_eval_latency",
 ]
 
@@ -185,10 +186,16 @@ def lib():
         L.mi_vina_set_screen.restype = C.c_int
         L.mi_vina_screen_size.argtypes = [vp]
         L.mi_vina_screen_size.restype = C.c_int
-        L.mi_vina_screen_dims.argtypes = [vp, i32p, i32p]
+        L.mi_vina_screen_dims.argtypes = [vp, i32p, i32p, i32p]
         L.mi_vina_screen_dims.restype = C.c_int
         L.mi_vina_mc_screen.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mi_vina_mc_screen.restype = C.c_int
+        L.mi_vina_eval_screen.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.mi_vina_eval_screen.restype = C.c_int
+        L.mi_vina_refine_screen.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi_vina_refine_screen.restype = C.c_int
+        L.mi_vina_final_energies_screen.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi_vina_final_energies_screen.restype = C.c_int
         L.mi_vina_ligand_heavy_atoms.argtypes = [vp]
         L.mi_vina_ligand_heavy_atoms.restype = C.c_int
         L.mi_vina_refine_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp]
@@ -539,9 +546,10 @@ class Vina:
                                   _ptr(a["abeg"]), _ptr(a["aend"]), _ptr(a["rel_origin"]), _ptr(a["rel_axis"]),
                                   len(a["pairs"]), _ptr(a["pairs"]))
         check(lib().mi_vina_set_screen(self.handle, len(ligs), C.cast(descs, C.c_void_p)))
-        mc, mh = C.c_int32(), C.c_int32()
-        check(lib().mi_vina_screen_dims(self.handle, C.byref(mc), C.byref(mh)))
-        self.screen_conf, self.screen_heavy = mc.value, mh.value
+        mc, mh, ma = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().mi_vina_screen_dims(self.handle, C.byref(mc), C.byref(mh), C.byref(ma)))
+        self.screen_conf, self.screen_heavy, self.screen_atoms = mc.value, mh.value, ma.value
+        self.screen_natoms = [len(a["smt"]) for a in keep]
         self.screen_tors = [len(a["parent"]) - 1 for a in keep]
         self.screen_nheavy = [int((a["smt"] > 1).sum()) for a in keep]
 
@@ -562,6 +570,43 @@ class Vina:
         check(lib().mi_vina_mc_screen(self.handle, B, _ptr(chain_ligand), _ptr(seeds), _ptr(c1), _ptr(c2),
                                       C.cast(P, C.c_void_p), _ptr(n), _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev)))
         return n, e, cf, xyz, ev
+
+    def eval_screen(self, item_ligand, confs, v=(1000.0, 1000.0, 1000.0), deriv=True, want_coords=False):
+        """mi_vina_eval_screen: confs [B, max_conf] -> (e [B], change [B, max_conf-1] or None, coords [B, max_atoms, 3] or None)"""
+        item_ligand = np.ascontiguousarray(item_ligand, dtype=np.int32)
+        confs = _f32(confs).reshape(-1, self.screen_conf)
+        B = len(confs)
+        vv = _f32(v)
+        e = np.empty(B, dtype=np.float32)
+        ch = np.zeros((B, self.screen_conf - 1), dtype=np.float32) if deriv else None
+        co = np.zeros((B, self.screen_atoms, 3), dtype=np.float32) if want_coords else None
+        check(lib().mi_vina_eval_screen(self.handle, _ptr(item_ligand), _ptr(confs), B, _ptr(vv), int(deriv), _ptr(e),
+                                        _ptr(ch), _ptr(co)))
+        return e, ch, co
+
+    def refine_screen(self, item_ligand, confs, max_iters, v=(1000.0, 1000.0, 1000.0)):
+        """mi_vina_refine_screen: confs [B, max_conf] (copied), max_iters per ligand -> (e, confs, tries)"""
+        item_ligand = np.ascontiguousarray(item_ligand, dtype=np.int32)
+        confs = np.array(_f32(confs).reshape(-1, self.screen_conf), copy=True)
+        B = len(confs)
+        mi = np.ascontiguousarray(max_iters, dtype=np.int32)
+        vv = _f32(v)
+        e = np.empty(B, dtype=np.float32)
+        tries = np.empty(B, dtype=np.int32)
+        check(lib().mi_vina_refine_screen(self.handle, _ptr(item_ligand), _ptr(confs), B, _ptr(vv), _ptr(mi), _ptr(e),
+                                          _ptr(tries)))
+        return e, confs, tries
+
+    def final_energies_screen(self, item_ligand, confs, num_tors, v=(1000.0, 1000.0, 1000.0)):
+        item_ligand = np.ascontiguousarray(item_ligand, dtype=np.int32)
+        confs = _f32(confs).reshape(-1, self.screen_conf)
+        B = len(confs)
+        nt = _f32(num_tors)
+        vv = _f32(v)
+        e, intra = np.empty(B, dtype=np.float32), np.empty(B, dtype=np.float32)
+        check(lib().mi_vina_final_energies_screen(self.handle, _ptr(item_ligand), _ptr(confs), B, _ptr(vv), _ptr(nt),
+                                                  _ptr(e), _ptr(intra)))
+        return e, intra
 
     def eval_latency_us(self, confs, mode, reps=200):
         confs = _f32(confs).reshape(-1, 7 + self.n_tors)

@@ -37,6 +37,12 @@ struct VinaEnv {
   int n_rec;
   float w5[5];
   float box_begin[3], box_end[3];
+  // screen mode of the batch kernels (mi_vina_*_screen): item b is a conformation of ligand item_lig[b] of `ligs`;
+  // rows of confs / change / coords are then strided by the maxima over the set
+  const struct VinaLigand *ligs;
+  const int *item_lig;
+  const int *lig_iters;  // refine: per-ligand BFGS iteration cap
+  int conf_stride, change_stride, coord_stride;
 };
 
 struct VinaLigand {

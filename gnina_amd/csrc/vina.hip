@@ -798,19 +798,22 @@ __global__ __launch_bounds__(64) void vina_eval_kernel(VinaEnv env, VinaLigand L
                                                        float *coords_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *p = lds;
+  if (env.ligs) L = env.ligs[env.item_lig[blockIdx.x]];
   WaveWork w = carve_work(p, L);
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  const size_t cs = env.ligs ? env.conf_stride : nc, gs = env.ligs ? env.change_stride : n,
+               xs = env.ligs ? env.coord_stride : 3 * L.n_atoms;
   float *conf = carve(p, nc);
   float *change = carve(p, n);
   const int b = blockIdx.x, lane = threadIdx.x;
-  for (int i = lane; i < nc; i += 64) conf[i] = confs[(size_t)b * nc + i];
+  for (int i = lane; i < nc; i += 64) conf[i] = confs[b * cs + i];
   wave_sync();
   const float e = eval_conf<MODE>(env, L, conf, v0, v1, v2, w, change);
   if (lane == 0) energy[b] = e;
   if (MODE == 0 && change_out)
-    for (int i = lane; i < n; i += 64) change_out[(size_t)b * n + i] = change[i];
+    for (int i = lane; i < n; i += 64) change_out[b * gs + i] = change[i];
   if (coords_out)
-    for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[(size_t)b * 3 * L.n_atoms + i] = w.coords[i];
+    for (int i = lane; i < 3 * L.n_atoms; i += 64) coords_out[b * xs + i] = w.coords[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1339,13 +1342,19 @@ __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand
                                                          float v2, int max_iters, float *energy, int *tries_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  if (env.ligs) {
+    const int l = env.item_lig[blockIdx.x];
+    L = env.ligs[l];
+    max_iters = env.lig_iters[l];
+  }
   if (env.stage) L = stage_ligand(L, pp);
   WaveWork w = carve_work(pp, L);
   const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt;
+  const size_t cs = env.ligs ? env.conf_stride : nc;
   BfgsWork k = carve_bfgs(pp, n, nc);
   const int b = blockIdx.x, lane = threadIdx.x;
   int evals = 0;
-  for (int i = lane; i < nc; i += 64) k.x[i] = confs[(size_t)b * nc + i];
+  for (int i = lane; i < nc; i += 64) k.x[i] = confs[b * cs + i];
   wave_sync();
   env.direct = 1;
   float slope = 10.f, e = 0.f;
@@ -1366,7 +1375,7 @@ __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand
     wave_sync();
   }
   if (!inside) e = VMAXFL;
-  for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = k.x[i];
+  for (int i = lane; i < nc; i += 64) confs[b * cs + i] = k.x[i];
   if (lane == 0) {
     energy[b] = e;
     if (tries_out) tries_out[b] = tries;

@@ -426,17 +426,100 @@ mi_status mi_vina_set_screen(mi_vina *vv, int n_lig, const mi_ligand_desc *descs
 
 int mi_vina_screen_size(const mi_vina *vv) { return vv ? (int)reinterpret_cast<const Vina *>(vv)->screen.size() : 0; }
 
-mi_status mi_vina_screen_dims(const mi_vina *vv, int32_t *max_conf, int32_t *max_heavy) {
+mi_status mi_vina_screen_dims(const mi_vina *vv, int32_t *max_conf, int32_t *max_heavy, int32_t *max_atoms) {
   VTRY
-  MIG_CHECK(vv && max_conf && max_heavy, 1, "bad arguments");
+  MIG_CHECK(vv && max_conf && max_heavy && max_atoms, 1, "bad arguments");
   const Vina &v = *reinterpret_cast<const Vina *>(vv);
-  int mc = 0, mh = 0;
+  int mc = 0, mh = 0, ma = 0;
   for (const auto &l : v.screen) {
     mc = std::max(mc, 7 + l->lig.n_nodes - 1);
     mh = std::max(mh, l->lig.n_heavy);
+    ma = std::max(ma, l->lig.n_atoms);
   }
   *max_conf = mc;
   *max_heavy = mh;
+  *max_atoms = ma;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+namespace {
+// the maxima over the screen's ligands: LDS sizing and row strides of the *_screen calls
+VinaLigand screen_big(const Vina &v) {
+  VinaLigand big{};
+  for (const auto &l : v.screen) {
+    big.n_atoms = std::max(big.n_atoms, l->lig.n_atoms);
+    big.n_nodes = std::max(big.n_nodes, l->lig.n_nodes);
+    big.n_pairs = std::max(big.n_pairs, l->lig.n_pairs);
+    big.n_heavy = std::max(big.n_heavy, l->lig.n_heavy);
+  }
+  return big;
+}
+
+void screen_env(Vina &v, VinaEnv &env, const int32_t *item_ligand, int B, const VinaLigand &big) {
+  const int nl = (int)v.screen.size();
+  for (int b = 0; b < B; b++) MIG_CHECK(item_ligand[b] >= 0 && item_ligand[b] < nl, 1, "item_ligand out of range");
+  v.d_chain_lig.upload(item_ligand, B, v.stream);
+  env.ligs = v.d_screen.p;
+  env.item_lig = v.d_chain_lig.p;
+  env.conf_stride = 7 + big.n_nodes - 1;
+  env.change_stride = 6 + big.n_nodes - 1;
+  env.coord_stride = 3 * big.n_atoms;
+}
+}  // namespace
+
+mi_status mi_vina_eval_screen(mi_vina *vv, const int32_t *item_ligand, const float *confs, int B, const float *v3,
+                              int with_deriv, float *energy, float *change, float *coords) {
+  VTRY
+  MIG_CHECK(vv && item_ligand && confs && v3 && energy && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && !v.screen.empty(), 4, "build the cache and set the screen's ligands first");
+  if (B == 0) return MI_OK;
+  const VinaLigand big = screen_big(v);
+  VinaEnv env = make_env(v);
+  screen_env(v, env, item_ligand, B, big);
+  const size_t cs = env.conf_stride, gs = env.change_stride, xs = env.coord_stride;
+  v.d_confs.upload(confs, (size_t)B * cs, v.stream);
+  v.d_energy.ensure(B);
+  if (change) v.d_change.ensure((size_t)B * gs);
+  if (coords) v.d_coords.ensure((size_t)B * xs);
+  env.direct = (with_deriv & MI_VINA_DIRECT) ? 1 : 0;
+  env.exact = (with_deriv & MI_VINA_EXACT) ? 1 : 0;
+  with_deriv &= 7;
+  launch_vina_eval(env, big, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
+                   change ? v.d_change.p : nullptr, coords ? v.d_coords.p : nullptr, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (change && with_deriv == 1)
+    MIG_HIP(hipMemcpyAsync(change, v.d_change.p, (size_t)B * gs * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (coords) MIG_HIP(hipMemcpyAsync(coords, v.d_coords.p, (size_t)B * xs * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_refine_screen(mi_vina *vv, const int32_t *item_ligand, float *confs, int B, const float *v3,
+                                const int32_t *max_iters, float *energy, int32_t *tries) {
+  VTRY
+  MIG_CHECK(vv && item_ligand && confs && v3 && max_iters && energy && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && !v.screen.empty(), 4, "build the cache and set the screen's ligands first");
+  if (B == 0) return MI_OK;
+  const VinaLigand big = screen_big(v);
+  VinaEnv env = make_env(v);
+  screen_env(v, env, item_ligand, B, big);
+  v.d_lig_iters.upload(max_iters, v.screen.size(), v.stream);
+  env.lig_iters = v.d_lig_iters.p;
+  const size_t cs = env.conf_stride;
+  v.d_confs.upload(confs, (size_t)B * cs, v.stream);
+  v.d_energy.ensure(B);
+  v.d_evals.ensure(B);
+  launch_vina_refine(env, big, v.d_confs.p, B, v3[0], v3[1], v3[2], 0, v.d_energy.p, v.d_evals.p, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(confs, v.d_confs.p, (size_t)B * cs * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (tries) MIG_HIP(hipMemcpyAsync(tries, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
   return MI_OK;
   VCATCH_STATUS
 }
@@ -1065,6 +1148,33 @@ mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const f
   for (int b = 0; b < B; b++) {
     const float x = total[b] - intra[b];
     const float y = 1 + w * num_tors / 5.0f;
+    float r;  // smooth_div, everything.h:52-56
+    if (std::fabs(x) < 1.1920928955078125e-07f) r = 0;
+    else if (std::fabs(y) < 1.1920928955078125e-07f) r = (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;
+    else r = x / y;
+    e_final[b] = r;
+    if (intramolecular) intramolecular[b] = intra[b];
+  }
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+mi_status mi_vina_final_energies_screen(mi_vina *vv, const int32_t *item_ligand, const float *confs, int B,
+                                        const float *v3, const float *num_tors, float *e_final, float *intramolecular) {
+  VTRY
+  MIG_CHECK(vv && item_ligand && confs && v3 && num_tors && e_final && B >= 0, 1, "bad arguments");
+  if (B == 0) return MI_OK;
+  std::vector<float> total(B), intra(B);
+  mi_status st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 0 | MI_VINA_DIRECT | MI_VINA_EXACT, total.data(),
+                                     nullptr, nullptr);
+  if (st != MI_OK) return st;
+  st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
+  if (st != MI_OK) return st;
+  const float weight = (float)(5 * 0.05846 / 0.1 - 1);  // main.cpp:1329
+  const float w = 0.1f * (weight + 1);
+  for (int b = 0; b < B; b++) {
+    const float x = total[b] - intra[b];
+    const float y = 1 + w * num_tors[item_ligand[b]] / 5.0f;
     float r;  // smooth_div, everything.h:52-56
     if (std::fabs(x) < 1.1920928955078125e-07f) r = 0;
     else if (std::fabs(y) < 1.1920928955078125e-07f) r = (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;

@@ -269,10 +269,21 @@ int mi_vina_ligand_heavy_atoms(const mi_vina *);
  * floats of its rows.  A chain's result is bit-identical to mi_vina_mc_batch of that ligand with the same seed. */
 mi_status mi_vina_set_screen(mi_vina *, int n_lig, const mi_ligand_desc *descs);
 int mi_vina_screen_size(const mi_vina *);
-mi_status mi_vina_screen_dims(const mi_vina *, int32_t *max_conf, int32_t *max_heavy);
+mi_status mi_vina_screen_dims(const mi_vina *, int32_t *max_conf, int32_t *max_heavy, int32_t *max_atoms);
 mi_status mi_vina_mc_screen(mi_vina *, int B, const int32_t *chain_ligand, const uint64_t *seeds, const float *corner1,
                             const float *corner2, const mi_mc_params *params, int32_t *out_n, float *out_e,
                             float *out_conf, float *out_coords, int32_t *evals);
+/* The per-ligand tail of do_search (main.cpp:324-347) for the poses of a whole screen in one launch each: item b
+ * is a conformation of ligand item_ligand[b].  Rows are strided by the maxima over the set (mi_vina_screen_dims):
+ * confs [B][max_conf], change [B][max_conf-1], coords [B][max_atoms][3]; an item of ligand l uses the first
+ * 7+T_l / 6+T_l / 3*n_atoms_l floats of its rows.  Same semantics and bits as mi_vina_eval_batch /
+ * mi_vina_refine_batch / mi_vina_final_energies of that ligand; max_iters and num_tors are per ligand [n_lig]. */
+mi_status mi_vina_eval_screen(mi_vina *, const int32_t *item_ligand, const float *confs, int B, const float *v3,
+                              int with_deriv, float *energy, float *change, float *coords);
+mi_status mi_vina_refine_screen(mi_vina *, const int32_t *item_ligand, float *confs, int B, const float *v3,
+                                const int32_t *max_iters, float *energy, int32_t *tries);
+mi_status mi_vina_final_energies_screen(mi_vina *, const int32_t *item_ligand, const float *confs, int B,
+                                        const float *v3, const float *num_tors, float *e_final, float *intramolecular);
 /* do_search's ranking tail (main.cpp:348-361): sort (pose_sort_order: CNNscore / CNNaffinity descending,
  * Energy ascending) then remove_redundant(out_cont, out_min_rmsd) (main.cpp:182-192).  Host only.
  * coords [n_poses][n_heavy][3]; order_out [n_poses] receives the kept pose indices, best first. */

@@ -348,3 +348,24 @@ def test_screen_launch_matches_per_ligand_chains(capi, T):
             assert np.array_equal(xyz[b, :m, :nh3], xyz1[k, :m].reshape(m, nh3))
     with pytest.raises(capi.MiGninaError):
         vina.mc_screen(np.array([3], np.int32), seeds[:1], c1, c2, params)      # ligand index out of range
+    # the per-ligand tail (refine_structure, coordinates, final energies) of all ligands' poses in one launch each
+    item = np.array([2, 0, 1, 1, 2], dtype=np.int32)
+    rows = np.zeros((len(item), vina.screen_conf), np.float32)
+    for k, l in enumerate(item):
+        rows[k, :7 + ligs[l]["n_tors"]] = synth.random_conf(np.random.RandomState(40 + k), ligs[l], np.zeros(3), 1.0)
+    iters = [(25 + len(lig["smt"])) // 3 for lig in ligs]
+    v3 = (1000.0, 1000.0, 1000.0)
+    es, chs, cos = vina.eval_screen(item, rows, v3, deriv=True, want_coords=True)
+    er, rcf, tr = vina.refine_screen(item, rows, iters)
+    ef, intra = vina.final_energies_screen(item, rcf, [float(lig["n_tors"]) for lig in ligs])
+    for l, lig in enumerate(ligs):
+        vina.set_ligand(lig)
+        idx = np.nonzero(item == l)[0]
+        nc, na = 7 + lig["n_tors"], len(lig["smt"])
+        e1, ch1, co1 = vina.eval_batch(rows[idx][:, :nc], v3, deriv=True, want_coords=True)
+        assert np.array_equal(es[idx], e1) and np.array_equal(chs[idx][:, :nc - 1], ch1)
+        assert np.array_equal(cos[idx][:, :na], co1)
+        e2, cf2, t2 = vina.refine_batch(rows[idx][:, :nc], max_iters=iters[l])
+        assert np.array_equal(er[idx], e2) and np.array_equal(rcf[idx][:, :nc], cf2) and np.array_equal(tr[idx], t2)
+        e3, i3 = vina.final_energies(cf2, float(lig["n_tors"]))
+        assert np.array_equal(ef[idx], e3) and np.array_equal(intra[idx], i3)

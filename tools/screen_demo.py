@@ -62,20 +62,29 @@ def main():
     t0 = time.perf_counter()
     cnt, e, cf, xyz, ev = vina.mc_screen(np.array(chain_lig, np.int32), np.array(seeds, np.uint64), begin, end, params)
     t_mc = time.perf_counter() - t0
-    # per ligand: merge the chains' containers, refine the kept poses, final energies (small launches)
+    # merge each ligand's chain containers (host), then refine / coordinates / final energies of the kept poses of
+    # ALL ligands in one launch each (mi_vina_*_screen)
     t0 = time.perf_counter()
-    results = []
     E = args.exhaustiveness
+    item, rows = [], []
     for i, lig in enumerate(ligs):
         nc, nh = 7 + lig["n_tors"], int((lig["smt"] > 1).sum())
         sl = slice(i * E, (i + 1) * E)
         me, mcf, mxyz = capi.merge_mc_outputs(cnt[sl], e[sl], np.ascontiguousarray(cf[sl][:, :, :nc]),
                                               np.ascontiguousarray(xyz[sl][:, :, :3 * nh]).reshape(E, -1, nh, 3), 2.0, 50)
-        vina.set_ligand(lig)
-        er, rcf, tries = vina.refine_batch(mcf[:args.poses])
-        _, _, co = vina.eval_batch(rcf, want_coords=True)
-        ef, intra = vina.final_energies(rcf, float(lig["n_tors"]))
-        results.append((co, ef))
+        for c in mcf[:args.poses]:
+            r = np.zeros(vina.screen_conf, np.float32)
+            r[:nc] = c
+            rows.append(r)
+            item.append(i)
+    item, rows = np.array(item, np.int32), np.stack(rows)
+    er, rcf, tries = vina.refine_screen(item, rows, [(25 + len(l["smt"])) // 3 for l in ligs])
+    _, _, co_all = vina.eval_screen(item, rcf, deriv=False, want_coords=True)
+    ef_all, intra = vina.final_energies_screen(item, rcf, [float(l["n_tors"]) for l in ligs])
+    results = []
+    for i, lig in enumerate(ligs):
+        idx = np.nonzero(item == i)[0]
+        results.append((co_all[idx][:, :len(lig["smt"])], ef_all[idx]))
     t_post = time.perf_counter() - t0
     t_dock = t_setup + t_mc + t_post
     evals = [int(ev.sum())]
