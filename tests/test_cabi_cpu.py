@@ -84,6 +84,12 @@ def test_null_and_error_paths_do_not_crash(capi):
     assert L.mi_vina_coords_batch(None, one, 1, one) != capi.MI_OK
     assert L.mi_cnn_eval_batch(None, None, one, 1, None, None, 0, one, None) != capi.MI_OK
     assert L.mi_cnn_refine_batch(None, None, one, 1, None, 3, one, None, None) != capi.MI_OK
+    assert L.mi_vina_set_screen(None, 0, None) != capi.MI_OK and L.mi_vina_screen_size(None) == 0
+    assert L.mi_vina_screen_dims(None, None, None, None) != capi.MI_OK
+    assert L.mi_vina_mc_screen(None, 1, one, one, one, one, None, one, one, None, None, None) != capi.MI_OK
+    assert L.mi_vina_eval_screen(None, one, one, 1, one, 1, one, None, None) != capi.MI_OK
+    assert L.mi_vina_refine_screen(None, one, one, 1, one, one, one, None) != capi.MI_OK
+    assert L.mi_vina_final_energies_screen(None, one, one, 1, one, one, one, None) != capi.MI_OK
     assert L.mi_model_load_file_ex(b"/nonexistent.mgw", C.c_float(0.25), C.c_float(23.75)) is None
     assert L.mi_read_gninatypes(None, None, None, 0, None) != capi.MI_OK
 
