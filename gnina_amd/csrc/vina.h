@@ -64,6 +64,8 @@ struct VinaLigand {
   const int2 *pair_slots;      // [n_pairs]
   int n_heavy;
   const int *heavy_list;       // [n_heavy] indices of the non-hydrogen atoms
+  const int *depth;            // [n_nodes] tree level of every node (root 0)
+  int n_levels;                // 1 + the deepest level
 };
 
 struct VinaMcArgs {

@@ -341,6 +341,7 @@ __device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
   L.slot_start = cp_i(G.slot_start, G.n_atoms + 1);
   L.pair_slots = reinterpret_cast<const int2 *>(cp_i(reinterpret_cast<const int *>(G.pair_slots), 2 * G.n_pairs));
   L.heavy_list = cp_i(G.heavy_list, G.n_heavy);
+  L.depth = cp_i(G.depth, G.n_nodes);
   L.local_xyz = cp_f(G.local_xyz, 3 * G.n_atoms);
   L.rel_origin = cp_f(G.rel_origin, 3 * G.n_nodes);
   L.rel_axis = cp_f(G.rel_axis, 3 * G.n_nodes);
@@ -368,7 +369,7 @@ static size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 static bool want_stage(int B) { return B <= 2048; }
 
 static size_t ligand_lds_floats(int na, int nn, int np, int nh) {
-  return 2 * pad4(na) + 3 * pad4(nn) + pad4(nn + 1) + pad4(nn) + 2 * pad4(2 * (size_t)np) + pad4(na + 1) + pad4(nh) +
+  return 2 * pad4(na) + 4 * pad4(nn) + pad4(nn + 1) + pad4(nn) + 2 * pad4(2 * (size_t)np) + pad4(na + 1) + pad4(nh) +
          pad4(3 * (size_t)na) + 2 * pad4(3 * (size_t)nn);
 }
 
@@ -514,6 +515,51 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       sincosf(angle / 2, &sn_r, &cn_r);
     }
   }
+  if (5 * L.n_levels <= 4 * L.n_nodes) {
+    // branched tree: one LEVEL per step instead of one node.  Lane k computes node k's frame from its parent's
+    // (16 values fetched from the parent's lane with ds_bpermute) when its level comes up -- the same arithmetic per
+    // node as the serial walk below, but siblings and cousins advance together and every lane stores its own frame.
+    float q[4], M[9], o[3], ax[3] = {0.f, 0.f, 0.f};
+    o[0] = conf[0], o[1] = conf[1], o[2] = conf[2];
+    q[0] = conf[3], q[1] = conf[4], q[2] = conf[5], q[3] = conf[6];
+    quat_to_r3(q, M);
+    const int my_depth = lane < L.n_nodes ? L.depth[lane] : -1;
+    const int src = par_r >= 0 ? par_r : 0;
+    for (int d = 1; d < L.n_levels; d++) {
+      float pM[9], pq[4], po[3];
+#pragma unroll
+      for (int i = 0; i < 9; i++) pM[i] = __shfl(M[i], src);
+#pragma unroll
+      for (int i = 0; i < 4; i++) pq[i] = __shfl(q[i], src);
+#pragma unroll
+      for (int i = 0; i < 3; i++) po[i] = __shfl(o[i], src);
+      float tx, ty, tz, nax, nay, naz;
+      mat_vec(pM, ro0, ro1, ro2, tx, ty, tz);
+      const float no0 = po[0] + tx, no1 = po[1] + ty, no2 = po[2] + tz;
+      mat_vec(pM, ra0, ra1, ra2, nax, nay, naz);
+      float rq[4] = {cn_r, sn_r * nax, sn_r * nay, sn_r * naz}, nq[4], nM[9];
+      quat_mul(rq, pq, nq);
+      quat_norm_approx(nq);
+      quat_to_r3(nq, nM);
+      if (my_depth == d) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) M[i] = nM[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = nq[i];
+        o[0] = no0, o[1] = no1, o[2] = no2;
+        ax[0] = nax, ax[1] = nay, ax[2] = naz;
+      }
+    }
+    if (lane < L.n_nodes) {
+      const int k = lane;
+#pragma unroll
+      for (int i = 0; i < 9; i++) w.M[9 * k + i] = M[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w.q[4 * k + i] = q[i];
+      w.origin[3 * k] = o[0], w.origin[3 * k + 1] = o[1], w.origin[3 * k + 2] = o[2];
+      w.axis[3 * k] = ax[0], w.axis[3 * k + 1] = ax[1], w.axis[3 * k + 2] = ax[2];
+    }
+  } else
   {
     float q[4], M[9], o[3];
     int prev = -1;

@@ -354,6 +354,13 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
   for (int i = 0; i < na; i++)
     if (d->smt[i] > 1) heavy.push_back(i);
   const size_t o_heavy = pushi(heavy.empty() ? aps.data() : heavy.data(), heavy.size());
+  std::vector<int> depth(nn, 0);  // level of every node; the tree walk may advance one level per step
+  int n_levels = 1;
+  for (int k = 1; k < nn; k++) {
+    depth[k] = depth[d->node_parent[k]] + 1;
+    n_levels = std::max(n_levels, depth[k] + 1);
+  }
+  const size_t o_depth = pushi(depth.data(), nn);
   const size_t o_smt = pushi(d->smt, na), o_node = pushi(node_of.data(), na), o_par = pushi(d->node_parent, nn),
                o_abeg = pushi(d->node_atom_begin, nn), o_aend = pushi(d->node_atom_end, nn),
                o_cs = pushi(child_start.data(), nn + 1),
@@ -389,6 +396,8 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
   L.pair_slots = reinterpret_cast<const int2 *>(out.d_int.p + o_apl);
   L.n_heavy = (int)heavy.size();
   L.heavy_list = out.d_int.p + o_heavy;
+  L.depth = out.d_int.p + o_depth;
+  L.n_levels = n_levels;
   L.local_xyz = out.d_flt.p + o_loc;
   L.rel_origin = out.d_flt.p + o_ro;
   L.rel_axis = out.d_flt.p + o_ra;
