@@ -271,18 +271,17 @@ __device__ __forceinline__ void mat_vec(const float *m, float vx, float vy, floa
 // ---- per-wave LDS workspace -----------------------------------------------------------------------
 struct WaveWork {
   float *origin, *axis, *M, *q;  // node frames
-  float *cs;                     // [2 n_nodes] cos / sin of every half torsion angle
   float *coords, *forces;        // [3 n_atoms]
-  float *node_ft;                // [6 n_nodes]
-  float4 *contrib;               // [n_slots] per-atom lists of pair-force contributions (see eval_conf stage 4/5)
+  float *cx, *cy, *cz;           // [n_slots] each: per-atom lists of pair-force contributions, one array per
+                                 // component so that four consecutive slots are one 16-byte read (eval_conf stage 4/5)
   float4 *ft;                    // [2 n_atoms] per-atom force and torque about its node origin (fold_forces)
 };
+
+constexpr int kPairGroup = 6;  // intramolecular pairs a lane looks up together (eval_conf stage 4)
 
 // Ordering point between the lanes of ONE wave (private LDS workspace): LDS instructions of a wave execute in
 // issue order, so no s_barrier and no counter drain is needed -- only the compiler must not move LDS accesses
 // across it.  Data shared between the waves of a workgroup still goes through __syncthreads().
-constexpr int kPairGroup = 6;
-
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -297,18 +296,19 @@ __device__ __forceinline__ float *carve(float *&p, int n) {
 // init = false only measures the footprint (multi-wave kernels place one workspace per wave)
 __device__ WaveWork carve_work(float *&p, const VinaLigand &L, bool init = true) {
   WaveWork w;
-  w.contrib = reinterpret_cast<float4 *>(carve(p, 4 * (2 * L.n_pairs + 3 * L.n_atoms)));
+  const int n_slots = (2 * L.n_pairs + 3 * L.n_atoms + 3) & ~3;  // upper bound of the ligand's slot count
+  w.cx = carve(p, n_slots);
+  w.cy = carve(p, n_slots);
+  w.cz = carve(p, n_slots);
   w.ft = reinterpret_cast<float4 *>(carve(p, 8 * L.n_atoms));
   w.origin = carve(p, 3 * L.n_nodes);
   w.axis = carve(p, 3 * L.n_nodes);
   w.M = carve(p, 9 * L.n_nodes);
   w.q = carve(p, 4 * L.n_nodes);
-  w.cs = carve(p, 2 * L.n_nodes);
   w.coords = carve(p, 3 * L.n_atoms);
   w.forces = carve(p, 3 * L.n_atoms);
-  w.node_ft = carve(p, 6 * L.n_nodes);
   if (init) {
-    for (int i = threadIdx.x & 63; i < 2 * L.n_pairs + 3 * L.n_atoms; i += 64) w.contrib[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x & 63; i < 3 * n_slots; i += 64) w.cx[i] = 0.f;  // cx, cy, cz are contiguous
     wave_sync();
   }
   return w;
@@ -374,9 +374,8 @@ static size_t ligand_lds_floats(int na, int nn, int np, int nh) {
 }
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage) {
-  size_t f = pad4(4 * (2 * (size_t)n_pairs + 3 * (size_t)n_atoms)) + pad4(8 * (size_t)n_atoms) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
-             pad4(4 * (size_t)n_nodes) + pad4(2 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms) +
-             pad4(6 * (size_t)n_nodes);
+  size_t f = 3 * pad4(2 * (size_t)n_pairs + 3 * (size_t)n_atoms) + pad4(8 * (size_t)n_atoms) + 2 * pad4(3 * (size_t)n_nodes) + pad4(9 * (size_t)n_nodes) +
+             pad4(4 * (size_t)n_nodes) + 2 * pad4(3 * (size_t)n_atoms);
   const size_t nt = n_nodes - 1, n = 6 + nt, nc = 7 + nt;
   f += pad4(nc);  // conf being evaluated
   f += pad4(n);   // change
@@ -763,8 +762,8 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
           }
         }
         if (DERIV && p < L.n_pairs) {  // forces[a] -= f; forces[b] += f, as entries of the two atoms' lists
-          w.contrib[sl[u].x] = make_float4(-out.x, -out.y, -out.z, 0.f);
-          w.contrib[sl[u].y] = out;
+          w.cx[sl[u].x] = -out.x, w.cy[sl[u].x] = -out.y, w.cz[sl[u].x] = -out.z;
+          w.cx[sl[u].y] = out.x, w.cy[sl[u].y] = out.y, w.cz[sl[u].y] = out.z;
         }
       }
     }
@@ -791,8 +790,8 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
     if (DERIV) {
       const int2 sl = L.pair_slots[p];
-      w.contrib[sl.x] = make_float4(-out.x, -out.y, -out.z, 0.f);
-      w.contrib[sl.y] = out;
+      w.cx[sl.x] = -out.x, w.cy[sl.x] = -out.y, w.cz[sl.x] = -out.z;
+      w.cx[sl.y] = out.x, w.cy[sl.y] = out.y, w.cz[sl.y] = out.z;
     }
   }
   // 3b. interpolate the receptor grids whose corner loads were issued in stage 3
@@ -818,11 +817,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       // 16-byte reads per LDS latency, no index indirection; the additions keep the pair order
       const int e_end = L.slot_start[i + 1];
       for (int e = L.slot_start[i]; e < e_end; e += 4) {
-        const float4 c0 = w.contrib[e], c1 = w.contrib[e + 1], c2 = w.contrib[e + 2], c3 = w.contrib[e + 3];
-        fx += c0.x, fy += c0.y, fz += c0.z;
-        fx += c1.x, fy += c1.y, fz += c1.z;
-        fx += c2.x, fy += c2.y, fz += c2.z;
-        fx += c3.x, fy += c3.y, fz += c3.z;
+        const float4 x4 = *reinterpret_cast<const float4 *>(w.cx + e), y4 = *reinterpret_cast<const float4 *>(w.cy + e),
+                     z4 = *reinterpret_cast<const float4 *>(w.cz + e);
+        fx += x4.x, fy += y4.x, fz += z4.x;
+        fx += x4.y, fy += y4.y, fz += z4.y;
+        fx += x4.z, fy += y4.z, fz += z4.z;
+        fx += x4.w, fy += y4.w, fz += z4.w;
       }
       w.forces[3 * i] = fx;
       w.forces[3 * i + 1] = fy;
