@@ -277,7 +277,11 @@ struct WaveWork {
   float4 *ft;                    // [2 n_atoms] per-atom force and torque about its node origin (fold_forces)
 };
 
-constexpr int kPairGroup = 6;  // intramolecular pairs a lane looks up together (eval_conf stage 4)
+// Two tunings of the same arithmetic.  Latency (few chains, one wave per SIMD anyway): six pair look-ups per lane in
+// flight, H rows in registers.  Throughput (thousands of chains): three look-ups, H in LDS -- half the registers,
+// twice the resident waves.  Results are bit-identical: only batching and residence change, not the operations.
+constexpr int kPairGroup = 6, kPairGroupTp = 3;  // intramolecular pairs a lane looks up together (eval_conf stage 4)
+constexpr int kHReg = 24, kHRegTp = 4;           // variables up to which lane i keeps row i of H in registers
 
 // Ordering point between the lanes of ONE wave (private LDS workspace): LDS instructions of a wave execute in
 // issue order, so no s_barrier and no counter drain is needed -- only the compiler must not move LDS accesses
@@ -488,7 +492,7 @@ __device__ __forceinline__ void fold_forces(const VinaLigand &L, const WaveWork 
 // MODE 2: cache::eval (cache.cpp:52-63: receptor-grid term only -- the energy gnina's Metropolis step
 // uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates); MODE 4: eval_intramolecular
 // (model.cu:352-399: ligand pairs only, energy only).  Returns the energy in every lane; MODE 0 writes change[6 + T] to LDS.
-template <int MODE>
+template <int MODE, int PG = kPairGroup>
 __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float *conf, float v0, float v1,
                                            float v2, const WaveWork &w, float *change) {
   constexpr bool DERIV = MODE == 0;
@@ -710,18 +714,18 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
     wave_sync();
   }
-  // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs kPairGroup at a time
-  // (one group covers 384 pairs, a typical drug-like ligand) and issues their table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
+  // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs PG at a time
+  // (six: one group covers 384 pairs, a typical drug-like ligand) and issues their table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
   // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
   if ((MODE < 2 || MODE == 4) && !env.exact) {
-    for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * kPairGroup) {
-      float rx[kPairGroup], ry[kPairGroup], rz[kPairGroup], rem[kPairGroup];
-      float2 s1[kPairGroup], s2[kPairGroup];
-      float fastv[kPairGroup];
-      int2 sl[kPairGroup];
-      bool in[kPairGroup];
+    for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * PG) {
+      float rx[PG], ry[PG], rz[PG], rem[PG];
+      float2 s1[PG], s2[PG];
+      float fastv[PG];
+      int2 sl[PG];
+      bool in[PG];
 #pragma unroll
-      for (int u = 0; u < kPairGroup; u++) {
+      for (int u = 0; u < PG; u++) {
         const int p = p0 + 64 * u;
         const bool valid = p < L.n_pairs;
         const int2 ab = L.pairs[valid ? p : 0];
@@ -744,7 +748,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         }
       }
 #pragma unroll
-      for (int u = 0; u < kPairGroup; u++) {
+      for (int u = 0; u < PG; u++) {
         const int p = p0 + 64 * u;
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in[u]) {
@@ -1167,6 +1171,7 @@ struct WaveTeam {
 // The start point is evaluated by the same eval_conf call as the trials (step -1, a "search" of one trial that
 // is always accepted): eval_conf is inlined, and one call site keeps the minimiser kernels' code small enough
 // to stay in the instruction cache while every access keeps its address space (LDS reads stay ds_read).
+template <int HREG = kHReg, int PG = kPairGroup>
 __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand &L, const WaveWork &w, const BfgsWork &k,
                                            float v0, float v1, float v2, int max_iters, int &evals, const WaveTeam &tm,
                                            long long *eval_ticks = nullptr) {
@@ -1177,14 +1182,13 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   float *x = k.x, *x_new = k.x_new, *g_new = k.g_new, *h = k.h;
   float x_r = lane < nc ? x[lane] : 0.f;
   const float x_orig = x_r;
-  // H: up to kHReg variables, lane i keeps the full (symmetric) row i in registers -- both triangles are updated
+  // H: up to HREG (kHReg) variables, lane i keeps the full (symmetric) row i in registers -- both triangles are updated
   // with the operands in the reference's order, so they stay bit-identical to the triangular update; larger
   // problems keep the triangle in LDS.
-  constexpr int kHReg = 24;
-  const bool hreg = n <= kHReg;
-  float hrow[kHReg];
+  const bool hreg = n <= HREG;
+  float hrow[HREG];
 #pragma unroll
-  for (int j = 0; j < kHReg; j++) hrow[j] = (j == lane && lane < n) ? 1.f : 0.f;
+  for (int j = 0; j < HREG; j++) hrow[j] = (j == lane && lane < n) ? 1.f : 0.f;
   if (!hreg) {
     for (int i = lane; i < n * (n + 1) / 2; i += 64) h[i] = 0.f;
     wave_sync();
@@ -1193,7 +1197,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   auto minus_hrow_times = [&](float v) {  // -(H v)[lane], j ascending
     float sum = 0.f;
 #pragma unroll
-    for (int j0 = 0; j0 < kHReg; j0 += 4) {
+    for (int j0 = 0; j0 < HREG; j0 += 4) {
       if (j0 < n) {
 #pragma unroll
         for (int u = 0; u < 4; u++) sum += hrow[j0 + u] * rl(v, j0 + u);
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       if (lane < nc) x_new[lane] = xn;
       wave_sync();
       lapb(3);
-      const float f_t = eval_conf<0>(env, L, x_new, v0, v1, v2, w, g_new);
+      const float f_t = eval_conf<0, PG>(env, L, x_new, v0, v1, v2, w, g_new);
       lapb(0);
       if (start) {  // every wave evaluated the start point itself
         t_acc = 0;
@@ -1289,7 +1293,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         const float dgl = alpha * dot_lanes(y_r, p_r, n) / yy;
         if (hreg) {
 #pragma unroll
-          for (int j = 0; j < kHReg; j++)
+          for (int j = 0; j < HREG; j++)
             if (j == lane && lane < n) hrow[j] = dgl;
         } else {
           if (lane < n) h[hidx(lane, lane)] = dgl;
@@ -1309,7 +1313,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         const float ar = alpha * r, c = alpha * alpha * (r * r * yhy + r);
         const float cp_r = c * p_r;
 #pragma unroll
-        for (int j0 = 0; j0 < kHReg; j0 += 4) {
+        for (int j0 = 0; j0 < HREG; j0 += 4) {
           if (j0 < n) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1482,7 +1486,10 @@ struct McRng {
 // W = blockDim.x / 64 waves per chain (see WaveTeam): every wave replays the whole chain -- same RNG stream,
 // same decisions -- and they share the work only inside the BFGS line searches.  Wave 0 alone owns the output
 // container (global memory) and publishes what the others need (the container's size) through LDS.
-__global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
+template <bool PROF, bool TP>
+__device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a) {
+  if (!PROF) a.prof = nullptr;  // the timing code folds away in the production instantiations
+  constexpr int HR = TP ? kHRegTp : kHReg, PG = TP ? kPairGroupTp : kPairGroup;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
   if (a.ligs) {  // screen mode: this chain's ligand and search length
@@ -1574,7 +1581,7 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
         k.x[2] += a.amplitude * dz;
       }
     } else if (which == 1) {
-      (void)eval_conf<3>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // coordinates of the candidate
+      (void)eval_conf<3, PG>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // coordinates of the candidate
       float acc = 0.f;
       for (int i = lane; i < L.n_atoms; i += 64)
         if (L.smt[i] > 1) {
@@ -1605,9 +1612,9 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
     float cand_e = 0.f;
     for (int pass = 0; pass < 2; pass++) {
       const float *cap = pass == 0 ? a.hunt : a.auth;
-      (void)bfgs_wave(env, L, w, k, cap[0], cap[1], cap[2], a.max_iters, evals, tm, evt);
+      (void)bfgs_wave<HR, PG>(env, L, w, k, cap[0], cap[1], cap[2], a.max_iters, evals, tm, evt);
       lap(pass == 0 ? 1 : 3);
-      const float e_now = eval_conf<2>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // update_energy; leaves coords of k.x in w.coords
+      const float e_now = eval_conf<2, PG>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // update_energy; leaves coords of k.x in w.coords
       if (pass == 0) {
         cand_e = e_now;
         bool accept = step == 0 || cand_e < tmp_e;
@@ -1716,6 +1723,18 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   }
 }
 
+// The two instantiations: latency tuning for teams of waves (one workgroup of W waves per chain), throughput tuning
+// for one wave per chain with the register budget of two waves per SIMD.
+template <bool PROF>
+__global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
+  mc_chain<PROF, false>(env, L, a);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vina_mc_tp_kernel(VinaEnv env, VinaLigand L,
+                                                                                                   VinaMcArgs a) {
+  mc_chain<false, true>(env, L, a);
+}
+
 // Waves per chain: a single docking job (few chains) is bound by the latency of dependent evaluations, so
 // the line searches are spread over 4 waves; with many chains in flight the speculative trials would only take
 // issue slots from other chains.
@@ -1749,8 +1768,16 @@ void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs
     W /= 2;
     lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, W);
   }
-  big_lds(vina_mc_kernel);
-  hipLaunchKernelGGL(vina_mc_kernel, dim3(B), dim3(64 * W), lds, s, env, lig, a);
+  if (a.prof) {
+    big_lds(vina_mc_kernel<true>);
+    hipLaunchKernelGGL(vina_mc_kernel<true>, dim3(B), dim3(64 * W), lds, s, env, lig, a);
+  } else if (W == 1) {
+    big_lds(vina_mc_tp_kernel);
+    hipLaunchKernelGGL(vina_mc_tp_kernel, dim3(B), dim3(64), lds, s, env, lig, a);
+  } else {
+    big_lds(vina_mc_kernel<false>);
+    hipLaunchKernelGGL(vina_mc_kernel<false>, dim3(B), dim3(64 * W), lds, s, env, lig, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
