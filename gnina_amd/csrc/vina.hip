@@ -1360,9 +1360,11 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   return f0;
 }
 
-__global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
-                                                       float v2, int max_iters, float *energy, float *grad_out,
-                                                       int *evals_out) {
+// TP: the throughput tuning (see kPairGroupTp / kHRegTp) with the register budget of three waves per SIMD
+template <bool TP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP ? 3 : 1, TP ? 3 : 2))) void vina_bfgs_kernel(
+    VinaEnv env, VinaLigand L, float *confs, float v0, float v1, float v2, int max_iters, float *energy, float *grad_out,
+    int *evals_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
   if (env.stage) L = stage_ligand(L, pp);
@@ -1374,7 +1376,8 @@ __global__ __launch_bounds__(64) void vina_bfgs_kernel(VinaEnv env, VinaLigand L
   for (int i = lane; i < nc; i += 64) k.x[i] = confs[(size_t)b * nc + i];
   wave_sync();
   const WaveTeam solo{1, 0, 0, nullptr, nullptr};
-  const float f0 = bfgs_wave(env, L, w, k, v0, v1, v2, max_iters, evals, solo);
+  const float f0 = bfgs_wave<TP ? kHRegTp : kHReg, TP ? kPairGroupTp : kPairGroup>(env, L, w, k, v0, v1, v2, max_iters,
+                                                                                  evals, solo);
   for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = k.x[i];
   if (grad_out)
     for (int i = lane; i < n; i += 64) grad_out[(size_t)b * n + i] = k.g[i];
@@ -1843,9 +1846,15 @@ void launch_vina_bfgs(const VinaEnv &env0, const VinaLigand &lig, float *confs, 
   VinaEnv env = env0;
   env.stage = want_stage(B) ? 1 : 0;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
-  big_lds(vina_bfgs_kernel);
-  hipLaunchKernelGGL(vina_bfgs_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy, grad,
-                     evals);
+  if (B > 2048) {  // thousands of chains: occupancy over per-chain latency
+    big_lds(vina_bfgs_kernel<true>);
+    hipLaunchKernelGGL(vina_bfgs_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
+                       grad, evals);
+  } else {
+    big_lds(vina_bfgs_kernel<false>);
+    hipLaunchKernelGGL(vina_bfgs_kernel<false>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
+                       grad, evals);
+  }
 }
 
 }  // namespace mig

@@ -112,6 +112,12 @@ def test_bfgs_step_exact_then_statistically_equivalent(setup):
     # batch independence: one conformation alone gives the same bits as inside the batch
     e1, c1, _, _ = vina.bfgs_batch(confs[5:6], v)
     assert e1[0] == e[5] and np.array_equal(c1[0], cf[5])
+    # ... and as inside a batch large enough for the throughput instantiation of the kernel (> 2,048 chains:
+    # fewer look-ups in flight, H in LDS instead of registers -- same operations)
+    big = np.tile(confs, (80, 1))
+    eb, cb, gb, evb = vina.bfgs_batch(big, v)
+    assert np.array_equal(eb[:len(confs)], e) and np.array_equal(cb[:len(confs)], cf) and np.array_equal(evb[:len(confs)], ev)
+    assert np.array_equal(eb[-len(confs):], e)
 
 
 def test_vina_error_paths(capi):
