@@ -9,15 +9,21 @@
 //
 // MI355X design (not the reference's experimental --gpu_docking layout, which runs one BFGS per
 // kernel launch in a single block with dynamic parallelism, bfgs.cu:229-337):
-//  * ONE 64-lane wavefront owns ONE conformation for its whole life -- evaluation, line search and
-//    the quasi-Newton update all stay inside one kernel, state lives in LDS (a few KB), nothing
-//    returns to the host between function evaluations.  A batch of B conformations (MC chains x
-//    ligands) is B independent wavefronts; 256 CUs x 8+ waves/SIMD keep thousands in flight, which
-//    is what hides the L2 gather latency of the grid and table look-ups.
-//  * Lanes map to atoms for the receptor-grid term (8-point trilinear gather per atom), to pairs for
-//    the intramolecular term, to tree nodes for the force/torque sums; pair forces are written to
-//    LDS and gathered per atom in pair order, so there are no atomics and results are
-//    deterministic.  The energy is a fixed-order butterfly reduction across the wave.
+//  * ONE 64-lane wavefront owns ONE conformation for its whole life -- evaluation, line search and the
+//    quasi-Newton update (and, in the Monte-Carlo kernel, the whole chain) stay inside one kernel; nothing
+//    returns to the host between function evaluations.  What a dependent chain touches lives in registers
+//    (node constants, BFGS vectors, rows of H), the rest in a private LDS workspace of ~12 KB.
+//  * Lanes map to tree nodes for the frames (one level per step on branched trees), to atoms for the
+//    receptor-grid term (8-point trilinear gather per atom), to pairs for the intramolecular term, to atoms
+//    again for the per-atom lists of pair forces (contribution slots, pair order), to nodes for the
+//    force/torque sums: no atomics, deterministic.  The energy is a fixed-order butterfly (DPP).
+//  * Few chains are latency bound: W waves per chain evaluate the trials of a line search at once
+//    (WaveTeam) and take the first accepted one in trial order.  Thousands of chains are throughput bound:
+//    the same code with fewer loads in flight and H in LDS fits two to three waves per SIMD
+//    (vina_mc_tp_kernel, vina_bfgs_kernel<true>).  A screen's ligands share one launch (VinaMcArgs::ligs,
+//    VinaEnv::ligs).  All of these give the same bits: only batching and residence differ.
+//  * Ordering points between the lanes of one wave are compiler fences (wave_sync): LDS executes a wave's
+//    instructions in order; __syncthreads() only where waves of a team exchange data.
 //  * All arithmetic is fp32 in the reference's operation order (compiled with -ffp-contract=off);
 //    only sinf/cosf and the reduction order differ from the CPU oracle.
 #include <cstdlib>
