@@ -682,14 +682,9 @@ mi_status mi_vina_mc_screen(mi_vina *vv, int B, const int32_t *chain_ligand, con
   const int S = P[0].num_saved;
   MIG_CHECK(S > 0 && S <= 64 && P[0].temperature > 0, 1, "bad Monte-Carlo parameters (num_saved must be in [1, 64])");
   if (B == 0) return MI_OK;
-  VinaLigand big{};  // the maxima over the set size the LDS workspace and the container strides
+  const VinaLigand big = screen_big(v);  // the maxima over the set size the LDS workspace and the container strides
   std::vector<int> steps(nl), iters(nl);
   for (int l = 0; l < nl; l++) {
-    const VinaLigand &L = v.screen[l]->lig;
-    big.n_atoms = std::max(big.n_atoms, L.n_atoms);
-    big.n_nodes = std::max(big.n_nodes, L.n_nodes);
-    big.n_pairs = std::max(big.n_pairs, L.n_pairs);
-    big.n_heavy = std::max(big.n_heavy, L.n_heavy);
     MIG_CHECK(P[l].num_saved == S && P[l].n_steps >= 0 && P[l].max_iters >= 0, 1,
               "every ligand of a screen uses the same num_saved");
     steps[l] = P[l].n_steps;
