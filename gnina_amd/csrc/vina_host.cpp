@@ -420,15 +420,16 @@ mi_status mi_vina_set_screen(mi_vina *vv, int n_lig, const mi_ligand_desc *descs
   VTRY
   MIG_CHECK(vv && n_lig >= 0 && (n_lig == 0 || descs), 1, "bad arguments");
   Vina &v = *reinterpret_cast<Vina *>(vv);
-  v.screen.clear();
+  std::vector<std::unique_ptr<LigandDev>> fresh;  // swapped in only when every description was accepted
   std::vector<VinaLigand> h(n_lig);
   for (int l = 0; l < n_lig; l++) {
-    v.screen.emplace_back(new LigandDev());
-    build_ligand(descs + l, *v.screen.back(), v.stream);
-    h[l] = v.screen.back()->lig;
+    fresh.emplace_back(new LigandDev());
+    build_ligand(descs + l, *fresh.back(), v.stream);
+    h[l] = fresh.back()->lig;
   }
   if (n_lig) v.d_screen.upload(h.data(), h.size(), v.stream);
   MIG_HIP(hipStreamSynchronize(v.stream));
+  v.screen.swap(fresh);
   return MI_OK;
   VCATCH_STATUS
 }
