@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -123,6 +123,9 @@ def lib():
         L.mi_write_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int]
         L.mi_io_last_error.restype = C.c_char_p
         L.mi_pdbqt_read_receptor.argtypes = [C.c_char_p, vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.mi_pdbqt_read_receptor_flex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int),
+                                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mi_pdbqt_read_receptor_flex.restype = C.c_int
         L.mi_pdbqt_ligand_open.argtypes = [C.c_char_p, C.c_int]
         L.mi_pdbqt_ligand_open.restype = vp
         L.mi_pdbqt_ligand_close.argtypes = [vp]
@@ -261,6 +264,21 @@ def read_pdbqt_receptor(path):
     if lib().mi_pdbqt_read_receptor(path.encode(), _ptr(xyz), _ptr(smt), n.value, C.byref(n)) != MI_OK:
         raise MiGninaError(lib().mi_pdbqt_last_error().decode())
     return xyz, smt
+
+
+def read_pdbqt_receptor_flex(rigid, flex, is_text=False):
+    """rigid receptor + flexible residues (.pdbqt paths, or contents with is_text) -> (xyz [n,3], smt [n], n_movable,
+    n_inflex); rows: movable side-chain atoms, the residues' fixed atoms, the rigid part (DLScorer::setReceptor's
+    order: declare rows 0 .. n_movable-1 with Scorer.set_flex)"""
+    n, nm, ni = C.c_int(), C.c_int(), C.c_int()
+    a, b = rigid.encode(), flex.encode()
+    if lib().mi_pdbqt_read_receptor_flex(a, b, int(is_text), None, None, 0, C.byref(n), C.byref(nm), C.byref(ni)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    xyz, smt = np.empty((n.value, 3), dtype=np.float32), np.empty(n.value, dtype=np.int32)
+    if lib().mi_pdbqt_read_receptor_flex(a, b, int(is_text), _ptr(xyz), _ptr(smt), n.value, C.byref(n), C.byref(nm),
+                                         C.byref(ni)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    return xyz, smt, nm.value, ni.value
 
 
 def read_pdbqt_ligand(path_or_text, is_text=False):

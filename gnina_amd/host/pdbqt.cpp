@@ -387,11 +387,11 @@ PdbqtReceptor parse_pdbqt_receptor(const std::string &name, const std::string &t
   return out;
 }
 
-PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text) {
-  LineReader r(name, text);
-  PS root;
+// ROOT ... ENDROOT, then BRANCH blocks, up to TORSDOF / end of input (a ligand) or END_RES (one flexible residue):
+// parse_pdbqt_root + parse_pdbqt_aux (parse_pdbqt.cpp:219-244,273-305).  Returns TORSDOF (-1: none seen).
+static int parse_tree(LineReader &r, PS &root, bool residue) {
+  const std::string &name = r.name;
   std::string s;
-  // parse_pdbqt_root (:219-244)
   bool have_root = false;
   while (!have_root && r.next(s)) {
     if (ignorable(s)) continue;
@@ -417,30 +417,32 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
       fail(name, r.count, "Unknown or inappropriate tag");
     }
   }
-  // parse_pdbqt_aux (:273-305)
   int torsdof = -1;
   while (r.next(s)) {
     if (ignorable(s)) continue;
     if (starts_with(s, "BRANCH")) {
       branch_aux(r, s, root);
-    } else if (starts_with(s, "TORSDOF")) {
+    } else if (!residue && starts_with(s, "TORSDOF")) {
       if (torsdof >= 0) fail(name, r.count, "TORSDOF can occur only once");
       std::istringstream is(s.substr(7));
       long t;
       is >> t;
       if (!is || t < 0) fail(name, r.count, "Syntax error");
       torsdof = (int)t;
+    } else if (residue && starts_with(s, "END_RES")) {
+      return torsdof;
     } else if (starts_with(s, "MODEL")) {
       fail(name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
     } else {
       fail(name, r.count, "Unknown or inappropriate tag");
     }
   }
-  if (root.atoms.empty()) fail(name, r.count, "No atoms in the ligand");
-  if (torsdof < 0) fail(name, r.count, "Missing TORSDOF");
+  return torsdof;
+}
 
-  // postprocess_ligand (:384-391): root frame at the first root atom
-  Builder b;
+// postprocess_ligand / postprocess_residue: the tree in model order.  Node 0 holds the ROOT atoms and the first
+// ("immobile") atoms of the top-level branches -- the rigid root of a ligand, the inflex atoms of a residue.
+static void build_tree(PS &root, Builder &b) {
   b.parent.push_back(-1);
   b.abeg.push_back(0);
   b.aend.push_back(0);
@@ -450,12 +452,30 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
     b.rel_axis.push_back(0.f);
   }
   b.branch(root, 0);
+}
+
+static std::vector<unsigned char> mobility_of(const Builder &b) {
   const int n = (int)b.atoms.size();
   std::vector<unsigned char> mobm((size_t)n * n, 0);
   for (const Builder::Mark &m : b.marks) {
     const int lo = std::min(m.a, m.b), hi = std::max(m.a, m.b);
     mobm[(size_t)lo * n + hi] = m.t;  // later marks overwrite earlier ones, like the reference's assignments
   }
+  return mobm;
+}
+
+PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text) {
+  LineReader r(name, text);
+  PS root;
+  const int torsdof = parse_tree(r, root, false);
+  if (root.atoms.empty()) fail(name, r.count, "No atoms in the ligand");
+  if (torsdof < 0) fail(name, r.count, "Missing TORSDOF");
+
+  // postprocess_ligand (:384-391): root frame at the first root atom
+  Builder b;
+  build_tree(root, b);
+  const int n = (int)b.atoms.size();
+  const std::vector<unsigned char> mobm = mobility_of(b);
   auto mob = [&](int i, int j) -> int { return i == j ? 1 : mobm[(size_t)std::min(i, j) * n + std::max(i, j)]; };
   std::vector<std::vector<int>> bonds;
   std::vector<int> sm;
@@ -505,6 +525,90 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
   return L;
 }
 
+// Flexible receptor: rigid part + flexible residues (parse_receptor_pdbqt(rigid, flex), parse_pdbqt.cpp:419-527).
+// A residue (BEGIN_RES ... END_RES) has the grammar of a ligand; postprocess_residue (:392-417) makes its ROOT atoms
+// and the first atoms of its top-level branches `inflex` (fixed, but part of the model, not of the receptor grid)
+// and every top-level branch a first_segment tree of movable atoms -- exactly node 0 / nodes >= 1 of the ligand
+// construction above.  Bonds for the X-Score typing follow model::distance_type_between (model.cpp:491-508):
+// rigid-rigid and rigid-inflex are fixed, rigid-movable is variable (never bonded), inside a residue the tree's
+// own marks, inflex-inflex fixed, movable atoms of different residues variable.
+PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const std::string &rigid_text,
+                                            const std::string &flex_name, const std::string &flex_text) {
+  struct Res {
+    Builder b;
+    std::vector<unsigned char> mobm;
+  };
+  std::vector<Res> residues;
+  {
+    LineReader r(flex_name, flex_text);
+    std::string s;
+    while (r.next(s)) {  // parse_pdbqt_flex, :481-527
+      if (s.empty() || starts_with(s, "WARNING") || starts_with(s, "REMARK") || starts_with(s, "USER")) continue;
+      if (starts_with(s, "BEGIN_RES")) {
+        PS root;
+        (void)parse_tree(r, root, true);
+        if (root.atoms.empty()) fail(flex_name, r.count, "No atoms in the residue");
+        residues.emplace_back();
+        build_tree(root, residues.back().b);
+        residues.back().mobm = mobility_of(residues.back().b);
+      } else if (starts_with(s, "MODEL")) {
+        fail(flex_name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+      } else {
+        fail(flex_name, r.count, "Unknown or inappropriate tag");
+      }
+    }
+  }
+  // rows in DLScorer::setReceptor's order (dl_scorer.cpp:93-193): movable, inflex, rigid
+  struct Row {
+    int res, idx;  // residue (-1 rigid), index in the residue's model order
+    int kind;      // 0 movable, 1 inflex, 2 rigid
+  };
+  std::vector<PAtom> atoms;
+  std::vector<Row> rows;
+  for (int kind = 0; kind < 2; kind++)
+    for (size_t q = 0; q < residues.size(); q++) {
+      const Builder &b = residues[q].b;
+      for (int i = 0; i < (int)b.atoms.size(); i++) {
+        const bool inflex = i >= b.abeg[0] && i < b.aend[0];
+        if ((kind == 1) != inflex) continue;
+        atoms.push_back(b.atoms[i]);
+        rows.push_back({(int)q, i, kind});
+      }
+    }
+  PdbqtFlexReceptor out;
+  for (const Row &rw : rows) (rw.kind == 0 ? out.n_movable : out.n_inflex)++;
+  {
+    LineReader r(rigid_name, rigid_text);
+    std::string s;
+    while (r.next(s)) {
+      if (starts_with(s, "ATOM  ") || starts_with(s, "HETATM")) {
+        atoms.push_back(parse_atom(rigid_name, r.count, s));
+        rows.push_back({-1, 0, 2});
+      } else if (starts_with(s, "MODEL")) {
+        fail(rigid_name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
+      }
+    }
+  }
+  auto mob = [&](int i, int j) -> int {
+    if (i == j) return 1;
+    const Row &a = rows[i], &b = rows[j];
+    if (a.kind == 2 || b.kind == 2) return (a.kind == 0 || b.kind == 0) ? 0 : 1;
+    if (a.res == b.res) {
+      const int n = (int)residues[a.res].b.atoms.size();
+      return residues[a.res].mobm[(size_t)std::min(a.idx, b.idx) * n + std::max(a.idx, b.idx)];
+    }
+    return (a.kind == 1 && b.kind == 1) ? 1 : 0;
+  };
+  std::vector<std::vector<int>> bonds;
+  std::vector<int> sm;
+  bonds_and_types(atoms, mob, bonds, sm);
+  for (size_t i = 0; i < atoms.size(); i++) {
+    out.xyz.insert(out.xyz.end(), atoms[i].c, atoms[i].c + 3);
+    out.smt.push_back(sm[i]);
+  }
+  return out;
+}
+
 static std::string num9(float v) {  // boost::lexical_cast<std::string>(float): up to 9 significant digits
   char buf[48];
   snprintf(buf, sizeof buf, "%.9g", (double)v);
@@ -545,6 +649,9 @@ static std::string slurp(const std::string &path) {
 }
 
 PdbqtReceptor read_pdbqt_receptor(const std::string &path) { return parse_pdbqt_receptor(path, slurp(path)); }
+PdbqtFlexReceptor read_pdbqt_receptor_flex(const std::string &rigid_path, const std::string &flex_path) {
+  return parse_pdbqt_receptor_flex(rigid_path, slurp(rigid_path), flex_path, slurp(flex_path));
+}
 PdbqtLigand read_pdbqt_ligand(const std::string &path) { return parse_pdbqt_ligand(path, slurp(path)); }
 
 }  // namespace gnina_amd
@@ -567,6 +674,29 @@ mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int
     if (!path || !n_atoms) throw std::runtime_error("NULL argument");
     gnina_amd::PdbqtReceptor r = gnina_amd::read_pdbqt_receptor(path);
     *n_atoms = (int)r.smt.size();
+    if (xyz && smt) {
+      if ((int)r.smt.size() > capacity) throw std::runtime_error("capacity too small");
+      if (!r.smt.empty()) {
+        std::memcpy(xyz, r.xyz.data(), r.xyz.size() * sizeof(float));
+        std::memcpy(smt, r.smt.data(), r.smt.size() * sizeof(int32_t));
+      }
+    }
+    return MI_OK;
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return MI_ERR_INVALID;
+  }
+}
+
+mi_status mi_pdbqt_read_receptor_flex(const char *rigid, const char *flex, int is_text, float *xyz, int32_t *smt,
+                                      int capacity, int *n_atoms, int *n_movable, int *n_inflex) {
+  try {
+    if (!rigid || !flex || !n_atoms || !n_movable || !n_inflex) throw std::runtime_error("NULL argument");
+    gnina_amd::PdbqtFlexReceptor r = is_text ? gnina_amd::parse_pdbqt_receptor_flex("<rigid>", rigid, "<flex>", flex)
+                                             : gnina_amd::read_pdbqt_receptor_flex(rigid, flex);
+    *n_atoms = (int)r.smt.size();
+    *n_movable = r.n_movable;
+    *n_inflex = r.n_inflex;
     if (xyz && smt) {
       if ((int)r.smt.size() > capacity) throw std::runtime_error("capacity too small");
       if (!r.smt.empty()) {

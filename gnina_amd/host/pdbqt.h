@@ -12,8 +12,11 @@
 //     pairs (initialize_pairs: variable distance, more than 3 bonds apart, heavy atoms).
 // The output is exactly what mi_scorer_set_receptor / mi_vina_set_receptor and mi_vina_set_ligand take.
 //
-// Not restated: flexible residues (BEGIN_RES), the `fix_hydrogens` option (off by default in gnina), multi-MODEL
-// files.  Parity: "unpinned" -- the reference ships no ligand .pdbqt fixture with expected types or pairs, so
+// Flexible receptors: parse_receptor_pdbqt(rigid, flex) -- residues between BEGIN_RES / END_RES have the grammar of a
+// ligand (parse_pdbqt.cpp:392-417,419-527); the reader returns the atoms in DLScorer::setReceptor's row order
+// (movable, inflex, rigid) with the X-Score types of the combined model (the residues' torsion trees are parsed
+// and used for the bond mobility, not yet returned).
+// Not restated: the `fix_hydrogens` option (off by default in gnina), multi-MODEL files.  Parity: "unpinned" -- the reference ships no ligand .pdbqt fixture with expected types or pairs, so
 // the tests check hand-derived small molecules and structural invariants (tests/test_pdbqt_cpu.py).
 #pragma once
 #include <cstdint>
@@ -44,6 +47,19 @@ struct PdbqtLigand {
   std::vector<std::string> lines;
   std::vector<int32_t> line_atom;
 };
+
+struct PdbqtFlexReceptor {
+  // rows: [0, n_movable) movable atoms of the flexible residues (residue by residue, tree order),
+  // [n_movable, n_movable + n_inflex) their fixed atoms (ROOT atoms and the first atom of every top-level branch),
+  // then the rigid receptor -- the order of DLScorer::setReceptor (dl_scorer.cpp:93-193): the first n_movable rows
+  // are what mi_scorer_set_flex declares
+  std::vector<float> xyz;    // [n][3]
+  std::vector<int32_t> smt;  // [n] after adjust_smina_type on the combined model
+  int n_movable = 0, n_inflex = 0;
+};
+PdbqtFlexReceptor read_pdbqt_receptor_flex(const std::string &rigid_path, const std::string &flex_path);
+PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const std::string &rigid_text,
+                                            const std::string &flex_name, const std::string &flex_text);
 
 // One docked pose as gnina writes it to a .pdbqt (result_info::write, result_info.cpp:151-164 +
 // context::writePDBQT / coords_to_pdbqt_string, model.cpp:779-810): MODEL n, REMARK minimizedAffinity /

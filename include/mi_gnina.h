@@ -354,6 +354,15 @@ const char *mi_io_last_error(void);
  * (BEGIN_RES) are not read.  Errors: NULL / MI_ERR_INVALID + mi_pdbqt_last_error() ("file:line: what"). */
 typedef struct mi_pdbqt_ligand mi_pdbqt_ligand;
 mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int capacity, int *n_atoms);
+/* parse_receptor_pdbqt(rigid, flex) (parse_pdbqt.cpp:419-527): rigid receptor + flexible residues (BEGIN_RES ...
+ * END_RES blocks with the ROOT / BRANCH grammar of a ligand).  Rows come back in DLScorer::setReceptor's order
+ * (dl_scorer.cpp:93-193): n_movable movable side-chain atoms, n_inflex fixed atoms of the residues, then the rigid
+ * atoms; types are those of the combined model (bonds never join a movable atom to the rigid part,
+ * model.cpp:491-508).  Feed the rows to mi_scorer_set_receptor and declare rows 0 .. n_movable-1 with
+ * mi_scorer_set_flex.  rigid / flex are paths, or the file contents when is_text != 0.  Same two-call protocol
+ * (xyz = smt = NULL to query the size) and error reporting as mi_pdbqt_read_receptor. */
+mi_status mi_pdbqt_read_receptor_flex(const char *rigid, const char *flex, int is_text, float *xyz, int32_t *smt,
+                                      int capacity, int *n_atoms, int *n_movable, int *n_inflex);
 mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text);
 void mi_pdbqt_ligand_close(mi_pdbqt_ligand *);
 mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof);

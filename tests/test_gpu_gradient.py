@@ -146,3 +146,26 @@ def test_flexible_receptor_rows(capi, CG, name):
     s.set_flex(np.zeros(0, np.int32))
     plain = s.score_batch(poses, lig_smt)
     assert np.abs(plain["pose"] - CG[name + "/pose"][:2]).max() < 1e-4
+
+
+def test_flexible_receptor_from_pdbqt_files(capi):
+    """The rows of mi_pdbqt_read_receptor_flex go straight into mi_scorer_set_receptor / mi_scorer_set_flex (movable
+    side-chain atoms first): scoring with moved side-chain coordinates equals scoring a receptor whose rows were
+    moved, and the side-chain gradient is non-zero where the ligand touches it."""
+    from tests.test_pdbqt_cpu import RIGID, SER_FLEX
+    rec_xyz, rec_smt, n_mov, n_inflex = capi.read_pdbqt_receptor_flex(RIGID, SER_FLEX, is_text=True)
+    assert (n_mov, n_inflex) == (2, 2)
+    lig = np.array([[[3.5, 2.6, 1.0], [4.6, 3.4, 1.2], [4.4, 1.4, 0.4]]], dtype=np.float32)
+    lig_smt = np.array([2, 13, 6], dtype=np.int32)
+    moved = rec_xyz[:n_mov][None] + np.array([[[0.4, -0.3, 0.2], [0.5, -0.2, 0.3]]], dtype=np.float32)
+    s = capi.Scorer(["default2017"])
+    s.set_receptor(rec_xyz, rec_smt)
+    s.set_flex(np.arange(n_mov, dtype=np.int32))
+    out = s.score_flex(lig, lig_smt, moved)
+    ref_xyz = rec_xyz.copy()
+    ref_xyz[:n_mov] = moved[0]
+    s2 = capi.Scorer(["default2017"])
+    s2.set_receptor(ref_xyz, rec_smt)
+    ref = s2.score_batch(lig, lig_smt)
+    assert out["pose"][0] == ref["pose"][0] and out["affinity"][0] == ref["affinity"][0]
+    assert np.abs(out["flex_grad"][0][0]).max() > 0 and not out["flex_grad"][0][1].any()   # OG typed, HG (polar H) not

@@ -168,3 +168,45 @@ def test_pose_writer_round_trip(capi):
         assert "REMARK  hand-made test ligand" in m and "TORSDOF 3" in m and "BRANCH   3   4" in m
     with pytest.raises(capi.MiGninaError, match="8-column"):
         capi.pdbqt_poses_text(text, poses * 1e5, energies=[0, 0, 0], is_text=True)
+
+
+SER_FLEX = "\n".join([
+    "BEGIN_RES SER A  10", "REMARK  2 active torsions", "ROOT", atom_line(1, "CA", 0.0, 0.0, 0.0, "C"), "ENDROOT",
+    "BRANCH   1   2", atom_line(2, "CB", 1.52, 0.0, 0.0, "C"),
+    "BRANCH   2   3", atom_line(3, "OG", 2.10, 1.30, 0.0, "OA"), atom_line(4, "HG", 3.05, 1.30, 0.0, "HD"),
+    "ENDBRANCH   2   3", "ENDBRANCH   1   2", "END_RES", ""])
+RIGID = "\n".join([atom_line(10, "N", -0.53, 1.36, 0.0, "N"), atom_line(11, "CX", 2.10, 2.80, 0.0, "C"), "TER", ""])
+
+
+def test_flexible_receptor_rows_and_typing(capi, tmp_path):
+    """parse_receptor_pdbqt(rigid, flex): postprocess_residue makes the ROOT atom and the first atom of the top-level
+    branch inflex ([CA, CB]), the rest movable in tree order ([OG, HG]); rows come back movable | inflex | rigid
+    (DLScorer::setReceptor).  Typing on the combined model: OG carries HG -> donor/acceptor 12; CB is bonded to OG
+    -> 3; CA is bonded (inflex-rigid distances are fixed) to the backbone N of the rigid part -> 3; the rigid carbon
+    1.5 A from OG is NOT bonded to it (rigid-movable distances are variable, model.cpp:491-508) -> stays 2."""
+    xyz, smt, nm, ni = capi.read_pdbqt_receptor_flex(RIGID, SER_FLEX, is_text=True)
+    assert (nm, ni, len(smt)) == (2, 2, 6)
+    assert np.allclose(xyz, [[2.10, 1.30, 0], [3.05, 1.30, 0], [0, 0, 0], [1.52, 0, 0], [-0.53, 1.36, 0], [2.10, 2.80, 0]])
+    assert smt.tolist() == [12, 1, 3, 3, 6, 2]
+    # the same six atoms as one rigid receptor: now the carbon next to OG is bonded to a heteroatom
+    allrigid = "\n".join(l for l in (SER_FLEX + RIGID).split("\n") if l.startswith("ATOM"))
+    p = tmp_path / "all.pdbqt"
+    p.write_text(allrigid + "\n")
+    _, smt_r = capi.read_pdbqt_receptor(str(p))
+    assert smt_r.tolist() == [3, 3, 12, 1, 6, 3]
+    # files on disk, two residues: the second residue's atoms follow the first's inside each group
+    f, r = tmp_path / "flex.pdbqt", tmp_path / "rigid.pdbqt"
+    second = SER_FLEX.replace("SER A  10", "SER A  11")
+    for old, new in (("   0.000   0.000   0.000", "  20.000   0.000   0.000"), ("   1.520   0.000", "  21.520   0.000"),
+                     ("   2.100   1.300", "  22.100   1.300"), ("   3.050   1.300", "  23.050   1.300")):
+        second = second.replace(old, new)
+    f.write_text(SER_FLEX + second)
+    r.write_text(RIGID)
+    xyz2, smt2, nm2, ni2 = capi.read_pdbqt_receptor_flex(str(r), str(f))
+    assert (nm2, ni2, len(smt2)) == (4, 4, 10)
+    assert np.allclose(xyz2[:4, 0], [2.10, 3.05, 22.10, 23.05]) and np.allclose(xyz2[4:8, 0], [0, 1.52, 20, 21.52])
+    assert smt2.tolist() == [12, 1, 12, 1, 3, 3, 2, 3, 6, 2]     # the second CA has no rigid N next to it -> 2
+    with pytest.raises(capi.MiGninaError, match=r"<flex>:\d+: Unknown or inappropriate tag"):
+        capi.read_pdbqt_receptor_flex(RIGID, SER_FLEX.replace("END_RES", "ENDRES"), is_text=True)
+    with pytest.raises(capi.MiGninaError, match="Unknown or inappropriate tag"):
+        capi.read_pdbqt_receptor_flex(RIGID, "ROOT\n" + SER_FLEX, is_text=True)
