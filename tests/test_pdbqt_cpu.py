@@ -210,3 +210,17 @@ def test_flexible_receptor_rows_and_typing(capi, tmp_path):
         capi.read_pdbqt_receptor_flex(RIGID, SER_FLEX.replace("END_RES", "ENDRES"), is_text=True)
     with pytest.raises(capi.MiGninaError, match="Unknown or inappropriate tag"):
         capi.read_pdbqt_receptor_flex(RIGID, "ROOT\n" + SER_FLEX, is_text=True)
+
+
+def test_pdbqt_to_gninatypes_tool(capi, tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r, f, out = tmp_path / "r.pdbqt", tmp_path / "f.pdbqt", tmp_path / "o.gninatypes"
+    r.write_text(RIGID)
+    f.write_text(SER_FLEX)
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "pdbqt_to_gninatypes.py"), "--flex", str(f), str(r),
+                          str(out)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "2 movable + 2 inflex + 2 rigid" in res.stdout, res.stderr
+    xyz, smt = capi.read_gninatypes(str(out))
+    assert smt.tolist() == [12, 1, 3, 3, 6, 2] and np.allclose(xyz[0], [2.10, 1.30, 0.0])
