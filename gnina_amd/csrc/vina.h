@@ -82,6 +82,7 @@ struct VinaMcArgs {
   // counts; containers use the common strides below (floats per saved conformation / coordinate set)
   const VinaLigand *ligs;
   const int *chain_lig, *lig_steps, *lig_iters;
+  const int *order;  // optional [B]: workgroup g runs chain order[g] (longest searches first)
   int conf_stride, coord_stride;
 };
 

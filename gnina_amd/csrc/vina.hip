@@ -1501,8 +1501,11 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   constexpr int HR = TP ? kHRegTp : kHReg, PG = TP ? kPairGroupTp : kPairGroup;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *pp = lds;
+  // workgroups start in index order and the launch ends with its slowest chain: screen launches hand the chains
+  // out longest first (a.order), whatever order the caller listed them in
+  const int chain = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   if (a.ligs) {  // screen mode: this chain's ligand and search length
-    const int l = a.chain_lig[blockIdx.x];
+    const int l = a.chain_lig[chain];
     L = a.ligs[l];
     a.n_steps = a.lig_steps[l];
     a.max_iters = a.lig_iters[l];
@@ -1532,7 +1535,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   float *rm = carve(pp, 64);                       // rmsd of the candidate to each saved pose (wave 0)
   int *ord = reinterpret_cast<int *>(carve(pp, a.num_saved));  // sorted position -> physical slot (wave 0)
   const WaveTeam tm{W, wv, stride, sh_f, sh_ok};
-  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int b = chain, lane = threadIdx.x & 63;
   McRng rng{a.seeds[b]};
   int evals = 0;
   // scratch container of this chain (physical slots)

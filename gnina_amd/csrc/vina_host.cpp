@@ -93,7 +93,7 @@ struct Vina {
   // screen: many ligands resident at once, docked by one launch (mi_vina_set_screen / mi_vina_mc_screen)
   std::vector<std::unique_ptr<LigandDev>> screen;
   DevBuf<VinaLigand> d_screen;
-  DevBuf<int> d_chain_lig, d_lig_steps, d_lig_iters;
+  DevBuf<int> d_chain_lig, d_lig_steps, d_lig_iters, d_chain_order;
   // scratch
   DevBuf<float> d_confs, d_energy, d_change, d_coords;
   DevBuf<float> d_ext_forces, d_ext_e, d_ext_centers;
@@ -727,6 +727,18 @@ mi_status mi_vina_mc_screen(mi_vina *vv, int B, const int32_t *chain_ligand, con
   a.out_coords = v.d_mc_xyz.p;
   a.out_n = v.d_out_n.p;
   a.evals = v.d_evals.p;
+  {  // longest searches first: steps x (pairs + atoms) as the cost of a chain; stable, so ties keep the caller's order
+    std::vector<int> order(B);
+    std::vector<double> cost(B);
+    for (int b = 0; b < B; b++) {
+      const VinaLigand &L = v.screen[chain_ligand[b]]->lig;
+      order[b] = b;
+      cost[b] = (double)steps[chain_ligand[b]] * (L.n_pairs + 8.0 * L.n_atoms);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+    v.d_chain_order.upload(order.data(), B, v.stream);
+    a.order = v.d_chain_order.p;
+  }
   a.ligs = v.d_screen.p;
   a.chain_lig = v.d_chain_lig.p;
   a.lig_steps = v.d_lig_steps.p;

@@ -266,7 +266,8 @@ int mi_vina_ligand_heavy_atoms(const mi_vina *);
  * params[0]).  Same search box, receptor and cache grids for all (build the cache for the union of the ligands'
  * atom types).  Outputs as mi_vina_mc_batch with common strides: out_conf [B][num_saved][max_conf], out_coords
  * [B][num_saved][max_heavy][3] (mi_vina_screen_dims); a chain of ligand l fills the first 7+T_l / n_heavy_l*3
- * floats of its rows.  A chain's result is bit-identical to mi_vina_mc_batch of that ligand with the same seed. */
+ * floats of its rows.  A chain's result is bit-identical to mi_vina_mc_batch of that ligand with the same seed.
+ * Chains may be listed in any order: the launch hands them to the device longest search first. */
 mi_status mi_vina_set_screen(mi_vina *, int n_lig, const mi_ligand_desc *descs);
 int mi_vina_screen_size(const mi_vina *);
 mi_status mi_vina_screen_dims(const mi_vina *, int32_t *max_conf, int32_t *max_heavy, int32_t *max_atoms);

@@ -42,8 +42,6 @@ def main():
         lig["coords0"] = (lig["coords0"] + shift).astype(np.float32)
         lig["conf0"][:3] += shift
         ligs.append(lig)
-    # longest searches first: the launch ends with its slowest chain, and workgroups start in index order
-    ligs.sort(key=lambda l: -(50 + len(l["smt"]) + 10 * (6 + l["n_tors"])) * len(l["pairs"]))
     size = np.full(3, 22.0, np.float32)            # one search box for the whole screen (the binding site)
     begin, end, n = setup_grid_dims(np.zeros(3, np.float32), size)
     types = sorted({int(t) for lig in ligs for t in lig["smt"] if t > 1})
