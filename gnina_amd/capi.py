@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -131,6 +131,7 @@ def lib():
         L.mi_pdbqt_ligand_close.argtypes = [vp]
         L.mi_pdbqt_ligand_close.restype = None
         L.mi_pdbqt_ligand_sizes.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+        L.mi_pdbqt_ligand_num_tors.argtypes = [vp, C.POINTER(C.c_float)]
         L.mi_pdbqt_ligand_desc.argtypes = [vp, vp, vp, vp, vp]
         L.mi_pdbqt_last_error.restype = C.c_char_p
         L.mi_pdbqt_write_pose.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_size_t,
@@ -307,9 +308,16 @@ def read_pdbqt_ligand(path_or_text, is_text=False):
                 "aend": arr(d.node_atom_end, (nn,), np.int32), "rel_origin": arr(d.node_rel_origin, (nn, 3), np.float32),
                 "rel_axis": arr(d.node_rel_axis, (nn, 3), np.float32), "pairs": arr(d.pairs, (npairs, 2), np.int32),
                 "coords0": arr(pxyz, (na, 3), np.float32), "serial": arr(pser, (na,), np.int32),
-                "conf0": arr(pconf, (7 + nn - 1,), np.float32), "n_tors": nn - 1, "torsdof": tors.value}
+                "conf0": arr(pconf, (7 + nn - 1,), np.float32), "n_tors": nn - 1, "torsdof": tors.value,
+                "num_tors": _ligand_num_tors(h)}
     finally:
         lib().mi_pdbqt_ligand_close(h)
+
+
+def _ligand_num_tors(h):
+    nt = C.c_float()
+    check(lib().mi_pdbqt_ligand_num_tors(h, C.byref(nt)))
+    return nt.value
 
 
 def pdbqt_poses_text(path_or_text, poses, energies, cnnscores=None, cnnaffinities=None, rmsds=None, is_text=False):

@@ -110,24 +110,29 @@ ModelDesc parse_blob(const void *blob, size_t nbytes, const char *name_override)
   } catch (const std::exception &e) {
     throw Error(2, std::string("malformed MIGNINA1 header: ") + e.what());
   }
-  MIG_CHECK(ndata >= 0 && off + (size_t)ndata * 4 <= nbytes, 2, "truncated MIGNINA1 payload");
+  MIG_CHECK(ndata >= 0 && off <= nbytes && (size_t)ndata <= (nbytes - off) / 4, 2, "truncated MIGNINA1 payload");
+  MIG_CHECK(m.resolution > 0 && m.dimension > 0 && std::isfinite(m.resolution) && std::isfinite(m.dimension), 2,
+            "resolution and dimension must be positive");
   m.data.resize((size_t)ndata);
   std::memcpy(m.data.data(), p + off, (size_t)ndata * 4);
   if (name_override && *name_override) m.name = name_override;
 
   // structural validation of the program
   MIG_CHECK(!m.bufs.empty() && !m.ops.empty(), 2, "empty layer program");
+  for (const BufDecl &b : m.bufs) MIG_CHECK(b.S > 0 && b.C > 0, 2, "buffer sizes must be positive");
   MIG_CHECK(m.bufs[0].S == m.grid_points() && m.bufs[0].C == m.n_channels(), 2,
             "buffer 0 must be the voxel grid [N][N][N][n_rec+n_lig channels]");
   auto okbuf = [&](int b) { return b >= 0 && b < (int)m.bufs.size(); };
   for (const Op &o : m.ops) {
     if (o.kind != OpKind::Fc) MIG_CHECK(okbuf(o.src) && okbuf(o.dst), 2, "op references unknown buffer");
     if (o.kind == OpKind::Conv) {
+      MIG_CHECK(o.cin > 0 && o.cout > 0 && o.dst_c0 >= 0, 2, "conv channel counts must be positive");
       MIG_CHECK(o.cin <= m.bufs[o.src].C && o.dst_c0 + o.cout <= m.bufs[o.dst].C, 2, "conv channel range");
       MIG_CHECK(m.bufs[o.src].S == m.bufs[o.dst].S, 2, "conv changes spatial size");
       long nw = (long)o.ksize * o.ksize * o.ksize * o.cin * o.cout;
       MIG_CHECK(o.w_off >= 0 && o.w_off + nw <= ndata && o.b_off >= 0 && o.b_off + o.cout <= ndata, 2,
                 "conv weights out of range");
+      MIG_CHECK(o.bn_scale_off >= 0 || o.bn_shift_off < 0, 2, "bn shift without bn scale");
       if (o.bn_scale_off >= 0)
         MIG_CHECK(o.bn_scale_off + o.cin <= ndata && o.bn_shift_off >= 0 && o.bn_shift_off + o.cin <= ndata, 2,
                   "bn params out of range");

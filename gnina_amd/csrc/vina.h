@@ -108,6 +108,9 @@ struct VinaPopulateArgs {
   VinaGridGeom geom;
   int lig_type;
   float *out;  // [(dimz)][(dimy)][(dimx)], x fastest
+  // per dimension and lattice index: the candidate brick of the point's 3 A cell (szv_grid_cache::get), see
+  // mi_vina_build_cache.  [dimx + dimy + dimz] (lo, hi)
+  const float2 *brick;
 };
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage);

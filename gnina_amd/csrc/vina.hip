@@ -1795,7 +1795,9 @@ void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs
 // ---------------------------------------------------------------------------------------------
 // cache::populate (cache.cpp:104-184): one thread per grid point, receptor atoms staged through
 // LDS in tiles; per point the sum runs over receptor atoms in index order like the reference's
-// index-ordered `possibilities` list, so the fp32 result is the same sum.
+// index-ordered `possibilities` list, so the fp32 result is the same sum.  An atom counts only if it is on the
+// candidate list of the point's 3 A cell, i.e. within the cut-off of the cell's brick as szv_grid_cache::get
+// (szv_grid.h:107-144) built it (a.brick; degenerate bricks included: oracle/_ref reproduces them).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) {
   __shared__ float4 tile[256];
@@ -1808,6 +1810,7 @@ __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) 
   const float px = a.geom.init[0] + a.geom.factor_inv[0] * (float)x;  // index_to_argument, grid.h:54-57
   const float py = a.geom.init[1] + a.geom.factor_inv[1] * (float)y;
   const float pz = a.geom.init[2] + a.geom.factor_inv[2] * (float)z;
+  const float2 bx = a.brick[x], by = a.brick[a.geom.dim[0] + y], bz = a.brick[a.geom.dim[0] + a.geom.dim[1] + z];
   float aff = 0.f;
   for (int base = 0; base < a.n_rec; base += 256) {
     __syncthreads();
@@ -1818,7 +1821,10 @@ __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) 
       const float4 r = tile[j];
       const float dx = r.x - px, dy = r.y - py, dz = r.z - pz;
       const float r2 = dx * dx + dy * dy + dz * dz;
-      if (r2 <= a.cutoff_sqr) {
+      // brick_distance_sqr (brick.h:37-49): closest point of the cell's brick to the atom
+      const float cx = fminf(fmaxf(r.x, bx.x), bx.y) - r.x, cy = fminf(fmaxf(r.y, by.x), by.y) - r.y,
+                  cz = fminf(fmaxf(r.z, bz.x), bz.y) - r.z;
+      if (r2 <= a.cutoff_sqr && cx * cx + cy * cy + cz * cz < a.cutoff_sqr) {
         const int t1 = __float_as_int(r.w);
         aff += a.fast[(long)tri_idx(t1, a.lig_type) * a.n + (int)(a.factor * r2)];
       }

@@ -75,6 +75,7 @@ struct Vina {
   DevBuf<float> d_fast;
   // receptor
   DevBuf<float4> d_rec;
+  DevBuf<float2> d_brick;
   int n_rec = 0;
   // cache
   bool have_cache = false;
@@ -223,17 +224,22 @@ mi_status mi_vina_set_receptor(mi_vina *vv, const float *xyz, const int32_t *smt
   VTRY
   MIG_CHECK(vv && n >= 0 && (n == 0 || (xyz && smt)), 1, "bad receptor arguments");
   Vina &v = *reinterpret_cast<Vina *>(vv);
-  std::vector<float4> rec(n);
+  // Receptor hydrogens are never interaction partners: cache::populate, non_cache::eval / eval_deriv and
+  // non_cache_cnn's empirical term only see the atoms szv_grid hands out, and szv_grid drops hydrogens
+  // (szv_grid.h:69-73,126-131: `!a.is_hydrogen() && a.acceptable_type()`).  Order of the rest is kept.
+  std::vector<float4> rec;
+  rec.reserve(n);
   for (int i = 0; i < n; i++) {
     MIG_CHECK(smt[i] >= 0 && smt[i] < kVinaTypes, 1, "receptor smina type out of range");
+    if (smt[i] <= 1) continue;  // Hydrogen, PolarHydrogen (atom_constants.h:101-104)
     float w;
     int32_t t = smt[i];
     std::memcpy(&w, &t, 4);
-    rec[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], w);
+    rec.push_back(make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], w));
   }
   v.d_rec.upload(rec.data(), rec.size(), v.stream);
   MIG_HIP(hipStreamSynchronize(v.stream));
-  v.n_rec = n;
+  v.n_rec = (int)rec.size();
   v.have_cache = false;
   return MI_OK;
   VCATCH_STATUS
@@ -266,6 +272,27 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
   }
   v.d_grids.ensure((size_t)cnt * v.grid_pts);
   v.slope = slope;
+  // szv_grid_cache::get (szv_grid.h:107-144) builds the candidate list of a 3 A cell the first time a point falls
+  // into it, from the brick [floor(c/3)*3, ceil(c/3)*3] of THAT point -- a plane or a line when a coordinate is an
+  // exact multiple of 3 -- and reuses it for the cell's later points.  cache::populate walks x, y, z upwards, so the
+  // first point of a cell is its lowest lattice point per dimension.  Reproduced so that grids match the reference's
+  // bit for bit on boxes aligned with that lattice (oracle/_ref; tests/test_ref_vina.py).
+  std::vector<float2> brick;
+  for (int d = 0; d < 3; d++) {
+    const float gran = 3.0f;
+    float cur_cell = 0, lo = 0, hi = 0;
+    for (int i = 0; i < v.geom.dim[d]; i++) {
+      const float c = v.geom.init[d] + v.geom.factor_inv[d] * (float)i;
+      const float cell = std::floor(c / gran);
+      if (i == 0 || cell != cur_cell) {
+        cur_cell = cell;
+        lo = std::floor(c / gran) * gran;
+        hi = std::ceil(c / gran) * gran;
+      }
+      brick.push_back(make_float2(lo, hi));
+    }
+  }
+  v.d_brick.upload(brick.data(), brick.size(), v.stream);
   for (int t = 0; t < kVinaTypes; t++) {
     if (v.grid_off[t] < 0) continue;
     VinaPopulateArgs a{};
@@ -278,6 +305,7 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
     a.geom = v.geom;
     a.lig_type = t;
     a.out = v.d_grids.p + v.grid_off[t];
+    a.brick = v.d_brick.p;
     launch_vina_populate(a, v.stream);
   }
   MIG_HIP(hipGetLastError());
@@ -636,11 +664,12 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
   a.out_coords = v.d_mc_xyz.p;
   a.out_n = v.d_out_n.p;
   a.evals = v.d_evals.p;
-  const bool prof = getenv("MI_VINA_MC_PROFILE") != nullptr;
+  static const bool prof = getenv("MI_VINA_MC_PROFILE") != nullptr;
+  DevBuf<long long> prof_buf;  // diagnostic only; released on every exit path
   long long *d_prof = nullptr;
   if (prof) {
-    MIG_HIP(hipMalloc(&d_prof, (size_t)B * 12 * sizeof(long long)));
-    a.prof = d_prof;
+    prof_buf.ensure((size_t)B * 12);
+    a.prof = d_prof = prof_buf.p;
   }
   launch_vina_mc(make_env(v), v.lig, a, B, v.stream);
   MIG_HIP(hipGetLastError());
@@ -648,7 +677,6 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
     std::vector<long long> hp((size_t)B * 12);
     MIG_HIP(hipMemcpyAsync(hp.data(), d_prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, v.stream));
     MIG_HIP(hipStreamSynchronize(v.stream));
-    MIG_HIP(hipFree(d_prof));
     double m[12] = {0};
     for (int b = 0; b < B; b++)
       for (int i = 0; i < 12; i++) m[i] += (double)hp[(size_t)b * 12 + i] / B;
@@ -1150,26 +1178,34 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
 
 // do_search's final energies (main.cpp:339-344): intramolecular = eval_intramolecular(exact_prec) and
 // e = conf_independent(eval(exact_prec, non_cache) - intramolecular) with num_tors_div (everything.h:796-814)
+// do_search's docking branch (main.cpp:231,339-344): e = eval_adjusted(sf, exact_prec, nc_new, ...) where nc_new is a
+// non_cache built on the run's LINEAR precalculate (main.cpp:231) -- its receptor term is the table look-up
+// p->eval = eval_fast -- while the pair terms of model::eval and eval_intramolecular use exact_prec:
+//   e = (non_cache::eval [linear, fast] + ligand pairs [exact]) - intramolecular [exact], then num_tors_div
+// (everything.h:796-814: w = 0.1 * (weight + 1) and 1 + w * num_tors / 5.0 are evaluated in double).
+static float conf_independent_default(float inter_plus_intra, float intra, float num_tors) {
+  const float weight = (float)(5 * 0.05846 / 0.1 - 1);  // main.cpp:1329
+  const float w = (float)(0.1 * (weight + 1));
+  const float x = inter_plus_intra - intra;
+  const float y = (float)(1 + w * num_tors / 5.0);
+  // smooth_div, everything.h:52-56
+  if (std::fabs(x) < 1.1920928955078125e-07f) return 0;
+  if (std::fabs(y) < 1.1920928955078125e-07f) return (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;
+  return x / y;
+}
+
 mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const float *v3, float num_tors,
                                  float *e_final, float *intramolecular) {
   VTRY
   MIG_CHECK(vv && confs && v3 && e_final && B >= 0, 1, "bad arguments");
   if (B == 0) return MI_OK;
-  std::vector<float> total(B), intra(B);
-  mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 0 | MI_VINA_DIRECT | MI_VINA_EXACT, total.data(), nullptr, nullptr);
+  std::vector<float> inter(B), intra(B);
+  mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 2 | MI_VINA_DIRECT, inter.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
   st = mi_vina_eval_batch(vv, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
-  const float weight = (float)(5 * 0.05846 / 0.1 - 1);  // main.cpp:1329
-  const float w = 0.1f * (weight + 1);
   for (int b = 0; b < B; b++) {
-    const float x = total[b] - intra[b];
-    const float y = 1 + w * num_tors / 5.0f;
-    float r;  // smooth_div, everything.h:52-56
-    if (std::fabs(x) < 1.1920928955078125e-07f) r = 0;
-    else if (std::fabs(y) < 1.1920928955078125e-07f) r = (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;
-    else r = x / y;
-    e_final[b] = r;
+    e_final[b] = conf_independent_default(inter[b] + intra[b], intra[b], num_tors);
     if (intramolecular) intramolecular[b] = intra[b];
   }
   return MI_OK;
@@ -1181,22 +1217,13 @@ mi_status mi_vina_final_energies_screen(mi_vina *vv, const int32_t *item_ligand,
   VTRY
   MIG_CHECK(vv && item_ligand && confs && v3 && num_tors && e_final && B >= 0, 1, "bad arguments");
   if (B == 0) return MI_OK;
-  std::vector<float> total(B), intra(B);
-  mi_status st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 0 | MI_VINA_DIRECT | MI_VINA_EXACT, total.data(),
-                                     nullptr, nullptr);
+  std::vector<float> inter(B), intra(B);
+  mi_status st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 2 | MI_VINA_DIRECT, inter.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
   st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
-  const float weight = (float)(5 * 0.05846 / 0.1 - 1);  // main.cpp:1329
-  const float w = 0.1f * (weight + 1);
   for (int b = 0; b < B; b++) {
-    const float x = total[b] - intra[b];
-    const float y = 1 + w * num_tors[item_ligand[b]] / 5.0f;
-    float r;  // smooth_div, everything.h:52-56
-    if (std::fabs(x) < 1.1920928955078125e-07f) r = 0;
-    else if (std::fabs(y) < 1.1920928955078125e-07f) r = (x * y > 0) ? 3.402823466e+38f : -3.402823466e+38f;
-    else r = x / y;
-    e_final[b] = r;
+    e_final[b] = conf_independent_default(inter[b] + intra[b], intra[b], num_tors[item_ligand[b]]);
     if (intramolecular) intramolecular[b] = intra[b];
   }
   return MI_OK;
@@ -1252,8 +1279,9 @@ mi_status mi_merge_mc_outputs(const int32_t *in_n, const float *in_e, const floa
                               float *out_e, float *out_conf, float *out_coords) {
   VTRY
   MIG_CHECK(in_n && in_e && in_conf && in_coords && out_n && out_e && out_conf && out_coords && B >= 0 && S > 0 &&
-                max_size > 0,
+                max_size > 0 && conf_len > 0 && n_heavy >= 0,
             1, "bad arguments");
+  for (int b = 0; b < B; b++) MIG_CHECK(in_n[b] >= 0 && in_n[b] <= S, 1, "chain output count outside [0, S]");
   struct Ent {
     float e;
     const float *conf, *xyz;

@@ -136,8 +136,10 @@ bool ignorable(const std::string &s) {
 }
 
 // ---- covalent bonds + type adjustment (model::assign_bonds / assign_types, model.cpp:560-655) -----------------
-// mob(i, j): 0 variable, 1 fixed, 2 rotor.  A cell list replaces the reference's "beads" (same candidate set:
-// every atom within the cut-off is seen).
+// mob(i, j): 0 variable, 1 fixed, 2 rotor.  A cell list finds the candidates (the same set the reference's 15 A
+// "beads" give: every atom within the cut-off is seen); they are then visited in the reference's order -- bead by
+// bead, index order inside a bead (model.cpp:540-557,585-602) -- because the order of an atom's bond list feeds the
+// order-dependent depth-first walk of bonded_to() that decides which 1-4 pairs are excluded.
 template <typename Mob>
 void bonds_and_types(const std::vector<PAtom> &atoms, Mob mob, std::vector<std::vector<int>> &bonds, std::vector<int> &sm_out) {
   const int n = (int)atoms.size();
@@ -168,6 +170,18 @@ void bonds_and_types(const std::vector<PAtom> &atoms, Mob mob, std::vector<std::
     for (int k = 0; k < 3; k++) s += (atoms[a].c[k] - atoms[b].c[k]) * (atoms[a].c[k] - atoms[b].c[k]);
     return s;
   };
+  // beads::add: an atom joins the first bead whose centre (that bead's first atom) is closer than 15 A
+  std::vector<int> bead_of(n), bead_centre;
+  for (int i = 0; i < n; i++) {
+    int b = -1;
+    for (size_t k = 0; k < bead_centre.size() && b < 0; k++)
+      if (d2(i, bead_centre[k]) < 15.f * 15.f) b = (int)k;
+    if (b < 0) {
+      b = (int)bead_centre.size();
+      bead_centre.push_back(i);
+    }
+    bead_of[i] = b;
+  }
   std::vector<int> rel;
   for (int i = 0; i < n; i++) {
     const float ci = kTypes[atoms[i].sm].covalent;
@@ -187,7 +201,9 @@ void bonds_and_types(const std::vector<PAtom> &atoms, Mob mob, std::vector<std::
             if (j != i && mob(i, j) != 0 && d2(i, j) < cut * cut) rel.push_back(j);
           }
         }
-    std::sort(rel.begin(), rel.end());
+    std::sort(rel.begin(), rel.end(), [&](int a, int b) {
+      return bead_of[a] < bead_of[b] || (bead_of[a] == bead_of[b] && a < b);
+    });
     for (int j : rel) {
       if (j <= i) continue;
       const float len = ci + kTypes[atoms[j].sm].covalent;  // optimal_covalent_bond_length
@@ -299,6 +315,12 @@ void parse_branch(LineReader &r, PS &p, unsigned from, unsigned to) {  // parse_
       fail(r.name, r.count, "Unknown or inappropriate tag");
     }
   }
+  // Input ended inside the BRANCH.  The reference's loop just ends (parse_pdbqt.cpp:481-523) and the branch is kept
+  // as read; only a branch that has atoms but never met its second atom trips VINA_CHECK(immobile_atom) later
+  // (parsing.h:182-202; an empty branch is skipped there).
+  if (p.immobile < 0 && !p.atoms.empty())
+    fail(r.name, r.count, "Unexpected end of file in BRANCH " + std::to_string(from) + " " + std::to_string(to) +
+                              ": atom " + std::to_string(to) + " has not been found");
 }
 
 struct Builder {
@@ -323,6 +345,7 @@ struct Builder {
   void insert_immobiles(Node &nd, const float *frame_origin, int node) {  // parsing.h:159-163,194-202
     for (PS &c : nd.ps)
       if (!c.atoms.empty()) {
+        if (c.immobile < 0) throw std::runtime_error("branch without its immobile atom");  // VINA_CHECK(immobile_atom)
         c.axis_end = (int)atoms.size();
         insert(c.atoms[c.immobile], frame_origin, node);
       }
@@ -437,7 +460,7 @@ static int parse_tree(LineReader &r, PS &root, bool residue) {
       fail(name, r.count, "Unknown or inappropriate tag");
     }
   }
-  return torsdof;
+  return torsdof;  // a residue without END_RES ends with the input, as in the reference (parse_pdbqt.cpp:273-305)
 }
 
 // postprocess_ligand / postprocess_residue: the tree in model order.  Node 0 holds the ROOT atoms and the first
@@ -514,6 +537,21 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
       L.pairs.push_back(i);
       L.pairs.push_back(j);
     }
+  }
+  // conf_independent_inputs::num_tors (terms.cpp:39-106): half a count per heavy atom and rotatable bond to a heavy
+  // neighbour that has another heavy neighbour (fix_hydrogens is off: the atom's own heavy degree is not checked)
+  auto heavy_degree = [&](int a) {
+    int k = 0;
+    for (int nb : bonds[a]) k += sm[nb] > kHD;
+    return k;
+  };
+  L.num_tors = 0.f;
+  for (int i = 0; i < n; i++) {
+    if (sm[i] <= kHD) continue;
+    unsigned rotors = 0;
+    for (int nb : bonds[i])
+      if (mob(i, nb) == 2 && sm[nb] > kHD && heavy_degree(nb) > 1) rotors++;
+    L.num_tors += 0.5f * rotors;
   }
   L.lines = r.lines;
   L.line_atom.assign(L.lines.size(), -1);
@@ -724,6 +762,12 @@ mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text) {
 }
 
 void mi_pdbqt_ligand_close(mi_pdbqt_ligand *h) { delete h; }
+
+mi_status mi_pdbqt_ligand_num_tors(const mi_pdbqt_ligand *h, float *num_tors) {
+  if (!h || !num_tors) return MI_ERR_INVALID;
+  *num_tors = h->L.num_tors;
+  return MI_OK;
+}
 
 mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *h, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof) {
   if (!h) return MI_ERR_INVALID;

@@ -42,6 +42,7 @@ struct PdbqtLigand {
   std::vector<int32_t> pairs;    // [n_pairs][2], a < b
   std::vector<float> conf0;      // [7 + T]: root origin, identity quaternion, zero torsions = the input pose
   int torsdof = 0;               // TORSDOF record
+  float num_tors = 0;            // conf_independent_inputs::num_tors (terms.cpp:74-106), what num_tors_div divides by
   // the file's lines and, for ATOM/HETATM lines, the model index of the atom (-1 otherwise): gnina's `context`
   // (model.h:205-230), used to write poses back in the input's own format
   std::vector<std::string> lines;

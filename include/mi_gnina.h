@@ -229,9 +229,11 @@ enum {
  * non_cache::within; energy = max_fl when the pose never gets inside.  In place; tries [B] optional. */
 mi_status mi_vina_refine_batch(mi_vina *, float *confs, int B, const float *v3, int max_iters, float *energy,
                                int32_t *tries);
-/* The energies do_search reports (main.cpp:339-344): intramolecular = eval_intramolecular(exact_prec);
- * e_final = conf_independent(eval(exact_prec, non_cache) - intramolecular) with the default num_tors_div
- * weight (everything.h:796-814, main.cpp:1329).  num_tors = conf_independent_inputs::num_tors (terms.cpp:74-106). */
+/* The energies do_search's docking branch reports (main.cpp:339-344): intramolecular = eval_intramolecular(exact_prec);
+ * e_final = conf_independent(eval(exact_prec, nc_new) - intramolecular) with the default num_tors_div weight
+ * (everything.h:796-814, main.cpp:1329).  nc_new is a non_cache on the run's LINEAR tables (main.cpp:231), so the
+ * receptor term is the table look-up (precalculate::eval = eval_fast) and only the pair terms are exact.
+ * num_tors = conf_independent_inputs::num_tors (terms.cpp:74-106; mi_pdbqt_ligand_num_tors), not TORSDOF. */
 mi_status mi_vina_final_energies(mi_vina *, const float *confs, int B, const float *v3, float num_tors,
                                  float *e_final, float *intramolecular);
 /* quasi_newton::operator() (quasi_newton.cpp:49-83) = bfgs<> with fast_line_search (bfgs.h:73-91,
@@ -367,6 +369,9 @@ mi_status mi_pdbqt_read_receptor_flex(const char *rigid, const char *flex, int i
 mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text);
 void mi_pdbqt_ligand_close(mi_pdbqt_ligand *);
 mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof);
+/* conf_independent_inputs::num_tors of the ligand (terms.cpp:39-106): the `num_tors` mi_vina_final_energies takes.
+ * It counts rotatable bonds between heavy atoms that both have further heavy neighbours, not TORSDOF. */
+mi_status mi_pdbqt_ligand_num_tors(const mi_pdbqt_ligand *, float *num_tors);
 mi_status mi_pdbqt_ligand_desc(const mi_pdbqt_ligand *, mi_ligand_desc *desc, const float **xyz,
                                const int32_t **serial, const float **conf0);
 /* One pose in gnina's .pdbqt output format (result_info::write, result_info.cpp:151-164; coordinates written back

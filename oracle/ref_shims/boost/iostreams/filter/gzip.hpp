@@ -1,0 +1,2 @@
+#pragma once
+#include <boost/iostreams/filtering_stream.hpp>

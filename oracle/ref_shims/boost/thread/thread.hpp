@@ -1,0 +1,3 @@
+#pragma once
+#include <boost/thread/mutex.hpp>
+#include <thread>

@@ -190,8 +190,10 @@ class McParams(C.Structure):
 
 
 def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, temperature=1.2, amplitude=2.0,
-             min_rmsd=1.0):
-    """monte_carlo::operator() for one chain -> (energies [n], confs [n,7+T], coords [n,nh,3], evals)"""
+             min_rmsd=1.0, rng_kind=0, conf0=None):
+    """monte_carlo::operator() for one chain -> (energies [n], confs [n,7+T], coords [n,nh,3], evals).
+    rng_kind 0: the splitmix stream shared with the HIP kernel; 1: mt19937 + Boost's distributions as restated for
+    oracle/_ref (follows the reference's chain step for step)."""
     lig = scene.lig
     nh = int((lig.arr["smt"] > 1).sum())
     P = McParams(n_steps, max_iters, num_saved, temperature, amplitude, min_rmsd, (C.c_float * 3)(10, 10, 10),
@@ -202,12 +204,13 @@ def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, te
     c1 = np.ascontiguousarray(corner1, dtype=np.float32)
     c2 = np.ascontiguousarray(corner2, dtype=np.float32)
     ev = C.c_long()
-    f = _voxel.lib().ora_vina_mc_chain
+    f = _voxel.lib().ora_vina_mc_chain_rng
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.POINTER(GridDims), C.POINTER(_f32p), C.c_float, C.POINTER(Ligand), _f32p, _f32p,
-                  C.c_uint64, C.POINTER(McParams), _f32p, _f32p, _f32p, C.POINTER(C.c_long)]
+                  C.c_uint64, C.c_int, _f32p, C.POINTER(McParams), _f32p, _f32p, _f32p, C.POINTER(C.c_long)]
+    c0 = None if conf0 is None else np.ascontiguousarray(conf0, dtype=np.float32)
     n = f(scene.tables.h, C.byref(scene.gd), scene.ptrs, scene.slope, C.byref(lig.c), _p(c1), _p(c2), int(seed),
-          C.byref(P), _p(e), _p(cf), _p(xyz), C.byref(ev))
+          int(rng_kind), None if c0 is None else _p(c0), C.byref(P), _p(e), _p(cf), _p(xyz), C.byref(ev))
     return e[:n], cf[:n], xyz[:n], ev.value
 
 
@@ -312,3 +315,22 @@ def bfgs_callback(lig, conf, fx, max_iters):
     keep = _FX(cb)
     e = f(C.byref(lig.c), _p(conf), int(max_iters), keep, None, _p(g), C.byref(ev))
     return e, conf, g, ev.value
+
+
+def mutate(lig, conf, seed, amplitude=2.0, rng_kind=1):
+    """mutate_conf (mutate.cpp:35-73) with a freshly seeded generator"""
+    x = np.array(conf, dtype=np.float32, copy=True)
+    f = _voxel.lib().ora_vina_mutate
+    f.restype = None
+    f.argtypes = [C.POINTER(Ligand), C.c_int, C.c_uint64, C.c_float, _f32p]
+    f(C.byref(lig.c), int(rng_kind), int(seed), amplitude, _p(x))
+    return x
+
+
+def random_stream(kind, seed, n):
+    u, i, g = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    f = _voxel.lib().ora_vina_random_stream
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_uint64, C.c_int, _f32p, _i32p, _f32p]
+    f(int(kind), int(seed), n, _p(u), _p(i, C.c_int32), _p(g))
+    return u, i, g

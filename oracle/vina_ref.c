@@ -221,11 +221,43 @@ static grid_geom geom_of(const ora_grid_dims *gd) {
 }
 
 /* One ligand-type grid.  data: [(nz+1)][(ny+1)][(nx+1)] with x fastest.  Sum over receptor atoms in
- * index order (szv_grid possibilities are index ordered), r2 <= cutoff_sqr, hydrogens included as
- * the reference does not filter grid_atoms here (cache.cpp:141-150; their table rows are just small). */
+ * index order (szv_grid possibilities are index ordered), r2 <= cutoff_sqr.  Receptor hydrogens take no part:
+ * cache::populate and non_cache::eval only ever see the atoms szv_grid hands out, and szv_grid drops
+ * hydrogens (szv_grid.h compute_relevant / get: `!a.is_hydrogen() && a.acceptable_type()`).  [Found by pinning
+ * this file against oracle/_ref: round 1 had them in.] */
+/* szv_grid_cache::get (szv_grid.h:107-144): the candidate list of a 3 A cell is built the FIRST time a point
+ * falls into the cell, from the brick [floor(c/3)*3, ceil(c/3)*3] of THAT point's coordinates -- a degenerate brick
+ * (a plane or a line) when the coordinate is an exact multiple of 3 -- and reused for every later point of the
+ * cell.  cache::populate walks x, then y, then z upwards, so the first point of a cell is its lowest lattice point
+ * per dimension: per dimension and lattice index, the brick bounds inherited from that point. */
+void ora_vina_cell_bricks(const ora_grid_dims *gd, int d, float *lo, float *hi) {
+  grid_geom g = geom_of(gd);
+  const float gran = 3.0f;
+  float cur_cell = 0, cur_lo = 0, cur_hi = 0;
+  for (int i = 0; i < g.dim[d]; i++) {
+    float c = g.init[d] + g.factor_inv[d] * (float)i;
+    float cell = floorf(c / gran);
+    if (i == 0 || cell != cur_cell) {
+      cur_cell = cell;
+      cur_lo = floorf(c / gran) * gran;
+      cur_hi = ceilf(c / gran) * gran;
+    }
+    lo[i] = cur_lo;
+    hi[i] = cur_hi;
+  }
+}
+
+static float closest_between(float b, float e, float x) { return x <= b ? b : (x >= e ? e : x); } /* brick.h:28-35 */
+
 void ora_vina_cache_populate(const ora_vina_tables *T, const ora_grid_dims *gd, const float *rec_xyz,
                              const int32_t *rec_smt, int n_rec, int lig_type, float *data) {
   grid_geom g = geom_of(gd);
+  float *blo[3], *bhi[3];
+  for (int d = 0; d < 3; d++) {
+    blo[d] = (float *)malloc(sizeof(float) * g.dim[d]);
+    bhi[d] = (float *)malloc(sizeof(float) * g.dim[d]);
+    ora_vina_cell_bricks(gd, d, blo[d], bhi[d]);
+  }
   for (int z = 0; z < g.dim[2]; z++)
     for (int y = 0; y < g.dim[1]; y++)
       for (int x = 0; x < g.dim[0]; x++) {
@@ -234,12 +266,22 @@ void ora_vina_cache_populate(const ora_vina_tables *T, const ora_grid_dims *gd, 
         float pz = g.init[2] + g.factor_inv[2] * (float)z;
         float aff = 0;
         for (int i = 0; i < n_rec; i++) {
-          float dx = rec_xyz[3 * i] - px, dy = rec_xyz[3 * i + 1] - py, dz = rec_xyz[3 * i + 2] - pz;
+          if (is_hydrogen(rec_smt[i])) continue;
+          const float *a = rec_xyz + 3 * i;
+          float cx = closest_between(blo[0][x], bhi[0][x], a[0]) - a[0];
+          float cy = closest_between(blo[1][y], bhi[1][y], a[1]) - a[1];
+          float cz = closest_between(blo[2][z], bhi[2][z], a[2]) - a[2];
+          if (!(cx * cx + cy * cy + cz * cz < T->cutoff_sqr)) continue; /* not in the cell's candidate list */
+          float dx = a[0] - px, dy = a[1] - py, dz = a[2] - pz;
           float r2 = dx * dx + dy * dy + dz * dz; /* vec_distance_sqr: sqr(x)+sqr(y)+sqr(z) */
           if (r2 <= T->cutoff_sqr) aff += ora_vina_eval_fast(T, rec_smt[i], lig_type, r2);
         }
         data[(size_t)x + (size_t)g.dim[0] * ((size_t)y + (size_t)g.dim[1] * z)] = aff;
       }
+  for (int d = 0; d < 3; d++) {
+    free(blo[d]);
+    free(bhi[d]);
+  }
 }
 
 /* grid::evaluate_aux (grid.cpp:96-186). deriv may be NULL. */
@@ -582,6 +624,9 @@ typedef struct {
   /* any other igrid (non_cache_cnn: the CNN loss + box penalties): the objective comes from a callback */
   float (*cb)(const float *conf, float *change, void *user);
   void *user;
+  /* the conformation of the most recent evaluation = what `model` holds afterwards (model::eval_deriv starts with
+   * set(c)); optional, [7+T] */
+  float *model_conf;
 } bfgs_ctx;
 
 float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact, const ora_grid_dims *gd, float slope,
@@ -591,6 +636,7 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
 
 static float fx(bfgs_ctx *c, const float *conf, float *g) {
   c->evals++;
+  if (c->model_conf) memcpy(c->model_conf, conf, sizeof(float) * (size_t)(7 + c->L->n_nodes - 1));
   if (c->cb) return c->cb(conf, g, c->user);
   if (c->direct)
     return ora_vina_noncache_eval(c->T, NULL, 0, c->gd, c->slope, c->rec_xyz, c->rec_smt, c->n_rec, c->L, conf, c->v, 1,
@@ -611,9 +657,19 @@ static float dotn(const float *a, const float *b, int n) {
 /* returns the final energy; conf is updated in place; change g receives the final gradient */
 float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
                     const ora_ligand *L, float *conf, const float *v, int max_iters, float *g_out, long *evals_out) {
-  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0, NULL, NULL};
+  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0, NULL, NULL, NULL};
   float f = bfgs_run(&ctx, conf, max_iters, g_out);
   if (evals_out) *evals_out = ctx.evals;
+  return f;
+}
+
+/* the same, also reporting the conformation `model` is left in (the last evaluated one; differs from the returned
+ * conformation when bfgs reverts to its starting point, bfgs.h:490-494) */
+static float bfgs_model(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                        const ora_ligand *L, float *conf, const float *v, int max_iters, float *model_conf, long *evals) {
+  bfgs_ctx ctx = {T, gd, grids, slope, L, v, 0, 0, NULL, NULL, 0, NULL, NULL, model_conf};
+  float f = bfgs_run(&ctx, conf, max_iters, NULL);
+  *evals += ctx.evals;
   return f;
 }
 
@@ -623,7 +679,7 @@ float ora_vina_bfgs(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
 typedef float (*ora_fx_cb)(const float *conf, float *change, void *user);
 float ora_vina_bfgs_cb(const ora_ligand *L, float *conf, int max_iters, ora_fx_cb cb, void *user, float *g_out,
                        long *evals_out) {
-  bfgs_ctx ctx = {NULL, NULL, NULL, 0, L, NULL, 0, 0, NULL, NULL, 0, cb, user};
+  bfgs_ctx ctx = {NULL, NULL, NULL, 0, L, NULL, 0, 0, NULL, NULL, 0, cb, user, NULL};
   float f = bfgs_run(&ctx, conf, max_iters, g_out);
   if (evals_out) *evals_out = ctx.evals;
   return f;
@@ -656,7 +712,7 @@ float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const f
   float slope = 10, e = 0;
   int p = 0;
   for (; p < 5; p++) {
-    bfgs_ctx ctx = {T, gd, NULL, slope, L, v, 0, 1, rec_xyz, rec_smt, n_rec, NULL, NULL};
+    bfgs_ctx ctx = {T, gd, NULL, slope, L, v, 0, 1, rec_xyz, rec_smt, n_rec, NULL, NULL, NULL};
     e = bfgs_run(&ctx, conf, max_iters, NULL);
     if (ora_vina_within(gd, L, conf)) break;
     slope *= 10;
@@ -774,6 +830,7 @@ float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
     if (is_hydrogen(t) || !grids[t]) continue;
     e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v[1], NULL);
   }
+  float ie = 0; /* eval_interacting_pairs sums on its own, model::eval adds the total (model.cu:22-36,118-123) */
   for (int p = 0; p < L->n_pairs; p++) {
     int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
     float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
@@ -783,9 +840,10 @@ float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
       /* p.eval = eval_fast(...) in the reference (precalculate.h:67-70): midpoint table */
       float pe = ora_vina_eval_fast(T, L->smt[a], L->smt[b], r2);
       curl1(&pe, v[0]);
-      e += pe;
+      ie += pe;
     }
   }
+  e += ie;
   free(coords);
   free(origin);
   free(axis);
@@ -826,25 +884,80 @@ float ora_vina_cache_eval(const ora_grid_dims *gd, const float *const *grids, fl
  * chain's current conformation (the reference reads whatever coordinates the last evaluation left
  * in `model`, identical except after a rejected BFGS).
  * ------------------------------------------------------------------------------------------- */
+/* Two generators behind one interface.
+ * kind 0: the counter-based splitmix64 stream shared with the HIP kernel (statistical parity with the reference).
+ * kind 1: boost::mt19937 (= the standard MT19937) under restatements of Boost.Random's distributions, exactly
+ *         what oracle/ref_shims/boost/random.hpp gives the reference code in oracle/_ref: uniform_real =
+ *         u32 / 2^32 * (b - a) + a, redrawn when it reaches b; uniform_int = equal buckets with rejection;
+ *         normal_distribution = Box-Muller on two fresh uniforms (random_normal builds a new distribution object per
+ *         call, random.cpp:38-42, so the cached second value is never used).  With kind 1 this chain follows the
+ *         reference's monte_carlo.cpp step for step (tests/test_ref_vina.py). */
 typedef struct {
+  int kind;
   uint64_t s;
+  uint32_t mt[624];
+  int mti;
 } ora_rng;
 
-static uint32_t rng_u32(ora_rng *r) { /* splitmix64, high half */
-  r->s += 0x9E3779B97F4A7C15ull;
-  uint64_t z = r->s;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+static void rng_seed(ora_rng *r, int kind, uint64_t seed) {
+  r->kind = kind;
+  r->s = seed;
+  r->mt[0] = (uint32_t)seed;
+  for (int i = 1; i < 624; i++) r->mt[i] = 1812433253u * (r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) + (uint32_t)i;
+  r->mti = 624;
+}
+static uint32_t rng_u32(ora_rng *r) {
+  if (r->kind == 0) { /* splitmix64, high half */
+    r->s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = r->s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+  }
+  if (r->mti >= 624) {
+    for (int i = 0; i < 624; i++) {
+      uint32_t y = (r->mt[i] & 0x80000000u) | (r->mt[(i + 1) % 624] & 0x7fffffffu);
+      r->mt[i] = r->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    r->mti = 0;
+  }
+  uint32_t y = r->mt[r->mti++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
 }
 static float rng_u01(ora_rng *r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
-static float rng_fl(ora_rng *r, float a, float b) { return a + (b - a) * rng_u01(r); }
-static int rng_int(ora_rng *r, int a, int b) { return a + (int)(rng_u32(r) % (uint32_t)(b - a + 1)); }
-static float rng_normal(ora_rng *r) { /* Box-Muller */
-  float u1 = ((float)(rng_u32(r) >> 8) + 1.0f) * (1.0f / 16777216.0f);
-  float u2 = rng_u01(r);
-  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * V_PI * u2);
+static float rng_fl(ora_rng *r, float a, float b) { /* random_fl, random.cpp:27-35 */
+  if (r->kind == 0) return a + (b - a) * rng_u01(r);
+  for (;;) {
+    float numerator = (float)rng_u32(r), divisor = 4294967296.0f;
+    float result = numerator / divisor * (b - a) + a;
+    if (result < b) return result;
+  }
+}
+static int rng_int(ora_rng *r, int a, int b) { /* random_int, random.cpp:44-52 */
+  if (r->kind == 0) return a + (int)(rng_u32(r) % (uint32_t)(b - a + 1));
+  const uint32_t range = (uint32_t)b - (uint32_t)a, brange = 0xffffffffu;
+  if (range == 0) return a;
+  uint32_t bucket = brange / (range + 1);
+  if (brange % (range + 1) == range) ++bucket;
+  for (;;) {
+    uint32_t q = rng_u32(r) / bucket;
+    if (q <= range) return (int)(q + (uint32_t)a);
+  }
+}
+static float rng_normal(ora_rng *r) { /* random_normal(0, 1), random.cpp:37-42 */
+  if (r->kind == 0) { /* Box-Muller */
+    float u1 = ((float)(rng_u32(r) >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = rng_u01(r);
+    return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * V_PI * u2);
+  }
+  float r1 = rng_fl(r, 0, 1), r2 = rng_fl(r, 0, 1);
+  float rho = sqrtf(-2.0f * logf(1.0f - r2));
+  return rho * cosf(2.0f * 3.14159265358979323846f * r1) * 1.0f + 0.0f;
 }
 static void rng_inside_sphere(ora_rng *r, float *o) { /* random.cpp:66-75 */
   for (;;) {
@@ -854,6 +967,14 @@ static void rng_inside_sphere(ora_rng *r, float *o) { /* random.cpp:66-75 */
     if (o[0] * o[0] + o[1] * o[1] + o[2] * o[2] < 1) return;
   }
 }
+/* raw draws for the tests that check the restated distributions against oracle/_ref's */
+void ora_vina_random_stream(int kind, uint64_t seed, int n, float *uniform01, int32_t *ints_0_9, float *normals) {
+  ora_rng r;
+  rng_seed(&r, kind, seed);
+  for (int i = 0; i < n; i++) uniform01[i] = rng_fl(&r, 0, 1);
+  for (int i = 0; i < n; i++) ints_0_9[i] = rng_int(&r, 0, 9);
+  for (int i = 0; i < n; i++) normals[i] = rng_normal(&r);
+}
 
 typedef struct {
   int n_steps, max_iters, num_saved;
@@ -861,76 +982,121 @@ typedef struct {
   float hunt_cap[3], authentic_v[3];
 } ora_mc_params;
 
+/* mutate_conf (mutate.cpp:35-73) of cand; `model_conf` = the conformation `model` currently holds, which is what
+ * model::gyration_radius reads (coords and the root node's origin, model.cpp:1002-1014). */
+static void mc_mutate(const ora_ligand *L, ora_rng *rng, float amplitude, float *cand, const float *model_conf,
+                      float *coords, float *origin, float *axis) {
+  const int nt = L->n_nodes - 1, na = L->n_atoms;
+  int which = rng_int(rng, 0, 2 + nt - 1);
+  if (which == 0) {
+    float d[3];
+    rng_inside_sphere(rng, d);
+    for (int k = 0; k < 3; k++) cand[k] += amplitude * d[k];
+  } else if (which == 1) {
+    ora_vina_set_conf(L, model_conf, coords, origin, axis);
+    float acc = 0;
+    int cnt = 0;
+    for (int i = 0; i < na; i++)
+      if (!is_hydrogen(L->smt[i])) {
+        float dx = coords[3 * i] - origin[0], dy = coords[3 * i + 1] - origin[1], dz = coords[3 * i + 2] - origin[2];
+        acc += dx * dx + dy * dy + dz * dz;
+        cnt++;
+      }
+    float gr = cnt > 0 ? sqrtf(acc / (float)cnt) : 0;
+    if (gr > V_EPS) {
+      float d[3];
+      rng_inside_sphere(rng, d);
+      float s = amplitude / gr;
+      float rot[6] = {0, 0, 0, s * d[0], s * d[1], s * d[2]};
+      ora_vina_conf_increment(cand, rot, 1.0f, 0); /* quaternion_increment(orientation, rotation) */
+    }
+  } else {
+    cand[7 + (which - 2)] = rng_fl(rng, -V_PI, V_PI);
+  }
+}
+void ora_vina_mutate(const ora_ligand *L, int rng_kind, uint64_t seed, float amplitude, float *conf) {
+  ora_rng rng;
+  rng_seed(&rng, rng_kind, seed);
+  float *coords = (float *)malloc(sizeof(float) * 3 * L->n_atoms), *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes),
+        *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *mc = (float *)malloc(sizeof(float) * (7 + L->n_nodes - 1));
+  memcpy(mc, conf, sizeof(float) * (7 + L->n_nodes - 1));
+  mc_mutate(L, &rng, amplitude, conf, mc, coords, origin, axis);
+  free(coords);
+  free(origin);
+  free(axis);
+  free(mc);
+}
+
 /* out arrays sized for num_saved entries: out_e[num_saved], out_conf[num_saved][7+T],
- * out_coords[num_saved][n_heavy][3]; returns the number of saved poses (sorted by energy). */
-int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
-                      const ora_ligand *L, const float *corner1, const float *corner2, uint64_t seed,
-                      const ora_mc_params *P, float *out_e, float *out_conf, float *out_coords, long *evals_out) {
+ * out_coords[num_saved][n_heavy][3]; returns the number of saved poses (sorted by energy).
+ *
+ * `model` state: the reference evaluates the Metropolis energy (update_energy, monte_carlo.cpp:44-47) and the
+ * gyration radius on whatever coordinates the last evaluation left in `model`.  That is the returned conformation
+ * except when bfgs ends by reverting to its starting point (bfgs.h:490-494): then `model` still holds the last
+ * line-search trial.  model_conf tracks it; m.set(tmp.c) after an accepted step resets it (monte_carlo.cpp:122,131). */
+int ora_vina_mc_chain_rng(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                          const ora_ligand *L, const float *corner1, const float *corner2, uint64_t seed, int rng_kind,
+                          const float *conf0, const ora_mc_params *P, float *out_e, float *out_conf, float *out_coords, long *evals_out) {
   const int nt = L->n_nodes - 1, nc = 7 + nt, na = L->n_atoms;
   int nh = 0;
   for (int i = 0; i < na; i++) nh += !is_hydrogen(L->smt[i]);
-  ora_rng rng = {seed};
-  float *tmp = (float *)malloc(sizeof(float) * nc), *cand = (float *)malloc(sizeof(float) * nc);
+  ora_rng rng;
+  rng_seed(&rng, rng_kind, seed);
+  float *tmp = (float *)malloc(sizeof(float) * nc), *cand = (float *)malloc(sizeof(float) * nc),
+        *model_conf = (float *)malloc(sizeof(float) * nc);
   float *coords = (float *)malloc(sizeof(float) * 3 * na), *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes),
         *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *hc = (float *)malloc(sizeof(float) * 3 * nh);
-  long evals = 0, ev;
+  long evals = 0;
   /* conf::randomize */
   for (int k = 0; k < 3; k++) tmp[k] = rng_fl(&rng, corner1[k], corner2[k]);
   for (;;) {
-    float q[4] = {rng_normal(&rng), rng_normal(&rng), rng_normal(&rng), rng_normal(&rng)};
-    float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float q[4];
+    for (int k = 0; k < 4; k++) q[k] = rng_normal(&rng); /* a0..a3 in order (quaternion.cu:81-86) */
+    /* abs(qt) (quaternion.h:169-190): scaled by the largest component */
+    float maxim = 0, nrm = 0;
+    for (int k = 0; k < 4; k++)
+      if (fabsf(q[k]) > maxim) maxim = fabsf(q[k]);
+    if (maxim != 0) {
+      float mixam = (float)(1.0 / maxim), sum = 0;
+      for (int k = 0; k < 4; k++) {
+        float val = q[k] * mixam;
+        sum += val * val;
+      }
+      nrm = maxim * sqrtf(sum);
+    }
     if (nrm > V_EPS) {
       for (int k = 0; k < 4; k++) tmp[3 + k] = q[k] / nrm;
       break;
     }
   }
   for (int k = 0; k < nt; k++) tmp[7 + k] = rng_fl(&rng, -V_PI, V_PI);
+  /* before the first evaluation `model` holds the input pose; the first mutation of the orientation reads it */
+  if (conf0) {
+    memcpy(model_conf, conf0, sizeof(float) * nc);
+  } else { /* any rigid placement of the input torsions gives the same radius */
+    memset(model_conf, 0, sizeof(float) * nc);
+    model_conf[3] = 1.0f;
+  }
   float tmp_e = 0, best_e = V_MAXFL;
   int n_out = 0;
   for (int step = 0; step < P->n_steps; step++) {
     memcpy(cand, tmp, sizeof(float) * nc);
-    /* mutate_conf */
-    int which = rng_int(&rng, 0, 2 + nt - 1);
-    if (which == 0) {
-      float d[3];
-      rng_inside_sphere(&rng, d);
-      for (int k = 0; k < 3; k++) cand[k] += P->mutation_amplitude * d[k];
-    } else if (which == 1) {
-      ora_vina_set_conf(L, cand, coords, origin, axis);
-      float acc = 0;
-      int cnt = 0;
-      for (int i = 0; i < na; i++)
-        if (!is_hydrogen(L->smt[i])) { /* model::gyration_radius, model.cpp:1002-1014 */
-          float dx = coords[3 * i] - origin[0], dy = coords[3 * i + 1] - origin[1], dz = coords[3 * i + 2] - origin[2];
-          acc += dx * dx + dy * dy + dz * dz;
-          cnt++;
-        }
-      float gr = cnt > 0 ? sqrtf(acc / (float)cnt) : 0;
-      if (gr > V_EPS) {
-        float d[3];
-        rng_inside_sphere(&rng, d);
-        float s = P->mutation_amplitude / gr;
-        float rot[6] = {0, 0, 0, s * d[0], s * d[1], s * d[2]};
-        ora_vina_conf_increment(cand, rot, 1.0f, 0); /* quaternion_increment(orientation, rotation) */
-      }
-    } else {
-      cand[7 + (which - 2)] = rng_fl(&rng, -V_PI, V_PI);
-    }
-    ora_vina_bfgs(T, gd, grids, slope, L, cand, P->hunt_cap, P->max_iters, NULL, &ev);
-    evals += ev;
-    float cand_e = ora_vina_cache_eval(gd, grids, slope, L, cand, P->authentic_v[1]);
+    mc_mutate(L, &rng, P->mutation_amplitude, cand, model_conf, coords, origin, axis);
+    bfgs_model(T, gd, grids, slope, L, cand, P->hunt_cap, P->max_iters, model_conf, &evals);
+    float cand_e = ora_vina_cache_eval(gd, grids, slope, L, model_conf, P->authentic_v[1]);
     int accept = step == 0 || cand_e < tmp_e;
     if (!accept) { /* metropolis_accept */
       float prob = expf((tmp_e - cand_e) / P->temperature);
-      accept = rng_u01(&rng) < prob;
+      accept = rng_fl(&rng, 0, 1) < prob;
     }
     if (accept) {
       memcpy(tmp, cand, sizeof(float) * nc);
       tmp_e = cand_e;
+      memcpy(model_conf, tmp, sizeof(float) * nc); /* m.set(tmp.c) */
       if (tmp_e < best_e || n_out < P->num_saved) {
-        ora_vina_bfgs(T, gd, grids, slope, L, tmp, P->authentic_v, P->max_iters, NULL, &ev);
-        evals += ev;
-        tmp_e = ora_vina_cache_eval(gd, grids, slope, L, tmp, P->authentic_v[1]);
+        bfgs_model(T, gd, grids, slope, L, tmp, P->authentic_v, P->max_iters, model_conf, &evals);
+        tmp_e = ora_vina_cache_eval(gd, grids, slope, L, model_conf, P->authentic_v[1]);
+        memcpy(model_conf, tmp, sizeof(float) * nc); /* m.set(tmp.c) */
         ora_vina_set_conf(L, tmp, coords, origin, axis);
         int h = 0;
         for (int i = 0; i < na; i++)
@@ -945,11 +1111,11 @@ int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const f
         float closest_rmsd = V_MAXFL;
         for (int o = 0; o < n_out; o++) {
           float acc = 0;
-          for (int i = 0; i < 3 * nh; i++) {
-            float d = hc[i] - out_coords[(size_t)o * 3 * nh + i];
-            acc += d * d;
+          for (int i = 0; i < nh; i++) { /* rmsd_upper_bound: sum of vec_distance_sqr per atom (coords.cpp:25-32) */
+            float dx = hc[3 * i] - out_coords[(size_t)o * 3 * nh + 3 * i], dy = hc[3 * i + 1] - out_coords[(size_t)o * 3 * nh + 3 * i + 1],
+                  dz = hc[3 * i + 2] - out_coords[(size_t)o * 3 * nh + 3 * i + 2];
+            acc += dx * dx + dy * dy + dz * dz;
           }
-          /* vec_distance_sqr sums per atom then accumulates; same value up to association */
           float res = nh > 0 ? sqrtf(acc / (float)nh) : 0;
           if (o == 0 || res < closest_rmsd) {
             closest = o;
@@ -1007,11 +1173,19 @@ int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const f
   if (evals_out) *evals_out = evals;
   free(tmp);
   free(cand);
+  free(model_conf);
   free(coords);
   free(origin);
   free(axis);
   free(hc);
   return n_out;
+}
+
+int ora_vina_mc_chain(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
+                      const ora_ligand *L, const float *corner1, const float *corner2, uint64_t seed,
+                      const ora_mc_params *P, float *out_e, float *out_conf, float *out_coords, long *evals_out) {
+  return ora_vina_mc_chain_rng(T, gd, grids, slope, L, corner1, corner2, seed, 0, NULL, P, out_e, out_conf, out_coords,
+                               evals_out);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -1076,6 +1250,7 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
     oob *= slope;
     float this_e = 0, d[3] = {0, 0, 0};
     for (int j = 0; j < n_rec; j++) {
+      if (is_hydrogen(rec_smt[j])) continue; /* szv_grid possibilities hold no hydrogens */
       float rx = adj[0] - rec_xyz[3 * j], ry = adj[1] - rec_xyz[3 * j + 1], rz = adj[2] - rec_xyz[3 * j + 2];
       float r2 = rx * rx + ry * ry + rz * rz;
       if (r2 < T->cutoff_sqr) {

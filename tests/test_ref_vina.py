@@ -1,0 +1,284 @@
+"""Pins the Vina/smina path to THE REFERENCE ITSELF: oracle/_ref/libgnina_ref.so is gnina's own parse_pdbqt.cpp,
+model.cpp/.cu, tree.h, conf.h, everything.h, weighted_terms.cpp, precalculate.h, cache.cpp, grid.cpp, szv_grid.h,
+non_cache.cpp, bfgs.h, quasi_newton.cpp, monte_carlo.cpp, mutate.cpp ... compiled unmodified from /root/reference
+behind stand-in headers (oracle/ref_shims, recipe oracle/Makefile.ref).  Checked against it here, on the same PDBQT
+bytes:
+  * gnina_amd/host/pdbqt.cpp (atom order, types, pairs, trees, num_tors, error behaviour)        -- bit-exact
+  * oracle/vina_ref.c, the restatement the GPU parity tests use (rows a11-a18 of SURVEY 8)       -- bit-exact:
+    tables, cache grids (incl. szv_grid's first-point candidate bricks), eval / eval_deriv on cache and non_cache,
+    exact pair terms, conf increment, whole BFGS runs, whole Monte-Carlo chains (same mt19937 stream).
+CPU only; needs /root/reference (skipped elsewhere).  tests/golden/vina_goldens.npz freezes reference outputs of the
+same cases for the GPU tests (tests/golden/make_vina_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref, vina as V
+from tests import ref_cases as RC
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(RC.REF_DATA) or not ref.available(),
+                                reason="needs /root/reference (oracle/_ref is built from it)")
+V3 = (1000.0, 1000.0, 1000.0)
+HUNT = (10.0, 10.0, 10.0)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import build, capi as c
+    build.build()
+    return c
+
+
+@pytest.fixture(scope="module")
+def rigid_text():
+    return open(RC.GSK3B).read()
+
+
+class Case:
+    """reference scene + our reader's ligand + the oracle scene on the same box"""
+
+    def __init__(self, capi, rigid_text, lig_text, center=None, size=None):
+        self.ref = ref.Scene(rigid_text, lig_text)
+        self.lig = capi.read_pdbqt_ligand(lig_text, is_text=True)
+        self.rec_xyz, self.rec_smt = self.ref.grid_atoms()
+        if center is None:
+            center, size = RC.box_of(self.lig["coords0"])
+        self.begin, self.end, self.n = self.ref.build_grids(center, size)
+        self.gd = V.setup_grid_dims(center, size)
+        self.T = V.Tables()
+        self.h = V.LigandHandle(self.lig)
+        types = sorted(set(int(t) for t in self.lig["smt"] if t > 1))
+        self.grids = {t: V.cache_populate(self.T, self.gd, self.rec_xyz, self.rec_smt, t) for t in types}
+        self.ora = V.Scene(self.T, self.gd, self.grids, self.h)
+        self.max_iters = (25 + self.ref.n_movable) // 3
+
+
+@pytest.fixture(scope="module")
+def adduct(capi, rigid_text):
+    return Case(capi, rigid_text, RC.cys_adduct_ligand())
+
+
+@pytest.fixture(scope="module")
+def chain(capi, rigid_text):
+    return Case(capi, rigid_text, RC.long_chain_ligand())
+
+
+def test_receptor_types_and_coordinates_are_the_references(capi, rigid_text):
+    s = ref.Scene(rigid_text)
+    gx, gs = s.grid_atoms()
+    rx, rs = capi.read_pdbqt_receptor(RC.GSK3B)
+    assert len(gs) == 3460 and np.array_equal(gs, rs) and np.array_equal(gx, rx)
+    assert (gs <= 1).sum() > 300          # the file has polar hydrogens: they matter below
+
+
+@pytest.mark.parametrize("which", ["adduct", "chain", "hand"])
+def test_ligand_reader_matches_the_reference(capi, rigid_text, which, request):
+    if which == "hand":
+        from tests.test_pdbqt_cpu import chain_pdbqt
+        c = Case(capi, rigid_text, chain_pdbqt())
+    else:
+        c = request.getfixturevalue(which)
+    s, lig = c.ref, c.lig
+    xyz, smt, _ = s.atoms()
+    assert s.n_atoms == len(lig["smt"]) and s.n_lig_tors == lig["n_tors"]
+    assert np.array_equal(smt, lig["smt"]) and np.array_equal(xyz, lig["coords0"])     # atom order, adjust_smina_type
+    pairs, t12 = s.pairs()
+    assert np.array_equal(pairs, lig["pairs"])                                          # initialize_pairs, in order
+    assert np.array_equal(s.initial_conf(), lig["conf0"])
+    # conf_independent_inputs::num_tors through the num_tors_div term
+    assert s.conf_independent(100.0) == V.conf_independent(100.0, lig["num_tors"])
+    # the torsion tree: model::set on random conformations, bit for bit
+    rng = np.random.RandomState(0)
+    for conf in RC.random_confs(rng, lig["conf0"], 6):
+        assert np.array_equal(s.set_conf(conf), V.set_conf(c.h, conf)[0])
+
+
+def test_long_ligand_spans_two_beads_and_bond_lists_follow_bead_order(chain):
+    """model::assign_bonds visits candidates bead by bead (15 A); bonded_to()'s depth-first walk depends on it."""
+    xyz = chain.lig["coords0"]
+    assert np.linalg.norm(xyz[-3] - xyz[0]) > 15.0
+    n_rec = chain.ref.n_grid_atoms
+    # our pairs already equal the reference's (previous test); also check a bond list crossing the bead boundary
+    far = int(np.argmax(np.linalg.norm(xyz - xyz[0], axis=1) > 15.0))
+    assert sorted(chain.ref.bonds(n_rec + far)) == sorted(chain.ref.bonds(n_rec + far))
+    assert len(chain.ref.bonds(n_rec + far)) >= 2
+
+
+def test_truncated_inputs_behave_like_the_reference(capi, rigid_text):
+    """EOF inside a BRANCH: the reference keeps what it read, unless the branch never met its second ("immobile")
+    atom -- then VINA_CHECK(immobile_atom) fires (parsing.h:186,197).  Ours used to read out of bounds there."""
+    flex = open(RC.FLEX_RES).read().splitlines()
+    k = max(i for i, l in enumerate(flex) if l.startswith("BRANCH  13  22"))
+    bad = "\n".join(flex[:k + 1] + [flex[k + 3]]) + "\n"    # BRANCH 13 22, then atom 23 and the end: atom 22 never seen
+    with pytest.raises(ref.RefError):
+        ref.Scene(rigid_text, None, flex_text=bad)
+    with pytest.raises(capi.MiGninaError, match="end of file"):
+        capi.read_pdbqt_receptor_flex(rigid_text, bad, is_text=True)
+    for upto in (k + 1, k + 2, k + 5):                       # an empty branch; atom 22 only; inside a sub-branch
+        ok = "\n".join(flex[:upto]) + "\n"                   # no ENDBRANCH, no END_RES
+        s = ref.Scene(rigid_text, None, flex_text=ok)
+        rows_xyz, rows_smt, n_mov, n_inflex = capi.read_pdbqt_receptor_flex(rigid_text, ok, is_text=True)
+        xyz, smt, _ = s.atoms()
+        assert n_mov == s.n_movable and n_mov + n_inflex == s.n_atoms
+        assert np.array_equal(rows_xyz[:s.n_atoms], xyz) and np.array_equal(rows_smt[:s.n_atoms], smt)
+    lig = RC.cys_adduct_ligand().splitlines()
+    k = max(i for i, l in enumerate(lig) if l.startswith("BRANCH  13  22"))
+    lig_bad = "\n".join(lig[:k + 1] + [lig[k + 3], "TORSDOF 10"]) + "\n"
+    with pytest.raises(ref.RefError):
+        ref.Scene(rigid_text, lig_bad)
+    with pytest.raises(capi.MiGninaError):
+        capi.read_pdbqt_ligand(lig_bad, is_text=True)
+    with pytest.raises(ref.RefError):                        # a ligand without TORSDOF
+        ref.Scene(rigid_text, "\n".join(lig[:k + 2]) + "\n")
+    with pytest.raises(capi.MiGninaError, match="TORSDOF"):
+        capi.read_pdbqt_ligand("\n".join(lig[:k + 2]) + "\n", is_text=True)
+
+
+def test_flexible_receptor_rows_are_the_references(capi, rigid_text):
+    flex = open(RC.FLEX_RES).read()
+    s = ref.Scene(rigid_text, None, flex_text=flex)
+    xyz, smt, _ = s.atoms()                               # movable, then inflex
+    gx, gs = s.grid_atoms()
+    rows_xyz, rows_smt, n_mov, n_inflex = capi.read_pdbqt_receptor_flex(rigid_text, flex, is_text=True)
+    assert n_mov == s.n_movable and n_mov + n_inflex == s.n_atoms
+    assert np.array_equal(rows_xyz[:s.n_atoms], xyz) and np.array_equal(rows_smt[:s.n_atoms], smt)
+    assert np.array_equal(rows_xyz[s.n_atoms:], gx) and np.array_equal(rows_smt[s.n_atoms:], gs)
+
+
+def test_pair_tables_and_exact_terms_bit_exact(adduct):
+    s, T = adduct.ref, adduct.T
+    rng = np.random.RandomState(5)
+    r2 = np.concatenate([np.arange(0, 2049) / 32.0, rng.uniform(0, 64, 400)]).astype(np.float32)
+    for t1 in range(0, 28, 3):
+        for t2 in range(t1, 28, 2):
+            fast, e, dor = s.table_eval(t1, t2, r2)
+            fo = np.array([T.eval_fast(t1, t2, float(x)) for x in r2], dtype=np.float32)
+            ed = np.array([T.eval_deriv(t1, t2, float(x)) for x in r2], dtype=np.float32)
+            assert np.array_equal(fast, fo) and np.array_equal(e, ed[:, 0]) and np.array_equal(dor, ed[:, 1])
+    for t1 in range(28):
+        for t2 in range(t1, 28, 3):
+            for r in np.linspace(0.4, 8.0, 23):
+                assert s.pair_energy(t1, t2, float(r)) == V.pair_energy(t1, t2, float(r))
+
+
+def _lattice(begin, end, n, idx):
+    return np.stack([begin[i] + (end[i] - begin[i]) * idx[:, i].astype(np.float32) / np.float32(n[i])
+                     for i in range(3)], 1).astype(np.float32)
+
+
+def test_cache_grids_bit_exact_and_receptor_hydrogens_do_not_count(adduct):
+    c = adduct
+    rng = np.random.RandomState(1)
+    for t, g in c.grids.items():
+        idx = rng.randint(0, [c.n[0] + 1, c.n[1] + 1, c.n[2] + 1], size=(400, 3))
+        probe = c.ref.cache_probe(t, _lattice(c.begin, c.end, c.n, idx), v=1e10)
+        assert np.array_equal(probe, g[idx[:, 2], idx[:, 1], idx[:, 0]])
+    # with the hydrogens in (round 1's reading of cache.cpp) the grids are visibly different
+    t = 2
+    wrong = V.cache_populate(c.T, c.gd, c.rec_xyz, np.where(c.rec_smt <= 1, 2, c.rec_smt).astype(np.int32), t)
+    assert np.abs(wrong - c.grids[t]).max() > 0.5
+
+
+def test_cache_grid_on_a_box_aligned_with_szv_grids_cells(capi, rigid_text):
+    """Box begin = a multiple of 3: every 8th lattice plane starts a 3 A cell whose candidate list szv_grid_cache::get
+    builds from a degenerate brick; atoms beyond 8 A of that plane are missing for the whole cell."""
+    center, size = np.array([-7.5, 9.0, 0.7], np.float32), np.array([15.0, 16.0, 14.0], np.float32)
+    c = Case(capi, rigid_text, RC.cys_adduct_ligand(), center, size)
+    assert c.begin[0] == -15.0
+    rng = np.random.RandomState(2)
+    t = 2
+    idx = rng.randint(0, [c.n[0] + 1, c.n[1] + 1, c.n[2] + 1], size=(3000, 3))
+    probe = c.ref.cache_probe(t, _lattice(c.begin, c.end, c.n, idx), v=1e10)
+    mine = c.grids[t][idx[:, 2], idx[:, 1], idx[:, 0]]
+    assert np.array_equal(probe, mine)
+    # and that really is the quirk: plain "every atom within 8 A" gives other numbers on this box
+    full = np.zeros(len(idx), dtype=np.float32)
+    pts = _lattice(c.begin, c.end, c.n, idx)
+    heavy = c.rec_smt > 1
+    for k in range(0, len(idx), 500):
+        p = pts[k]
+        r2 = ((c.rec_xyz[heavy] - p) ** 2).sum(1)
+        acc = np.float32(0)
+        for j in np.nonzero(r2 <= 64)[0]:
+            acc = np.float32(acc + np.float32(c.T.eval_fast(int(c.rec_smt[heavy][j]), t, float(r2[j]))))
+        full[k] = acc
+    ks = np.arange(0, len(idx), 500)
+    assert np.abs(full[ks] - mine[ks]).max() > 1e-3
+
+
+@pytest.mark.parametrize("which", ["adduct", "chain"])
+def test_eval_and_eval_deriv_bit_exact(which, request):
+    c = request.getfixturevalue(which)
+    s, lig = c.ref, c.lig
+    rng = np.random.RandomState(3)
+    confs = np.concatenate([RC.random_confs(rng, lig["conf0"], 4, small=True), RC.random_confs(rng, lig["conf0"], 4),
+                            RC.random_confs(rng, lig["conf0"], 2, spread=9.0)])          # the last two leave the box
+    for conf in confs:
+        for v in (V3, HUNT):
+            er, cr, xr, fr = s.eval_deriv(conf, v)
+            eo, co, xo, fo = c.ora.eval_deriv(conf, v)
+            assert er == eo and np.array_equal(cr, co) and np.array_equal(xr, xo)
+            assert np.array_equal(np.abs(fr), np.abs(fo))
+            assert s.eval(conf, v) == c.ora.eval(conf, v)                               # model::eval
+            assert s.ig_eval(conf, v[1]) == V.cache_eval(c.ora, conf, v[1])            # cache::eval (Metropolis)
+        er, cr, _, _ = s.eval_deriv(conf, V3, ig=1)                                     # non_cache
+        eo, co, _, _ = V.noncache_eval(c.ora, c.rec_xyz, c.rec_smt, conf, V3)
+        assert er == eo and np.array_equal(cr, co)
+        assert s.eval(conf, V3, ig=1) == V.noncache_eval(c.ora, c.rec_xyz, c.rec_smt, conf, V3, deriv=False)[0]
+        assert s.within(conf) == bool(V._voxel.lib().ora_vina_within(
+            V.C.byref(c.gd), V.C.byref(c.h.c), conf.ctypes.data_as(V.C.POINTER(V.C.c_float))))
+
+
+def test_final_energies_follow_do_searchs_docking_branch(adduct):
+    """main.cpp:231,339-344: receptor term from a non_cache on the LINEAR tables, pair terms exact, num_tors_div."""
+    c = adduct
+    rng = np.random.RandomState(4)
+    for conf in RC.random_confs(rng, c.lig["conf0"], 5, small=True, spread=0.5):
+        ef, intra = c.ref.final_energies(conf)
+        _, _, inter_lin, _ = V.noncache_eval(c.ora, c.rec_xyz, c.rec_smt, conf, V3, deriv=False, exact=False)
+        _, _, _, intra_x = V.noncache_eval(c.ora, c.rec_xyz, c.rec_smt, conf, V3, deriv=False, exact=True)
+        assert intra == intra_x
+        mine = V.conf_independent(np.float32(np.float32(inter_lin) + np.float32(intra_x)) - np.float32(intra_x),
+                                  c.lig["num_tors"])
+        assert ef == mine
+
+
+@pytest.mark.parametrize("which", ["adduct", "chain"])
+def test_bfgs_runs_are_bit_identical(which, request):
+    c = request.getfixturevalue(which)
+    rng = np.random.RandomState(6)
+    confs = np.concatenate([RC.random_confs(rng, c.lig["conf0"], 3, small=True), RC.random_confs(rng, c.lig["conf0"], 3)])
+    for conf in confs:
+        g = rng.normal(size=c.ref.change_len).astype(np.float32)
+        assert np.array_equal(c.ref.conf_increment(conf, g, 0.37), V.conf_increment(conf, g, 0.37, c.ref.n_lig_tors))
+        for v in (V3, HUNT):
+            for iters in (1, 3, c.max_iters):
+                er, xr, gr = c.ref.bfgs(conf, v, max_iters=iters)
+                eo, xo, go, _ = c.ora.bfgs(conf, v, max_iters=iters)
+                assert er == eo and np.array_equal(xr, xo) and np.array_equal(gr, go)
+
+
+def test_random_distributions_of_the_stand_in_boost(adduct):
+    """oracle kind-1 generator == what oracle/ref_shims/boost/random.hpp hands the reference (mt19937 is standard;
+    the distributions are restatements: the stream of a real Boost build is unpinned)."""
+    for seed in (0, 7, 12345):
+        a, b = ref.random_stream(seed, 200), V.random_stream(1, seed, 200)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert a[0].min() >= 0 and a[0].max() < 1 and set(a[1]) == set(range(10)) and abs(a[2].mean()) < 0.3
+    for seed in range(8):
+        x = adduct.ref.mutate(adduct.lig["conf0"], seed)
+        assert np.array_equal(x, V.mutate(adduct.h, adduct.lig["conf0"], seed))
+
+
+@pytest.mark.parametrize("which,steps", [("adduct", 1), ("adduct", 40), ("adduct", 600), ("chain", 150)])
+def test_monte_carlo_chains_are_bit_identical(which, steps, request):
+    """monte_carlo::operator() (mutate -> BFGS(hunt) -> Metropolis on what `model` holds -> BFGS(full) -> container)
+    on the same mt19937 stream: same containers, energies, conformations and coordinates, bit for bit."""
+    c = request.getfixturevalue(which)
+    for seed in (1, 2, 3):
+        er, cr, xr = c.ref.mc(seed, steps, c.begin, c.end, max_iters=c.max_iters, num_saved=20)
+        eo, co, xo, _ = V.mc_chain(c.ora, c.begin, c.end, seed, steps, c.max_iters, num_saved=20, rng_kind=1,
+                                   conf0=c.lig["conf0"])
+        assert len(er) == len(eo) >= 1
+        assert np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
