@@ -24,7 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+FLOP_PER_POSE = {"default2017": 1122895872, "crossdock_default2018": 998148096, "dense": 4541572416,
+                 "dense_1_3@96": 36.33e9}   # SURVEY 8d / BASELINE.md section 2 (2 * MACs, unpadded)
 
 
 def parse():
@@ -38,6 +41,7 @@ def parse():
     ap.add_argument("--n-rec", type=int, default=2500)
     ap.add_argument("--n-lig", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 entries of `also`")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -151,6 +155,143 @@ def other_models(args, capi, synth, torch, dev):
             del sc, m
         except Exception as e:  # the headline line must still print
             out[name] = {"error": str(e)}
+    return out
+
+
+def conv1_dense(args, scorer, step, steps):
+    """The dominant kernel with zero-quad skipping switched off (MI_GNINA_NO_SPARSE=1, read per launch): every
+    algorithmic MAC is executed, so this rate IS the MFMA pipe's -- it does not depend on how empty the receptor is."""
+    os.environ["MI_GNINA_NO_SPARSE"] = "1"
+    try:
+        for _ in range(2):
+            step()
+        scorer.synchronize()
+        scorer.enable_profile(True)
+        for _ in range(steps):
+            step()
+        prof = scorer.profile()
+        scorer.enable_profile(False)
+    finally:
+        del os.environ["MI_GNINA_NO_SPARSE"]
+    conv = max((r for r in prof if r["kernel"].startswith("conv")), key=lambda r: r["ms_total"])
+    ms = conv["ms_total"] / conv["launches"]
+    tf = conv["flops"] / conv["launches"] / (ms * 1e-3) / 1e12
+    return {"kernel": conv["kernel"], "avg_launch_ms": round(ms, 4), "tflops": round(tf, 2),
+            "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            "note": "no zero-skipping: executed == algorithmic FLOPs"}
+
+
+def config_c3(capi):
+    """BASELINE config C3 as specified: ONE complex, exhaustiveness 64, gnina's step count, Monte-Carlo + BFGS on the
+    cache grids, then merge -> refine -> CNN rescore (default ensemble) -> final energies -> rank.  A latency
+    workload: 64 chains on a chip with 4,096 wave slots (evaluations/s is the figure SURVEY 8d asks for)."""
+    from tests import vina_scene
+    sc = vina_scene.build(0)
+    lig = sc["lig"]
+    T = lig["n_tors"]
+    n = np.ceil(sc["size"] / np.float32(0.375)).astype(np.int32)
+    span = np.float32(0.375) * n.astype(np.float32)
+    begin = sc["center"].astype(np.float32) - span / 2
+    end = begin + span
+    types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+    t0 = time.perf_counter()
+    vina = capi.Vina()
+    vina.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    vina.build_cache(begin, end, n, types, 1e3)
+    vina.set_ligand(lig)
+    t_setup = time.perf_counter() - t0
+    n_mov = len(lig["smt"])
+    steps = int(70 * 3 * (50 + n_mov + 10 * (6 + T)) / 2)      # main.cpp:441-443
+    iters = (25 + n_mov) // 3
+    P = capi.McParams.default(steps, iters, 50)
+    seeds = np.arange(1, 65, dtype=np.uint64) * np.uint64(7919)
+    vina.mc_batch(seeds[:4], begin, end, capi.McParams.default(20, iters, 50))   # warm-up (module load, allocations)
+    t0 = time.perf_counter()
+    cnt, e, cf, xyz, ev = vina.mc_batch(seeds, begin, end, P)
+    t_mc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    me, mcf, mxyz = capi.merge_mc_outputs(cnt, e, cf, xyz, 2.0, 50)
+    er, rcf, tries = vina.refine_batch(mcf)
+    _, _, co = vina.eval_batch(rcf, want_coords=True)
+    scorer = capi.Scorer(["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])   # gnina's default ensemble
+    scorer.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    out = scorer.score_batch(co, lig["smt"])
+    ef, intra = vina.final_energies(rcf, float(T))
+    heavy = np.nonzero(lig["smt"] > 1)[0]
+    keep = capi.rank_poses(out["pose"], out["affinity"], ef, co[:, heavy], 0, 1.0)
+    t_tail = time.perf_counter() - t0
+    return {"workload": f"C3: 1 complex, 64 chains x {steps} steps, {n_mov}-atom ligand / {T} torsions, receptor "
+                        f"{len(sc['rec_smt'])} atoms, then merge/refine/CNN-rescore(default ensemble)/rank",
+            "total_s": round(t_setup + t_mc + t_tail, 3), "setup_s": round(t_setup, 3), "mc_s": round(t_mc, 3),
+            "tail_s": round(t_tail, 3), "mc_evals": int(ev.sum()), "mc_evals_per_s": round(float(ev.sum()) / t_mc),
+            "poses_reported": int(len(keep)), "bound": "latency (dependent evaluations); no roofline fraction, SURVEY 8d"}
+
+
+def config_c4(capi, synth):
+    """BASELINE config C4, one GPU's share of it: a ragged batch of 1,024 ligands x 9 poses through the 15-model
+    crossdock_default2018 ensemble (one voxelization, 15 forwards per pose), host pointers in and out."""
+    names = ["crossdock_default2018" + s for s in ("", "_1", "_2", "_3", "_4", "_1_3", "_1_3_1", "_1_3_2", "_1_3_3",
+                                                    "_1_3_4", "_KD_1", "_KD_2", "_KD_3", "_KD_4", "_KD_5")]
+    have = [n for n in names if os.path.exists(os.path.join(ROOT, "gnina_amd", "weights", n + ".mgw"))]
+    models = [capi.Model(n) for n in have] + [capi.Model("crossdock_default2018") for _ in range(15 - len(have))]
+    s = capi.Scorer(models)
+    rng = np.random.RandomState(0)
+    m0 = models[0]
+    rec_xyz, rec_smt = synth.make_receptor(rng, 2500, synth.mapped_types(m0.chan_of_smt(False)))
+    lig_types = synth.mapped_types(m0.chan_of_smt(True))
+    s.set_receptor(rec_xyz, rec_smt)
+    n_lig, P, Lmax = 1024, 9, 48
+    xyz = np.zeros((n_lig * P, Lmax, 3), dtype=np.float32)
+    smt = np.full((n_lig * P, Lmax), -1, dtype=np.int32)
+    for i in range(n_lig):
+        L = rng.randint(16, 49)
+        lx, ls = synth.make_ligand(rng, L, lig_types)
+        xyz[i * P:(i + 1) * P, :L] = synth.make_poses(rng, lx, P)
+        smt[i * P:(i + 1) * P, :L] = ls
+    s.score_ragged(xyz[:P * 64], smt[:P * 64])
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s.score_ragged(xyz, smt)
+    dt = (time.perf_counter() - t0) / reps
+    fwd = 15 * n_lig * P / dt
+    tf = fwd * FLOP_PER_POSE["crossdock_default2018"] / 1e12
+    return {"workload": f"C4 (one GPU's shard): 1,024 ligands x 9 poses, L ~ U{{16..48}}, ragged, 15 x Default2018 "
+                        f"({len(have)} distinct weight blobs), host pointers",
+            "ligands_per_s": round(n_lig / dt, 1), "poses_per_s": round(n_lig * P / dt, 1),
+            "model_forwards_per_s": round(fwd, 1), "s_per_100k_ligands_1gpu": round(1e5 / (n_lig / dt), 1),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "note": "end to end incl. voxelization, PCIe and host set-up; algorithmic conv FLOPs"}}
+
+
+def config_c5(capi, synth):
+    """BASELINE config C5's network on one GPU: dense_1_3 at 0.25 A (96^3, 36.3 GFLOP per pose), B = 256, forward and
+    forward + backward (one BFGS evaluation of CNN refinement), exact fp32 and the bf16-MFMA path."""
+    m = capi.Model("dense_1_3", resolution=0.25, dimension=23.75)
+    s = capi.Scorer([m])
+    rng = np.random.RandomState(0)
+    rec_xyz, rec_smt = synth.make_receptor(rng, 2500, synth.mapped_types(m.chan_of_smt(False)))
+    lx, ls = synth.make_ligand(rng, 32, synth.mapped_types(m.chan_of_smt(True)))
+    s.set_receptor(rec_xyz, rec_smt)
+    B = 256
+    poses = synth.make_poses(rng, lx, B)
+    out = {"workload": "C5 network: dense_1_3 @ 0.25 A (96^3 x 28ch), B = 256, host pointers"}
+    gf = FLOP_PER_POSE["dense_1_3@96"]
+    for tag, bf, peak in (("f32", False, PEAK_FP32_MFMA_TFLOPS), ("bf16", True, PEAK_BF16_MFMA_TFLOPS)):
+        s.set_precision(bf)
+        s.score_batch(poses[:32], ls)
+        t0 = time.perf_counter()
+        s.score_batch(poses, ls)
+        dt = time.perf_counter() - t0
+        s.score_grad(poses[:32], ls)
+        t0 = time.perf_counter()
+        s.score_grad(poses, ls)
+        dg = time.perf_counter() - t0
+        tf = B / dt * gf / 1e12
+        out[tag] = {"poses_per_s_forward": round(B / dt, 1), "poses_per_s_forward_backward": round(B / dg, 1),
+                    "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                 "frac": round(tf / peak, 4), "note": "forward, end to end, algorithmic FLOPs"}}
     return out
 
 
@@ -276,18 +417,30 @@ def main():
             "kernels": [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
                          "ms_per_step": round(r["ms_total"] / args.steps, 4),
                          "tflops": round(r["flops"] / (r["ms_total"] * 1e-3) / 1e12, 2) if r["flops"] else None,
-                         "gbs_algorithmic": round(r["bytes"] / (r["ms_total"] * 1e-3) / 1e9, 1)}
+                         "gbs_algorithmic": (round(r["bytes"] / (r["ms_total"] * 1e-3) / 1e9, 1)
+                                             if not r["kernel"].startswith("voxelize") else None)}
                         for r in prof],
             "voxelizer": {"bound": "hbm", "ms_per_launch": round(vox_ms, 4),
-                          "achieved_GBs_unfused_equivalent": round(vox["bytes"] / vox["launches"] / (vox_ms * 1e-3) / 1e9, 1),
+                          "written_GBs": round(vox["bytes"] / 8 / vox["launches"] / (vox_ms * 1e-3) / 1e9, 1),
                           "peak_GBs": PEAK_HBM_GBS,
-                          "note": "bytes = C*N^3*4 per pose (un-fused figure, SURVEY 8d); the kernel writes the "
-                                  "2x2x2-pooled grid, 8x fewer bytes"},
+                          "frac": round(vox["bytes"] / 8 / vox["launches"] / (vox_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "poses_per_launch": vox["poses"] // vox["launches"],
+                          "note": "bytes actually written: the 2x2x2-pooled grid, C*(N/2)^3*4 per pose (the un-fused "
+                                  "C*N^3*4 figure of SURVEY 8d is 8x that and never exists in HBM); VALU-bound "
+                                  "(exp/sqrt per atom-voxel pair), not HBM-bound"},
             "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
             "dominant_kernel_overall": dom["kernel"],
         }
         if world == 1:
             res["also"] = other_models(args, capi, synth, torch, dev)
+            res["roofline"]["dense_no_skip"] = conv1_dense(args, scorer, step, max(3, min(args.steps, 10)))
+            if not args.no_configs:
+                for key, fn in (("c3", lambda: config_c3(capi)), ("c4", lambda: config_c4(capi, synth)),
+                                ("c5", lambda: config_c5(capi, synth))):
+                    try:
+                        res["also"][key] = fn()
+                    except Exception as e:  # the headline line must still print
+                        res["also"][key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(args, os.path.join(ROOT, "gnina_amd", "weights", args.model + ".mgw"),
                                           rec_xyz, rec_smt, lig_smt, poses, args.cpu_seconds)

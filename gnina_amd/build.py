@@ -70,6 +70,31 @@ def build_host(force=False, verbose=False):
     return exe
 
 
+def extract_weights(models_dir="/root/reference/gninasrc/lib/models", verbose=False):
+    """Weight blobs of ALL the reference's built-in models (cnn_torch_scorer.cpp:24-64: default2017, the default2018 /
+    dense families, *_ensemble members ...) from its TorchScript files, into gnina_amd/weights/.  Seven blobs are
+    committed; the other ~57 (116 MB) are derived data produced here whenever the reference is present (this
+    container) and travel to the GPU box with the working tree -- they are git-ignored, not gpurun-ignored."""
+    wdir = os.path.join(HERE, "weights")
+    if not os.path.isdir(models_dir):
+        return 0
+    todo = [f for f in sorted(os.listdir(models_dir))
+            if f.endswith(".pt") and not os.path.exists(os.path.join(wdir, f[:-3].replace(".", "_") + ".mgw"))]
+    if not todo:
+        return 0
+    from gnina_amd.tools import extract_weights as ew
+    n = 0
+    for f in todo:
+        data, name = ew.convert(os.path.join(models_dir, f))
+        with open(os.path.join(wdir, name + ".mgw"), "wb") as out:
+            out.write(data)
+        n += 1
+        if verbose:
+            print("extracted", name, len(data))
+    return n
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    print("weight blobs extracted:", extract_weights(verbose=True))

@@ -200,13 +200,15 @@ def test_noncache_exact_and_refine_match_oracle(setup):
         for b in range(0, len(confs), 3):
             e0 = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=exact)[0]
             assert abs(e_only[b] - e0) <= 2e-4 * max(1.0, abs(e0))
-    # final energies: conf_independent(inter_exact) and the exact intramolecular term
+    # final energies (do_search's docking branch, main.cpp:231,339-344): receptor term = non_cache on the LINEAR
+    # tables, pair terms exact, then num_tors_div -- the oracle recipe is pinned to the reference in test_ref_vina.py
     num_tors = 6.0
     ef, intra = vina.final_energies(confs, num_tors, v)
     for b in range(len(confs)):
-        tot, _, inter0, intra0 = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=True)
+        _, _, inter_l, _ = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=False)
+        _, _, _, intra0 = V.noncache_eval(S, sc["rec_xyz"], sc["rec_smt"], confs[b], v, deriv=False, exact=True)
         assert abs(intra[b] - intra0) <= 2e-4 * max(1.0, abs(intra0))
-        ref = V.conf_independent(np.float32(tot) - np.float32(intra0), num_tors)
+        ref = V.conf_independent(np.float32(np.float32(inter_l) + np.float32(intra0)) - np.float32(intra0), num_tors)
         assert abs(ef[b] - ref) <= 5e-4 * max(1.0, abs(ref))
     # refine_structure: everything ends inside the box (or reports max_fl), energies never increase
     e_start = vina.eval_batch(confs, v, deriv=False, direct=True)[0]
