@@ -280,11 +280,11 @@ def config_c5(capi, synth):
     gf = FLOP_PER_POSE["dense_1_3@96"]
     for tag, bf, peak in (("f32", False, PEAK_FP32_MFMA_TFLOPS), ("bf16", True, PEAK_BF16_MFMA_TFLOPS)):
         s.set_precision(bf)
-        s.score_batch(poses[:32], ls)
+        s.score_batch(poses, ls)              # warm-up at the full batch: activation buffers are allocated once
         t0 = time.perf_counter()
         s.score_batch(poses, ls)
         dt = time.perf_counter() - t0
-        s.score_grad(poses[:32], ls)
+        s.score_grad(poses, ls)
         t0 = time.perf_counter()
         s.score_grad(poses, ls)
         dg = time.perf_counter() - t0

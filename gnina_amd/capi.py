@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -119,6 +119,7 @@ def lib():
         L.mi_scorer_score_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mi_scorer_score_grad.restype = C.c_int
         L.mi_scorer_set_flex.argtypes = [vp, vp, C.c_int]
+        L.mi_scorer_set_rotations.argtypes = [vp, vp, C.c_int]
         L.mi_read_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.mi_write_gninatypes.argtypes = [C.c_char_p, vp, vp, C.c_int]
         L.mi_io_last_error.restype = C.c_char_p
@@ -436,6 +437,11 @@ class Scorer:
     def set_precision(self, bf16):
         """False: exact fp32 (parity path); True: bf16-MFMA convolutions (forward only)."""
         check(lib().mi_scorer_set_precision(self.handle, 1 if bf16 else 0))
+
+    def set_rotations(self, quats):
+        """per-pose unit quaternions (a, b, c, d) for the NEXT scoring call (TorchModel::forward's `rotate`)"""
+        q = _f32(quats).reshape(-1, 4)
+        check(lib().mi_scorer_set_rotations(self.handle, _ptr(q), len(q)))
 
     def set_flex(self, rec_rows):
         """Receptor rows (of set_receptor's arrays) whose coordinates are supplied per pose."""

@@ -669,6 +669,10 @@ struct Scorer {
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
   DevBuf<float> d_flex, d_flex_grad;    // [B][n_flex][3]
   const float *cur_flex = nullptr;      // device flex coordinates of the call in flight (or nullptr)
+  // per-pose rotations of the next scoring call (mi_scorer_set_rotations; TorchModel::forward's `rotate`)
+  std::vector<float> next_rot;          // host [B][4], consumed by one call
+  DevBuf<float> d_rot;
+  const float *cur_rot = nullptr;
   // outputs per model [n_models][B] and reduced
   DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var, d_out4;
   float *h_out4 = nullptr;  // pinned staging of the four output arrays
@@ -864,6 +868,20 @@ static void set_receptor(Scorer &s, const float *xyz, const int32_t *smt, int n)
   s.flex_rows.clear();
 }
 
+// Rotations given with mi_scorer_set_rotations apply to exactly one scoring call: upload at entry, forget at exit.
+struct RotScope {
+  Scorer &s;
+  RotScope(Scorer &sc, int B) : s(sc) {
+    if (s.next_rot.empty()) return;
+    std::vector<float> r;
+    r.swap(s.next_rot);  // consumed even if the call fails
+    MIG_CHECK((int)r.size() == 4 * B, 1, "mi_scorer_set_rotations was given a different number of poses than this call");
+    s.d_rot.upload(r.data(), r.size(), s.stream);
+    s.cur_rot = s.d_rot.p;
+  }
+  ~RotScope() { s.cur_rot = nullptr; }
+};
+
 // Declare the receptor rows that move with every pose (flexible side chains).  In the reference these are
 // the first num_flex rows of receptor_coords (dl_scorer.cpp:150-193) and receptor_map sends their
 // gradients back to the model (cnn_torch_scorer.cpp:216-224).
@@ -1040,6 +1058,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
     ga.pose_n_lig = s.d_pose_nlig.p + b0;
   }
   ga.centers_in = d_centers_in ? d_centers_in + (size_t)b0 * 3 : nullptr;
+  ga.rot = s.cur_rot ? s.cur_rot + (size_t)b0 * 4 : nullptr;
   ga.center_typed_only = (flags & MI_CENTER_TYPED_ONLY) ? 1 : 0;
   ga.half_dim = m->d.dimension / 2.0f;
   ga.centers_out = s.d_centers.p + (size_t)b0 * 3;
@@ -1293,6 +1312,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   for (Model *m : s.models)
     MIG_CHECK(m->grad_supported, 1, "gradient not supported for model " + m->d.name + ": " + m->grad_unsupported_reason);
   if (B == 0) return;
+  RotScope rot_scope(s, B);
   set_call_capacity(s, B, true);
   const int nm = (int)s.models.size();
   s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
@@ -1356,6 +1376,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
         vb.lig_grad = s.d_lig_grad.p + (size_t)b0 * L * 3;
         vb.scale = 1.0f / (float)nm;
         vb.accumulate = 1;
+        vb.rot = s.cur_rot ? s.cur_rot + (size_t)b0 * 4 : nullptr;
         {
           ProfScope ps(s, "voxel_backward", 0.0, 0.0, nb);
           launch_voxel_backward(vb, nb, m->input_pool, s.stream);
@@ -1402,6 +1423,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
   MIG_CHECK(pose && aff && loss, 1, "output arrays must not be NULL");
   if (B == 0) return;
+  RotScope rot_scope(s, B);
   set_call_capacity(s, B, false);
   const int nm = (int)s.models.size();
   const float *d_lig = lig_xyz;
@@ -1679,6 +1701,23 @@ mi_status mi_scorer_set_precision(mi_scorer *sc, int precision) {
   MIG_CHECK(sc, 1, "NULL scorer");
   MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16, 1, "unknown precision");
   reinterpret_cast<Scorer *>(sc)->precision = precision;
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_scorer_set_rotations(mi_scorer *sc, const float *quats, int B) {
+  MI_TRY
+  MIG_CHECK(sc && B >= 0 && (B == 0 || quats), 1, "bad rotation arguments");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  s.next_rot.assign(quats, quats + (size_t)4 * B);
+  for (int b = 0; b < B; b++) {
+    const float *q = quats + 4 * b;
+    const float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!(std::fabs(n2 - 1.0f) < 1e-3f)) {
+      s.next_rot.clear();
+      MIG_CHECK(false, 1, "rotation quaternions must have unit length");
+    }
+  }
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -74,6 +74,8 @@ struct VinaMcArgs {
   float hunt[3], auth[3];
   float c1[3], c2[3];            // search box corners
   const unsigned long long *seeds;  // [B]
+  unsigned *mt;  // [B][mt_team][624] MT19937 states, seeded on the host (one private copy per wave of a chain's team)
+  int mt_team;   // copies per chain (>= the team size the launch ends up with)
   float *scratch_e, *scratch_conf, *scratch_coords;  // per-chain physical container
   float *out_e, *out_conf, *out_coords;              // sorted output [B][num_saved]...
   int *out_n, *evals;

@@ -1355,6 +1355,10 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
     wave_sync();
     lapb(5);
   }
+  // What `model` holds after the call is the conformation of the last evaluation: x before the revert below (every
+  // iteration ends with x = x_new, accepted trial or not).  Monte-Carlo's update_energy and gyration_radius read it
+  // (monte_carlo.cpp:44-47, mutate.cpp:55); it is left in k.x_new.
+  if (lane < nc) x_new[lane] = x_r;
   if (!(f0 <= f_orig)) {  // bfgs.h:491-495
     f0 = f_orig;
     x_r = x_orig;
@@ -1454,9 +1458,13 @@ void launch_vina_refine(const VinaEnv &env0, const VinaLigand &lig, float *confs
 // ---------------------------------------------------------------------------------------------
 // Monte-Carlo chain: monte_carlo::operator() (monte_carlo.cpp:99-148) -- one wavefront per chain for
 // the WHOLE chain (mutate -> BFGS(hunt cap) -> Metropolis -> BFGS(full cap) -> container insert),
-// no host round trip between steps.  RNG: a counter-based generator shared with the CPU oracle
-// (boost::mt19937 + boost distributions cannot be reproduced without the unvendored Boost; parity
-// for this row is statistical, SURVEY "Hard parts").
+// no host round trip between steps.
+// RNG: the reference's boost::mt19937 (= the standard MT19937, one 624-word state per wave in global memory, seeded
+// on the host, regenerated by the wave's 64 lanes every 624 draws) under restatements of the Boost distributions
+// random.cpp draws from -- the same ones oracle/ref_shims/boost/random.hpp gives the reference code in oracle/_ref,
+// whose chains oracle/vina_ref.c follows bit for bit (tests/test_ref_vina.py).  On the device logf / cosf and the
+// force sums differ in the last bits, so chains agree with the reference's for their first steps and statistically
+// afterwards.
 // ---------------------------------------------------------------------------------------------
 // order the memory accesses of one wave's lanes (the wave runs in lock step; this is the compiler / counter fence)
 __device__ __forceinline__ void wsync() {
@@ -1465,22 +1473,64 @@ __device__ __forceinline__ void wsync() {
 }
 
 struct McRng {
-  unsigned long long s;
-  __device__ unsigned u32() {
-    s += 0x9E3779B97F4A7C15ull;
-    unsigned long long z = s;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32);
+  unsigned *mt;  // this wave's 624-word state (global memory)
+  int idx;       // next word; 624 = regenerate first
+  // the state is rewritten by this wave's own lanes: read it past the (non-coherent) vector L1
+  __device__ unsigned ld(int i) const { return __hip_atomic_load(&mt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  // The sequential twist reads mt[i + 1] before it is replaced and mt[(i + 397) % 624] after it was (for i >= 227):
+  // three ranges whose inputs are complete when the range starts, 64 words at a time, loads before stores.
+  __device__ void twist() {
+    const int lane = threadIdx.x & 63;
+    const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+#pragma unroll 1
+    for (int ph = 0; ph < 3; ph++)
+#pragma unroll 1
+      for (int i0 = lo[ph]; i0 < hi[ph]; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned v = 0;
+        if (i < hi[ph]) {
+          const unsigned y = (ld(i) & 0x80000000u) | (ld(i + 1 < 624 ? i + 1 : 0) & 0x7fffffffu);
+          v = ld(i + 397 < 624 ? i + 397 : i - 227) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wsync();
+        if (i < hi[ph]) __hip_atomic_store(&mt[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        wsync();
+      }
+    idx = 0;
   }
-  __device__ float u01() { return (float)(u32() >> 8) * (1.0f / 16777216.0f); }
-  __device__ float fl(float a, float b) { return a + (b - a) * u01(); }
-  __device__ int irange(int a, int b) { return a + (int)(u32() % (unsigned)(b - a + 1)); }
+  __device__ unsigned u32() {
+    if (idx >= 624) twist();
+    unsigned y = ld(idx++);
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  // boost::uniform_real<float> (random_fl, random.cpp:27-35): u32 / 2^32 * (b - a) + a, redrawn if it reaches b
+  __device__ float fl(float a, float b) {
+    for (;;) {
+      const float result = (float)u32() / 4294967296.0f * (b - a) + a;
+      if (result < b) return result;
+    }
+  }
+  // boost::uniform_int<int> (random_int, random.cpp:44-52): equal buckets with rejection
+  __device__ int irange(int a, int b) {
+    const unsigned range = (unsigned)b - (unsigned)a, brange = 0xffffffffu;
+    if (range == 0) return a;
+    unsigned bucket = brange / (range + 1);
+    if (brange % (range + 1) == range) ++bucket;
+    for (;;) {
+      const unsigned q = u32() / bucket;
+      if (q <= range) return (int)(q + (unsigned)a);
+    }
+  }
+  // boost::normal_distribution<float>(0, 1), Box-Muller on two fresh uniforms (random_normal builds a new
+  // distribution object per call, random.cpp:37-42)
   __device__ float normal() {
-    float u1 = ((float)(u32() >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    float u2 = u01();
-    return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * VPI * u2);
+    const float r1 = fl(0.f, 1.f), r2 = fl(0.f, 1.f);
+    return sqrtf(-2.0f * logf(1.0f - r2)) * cosf(2.0f * 3.14159265358979323846f * r1);
   }
   __device__ void inside_sphere(float &x, float &y, float &z) {  // random.cpp:66-75
     for (;;) {
@@ -1522,6 +1572,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
     (void)carve_work(q, L, false);
     (void)carve_bfgs(q, n, nc);
     (void)carve(q, nc);
+    (void)carve(q, nc);
     (void)carve(q, 3 * nh);
     (void)carve(q, 64);
     (void)carve(q, a.num_saved);
@@ -1531,12 +1582,13 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   WaveWork w = carve_work(pp, L);
   BfgsWork k = carve_bfgs(pp, n, nc);
   float *tmp = carve(pp, nc);
+  float *mconf = carve(pp, nc);  // the conformation the reference's `model` holds (see bfgs_wave's closing comment)
   float *hc = carve(pp, 3 * nh);
   float *rm = carve(pp, 64);                       // rmsd of the candidate to each saved pose (wave 0)
   int *ord = reinterpret_cast<int *>(carve(pp, a.num_saved));  // sorted position -> physical slot (wave 0)
   const WaveTeam tm{W, wv, stride, sh_f, sh_ok};
   const int b = chain, lane = threadIdx.x & 63;
-  McRng rng{a.seeds[b]};
+  McRng rng{a.mt + ((size_t)b * a.mt_team + wv) * 624, 624};
   int evals = 0;
   // scratch container of this chain (physical slots)
   float *s_e = a.scratch_e + (size_t)b * a.num_saved;
@@ -1548,12 +1600,22 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   {
     float px = rng.fl(a.c1[0], a.c2[0]), py = rng.fl(a.c1[1], a.c2[1]), pz = rng.fl(a.c1[2], a.c2[2]);
     float q0, q1, q2, q3, nrm;
-    do {
+    do {  // random_orientation (quaternion.cu:81-94); abs(qt) scales by the largest component (quaternion.h:169-190)
       q0 = rng.normal();
       q1 = rng.normal();
       q2 = rng.normal();
       q3 = rng.normal();
-      nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+      const float maxim = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3)));
+      nrm = 0.f;
+      if (maxim != 0.f) {
+        const float mixam = (float)(1.0 / (double)maxim);
+        const float v0 = q0 * mixam, v1 = q1 * mixam, v2 = q2 * mixam, v3 = q3 * mixam;
+        float sum = v0 * v0;
+        sum += v1 * v1;
+        sum += v2 * v2;
+        sum += v3 * v3;
+        nrm = maxim * sqrtf(sum);
+      }
     } while (!(nrm > VEPS));
     if (lane == 0) {
       tmp[0] = px, tmp[1] = py, tmp[2] = pz;
@@ -1563,6 +1625,9 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
       float tv = rng.fl(-VPI, VPI);
       if (lane == 0) tmp[7 + t] = tv;
     }
+    // before the first evaluation `model` holds the input pose: zero torsions (its rigid placement does not matter
+    // to the gyration radius, the only thing read from it)
+    for (int i = lane; i < nc; i += 64) mconf[i] = i == 3 ? 1.f : 0.f;
   }
   wave_sync();
   float tmp_e = 0.f, best_e = VMAXFL;
@@ -1593,7 +1658,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
         k.x[2] += a.amplitude * dz;
       }
     } else if (which == 1) {
-      (void)eval_conf<3, PG>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // coordinates of the candidate
+      (void)eval_conf<3, PG>(env, L, mconf, 0.f, 0.f, 0.f, w, nullptr);  // the coordinates `model` holds
       float acc = 0.f;
       for (int i = lane; i < L.n_atoms; i += 64)
         if (L.smt[i] > 1) {
@@ -1626,26 +1691,39 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
       const float *cap = pass == 0 ? a.hunt : a.auth;
       (void)bfgs_wave<HR, PG>(env, L, w, k, cap[0], cap[1], cap[2], a.max_iters, evals, tm, evt);
       lap(pass == 0 ? 1 : 3);
-      const float e_now = eval_conf<2, PG>(env, L, k.x, 0.f, a.auth[1], 0.f, w, nullptr);  // update_energy; leaves coords of k.x in w.coords
+      // update_energy (monte_carlo.cpp:44-47): ig.eval on the coordinates `model` holds = the last evaluated
+      // conformation (k.x_new), which is k.x unless bfgs reverted to its start
+      bool reverted = false;
+      for (int i = lane; i < nc; i += 64) reverted |= k.x_new[i] != k.x[i];
+      reverted = __any(reverted);
+      const float e_now = eval_conf<2, PG>(env, L, k.x_new, 0.f, a.auth[1], 0.f, w, nullptr);  // leaves its coords in w.coords
       if (pass == 0) {
         cand_e = e_now;
         bool accept = step == 0 || cand_e < tmp_e;
         if (!accept) {  // metropolis_accept, monte_carlo.cpp:38-42
           const float prob = expf((tmp_e - cand_e) / a.temperature);
-          accept = rng.u01() < prob;
+          accept = rng.fl(0.f, 1.f) < prob;
         }
         lap(2);
-        if (!accept) break;
+        if (!accept) {  // `model` keeps the rejected candidate's last evaluation
+          for (int i = lane; i < nc; i += 64) mconf[i] = k.x_new[i];
+          wave_sync();
+          break;
+        }
         tmp_e = cand_e;
         pt[7] += a.prof ? 1 : 0;
         if (!(tmp_e < best_e || n_out < a.num_saved)) {
-          for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
+          for (int i = lane; i < nc; i += 64) tmp[i] = mconf[i] = k.x[i];  // tmp = candidate; m.set(tmp.c)
           wave_sync();
           break;
         }
       } else {
         tmp_e = e_now;
-        for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i];
+        for (int i = lane; i < nc; i += 64) tmp[i] = mconf[i] = k.x[i];  // m.set(tmp.c), monte_carlo.cpp:131
+        if (reverted) {  // the coordinates in w.coords are the last trial's, not tmp's
+          wave_sync();
+          (void)eval_conf<3, PG>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);
+        }
         for (int h = lane; h < nh; h += 64) {
           const int i = L.heavy_list[h];
           hc[3 * h] = w.coords[3 * i];
@@ -1659,9 +1737,9 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
           for (int o = lane; o < n_out; o += 64) {
             const float *ref = s_xyz + (size_t)ord[o] * xs_;
             float acc = 0.f;
-            for (int i = 0; i < 3 * nh; i++) {
-              const float d = hc[i] - ref[i];
-              acc += d * d;
+            for (int i = 0; i < nh; i++) {  // rmsd_upper_bound: one vec_distance_sqr per atom (coords.cpp:25-32)
+              const float dx = hc[3 * i] - ref[3 * i], dy = hc[3 * i + 1] - ref[3 * i + 1], dz = hc[3 * i + 2] - ref[3 * i + 2];
+              acc += dx * dx + dy * dy + dz * dz;
             }
             rm[o & 63] = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;
           }
@@ -1760,7 +1838,7 @@ int vina_mc_team(int B) {
 
 size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage, int W) {
   const size_t ligand = stage ? ligand_lds_floats(n_atoms, n_nodes, n_pairs, n_atoms) : 0;
-  const size_t wave = vina_wave_lds_bytes(n_atoms, n_nodes, n_pairs, true, false) / sizeof(float) + pad4(7 + n_nodes - 1) +
+  const size_t wave = vina_wave_lds_bytes(n_atoms, n_nodes, n_pairs, true, false) / sizeof(float) + 2 * pad4(7 + n_nodes - 1) +
                       pad4(3 * (size_t)n_heavy) + 64 + pad4(num_saved);
   return (ligand + 2 * pad4(W) + 4 + W * wave) * sizeof(float);
 }

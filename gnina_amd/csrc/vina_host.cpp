@@ -100,6 +100,7 @@ struct Vina {
   DevBuf<float> d_ext_forces, d_ext_e, d_ext_centers;
   DevBuf<int> d_evals, d_out_n;
   DevBuf<unsigned long long> d_seeds;
+  DevBuf<unsigned> d_mt;
   DevBuf<float> d_mc_e, d_mc_conf, d_mc_xyz, d_sc_e, d_sc_conf, d_sc_xyz;
   ~Vina() {
     if (stream) (void)hipStreamDestroy(stream);
@@ -620,6 +621,20 @@ int mi_vina_ligand_heavy_atoms(const mi_vina *vv) {
   return vv && reinterpret_cast<const Vina *>(vv)->have_lig ? reinterpret_cast<const Vina *>(vv)->lig.n_heavy : 0;
 }
 
+// boost::mt19937 generator(seed) (parallel_mc.cpp:190-192 hands every task its own seed): the standard MT19937
+// seeding, one 624-word state per wave of a chain's team (the waves replay the chain, each on a private copy).
+static void upload_mt_states(Vina &v, const uint64_t *seeds, int B) {
+  const int W = vina_mc_team(B);
+  std::vector<unsigned> st((size_t)B * W * 624);
+  for (int b = 0; b < B; b++) {
+    unsigned *m = &st[(size_t)b * W * 624];
+    m[0] = (unsigned)seeds[b];
+    for (int i = 1; i < 624; i++) m[i] = 1812433253u * (m[i - 1] ^ (m[i - 1] >> 30)) + (unsigned)i;
+    for (int w = 1; w < W; w++) std::memcpy(m + (size_t)w * 624, m, 624 * sizeof(unsigned));
+  }
+  v.d_mt.upload(st.data(), st.size(), v.stream);
+}
+
 mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const float *corner1, const float *corner2,
                            const mi_mc_params *P, int32_t *out_n, float *out_e, float *out_conf, float *out_coords,
                            int32_t *evals) {
@@ -634,6 +649,7 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
   MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true, 1) <= 152 * 1024, 1,
             "ligand too large for the per-wave LDS workspace");
   v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
+  upload_mt_states(v, seeds, B);
   v.d_mc_e.ensure((size_t)B * S);
   v.d_mc_conf.ensure((size_t)B * S * nc);
   v.d_mc_xyz.ensure((size_t)B * S * 3 * nh + 1);
@@ -656,6 +672,8 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
     a.c2[i] = corner2[i];
   }
   a.seeds = v.d_seeds.p;
+  a.mt = v.d_mt.p;
+  a.mt_team = vina_mc_team(B);
   a.scratch_e = v.d_sc_e.p;
   a.scratch_conf = v.d_sc_conf.p;
   a.scratch_coords = v.d_sc_xyz.p;
@@ -724,6 +742,7 @@ mi_status mi_vina_mc_screen(mi_vina *vv, int B, const int32_t *chain_ligand, con
   MIG_CHECK(vina_mc_lds_bytes(big.n_atoms, big.n_nodes, big.n_pairs, nhm, S, true, 1) <= 152 * 1024, 1,
             "ligands too large for the per-wave LDS workspace");
   v.d_seeds.upload(reinterpret_cast<const unsigned long long *>(seeds), B, v.stream);
+  upload_mt_states(v, seeds, B);
   v.d_chain_lig.upload(chain_ligand, B, v.stream);
   v.d_lig_steps.upload(steps.data(), nl, v.stream);
   v.d_lig_iters.upload(iters.data(), nl, v.stream);
@@ -747,6 +766,8 @@ mi_status mi_vina_mc_screen(mi_vina *vv, int B, const int32_t *chain_ligand, con
     a.c2[i] = corner2[i];
   }
   a.seeds = v.d_seeds.p;
+  a.mt = v.d_mt.p;
+  a.mt_team = vina_mc_team(B);
   a.scratch_e = v.d_sc_e.p;
   a.scratch_conf = v.d_sc_conf.p;
   a.scratch_coords = v.d_sc_xyz.p;

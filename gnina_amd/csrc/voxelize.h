@@ -37,6 +37,9 @@ struct GatherArgs {
   const int *pose_rows;     // [B] real ligand rows of pose b (<= L), or nullptr = one ligand for the whole batch
   const int *pose_n_lig;    // [B] typed atoms of pose b
   const float *centers_in;  // [B][3] or nullptr; non-finite x -> ligand mean
+  // Transform(gcenter, 0, rotate) (torch_model.cpp:170-173): unit quaternions [B][4] (a, b, c, d), every atom becomes
+  // R(q)(x - centre) + centre before it is placed on the grid; nullptr = no rotation
+  const float *rot;
   int center_typed_only;
   float half_dim;
   float *centers_out;  // [B][3]
@@ -85,6 +88,7 @@ struct VoxBackArgs {
   float *lig_grad;  // [B][L][3]
   float scale;      // e.g. 1 / n_models
   int accumulate;   // add into lig_grad instead of overwriting
+  const float *rot; // [B][4] rotation of the forward pass (see GatherArgs); the gradient is rotated back
 };
 
 void launch_gather(const GatherArgs &g, int B, hipStream_t s);

@@ -35,6 +35,26 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// Rotation of libmolgrid's Transform (rotate about the grid centre, no translation): rows of R(q) for a unit
+// quaternion q = a + bi + cj + dk.
+struct Rot3 {
+  float m[3][3];
+};
+__device__ __forceinline__ Rot3 rot_of_quat(const float *q) {
+  const float a = q[0], b = q[1], c = q[2], d = q[3];
+  Rot3 r;
+  r.m[0][0] = a * a + b * b - c * c - d * d, r.m[0][1] = 2.f * (b * c - a * d), r.m[0][2] = 2.f * (b * d + a * c);
+  r.m[1][0] = 2.f * (b * c + a * d), r.m[1][1] = a * a - b * b + c * c - d * d, r.m[1][2] = 2.f * (c * d - a * b);
+  r.m[2][0] = 2.f * (b * d - a * c), r.m[2][1] = 2.f * (c * d + a * b), r.m[2][2] = a * a - b * b - c * c + d * d;
+  return r;
+}
+__device__ __forceinline__ void rot_about(const Rot3 &r, float cx, float cy, float cz, float &x, float &y, float &z) {
+  const float dx = x - cx, dy = y - cy, dz = z - cz;
+  x = (r.m[0][0] * dx + r.m[0][1] * dy + r.m[0][2] * dz) + cx;
+  y = (r.m[1][0] * dx + r.m[1][1] * dy + r.m[1][2] * dz) + cy;
+  z = (r.m[2][0] * dx + r.m[2][1] * dy + r.m[2][2] * dz) + cz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // gather_pose_atoms
 // ---------------------------------------------------------------------------------------------
@@ -85,6 +105,8 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
   if (tid < kMaxSlabs) s_base[tid] = 0;
   __syncthreads();
   const float cx = s_center[0], cy = s_center[1], cz = s_center[2];
+  Rot3 R;
+  if (g.rot) R = rot_of_quat(g.rot + 4 * (size_t)b);
 
   const int total = g.n_rec + n_lig;
   for (int base = 0; base < total; base += 256) {
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
         a.inv_ar = lc.inv_ar;
         ch = g.lig_chan[po + j];
       }
+      if (g.rot) rot_about(R, cx, cy, cz, a.x, a.y, a.z);
       float reach = g.half_dim + a.ar * 1.5f + 0.01f;
       keep = fabsf(a.x - cx) <= reach && fabsf(a.y - cy) <= reach && fabsf(a.z - cz) <= reach;
     }
@@ -355,8 +378,13 @@ __global__ __launch_bounds__(64) void voxel_backward_kernel(VoxBackArgs a) {
   const int src = a.lig_perm[j];
   const LigConsts lc = a.lig_consts[j];
   const int c = a.lig_chan[j];
-  const float ax = a.lig_xyz[((size_t)b * a.L + src) * 3], ay = a.lig_xyz[((size_t)b * a.L + src) * 3 + 1],
-              az = a.lig_xyz[((size_t)b * a.L + src) * 3 + 2];
+  float ax = a.lig_xyz[((size_t)b * a.L + src) * 3], ay = a.lig_xyz[((size_t)b * a.L + src) * 3 + 1],
+        az = a.lig_xyz[((size_t)b * a.L + src) * 3 + 2];
+  Rot3 R;
+  if (a.rot) {  // the grid saw the rotated atom
+    R = rot_of_quat(a.rot + 4 * (size_t)b);
+    rot_about(R, a.centers[3 * b], a.centers[3 * b + 1], a.centers[3 * b + 2], ax, ay, az);
+  }
   const float ox = a.centers[3 * b] - a.half_dim, oy = a.centers[3 * b + 1] - a.half_dim,
               oz = a.centers[3 * b + 2] - a.half_dim;
   const float maxr = lc.ar * 1.5f;
@@ -406,6 +434,11 @@ __global__ __launch_bounds__(64) void voxel_backward_kernel(VoxBackArgs a) {
     gx += __shfl_xor(gx, off);
     gy += __shfl_xor(gy, off);
     gz += __shfl_xor(gz, off);
+  }
+  if (a.rot) {  // Transform::backward(grad, grad, false): the gradient vector goes back through R^T
+    const float tx = R.m[0][0] * gx + R.m[1][0] * gy + R.m[2][0] * gz, ty = R.m[0][1] * gx + R.m[1][1] * gy + R.m[2][1] * gz,
+                tz = R.m[0][2] * gx + R.m[1][2] * gy + R.m[2][2] * gz;
+    gx = tx, gy = ty, gz = tz;
   }
   if (lane == 0) {
     float *o = a.lig_grad + ((size_t)b * a.L + src) * 3;

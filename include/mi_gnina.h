@@ -142,6 +142,13 @@ int mi_model_supports_gradient(const mi_model *);
  * [B][L][3] and flex_grad [B][n_flex][3] are optional outputs (both NULL: forward only).  Gradients of
  * untyped rows are 0.  Host pointers. */
 mi_status mi_scorer_set_flex(mi_scorer *, const int32_t *rec_rows, int n_flex);
+/* TorchModel::forward's `rotate` (torch_model.cpp:170-173,204-206; used for --cnn_rotation averaging,
+ * cnn_torch_scorer.cpp:130-141): libmolgrid's Transform(gcenter, 0, rotate) turns every atom -- receptor and ligand --
+ * about the grid centre, x' = R(q)(x - c) + c, before GridMaker::forward, and Transform::backward turns the atom
+ * gradients back.  quats [B][4] = unit quaternions (a, b, c, d), one per pose ((1,0,0,0) = none); they apply to the
+ * NEXT scoring call of this scorer only (score_batch / score_ragged / score_grad / score_flex / voxelize_batch),
+ * whose B must match.  Which quaternions libmolgrid draws is the caller's business (HipCNNScorer, hip_cnn_scorer.cpp). */
+mi_status mi_scorer_set_rotations(mi_scorer *, const float *quats, int B);
 mi_status mi_scorer_score_flex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                const float *centers, const float *flex_xyz, float *pose, float *affinity,
                                float *loss, float *aff_var, float *lig_grad, float *flex_grad);

@@ -190,10 +190,10 @@ class McParams(C.Structure):
 
 
 def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, temperature=1.2, amplitude=2.0,
-             min_rmsd=1.0, rng_kind=0, conf0=None):
+             min_rmsd=1.0, rng_kind=1, conf0=None):
     """monte_carlo::operator() for one chain -> (energies [n], confs [n,7+T], coords [n,nh,3], evals).
-    rng_kind 0: the splitmix stream shared with the HIP kernel; 1: mt19937 + Boost's distributions as restated for
-    oracle/_ref (follows the reference's chain step for step)."""
+    rng_kind 1 (default, also what the HIP kernel draws from): mt19937 + Boost's distributions as restated for
+    oracle/_ref -- the chain follows the reference's step for step; 0: a counter-based splitmix stream (legacy)."""
     lig = scene.lig
     nh = int((lig.arr["smt"] > 1).sum())
     P = McParams(n_steps, max_iters, num_saved, temperature, amplitude, min_rmsd, (C.c_float * 3)(10, 10, 10),

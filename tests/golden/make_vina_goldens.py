@@ -83,6 +83,12 @@ def case(G, name, rigid, lig_text, center=None, size=None, seed=0, mc=((1, 60), 
     for seed_, steps in mc:
         er, cr, xr = s.mc(seed_, steps, b, e, max_iters=mi, num_saved=20)
         G[P + f"mc/{seed_}_{steps}/e"], G[P + f"mc/{seed_}_{steps}/conf"], G[P + f"mc/{seed_}_{steps}/coords"] = er, cr, xr
+    # short chains from many seeds: what a device (other libm, other summation order) can follow step for step
+    for steps in (1, 3):
+        rows = [s.mc(seed_, steps, b, e, max_iters=mi, num_saved=20) for seed_ in range(100, 132)]
+        G[P + f"mcshort/{steps}/n"] = np.array([len(r[0]) for r in rows], np.int32)
+        G[P + f"mcshort/{steps}/e0"] = np.array([r[0][0] for r in rows], np.float32)
+        G[P + f"mcshort/{steps}/conf0"] = np.stack([r[1][0] for r in rows])
     print(name, "atoms", s.n_atoms, "torsions", s.n_lig_tors, "pairs", s.n_lig_pairs, "box", n)
 
 

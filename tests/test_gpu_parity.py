@@ -276,3 +276,69 @@ def test_full_size_batch_properties(capi, CG):
         p, aff, _ = cnn_ref.scores(blob, grids)
     assert np.abs(a["pose"][sample] - p.numpy()).max() < 1e-4
     assert np.abs(a["affinity"][sample] - aff.numpy()).max() < 1e-4
+
+
+ALL = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens_all.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in ALL["names"]])
+def test_every_builtin_model_matches_the_references_torchscript(capi, name):
+    """All 64 built-in models (cnn_torch_scorer.cpp:24-64: default2017, the default2018 / dense families, every
+    *_ensemble member, `fast`, `default1.0`), HIP vs the reference's own .pt outputs on the same atoms.  Blobs other
+    than the seven committed ones are extracted from the reference at build time (gnina_amd/build.py)."""
+    if not os.path.exists(os.path.join(WEIGHTS, name + ".mgw")):
+        pytest.skip(f"{name}.mgw not extracted (python -m gnina_amd.build where the reference is present)")
+    sig = f"sig{int(ALL[name + '/sig'])}"
+    s = capi.Scorer([name])
+    s.set_receptor(ALL[sig + "/rec_xyz"], ALL[sig + "/rec_smt"])
+    out = s.score_batch(ALL[sig + "/poses"], ALL[sig + "/lig_smt"])
+    assert np.abs(out["pose"] - ALL[name + "/pose"]).max() < 1e-4
+    assert np.abs(out["affinity"] - ALL[name + "/affinity"]).max() < 1e-4
+    assert np.abs(out["loss"] - ALL[name + "/loss"]).max() < 1e-3 * max(1.0, float(np.abs(ALL[name + "/loss"]).max()))
+
+
+def _rot_matrix(q):
+    a, b, c, d = q
+    return np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                     [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                     [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+
+
+def test_rotated_scoring_equals_scoring_the_rotated_complex(capi, CG):
+    """TorchModel::forward(rotate = true): libmolgrid's Transform turns receptor and ligand about the grid centre
+    before GridMaker::forward (torch_model.cpp:170-173).  mi_scorer_set_rotations must give what scoring the
+    explicitly rotated atoms gives (grid, scores), and the atom gradients must come back in the unrotated frame."""
+    name = "default2017"
+    rec_xyz, rec_smt = CG[name + "/rec_xyz"], CG[name + "/rec_smt"]
+    poses, lig_smt = CG[name + "/poses"], CG[name + "/lig_smt"]
+    B = len(poses)
+    rng = np.random.RandomState(5)
+    q = rng.normal(size=(B, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = (1, 0, 0, 0)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    centers = poses.mean(1).astype(np.float32)        # lig.center() of the unrotated ligand
+    s.set_rotations(q)
+    out = s.score_batch(poses, lig_smt, centers=centers)
+    plain = s.score_batch(poses, lig_smt, centers=centers)            # rotations are consumed by one call
+    assert abs(out["pose"][0] - plain["pose"][0]) < 1e-6 and np.abs(out["pose"][1:] - plain["pose"][1:]).max() > 1e-5
+    s.set_rotations(q)
+    g_rot = s.score_grad(poses, lig_smt, centers=centers)
+    for b in range(B):
+        R = _rot_matrix(q[b])
+        c = centers[b].astype(np.float64)
+        s2 = capi.Scorer([name])
+        s2.set_receptor(((rec_xyz - c) @ R.T + c).astype(np.float32), rec_smt)
+        lig_r = ((poses[b] - c) @ R.T + c).astype(np.float32)
+        o2 = s2.score_grad(lig_r[None], lig_smt, centers=centers[b:b + 1])
+        assert abs(out["pose"][b] - o2["pose"][0]) < 2e-5 and abs(out["affinity"][b] - o2["affinity"][0]) < 2e-4
+        back = o2["lig_grad"][0] @ R                                   # R^T g, row-vector form
+        scale = max(1e-6, np.abs(back).max())
+        assert np.abs(g_rot["lig_grad"][b] - back).max() < 2e-3 * scale
+    with pytest.raises(capi.MiGninaError):
+        s.set_rotations(q * 2)                                         # not unit length
+    s.set_rotations(q[:2])
+    with pytest.raises(capi.MiGninaError):
+        s.score_batch(poses, lig_smt)                                  # pose count mismatch
+    assert np.allclose(s.score_batch(poses, lig_smt, centers=centers)["pose"], plain["pose"], atol=1e-6)

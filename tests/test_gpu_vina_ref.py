@@ -130,3 +130,23 @@ def test_bfgs_against_the_references_quasi_newton(capi, name):
         inside = np.isfinite(e0) & (np.abs(e0) < 1e4)
         assert abs(np.median(e[inside]) - np.median(e0[inside])) <= 0.2 * abs(np.median(e0[inside])) + 1.0
         assert (e <= v.eval_batch(confs, cap)[0] + 1e-4 * np.abs(e)).all()       # never worse than the start
+
+
+@pytest.mark.parametrize("name", CASES[:2])
+def test_monte_carlo_follows_the_references_chains(capi, name):
+    """monte_carlo::operator() on the device draws from the same mt19937 stream (and the same restated Boost
+    distributions) as the reference in oracle/_ref: a 1-step chain -- random start, one mutation, BFGS with the hunt
+    cap, Metropolis on what `model` holds, BFGS with the full cap -- must land where the reference's lands for most
+    seeds; 3-step chains still for many (every step doubles the chances of a last-bit difference flipping a line
+    search).  The CPU restatement matches the reference bit for bit over thousands of steps (test_ref_vina.py)."""
+    P = name + "/"
+    v, lig = engine(capi, name)
+    mi = int(G[P + "max_iters"])
+    seeds = np.arange(100, 132, dtype=np.uint64)
+    for steps, need in ((1, 24), (3, 14)):
+        n, e, cf, xyz, ev = v.mc_batch(seeds, list(G[P + "begin"]), list(G[P + "end"]), capi.McParams.default(steps, mi, 20))
+        e0, c0 = G[P + f"mcshort/{steps}/e0"], G[P + f"mcshort/{steps}/conf0"]
+        same = sum(abs(e[b, 0] - e0[b]) <= 1e-3 * max(1.0, abs(e0[b])) and np.abs(cf[b, 0] - c0[b]).max() < 1e-2
+                   for b in range(len(seeds)))
+        assert same >= need, (name, steps, same)
+        assert (n >= 1).all()
