@@ -59,8 +59,10 @@ def build_host(force=False, verbose=False):
     build(force=force, verbose=verbose)
     root = os.path.dirname(HERE)
     exe = os.path.join(LIBDIR, "test_host_scorer")
-    srcs = [os.path.join(root, "tests", "cpp", "test_host_scorer.cpp"), os.path.join(HERE, "host", "hip_cnn_scorer.cpp")]
-    deps = srcs + [os.path.join(HERE, "host", "hip_cnn_scorer.h"), os.path.join(HERE, "host", "gnina_types.h"), LIB]
+    srcs = [os.path.join(root, "tests", "cpp", "test_host_scorer.cpp"), os.path.join(HERE, "host", "hip_cnn_scorer.cpp"),
+            os.path.join(HERE, "host", "hip_cache.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "hip_cnn_scorer.h"), os.path.join(HERE, "host", "hip_cache.h"),
+                   os.path.join(HERE, "host", "gnina_types.h"), LIB]
     if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", exe] + srcs + ["-L" + LIBDIR, "-lmi_gnina",
                                                                       "-Wl,-rpath,$ORIGIN"]

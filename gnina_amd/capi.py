@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -140,6 +140,7 @@ def lib():
         L.mi_scorer_set_precision.argtypes = [vp, C.c_int]
         L.mi_scorer_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.mi_vina_coords_batch.argtypes = [vp, vp, C.c_int, vp]
+        L.mi_vina_cache_eval_coords.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
         L.mi_cnn_eval_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]
         L.mi_cnn_refine_batch.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
         L.mi_scorer_score_flex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -657,6 +658,18 @@ class Vina:
         tries = np.empty(B, dtype=np.int32)
         check(lib().mi_vina_refine_batch(self.handle, _ptr(confs), B, _ptr(vv), int(max_iters), _ptr(e), _ptr(tries)))
         return e, confs, tries
+
+    def cache_eval_coords(self, coords, smt, v=1000.0, deriv=True):
+        """igrid::eval / eval_deriv of the cache on coordinates [B][n][3] -> (energy [B], minus_forces [B][n][3] | None)"""
+        coords = _f32(coords)
+        if coords.ndim == 2:
+            coords = coords[None]
+        B, n = coords.shape[0], coords.shape[1]
+        smt = _i32(smt)
+        e = np.empty(B, dtype=np.float32)
+        f = np.empty((B, n, 3), dtype=np.float32) if deriv else None
+        check(lib().mi_vina_cache_eval_coords(self.handle, _ptr(coords), _ptr(smt), n, B, float(v), _ptr(e), _ptr(f)))
+        return e, f
 
     def coords_batch(self, confs):
         """model::set(conf): coords [B, n_atoms, 3]"""

@@ -128,6 +128,8 @@ void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float
                           float *energy, float *change, hipStream_t s);
 // in-place BFGS (quasi_newton, bfgs.h:357-502 with fast_line_search); evals [B] optional
 size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage, int waves_per_chain);
+void launch_vina_cache_coords(const VinaEnv &env, const float *coords, const int *smt, int n_atoms, int B, float v,
+                              float *energy, float *minus_forces, hipStream_t s);
 int vina_mc_team(int B);  // waves per chain the Monte-Carlo kernel uses for B chains
 // `lig` sizes the LDS workspace (screen mode: counts = the maxima over the set, pointers unused)
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);

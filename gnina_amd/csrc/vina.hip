@@ -1006,6 +1006,49 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cache::eval / cache::eval_deriv (cache.cpp:50-83) on given coordinates: the igrid seam itself (igrid.h:32-46) for
+// callers that hold a `model` with coordinates rather than a conformation.  One wavefront per coordinate set;
+// per-atom energies are added in atom order like the reference's loop.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vina_cache_coords_kernel(VinaEnv env, const float *coords, const int *smt, int n_atoms,
+                                                               float v, float *energy, float *minus_forces) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float *xyz = coords + (size_t)b * n_atoms * 3;
+  for (int i = lane; i < n_atoms; i += 64) {
+    const int t = smt[i];
+    float e = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
+    if (t > 1 && t < kVinaTypes && env.grid_off[t] >= 0) {
+      const float *g = env.grid_data + env.grid_off[t];
+      if (minus_forces)
+        e = grid_evaluate<true>(env.geom, g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], env.slope, v, fx, fy, fz);
+      else
+        e = grid_evaluate<false>(env.geom, g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], env.slope, v, fx, fy, fz);
+    }
+    lds[i] = e;
+    if (minus_forces) {
+      float *o = minus_forces + ((size_t)b * n_atoms + i) * 3;
+      o[0] = fx, o[1] = fy, o[2] = fz;
+    }
+  }
+  wave_sync();
+  if (lane == 0) {
+    float e = 0.f;
+    for (int i = 0; i < n_atoms; i++) {
+      const int t = smt[i];
+      if (t > 1 && t < kVinaTypes && env.grid_off[t] >= 0) e += lds[i];
+    }
+    energy[b] = e;
+  }
+}
+
+void launch_vina_cache_coords(const VinaEnv &env, const float *coords, const int *smt, int n_atoms, int B, float v,
+                              float *energy, float *minus_forces, hipStream_t s) {
+  hipLaunchKernelGGL(vina_cache_coords_kernel, dim3(B), dim3(64), (size_t)n_atoms * sizeof(float), s, env, coords, smt,
+                     n_atoms, v, energy, minus_forces);
+}
+
 void launch_vina_coords(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float *coords,
                         hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);

@@ -98,7 +98,7 @@ struct Vina {
   // scratch
   DevBuf<float> d_confs, d_energy, d_change, d_coords;
   DevBuf<float> d_ext_forces, d_ext_e, d_ext_centers;
-  DevBuf<int> d_evals, d_out_n;
+  DevBuf<int> d_evals, d_out_n, d_smt_in;
   DevBuf<unsigned long long> d_seeds;
   DevBuf<unsigned> d_mt;
   DevBuf<float> d_mc_e, d_mc_conf, d_mc_xyz, d_sc_e, d_sc_conf, d_sc_xyz;
@@ -835,6 +835,33 @@ mi_status mi_vina_refine_batch(mi_vina *vv, float *confs, int B, const float *v3
 // CNN in the optimisation loop: non_cache_cnn as quasi_newton's igrid (non_cache_cnn.cpp:33-54,79-169;
 // selected at main.cpp:475-476 for --cnn_scoring refinement and above).
 // ---------------------------------------------------------------------------------------------
+// igrid::eval / eval_deriv of the cache igrid on coordinates (cache.cpp:50-83), see mi_gnina.h
+mi_status mi_vina_cache_eval_coords(mi_vina *vv, const float *coords, const int32_t *smt, int n_atoms, int B, float v1,
+                                    float *energy, float *minus_forces) {
+  VTRY
+  MIG_CHECK(vv && coords && smt && energy && n_atoms >= 0 && n_atoms <= 16384 && B >= 0, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache, 4, "build the cache first (mi_vina_build_cache)");
+  if (B == 0 || n_atoms == 0) {
+    for (int b = 0; b < B; b++) energy[b] = 0.f;
+    return MI_OK;
+  }
+  v.d_coords.upload(coords, (size_t)B * n_atoms * 3, v.stream);
+  v.d_smt_in.upload(smt, n_atoms, v.stream);
+  v.d_energy.ensure(B);
+  if (minus_forces) v.d_ext_forces.ensure((size_t)B * n_atoms * 3);
+  launch_vina_cache_coords(make_env(v), v.d_coords.p, v.d_smt_in.p, n_atoms, B, v1, v.d_energy.p,
+                           minus_forces ? v.d_ext_forces.p : nullptr, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(energy, v.d_energy.p, B * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (minus_forces)
+    MIG_HIP(hipMemcpyAsync(minus_forces, v.d_ext_forces.p, (size_t)B * n_atoms * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                           v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
 mi_status mi_vina_coords_batch(mi_vina *vv, const float *confs, int B, float *coords) {
   VTRY
   MIG_CHECK(vv && confs && coords && B >= 0, 1, "bad arguments");

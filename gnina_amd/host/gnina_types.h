@@ -92,8 +92,29 @@ struct cnn_options {            // user_opts.h:36-64 (fields the scorer uses)
   unsigned seed = 0;
 };
 
+// igrid.h:32-46 (the Vina / Monte-Carlo seam) and the few types its users touch
+struct grid {                   // grid.h: the optional user grid; never initialised here
+  bool initialized() const { return false; }
+};
+struct igrid {
+  virtual ~igrid() {}
+  virtual fl eval(model &m, fl v) const = 0;                               // needs m.coords
+  virtual fl eval_deriv(model &m, fl v, const grid &user_grid) const = 0;  // needs m.coords, sets m.minus_forces
+  virtual bool skip_interacting_pairs() const { return false; }
+  virtual void adjust_center(model &m) {}
+  virtual vec get_center() const { return vec(0, 0, 0); }
+  virtual bool move_receptor() { return false; }
+};
+struct minimization_params {    // common.h:50-61
+  unsigned maxiters = 0;
+};
+
 struct usage_error : std::runtime_error { using std::runtime_error::runtime_error; };      // common.h
-struct internal_error : std::runtime_error { using std::runtime_error::runtime_error; };
+struct internal_error : std::runtime_error {   // common.h:270-274: (file, line); adapters put their message in `file`
+  std::string file;
+  unsigned line;
+  internal_error(const std::string &file_, unsigned line_) : std::runtime_error(file_), file(file_), line(line_) {}
+};
 
 class DLScorer {                // dl_scorer.h:23-66, signatures verbatim
  protected:

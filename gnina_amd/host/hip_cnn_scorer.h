@@ -8,6 +8,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -22,12 +23,26 @@ std::string builtin_model_dir();
 // names available as built-ins (file stems with '.' -> '_', make_model_cpp.py:27-29)
 std::vector<std::string> builtin_model_names();
 
+// libmolgrid's Transform(center, 0, random_rotate = true) (called at torch_model.cpp:170): a uniformly random unit
+// quaternion by Shoemake's method from libmolgrid::random_engine, a std::default_random_engine that
+// CNNTorchScorer::score re-seeds with cnn_options::seed for every model (cnn_torch_scorer.cpp:126-127).  libmolgrid is
+// not part of the reference tree (fetched at build time): the formula below is restated from its published
+// source and the stream is "unpinned"; the averaging arithmetic around it follows cnn_torch_scorer.cpp:117-193 exactly.
+struct RotationStream {
+  std::default_random_engine engine;
+  void seed(unsigned s) { engine.seed(s); }
+  void next(float q[4]);   // (a, b, c, d) of a + bi + cj + dk
+};
+
 class HipTorchModel {
   mi_model *model_ = nullptr;
   mi_scorer *scorer_ = nullptr;          // single-model scorer used by forward()
   const void *rec_key_ = nullptr;        // receptor identity cache (data pointer + size)
   size_t rec_n_ = 0;
+  bool all_rows_flex_ = false;           // receptor gradient requested: every receptor row is declared movable
   float res_ = 0.5f, dim_ = 23.5f;
+  std::vector<gfloat3> gradient_rec, gradient_lig;   // torch_model.h:26
+  RotationStream rot_;
 
  public:
   HipTorchModel(const std::string &path, const std::string &name);
@@ -35,11 +50,17 @@ class HipTorchModel {
   HipTorchModel(const HipTorchModel &) = delete;
   HipTorchModel &operator=(const HipTorchModel &) = delete;
 
-  // TorchModel::forward (torch_model.h:34-36): returns {pose, affinity, loss}.
-  // rotate / compute_gradient are not supported yet and throw internal_error when set.
+  // TorchModel::forward (torch_model.h:34-36, torch_model.cpp:153-224): returns {pose, affinity, loss}.
+  // rotate: the atoms are turned about the grid centre by the next quaternion of the rotation stream (seed_rotations)
+  // before voxelization.  compute_gradient: d loss / d coordinates of every ligand and receptor atom is kept for
+  // getLigandGradient / getReceptorGradient (in the unrotated frame).
   std::vector<float> forward(const std::vector<float3> &rec_coords, const std::vector<smt> &rec_types,
                              const std::vector<float3> &lig_coords, const std::vector<smt> &lig_types,
                              const vec &center, bool rotate, bool compute_gradient);
+  // "assumes forward was called with compute_gradient" (torch_model.h:38-40)
+  void getLigandGradient(std::vector<gfloat3> &grad);
+  void getReceptorGradient(std::vector<gfloat3> &grad);
+  void seed_rotations(unsigned seed) { rot_.seed(seed); }   // libmolgrid::random_engine.seed (cnn_torch_scorer.cpp:127)
   float get_grid_dim() const { return dim_; }
   float get_grid_res() const { return res_; }
   mi_model *handle() const { return model_; }

@@ -328,6 +328,12 @@ typedef struct mi_cnn_box {
   float empirical_weight;        /* default 1 */
   float v;                       /* authentic_v[1] = 1000 */
 } mi_cnn_box;
+/* The `igrid` seam itself (igrid.h:32-46) for the cache igrid: cache::eval (minus_forces = NULL) / cache::eval_deriv
+ * (cache.cpp:50-83) on B coordinate sets coords [B][n_atoms][3] of atoms with smina types smt [n_atoms] -- what a caller
+ * holding a gnina `model` passes (m.coords, movable atoms).  energy [B]; minus_forces [B][n_atoms][3] receives
+ * what cache::eval_deriv leaves in model::minus_forces (0 for hydrogens).  v = the curl cap (v[1]).  Host pointers. */
+mi_status mi_vina_cache_eval_coords(mi_vina *, const float *coords, const int32_t *smt, int n_atoms, int B, float v,
+                                    float *energy, float *minus_forces);
 /* model::set(conf) for B conformations: coords [B][n_atoms][3]. */
 mi_status mi_vina_coords_batch(mi_vina *, const float *confs, int B, float *coords);
 /* non_cache_cnn::eval_deriv (with_deriv = 1: energy [B], change [B][6+T]) / ::eval (0: energy only). */

@@ -26,6 +26,9 @@ def build(force=False):
     if force:
         subprocess.run(cmd + ["clean"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    # the igrid drop-in test links the reference's objects with libmi_gnina.so: only once that exists
+    if os.path.exists(os.path.join(os.path.dirname(HERE), "gnina_amd", "lib", "libmi_gnina.so")):
+        subprocess.run(cmd + ["dropin"], check=True, stdout=subprocess.DEVNULL)
     return LIB
 
 

@@ -93,6 +93,79 @@ int main(int argc, char **argv) {
     return 0;
   }
 
+  if (argc > 3 && std::string(argv[3]) == "--torchmodel") {
+    // the inner seam (torch_model.h:32-46): forward with compute_gradient, the gradient accessors, rotate
+    const std::string name = opts.cnn_model_names.at(0);
+    gnina_amd::HipTorchModel tm(std::string(argv[2]) + "/" + name + ".mgw", name);
+    std::vector<float3> rc(n_rec), lc(n_lig);
+    std::vector<smt> rt(rec_smt.begin(), rec_smt.end()), ltypes(lig_smt.begin(), lig_smt.end());
+    for (int i = 0; i < n_rec; i++) rc[i] = float3{rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2]};
+    for (int i = 0; i < n_lig; i++) lc[i] = float3{poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]};
+    const vec nan_center(NAN, NAN, NAN);
+    std::vector<float> o = tm.forward(rc, rt, lc, ltypes, nan_center, false, false);
+    std::printf("tm_forward %.9g %.9g %.9g\n", o[0], o[1], o[2]);
+    o = tm.forward(rc, rt, lc, ltypes, nan_center, false, true);
+    std::vector<gfloat3> gl, gr;
+    tm.getLigandGradient(gl);
+    tm.getReceptorGradient(gr);
+    std::printf("tm_grad %.9g %.9g %.9g n_lig %zu n_rec %zu\n", o[0], o[1], o[2], gl.size(), gr.size());
+    for (size_t i = 0; i < gl.size(); i++) std::printf("gl %zu %.9g %.9g %.9g\n", i, gl[i].x, gl[i].y, gl[i].z);
+    int shown = 0;
+    for (size_t i = 0; i < gr.size() && shown < 40; i++)
+      if (gr[i].x != 0 || gr[i].y != 0 || gr[i].z != 0) {
+        std::printf("gr %zu %.9g %.9g %.9g\n", i, gr[i].x, gr[i].y, gr[i].z);
+        shown++;
+      }
+    tm.seed_rotations(5);
+    o = tm.forward(rc, rt, lc, ltypes, nan_center, true, false);
+    gnina_amd::RotationStream rs;
+    rs.seed(5);
+    float q[4];
+    rs.next(q);
+    std::printf("tm_rotated %.9g %.9g %.9g quat %.9g %.9g %.9g %.9g\n", o[0], o[1], o[2], q[0], q[1], q[2], q[3]);
+    return 0;
+  }
+
+  if (argc > 5 && std::string(argv[3]) == "--rotations") {
+    // --cnn_rotation N with --seed S (cnn_torch_scorer.cpp:117-193): averaged score / affinity / variance / forces
+    opts.cnn_rotations = (unsigned)std::atoi(argv[4]);
+    opts.seed = (unsigned)std::atoi(argv[5]);
+    gnina_amd::HipCNNScorer scorer(opts);
+    model m;
+    for (int i = 0; i < n_rec; i++) {
+      atom a;
+      a.sm = rec_smt[i];
+      a.coords = vec(rec_xyz[3 * i], rec_xyz[3 * i + 1], rec_xyz[3 * i + 2]);
+      m.grid_atoms.push_back(a);
+    }
+    for (int i = 0; i < n_lig; i++) {
+      atom a;
+      a.sm = lig_smt[i];
+      m.atoms.push_back(a);
+      m.coords.push_back(vec(poses[(size_t)i * 3], poses[(size_t)i * 3 + 1], poses[(size_t)i * 3 + 2]));
+    }
+    m.m_num_movable_atoms = n_lig;
+    m.ligands.resize(1);
+    m.ligands[0].node.begin = 0;
+    m.ligands[0].node.end = n_lig;
+    gnina_amd::RotationStream rs;
+    rs.seed(opts.seed);
+    std::printf("quat 0 1 0 0 0\n");
+    for (unsigned r = 1; r < opts.cnn_rotations; r++) {
+      float q[4];
+      rs.next(q);
+      std::printf("quat %u %.9g %.9g %.9g %.9g\n", r, q[0], q[1], q[2], q[3]);
+    }
+    float aff, loss, var;
+    float s0 = scorer.score(m, true, aff, loss, var);
+    std::printf("rot_score %.9g %.9g %.9g %.9g\n", s0, aff, loss, var);
+    for (int i = 0; i < n_lig; i++)
+      std::printf("force %d %.9g %.9g %.9g\n", i, m.minus_forces[i][0], m.minus_forces[i][1], m.minus_forces[i][2]);
+    float s1 = scorer.score(m, false, aff, loss, var);   // same seed -> same orientations -> same numbers
+    std::printf("rot_again %.9g %.9g %.9g\n", s1, aff, var);
+    return 0;
+  }
+
   if (argc > 3 && std::string(argv[3]) == "--cov") {
     // covalent docking: no ligand in the model, the atoms flagged `iscov` are what the CNN sees as the ligand
     gnina_amd::HipCNNScorer scorer(opts);

@@ -115,3 +115,147 @@ def test_dlscorer_adapter_covalent_branch(exe, golden_dir, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     cov = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("cov")][0]
     assert abs(float(cov[1]) - G[name + "/pose"][0]) < 1e-4 and abs(float(cov[2]) - G[name + "/affinity"][0]) < 1e-4
+
+
+def _write_atoms(path, rec_xyz, rec_smt, lig_smt, poses, names):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", len(rec_smt), len(lig_smt), len(poses), len(names)))
+        for n in names:
+            f.write(struct.pack("<i", len(n)) + n.encode())
+        f.write(rec_xyz.astype("<f4").tobytes())
+        f.write(rec_smt.astype("<i4").tobytes())
+        f.write(lig_smt.astype("<i4").tobytes())
+        f.write(poses.astype("<f4").tobytes())
+
+
+@pytest.mark.gpu
+def test_torchmodel_seam_gradients_and_rotate(exe, golden_dir, tmp_path):
+    """HipTorchModel (torch_model.h:32-46): forward(compute_gradient) + getLigandGradient / getReceptorGradient for
+    EVERY receptor atom, and forward(rotate) with a seeded rotation stream."""
+    from gnina_amd import capi
+    G = np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    path = tmp_path / "atoms.bin"
+    _write_atoms(path, rec_xyz, rec_smt, lig_smt, poses[:1], [name])
+    r = subprocess.run([exe, str(path), WEIGHTS, "--torchmodel"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n")]
+    fwd = [l for l in lines if l[0] == "tm_forward"][0]
+    assert abs(float(fwd[1]) - G[name + "/pose"][0]) < 1e-4 and abs(float(fwd[2]) - G[name + "/affinity"][0]) < 1e-4
+    grad = [l for l in lines if l[0] == "tm_grad"][0]
+    assert float(grad[1]) == float(fwd[1]) and int(grad[5]) == len(lig_smt) and int(grad[7]) == len(rec_smt)
+    capi.init(0)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    ref = s.score_grad(poses[:1], lig_smt)
+    gl = np.array([[float(x) for x in l[2:5]] for l in lines if l[0] == "gl"])
+    assert np.abs(gl - ref["lig_grad"][0]).max() <= 1e-6 * max(1.0, np.abs(gl).max())
+    s.set_flex(np.arange(len(rec_smt)))
+    full = s.score_flex(poses[:1], lig_smt, rec_xyz[None])
+    gr = {int(l[1]): [float(x) for x in l[2:5]] for l in lines if l[0] == "gr"}
+    assert len(gr) > 10
+    for i, g in gr.items():
+        assert np.abs(np.array(g) - full["flex_grad"][0, i]).max() <= 1e-6 * max(1.0, np.abs(full["flex_grad"]).max())
+    rot = [l for l in lines if l[0] == "tm_rotated"][0]
+    q = np.array([float(x) for x in rot[5:9]], dtype=np.float32)
+    assert abs(np.linalg.norm(q) - 1) < 1e-5
+    s2 = capi.Scorer([name])
+    s2.set_receptor(rec_xyz, rec_smt)
+    s2.set_rotations(q[None])
+    o = s2.score_batch(poses[:1], lig_smt)
+    assert abs(float(rot[1]) - o["pose"][0]) < 1e-6 and abs(float(rot[1]) - float(fwd[1])) > 1e-6
+
+
+@pytest.mark.gpu
+def test_cnn_rotations_average_like_the_reference(exe, golden_dir, tmp_path):
+    """--cnn_rotation N (cnn_torch_scorer.cpp:117-193): mean score / affinity / loss over models x orientations,
+    population variance of all affinities, mean forces; orientation 0 is the pose as it is."""
+    from gnina_amd import capi
+    G = np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+    names = ["crossdock_default2018", "crossdock_default2018_KD_4"]
+    base = names[0]
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{base}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    path = tmp_path / "atoms.bin"
+    _write_atoms(path, rec_xyz, rec_smt, lig_smt, poses[:1], names)
+    n_rot = 5
+    r = subprocess.run([exe, str(path), WEIGHTS, "--rotations", str(n_rot), "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n")]
+    quats = np.array([[float(x) for x in l[2:6]] for l in lines if l[0] == "quat"], dtype=np.float32)
+    assert quats.shape == (n_rot, 4) and list(quats[0]) == [1, 0, 0, 0]
+    score, aff, loss, var = (float(x) for x in [l for l in lines if l[0] == "rot_score"][0][1:5])
+    capi.init(0)
+    per_model = []
+    grads = []
+    for n in names:
+        s = capi.Scorer([n])
+        s.set_receptor(rec_xyz, rec_smt)
+        s.set_rotations(quats)
+        o = s.score_grad(np.repeat(poses[:1], n_rot, 0), lig_smt)
+        per_model.append(o)
+        grads.append(o["lig_grad"])
+    p = np.stack([o["pose"] for o in per_model])          # [model][rotation]
+    a = np.stack([o["affinity"] for o in per_model])
+    assert abs(score - p.astype(np.float64).mean()) < 2e-6 and abs(aff - a.mean()) < 2e-5
+    assert abs(var - a.var()) < 1e-4
+    forces = np.array([[float(x) for x in l[2:5]] for l in lines if l[0] == "force"])
+    want = np.mean(grads, axis=(0, 1))
+    heavy = lig_smt > 1
+    assert np.abs(forces[heavy] - want[heavy]).max() <= 2e-3 * max(1e-6, np.abs(want).max())
+    again = [l for l in lines if l[0] == "rot_again"][0]
+    assert float(again[1]) == score and abs(float(again[3]) - var) < 1e-7
+    # rotation 0 alone is the plain score
+    s = capi.Scorer(names)
+    s.set_receptor(rec_xyz, rec_smt)
+    assert abs(s.score_batch(poses[:1], lig_smt)["pose"][0] - p[:, 0].mean()) < 1e-6
+
+
+def _synthetic_pdbqt_pair(tmp_path):
+    """A receptor of random typed atoms around a pocket and a flexible chain ligand, as PDBQT files."""
+    from tests import ref_cases as RC
+    rng = np.random.RandomState(3)
+    ad = ["C", "A", "N", "NA", "OA", "S", "HD"]
+    lines = []
+    lig_text = RC.long_chain_ligand(n=10, origin=(0.0, 0.0, 0.0))
+    k = 0
+    while k < 900:
+        p = rng.uniform(-16, 22, 3)
+        if abs(p[1]) < 3.0 and abs(p[2]) < 3.0 and -3 < p[0] < 15:      # keep a channel for the ligand
+            continue
+        lines.append(RC.atom_line(k + 1, "X", *p, ad[rng.randint(len(ad))], res="REC", resnum=1 + k // 8))
+        k += 1
+    rec = tmp_path / "rec.pdbqt"
+    lig = tmp_path / "lig.pdbqt"
+    rec.write_text("\n".join(lines) + "\n")
+    lig.write_text(lig_text)
+    return str(rec), str(lig)
+
+
+@pytest.mark.gpu
+def test_reference_code_runs_on_the_hip_igrid(tmp_path):
+    """oracle/_ref/test_igrid_dropin: gnina's OWN model::eval_deriv, quasi_newton (CPU bfgs<>) and monte_carlo with
+    HipCache as their igrid, next to the same calls on gnina's cache; HipQuasiNewton's device dispatch."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_igrid_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_igrid_dropin is built where /root/reference exists (make -f oracle/Makefile.ref dropin)")
+    rec, lig = _synthetic_pdbqt_pair(tmp_path)
+    r = subprocess.run([exe, rec, lig], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n")]
+    ev = [l for l in lines if l[0] == "eval_deriv"]
+    assert len(ev) == 4
+    for l in ev:
+        e1, e2, dch, scale, i1, i2 = float(l[2]), float(l[3]), float(l[5]), float(l[7]), float(l[9]), float(l[10])
+        assert abs(e1 - e2) <= 1e-4 * max(1.0, abs(e1)) and dch <= 1e-3 * max(1.0, scale)
+        assert abs(i1 - i2) <= 1e-4 * max(1.0, abs(i1))
+    cpu = [l for l in lines if l[0] == "cpu_bfgs_on"]
+    close = sum(abs(float(l[3]) - float(l[5])) <= 0.05 * abs(float(l[3])) + 0.5 for l in cpu)
+    assert len(cpu) == 3 and close >= 2                      # gnina's bfgs<> reaches the same minima on either igrid
+    dev = [l for l in lines if l[0] == "device_bfgs"]
+    assert all(l[3] == "1" for l in dev) and all(np.isfinite(float(l[5])) for l in dev)
+    assert abs(float(dev[0][5]) - float(cpu[0][3])) <= 0.05 * abs(float(cpu[0][3])) + 0.5
+    assert all(l[2] == "0" for l in lines if l[0] == "device_bfgs_on_ref_cache")   # not a HipCache: caller's CPU path
+    mc = {l[1]: l for l in lines if l[0] == "mc_on"}
+    assert int(mc["ref_cache"][3]) >= 1 and int(mc["hip_cache"][3]) >= 1
+    assert np.isfinite(float(mc["hip_cache"][5]))
