@@ -318,10 +318,18 @@ def main():
         scorer.set_chunk(args.chunk)
     rec_types = synth.mapped_types(model.chan_of_smt(False))
     lig_types = synth.mapped_types(model.chan_of_smt(True))
-    # every rank has the same receptor (replicated) and its own shard of poses
+    # every rank has the same receptor (replicated) and its own shard of poses: rank 0 makes the receptor
+    # and the ligand and hands them out with one broadcast over RCCL, like a screening driver would
+    from gnina_amd import shard
     rng0 = np.random.RandomState(0)
-    rec_xyz, rec_smt = synth.make_receptor(rng0, args.n_rec, rec_types)
-    lig_xyz, lig_smt = synth.make_ligand(rng0, args.n_lig, lig_types)
+    if rank == 0:
+        rec_xyz, rec_smt = synth.make_receptor(rng0, args.n_rec, rec_types)
+        lig_xyz, lig_smt = synth.make_ligand(rng0, args.n_lig, lig_types)
+        blob = [rec_xyz, rec_smt, lig_xyz, lig_smt]
+    else:
+        blob = None
+    rec_xyz, rec_smt, lig_xyz, lig_smt = shard.broadcast_arrays(blob, dist, dev)
+    bcast_bytes = int(rec_xyz.nbytes + rec_smt.nbytes + lig_xyz.nbytes + lig_smt.nbytes)
     poses = synth.make_poses(np.random.RandomState(1000 + rank), lig_xyz, args.batch)
     scorer.set_receptor(rec_xyz, rec_smt)
 
@@ -363,6 +371,25 @@ def main():
     prof = scorer.profile()
     scorer.enable_profile(False)
     gpu_scores = d_out.cpu().numpy()
+
+    # outside the timed region: the screening pattern end to end on a fixed pose set -- contiguous pose shards scored
+    # by their ranks, one all_gather of 4 floats per pose over RCCL (shard.score_sharded) -- checked on rank 0 against
+    # scoring the whole set alone: the same bits, in pose order
+    rccl = None
+    if dist is not None:
+        vposes = synth.make_poses(np.random.RandomState(4242), lig_xyz, 256 * world + 3)
+
+        def score_np(p):
+            o = scorer.score_batch(p, lig_smt)
+            return np.stack([o["pose"], o["affinity"], o["loss"], o["variance"]], 1)
+
+        gathered = shard.score_sharded(score_np, vposes, dist, dev)
+        if rank == 0:
+            alone = score_np(vposes)
+            rccl = {"ranks": world, "backend": dist.get_backend(), "receptor_broadcast_bytes": bcast_bytes,
+                    "sharded_poses": int(len(vposes)), "allgather_equals_single_rank": bool(np.array_equal(gathered, alone))}
+            assert rccl["allgather_equals_single_rank"], "sharded scores differ from single-rank scores"
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -431,6 +458,8 @@ def main():
             "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
             "dominant_kernel_overall": dom["kernel"],
         }
+        if rccl is not None:
+            res["rccl"] = rccl
         if world == 1:
             res["also"] = other_models(args, capi, synth, torch, dev)
             res["roofline"]["dense_no_skip"] = conv1_dense(args, scorer, step, max(3, min(args.steps, 10)))
