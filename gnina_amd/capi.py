@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -39,7 +39,9 @@ class LigandDesc(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("smt", C.c_void_p), ("local_xyz", C.c_void_p), ("n_nodes", C.c_int32),
                 ("node_parent", C.c_void_p), ("node_atom_begin", C.c_void_p), ("node_atom_end", C.c_void_p),
                 ("node_rel_origin", C.c_void_p), ("node_rel_axis", C.c_void_p), ("n_pairs", C.c_int32),
-                ("pairs", C.c_void_p)]
+                ("pairs", C.c_void_p),
+                # flexible residues: zero / NULL for a plain ligand
+                ("n_movable", C.c_int32), ("pair_kind", C.c_void_p), ("lig_begin", C.c_int32), ("lig_end", C.c_int32)]
 
 
 class CnnBox(C.Structure):
@@ -127,6 +129,12 @@ def lib():
         L.mi_pdbqt_read_receptor_flex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int),
                                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_pdbqt_read_receptor_flex.restype = C.c_int
+        L.mi_pdbqt_model_open.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.mi_pdbqt_model_open.restype = vp
+        L.mi_pdbqt_model_close.argtypes = [vp]
+        L.mi_pdbqt_model_close.restype = None
+        L.mi_pdbqt_model_sizes.argtypes = [vp, vp]
+        L.mi_pdbqt_model_desc.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.mi_pdbqt_ligand_open.argtypes = [C.c_char_p, C.c_int]
         L.mi_pdbqt_ligand_open.restype = vp
         L.mi_pdbqt_ligand_close.argtypes = [vp]
@@ -314,6 +322,43 @@ def read_pdbqt_ligand(path_or_text, is_text=False):
                 "num_tors": _ligand_num_tors(h)}
     finally:
         lib().mi_pdbqt_ligand_close(h)
+
+
+def read_pdbqt_model(rigid, flex, ligand, is_text=False):
+    """rigid receptor + flexible residues + ligand (.pdbqt) -> (rec_xyz, rec_smt, desc): desc is a dict in the layout
+    of read_pdbqt_ligand plus n_movable / pair_kind / lig_begin / lig_end -- atoms [flex movable | ligand | inflex],
+    conf0 [7 + T_ligand + T_flex] -- what Vina.set_ligand takes for a search with flexible side chains."""
+    h = lib().mi_pdbqt_model_open(rigid.encode(), flex.encode(), ligand.encode(), 1 if is_text else 0)
+    if not h:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    try:
+        sz = np.zeros(8, dtype=np.int32)
+        check(lib().mi_pdbqt_model_sizes(h, _ptr(sz)))
+        na, nn, npairs, nrig, nfm, ninf, tl, tf = (int(x) for x in sz)
+        d = LigandDesc()
+        pxyz, pconf, prx = (C.POINTER(C.c_float)() for _ in range(3))
+        prs = C.POINTER(C.c_int32)()
+        nt = C.c_float()
+        check(lib().mi_pdbqt_model_desc(h, C.byref(d), C.byref(pxyz), C.byref(pconf), C.byref(prx), C.byref(prs), C.byref(nt)))
+
+        def arr(p, shape, dt):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.zeros(shape, dtype=dt)
+            ct = C.c_float if dt == np.float32 else C.c_int32
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).reshape(shape).astype(dt, copy=True)
+
+        desc = {"smt": arr(d.smt, (na,), np.int32), "local_xyz": arr(d.local_xyz, (na, 3), np.float32),
+                "parent": arr(d.node_parent, (nn,), np.int32), "abeg": arr(d.node_atom_begin, (nn,), np.int32),
+                "aend": arr(d.node_atom_end, (nn,), np.int32), "rel_origin": arr(d.node_rel_origin, (nn, 3), np.float32),
+                "rel_axis": arr(d.node_rel_axis, (nn, 3), np.float32), "pairs": arr(d.pairs, (npairs, 2), np.int32),
+                "pair_kind": arr(d.pair_kind, (npairs,), np.int32), "n_movable": d.n_movable, "lig_begin": d.lig_begin,
+                "lig_end": d.lig_end, "coords0": arr(pxyz, (na, 3), np.float32),
+                "conf0": arr(pconf, (7 + nn - 1,), np.float32), "n_tors": nn - 1, "n_lig_tors": tl, "n_flex_tors": tf,
+                "n_flex_movable": nfm, "n_inflex": ninf, "num_tors": nt.value}
+        return arr(prx, (nrig, 3), np.float32), arr(prs, (nrig,), np.int32), desc
+    finally:
+        lib().mi_pdbqt_model_close(h)
 
 
 def _ligand_num_tors(h):
@@ -561,10 +606,14 @@ class Vina:
     def set_ligand(self, lig):
         a = {k: np.ascontiguousarray(lig[k]) for k in
              ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs")}
+        if lig.get("pair_kind") is not None:
+            a["pair_kind"] = np.ascontiguousarray(lig["pair_kind"], dtype=np.int32)
         self._keep = a
         d = LigandDesc(len(a["smt"]), _ptr(a["smt"]), _ptr(a["local_xyz"]), len(a["parent"]), _ptr(a["parent"]),
                        _ptr(a["abeg"]), _ptr(a["aend"]), _ptr(a["rel_origin"]), _ptr(a["rel_axis"]),
-                       len(a["pairs"]), _ptr(a["pairs"]))
+                       len(a["pairs"]), _ptr(a["pairs"]), int(lig.get("n_movable", 0)),
+                       _ptr(a["pair_kind"]) if "pair_kind" in a else None, int(lig.get("lig_begin", 0)),
+                       int(lig.get("lig_end", 0)))
         check(lib().mi_vina_set_ligand(self.handle, C.byref(d)))
         self.n_atoms, self.n_tors = len(a["smt"]), len(a["parent"]) - 1
 

@@ -66,6 +66,14 @@ struct VinaLigand {
   const int *heavy_list;       // [n_heavy] indices of the non-hydrogen atoms
   const int *depth;            // [n_nodes] tree level of every node (root 0)
   int n_levels;                // 1 + the deepest level
+  // Flexible receptor residues (model.h: atoms = [flex movable | ligand | inflex]; tree.h:266-283,374-393):
+  //  parent[k] == -2: node k is a residue's first_segment -- its frame hangs off the world (rel_origin / rel_axis are
+  //  absolute); node_of_atom[i] == -1: an inflex atom, fixed at local_xyz, a partner in pairs only;
+  //  atoms [0, n_movable) get the receptor term; pair_cap[p] != 0: a pair of model::other_pairs (curl cap v[2])
+  //  instead of the ligand's own (v[0]); [lig_begin, lig_end) = the ligand's atoms (gyration radius).
+  int n_movable;
+  const int *pair_cap;         // [n_pairs] or nullptr (plain ligand)
+  int lig_begin, lig_end;
 };
 
 struct VinaMcArgs {

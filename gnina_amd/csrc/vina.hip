@@ -352,6 +352,7 @@ __device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
   L.pair_slots = reinterpret_cast<const int2 *>(cp_i(reinterpret_cast<const int *>(G.pair_slots), 2 * G.n_pairs));
   L.heavy_list = cp_i(G.heavy_list, G.n_heavy);
   L.depth = cp_i(G.depth, G.n_nodes);
+  if (G.pair_cap) L.pair_cap = cp_i(G.pair_cap, G.n_pairs);
   L.local_xyz = cp_f(G.local_xyz, 3 * G.n_atoms);
   L.rel_origin = cp_f(G.rel_origin, 3 * G.n_nodes);
   L.rel_axis = cp_f(G.rel_axis, 3 * G.n_nodes);
@@ -380,7 +381,7 @@ static bool want_stage(int B) { return B <= 2048; }
 
 static size_t ligand_lds_floats(int na, int nn, int np, int nh) {
   return 2 * pad4(na) + 4 * pad4(nn) + pad4(nn + 1) + pad4(nn) + 2 * pad4(2 * (size_t)np) + pad4(na + 1) + pad4(nh) +
-         pad4(3 * (size_t)na) + 2 * pad4(3 * (size_t)nn);
+         pad4(3 * (size_t)na) + 2 * pad4(3 * (size_t)nn) + pad4(np);  // (+ pair_cap, only present with flexible residues)
 }
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage) {
@@ -427,6 +428,7 @@ __device__ __forceinline__ void fold_forces(const VinaLigand &L, const WaveWork 
   // latency, keeping the six sums and the node origin in registers.
   for (int i = lane; i < L.n_atoms; i += 64) {
     const int k = L.node_of_atom[i];
+    if (k < 0) continue;  // inflex atom: its forces are ignored (model.cu:221)
     const float rx = w.coords[3 * i] - w.origin[3 * k], ry = w.coords[3 * i + 1] - w.origin[3 * k + 1],
                 rz = w.coords[3 * i + 2] - w.origin[3 * k + 2];
     const float gx = w.forces[3 * i], gy = w.forces[3 * i + 1], gz = w.forces[3 * i + 2];
@@ -469,7 +471,8 @@ __device__ __forceinline__ void fold_forces(const VinaLigand &L, const WaveWork 
   float rx = 0.f, ry = 0.f, rz = 0.f;
   if (lane > 0 && lane < L.n_nodes) {
     const int pr = L.parent[lane];
-    rx = ox - w.origin[3 * pr], ry = oy - w.origin[3 * pr + 1], rz = oz - w.origin[3 * pr + 2];
+    if (pr >= 0)  // a residue's first segment (parent -2) hands nothing up (flex.derivative, tree.h:374-393)
+      rx = ox - w.origin[3 * pr], ry = oy - w.origin[3 * pr + 1], rz = oz - w.origin[3 * pr + 2];
   }
   for (int k = L.n_nodes - 1; k >= 0; k--) {
     const int s = __builtin_amdgcn_readlane(cs, k), e_end = __builtin_amdgcn_readlane(ce, k);
@@ -542,6 +545,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       for (int i = 0; i < 4; i++) pq[i] = __shfl(q[i], src);
 #pragma unroll
       for (int i = 0; i < 3; i++) po[i] = __shfl(o[i], src);
+      if (par_r == -2) {  // first_segment::set_conf (tree.h:272-277): the world's frame
+#pragma unroll
+        for (int i = 0; i < 9; i++) pM[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+        pq[0] = 1.f, pq[1] = pq[2] = pq[3] = 0.f;
+        po[0] = po[1] = po[2] = 0.f;
+      }
       float tx, ty, tz, nax, nay, naz;
       mat_vec(pM, ro0, ro1, ro2, tx, ty, tz);
       const float no0 = po[0] + tx, no1 = po[1] + ty, no2 = po[2] + tz;
@@ -579,7 +588,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         q[0] = conf[3], q[1] = conf[4], q[2] = conf[5], q[3] = conf[6];
       } else {
         const int p = __builtin_amdgcn_readlane(par_r, k);
-        if (p != prev) {  // branch point: reload the parent's frame (stored earlier in this walk by lane 0)
+        if (p == -2) {  // a residue's first segment: its parent is the world
+#pragma unroll
+          for (int i = 0; i < 9; i++) M[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+          q[0] = 1.f, q[1] = q[2] = q[3] = 0.f;
+          o[0] = o[1] = o[2] = 0.f;
+        } else if (p != prev) {  // branch point: reload the parent's frame (stored earlier in this walk by lane 0)
 #pragma unroll
           for (int i = 0; i < 9; i++) M[i] = w.M[9 * p + i];
 #pragma unroll
@@ -622,9 +636,13 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   bool tap_on[kTapIt];
   auto place_atom = [&](int i, float &cx, float &cy, float &cz) {
     const int k = L.node_of_atom[i];
-    float tx, ty, tz;
-    mat_vec(w.M + 9 * k, L.local_xyz[3 * i], L.local_xyz[3 * i + 1], L.local_xyz[3 * i + 2], tx, ty, tz);
-    cx = w.origin[3 * k] + tx, cy = w.origin[3 * k + 1] + ty, cz = w.origin[3 * k + 2] + tz;
+    if (k < 0) {  // inflex atom: stays where the file has it
+      cx = L.local_xyz[3 * i], cy = L.local_xyz[3 * i + 1], cz = L.local_xyz[3 * i + 2];
+    } else {
+      float tx, ty, tz;
+      mat_vec(w.M + 9 * k, L.local_xyz[3 * i], L.local_xyz[3 * i + 1], L.local_xyz[3 * i + 2], tx, ty, tz);
+      cx = w.origin[3 * k] + tx, cy = w.origin[3 * k + 1] + ty, cz = w.origin[3 * k + 2] + tz;
+    }
     w.coords[3 * i] = cx;
     w.coords[3 * i + 1] = cy;
     w.coords[3 * i + 2] = cz;
@@ -637,7 +655,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       float cx, cy, cz;
       place_atom(i, cx, cy, cz);
       const int t = L.smt[i];
-      if (GRID && !env.direct && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+      if (GRID && !env.direct && i < L.n_movable && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
         grid_fetch(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, tap[it]);
         tap_on[it] = true;
       } else if (DERIV) {
@@ -652,7 +670,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     place_atom(i, cx, cy, cz);
     const int t = L.smt[i];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (GRID && !env.direct && t > 1 && env.grid_off[t] >= 0)
+    if (GRID && !env.direct && i < L.n_movable && t > 1 && env.grid_off[t] >= 0)
       e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
     if (DERIV) {
       w.forces[3 * i] = fx;
@@ -664,7 +682,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   if (MODE != 3 && MODE != 4 && env.direct) {
     // non_cache::eval / eval_deriv (non_cache.cpp:52-83,125-179): every ligand heavy atom against every
     // receptor atom within the cutoff -- the 64 lanes stride over the receptor, one ligand atom at a time
-    for (int i = 0; i < L.n_atoms; i++) {
+    for (int i = 0; i < L.n_movable; i++) {
       const int t1 = L.smt[i];
       if (t1 <= 1) continue;
       float adj[3], oobd[3] = {0.f, 0.f, 0.f}, oob = 0.f;
@@ -725,7 +743,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
   if ((MODE < 2 || MODE == 4) && !env.exact) {
     for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * PG) {
-      float rx[PG], ry[PG], rz[PG], rem[PG];
+      float rx[PG], ry[PG], rz[PG], rem[PG], capv[PG];
       float2 s1[PG], s2[PG];
       float fastv[PG];
       int2 sl[PG];
@@ -735,6 +753,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         const int p = p0 + 64 * u;
         const bool valid = p < L.n_pairs;
         const int2 ab = L.pairs[valid ? p : 0];
+        capv[u] = (L.pair_cap && L.pair_cap[valid ? p : 0]) ? v2 : v0;
         if (DERIV) sl[u] = L.pair_slots[valid ? p : 0];
         rx[u] = w.coords[3 * ab.y] - w.coords[3 * ab.x];
         ry[u] = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1];
@@ -762,12 +781,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
             float pe = s1[u].x + rem[u] * (s2[u].x - s1[u].x);
             const float dor = s1[u].y + rem[u] * (s2[u].y - s1[u].y);
             float fx = dor * rx[u], fy = dor * ry[u], fz = dor * rz[u];
-            curl3(pe, fx, fy, fz, v0);
+            curl3(pe, fx, fy, fz, capv[u]);
             out = make_float4(fx, fy, fz, pe);
             e_part += pe;
           } else {
             float pe = fastv[u];
-            curl1(pe, v0);
+            curl1(pe, capv[u]);
             e_part += pe;
           }
         }
@@ -784,17 +803,18 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
     const float r2 = rx * rx + ry * ry + rz * rz;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float capx = (L.pair_cap && L.pair_cap[p]) ? v2 : v0;
     if (r2 < env.cutoff_sqr) {
       if (DERIV) {
         float pe, dor;
         prec_eval_deriv(env, L.smt[ab.x], L.smt[ab.y], r2, pe, dor);
         float fx = dor * rx, fy = dor * ry, fz = dor * rz;
-        curl3(pe, fx, fy, fz, v0);
+        curl3(pe, fx, fy, fz, capx);
         out = make_float4(fx, fy, fz, pe);
         e_part += pe;
       } else {
         float pe = prec_eval(env, L.smt[ab.x], L.smt[ab.y], r2);
-        curl1(pe, v0);
+        curl1(pe, capx);
         e_part += pe;
       }
     }
@@ -1703,14 +1723,16 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
     } else if (which == 1) {
       (void)eval_conf<3, PG>(env, L, mconf, 0.f, 0.f, 0.f, w, nullptr);  // the coordinates `model` holds
       float acc = 0.f;
-      for (int i = lane; i < L.n_atoms; i += 64)
+      int n_gyr = 0;
+      for (int i = L.lig_begin; i < L.lig_end; i++) n_gyr += L.smt[i] > 1;  // (a handful of atoms; uniform)
+      for (int i = L.lig_begin + lane; i < L.lig_end; i += 64)
         if (L.smt[i] > 1) {
           const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
                       dz = w.coords[3 * i + 2] - w.origin[2];
           acc += dx * dx + dy * dy + dz * dz;
         }
       acc = wave_sum(acc);
-      const float gr = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
+      const float gr = n_gyr > 0 ? sqrtf(acc / (float)n_gyr) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
       if (gr > VEPS) {
         float dx, dy, dz;
         rng.inside_sphere(dx, dy, dz);

@@ -336,16 +336,20 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
   MIG_CHECK(vina_wave_lds_bytes(na, nn, np, true, true) <= 152 * 1024, 1,
             "ligand too large for the per-wave LDS workspace (160 KB per workgroup)");
   MIG_CHECK(nn <= 57, 1, "more than 56 rotatable bonds: the minimiser keeps the 7 + T conformation entries one per lane");
+  const int n_mov = d->n_movable > 0 ? d->n_movable : na;
+  MIG_CHECK(n_mov <= na && d->lig_begin >= 0 && d->lig_begin <= d->lig_end && d->lig_end <= na, 1,
+            "bad n_movable / ligand atom range");
   std::vector<int> node_of(na, -1);
   for (int k = 0; k < nn; k++) {
-    MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : d->node_parent[k] >= 0), 1,
-              "nodes must be in DFS pre-order (parent index < node index, root first)");
+    MIG_CHECK(d->node_parent[k] < k && (k == 0 ? d->node_parent[k] == -1 : (d->node_parent[k] >= 0 || d->node_parent[k] == -2)),
+              1, "nodes must be in DFS pre-order (parent index < node index, root first; -2 = a residue's first segment)");
     MIG_CHECK(d->node_atom_begin[k] >= 0 && d->node_atom_begin[k] <= d->node_atom_end[k] && d->node_atom_end[k] <= na,
               1, "bad node atom range");
     for (int i = d->node_atom_begin[k]; i < d->node_atom_end[k]; i++) node_of[i] = k;
   }
   for (int i = 0; i < na; i++) {
-    MIG_CHECK(node_of[i] >= 0, 1, "atom not covered by any node");
+    MIG_CHECK(node_of[i] >= 0 || i >= n_mov, 1, "movable atom not covered by any node");  // inflex atoms have none
+    MIG_CHECK(node_of[i] < 0 || i < n_mov, 1, "an atom beyond n_movable belongs to a node");
     MIG_CHECK(d->smt[i] >= 0 && d->smt[i] < kVinaTypes, 1, "ligand smina type out of range");
   }
   // CSR of children (increasing index) and of pairs per atom (pair order)
@@ -379,14 +383,14 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
     while (ints.size() % 4) ints.push_back(0);
     return off;
   };
-  std::vector<int> heavy;
-  for (int i = 0; i < na; i++)
+  std::vector<int> heavy;  // model::get_heavy_atom_movable_coords: the movable non-hydrogen atoms
+  for (int i = 0; i < n_mov; i++)
     if (d->smt[i] > 1) heavy.push_back(i);
   const size_t o_heavy = pushi(heavy.empty() ? aps.data() : heavy.data(), heavy.size());
   std::vector<int> depth(nn, 0);  // level of every node; the tree walk may advance one level per step
   int n_levels = 1;
   for (int k = 1; k < nn; k++) {
-    depth[k] = depth[d->node_parent[k]] + 1;
+    depth[k] = d->node_parent[k] == -2 ? 1 : depth[d->node_parent[k]] + 1;
     n_levels = std::max(n_levels, depth[k] + 1);
   }
   const size_t o_depth = pushi(depth.data(), nn);
@@ -396,6 +400,7 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
                o_cl = pushi(child_list.empty() ? aps.data() : child_list.data(), child_list.size()),
                o_pairs = pushi(np ? d->pairs : aps.data(), 2 * (size_t)np), o_aps = pushi(aps.data(), na + 1),
                o_apl = pushi(apl.empty() ? aps.data() : apl.data(), apl.size());
+  const size_t o_cap = d->pair_kind && np ? pushi(d->pair_kind, np) : 0;
   std::vector<float> flts;
   auto pushf = [&](const float *p, size_t n) {
     size_t off = flts.size();
@@ -427,6 +432,10 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
   L.heavy_list = out.d_int.p + o_heavy;
   L.depth = out.d_int.p + o_depth;
   L.n_levels = n_levels;
+  L.n_movable = n_mov;
+  L.pair_cap = d->pair_kind && np ? out.d_int.p + o_cap : nullptr;
+  L.lig_begin = d->lig_end > d->lig_begin ? d->lig_begin : 0;
+  L.lig_end = d->lig_end > d->lig_begin ? d->lig_end : na;
   L.local_xyz = out.d_flt.p + o_loc;
   L.rel_origin = out.d_flt.p + o_ro;
   L.rel_axis = out.d_flt.p + o_ra;

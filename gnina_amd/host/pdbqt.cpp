@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -570,13 +571,43 @@ PdbqtLigand parse_pdbqt_ligand(const std::string &name, const std::string &text)
 // construction above.  Bonds for the X-Score typing follow model::distance_type_between (model.cpp:491-508):
 // rigid-rigid and rigid-inflex are fixed, rigid-movable is variable (never bonded), inside a residue the tree's
 // own marks, inflex-inflex fixed, movable atoms of different residues variable.
-PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const std::string &rigid_text,
-                                            const std::string &flex_name, const std::string &flex_text) {
+namespace {
+// The receptor model of parse_receptor_pdbqt(rigid, flex): grid_atoms = rigid, atoms = [movable | inflex]
+// (pdbqt_initializer::initialize_from_rigid / initialize_from_nrp, parse_pdbqt.cpp:419-470), bonds and X-Score types
+// assigned over the index space assign_bonds uses (grid atoms first, model.cpp:563-571).
+struct FlexModel {
   struct Res {
     Builder b;
     std::vector<unsigned char> mobm;
+    int n_inflex = 0;   // atoms of the Builder's node 0: ROOT atoms + first atoms of the top-level branches
+    int mov_off = 0;    // index of the residue's first movable atom among all movable atoms
+    int inflex_off = 0; // index of its first inflex atom among all inflex atoms
   };
   std::vector<Res> residues;
+  struct Row {
+    int res, idx;  // residue (-1 rigid), index in the residue's Builder order
+    int kind;      // 0 movable, 1 inflex, 2 rigid
+  };
+  int n_rigid = 0, n_movable = 0, n_inflex = 0;
+  std::vector<PAtom> atoms;       // [rigid | movable | inflex]
+  std::vector<Row> rows;
+  std::vector<std::vector<int>> bonds;
+  std::vector<int> sm;
+  int mob(int i, int j) const {   // model::distance_type_between (model.cpp:491-508)
+    if (i == j) return 1;
+    const Row &a = rows[i], &b = rows[j];
+    if (a.kind == 2 || b.kind == 2) return (a.kind == 0 || b.kind == 0) ? 0 : 1;
+    if (a.res == b.res) {
+      const int n = (int)residues[a.res].b.atoms.size();
+      return residues[a.res].mobm[(size_t)std::min(a.idx, b.idx) * n + std::max(a.idx, b.idx)];
+    }
+    return (a.kind == 1 && b.kind == 1) ? 1 : 0;
+  }
+};
+
+FlexModel build_flex_model(const std::string &rigid_name, const std::string &rigid_text, const std::string &flex_name,
+                           const std::string &flex_text) {
+  FlexModel fm;
   {
     LineReader r(flex_name, flex_text);
     std::string s;
@@ -586,9 +617,9 @@ PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const
         PS root;
         (void)parse_tree(r, root, true);
         if (root.atoms.empty()) fail(flex_name, r.count, "No atoms in the residue");
-        residues.emplace_back();
-        build_tree(root, residues.back().b);
-        residues.back().mobm = mobility_of(residues.back().b);
+        fm.residues.emplace_back();
+        build_tree(root, fm.residues.back().b);
+        fm.residues.back().mobm = mobility_of(fm.residues.back().b);
       } else if (starts_with(s, "MODEL")) {
         fail(flex_name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
       } else {
@@ -596,55 +627,169 @@ PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const
       }
     }
   }
-  // rows in DLScorer::setReceptor's order (dl_scorer.cpp:93-193): movable, inflex, rigid
-  struct Row {
-    int res, idx;  // residue (-1 rigid), index in the residue's model order
-    int kind;      // 0 movable, 1 inflex, 2 rigid
-  };
-  std::vector<PAtom> atoms;
-  std::vector<Row> rows;
-  for (int kind = 0; kind < 2; kind++)
-    for (size_t q = 0; q < residues.size(); q++) {
-      const Builder &b = residues[q].b;
-      for (int i = 0; i < (int)b.atoms.size(); i++) {
-        const bool inflex = i >= b.abeg[0] && i < b.aend[0];
-        if ((kind == 1) != inflex) continue;
-        atoms.push_back(b.atoms[i]);
-        rows.push_back({(int)q, i, kind});
-      }
-    }
-  PdbqtFlexReceptor out;
-  for (const Row &rw : rows) (rw.kind == 0 ? out.n_movable : out.n_inflex)++;
   {
     LineReader r(rigid_name, rigid_text);
     std::string s;
     while (r.next(s)) {
       if (starts_with(s, "ATOM  ") || starts_with(s, "HETATM")) {
-        atoms.push_back(parse_atom(rigid_name, r.count, s));
-        rows.push_back({-1, 0, 2});
+        fm.atoms.push_back(parse_atom(rigid_name, r.count, s));
+        fm.rows.push_back({-1, 0, 2});
       } else if (starts_with(s, "MODEL")) {
         fail(rigid_name, r.count, "Unexpected multi-MODEL input. Use \"vina_split\" first?");
       }
     }
   }
-  auto mob = [&](int i, int j) -> int {
-    if (i == j) return 1;
-    const Row &a = rows[i], &b = rows[j];
-    if (a.kind == 2 || b.kind == 2) return (a.kind == 0 || b.kind == 0) ? 0 : 1;
-    if (a.res == b.res) {
-      const int n = (int)residues[a.res].b.atoms.size();
-      return residues[a.res].mobm[(size_t)std::min(a.idx, b.idx) * n + std::max(a.idx, b.idx)];
+  fm.n_rigid = (int)fm.atoms.size();
+  for (int kind = 0; kind < 2; kind++)
+    for (size_t q = 0; q < fm.residues.size(); q++) {
+      FlexModel::Res &R = fm.residues[q];
+      const Builder &b = R.b;
+      (kind == 0 ? R.mov_off : R.inflex_off) = kind == 0 ? fm.n_movable : fm.n_inflex;
+      for (int i = 0; i < (int)b.atoms.size(); i++) {
+        const bool inflex = i >= b.abeg[0] && i < b.aend[0];
+        if ((kind == 1) != inflex) continue;
+        fm.atoms.push_back(b.atoms[i]);
+        fm.rows.push_back({(int)q, i, kind});
+        (kind == 0 ? fm.n_movable : fm.n_inflex)++;
+        if (kind == 1) R.n_inflex++;
+      }
     }
-    return (a.kind == 1 && b.kind == 1) ? 1 : 0;
+  bonds_and_types(fm.atoms, [&](int i, int j) { return fm.mob(i, j); }, fm.bonds, fm.sm);
+  return fm;
+}
+}  // namespace
+
+PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const std::string &rigid_text,
+                                            const std::string &flex_name, const std::string &flex_text) {
+  const FlexModel fm = build_flex_model(rigid_name, rigid_text, flex_name, flex_text);
+  // rows in DLScorer::setReceptor's order (dl_scorer.cpp:93-193): movable, inflex, rigid
+  PdbqtFlexReceptor out;
+  out.n_movable = fm.n_movable;
+  out.n_inflex = fm.n_inflex;
+  auto put = [&](int i) {
+    out.xyz.insert(out.xyz.end(), fm.atoms[i].c, fm.atoms[i].c + 3);
+    out.smt.push_back(fm.sm[i]);
   };
-  std::vector<std::vector<int>> bonds;
-  std::vector<int> sm;
-  bonds_and_types(atoms, mob, bonds, sm);
-  for (size_t i = 0; i < atoms.size(); i++) {
-    out.xyz.insert(out.xyz.end(), atoms[i].c, atoms[i].c + 3);
-    out.smt.push_back(sm[i]);
-  }
+  for (int i = fm.n_rigid; i < (int)fm.atoms.size(); i++) put(i);
+  for (int i = 0; i < fm.n_rigid; i++) put(i);
   return out;
+}
+
+// gnina's `model` for a docking run with flexible residues: parse_receptor_pdbqt(rigid, flex) + m.append(ligand)
+// (molgetter.cpp:66-75,430-437; model::append, model.cpp:176-226).  Atoms = [flex movable | ligand | inflex]; nodes =
+// [ligand root | ligand segments | one first_segment tree per top-level branch of every residue] so that torsion k
+// belongs to node k + 1 and conf = [7 + T_ligand + T_flex] like gnina's (conf.h:361-373).
+PdbqtModel parse_pdbqt_model(const std::string &rigid_name, const std::string &rigid_text, const std::string &flex_name,
+                             const std::string &flex_text, const std::string &lig_name, const std::string &lig_text) {
+  const FlexModel fm = build_flex_model(rigid_name, rigid_text, flex_name, flex_text);
+  const PdbqtLigand lig = parse_pdbqt_ligand(lig_name, lig_text);
+  PdbqtModel M;
+  for (int i = 0; i < fm.n_rigid; i++) {
+    M.rec_xyz.insert(M.rec_xyz.end(), fm.atoms[i].c, fm.atoms[i].c + 3);
+    M.rec_smt.push_back(fm.sm[i]);
+  }
+  const int n_lig = (int)lig.smt.size(), n_mov = fm.n_movable, n_inf = fm.n_inflex;
+  M.n_flex_movable = n_mov;
+  M.n_inflex = n_inf;
+  M.lig_begin = n_mov;
+  M.lig_end = n_mov + n_lig;
+  M.n_movable = n_mov + n_lig;
+  M.torsdof = lig.torsdof;
+  M.num_tors = lig.num_tors;
+  const int n_atoms = n_mov + n_lig + n_inf;
+  M.xyz.resize((size_t)3 * n_atoms);
+  M.local_xyz.resize((size_t)3 * n_atoms);
+  M.smt.resize(n_atoms);
+  // receptor-model index (movable, then inflex) -> combined index (appender::operator(), model.cpp:84-98)
+  auto rec_to_model = [&](int a) { return a < n_mov ? a : a + n_lig; };
+  for (int a = 0; a < n_mov + n_inf; a++) {
+    const int src = fm.n_rigid + a, dst = rec_to_model(a);
+    for (int d = 0; d < 3; d++) M.xyz[3 * dst + d] = M.local_xyz[3 * dst + d] = fm.atoms[src].c[d];  // inflex: as in the file
+    M.smt[dst] = fm.sm[src];
+  }
+  for (int i = 0; i < n_lig; i++) {
+    for (int d = 0; d < 3; d++) {
+      M.xyz[3 * (n_mov + i) + d] = lig.xyz[3 * i + d];
+      M.local_xyz[3 * (n_mov + i) + d] = lig.local_xyz[3 * i + d];
+    }
+    M.smt[n_mov + i] = lig.smt[i];
+  }
+  // nodes: the ligand's first
+  const int nl_nodes = (int)lig.node_parent.size();
+  for (int k = 0; k < nl_nodes; k++) {
+    M.node_parent.push_back(lig.node_parent[k]);
+    M.node_atom_begin.push_back(lig.node_atom_begin[k] + n_mov);
+    M.node_atom_end.push_back(lig.node_atom_end[k] + n_mov);
+    for (int d = 0; d < 3; d++) {
+      M.node_rel_origin.push_back(lig.node_rel_origin[3 * k + d]);
+      M.node_rel_axis.push_back(lig.node_rel_axis[3 * k + d]);
+    }
+  }
+  M.n_lig_torsions = nl_nodes - 1;
+  // residues: Builder node k >= 1 -> model node; children of the Builder's node 0 are first_segments (world)
+  for (const FlexModel::Res &R : fm.residues) {
+    const Builder &b = R.b;
+    const int base = (int)M.node_parent.size() - 1;  // Builder node k -> model node base + k
+    for (int k = 1; k < (int)b.parent.size(); k++) {
+      const bool first = b.parent[k] == 0;
+      M.node_parent.push_back(first ? -2 : base + b.parent[k]);
+      // the Builder numbers the residue's atoms [inflex (node 0) | movable]; movable atom i -> mov_off + i - n_inflex
+      M.node_atom_begin.push_back(R.mov_off + b.abeg[k] - R.n_inflex);
+      M.node_atom_end.push_back(R.mov_off + b.aend[k] - R.n_inflex);
+      for (int d = 0; d < 3; d++) {
+        M.node_rel_origin.push_back(first ? b.origin[3 * k + d] : b.rel_origin[3 * k + d]);
+        M.node_rel_axis.push_back(b.rel_axis[3 * k + d]);  // built at the identity orientation: also the absolute axis
+      }
+    }
+    // local coordinates of the residue's movable atoms (relative to their node's origin)
+    for (int i = R.n_inflex; i < (int)b.atoms.size(); i++)
+      for (int d = 0; d < 3; d++) M.local_xyz[3 * (R.mov_off + i - R.n_inflex) + d] = b.local[3 * i + d];
+  }
+  M.n_flex_torsions = (int)M.node_parent.size() - nl_nodes;
+  // pairs.  (1) the receptor model's own other_pairs: initialize_pairs (model.cpp:682-703) over atoms = [movable |
+  // inflex]; (2) model::append: every (receptor-model atom, ligand atom) pair, hydrogens included (model.cpp:182-199);
+  // (3) the ligand's internal pairs.  other_pairs (kind 1) first: model::eval_deriv adds them first.
+  const int nr = n_mov + n_inf;
+  auto bonded_to3 = [&](int a) {  // model::bonded_to(a, 3): bonds to grid atoms are not followed (model.cpp:664-675)
+    struct Rec {
+      static void go(int a, int depth, const FlexModel &fm, std::vector<int> &out) {
+        if (std::find(out.begin(), out.end(), a) != out.end()) return;
+        out.push_back(a);
+        if (depth > 0)
+          for (int nb : fm.bonds[fm.n_rigid + a])
+            if (nb >= fm.n_rigid) go(nb - fm.n_rigid, depth - 1, fm, out);
+      }
+    };
+    std::vector<int> out;
+    Rec::go(a, 3, fm, out);
+    return out;
+  };
+  for (int i = 0; i < nr; i++) {
+    const std::vector<int> near = bonded_to3(i);
+    for (int j = i + 1; j < nr; j++) {
+      if (i >= n_mov && j >= n_mov) continue;  // inflex-inflex
+      if (fm.mob(fm.n_rigid + i, fm.n_rigid + j) != 0) continue;
+      if (std::find(near.begin(), near.end(), j) != near.end()) continue;
+      if (fm.sm[fm.n_rigid + i] <= kHD || fm.sm[fm.n_rigid + j] <= kHD) continue;
+      M.pairs.push_back(rec_to_model(i));
+      M.pairs.push_back(rec_to_model(j));
+      M.pair_kind.push_back(1);
+    }
+  }
+  for (int i = 0; i < nr; i++)
+    for (int j = 0; j < n_lig; j++) {
+      M.pairs.push_back(rec_to_model(i));
+      M.pairs.push_back(n_mov + j);
+      M.pair_kind.push_back(1);
+    }
+  for (size_t p = 0; p + 1 < lig.pairs.size(); p += 2) {
+    M.pairs.push_back(lig.pairs[p] + n_mov);
+    M.pairs.push_back(lig.pairs[p + 1] + n_mov);
+    M.pair_kind.push_back(0);
+  }
+  M.conf0 = lig.conf0;
+  M.conf0.resize(lig.conf0.size() + M.n_flex_torsions, 0.f);
+  return M;
 }
 
 static std::string num9(float v) {  // boost::lexical_cast<std::string>(float): up to 9 significant digits
@@ -691,6 +836,9 @@ PdbqtFlexReceptor read_pdbqt_receptor_flex(const std::string &rigid_path, const 
   return parse_pdbqt_receptor_flex(rigid_path, slurp(rigid_path), flex_path, slurp(flex_path));
 }
 PdbqtLigand read_pdbqt_ligand(const std::string &path) { return parse_pdbqt_ligand(path, slurp(path)); }
+PdbqtModel read_pdbqt_model(const std::string &rigid_path, const std::string &flex_path, const std::string &lig_path) {
+  return parse_pdbqt_model(rigid_path, slurp(rigid_path), flex_path, slurp(flex_path), lig_path, slurp(lig_path));
+}
 
 }  // namespace gnina_amd
 
@@ -701,6 +849,9 @@ thread_local std::string g_pdbqt_error;
 
 struct mi_pdbqt_ligand {
   gnina_amd::PdbqtLigand L;
+};
+struct mi_pdbqt_model {
+  gnina_amd::PdbqtModel M;
 };
 
 extern "C" {
@@ -724,6 +875,60 @@ mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int
     g_pdbqt_error = e.what();
     return MI_ERR_INVALID;
   }
+}
+
+mi_pdbqt_model *mi_pdbqt_model_open(const char *rigid, const char *flex, const char *ligand, int is_text) {
+  try {
+    if (!rigid || !flex || !ligand) throw std::runtime_error("NULL argument");
+    std::unique_ptr<mi_pdbqt_model> h(new mi_pdbqt_model);
+    h->M = is_text ? gnina_amd::parse_pdbqt_model("<rigid>", rigid, "<flex>", flex, "<ligand>", ligand)
+                   : gnina_amd::read_pdbqt_model(rigid, flex, ligand);
+    return h.release();
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return nullptr;
+  }
+}
+void mi_pdbqt_model_close(mi_pdbqt_model *h) { delete h; }
+mi_status mi_pdbqt_model_sizes(const mi_pdbqt_model *h, int32_t *out8) {
+  if (!h || !out8) return MI_ERR_INVALID;
+  const gnina_amd::PdbqtModel &M = h->M;
+  out8[0] = (int32_t)M.smt.size();
+  out8[1] = (int32_t)M.node_parent.size();
+  out8[2] = (int32_t)(M.pairs.size() / 2);
+  out8[3] = (int32_t)M.rec_smt.size();
+  out8[4] = M.n_flex_movable;
+  out8[5] = M.n_inflex;
+  out8[6] = M.n_lig_torsions;
+  out8[7] = M.n_flex_torsions;
+  return MI_OK;
+}
+mi_status mi_pdbqt_model_desc(const mi_pdbqt_model *h, mi_ligand_desc *desc, const float **xyz, const float **conf0,
+                              const float **rec_xyz, const int32_t **rec_smt, float *num_tors) {
+  if (!h || !desc) return MI_ERR_INVALID;
+  const gnina_amd::PdbqtModel &M = h->M;
+  *desc = mi_ligand_desc{};
+  desc->n_atoms = (int32_t)M.smt.size();
+  desc->smt = M.smt.data();
+  desc->local_xyz = M.local_xyz.data();
+  desc->n_nodes = (int32_t)M.node_parent.size();
+  desc->node_parent = M.node_parent.data();
+  desc->node_atom_begin = M.node_atom_begin.data();
+  desc->node_atom_end = M.node_atom_end.data();
+  desc->node_rel_origin = M.node_rel_origin.data();
+  desc->node_rel_axis = M.node_rel_axis.data();
+  desc->n_pairs = (int32_t)(M.pairs.size() / 2);
+  desc->pairs = M.pairs.data();
+  desc->n_movable = M.n_movable;
+  desc->pair_kind = M.pair_kind.data();
+  desc->lig_begin = M.lig_begin;
+  desc->lig_end = M.lig_end;
+  if (xyz) *xyz = M.xyz.data();
+  if (conf0) *conf0 = M.conf0.data();
+  if (rec_xyz) *rec_xyz = M.rec_xyz.data();
+  if (rec_smt) *rec_smt = M.rec_smt.data();
+  if (num_tors) *num_tors = M.num_tors;
+  return MI_OK;
 }
 
 mi_status mi_pdbqt_read_receptor_flex(const char *rigid, const char *flex, int is_text, float *xyz, int32_t *smt,

@@ -62,6 +62,29 @@ PdbqtFlexReceptor read_pdbqt_receptor_flex(const std::string &rigid_path, const 
 PdbqtFlexReceptor parse_pdbqt_receptor_flex(const std::string &rigid_name, const std::string &rigid_text,
                                             const std::string &flex_name, const std::string &flex_text);
 
+// gnina's `model` of a docking run with flexible residues: rigid receptor (the grid atoms) + what moves.
+// Atoms = [flexible-residue movable atoms | ligand | inflex atoms of the residues] (model.h: movable atoms first),
+// nodes = [ligand root | ligand segments | the residues' trees], conf = [7 + T_ligand + T_flex].
+struct PdbqtModel {
+  std::vector<float> rec_xyz;      // [n_rigid][3] receptor atoms for the grids (mi_vina_set_receptor)
+  std::vector<int32_t> rec_smt;    // typed within the receptor model (rigid + residues), like the reference
+  std::vector<float> xyz;          // [n_atoms][3] input coordinates in model order
+  std::vector<int32_t> smt;
+  std::vector<float> local_xyz;    // [n_atoms][3] relative to the owning node's origin; inflex atoms: absolute
+  std::vector<int32_t> node_parent;  // -1 ligand root, -2 a residue's first segment (hangs off the world), else index
+  std::vector<int32_t> node_atom_begin, node_atom_end;
+  std::vector<float> node_rel_origin, node_rel_axis;  // first segments: absolute origin / axis
+  std::vector<int32_t> pairs;      // [n_pairs][2]
+  std::vector<int32_t> pair_kind;  // [n_pairs] 1 = model::other_pairs (cap v[2]), 0 = ligand-internal (cap v[0])
+  std::vector<float> conf0;        // [7 + T_ligand + T_flex]: the input pose
+  int n_movable = 0, n_flex_movable = 0, n_inflex = 0, lig_begin = 0, lig_end = 0;
+  int n_lig_torsions = 0, n_flex_torsions = 0, torsdof = 0;
+  float num_tors = 0;
+};
+PdbqtModel read_pdbqt_model(const std::string &rigid_path, const std::string &flex_path, const std::string &lig_path);
+PdbqtModel parse_pdbqt_model(const std::string &rigid_name, const std::string &rigid_text, const std::string &flex_name,
+                             const std::string &flex_text, const std::string &lig_name, const std::string &lig_text);
+
 // One docked pose as gnina writes it to a .pdbqt (result_info::write, result_info.cpp:151-164 +
 // context::writePDBQT / coords_to_pdbqt_string, model.cpp:779-810): MODEL n, REMARK minimizedAffinity /
 // [minimizedRMSD] / [CNNscore] / [CNNaffinity], the input lines with columns 31-54 rewritten (%8.3f), ENDMDL.

@@ -217,6 +217,18 @@ typedef struct mi_ligand_desc {
   const float *node_rel_axis;     /* [n_nodes][3] segment::relative_axis */
   int32_t n_pairs;
   const int32_t *pairs;           /* [n_pairs][2] */
+  /* Flexible receptor residues in the search (model.h: atoms = [flex movable | ligand | inflex]; flex.derivative
+   * tree.h:374-393; model::other_pairs model.cu:209-213; conf = [7 + T_ligand + T_flex], conf.h:361-373).  All zero /
+   * NULL for a plain ligand.  mi_pdbqt_model_open builds such a description from .pdbqt files.
+   *   node_parent[k] == -2: node k is a residue's first_segment -- it hangs off the world, node_rel_origin / axis are
+   *                         absolute; its subtree follows it like a ligand branch;
+   *   atoms outside every node: inflex atoms, fixed at local_xyz (absolute), partners in pairs only;
+   *   n_movable:  atoms [0, n_movable) get the receptor term (0 = n_atoms);
+   *   pair_kind:  [n_pairs] 0 = ligand-internal pair (curl cap v[0]), 1 = pair of model::other_pairs (cap v[2]);
+   *   lig_begin / lig_end: the ligand's atom range (mutate_conf's gyration radius); 0, 0 = all atoms. */
+  int32_t n_movable;
+  const int32_t *pair_kind;
+  int32_t lig_begin, lig_end;
 } mi_ligand_desc;
 mi_status mi_vina_set_ligand(mi_vina *, const mi_ligand_desc *);
 /* model::eval_deriv(p, ig = cache, v, conf, change) (model.cu:202-225) [with_deriv = 1] or model::eval
@@ -379,6 +391,19 @@ mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int
  * (xyz = smt = NULL to query the size) and error reporting as mi_pdbqt_read_receptor. */
 mi_status mi_pdbqt_read_receptor_flex(const char *rigid, const char *flex, int is_text, float *xyz, int32_t *smt,
                                       int capacity, int *n_atoms, int *n_movable, int *n_inflex);
+/* gnina's `model` of a docking run WITH flexible residues: parse_receptor_pdbqt(rigid, flex) + m.append(ligand)
+ * (molgetter.cpp:66-75,430-437; model::append model.cpp:176-226): the rigid atoms for the grids (rec_xyz / rec_smt,
+ * [sizes[3]]) and ONE description of everything that moves -- atoms [flex movable | ligand | inflex], nodes [ligand |
+ * residue trees], pairs with their kind -- ready for mi_vina_set_ligand.  conf0 [7 + T_ligand + T_flex] reproduces the
+ * input; xyz [n_atoms][3] = input coordinates in model order.  sizes = {n_atoms, n_nodes, n_pairs, n_rigid,
+ * n_flex_movable, n_inflex, T_ligand, T_flex}.  Arguments are paths, or file contents when is_text != 0.  The cache
+ * needs grids for the types of ALL movable atoms (flexible side chains included). */
+typedef struct mi_pdbqt_model mi_pdbqt_model;
+mi_pdbqt_model *mi_pdbqt_model_open(const char *rigid, const char *flex, const char *ligand, int is_text);
+void mi_pdbqt_model_close(mi_pdbqt_model *);
+mi_status mi_pdbqt_model_sizes(const mi_pdbqt_model *, int32_t *sizes8);
+mi_status mi_pdbqt_model_desc(const mi_pdbqt_model *, mi_ligand_desc *desc, const float **xyz, const float **conf0,
+                              const float **rec_xyz, const int32_t **rec_smt, float *num_tors);
 mi_pdbqt_ligand *mi_pdbqt_ligand_open(const char *path_or_text, int is_text);
 void mi_pdbqt_ligand_close(mi_pdbqt_ligand *);
 mi_status mi_pdbqt_ligand_sizes(const mi_pdbqt_ligand *, int *n_atoms, int *n_nodes, int *n_pairs, int *torsdof);

@@ -20,7 +20,9 @@ class GridDims(C.Structure):
 class Ligand(C.Structure):
     _fields_ = [("n_atoms", C.c_int), ("smt", _i32p), ("local_xyz", _f32p), ("n_nodes", C.c_int),
                 ("parent", _i32p), ("abeg", _i32p), ("aend", _i32p), ("rel_origin", _f32p), ("rel_axis", _f32p),
-                ("n_pairs", C.c_int), ("pairs", _i32p)]
+                ("n_pairs", C.c_int), ("pairs", _i32p),
+                # flexible residues (see ora_ligand in vina_ref.c): 0 / NULL = a plain ligand
+                ("n_movable", C.c_int), ("pair_kind", _i32p), ("lig_begin", C.c_int), ("lig_end", C.c_int)]
 
 
 _configured = False
@@ -121,9 +123,14 @@ class LigandHandle:
         a = self.arr
         self.n_atoms, self.n_nodes = len(a["smt"]), len(a["parent"])
         self.n_tors = self.n_nodes - 1
+        if lig.get("pair_kind") is not None:
+            a["pair_kind"] = np.ascontiguousarray(lig["pair_kind"], dtype=np.int32)
+        self.n_movable = int(lig.get("n_movable", 0)) or self.n_atoms
         self.c = Ligand(self.n_atoms, _p(a["smt"], C.c_int32), _p(a["local_xyz"]), self.n_nodes,
                         _p(a["parent"], C.c_int32), _p(a["abeg"], C.c_int32), _p(a["aend"], C.c_int32),
-                        _p(a["rel_origin"]), _p(a["rel_axis"]), len(a["pairs"]), _p(a["pairs"], C.c_int32))
+                        _p(a["rel_origin"]), _p(a["rel_axis"]), len(a["pairs"]), _p(a["pairs"], C.c_int32),
+                        int(lig.get("n_movable", 0)), _p(a["pair_kind"], C.c_int32) if "pair_kind" in a else None,
+                        int(lig.get("lig_begin", 0)), int(lig.get("lig_end", 0)))
 
 
 def set_conf(lig, conf):
@@ -195,7 +202,7 @@ def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, te
     rng_kind 1 (default, also what the HIP kernel draws from): mt19937 + Boost's distributions as restated for
     oracle/_ref -- the chain follows the reference's step for step; 0: a counter-based splitmix stream (legacy)."""
     lig = scene.lig
-    nh = int((lig.arr["smt"] > 1).sum())
+    nh = int((lig.arr["smt"][:lig.n_movable] > 1).sum())
     P = McParams(n_steps, max_iters, num_saved, temperature, amplitude, min_rmsd, (C.c_float * 3)(10, 10, 10),
                  (C.c_float * 3)(1000, 1000, 1000))
     e = np.zeros(num_saved, dtype=np.float32)

@@ -355,7 +355,20 @@ typedef struct {
   const float *rel_axis;   /* [n_nodes][3] */
   int n_pairs;
   const int32_t *pairs;    /* [n_pairs][2] intramolecular interacting pairs (model.cpp:682-703) */
+  /* Flexible receptor residues (model.h: atoms = [flex movable | ligand | inflex]; tree.h:266-283,374-393):
+   *  - a node with parent -2 is a residue's first_segment: its frame hangs off the world (rel_origin / rel_axis are
+   *    absolute, no rigid-body entries), conf = [7 + T_ligand + T_flex];
+   *  - atoms outside every node are inflex: fixed at local_xyz, partners in pairs only;
+   *  - n_movable: atoms [0, n_movable) get the receptor term and keep forces (0 = all atoms);
+   *  - pair_kind [n_pairs]: 0 = ligand-internal (cap v[0]), 1 = model::other_pairs (cap v[2]); NULL = all 0.  Pairs
+   *    of kind 1 come first (model::eval_deriv adds other_pairs, then the ligand's; model.cu:209-216);
+   *  - [lig_begin, lig_end): the ligand's atoms (gyration radius); 0, 0 = all atoms. */
+  int n_movable;
+  const int32_t *pair_kind;
+  int lig_begin, lig_end;
 } ora_ligand;
+
+static int n_movable_of(const ora_ligand *L) { return L->n_movable > 0 ? L->n_movable : L->n_atoms; }
 
 static void g_normalize_angle(float *x) { /* quaternion.h:259-282 */
   if (*x > 3 * V_PI) {
@@ -428,6 +441,8 @@ static void mat_vec(const float *m, const float *v, float *o) { /* common.h:243-
 void ora_vina_set_conf(const ora_ligand *L, const float *conf, float *coords, float *origin, float *axis) {
   float *q = (float *)malloc(sizeof(float) * 4 * L->n_nodes);
   float *M = (float *)malloc(sizeof(float) * 9 * L->n_nodes);
+  /* inflex atoms belong to no node: they stay where the file has them */
+  memcpy(coords, L->local_xyz, sizeof(float) * 3 * (size_t)L->n_atoms);
   for (int k = 0; k < L->n_nodes; k++) {
     if (k == 0) {
       origin[0] = conf[0];
@@ -435,6 +450,10 @@ void ora_vina_set_conf(const ora_ligand *L, const float *conf, float *coords, fl
       origin[2] = conf[2];
       memcpy(q, conf + 3, sizeof(float) * 4); /* set_orientation does not normalize (tree.h:53-56) */
       axis[0] = axis[1] = axis[2] = 0;
+    } else if (L->parent[k] == -2) { /* first_segment::set_conf (tree.h:272-277): fixed origin and axis */
+      memcpy(origin + 3 * k, L->rel_origin + 3 * k, sizeof(float) * 3);
+      memcpy(axis + 3 * k, L->rel_axis + 3 * k, sizeof(float) * 3);
+      angle_to_quat(axis + 3 * k, conf[7 + (k - 1)], q + 4 * k);
     } else {
       int p = L->parent[k];
       float t[3];
@@ -517,6 +536,20 @@ static void node_derivative(const ora_ligand *L, int k, const float *coords, con
   ft[5] = tq[2];
 }
 
+/* ligands.derivative + flex.derivative (model.cu:219-221): the ligand's tree from node 0, every residue's from its
+ * first_segment (its torque . axis is the torsion derivative; nothing propagates above it, tree.h:374-393) */
+static void all_derivatives(const ora_ligand *L, const float *coords, const float *forces, const float *origin,
+                            const float *axis, float *change) {
+  float ft[6];
+  node_derivative(L, 0, coords, forces, origin, axis, change, ft);
+  for (int k = 1; k < L->n_nodes; k++)
+    if (L->parent[k] == -2) node_derivative(L, k, coords, forces, origin, axis, change, ft);
+}
+
+/* one pass over the interacting pairs: model::other_pairs (kind 1, cap v[2]) are summed first, the ligand's own
+ * (kind 0, cap v[0]) second, each on its own accumulator (model.cu:209-216: ie += other; ie += ligand) */
+#define PAIR_CAP(L, p, v) (((L)->pair_kind && (L)->pair_kind[p]) ? (v)[2] : (v)[0])
+
 /* model::eval_deriv (model.cu:202-225) with ig = cache (cache.cpp:65-83):
  *   set(c); e = sum over movable heavy atoms of grid::evaluate on its type's grid (v[1]);
  *   e += eval_interacting_pairs_deriv(ligand pairs, v[0]) (model.cu:38-60);
@@ -534,7 +567,7 @@ float ora_vina_model_eval_deriv(const ora_vina_tables *T, const ora_grid_dims *g
   float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
   float e = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n_movable_of(L); i++) {
     int t = L->smt[i];
     if (is_hydrogen(t) || !grids[t]) continue; /* minus_forces[i] = 0 */
     float d[3];
@@ -544,28 +577,30 @@ float ora_vina_model_eval_deriv(const ora_vina_tables *T, const ora_grid_dims *g
     forces[3 * i + 2] = d[2];
   }
   float ie = 0;
-  for (int p = 0; p < L->n_pairs; p++) {
-    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
-    float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
-                  coords[3 * b + 2] - coords[3 * a + 2]};
-    float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-    if (r2 < T->cutoff_sqr) {
-      float pe, dor;
-      ora_vina_table_eval_deriv(T, L->smt[a], L->smt[b], r2, &pe, &dor);
-      float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
-      curl3(&pe, force, v[0]);
-      ie += pe;
-      for (int k = 0; k < 3; k++) {
-        forces[3 * a + k] -= force[k];
-        forces[3 * b + k] += force[k];
+  for (int kind = 1; kind >= 0; kind--) {
+    float sum = 0;
+    for (int p = 0; p < L->n_pairs; p++) {
+      if ((L->pair_kind ? L->pair_kind[p] : 0) != kind) continue;
+      int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+      float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
+                    coords[3 * b + 2] - coords[3 * a + 2]};
+      float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      if (r2 < T->cutoff_sqr) {
+        float pe, dor;
+        ora_vina_table_eval_deriv(T, L->smt[a], L->smt[b], r2, &pe, &dor);
+        float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
+        curl3(&pe, force, PAIR_CAP(L, p, v));
+        sum += pe;
+        for (int k = 0; k < 3; k++) {
+          forces[3 * a + k] -= force[k];
+          forces[3 * b + k] += force[k];
+        }
       }
     }
+    ie += sum;
   }
   e += ie;
-  if (change) {
-    float ft[6];
-    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
-  }
+  if (change) all_derivatives(L, coords, forces, origin, axis, change);
   if (coords_out) memcpy(coords_out, coords, sizeof(float) * 3 * n);
   if (forces_out) memcpy(forces_out, forces, sizeof(float) * 3 * n);
   free(coords);
@@ -694,10 +729,7 @@ void ora_vina_forces_to_change(const ora_ligand *L, const float *conf, const flo
   float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
-  if (forces && change) {
-    float ft[6];
-    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
-  }
+  if (forces && change) all_derivatives(L, coords, forces, origin, axis, change);
   if (coords_out) memcpy(coords_out, coords, sizeof(float) * 3 * n);
   free(coords);
   free(origin);
@@ -825,25 +857,30 @@ float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
   float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
   float e = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n_movable_of(L); i++) {
     int t = L->smt[i];
     if (is_hydrogen(t) || !grids[t]) continue;
     e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v[1], NULL);
   }
-  float ie = 0; /* eval_interacting_pairs sums on its own, model::eval adds the total (model.cu:22-36,118-123) */
-  for (int p = 0; p < L->n_pairs; p++) {
-    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
-    float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
-          dz = coords[3 * a + 2] - coords[3 * b + 2];
-    float r2 = dx * dx + dy * dy + dz * dz;
-    if (r2 < T->cutoff_sqr) {
-      /* p.eval = eval_fast(...) in the reference (precalculate.h:67-70): midpoint table */
-      float pe = ora_vina_eval_fast(T, L->smt[a], L->smt[b], r2);
-      curl1(&pe, v[0]);
-      ie += pe;
+  /* eval_interacting_pairs sums on its own; model::evale adds other_pairs, model::eval then the ligand's
+   * (model.cu:22-36,112-123) */
+  for (int kind = 1; kind >= 0; kind--) {
+    float ie = 0;
+    for (int p = 0; p < L->n_pairs; p++) {
+      if ((L->pair_kind ? L->pair_kind[p] : 0) != kind) continue;
+      int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+      float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
+            dz = coords[3 * a + 2] - coords[3 * b + 2];
+      float r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 < T->cutoff_sqr) {
+        /* p.eval = eval_fast(...) in the reference (precalculate.h:67-70): midpoint table */
+        float pe = ora_vina_eval_fast(T, L->smt[a], L->smt[b], r2);
+        curl1(&pe, PAIR_CAP(L, p, v));
+        ie += pe;
+      }
     }
+    e += ie;
   }
-  e += ie;
   free(coords);
   free(origin);
   free(axis);
@@ -860,7 +897,7 @@ float ora_vina_cache_eval(const ora_grid_dims *gd, const float *const *grids, fl
   float *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
   float e = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n_movable_of(L); i++) {
     int t = L->smt[i];
     if (is_hydrogen(t) || !grids[t]) continue;
     e += ora_vina_grid_evaluate(gd, grids[t], coords + 3 * i, slope, v1, NULL);
@@ -996,7 +1033,8 @@ static void mc_mutate(const ora_ligand *L, ora_rng *rng, float amplitude, float 
     ora_vina_set_conf(L, model_conf, coords, origin, axis);
     float acc = 0;
     int cnt = 0;
-    for (int i = 0; i < na; i++)
+    const int lb = L->lig_end > L->lig_begin ? L->lig_begin : 0, le = L->lig_end > L->lig_begin ? L->lig_end : na;
+    for (int i = lb; i < le; i++) /* model::gyration_radius: the ligand's atoms (model.cpp:1002-1014) */
       if (!is_hydrogen(L->smt[i])) {
         float dx = coords[3 * i] - origin[0], dy = coords[3 * i + 1] - origin[1], dz = coords[3 * i + 2] - origin[2];
         acc += dx * dx + dy * dy + dz * dz;
@@ -1037,14 +1075,14 @@ void ora_vina_mutate(const ora_ligand *L, int rng_kind, uint64_t seed, float amp
 int ora_vina_mc_chain_rng(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
                           const ora_ligand *L, const float *corner1, const float *corner2, uint64_t seed, int rng_kind,
                           const float *conf0, const ora_mc_params *P, float *out_e, float *out_conf, float *out_coords, long *evals_out) {
-  const int nt = L->n_nodes - 1, nc = 7 + nt, na = L->n_atoms;
+  const int nt = L->n_nodes - 1, nc = 7 + nt, na = n_movable_of(L); /* get_heavy_atom_movable_coords: movable atoms */
   int nh = 0;
   for (int i = 0; i < na; i++) nh += !is_hydrogen(L->smt[i]);
   ora_rng rng;
   rng_seed(&rng, rng_kind, seed);
   float *tmp = (float *)malloc(sizeof(float) * nc), *cand = (float *)malloc(sizeof(float) * nc),
         *model_conf = (float *)malloc(sizeof(float) * nc);
-  float *coords = (float *)malloc(sizeof(float) * 3 * na), *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes),
+  float *coords = (float *)malloc(sizeof(float) * 3 * L->n_atoms), *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes),
         *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *hc = (float *)malloc(sizeof(float) * 3 * nh);
   long evals = 0;
   /* conf::randomize */
@@ -1228,7 +1266,7 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
   float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
   float e = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n_movable_of(L); i++) {
     int t1 = L->smt[i];
     if (is_hydrogen(t1)) continue;
     float adj[3], oob_d[3] = {0, 0, 0}, oob = 0;
@@ -1275,33 +1313,35 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
     e += this_e + oob;
   }
   float ie = 0;
-  for (int p = 0; p < L->n_pairs; p++) {
-    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
-    float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
-                  coords[3 * b + 2] - coords[3 * a + 2]};
-    float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-    if (r2 < T->cutoff_sqr) {
-      if (deriv) {
-        float pe, dor;
-        prec_eval_deriv(T, w, exact, L->smt[a], L->smt[b], r2, &pe, &dor);
-        float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
-        curl3(&pe, force, v[0]);
-        ie += pe;
-        for (int k = 0; k < 3; k++) {
-          forces[3 * a + k] -= force[k];
-          forces[3 * b + k] += force[k];
+  for (int kind = 1; kind >= 0; kind--) {
+    float sum = 0;
+    for (int p = 0; p < L->n_pairs; p++) {
+      if ((L->pair_kind ? L->pair_kind[p] : 0) != kind) continue;
+      int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+      float r[3] = {coords[3 * b] - coords[3 * a], coords[3 * b + 1] - coords[3 * a + 1],
+                    coords[3 * b + 2] - coords[3 * a + 2]};
+      float r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      if (r2 < T->cutoff_sqr) {
+        if (deriv) {
+          float pe, dor;
+          prec_eval_deriv(T, w, exact, L->smt[a], L->smt[b], r2, &pe, &dor);
+          float force[3] = {dor * r[0], dor * r[1], dor * r[2]};
+          curl3(&pe, force, PAIR_CAP(L, p, v));
+          sum += pe;
+          for (int k = 0; k < 3; k++) {
+            forces[3 * a + k] -= force[k];
+            forces[3 * b + k] += force[k];
+          }
+        } else {
+          float pe = prec_eval(T, w, exact, L->smt[a], L->smt[b], r2);
+          curl1(&pe, PAIR_CAP(L, p, v));
+          sum += pe;
         }
-      } else {
-        float pe = prec_eval(T, w, exact, L->smt[a], L->smt[b], r2);
-        curl1(&pe, v[0]);
-        ie += pe;
       }
     }
+    ie += sum;
   }
-  if (deriv && change) {
-    float ft[6];
-    node_derivative(L, 0, coords, forces, origin, axis, change, ft);
-  }
+  if (deriv && change) all_derivatives(L, coords, forces, origin, axis, change);
   if (inter_out) *inter_out = e;
   if (intra_out) *intra_out = ie;
   free(coords);
@@ -1318,7 +1358,7 @@ int ora_vina_within(const ora_grid_dims *gd, const ora_ligand *L, const float *c
   float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
   ora_vina_set_conf(L, conf, coords, origin, axis);
   int ok = 1;
-  for (int i = 0; i < n && ok; i++) {
+  for (int i = 0; i < n_movable_of(L) && ok; i++) {
     if (is_hydrogen(L->smt[i])) continue;
     for (int k = 0; k < 3; k++)
       if (gd->n[k] > 0 && (coords[3 * i + k] < gd->begin[k] - 0.0001f || coords[3 * i + k] > gd->end[k] + 0.0001f)) ok = 0;

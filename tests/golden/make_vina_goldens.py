@@ -28,24 +28,32 @@ def lattice(b, e, n, idx):
                     1).astype(np.float32)
 
 
-def case(G, name, rigid, lig_text, center=None, size=None, seed=0, mc=((1, 60), (2, 200))):
-    s = ref.Scene(rigid, lig_text)
+def case(G, name, rigid, lig_text, center=None, size=None, seed=0, mc=((1, 60), (2, 200)), flex_text=None):
+    s = ref.Scene(rigid, lig_text, flex_text=flex_text)
     xyz, smt, _ = s.atoms()
     rx, rs = s.grid_atoms()
     if center is None:
-        center, size = RC.box_of(xyz)
+        center, size = RC.box_of(xyz[:s.n_movable])
     b, e, n = s.build_grids(center, size)
     rng = np.random.RandomState(seed)
     conf0 = s.initial_conf()
     P = name + "/"
     G[P + "lig_text"] = np.frombuffer(lig_text.encode(), dtype=np.uint8)
+    if flex_text is not None:
+        # the description our reader builds from (rigid, flex, ligand) -- checked against the reference's model in
+        # tests/test_ref_vina.py -- so that the GPU test needs no reference file
+        from gnina_amd import capi
+        _, _, d = capi.read_pdbqt_model(rigid, flex_text, lig_text, is_text=True)
+        for k in ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs", "pair_kind", "conf0"):
+            G[P + "desc/" + k] = np.asarray(d[k])
+        G[P + "desc/ints"] = np.array([d["n_movable"], d["lig_begin"], d["lig_end"]], np.int32)
     G[P + "rec_xyz"], G[P + "rec_smt"] = rx, rs
     G[P + "center"], G[P + "size"] = np.asarray(center, np.float32), np.asarray(size, np.float32)
     G[P + "begin"], G[P + "end"], G[P + "n"] = b, e, n
     G[P + "atoms_xyz"], G[P + "atoms_smt"], G[P + "pairs"] = xyz, smt, s.pairs()[0]
     G[P + "conf0"] = conf0
     G[P + "num_tors_div_of_100"] = np.float32(s.conf_independent(100.0))
-    types = sorted(set(int(t) for t in smt if t > 1))
+    types = sorted(set(int(t) for t in smt[:s.n_movable] if t > 1))
     G[P + "types"] = np.array(types, np.int32)
     idx = rng.randint(0, [n[0] + 1, n[1] + 1, n[2] + 1], size=(600, 3)).astype(np.int32)
     G[P + "grid_idx"] = idx
@@ -66,9 +74,10 @@ def case(G, name, rigid, lig_text, center=None, size=None, seed=0, mc=((1, 60), 
     G[P + "noncache/eval"] = np.array([s.eval(c, V3, ig=1) for c in confs], np.float32)
     G[P + "noncache/ig_eval"] = np.array([s.ig_eval(c, 1000.0, ig=1) for c in confs], np.float32)
     G[P + "within"] = np.array([s.within(c) for c in confs])
-    fe = [s.final_energies(c) for c in confs]
-    G[P + "final/e"] = np.array([x[0] for x in fe], np.float32)
-    G[P + "final/intra"] = np.array([x[1] for x in fe], np.float32)
+    if flex_text is None:
+        fe = [s.final_energies(c) for c in confs]
+        G[P + "final/e"] = np.array([x[0] for x in fe], np.float32)
+        G[P + "final/intra"] = np.array([x[1] for x in fe], np.float32)
     mi = (25 + s.n_movable) // 3
     G[P + "max_iters"] = np.int32(mi)
     for tag, v in (("v1000", V3), ("v10", HUNT)):
@@ -100,6 +109,9 @@ def main():
     G = {}
     case(G, "adduct", rigid, RC.cys_adduct_ligand())
     case(G, "chain", rigid, RC.long_chain_ligand(), seed=1)
+    # flexible side chain (the reference's flex_res_side_chain fixture) + a small ligand next to it
+    case(G, "flex", rigid, RC.long_chain_ligand(n=8, origin=(-9.0, 12.0, 3.0)), seed=3,
+         flex_text=open(RC.FLEX_RES).read(), mc=((1, 40),))
     # a box whose lattice hits szv_grid's 3 A cell boundaries exactly (degenerate candidate bricks)
     case(G, "aligned", rigid, RC.cys_adduct_ligand(), np.array([-7.5, 9.0, 0.7], np.float32),
          np.array([15.0, 16.0, 14.0], np.float32), seed=2, mc=((1, 40),))

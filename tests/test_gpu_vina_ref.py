@@ -154,3 +154,49 @@ def test_monte_carlo_follows_the_references_chains(capi, name):
                    for b in range(len(seeds)))
         assert same >= need, (name, steps, same)
         assert (n >= 1).all()
+
+
+def test_flexible_residues_in_the_search_on_the_device(capi):
+    """the side chain of a flexible residue moves with the ligand -- flex.derivative (tree.h:374-393),
+    model::other_pairs with their own curl cap (model.cu:209-213), the receptor term of the movable side-chain atoms,
+    conf = [7 + T_ligand + T_flex] -- against what the reference computes on the same model (frozen from oracle/_ref;
+    the description comes from our reader, checked against the reference's model in tests/test_ref_vina.py)."""
+    P = "flex/"
+    d = {k: G[P + "desc/" + k] for k in ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs",
+                                         "pair_kind", "conf0")}
+    d["n_movable"], d["lig_begin"], d["lig_end"] = (int(x) for x in G[P + "desc/ints"])
+    v = capi.Vina()
+    v.set_receptor(G[P + "rec_xyz"], G[P + "rec_smt"])
+    v.build_cache(list(G[P + "begin"]), list(G[P + "end"]), [int(x) for x in G[P + "n"]], [int(t) for t in G[P + "types"]], 1e3)
+    v.set_ligand(d)
+    confs = G[P + "confs"]
+    assert confs.shape[1] == 7 + 6 + 10
+    for tag, cap in (("v1000", V3), ("v10", HUNT)):
+        e, ch, co = v.eval_batch(confs, cap, deriv=True, want_coords=True)
+        assert np.abs(co - G[P + tag + "/coords"]).max() < 1e-4
+        for b in range(len(confs)):
+            e0, g0 = G[P + tag + "/e"][b], G[P + tag + "/change"][b]
+            assert abs(e[b] - e0) <= 1e-4 * max(1.0, abs(e0)), (tag, b, e[b], e0)
+            assert np.abs(ch[b] - g0).max() <= 1e-3 * max(1.0, np.abs(g0).max()), (tag, b)
+        e2 = v.eval_batch(confs, cap, deriv=False)[0]
+        e3 = v.eval_batch(confs, cap, grid_only=True)[0]
+        assert close(e2, G[P + tag + "/eval"], 1e-4) and close(e3, G[P + tag + "/ig_eval"], 1e-4)
+    e, ch, _ = v.eval_batch(confs, V3, deriv=True, direct=True)
+    for b in range(len(confs)):
+        assert abs(e[b] - G[P + "noncache/e"][b]) <= 1e-4 * max(1.0, abs(G[P + "noncache/e"][b]))
+        assert np.abs(ch[b] - G[P + "noncache/change"][b]).max() <= 1e-3 * max(1.0, np.abs(G[P + "noncache/change"][b]).max())
+    mi = int(G[P + "max_iters"])
+    for iters, need in ((1, 12), (3, 8)):
+        e, cf, g, ev = v.bfgs_batch(confs[:12], HUNT, max_iters=iters)
+        e0, c0 = G[P + f"bfgs/v10/{iters}/e"], G[P + f"bfgs/v10/{iters}/conf"]
+        same = sum(abs(e[b] - e0[b]) <= 1e-3 * max(1.0, abs(e0[b])) and np.abs(cf[b] - c0[b]).max() < 1e-2 for b in range(12))
+        assert same >= need, (iters, same)
+    # a Monte-Carlo search that moves the side chain: short chains follow the reference's
+    seeds = np.arange(100, 132, dtype=np.uint64)
+    n, e, cf, xyz, ev = v.mc_batch(seeds, list(G[P + "begin"]), list(G[P + "end"]), capi.McParams.default(1, 2, 20))
+    e0, c0 = G[P + "mcshort/1/e0"], G[P + "mcshort/1/conf0"]
+    same = sum(abs(e[b, 0] - e0[b]) <= 1e-3 * max(1.0, abs(e0[b])) and np.abs(cf[b, 0] - c0[b]).max() < 1e-2 for b in range(32))
+    assert same >= 22, same
+    n, e, cf, xyz, ev = v.mc_batch(seeds[:8], list(G[P + "begin"]), list(G[P + "end"]), capi.McParams.default(150, mi, 20))
+    assert (n >= 1).all() and np.isfinite(e[:, 0]).all()
+    assert np.abs(cf[:, 0, 13:] - d["conf0"][13:]).max() > 1e-3            # the residue's torsions were searched too

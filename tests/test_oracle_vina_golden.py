@@ -100,3 +100,41 @@ def test_bfgs_and_monte_carlo(capi, name):
         base = key[:-2]
         assert np.array_equal(e, G[base + "/e"]) and np.array_equal(cf, G[base + "/conf"])
         assert np.array_equal(xyz, G[base + "/coords"])
+
+
+def _flex_desc():
+    P = "flex/desc/"
+    d = {k: G[P + k] for k in ("smt", "local_xyz", "parent", "abeg", "aend", "rel_origin", "rel_axis", "pairs",
+                               "pair_kind", "conf0")}
+    d["n_movable"], d["lig_begin"], d["lig_end"] = (int(x) for x in G[P + "ints"])
+    d["n_tors"] = len(d["parent"]) - 1
+    return d
+
+
+def test_flexible_residues_in_the_search():
+    """model = rigid + flexible side chain + ligand (SURVEY 8f row 4): eval_deriv / eval / cache::eval / non_cache,
+    whole BFGS runs over 6 + T_ligand + T_flex variables and a Monte-Carlo chain, against the frozen reference."""
+    P = "flex/"
+    d = _flex_desc()
+    gd = V.setup_grid_dims(G[P + "center"], G[P + "size"])
+    T = V.Tables()
+    h = V.LigandHandle(d)
+    rx, rs = G[P + "rec_xyz"], G[P + "rec_smt"]
+    grids = {int(t): V.cache_populate(T, gd, rx, rs, int(t)) for t in G[P + "types"]}
+    S = V.Scene(T, gd, grids, h)
+    assert np.array_equal(d["conf0"], G[P + "conf0"])
+    mi = int(G[P + "max_iters"])
+    for i, conf in enumerate(G[P + "confs"]):
+        for tag, v in (("v1000", V3), ("v10", HUNT)):
+            e, ch, xyz, _ = S.eval_deriv(conf, v)
+            assert e == G[P + tag + "/e"][i] and np.array_equal(ch, G[P + tag + "/change"][i])
+            assert np.array_equal(xyz, G[P + tag + "/coords"][i])
+            assert S.eval(conf, v) == G[P + tag + "/eval"][i] and V.cache_eval(S, conf, v[1]) == G[P + tag + "/ig_eval"][i]
+        e, ch, _, _ = V.noncache_eval(S, rx, rs, conf, V3)
+        assert e == G[P + "noncache/e"][i] and np.array_equal(ch, G[P + "noncache/change"][i])
+        if i < 12:
+            e, x, g, _ = S.bfgs(conf, HUNT, max_iters=mi)
+            assert e == G[P + f"bfgs/v10/{mi}/e"][i] and np.array_equal(x, G[P + f"bfgs/v10/{mi}/conf"][i])
+    e, cf, xyz, _ = V.mc_chain(S, G[P + "begin"], G[P + "end"], 1, 40, mi, num_saved=20, rng_kind=1, conf0=d["conf0"])
+    assert np.array_equal(e, G[P + "mc/1_40/e"]) and np.array_equal(cf, G[P + "mc/1_40/conf"])
+    assert np.array_equal(xyz, G[P + "mc/1_40/coords"])

@@ -282,3 +282,64 @@ def test_monte_carlo_chains_are_bit_identical(which, steps, request):
                                    conf0=c.lig["conf0"])
         assert len(er) == len(eo) >= 1
         assert np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
+
+
+# ---- flexible residues in the search: model = rigid + flex + ligand ----------------------------
+@pytest.fixture(scope="module")
+def flexcase(capi, rigid_text):
+    flex = open(RC.FLEX_RES).read()
+    lig_txt = RC.long_chain_ligand(n=8, origin=(-9.0, 12.0, 3.0))
+    s = ref.Scene(rigid_text, lig_txt, flex_text=flex)
+    rx, rs, d = capi.read_pdbqt_model(rigid_text, flex, lig_txt, is_text=True)
+    center, size = RC.box_of(d["coords0"][:d["n_movable"]])
+    b, e, n = s.build_grids(center, size)
+    gd = V.setup_grid_dims(center, size)
+    T = V.Tables()
+    types = sorted(set(int(t) for t in d["smt"][:d["n_movable"]] if t > 1))
+    grids = {t: V.cache_populate(T, gd, rx, rs, t) for t in types}
+    h = V.LigandHandle(d)
+    return dict(ref=s, d=d, rx=rx, rs=rs, b=b, e=e, ora=V.Scene(T, gd, grids, h), h=h)
+
+
+def test_flex_model_is_the_references(flexcase):
+    """parse_receptor_pdbqt(rigid, flex) + m.append(ligand): atom order [flex movable | ligand | inflex], types of the
+    combined receptor model, model::other_pairs (initialize_pairs + every receptor-model / ligand atom pair of
+    model::append, hydrogens included) and the ligand's pairs in the reference's order, conf = [7 + T_lig + T_flex]."""
+    s, d = flexcase["ref"], flexcase["d"]
+    xyz, smt, _ = s.atoms()
+    assert s.n_flex == 1 and s.n_flex_tors == 10 == d["n_flex_tors"] and s.n_lig_tors == d["n_lig_tors"]
+    assert np.array_equal(smt, d["smt"]) and np.array_equal(xyz, d["coords0"]) and s.n_movable == d["n_movable"]
+    assert (s.lig_begin, s.lig_end) == (d["lig_begin"], d["lig_end"])
+    gx, gs = s.grid_atoms()
+    assert np.array_equal(gs, flexcase["rs"]) and np.array_equal(gx, flexcase["rx"])
+    assert np.array_equal(s.pairs(other=True)[0], d["pairs"][d["pair_kind"] == 1])
+    assert np.array_equal(s.pairs()[0], d["pairs"][d["pair_kind"] == 0])
+    assert np.array_equal(s.initial_conf(), d["conf0"])
+    rng = np.random.RandomState(0)
+    for conf in RC.random_confs(rng, d["conf0"], 5):
+        assert np.array_equal(s.set_conf(conf), V.set_conf(flexcase["h"], conf)[0])
+
+
+def test_flex_energies_bfgs_and_monte_carlo_bit_identical(flexcase):
+    """flex.derivative (tree.h:374-393), other_pairs with the v[2] cap (model.cu:209-213), the receptor term of the
+    movable side-chain atoms, BFGS over 6 + T_lig + T_flex variables, mutate_conf over ligand AND residue torsions."""
+    s, d, ora = flexcase["ref"], flexcase["d"], flexcase["ora"]
+    rng = np.random.RandomState(1)
+    mi = (25 + s.n_movable) // 3
+    for conf in np.concatenate([RC.random_confs(rng, d["conf0"], 3, small=True), RC.random_confs(rng, d["conf0"], 2)]):
+        for v in (V3, HUNT):
+            er, cr, xr, fr = s.eval_deriv(conf, v)
+            eo, co, xo, fo = ora.eval_deriv(conf, v)
+            assert er == eo and np.array_equal(cr, co) and np.array_equal(xr, xo)
+            assert s.eval(conf, v) == ora.eval(conf, v) and s.ig_eval(conf, v[1]) == V.cache_eval(ora, conf, v[1])
+            er, xr, gr = s.bfgs(conf, v, max_iters=mi)
+            eo, xo, go, _ = ora.bfgs(conf, v, max_iters=mi)
+            assert er == eo and np.array_equal(xr, xo) and np.array_equal(gr, go)
+        er, cr, _, _ = s.eval_deriv(conf, V3, ig=1)
+        eo, co, _, _ = V.noncache_eval(ora, flexcase["rx"], flexcase["rs"], conf, V3)
+        assert er == eo and np.array_equal(cr, co)
+    for seed, steps in ((1, 5), (2, 80), (3, 400)):
+        er, cr, xr = s.mc(seed, steps, flexcase["b"], flexcase["e"], max_iters=mi, num_saved=20)
+        eo, co, xo, _ = V.mc_chain(ora, flexcase["b"], flexcase["e"], seed, steps, mi, num_saved=20, rng_kind=1,
+                                   conf0=d["conf0"])
+        assert np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
