@@ -96,6 +96,16 @@ struct VinaMcArgs {
   int conf_stride, coord_stride;
 };
 
+// resumable chains of vina_mc_cnn_kernel (CNN as the Metropolis energy)
+struct VinaMcCnnState {
+  int phase, step;     // see vina_mc_cnn_kernel
+  float *st_f;         // [B][f_stride]
+  int *st_i;           // [B][i_stride]
+  int f_stride, i_stride;
+  const float *ext_e;  // [B] non_cache_cnn::eval of what model_out held
+  float *model_out;    // [B][7 + T]
+};
+
 struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN loss + per-atom gradient)
   const float *forces;      // [B][n_atoms][3] or nullptr (energy only)
   const float *e_in;        // [B] or nullptr
@@ -138,6 +148,8 @@ void launch_vina_extforce(const VinaEnv &env, const VinaLigand &lig, const float
 size_t vina_mc_lds_bytes(int n_atoms, int n_nodes, int n_pairs, int n_heavy, int num_saved, bool stage, int waves_per_chain);
 void launch_vina_cache_coords(const VinaEnv &env, const float *coords, const int *smt, int n_atoms, int B, float v,
                               float *energy, float *minus_forces, hipStream_t s);
+void launch_vina_mc_cnn(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, const VinaMcCnnState &st, int B,
+                        hipStream_t s);
 int vina_mc_team(int B);  // waves per chain the Monte-Carlo kernel uses for B chains
 // `lig` sizes the LDS workspace (screen mode: counts = the maxima over the set, pointers unused)
 void launch_vina_mc(const VinaEnv &env, const VinaLigand &lig, const VinaMcArgs &a, int B, hipStream_t s);

@@ -1605,6 +1605,145 @@ struct McRng {
   }
 };
 
+// add_to_output_container (coords.cpp:25-56) + out.sort() for one chain, run by one wave: the candidate (tmp, hc,
+// tmp_e) against the chain's physical container (s_e / s_conf / s_xyz in global memory) through `ord` (sorted position
+// -> physical slot) with the scratch `rm`.  Returns the container's new size.  wsync() orders the lanes' accesses.
+__device__ __forceinline__ int container_insert(const VinaMcArgs &a, float *s_e, float *s_conf, float *s_xyz, int cs_,
+                                                int xs_, int *ord, float *rm, const float *tmp, const float *hc,
+                                                float tmp_e, int n_out, int nc, int nh) {
+  const int lane = threadIdx.x & 63;
+  // rmsd to every saved pose, one pose per lane
+  for (int o = lane; o < n_out; o += 64) {
+    const float *ref = s_xyz + (size_t)ord[o] * xs_;
+    float acc = 0.f;
+    for (int i = 0; i < nh; i++) {  // rmsd_upper_bound: one vec_distance_sqr per atom (coords.cpp:25-32)
+      const float dx = hc[3 * i] - ref[3 * i], dy = hc[3 * i + 1] - ref[3 * i + 1], dz = hc[3 * i + 2] - ref[3 * i + 2];
+      acc += dx * dx + dy * dy + dz * dz;
+    }
+    rm[o & 63] = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;
+  }
+  wsync();
+  int closest = n_out;
+  float closest_rmsd = VMAXFL;
+  for (int o = 0; o < n_out && o < 64; o++) {  // first minimum, like find_closest
+    const float r = rm[o];
+    if (o == 0 || r < closest_rmsd) {
+      closest = o;
+      closest_rmsd = r;
+    }
+  }
+  int pos = -1;
+  if (closest < n_out && closest_rmsd < a.min_rmsd) {
+    if (tmp_e < s_e[ord[closest]]) pos = closest;
+  } else if (n_out < a.num_saved) {
+    pos = n_out;
+    if (lane == 0) ord[pos] = n_out;
+    n_out++;
+  } else if (n_out > 0 && tmp_e < s_e[ord[n_out - 1]]) {
+    pos = n_out - 1;
+  }
+  wsync();
+  if (pos >= 0) {
+    const int phys = ord[pos];
+    if (lane == 0) s_e[phys] = tmp_e;
+    for (int i = lane; i < nc; i += 64) s_conf[(size_t)phys * cs_ + i] = tmp[i];
+    for (int i = lane; i < 3 * nh; i += 64) s_xyz[(size_t)phys * xs_ + i] = hc[i];
+    wsync();
+    if (lane == 0) {  // out.sort(): keep `ord` ordered by energy
+      int o = pos;
+      while (o > 0 && s_e[ord[o]] < s_e[ord[o - 1]]) {
+        const int t = ord[o];
+        ord[o] = ord[o - 1];
+        ord[o - 1] = t;
+        o--;
+      }
+      while (o + 1 < n_out && s_e[ord[o + 1]] < s_e[ord[o]]) {
+        const int t = ord[o];
+        ord[o] = ord[o + 1];
+        ord[o + 1] = t;
+        o++;
+      }
+    }
+    wsync();
+  }
+  return n_out;
+}
+
+// mutate_conf (mutate.cpp:35-73) of the conformation in x (LDS), one wave; mconf = what `model` holds (gyration radius)
+template <int PG>
+__device__ __forceinline__ void mutate_wave(const VinaEnv &env, const VinaLigand &L, const WaveWork &w, McRng &rng, float *x,
+                                            const float *mconf, float amplitude) {
+  const int lane = threadIdx.x & 63, nt = L.n_nodes - 1;
+  const int which = rng.irange(0, 2 + nt - 1);
+  if (which == 0) {
+    float dx, dy, dz;
+    rng.inside_sphere(dx, dy, dz);
+    if (lane == 0) {
+      x[0] += amplitude * dx;
+      x[1] += amplitude * dy;
+      x[2] += amplitude * dz;
+    }
+  } else if (which == 1) {
+    (void)eval_conf<3, PG>(env, L, mconf, 0.f, 0.f, 0.f, w, nullptr);  // the coordinates `model` holds
+    float acc = 0.f;
+    int n_gyr = 0;
+    for (int i = L.lig_begin; i < L.lig_end; i++) n_gyr += L.smt[i] > 1;
+    for (int i = L.lig_begin + lane; i < L.lig_end; i += 64)
+      if (L.smt[i] > 1) {
+        const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
+                    dz = w.coords[3 * i + 2] - w.origin[2];
+        acc += dx * dx + dy * dy + dz * dz;
+      }
+    acc = wave_sum(acc);
+    const float gr = n_gyr > 0 ? sqrtf(acc / (float)n_gyr) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
+    if (gr > VEPS) {
+      float dx, dy, dz;
+      rng.inside_sphere(dx, dy, dz);
+      const float sc = amplitude / gr;
+      if (lane == 0) {
+        float rot[6] = {0.f, 0.f, 0.f, sc * dx, sc * dy, sc * dz};
+        conf_increment(x, rot, 1.0f, 0);
+      }
+    }
+  } else {
+    const float tv = rng.fl(-VPI, VPI);
+    if (lane == 0) x[7 + (which - 2)] = tv;
+  }
+  wave_sync();
+}
+
+// conf::randomize (conf.h:119-122,189-192) into x (LDS): every lane draws the same numbers
+__device__ __forceinline__ void randomize_wave(McRng &rng, float *x, const float *c1, const float *c2, int nt) {
+  const int lane = threadIdx.x & 63;
+  float px = rng.fl(c1[0], c2[0]), py = rng.fl(c1[1], c2[1]), pz = rng.fl(c1[2], c2[2]);
+  float q0, q1, q2, q3, nrm;
+  do {  // random_orientation (quaternion.cu:81-94); abs(qt) scales by the largest component (quaternion.h:169-190)
+    q0 = rng.normal();
+    q1 = rng.normal();
+    q2 = rng.normal();
+    q3 = rng.normal();
+    const float maxim = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3)));
+    nrm = 0.f;
+    if (maxim != 0.f) {
+      const float mixam = (float)(1.0 / (double)maxim);
+      const float v0 = q0 * mixam, v1 = q1 * mixam, v2 = q2 * mixam, v3 = q3 * mixam;
+      float sum = v0 * v0;
+      sum += v1 * v1;
+      sum += v2 * v2;
+      sum += v3 * v3;
+      nrm = maxim * sqrtf(sum);
+    }
+  } while (!(nrm > VEPS));
+  if (lane == 0) {
+    x[0] = px, x[1] = py, x[2] = pz;
+    x[3] = q0 / nrm, x[4] = q1 / nrm, x[5] = q2 / nrm, x[6] = q3 / nrm;
+  }
+  for (int t = 0; t < nt; t++) {
+    float tv = rng.fl(-VPI, VPI);
+    if (lane == 0) x[7 + t] = tv;
+  }
+}
+
 // W = blockDim.x / 64 waves per chain (see WaveTeam): every wave replays the whole chain -- same RNG stream,
 // same decisions -- and they share the work only inside the BFGS line searches.  Wave 0 alone owns the output
 // container (global memory) and publishes what the others need (the container's size) through LDS.
@@ -1659,35 +1798,8 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   float *s_conf = a.scratch_conf + (size_t)b * a.num_saved * cs_;
   float *s_xyz = a.scratch_coords + (size_t)b * a.num_saved * xs_;
 
-  // conf::randomize (conf.h:119-122,189-192): every lane draws the same numbers
   {
-    float px = rng.fl(a.c1[0], a.c2[0]), py = rng.fl(a.c1[1], a.c2[1]), pz = rng.fl(a.c1[2], a.c2[2]);
-    float q0, q1, q2, q3, nrm;
-    do {  // random_orientation (quaternion.cu:81-94); abs(qt) scales by the largest component (quaternion.h:169-190)
-      q0 = rng.normal();
-      q1 = rng.normal();
-      q2 = rng.normal();
-      q3 = rng.normal();
-      const float maxim = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3)));
-      nrm = 0.f;
-      if (maxim != 0.f) {
-        const float mixam = (float)(1.0 / (double)maxim);
-        const float v0 = q0 * mixam, v1 = q1 * mixam, v2 = q2 * mixam, v3 = q3 * mixam;
-        float sum = v0 * v0;
-        sum += v1 * v1;
-        sum += v2 * v2;
-        sum += v3 * v3;
-        nrm = maxim * sqrtf(sum);
-      }
-    } while (!(nrm > VEPS));
-    if (lane == 0) {
-      tmp[0] = px, tmp[1] = py, tmp[2] = pz;
-      tmp[3] = q0 / nrm, tmp[4] = q1 / nrm, tmp[5] = q2 / nrm, tmp[6] = q3 / nrm;
-    }
-    for (int t = 0; t < nt; t++) {
-      float tv = rng.fl(-VPI, VPI);
-      if (lane == 0) tmp[7 + t] = tv;
-    }
+    randomize_wave(rng, tmp, a.c1, a.c2, nt);
     // before the first evaluation `model` holds the input pose: zero torsions (its rigid placement does not matter
     // to the gyration radius, the only thing read from it)
     for (int i = lane; i < nc; i += 64) mconf[i] = i == 3 ? 1.f : 0.f;
@@ -1710,43 +1822,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
   for (int step = 0; step < a.n_steps; step++) {
     for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
     wave_sync();
-    // mutate_conf (mutate.cpp:35-73)
-    const int which = rng.irange(0, 2 + nt - 1);
-    if (which == 0) {
-      float dx, dy, dz;
-      rng.inside_sphere(dx, dy, dz);
-      if (lane == 0) {
-        k.x[0] += a.amplitude * dx;
-        k.x[1] += a.amplitude * dy;
-        k.x[2] += a.amplitude * dz;
-      }
-    } else if (which == 1) {
-      (void)eval_conf<3, PG>(env, L, mconf, 0.f, 0.f, 0.f, w, nullptr);  // the coordinates `model` holds
-      float acc = 0.f;
-      int n_gyr = 0;
-      for (int i = L.lig_begin; i < L.lig_end; i++) n_gyr += L.smt[i] > 1;  // (a handful of atoms; uniform)
-      for (int i = L.lig_begin + lane; i < L.lig_end; i += 64)
-        if (L.smt[i] > 1) {
-          const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
-                      dz = w.coords[3 * i + 2] - w.origin[2];
-          acc += dx * dx + dy * dy + dz * dz;
-        }
-      acc = wave_sum(acc);
-      const float gr = n_gyr > 0 ? sqrtf(acc / (float)n_gyr) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
-      if (gr > VEPS) {
-        float dx, dy, dz;
-        rng.inside_sphere(dx, dy, dz);
-        const float sc = a.amplitude / gr;
-        if (lane == 0) {
-          float rot[6] = {0.f, 0.f, 0.f, sc * dx, sc * dy, sc * dz};
-          conf_increment(k.x, rot, 1.0f, 0);
-        }
-      }
-    } else {
-      const float tv = rng.fl(-VPI, VPI);
-      if (lane == 0) k.x[7 + (which - 2)] = tv;
-    }
-    wave_sync();
+    mutate_wave<PG>(env, L, w, rng, k.x, mconf, a.amplitude);
     lap(0);
     // two passes through the same code: pass 0 = BFGS with the hunt caps + Metropolis, pass 1 (only for an
     // accepted candidate that is the best so far or while the container is not full) = BFGS with the authentic
@@ -1798,60 +1874,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
         wave_sync();
         lap(4);
         if (wv == 0) {  // the container belongs to wave 0; wsync() orders its lanes' LDS / global accesses
-          // add_to_output_container (coords.cpp:25-56): rmsd to every saved pose, one pose per lane
-          for (int o = lane; o < n_out; o += 64) {
-            const float *ref = s_xyz + (size_t)ord[o] * xs_;
-            float acc = 0.f;
-            for (int i = 0; i < nh; i++) {  // rmsd_upper_bound: one vec_distance_sqr per atom (coords.cpp:25-32)
-              const float dx = hc[3 * i] - ref[3 * i], dy = hc[3 * i + 1] - ref[3 * i + 1], dz = hc[3 * i + 2] - ref[3 * i + 2];
-              acc += dx * dx + dy * dy + dz * dz;
-            }
-            rm[o & 63] = nh > 0 ? sqrtf(acc / (float)nh) : 0.f;
-          }
-          wsync();
-          int closest = n_out;
-          float closest_rmsd = VMAXFL;
-          for (int o = 0; o < n_out && o < 64; o++) {  // first minimum, like find_closest
-            const float r = rm[o];
-            if (o == 0 || r < closest_rmsd) {
-              closest = o;
-              closest_rmsd = r;
-            }
-          }
-          int pos = -1;
-          if (closest < n_out && closest_rmsd < a.min_rmsd) {
-            if (tmp_e < s_e[ord[closest]]) pos = closest;
-          } else if (n_out < a.num_saved) {
-            pos = n_out;
-            if (lane == 0) ord[pos] = n_out;
-            n_out++;
-          } else if (n_out > 0 && tmp_e < s_e[ord[n_out - 1]]) {
-            pos = n_out - 1;
-          }
-          wsync();
-          if (pos >= 0) {
-            const int phys = ord[pos];
-            if (lane == 0) s_e[phys] = tmp_e;
-            for (int i = lane; i < nc; i += 64) s_conf[(size_t)phys * cs_ + i] = tmp[i];
-            for (int i = lane; i < 3 * nh; i += 64) s_xyz[(size_t)phys * xs_ + i] = hc[i];
-            wsync();
-            if (lane == 0) {  // out.sort(): keep `ord` ordered by energy
-              int o = pos;
-              while (o > 0 && s_e[ord[o]] < s_e[ord[o - 1]]) {
-                const int t = ord[o];
-                ord[o] = ord[o - 1];
-                ord[o - 1] = t;
-                o--;
-              }
-              while (o + 1 < n_out && s_e[ord[o + 1]] < s_e[ord[o]]) {
-                const int t = ord[o];
-                ord[o] = ord[o + 1];
-                ord[o + 1] = t;
-                o++;
-              }
-            }
-            wsync();
-          }
+          n_out = container_insert(a, s_e, s_conf, s_xyz, cs_, xs_, ord, rm, tmp, hc, tmp_e, n_out, nc, nh);
           if (lane == 0) sh_n[0] = n_out;
         }
         __syncthreads();
@@ -1888,6 +1911,139 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vina_mc_tp_kernel(VinaEnv env, VinaLigand L,
                                                                                                    VinaMcArgs a) {
   mc_chain<false, true>(env, L, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Monte-Carlo with the CNN as the Metropolis energy: --cnn_scoring metrorescore / metrorefine
+// (parallel_mc.cpp:145-155: mc(m, out, p, ig, ..., ig_metropolis = non_cache_cnn); monte_carlo.cpp:44-47 update_energy
+// = adjust_center + ig_metropolis->eval).  The CNN scores whole batches, so all chains of a launch advance in lock
+// step and stop where the reference calls update_energy: the host then evaluates non_cache_cnn::eval for every chain's
+// `model` in ONE batch (mi_cnn_eval_batch) and resumes the chains.  Three resumable phases per step over the same
+// device functions as vina_mc_kernel (one wave per chain; BFGS runs on the Vina grids like the reference's `ig`):
+//   phase 0 / 2: [container insert of the previous step]  mutate -> BFGS(hunt cap)          -> model_out
+//   phase 1    : Metropolis on the CNN energy -> [BFGS(full cap) if the pose is promising]     -> model_out
+//   phase 3    : last container insert, emit
+// Chain state between launches lives in global memory (st_f / st_i).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vina_mc_cnn_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a, VinaMcCnnState st) {
+  constexpr int HR = kHRegTp, PG = kPairGroupTp;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *pp = lds;
+  if (env.stage) L = stage_ligand(L, pp);
+  const int nt = L.n_nodes - 1, n = 6 + nt, nc = 7 + nt, nh = L.n_heavy;
+  float *sh_f = carve(pp, 1);
+  int *sh_ok = reinterpret_cast<int *>(carve(pp, 1));
+  WaveWork w = carve_work(pp, L);
+  BfgsWork k = carve_bfgs(pp, n, nc);
+  float *tmp = carve(pp, nc);
+  float *mconf = carve(pp, nc);
+  float *hc = carve(pp, 3 * nh);
+  float *rm = carve(pp, 64);
+  int *ord = reinterpret_cast<int *>(carve(pp, a.num_saved));
+  const WaveTeam tm{1, 0, 0, sh_f, sh_ok};
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  float *sf = st.st_f + (size_t)b * st.f_stride;   // [tmp nc][cand nc][mconf nc][tmp_e, best_e]
+  int *si = st.st_i + (size_t)b * st.i_stride;     // [n_out, rng idx, flag, -][ord num_saved]
+  float *s_e = a.scratch_e + (size_t)b * a.num_saved;
+  const int cs_ = a.conf_stride, xs_ = a.coord_stride;
+  float *s_conf = a.scratch_conf + (size_t)b * a.num_saved * cs_;
+  float *s_xyz = a.scratch_coords + (size_t)b * a.num_saved * xs_;
+  McRng rng{a.mt + (size_t)b * a.mt_team * 624, st.phase == 0 ? 624 : si[1]};
+  int evals = st.phase == 0 ? 0 : a.evals[b];
+  float tmp_e = 0.f, best_e = VMAXFL;
+  int n_out = 0, flag = 0;
+  if (st.phase == 0) {
+    randomize_wave(rng, tmp, a.c1, a.c2, nt);
+    for (int i = lane; i < nc; i += 64) mconf[i] = i == 3 ? 1.f : 0.f;
+  } else {
+    for (int i = lane; i < nc; i += 64) tmp[i] = sf[i], mconf[i] = sf[2 * nc + i];
+    tmp_e = sf[3 * nc], best_e = sf[3 * nc + 1];
+    n_out = si[0], flag = si[2];
+    for (int i = lane; i < a.num_saved; i += 64) ord[i] = si[4 + i];
+  }
+  wave_sync();
+  if (st.phase == 1) {
+    // metropolis_accept on the CNN energy of the candidate's `model` (monte_carlo.cpp:38-42,120-123)
+    const float cand_e = st.ext_e[b];
+    bool accept = st.step == 0 || cand_e < tmp_e;
+    if (!accept) {
+      const float prob = expf((tmp_e - cand_e) / a.temperature);
+      accept = rng.fl(0.f, 1.f) < prob;
+    }
+    flag = 1;  // rejected: `model` keeps the candidate's last evaluation (already in mconf)
+    if (accept) {
+      for (int i = lane; i < nc; i += 64) tmp[i] = mconf[i] = sf[nc + i];  // tmp = candidate; m.set(tmp.c)
+      tmp_e = cand_e;
+      flag = 2;
+      wave_sync();
+      if (tmp_e < best_e || n_out < a.num_saved) {  // refine with the full caps on the Vina grids (monte_carlo.cpp:128-131)
+        for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
+        wave_sync();
+        (void)bfgs_wave<HR, PG>(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals, tm, nullptr);
+        for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i], mconf[i] = k.x_new[i];
+        flag = 3;
+      }
+    }
+    wave_sync();
+  } else {
+    if (st.phase >= 2 && flag == 3) {
+      // update_energy after the second minimisation, m.set(tmp.c), add_to_output_container (monte_carlo.cpp:131-139)
+      tmp_e = st.ext_e[b];
+      for (int i = lane; i < nc; i += 64) mconf[i] = tmp[i];
+      wave_sync();
+      (void)eval_conf<3, PG>(env, L, tmp, 0.f, 0.f, 0.f, w, nullptr);
+      for (int h = lane; h < nh; h += 64) {
+        const int i = L.heavy_list[h];
+        hc[3 * h] = w.coords[3 * i], hc[3 * h + 1] = w.coords[3 * i + 1], hc[3 * h + 2] = w.coords[3 * i + 2];
+      }
+      wave_sync();
+      n_out = container_insert(a, s_e, s_conf, s_xyz, cs_, xs_, ord, rm, tmp, hc, tmp_e, n_out, nc, nh);
+      if (tmp_e < best_e) best_e = tmp_e;
+    }
+    flag = 0;
+    if (st.phase != 3) {  // propose the next candidate: mutate -> BFGS with the hunt caps
+      for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
+      wave_sync();
+      mutate_wave<PG>(env, L, w, rng, k.x, mconf, a.amplitude);
+      (void)bfgs_wave<HR, PG>(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals, tm, nullptr);
+      for (int i = lane; i < nc; i += 64) sf[nc + i] = k.x[i], mconf[i] = k.x_new[i];
+      wave_sync();
+    }
+  }
+  // what the CNN has to look at next: the conformation `model` holds
+  for (int i = lane; i < nc; i += 64) {
+    st.model_out[(size_t)b * nc + i] = mconf[i];
+    sf[i] = tmp[i], sf[2 * nc + i] = mconf[i];
+  }
+  for (int i = lane; i < a.num_saved; i += 64) si[4 + i] = ord[i];
+  if (lane == 0) {
+    sf[3 * nc] = tmp_e, sf[3 * nc + 1] = best_e;
+    si[0] = n_out, si[1] = rng.idx, si[2] = flag;
+    a.evals[b] = evals;
+  }
+  if (st.phase == 3) {  // emit the container in sorted order
+    wave_sync();
+    for (int o = 0; o < n_out; o++) {
+      const int phys = ord[o];
+      if (lane == 0) a.out_e[(size_t)b * a.num_saved + o] = s_e[phys];
+      for (int i = lane; i < nc; i += 64) a.out_conf[((size_t)b * a.num_saved + o) * cs_ + i] = s_conf[(size_t)phys * cs_ + i];
+      for (int i = lane; i < 3 * nh; i += 64)
+        a.out_coords[((size_t)b * a.num_saved + o) * xs_ + i] = s_xyz[(size_t)phys * xs_ + i];
+    }
+    if (lane == 0) a.out_n[b] = n_out;
+  }
+}
+
+void launch_vina_mc_cnn(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs &a0, const VinaMcCnnState &st, int B,
+                        hipStream_t s) {
+  VinaEnv env = env0;
+  VinaMcArgs a = a0;
+  env.stage = want_stage(B) ? 1 : 0;
+  a.conf_stride = 7 + lig.n_nodes - 1;
+  a.coord_stride = 3 * lig.n_heavy;
+  const size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, 1);
+  big_lds(vina_mc_cnn_kernel);
+  hipLaunchKernelGGL(vina_mc_cnn_kernel, dim3(B), dim3(64), lds, s, env, lig, a, st);
 }
 
 // Waves per chain: a single docking job (few chains) is bound by the latency of dependent evaluations, so

@@ -1121,6 +1121,131 @@ struct BfgsChain {
 
 }  // namespace
 
+// Monte-Carlo with the CNN as the Metropolis energy (--cnn_scoring metrorescore / metrorefine): see mi_gnina.h and
+// vina_mc_cnn_kernel.  update_energy = adjust_center (CNN cube centred on the heavy movable atoms of what `model`
+// holds) + non_cache_cnn::eval (CNN loss + out-of-box penalties), one batch for all chains per stop.
+mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t *seeds, const float *corner1,
+                               const float *corner2, const mi_mc_params *P, const mi_cnn_box *box, int32_t *out_n,
+                               float *out_e, float *out_conf, float *out_coords, int32_t *evals, int32_t *cnn_evals) {
+  VTRY
+  MIG_CHECK(vv && sc && seeds && corner1 && corner2 && P && box && out_n && out_e && B >= 0, 1, "bad arguments");
+  MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  MIG_CHECK(v.lig.n_movable == v.lig.n_atoms, 1, "flexible residues are not supported with the CNN in the loop yet");
+  MIG_CHECK(P->num_saved > 0 && P->num_saved <= 64 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1,
+            "bad Monte-Carlo parameters (num_saved must be in [1, 64], n_steps >= 1)");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, nc = 7 + nt, nh = v.lig.n_heavy, S = P->num_saved, na = v.lig.n_atoms;
+  MIG_CHECK(vina_mc_lds_bytes(v.lig.n_atoms, v.lig.n_nodes, v.lig.n_pairs, nh, S, true, 1) <= 152 * 1024, 1,
+            "ligand too large for the per-wave LDS workspace");
+  {  // one MT19937 state per chain (single-wave chains)
+    std::vector<unsigned> st((size_t)B * 624);
+    for (int b = 0; b < B; b++) {
+      unsigned *m = &st[(size_t)b * 624];
+      m[0] = (unsigned)seeds[b];
+      for (int i = 1; i < 624; i++) m[i] = 1812433253u * (m[i - 1] ^ (m[i - 1] >> 30)) + (unsigned)i;
+    }
+    v.d_mt.upload(st.data(), st.size(), v.stream);
+  }
+  v.d_mc_e.ensure((size_t)B * S);
+  v.d_mc_conf.ensure((size_t)B * S * nc);
+  v.d_mc_xyz.ensure((size_t)B * S * 3 * nh + 1);
+  v.d_sc_e.ensure((size_t)B * S);
+  v.d_sc_conf.ensure((size_t)B * S * nc);
+  v.d_sc_xyz.ensure((size_t)B * S * 3 * nh + 1);
+  v.d_out_n.ensure(B);
+  v.d_evals.ensure(B);
+  VinaMcArgs a{};
+  a.n_steps = P->n_steps;
+  a.max_iters = P->max_iters;
+  a.num_saved = S;
+  a.temperature = P->temperature;
+  a.amplitude = P->mutation_amplitude;
+  a.min_rmsd = P->min_rmsd;
+  for (int i = 0; i < 3; i++) {
+    a.hunt[i] = P->hunt_cap[i];
+    a.auth[i] = P->authentic_v[i];
+    a.c1[i] = corner1[i];
+    a.c2[i] = corner2[i];
+  }
+  a.mt = v.d_mt.p;
+  a.mt_team = 1;
+  a.scratch_e = v.d_sc_e.p;
+  a.scratch_conf = v.d_sc_conf.p;
+  a.scratch_coords = v.d_sc_xyz.p;
+  a.out_e = v.d_mc_e.p;
+  a.out_conf = v.d_mc_conf.p;
+  a.out_coords = v.d_mc_xyz.p;
+  a.out_n = v.d_out_n.p;
+  a.evals = v.d_evals.p;
+  VinaMcCnnState st{};
+  st.f_stride = 3 * nc + 4;
+  st.i_stride = 4 + S;
+  DevBuf<float> d_stf, d_model, d_ext;
+  DevBuf<int> d_sti;
+  d_stf.ensure((size_t)B * st.f_stride);
+  d_sti.ensure((size_t)B * st.i_stride);
+  d_model.ensure((size_t)B * nc);
+  d_ext.ensure(B);
+  st.st_f = d_stf.p;
+  st.st_i = d_sti.p;
+  st.model_out = d_model.p;
+  st.ext_e = d_ext.p;
+  std::vector<float> model((size_t)B * nc), coords((size_t)B * na * 3), centers((size_t)B * 3), energy(B);
+  CnnEvalScratch scratch;
+  long n_cnn = 0;
+  auto update_energy = [&]() -> mi_status {  // monte_carlo.cpp:44-47 for every chain's `model`
+    MIG_HIP(hipMemcpyAsync(model.data(), d_model.p, model.size() * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+    MIG_HIP(hipStreamSynchronize(v.stream));
+    mi_status s1 = mi_vina_coords_batch(vv, model.data(), B, coords.data());
+    if (s1 != MI_OK) return s1;
+    for (int b = 0; b < B; b++) {  // adjust_center: DLScorer::set_center_from_model (dl_scorer.cpp:197-217)
+      float s0 = 0, s1_ = 0, s2 = 0;
+      unsigned cnt = 0;
+      const float *xyz = &coords[(size_t)b * na * 3];
+      for (int i = 0; i < na; i++)
+        if (v.h_lig_smt[i] > 1) s0 += xyz[3 * i], s1_ += xyz[3 * i + 1], s2 += xyz[3 * i + 2], cnt++;
+      centers[3 * b] = s0 / (float)cnt, centers[3 * b + 1] = s1_ / (float)cnt, centers[3 * b + 2] = s2 / (float)cnt;
+    }
+    s1 = cnn_eval(v, sc, model.data(), B, box, centers.data(), box->slope, 0, energy.data(), nullptr, scratch);
+    if (s1 != MI_OK) return s1;
+    n_cnn += B;
+    MIG_HIP(hipMemcpyAsync(d_ext.p, energy.data(), B * sizeof(float), hipMemcpyHostToDevice, v.stream));
+    return MI_OK;
+  };
+  const VinaEnv env = make_env(v);
+  for (int step = 0; step < P->n_steps; step++) {
+    st.step = step;
+    st.phase = step == 0 ? 0 : 2;      // [insert of the previous step] + propose
+    launch_vina_mc_cnn(env, v.lig, a, st, B, v.stream);
+    MIG_HIP(hipGetLastError());
+    mi_status s1 = update_energy();
+    if (s1 != MI_OK) return s1;
+    st.phase = 1;                      // Metropolis [+ second minimisation]
+    launch_vina_mc_cnn(env, v.lig, a, st, B, v.stream);
+    MIG_HIP(hipGetLastError());
+    s1 = update_energy();
+    if (s1 != MI_OK) return s1;
+  }
+  st.phase = 3;
+  st.step = P->n_steps;
+  launch_vina_mc_cnn(env, v.lig, a, st, B, v.stream);
+  MIG_HIP(hipGetLastError());
+  MIG_HIP(hipMemcpyAsync(out_n, v.d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipMemcpyAsync(out_e, v.d_mc_e.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_conf)
+    MIG_HIP(hipMemcpyAsync(out_conf, v.d_mc_conf.p, (size_t)B * S * nc * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+  if (out_coords && nh > 0)
+    MIG_HIP(hipMemcpyAsync(out_coords, v.d_mc_xyz.p, (size_t)B * S * 3 * nh * sizeof(float), hipMemcpyDeviceToHost,
+                           v.stream));
+  if (evals) MIG_HIP(hipMemcpyAsync(evals, v.d_evals.p, B * sizeof(int), hipMemcpyDeviceToHost, v.stream));
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  if (cnn_evals) *cnn_evals = (int32_t)std::min<long>(n_cnn, 2147483647L);
+  return MI_OK;
+  VCATCH_STATUS
+}
+
 mi_status mi_cnn_eval_batch(mi_vina *vv, mi_scorer *sc, const float *confs, int B, const mi_cnn_box *box,
                             const float *cnn_centers, int with_deriv, float *energy, float *change) {
   VTRY

@@ -358,6 +358,18 @@ mi_status mi_cnn_eval_batch(mi_vina *, mi_scorer *, const float *confs, int B, c
  * batch.  confs in place; tries / evals [B] optional. */
 mi_status mi_cnn_refine_batch(mi_vina *, mi_scorer *, float *confs, int B, const mi_cnn_box *box, int max_iters,
                               float *energy, int32_t *tries, int32_t *evals);
+/* Monte-Carlo with the CNN as the Metropolis energy: --cnn_scoring metrorescore / metrorefine (user_opts.h:27-33;
+ * parallel_mc.cpp:145-155 runs monte_carlo with ig = the Vina grids and ig_metropolis = non_cache_cnn;
+ * monte_carlo.cpp:44-47: update_energy = adjust_center + ig_metropolis->eval).  Same chain as mi_vina_mc_batch --
+ * same mt19937 stream, mutation, BFGS on the Vina grids, container -- but every candidate's Metropolis energy is
+ * non_cache_cnn::eval of what `model` holds: CNN loss of the scorer's ensemble + slope * out-of-box distances (search
+ * box and the CNN cube re-centred on the pose, box->slope like non_cache's).  The chains of the call advance in lock
+ * step; at each of the two update_energy points of a step ALL chains are scored in one CNN batch.  Stored energies
+ * are CNN energies.  (--cnn_scoring all, where BFGS itself minimises the CNN, is mi_cnn_refine_batch's territory and
+ * is not offered inside the search.)  cnn_evals (optional) = CNN forward passes spent. */
+mi_status mi_vina_mc_cnn_batch(mi_vina *, mi_scorer *, int B, const uint64_t *seeds, const float *corner1,
+                               const float *corner2, const mi_mc_params *params, const mi_cnn_box *box, int32_t *out_n,
+                               float *out_e, float *out_conf, float *out_coords, int32_t *evals, int32_t *cnn_evals);
 /* Latency probe for tools/bench_vina.py: device time (ms) of `reps` dependent evaluations per wave. */
 mi_status mi_vina_eval_latency(mi_vina *, const float *confs, int B, int mode, int reps, float *ms_out);
 void *mi_vina_stream(mi_vina *);

@@ -162,3 +162,45 @@ def test_cnn_eval_deriv_with_empirical_mix(setup, mix_force, mix_energy):
         assert np.abs(ch - ch_plain).max() > 1e-3     # the blend really changed the forces
     else:
         assert np.abs(ch - ch_plain).max() < 1e-6 and np.abs(e - e_plain / (1 + wgt)).max() < 1e-4 * np.abs(e_plain).max()
+
+
+def test_monte_carlo_with_the_cnn_as_metropolis_energy(setup):
+    """--cnn_scoring metrorescore / metrorefine (parallel_mc.cpp:145-155, monte_carlo.cpp:44-47): the search minimises
+    on the Vina grids, the Metropolis criterion and the stored energies come from non_cache_cnn::eval.
+      * one step: the first candidate is always accepted, so the chain's conformation is bit-identical to the plain
+        Vina chain's (same mt19937 stream, same BFGS) while its energy is the CNN's;
+      * stored energies are non_cache_cnn::eval of the stored pose (where the second BFGS did not end by reverting);
+      * longer chains accept differently from the Vina chains (the reference's test_cnn.py:88-100 asserts exactly
+        that the outputs differ) and are deterministic."""
+    capi, sc, lig, v, olig = setup
+    names = ["crossdock_default2018"]
+    s = capi.Scorer(names)
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    gd = ovina.setup_grid_dims(sc["center"], sc["size"])
+    types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+    v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    v.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+    box = capi.CnnBox.make(23.5, list(gd.begin), list(gd.end), slope=1e3)
+    seeds = np.arange(7, 7 + 24, dtype=np.uint64)
+    iters = (25 + len(lig["smt"])) // 3
+    P1 = capi.McParams.default(1, iters, 10)
+    n0, e0, cf0, xyz0, ev0 = v.mc_batch(seeds, list(gd.begin), list(gd.end), P1)
+    n1, e1, cf1, xyz1, ev1, cnn1 = v.mc_cnn_batch(s, seeds, list(gd.begin), list(gd.end), P1, box)
+    assert (n0 == 1).all() and (n1 == 1).all() and cnn1 == 2 * len(seeds)
+    assert np.array_equal(cf0[:, 0], cf1[:, 0]) and np.array_equal(xyz0[:, 0], xyz1[:, 0]) and np.array_equal(ev0, ev1)
+    assert not np.allclose(e0[:, 0], e1[:, 0])
+    # the stored energy is the CNN igrid's energy of the stored pose (cube centred on its heavy atoms)
+    co = v.coords_batch(cf1[:, 0])
+    cen = np.stack([heavy_center(co[b], lig["smt"]) for b in range(len(seeds))])
+    chk, _ = v.cnn_eval_batch(s, cf1[:, 0], box, cen, deriv=False)
+    ok = np.abs(chk - e1[:, 0]) <= 1e-4 * np.maximum(1.0, np.abs(chk))
+    assert ok.mean() >= 0.75, ok
+    # longer chains
+    P = capi.McParams.default(40, iters, 10)
+    nA, eA, cfA, _, _, cnnA = v.mc_cnn_batch(s, seeds[:8], list(gd.begin), list(gd.end), P, box)
+    nB, eB, cfB, _, _, _ = v.mc_cnn_batch(s, seeds[:8], list(gd.begin), list(gd.end), P, box)
+    nV, eV, cfV, _, _ = v.mc_batch(seeds[:8], list(gd.begin), list(gd.end), P)
+    assert cnnA == 2 * 40 * 8 and (nA >= 1).all()
+    assert np.array_equal(eA, eB) and np.array_equal(cfA, cfB)                      # deterministic
+    assert all(np.all(np.diff(eA[b, :nA[b]]) >= 0) for b in range(8))               # containers sorted by CNN energy
+    assert not np.array_equal(cfA[:, 0], cfV[:, 0])                                  # the CNN accepts differently
