@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_sdf_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -360,6 +360,28 @@ def read_pdbqt_model(rigid, flex, ligand, is_text=False):
         return arr(prx, (nrig, 3), np.float32), arr(prs, (nrig,), np.int32), desc
     finally:
         lib().mi_pdbqt_model_close(h)
+
+
+def sdf_pose_text(name, elements, coords, bonds, energy, rmsd=-1.0, cnnscore=-1.0, cnnaffinity=0.0, cnnvariance=0.0,
+                  atom_index=None, props=()):
+    """one pose as gnina writes it to an .sdf (mi_sdf_write_pose)"""
+    el = b"".join((e.encode() + b"\0\0")[:2] for e in elements)
+    xyz = _f32(coords).reshape(-1, 3)
+    b = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 3)
+    pr = np.ascontiguousarray([(ord(t), a, v) for t, a, v in props], dtype=np.int32).reshape(-1, 3)
+    ai = None if atom_index is None else np.ascontiguousarray(atom_index, dtype=np.int32)
+    need = C.c_size_t()
+    args = (name.encode(), len(elements), el, _ptr(ai), _ptr(xyz), len(b), _ptr(b), len(pr), _ptr(pr), float(energy),
+            float(rmsd), float(cnnscore), float(cnnaffinity), float(cnnvariance))
+    f = lib().mi_sdf_write_pose
+    f.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    if f(*args, None, 0, C.byref(need)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    buf = C.create_string_buffer(need.value)
+    if f(*args, buf, need.value, C.byref(need)) != MI_OK:
+        raise MiGninaError(lib().mi_pdbqt_last_error().decode())
+    return buf.value.decode()
 
 
 def _ligand_num_tors(h):

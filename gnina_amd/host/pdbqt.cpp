@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <iomanip>
 #include <memory>
 #include <fstream>
 #include <sstream>
@@ -823,6 +824,49 @@ std::string write_pdbqt_pose(const PdbqtLigand &lig, const float *coords, int mo
   return out.str();
 }
 
+// One docked pose as gnina writes it to an .sdf (result_info::write's native branch, result_info.cpp:117-160, with the
+// molecule block of sdfcontext::write, model.cpp:827-907): name, two blank lines, counts line, atom block (%10.4f x3,
+// element), bond block, M  CHG / M  ISO properties, M  END, then the SD tags minimizedAffinity / minimizedRMSD /
+// CNNscore / CNNaffinity + CNN_VS / CNNaffinity_variance, $$$$.  The connection table comes from the caller (gnina
+// keeps the one OpenBabel read): elements [n_atoms][2] (not necessarily 0-terminated), atom_index [n_atoms] = model
+// atom of every SDF atom, bonds [n_bonds][3] = (a, b, order), 0-based; props [n_props][3] = ('c' | 'i', atom, value).
+std::string write_sdf_pose(const std::string &name, int n_atoms, const char *elements, const int32_t *atom_index,
+                           const float *coords, int n_bonds, const int32_t *bonds, int n_props, const int32_t *props,
+                           float energy, float rmsd, float cnnscore, float cnnaffinity, float cnnvariance) {
+  std::ostringstream out;
+  char buff[1024];
+  out << name << "\n\n\n";
+  snprintf(buff, sizeof buff, "%3d%3d  0  0  0  0  0  0  0  0999 V2000\n", n_atoms, n_bonds);
+  out << buff;
+  for (int i = 0; i < n_atoms; i++) {
+    const float *c = coords + 3 * (atom_index ? atom_index[i] : i);
+    char el[3] = {elements[2 * i], elements[2 * i + 1], 0};
+    snprintf(buff, sizeof buff, "%10.4f%10.4f%10.4f %-3.2s 0  0  0  0  0  0  0  0  0  0  0  0\n", (double)c[0],
+             (double)c[1], (double)c[2], el);
+    out << buff;
+  }
+  for (int i = 0; i < n_bonds; i++)
+    out << std::setw(3) << bonds[3 * i] + 1 << std::setw(3) << bonds[3 * i + 1] + 1 << std::setw(3) << bonds[3 * i + 2]
+        << "  0\n";
+  for (int i = 0; i < n_props; i++) {
+    if (props[3 * i] == 'c')
+      out << "M  CHG 1 " << std::setw(3) << props[3 * i + 1] + 1 << std::setw(4) << props[3 * i + 2] << "\n";
+    else if (props[3 * i] == 'i')
+      out << "M  ISO 1 " << std::setw(3) << props[3 * i + 1] + 1 << std::setw(4) << props[3 * i + 2] << "\n";
+  }
+  out << "M  END\n";
+  out << "> <minimizedAffinity>\n" << std::fixed << std::setprecision(5) << energy << "\n\n";
+  if (rmsd >= 0) out << "> <minimizedRMSD>\n" << std::fixed << std::setprecision(5) << rmsd << "\n\n";
+  if (cnnscore >= 0) out << "> <CNNscore>\n" << std::fixed << std::setprecision(10) << cnnscore << "\n\n";
+  if (cnnaffinity != 0) {
+    out << "> <CNNaffinity>\n" << std::fixed << std::setprecision(10) << cnnaffinity << "\n\n";
+    out << "> <CNN_VS>\n" << std::fixed << std::setprecision(10) << cnnaffinity * cnnscore << "\n\n";
+  }
+  if (cnnvariance != 0) out << "> <CNNaffinity_variance>\n" << std::fixed << std::setprecision(10) << cnnvariance << "\n\n";
+  out << "$$$$\n";
+  return out.str();
+}
+
 static std::string slurp(const std::string &path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("could not open " + path);
@@ -869,6 +913,29 @@ mi_status mi_pdbqt_read_receptor(const char *path, float *xyz, int32_t *smt, int
         std::memcpy(xyz, r.xyz.data(), r.xyz.size() * sizeof(float));
         std::memcpy(smt, r.smt.data(), r.smt.size() * sizeof(int32_t));
       }
+    }
+    return MI_OK;
+  } catch (const std::exception &e) {
+    g_pdbqt_error = e.what();
+    return MI_ERR_INVALID;
+  }
+}
+
+mi_status mi_sdf_write_pose(const char *name, int n_atoms, const char *elements, const int32_t *atom_index,
+                            const float *coords, int n_bonds, const int32_t *bonds, int n_props, const int32_t *props,
+                            float energy, float rmsd, float cnnscore, float cnnaffinity, float cnnvariance, char *out,
+                            size_t capacity, size_t *needed) {
+  try {
+    if (!name || !elements || !coords || !needed || n_atoms < 0 || n_bonds < 0 || n_props < 0 || (n_bonds && !bonds) ||
+        (n_props && !props))
+      throw std::runtime_error("bad arguments");
+    if (n_atoms > 999 || n_bonds > 999) throw std::runtime_error("V2000 counts are limited to 999 atoms / bonds");
+    const std::string s = gnina_amd::write_sdf_pose(name, n_atoms, elements, atom_index, coords, n_bonds, bonds, n_props,
+                                                    props, energy, rmsd, cnnscore, cnnaffinity, cnnvariance);
+    *needed = s.size() + 1;
+    if (out) {
+      if (capacity < s.size() + 1) throw std::runtime_error("capacity too small");
+      std::memcpy(out, s.c_str(), s.size() + 1);
     }
     return MI_OK;
   } catch (const std::exception &e) {

@@ -92,6 +92,11 @@ PdbqtModel parse_pdbqt_model(const std::string &rigid_name, const std::string &r
 std::string write_pdbqt_pose(const PdbqtLigand &lig, const float *coords, int modelnum, float energy, float rmsd,
                              float cnnscore, float cnnaffinity);
 
+// One docked pose in gnina's .sdf output (result_info::write native branch + sdfcontext::write): see pdbqt.cpp.
+std::string write_sdf_pose(const std::string &name, int n_atoms, const char *elements, const int32_t *atom_index,
+                           const float *coords, int n_bonds, const int32_t *bonds, int n_props, const int32_t *props,
+                           float energy, float rmsd, float cnnscore, float cnnaffinity, float cnnvariance);
+
 // Throw std::runtime_error("<name>:<line>: <what>") on malformed input, like parse_error.
 PdbqtReceptor read_pdbqt_receptor(const std::string &path);
 PdbqtLigand read_pdbqt_ligand(const std::string &path);

@@ -430,6 +430,17 @@ mi_status mi_pdbqt_ligand_desc(const mi_pdbqt_ligand *, mi_ligand_desc *desc, co
  * [n_atoms][3] in model order.  Call with out = NULL to get the size (*needed, incl. the terminating 0). */
 mi_status mi_pdbqt_write_pose(const mi_pdbqt_ligand *, const float *coords, int modelnum, float energy, float rmsd,
                               float cnnscore, float cnnaffinity, char *out, size_t capacity, size_t *needed);
+/* One pose in gnina's .sdf output format (result_info::write's native SDF branch, result_info.cpp:117-160, around
+ * sdfcontext::write's molecule block, model.cpp:827-907): V2000 counts / atoms (%10.4f) / bonds / M CHG / M ISO / M END,
+ * then > <minimizedAffinity> (5 decimals), [> <minimizedRMSD> if rmsd >= 0], [> <CNNscore> if >= 0 (10 decimals)],
+ * [> <CNNaffinity> and > <CNN_VS> = affinity * score if affinity != 0], [> <CNNaffinity_variance> if != 0], $$$$.
+ * The connection table is the caller's (gnina keeps what OpenBabel read): elements [n_atoms][2] chars, atom_index
+ * [n_atoms] (model atom of SDF atom i; NULL = identity), coords [.][3] in model order, bonds [n_bonds][3] = (a, b,
+ * order) 0-based, props [n_props][3] = ('c' charge | 'i' isotope, atom, value).  out = NULL: size query. */
+mi_status mi_sdf_write_pose(const char *name, int n_atoms, const char *elements, const int32_t *atom_index,
+                            const float *coords, int n_bonds, const int32_t *bonds, int n_props, const int32_t *props,
+                            float energy, float rmsd, float cnnscore, float cnnaffinity, float cnnvariance, char *out,
+                            size_t capacity, size_t *needed);
 const char *mi_pdbqt_last_error(void);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this

@@ -224,3 +224,38 @@ def test_pdbqt_to_gninatypes_tool(capi, tmp_path):
     assert res.returncode == 0 and "2 movable + 2 inflex + 2 rigid" in res.stdout, res.stderr
     xyz, smt = capi.read_gninatypes(str(out))
     assert smt.tolist() == [12, 1, 3, 3, 6, 2] and np.allclose(xyz[0], [2.10, 1.30, 0.0])
+
+
+def test_sdf_pose_output_follows_result_info_write(capi):
+    """gnina's native .sdf output (result_info.cpp:117-160 + sdfcontext::write, model.cpp:827-907), reconstructed line
+    by line: counts line, %10.4f coordinates, 3-wide bond fields, charge property, tags with 5 / 10 decimals, CNN_VS =
+    affinity x score, optional tags left out, $$$$."""
+    el = ["C", "O", "N", "Cl"]
+    xyz = np.array([[0, 0, 0], [1.25, 0.5, -0.125], [2.5, 0, 0], [-10.33337, 123.456789, 0.00004]], dtype=np.float32)
+    bonds = [(0, 1, 2), (1, 2, 1), (0, 3, 1)]
+    text = capi.sdf_pose_text("lig one", el, xyz, bonds, -7.123456, rmsd=1.5, cnnscore=0.987654321, cnnaffinity=6.5,
+                              cnnvariance=0.25, props=[("c", 2, 1)])
+    want = "\n".join([
+        "lig one", "", "",
+        "  4  3  0  0  0  0  0  0  0  0999 V2000",
+        "    0.0000    0.0000    0.0000 C   0  0  0  0  0  0  0  0  0  0  0  0",
+        "    1.2500    0.5000   -0.1250 O   0  0  0  0  0  0  0  0  0  0  0  0",
+        "    2.5000    0.0000    0.0000 N   0  0  0  0  0  0  0  0  0  0  0  0",
+        "  -10.3334  123.4568    0.0000 Cl  0  0  0  0  0  0  0  0  0  0  0  0",
+        "  1  2  2  0", "  2  3  1  0", "  1  4  1  0",
+        "M  CHG 1   3   1",
+        "M  END",
+        "> <minimizedAffinity>", "-7.12346", "",
+        "> <minimizedRMSD>", "1.50000", "",
+        "> <CNNscore>", "0.9876543283", "",
+        "> <CNNaffinity>", "6.5000000000", "",
+        "> <CNN_VS>", "%.10f" % float(np.float32(6.5) * np.float32(0.987654321)), "",
+        "> <CNNaffinity_variance>", "0.2500000000", "",
+        "$$$$", ""])
+    assert text == want
+    plain = capi.sdf_pose_text("x", el[:2], xyz[:2], bonds[:1], -1.0)      # rescoring off: no CNN tags, no rmsd
+    assert "> <CNNscore>" not in plain and "> <minimizedRMSD>" not in plain and "> <CNNaffinity>" not in plain
+    assert plain.endswith("> <minimizedAffinity>\n-1.00000\n\n$$$$\n")
+    # atom_index: SDF atom i takes the coordinates of model atom atom_index[i]
+    perm = capi.sdf_pose_text("x", el[:2], xyz, bonds[:1], 0.0, atom_index=[2, 1])
+    assert "    2.5000    0.0000    0.0000 C  " in perm
