@@ -48,6 +48,11 @@ struct ConvArgs {
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;
   int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
+  // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
+  // 1 = they are stacked along x (tcx % 4 == 0).  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
+  // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
+  // the raster order costs 3 LDS cycles per group) -- see DESIGN.md section 3.1.
+  int mt_x;
 };
 
 enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,

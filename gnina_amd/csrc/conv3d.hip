@@ -75,12 +75,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   const int NC = p.tcx * p.tcy * p.tcz;
   const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
   const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
+  // cell `cim` (0..3) of M-tile `mt` -> cell coordinates inside the workgroup tile (ConvArgs::mt_x)
+  auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) -> bool {
+    if (p.mt_x) {
+      cz = mt % p.tcz;
+      cy = (mt / p.tcz) % p.tcy;
+      cx = 4 * (mt / (p.tcz * p.tcy)) + cim;
+      return cx < p.tcx;
+    }
+    const int cell = mt * 4 + cim;
+    cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    return cell < NC;
+  };
   int baseA[TM];
 #pragma unroll
   for (int m = 0; m < TM; m++) {
-    int cell = (wm * TM + m) * 4 + cell_in_mt;
-    if (cell >= NC) cell = 0;
-    int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    int cx, cy, cz;
+    if (!cell_of(wm * TM + m, cell_in_mt, cx, cy, cz)) cx = cy = cz = 0;
     baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs;
   }
 
@@ -326,9 +337,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   for (int m = 0; m < TM; m++) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      const int cell = (wm * TM + m) * 4 + kh + 2 * half;  // accumulator rows: bit2 = lane>>5, bit4 = reg>>3
-      if (cell >= NC) continue;
-      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      int cx, cy, cz;  // accumulator rows: bit2 = lane>>5, bit4 = reg>>3
+      if (!cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz)) continue;
       const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
       if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
 #pragma unroll

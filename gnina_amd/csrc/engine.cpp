@@ -63,6 +63,7 @@ static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
   }
   cfg = cp.lat_cfg;
   a.tcx = cp.lat_tc[0], a.tcy = cp.lat_tc[1], a.tcz = cp.lat_tc[2];
+  a.mt_x = 0;  // (the latency tiles keep the raster order of cells)
   const int cells = a.S / 2;
   a.ntx = cdiv(cells, a.tcx);
   a.nty = cdiv(cells, a.tcy);
@@ -170,7 +171,9 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     a.tcx = 2, a.tcy = 2, a.tcz = 6;
   } else {
     cp.cfg = CONV_CFG_4x1_2x1;  // 8 M-tiles = 32 cells
-    if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
+    if (cells % 4 == 0 && o.ksize == 3 && !getenv("MI_GNINA_NO_MT_X"))
+      a.tcx = 4, a.tcy = 4, a.tcz = 2, a.mt_x = 1;  // M-tiles stacked along x: conflict-free A-operand reads (conv3d.h)
+    else if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
     else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
     else if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
     else a.tcx = 2, a.tcy = 4, a.tcz = 4;
