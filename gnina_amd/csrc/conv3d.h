@@ -40,6 +40,7 @@ struct ConvArgs {
   const float *post_bias;          // [coutp]
   int post_relu;
   int post_rows;                   // WM * TM * 32: voxel rows of a workgroup (LDS sizing)
+  int post_cc4, post_wrows;        // K-chunk geometry of post_w (the 1x1 conv's own plan: cc4, wrows)
   // bf16 kernels (conv3d_bf16.hip) only: element type of the tensors behind in / out / in_act
   // (1 = fp32, 0 = bf16; cc4 / ccs / cin4 then count OCTETS of 8 channels and wp is a packed bf16 array)
   int in_f32, out_f32, act_f32;
@@ -48,6 +49,7 @@ struct ConvArgs {
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;
   int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
+  int wrows;         // fp32 32x32x2 kernel: quad rows per chunk of the packed weights, 2 * (Q / 2 + 1) >= Q + 1; rows >= Q are zero
   // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
   // 1 = they are stacked along x (tcx % 4 == 0).  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;

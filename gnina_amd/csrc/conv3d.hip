@@ -24,12 +24,20 @@
 //   * A workgroup is WM x WN waves, each wave owning TM M-tiles x TN 32-wide N-tiles.
 #include "conv3d.h"
 
+#include <stdexcept>
+
+#ifndef MI_CONV_EXPERIMENT
+#define MI_CONV_EXPERIMENT 0  // 1, 2: timing experiments on the conv kernel (wrong results; never in the product build)
+#endif
+
 namespace mig {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN, bool SPARSE>
-__global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
+// (second launch bound = waves per SIMD the register allocation must leave room for: the two-accumulator shapes run
+// four workgroups per CU, i.e. <= 128 VGPRs; the TM = 7 shape two)
+template <int WM, int WN, int TM, int TN, bool SPARSE, bool MTX>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 : 1)) void conv3d_mfma_kernel(ConvArgs p) {
   constexpr int NWAVES = WM * WN;
   constexpr int NTHREADS = 64 * NWAVES;
   const int tid = threadIdx.x;
@@ -58,18 +66,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_tile = smem;                                  // [HV][CCs]
-  int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);  // [Q]
-  int *s_jq = s_qoff + Q;                                // [Q] compacted list of the non-zero quads of a chunk
-  int *s_flag = s_jq + Q;                                // [nchunks][CC4] "this channel quad is non-zero in the tile"
+  // [Q + 5] K-loop list of this chunk: .x = byte offset of the quad inside the halo tile (tap shift + channel quad),
+  // .y = byte offset of its packed weight row.  One ds_read_b64 per quad, fetched one pair ahead of its use; the
+  // list ends in five pad entries (zero weights) so that neither an odd quad count nor the read-ahead needs a branch.
+  int2 *s_list = reinterpret_cast<int2 *>(smem + (size_t)HV * CCs);
+  int *s_flag = reinterpret_cast<int *>(s_list + Q + 5);  // [nchunks][CC4] "this channel quad is non-zero in the tile"
   int *s_vox = s_flag + p.nchunks * CC4;                 // [HV] voxel index of every halo position inside the pose, -1 = padding
+  const int wstride_i = p.coutp * 4;                     // floats per quad row of packed weights
+  auto list_entry = [&](int q, int wrow) -> int2 {
+    const int tap = q / CC4, c4 = q - tap * CC4;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    return make_int2(((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4) * 4, wrow * wstride_i * 4);
+  };
 
   for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = 0;
-
-  for (int q = tid; q < Q; q += NTHREADS) {
-    int tap = q / CC4, c4 = q - tap * CC4;
-    int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    s_qoff[q] = (p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4;
-  }
+  // Row Q of every chunk's packed weights is all zero (ConvArgs::wrows): the list entry behind the last quad points
+  // there, so an odd number of quads needs no special case in the K loop (the idle half-wave multiplies by zeros).
+  if (!SPARSE)  // dense: quad q multiplies weight row q
+    for (int q = tid; q < Q + 5; q += NTHREADS) s_list[q] = list_entry(q < Q ? q : Q - 1, q < Q ? q : Q);
 
   // A-row geometry of this lane for each of its M-tiles
   const int NC = p.tcx * p.tcy * p.tcz;
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
   // cell `cim` (0..3) of M-tile `mt` -> cell coordinates inside the workgroup tile (ConvArgs::mt_x)
   auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) -> bool {
-    if (p.mt_x) {
+    if (MTX) {
       cz = mt % p.tcz;
       cy = (mt / p.tcz) % p.tcy;
       cx = 4 * (mt / (p.tcz * p.tcy)) + cim;
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
   for (int m = 0; m < TM; m++) {
     int cx, cy, cz;
     if (!cell_of(wm * TM + m, cell_in_mt, cx, cy, cz)) cx = cy = cz = 0;
-    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs;
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs * 4;  // bytes
   }
 
   f32x16 acc[TM][TN];
@@ -113,22 +127,69 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     int v = -1;
     if (in)
       v = p.in_mode == 2 ? (((x >> 1) * (S >> 1) + (y >> 1)) * (S >> 1) + (z >> 1)) | ((((x & 1) << 2) | ((y & 1) << 1) | (z & 1)) << 28)
-                         : (x * S + y) * S + z;
+          : p.in_mode == 0 ? ((x * S + y) * S + z) * p.in_cs  // forward convs: the float offset of the voxel's channel row
+                           : (x * S + y) * S + z;
     s_vox[hv] = v;
+    // forward staging writes the voxels inside the grid only: the zero padding is laid down once, here
+    if (p.in_mode == 0 && !in)
+      for (int c = 0; c < CCs; c += 4) *reinterpret_cast<float4 *>(s_tile + hv * CCs + c) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const unsigned inv_cc4 = ((1u << 20) + CC4 - 1) / CC4;  // it / CC4 == (it * inv_cc4) >> 20 for it < 2^20 / CC4
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
-  const float *wq = p.wp + (size_t)(n_base + row) * 4;  // + ((pair*2 + kh) * coutp) * 4
   const size_t wstride = (size_t)p.coutp * 4;           // floats per quad row of packed weights
 
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    __syncthreads();  // previous chunk's reads done (and s_qoff visible on the first pass)
+    __syncthreads();  // previous chunk's reads done (and s_list / s_vox visible on the first pass)
     // ---- stage the halo tile of this channel chunk into LDS (zero padded; BN folded in) ----
     const int c_base = chunk * CC4 * 4;
     // All global loads of a batch of U items per thread are issued before the first one is consumed: a
     // dependent load -> (mask, BN) -> ds_write chain per item would serialise one L2/HBM latency per iteration.
     const int total_items = HV * CC4;
     constexpr int U = 4;
+    if (p.in_mode == 0) {
+      // Forward convs, voxel-major: a thread takes halo voxels tid, tid + NTHREADS, ... and walks the channel quads of
+      // the chunk with immediate offsets -- no per-item index arithmetic (fp32 MFMA and VALU share the SIMD's fp32
+      // lanes on gfx950: every VALU instruction here is time taken from the K loops of the co-resident waves).
+      const float *src_c = in_b + c_base;
+      const int nq = min(CC4, p.cin4 - chunk * CC4);  // quads of this chunk that exist in the input
+      for (int hv = tid; hv < HV; hv += NTHREADS) {
+        const int off = s_vox[hv];
+        if (off < 0) continue;  // zero padding, already in place
+        float *dst = s_tile + hv * CCs;
+        for (int qb = 0; qb < nq; qb += U) {
+          float4 val[U];
+#pragma unroll
+          for (int u = 0; u < U; u++)
+            if (qb + u < nq) {
+#if MI_CONV_EXPERIMENT == 1  // (tools/conv_experiments.sh: staging without its global loads)
+              val[u] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+#else
+              val[u] = *reinterpret_cast<const float4 *>(src_c + off + (qb + u) * 4);
+#endif
+            }
+#pragma unroll
+          for (int u = 0; u < U; u++)
+            if (qb + u < nq) {
+              float4 x = val[u];
+              if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
+                const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c_base + (qb + u) * 4);
+                const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c_base + (qb + u) * 4);
+                x.x = x.x * sc.x + sh.x;
+                x.y = x.y * sc.y + sh.y;
+                x.z = x.z * sc.z + sh.z;
+                x.w = x.w * sc.w + sh.w;
+              }
+              *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
+              if (SPARSE && (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f)) s_flag[chunk * CC4 + qb + u] = 1;
+            }
+        }
+      }
+      if (nq < CC4)  // partial last chunk: its missing quads still hold the previous chunk's channels
+        for (int it = tid; it < HV * (CC4 - nq); it += NTHREADS) {
+          const int hv = it / (CC4 - nq), c4 = nq + it - hv * (CC4 - nq);
+          *reinterpret_cast<float4 *>(s_tile + hv * CCs + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else
     for (int base = 0; base < total_items; base += NTHREADS * U) {
       float4 val[U], act[U];
       uchar4 am[U];
@@ -158,7 +219,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
               am[u] = *reinterpret_cast<const uchar4 *>(p.in_argmax + cell * p.in_cs + c);
               act[u] = *reinterpret_cast<const float4 *>(p.in_act + cell * p.in_act_cs + c);
             } else {
+#if MI_CONV_EXPERIMENT == 1  // (tools/conv_experiments.sh: staging without its global loads)
+              val[u] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+#else
               val[u] = *reinterpret_cast<const float4 *>(in_b + (size_t)vi * p.in_cs + c);
+#endif
               if (p.in_mode == 1)  // ReLU backward: gradient passes where the forward activation was > 0
                 act[u] = *reinterpret_cast<const float4 *>(p.in_act + ((size_t)b * S * S * S + vi) * p.in_act_cs + c);
             }
@@ -209,10 +274,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
       for (int c = 0; c < CC4; c++) n_act += s_flag[chunk * CC4 + c];
       if (n_act == 0) continue;
       J = taps * n_act;
-      if (n_act == CC4) {
-        for (int j = tid; j < J; j += NTHREADS) s_jq[j] = j;
-      } else {
-        for (int j = tid; j < J; j += NTHREADS) {
+      for (int j = tid; j < J; j += NTHREADS) {
+        int q = j;
+        if (n_act != CC4) {
           const int tap = j / n_act, a = j - tap * n_act;
           int c4 = 0, seen = -1;
           for (int c = 0; c < CC4; c++) {
@@ -222,9 +286,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
               break;
             }
           }
-          s_jq[j] = tap * CC4 + c4;
+          q = tap * CC4 + c4;
         }
+        s_list[j] = list_entry(q, q);
       }
+      if (tid < 5) s_list[J + tid] = list_entry(Q - 1, Q);  // the pad entries: zero weights
       __syncthreads();
     }
 
@@ -234,28 +300,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     // compiler into load -> s_waitcnt vmcnt(0) -> MFMA, which exposes the L2 latency once per pair.
     // Dense: pair pr = quads (2 pr, 2 pr + 1), affine addressing.  Sparse: pairs of the compacted list
     // of surviving quads, in their original order.
-    const float *wchunk = wq + (size_t)chunk * P * 2 * wstride;
+#if MI_CONV_EXPERIMENT == 2  // (tools/conv_experiments.sh: everything but the K loop)
+    const int NP = 0;
+#else
     const int NP = SPARSE ? (J + 1) >> 1 : P;
+#endif
+    // the list entry of this half-wave's quad of pair pr; fetched one pair ahead so that the two dependent LDS
+    // round trips (entry -> operands) are never both on the critical path of an iteration
+    const int2 *lp = s_list + kh;
+    int2 e_next = lp[0];
+    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * p.wrows * wstride * 4;  // uniform
+    const unsigned wlane = (unsigned)(n_base + row) * 16u;
     auto load_pair = [&](int pr, float4 *aa, float4 *ww) {
-      int q;
-      bool live = true;
-      if (SPARSE) {
-        const int j = 2 * pr + kh;
-        live = j < J;  // odd J: the second half-wave of the last pair multiplies zeros
-        q = s_jq[live ? j : J - 1];
-      } else {
-        q = 2 * pr + kh;
-        q = q < Q ? q : Q - 1;  // odd Q: the pad quad has zero weights, any valid A address will do
-      }
-      const int qo = s_qoff[q];
+      const int2 e = e_next;
 #pragma unroll
-      for (int m = 0; m < TM; m++) {
-        aa[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-        if (SPARSE && !live) aa[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      const float *wrow = SPARSE ? wchunk + (size_t)q * wstride : wchunk + (size_t)(2 * pr + kh) * wstride;
+      for (int m = 0; m < TM; m++) aa[m] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_tile) + baseA[m] + e.x);
 #pragma unroll
-      for (int n = 0; n < TN; n++) ww[n] = *reinterpret_cast<const float4 *>(wrow + (size_t)n * 32 * 4);
+      for (int n = 0; n < TN; n++) ww[n] = *reinterpret_cast<const float4 *>(wbase + (wlane + (unsigned)e.y + (unsigned)n * 512u));
+      e_next = lp[2 * pr + 2];
     };
     auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
 #pragma unroll
@@ -271,11 +333,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
     float4 a0[TM], a1[TM], w0[TN], w1[TN];
     load_pair(0, a0, w0);
     int pr = 0;
+    // sched_barrier: the machine scheduler otherwise sinks each fetch down to its consumer (fetch -> wait -> MFMA),
+    // which exposes the LDS and L2 latencies once per pair
     for (; pr + 1 < NP; pr += 2) {
       load_pair(pr + 1, a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
       mfma_pair(a0, w0);
-      if (pr + 2 < NP) load_pair(pr + 2, a0, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_pair(pr + 2, a0, w0);  // (past the end: a clamped, unused fetch -- keeps the wait counts static, no branch)
+      __builtin_amdgcn_sched_barrier(0);
       mfma_pair(a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (NP & 1) mfma_pair(a0, w0);
   }
@@ -306,25 +374,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3d_mfma_kernel(ConvArgs p) {
         }
       }
     __syncthreads();
-    const int P2 = p.coutp >> 3;  // quad pairs of the 1x1 conv's K = coutp channels
+    // K = coutp channels of the 1x1 conv, in the chunked layout of its own plan (post_cc4 quads per chunk, an even
+    // number; post_wrows rows per chunk -- the rows behind the last quad of a chunk are the K loop's zero rows)
     const float *w2 = p.post_w + (size_t)(n_base + row) * 4 + (size_t)kh * wstride;
-    for (int pr = 0; pr < P2; pr++) {
-      float4 a2[TM], b2[TN];
+    const int P2 = p.post_cc4 >> 1;
+    for (int c2 = 0; c2 * p.post_cc4 * 4 < p.coutp; c2++)
+      for (int pr = 0; pr < P2; pr++) {
+        float4 a2[TM], b2[TN];
 #pragma unroll
-      for (int m = 0; m < TM; m++)
-        a2[m] = *reinterpret_cast<const float4 *>(s_mid + ((wm * TM + m) * 32 + row) * stride + (2 * pr + kh) * 4);
+        for (int m = 0; m < TM; m++)
+          a2[m] = *reinterpret_cast<const float4 *>(s_mid + ((wm * TM + m) * 32 + row) * stride + (c2 * p.post_cc4 + 2 * pr + kh) * 4);
 #pragma unroll
-      for (int n = 0; n < TN; n++) b2[n] = *reinterpret_cast<const float4 *>(w2 + (size_t)pr * 2 * wstride + (size_t)n * 32 * 4);
+        for (int n = 0; n < TN; n++)
+          b2[n] = *reinterpret_cast<const float4 *>(w2 + ((size_t)c2 * p.post_wrows + (size_t)pr * 2) * wstride + (size_t)n * 32 * 4);
 #pragma unroll
-      for (int m = 0; m < TM; m++)
+        for (int m = 0; m < TM; m++)
 #pragma unroll
-        for (int n = 0; n < TN; n++) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].x, b2[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].y, b2[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].z, b2[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].w, b2[n].w, acc[m][n], 0, 0, 0);
-        }
-    }
+          for (int n = 0; n < TN; n++) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].x, b2[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].y, b2[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].z, b2[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m].w, b2[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
     bias_ptr = p.post_bias;
     relu_flag = p.post_relu;
   }
@@ -562,34 +634,45 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * Q + p.nchunks * p.cc4 + HV) * sizeof(int);
+  // (the N = 16 kernel keeps a [Q] offset table where this one has its [Q + 5] int2 list: sized for the larger)
+  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 5) + p.nchunks * p.cc4 + HV) * sizeof(int);
   const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (p.coutp + 4) * sizeof(float) : 0;
   return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }
 
-template <int WM, int WN, int TM, int TN, bool SPARSE> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool SPARSE, bool MTX> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE, MTX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE>), grid, block, lds, s, p);
+  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE, MTX>), grid, block, lds, s, p);
 }
 
-template <int WM, int WN, int TM, int TN> static void launch_cfg(const ConvArgs &p, int B, hipStream_t s) {
+// MTX (ConvArgs::mt_x, M-tiles stacked along x) is compiled only where the engine asks for it (the 4x1/2x1 first-conv
+// tile): as a run-time branch it cost the TM = 7 kernel 8 VGPRs, i.e. its second wave per SIMD
+template <int WM, int WN, int TM, int TN, bool MTX_OK = false> static void launch_cfg(const ConvArgs &p, int B, hipStream_t s) {
+  if (p.mt_x && !MTX_OK) throw std::runtime_error("launch_conv: mt_x is not compiled for this tile configuration");
+  if (MTX_OK && p.mt_x) {
+    if (p.sparse)
+      launch_one<WM, WN, TM, TN, true, MTX_OK>(p, B, s);
+    else
+      launch_one<WM, WN, TM, TN, false, MTX_OK>(p, B, s);
+    return;
+  }
   if (p.sparse)
-    launch_one<WM, WN, TM, TN, true>(p, B, s);
+    launch_one<WM, WN, TM, TN, true, false>(p, B, s);
   else
-    launch_one<WM, WN, TM, TN, false>(p, B, s);
+    launch_one<WM, WN, TM, TN, false, false>(p, B, s);
 }
 
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
   switch (cfg) {
-    case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1>(p, B, s); break;
+    case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1, true>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
     case CONV_CFG_4x1_2x3: launch_cfg<4, 1, 2, 3>(p, B, s); break;
     case CONV_CFG_2x2_3x1: launch_cfg<2, 2, 3, 1>(p, B, s); break;

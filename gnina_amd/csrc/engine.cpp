@@ -209,7 +209,9 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   // pack weights [chunk][pair][2][coutp][4]
   const int taps = o.ksize * o.ksize * o.ksize;
   const int kstep = n16 ? 4 : 2;  // quads per MFMA step: pairs for 32x32x2, quartets for 16x16x4
-  const int Q = taps * a.cc4, P = (Q + kstep - 1) / kstep;
+  // (the 32x32x2 kernel wants an all-zero row behind the last quad of every chunk: see ConvArgs::wrows)
+  const int Q = taps * a.cc4, P = n16 ? (Q + kstep - 1) / kstep : Q / kstep + 1;
+  a.wrows = P * kstep;
   std::vector<float> wp((size_t)a.nchunks * P * kstep * a.coutp * 4, 0.f);
   // forward: canonical [tap][cin][cout]; backward: W'[tap][co][ci] = W[taps-1-tap][ci][co] (flipped, transposed)
   std::vector<float> wT;
@@ -253,6 +255,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.post_bias = nullptr;
   a.post_relu = 0;
   a.post_rows = 0;
+  a.post_cc4 = a.post_wrows = 0;
   if (o.bn_scale_off >= 0) {
     std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
     std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -541,8 +544,12 @@ static Model *build_model(ModelDesc &&desc) {
             MIG_CHECK(tm_ <= 3 && tn_ == 1, 2, "fused 1x1 conv planned on a kernel shape that does not carry it");
           }
           ConvPlan p2;
-          plan_conv(*m, *post, p2, 0, post->dst, 0);  // for its packed weights [pair][2][coutp][4] (K chunks are contiguous)
+          plan_conv(*m, *post, p2, 0, post->dst, 0);  // for its packed weights [pair][2][coutp][4]
+          MIG_CHECK(p2.a.cc4 % 2 == 0 && p2.a.cc4 * p2.a.nchunks * 4 == st.conv.a.coutp, 2,
+                    "fused 1x1 conv: its K chunks must hold an even number of channel quads and cover coutp exactly");
           st.conv.a.post_w = p2.a.wp;
+          st.conv.a.post_cc4 = p2.a.cc4;
+          st.conv.a.post_wrows = p2.a.wrows;
           st.conv.a.post_bias = p2.a.bias;
           st.conv.a.post_relu = post->relu;
           st.post_cout = post->cout;

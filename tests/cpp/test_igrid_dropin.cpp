@@ -33,7 +33,7 @@ static std::string slurp(const char *p) {
   return ss.str();
 }
 
-int main(int argc, char **argv) {
+static int run(int argc, char **argv) {
   if (argc < 3) {
     std::fprintf(stderr, "usage: %s rigid.pdbqt ligand.pdbqt\n", argv[0]);
     return 2;
@@ -124,4 +124,15 @@ int main(int argc, char **argv) {
     std::printf("mc_on %s n %zu best %.9g\n", which ? "hip_cache" : "ref_cache", out.size(), out[0].e);
   }
   return 0;
+}
+
+int main(int argc, char **argv) {
+  try {
+    return run(argc, argv);
+  } catch (const internal_error &e) {  // gnina's own type: (file, line) -- HipCache puts its message into `file`
+    fprintf(stderr, "internal_error: %s (%u)\n", e.file.c_str(), e.line);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "exception: %s\n", e.what());
+  }
+  return 3;
 }
