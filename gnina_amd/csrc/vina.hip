@@ -304,7 +304,7 @@ __device__ __forceinline__ float *carve(float *&p, int n) {
 }
 
 // init = false only measures the footprint (multi-wave kernels place one workspace per wave)
-__device__ WaveWork carve_work(float *&p, const VinaLigand &L, bool init = true) {
+__device__ __forceinline__ WaveWork carve_work(float *&p, const VinaLigand &L, bool init = true) {
   WaveWork w;
   const int n_slots = (2 * L.n_pairs + 3 * L.n_atoms + 3) & ~3;  // upper bound of the ligand's slot count
   w.cx = carve(p, n_slots);
@@ -327,7 +327,7 @@ __device__ WaveWork carve_work(float *&p, const VinaLigand &L, bool init = true)
 // Copy the (small, read-many) ligand description from global memory into LDS so that the sequential
 // tree walk and the per-pair / per-atom index look-ups of every evaluation hit LDS (~64 cycles) instead of
 // L2 (~200-500 cycles).  Returns a VinaLigand whose pointers address the LDS copies.
-__device__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
+__device__ __forceinline__ VinaLigand stage_ligand(const VinaLigand &G, float *&p) {
   const int tid = threadIdx.x, nthr = blockDim.x;  // one copy per workgroup, shared by its waves
   VinaLigand L = G;
   auto cp_i = [&](const int *src, int n) -> const int * {
@@ -1152,7 +1152,7 @@ struct BfgsWork {
   float *x, *g, *h;      // in/out conformation, final gradient, triangular inverse-Hessian estimate
 };
 
-__device__ BfgsWork carve_bfgs(float *&pp, int n, int nc) {
+__device__ __forceinline__ BfgsWork carve_bfgs(float *&pp, int n, int nc) {
   BfgsWork k;
   k.x_new = carve(pp, nc);
   k.g_new = carve(pp, n);
@@ -1539,10 +1539,10 @@ struct McRng {
   unsigned *mt;  // this wave's 624-word state (global memory)
   int idx;       // next word; 624 = regenerate first
   // the state is rewritten by this wave's own lanes: read it past the (non-coherent) vector L1
-  __device__ unsigned ld(int i) const { return __hip_atomic_load(&mt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ unsigned ld(int i) const { return __hip_atomic_load(&mt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   // The sequential twist reads mt[i + 1] before it is replaced and mt[(i + 397) % 624] after it was (for i >= 227):
   // three ranges whose inputs are complete when the range starts, 64 words at a time, loads before stores.
-  __device__ void twist() {
+  __device__ __forceinline__ void twist() {
     const int lane = threadIdx.x & 63;
     const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
 #pragma unroll 1
@@ -1562,7 +1562,7 @@ struct McRng {
       }
     idx = 0;
   }
-  __device__ unsigned u32() {
+  __device__ __forceinline__ unsigned u32() {
     if (idx >= 624) twist();
     unsigned y = ld(idx++);
     y ^= y >> 11;
@@ -1572,14 +1572,14 @@ struct McRng {
     return y;
   }
   // boost::uniform_real<float> (random_fl, random.cpp:27-35): u32 / 2^32 * (b - a) + a, redrawn if it reaches b
-  __device__ float fl(float a, float b) {
+  __device__ __forceinline__ float fl(float a, float b) {
     for (;;) {
       const float result = (float)u32() / 4294967296.0f * (b - a) + a;
       if (result < b) return result;
     }
   }
   // boost::uniform_int<int> (random_int, random.cpp:44-52): equal buckets with rejection
-  __device__ int irange(int a, int b) {
+  __device__ __forceinline__ int irange(int a, int b) {
     const unsigned range = (unsigned)b - (unsigned)a, brange = 0xffffffffu;
     if (range == 0) return a;
     unsigned bucket = brange / (range + 1);
@@ -1591,11 +1591,11 @@ struct McRng {
   }
   // boost::normal_distribution<float>(0, 1), Box-Muller on two fresh uniforms (random_normal builds a new
   // distribution object per call, random.cpp:37-42)
-  __device__ float normal() {
+  __device__ __forceinline__ float normal() {
     const float r1 = fl(0.f, 1.f), r2 = fl(0.f, 1.f);
     return sqrtf(-2.0f * logf(1.0f - r2)) * cosf(2.0f * 3.14159265358979323846f * r1);
   }
-  __device__ void inside_sphere(float &x, float &y, float &z) {  // random.cpp:66-75
+  __device__ __forceinline__ void inside_sphere(float &x, float &y, float &z) {  // random.cpp:66-75
     for (;;) {
       x = fl(-1, 1);
       y = fl(-1, 1);
