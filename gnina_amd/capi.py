@@ -24,7 +24,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -189,6 +189,10 @@ def lib():
         L.mi_vina_build_cache.restype = C.c_int
         L.mi_vina_cache_grid.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.mi_vina_cache_grid.restype = C.c_int
+        L.mi_user_grid_parse.argtypes = [C.c_char_p, C.c_size_t, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi_user_grid_parse.restype = C.c_int
+        L.mi_vina_set_user_grid.argtypes = [vp, vp, vp, vp, vp, C.c_float]
+        L.mi_vina_set_user_grid.restype = C.c_int
         L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
         L.mi_vina_set_ligand.restype = C.c_int
         L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
@@ -594,6 +598,21 @@ class Scorer:
             self.handle = None
 
 
+def user_grid_parse(text):
+    """setup_user_gd + the value lines of grid::init (main.cpp:635-670, grid.cpp:69-92) ->
+    (begin[3], end[3], n[3], values[nz][ny][nx] float64)"""
+    if isinstance(text, str):
+        text = text.encode()
+    b = np.zeros(3, dtype=np.float32)
+    e = np.zeros(3, dtype=np.float32)
+    n = np.zeros(3, dtype=np.int32)
+    cnt = C.c_size_t(0)
+    check(lib().mi_user_grid_parse(text, len(text), _ptr(b), _ptr(e), _ptr(n), None, 0, C.byref(cnt)))
+    v = np.zeros(cnt.value, dtype=np.float64)
+    check(lib().mi_user_grid_parse(text, len(text), _ptr(b), _ptr(e), _ptr(n), _ptr(v), v.size, C.byref(cnt)))
+    return b, e, n, v.reshape(int(n[2]), int(n[1]), int(n[0]))
+
+
 class Vina:
     """Vina/smina engine: pair tables + receptor cache grids + one prepared ligand
     (mirror of precalculate_linear + cache + model::eval_deriv + quasi_newton)."""
@@ -620,6 +639,18 @@ class Vina:
         begin, end, n, lt = _f32(begin), _f32(end), _i32(n), _i32(lig_types)
         check(lib().mi_vina_build_cache(self.handle, _ptr(begin), _ptr(end), _ptr(n), _ptr(lt), len(lt), slope))
         self.grid_shape = (int(n[2]) + 1, int(n[1]) + 1, int(n[0]) + 1)
+
+    def set_user_grid(self, begin, end, n, values, scaling_factor=1.0):
+        """--user_grid: values = the file's numbers ([nz][ny][nx], float64), or None to remove it; before build_cache"""
+        if values is None:
+            check(lib().mi_vina_set_user_grid(self.handle, None, None, None, None, 1.0))
+            return
+        b = np.ascontiguousarray(begin, dtype=np.float32)
+        e = np.ascontiguousarray(end, dtype=np.float32)
+        nn = np.ascontiguousarray(n, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        assert v.size == int(nn[0]) * int(nn[1]) * int(nn[2])
+        check(lib().mi_vina_set_user_grid(self.handle, _ptr(b), _ptr(e), _ptr(nn), _ptr(v), float(scaling_factor)))
 
     def cache_grid(self, smt):
         out = np.empty(self.grid_shape, dtype=np.float32)

@@ -37,6 +37,11 @@ struct VinaEnv {
   int n_rec;
   float w5[5];
   float box_begin[3], box_end[3];
+  // --user_grid (main.cpp:1342-1350): a second trilinear grid with its own dims, added per atom in
+  // non_cache(_cnn)::eval_deriv (non_cache.cpp:168-173, non_cache_cnn.cpp:141-150); null = none
+  VinaGridGeom ug_geom;
+  const float *ug_data;
+  int ug_model;  // MODE 2 adds model::eval's user-grid sum (MI_VINA_USER_TERM)
   // screen mode of the batch kernels (mi_vina_*_screen): item b is a conformation of ligand item_lig[b] of `ligs`;
   // rows of confs / change / coords are then strided by the maxima over the set
   const struct VinaLigand *ligs;
@@ -131,6 +136,10 @@ struct VinaPopulateArgs {
   // per dimension and lattice index: the candidate brick of the point's 3 A cell (szv_grid_cache::get), see
   // mi_vina_build_cache.  [dimx + dimy + dimz] (lo, hi)
   const float2 *brick;
+  // --user_grid: added to every point (cache.cpp:177-179); null = none
+  VinaGridGeom ug_geom;
+  const float *ug_data;
+  float ug_slope;
 };
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage);

@@ -725,6 +725,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         dx = wave_sum(dx);
         dy = wave_sum(dy);
         dz = wave_sum(dz);
+        if (env.ug_data) {  // user grid at the atom's own coordinates, before the curl (non_cache.cpp:168-173)
+          float ux, uy, uz;
+          pe += grid_evaluate<true>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
+                                    env.slope, 1000.f, ux, uy, uz);  // grid::evaluate_user, grid.cpp:47-49
+          dx += ux, dy += uy, dz += uz;
+        }
         curl3(pe, dx, dy, dz, v1);
         if (lane == 0) {
           w.forces[3 * i] = dx + env.slope * oobd[0];
@@ -861,6 +867,16 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     wave_sync();
     fold_forces(L, w, change);
   }
+  if ((MODE == 1 || (MODE == 2 && env.ug_model)) && env.ug_data) {
+    // model::eval's own user-grid term (model.cu:125-134): every atom of the ligand, hydrogens included, at slope
+    // 1000 -- this (not the igrid) is how --user_grid reaches eval_adjusted and the final energies
+    const int lb = L.lig_end > L.lig_begin ? L.lig_begin : 0, le = L.lig_end > L.lig_begin ? L.lig_end : L.n_atoms;
+    for (int i = lb + lane; i < le; i += 64) {
+      float ux, uy, uz;
+      e_part += grid_evaluate<false>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
+                                     1000.f, 1000.f, ux, uy, uz);
+    }
+  }
   wave_sync();
   return wave_sum(e_part);
 }
@@ -958,6 +974,14 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
         }
       }
       pen += dist * a.slope;
+      if (env.ug_data && a.forces) {  // this_e / deriv of non_cache_cnn.cpp:141-151: the user grid term, curled on its own
+        float ux, uy, uz;
+        float uge = grid_evaluate<true>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
+                                        a.slope, 1000.f, ux, uy, uz);
+        curl3(uge, ux, uy, uz, a.v);
+        pen += uge;
+        f[0] += ux, f[1] += uy, f[2] += uz;
+      }
       fx = f[0], fy = f[1], fz = f[2];
     }
     w.forces[3 * i] = fx;
@@ -1002,6 +1026,12 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
       dx = wave_sum(dx);
       dy = wave_sum(dy);
       dz = wave_sum(dz);
+      if (env.ug_data) {  // emp_e += uge; emp_deriv += ug_deriv (non_cache_cnn.cpp:146-149)
+        float ux, uy, uz;
+        pe += grid_evaluate<true>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
+                                  a.slope, 1000.f, ux, uy, uz);
+        dx += ux, dy += uy, dz += uz;
+      }
       curl3(pe, dx, dy, dz, a.v);
       if (lane == 0) {
         const float den = 1.0f + a.weight;
@@ -2128,6 +2158,12 @@ __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) 
         aff += a.fast[(long)tri_idx(t1, a.lig_type) * a.n + (int)(a.factor * r2)];
       }
     }
+  }
+  // cache.cpp:177-179: `user_grid.evaluate_user(vec(x, y, z), slope)` -- the lattice INDICES go in as the location
+  // (not the point's coordinates); reproduced as the reference computes it
+  if (a.ug_data) {
+    float ux, uy, uz;
+    aff += grid_evaluate<false>(a.ug_geom, a.ug_data, (float)x, (float)y, (float)z, a.ug_slope, 1000.f, ux, uy, uz);
   }
   if (live) a.out[idx] = aff;
 }

@@ -85,6 +85,10 @@ struct Vina {
   DevBuf<float> d_grids;
   float slope = 1e3f;
   float box_begin[3] = {0, 0, 0}, box_end[3] = {0, 0, 0};
+  // --user_grid
+  bool have_ug = false;
+  VinaGridGeom ug_geom{};
+  DevBuf<float> d_ug;
   float w5[5];
   // ligand
   bool have_lig = false;
@@ -169,6 +173,8 @@ static VinaEnv make_env(const Vina &v) {
     e.box_begin[i] = v.box_begin[i];
     e.box_end[i] = v.box_end[i];
   }
+  e.ug_geom = v.ug_geom;
+  e.ug_data = v.have_ug ? v.d_ug.p : nullptr;
   return e;
 }
 
@@ -307,11 +313,111 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
     a.lig_type = t;
     a.out = v.d_grids.p + v.grid_off[t];
     a.brick = v.d_brick.p;
+    a.ug_geom = v.ug_geom;
+    a.ug_data = v.have_ug ? v.d_ug.p : nullptr;
+    a.ug_slope = slope;
     launch_vina_populate(a, v.stream);
   }
   MIG_HIP(hipGetLastError());
   MIG_HIP(hipStreamSynchronize(v.stream));
   v.have_cache = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// grid::init(gd, user_in, ug_scaling_factor), grid.cpp:69-92: (n + 1)^3 points of which the file fills [0, n)^3 in
+// z, y, x order (x fastest) with -(value * scale); the last plane of every dimension stays 0.
+mi_status mi_vina_set_user_grid(mi_vina *vv, const float *begin3, const float *end3, const int32_t *n3,
+                                const double *values, float scaling_factor) {
+  VTRY
+  MIG_CHECK(vv, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  if (!values) {  // no user grid
+    v.have_ug = false;
+    return MI_OK;
+  }
+  MIG_CHECK(begin3 && end3 && n3, 1, "bad arguments");
+  VinaGridGeom g{};
+  for (int i = 0; i < 3; i++) {
+    MIG_CHECK(n3[i] > 0 && n3[i] < 4096 && end3[i] > begin3[i], 1, "bad user grid dims");
+    g.dim[i] = n3[i] + 1;
+    g.init[i] = begin3[i];
+    const float range = end3[i] - begin3[i];
+    g.dim_m1[i] = (float)g.dim[i] - 1.0f;
+    g.factor[i] = g.dim_m1[i] / range;
+    g.factor_inv[i] = 1 / g.factor[i];
+  }
+  std::vector<float> data((size_t)g.dim[0] * g.dim[1] * g.dim[2], 0.f);
+  size_t k = 0;
+  for (int z = 0; z < n3[2]; z++)
+    for (int y = 0; y < n3[1]; y++)
+      for (int x = 0; x < n3[0]; x++, k++)
+        data[(size_t)x + (size_t)g.dim[0] * ((size_t)y + (size_t)g.dim[1] * z)] = (float)(-(values[k] * (double)scaling_factor));
+  v.d_ug.upload(data.data(), data.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+  v.ug_geom = g;
+  v.have_ug = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// setup_user_gd (main.cpp:635-670) + the value lines of grid::init: three header lines are skipped, then SPACING g,
+// NELEMENTS nx ny nz, CENTER cx cy cz (fields split at every white-space character like boost::split with
+// is_space -- no token compression), then one number per line.  Arithmetic in the reference's types (fl = float,
+// atof = double).
+mi_status mi_user_grid_parse(const char *text, size_t len, float *begin3, float *end3, int32_t *n3, double *values,
+                             size_t cap, size_t *n_values) {
+  VTRY
+  MIG_CHECK(text && begin3 && end3 && n3 && n_values, 1, "bad arguments");
+  size_t pos = 0;
+  auto getline = [&](std::string &line) -> bool {
+    if (pos >= len) {
+      line.clear();
+      return false;
+    }
+    size_t e = pos;
+    while (e < len && text[e] != '\n') e++;
+    line.assign(text + pos, e - pos);
+    pos = e < len ? e + 1 : e;
+    return true;
+  };
+  auto split = [](const std::string &line) {
+    std::vector<std::string> t(1);
+    for (char c : line) {
+      if (c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f') t.emplace_back();
+      else t.back().push_back(c);
+    }
+    return t;
+  };
+  auto field = [](const std::vector<std::string> &t, size_t i) { return i < t.size() ? atof(t[i].c_str()) : 0.0; };
+  std::string line;
+  for (int i = 0; i < 3; i++) getline(line);
+  getline(line);
+  const float gran = (float)field(split(line), 1);
+  getline(line);
+  std::vector<std::string> t = split(line);
+  float size[3], center[3];
+  for (int i = 0; i < 3; i++) size[i] = (float)((field(t, 1 + i) + 1) * gran);
+  getline(line);
+  t = split(line);
+  for (int i = 0; i < 3; i++) center[i] = (float)(field(t, 1 + i) + 0.5 * gran);
+  MIG_CHECK(gran > 0.f, 1, "user grid: SPACING must be positive");
+  size_t total = 1;
+  for (int i = 0; i < 3; i++) {
+    n3[i] = (int32_t)std::ceil(size[i] / gran);
+    MIG_CHECK(n3[i] > 0 && n3[i] < 4096, 1, "user grid: bad NELEMENTS");
+    const float real_span = gran * (float)n3[i];
+    begin3[i] = center[i] - real_span / 2;
+    end3[i] = begin3[i] + real_span;
+    total *= (size_t)n3[i];
+  }
+  *n_values = total;
+  if (!values) return MI_OK;  // size query
+  MIG_CHECK(cap >= total, 1, "user grid: value buffer too small");
+  for (size_t k = 0; k < total; k++) {  // (a short file leaves atof("") = 0 like the reference's failed getline)
+    getline(line);
+    values[k] = atof(line.c_str());
+  }
   return MI_OK;
   VCATCH_STATUS
 }
@@ -533,6 +639,7 @@ mi_status mi_vina_eval_screen(mi_vina *vv, const int32_t *item_ligand, const flo
   if (coords) v.d_coords.ensure((size_t)B * xs);
   env.direct = (with_deriv & MI_VINA_DIRECT) ? 1 : 0;
   env.exact = (with_deriv & MI_VINA_EXACT) ? 1 : 0;
+  env.ug_model = (with_deriv & MI_VINA_USER_TERM) ? 1 : 0;
   with_deriv &= 7;
   launch_vina_eval(env, big, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
                    change ? v.d_change.p : nullptr, coords ? v.d_coords.p : nullptr, v.stream);
@@ -587,6 +694,7 @@ mi_status mi_vina_eval_batch(mi_vina *vv, const float *confs, int B, const float
   VinaEnv env = make_env(v);
   env.direct = (with_deriv & MI_VINA_DIRECT) ? 1 : 0;
   env.exact = (with_deriv & MI_VINA_EXACT) ? 1 : 0;
+  env.ug_model = (with_deriv & MI_VINA_USER_TERM) ? 1 : 0;
   with_deriv &= 7;
   launch_vina_eval(env, v.lig, v.d_confs.p, B, v3[0], v3[1], v3[2], with_deriv, v.d_energy.p,
                    change ? v.d_change.p : nullptr, coords ? v.d_coords.p : nullptr, v.stream);
@@ -935,6 +1043,7 @@ mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_c
     a.cnn_half = box->cnn_dimension / 2.0f;
   }
   a.slope = slope;
+  a.v = box && box->v > 0 ? box->v : 1000.0f;  // the curl cap `v` of eval_deriv(m, v, user_grid): user-grid term, blend
   if (box && with_deriv && (box->mix_emp_force || box->mix_emp_energy)) {
     MIG_CHECK(v.n_rec > 0, 4, "mix_emp_force / mix_emp_energy need the receptor (mi_vina_set_receptor)");
     a.mix_force = box->mix_emp_force ? 1 : 0;
@@ -1382,7 +1491,7 @@ mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const f
   MIG_CHECK(vv && confs && v3 && e_final && B >= 0, 1, "bad arguments");
   if (B == 0) return MI_OK;
   std::vector<float> inter(B), intra(B);
-  mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 2 | MI_VINA_DIRECT, inter.data(), nullptr, nullptr);
+  mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 2 | MI_VINA_DIRECT | MI_VINA_USER_TERM, inter.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
   st = mi_vina_eval_batch(vv, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
@@ -1400,7 +1509,7 @@ mi_status mi_vina_final_energies_screen(mi_vina *vv, const int32_t *item_ligand,
   MIG_CHECK(vv && item_ligand && confs && v3 && num_tors && e_final && B >= 0, 1, "bad arguments");
   if (B == 0) return MI_OK;
   std::vector<float> inter(B), intra(B);
-  mi_status st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 2 | MI_VINA_DIRECT, inter.data(), nullptr, nullptr);
+  mi_status st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 2 | MI_VINA_DIRECT | MI_VINA_USER_TERM, inter.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
   st = mi_vina_eval_screen(vv, item_ligand, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
   if (st != MI_OK) return st;

@@ -26,7 +26,8 @@ mi_ligand_desc LigandArrays::desc() const {
   return d;
 }
 
-HipCache::HipCache(const model &m, const grid_dims &gd_in, const std::vector<smt> &atom_types_needed, fl slope)
+HipCache::HipCache(const model &m, const grid_dims &gd_in, const std::vector<smt> &atom_types_needed, fl slope,
+                   const std::string *user_grid_text, fl ug_scaling_factor)
     : slope_(slope) {
   mi_vina *v = mi_vina_create(nullptr, 8.0f, 32.0f);  // precalculate_linear(sf, 32) on the default terms
   if (!v) throw internal_error(mi_last_error(), 0);
@@ -46,6 +47,16 @@ HipCache::HipCache(const model &m, const grid_dims &gd_in, const std::vector<smt
     b[i] = gd[i].begin;
     e[i] = gd[i].end;
     n[i] = (int32_t)gd[i].n;
+  }
+  if (user_grid_text) {  // --user_grid: the file main.cpp:1342-1350 reads; baked into the grids by populate
+    float ub[3], ue[3];
+    int32_t un[3];
+    size_t cnt = 0;
+    ok(mi_user_grid_parse(user_grid_text->data(), user_grid_text->size(), ub, ue, un, nullptr, 0, &cnt));
+    std::vector<double> vals(cnt);
+    ok(mi_user_grid_parse(user_grid_text->data(), user_grid_text->size(), ub, ue, un, vals.data(), cnt, &cnt));
+    ok(mi_vina_set_user_grid(v, ub, ue, un, vals.data(), ug_scaling_factor));
+    have_user_grid_ = true;
   }
   std::vector<int32_t> types(atom_types_needed.begin(), atom_types_needed.end());
   ok(mi_vina_build_cache(v, b, e, n, types.data(), (int)types.size(), slope));
@@ -69,7 +80,10 @@ fl HipCache::eval(model &m, fl v) const {
 // cache::eval_deriv (cache.cpp:65-83): also leaves the gradient of every movable atom in m.minus_forces (0 for
 // hydrogens)
 fl HipCache::eval_deriv(model &m, fl v, const grid &user_grid) const {
-  if (user_grid.initialized()) throw internal_error("user grids are not supported by HipCache", 0);
+  // cache::eval_deriv ignores its user_grid argument: the grid went into the lattice values at populate time
+  // (cache.cpp:65-83,177-179).  Same here -- but only if this cache was built with it.
+  if (user_grid.initialized() && !have_user_grid_)
+    throw internal_error("HipCache was built without the user grid (pass its file text to the constructor)", 0);
   const size_t n = smt_.size();
   xyz_.resize(n * 3);
   forces_.resize(n * 3);
@@ -177,7 +191,10 @@ void unflatten(const std::vector<float> &g, change &c) {
 
 bool HipQuasiNewton::operator()(model &m, const precalculate &, igrid &ig, output_type &out, change &g, const vec &v,
                                 const grid &user_grid) const {
-  if (user_grid.initialized()) return false;
+  if (user_grid.initialized()) {
+    auto *hc = dynamic_cast<HipCache *>(&ig);
+    if (!hc || !hc->has_user_grid()) return false;
+  }
   std::vector<float> x = flatten(out.c), grad;
   fl e = 0;
   if (!(*this)(ig, x, grad, v, e)) return false;

@@ -50,12 +50,15 @@ class HipCache : public igrid {
   std::vector<int32_t> smt_;       // smina types of the movable atoms the igrid is asked about
   mutable std::vector<float> xyz_, forces_;
   fl slope_ = 1e3;
-  bool have_ligand_ = false;
+  bool have_ligand_ = false, have_user_grid_ = false;
 
  public:
   // cache(scoring_function_version, gd, slope) + populate(m, p, atom_types_needed, ...) (cache.cpp:44-48,104-184):
   // default Vina terms / weights (main.cpp:1324-1329), receptor = m.grid_atoms, one grid per needed ligand type.
-  HipCache(const model &m, const grid_dims &gd, const std::vector<smt> &atom_types_needed, fl slope = 1e3);
+  // user_grid_text: content of the --user_grid file (main.cpp:1342-1350) or null; ug_scaling_factor as computed there.
+  HipCache(const model &m, const grid_dims &gd, const std::vector<smt> &atom_types_needed, fl slope = 1e3,
+           const std::string *user_grid_text = nullptr, fl ug_scaling_factor = 1);
+  bool has_user_grid() const { return have_user_grid_; }
 
   fl eval(model &m, fl v) const override;
   fl eval_deriv(model &m, fl v, const grid &user_grid) const override;

@@ -200,6 +200,23 @@ mi_status mi_vina_build_cache(mi_vina *, const float *begin3, const float *end3,
 /* copy one type's grid back: float[(n3[2]+1)][(n3[1]+1)][(n3[0]+1)], x fastest (array3d.h:91-96) */
 mi_status mi_vina_cache_grid(mi_vina *, int smt, float *out, size_t n_floats);
 
+/* --user_grid (main.cpp:993,1342-1350): a caller-supplied potential on its own lattice.
+ * mi_user_grid_parse = setup_user_gd (main.cpp:635-670) + the value lines of grid::init(gd, user_in, scale)
+ * (grid.cpp:69-92): three header lines, "SPACING g", "NELEMENTS nx ny nz", "CENTER cx cy cz", then one number per
+ * line, x fastest.  Call with values = NULL to learn *n_values (= nx' ny' nz' of the derived grid_dims), then again
+ * with room for them.  mi_vina_set_user_grid stores -(value * scaling_factor) like the reference (values = NULL
+ * removes the grid) and must precede mi_vina_build_cache to take part in the cache grids.  What it changes, exactly
+ * as in the reference: cache::populate adds evaluate_user at every lattice point -- with the point's INDICES as the
+ * location (cache.cpp:177-179); non_cache::eval_deriv (MI_VINA_DIRECT with derivatives: refine_structure) and
+ * non_cache_cnn::eval_deriv (mi_cnn_eval_batch / mi_cnn_refine_batch) add it per heavy atom at the atom's
+ * coordinates (non_cache.cpp:168-173, non_cache_cnn.cpp:141-150); the igrids' energy-only evaluations do not see it
+ * (non_cache.cpp:76 has the term commented out), but model::eval (mi_vina_eval_batch with_deriv = 0, hence
+ * mi_vina_final_energies) adds its own sum over ALL atoms of the ligand at slope 1000 (model.cu:125-134). */
+mi_status mi_user_grid_parse(const char *text, size_t len, float begin[3], float end[3], int32_t n[3], double *values,
+                             size_t cap, size_t *n_values);
+mi_status mi_vina_set_user_grid(mi_vina *, const float begin[3], const float end[3], const int32_t n[3],
+                                const double *values, float scaling_factor);
+
 /* model.ligands[0] as the PDBQT parser lays it out (parse_pdbqt.cpp:343-380; tree.h:152-233):
  * nodes in DFS pre-order, node 0 = rigid root, node k>0 = segment owning torsion k-1; atoms stored
  * node by node with coordinates local to their node; interacting pairs per model::initialize_pairs
@@ -242,7 +259,8 @@ mi_status mi_vina_eval_batch(mi_vina *, const float *confs, int B, const float *
  * 4 eval_intramolecular (ligand pairs only, model.cu:352-399); OR-able flags: */
 enum {
   MI_VINA_DIRECT = 16, /* receptor term from the atoms, no grids: the non_cache igrid (non_cache.cpp:52-83,125-179) */
-  MI_VINA_EXACT = 32   /* precalculate_exact instead of the linear tables (precalculate.h:452-494) */
+  MI_VINA_EXACT = 32,  /* precalculate_exact instead of the linear tables (precalculate.h:452-494) */
+  MI_VINA_USER_TERM = 64 /* with_deriv = 2 only: add model::eval's user-grid sum over the ligand's atoms (model.cu:125-134) */
 };
 /* refine_structure (main.cpp:131-171): BFGS on non_cache, out-of-box slope 10 -> x10 per try (<= 5) until
  * non_cache::within; energy = max_fl when the pose never gets inside.  In place; tries [B] optional. */

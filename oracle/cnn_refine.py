@@ -23,6 +23,7 @@ class NonCacheCnn:
         self.cnn_center = None                # set by adjust_center
         self.slope = 10.0
         self.evals = 0
+        self.user_grid = None                 # (vina.GridDims, data [(n+1)^3]) of --user_grid, or None
 
     def adjust_center(self, conf):
         """DLScorer::set_center_from_model (dl_scorer.cpp:197-217): fp32 mean of the heavy movable atoms"""
@@ -106,8 +107,19 @@ class NonCacheCnn:
             pen, f = self._bounds(coords[i])
             forces[i] = grad[i] + f
             emp_e = np.float32(0)
+            uge, ugd = np.float32(0), np.zeros(3, dtype=np.float32)
+            if self.user_grid is not None:      # non_cache_cnn.cpp:141-151: this_e / deriv, curled on their own
+                uge, ugd = vina.grid_evaluate(self.user_grid[0], self.user_grid[1], coords[i], self.slope, 1000.0)
+                uge, ugd = np.float32(uge), ugd.astype(np.float32)
+                ce, cd = uge, ugd.copy()
+                if ce > 0 and self.v < 0.1 * MAX_FL:
+                    tmp = np.float32(self.v / (self.v + ce))
+                    ce, cd = ce * tmp, cd * tmp * tmp
+                forces[i] = forces[i] + cd
+                e += ce
             if self.mix_emp_force:
                 emp_e, emp_d, oob = self._empirical(i, coords[i])
+                emp_e, emp_d = emp_e + uge, emp_d + ugd     # :146-149
                 if emp_e > 0 and self.v < 0.1 * MAX_FL:          # curl (curl.h:29-42)
                     tmp = np.float32(self.v / (self.v + emp_e))
                     emp_e, emp_d = emp_e * tmp, emp_d * tmp * tmp

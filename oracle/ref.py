@@ -58,6 +58,7 @@ def lib():
         L.ref_pair_energy.argtypes = [vp, C.c_int, C.c_int, C.c_float]
         L.ref_build_grids.argtypes = [vp, _f32p, _f32p, C.c_float, C.c_int, _f32p, _f32p, _i32p, _i32p, C.c_int]
         L.ref_cache_probe.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_float, _f32p, _f32p]
+        L.ref_set_user_grid.argtypes = [vp, _f32p, _f32p, _i32p, C.c_char_p, C.c_float]
         L.ref_set_conf.argtypes = [vp, _f32p, _f32p]
         L.ref_initial_conf.argtypes = [vp, _f32p]
         L.ref_eval_deriv.argtypes = [vp, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p]
@@ -163,6 +164,17 @@ class Scene:
                                      len(extra_types)))
         self.gd = (b, e, n)
         return b, e, n
+
+    def set_user_grid(self, begin, end, n, value_lines, scale=1.0):
+        """grid::init(gd, user_in, scale) on the file's value lines (one number per line); None removes the grid.
+        Call before build_grids: cache::populate bakes it into the lattice."""
+        if value_lines is None:
+            _check(lib().ref_set_user_grid(self.h, None, None, None, None, 1.0))
+            return
+        nn = np.ascontiguousarray(n, dtype=np.int32)
+        _check(lib().ref_set_user_grid(self.h, _p(_f(begin)), _p(_f(end)), _p(nn, C.c_int32),
+                                       value_lines.encode() if isinstance(value_lines, str) else value_lines,
+                                       float(scale)))
 
     def cache_probe(self, t, xyz, v=1000.0, deriv=False):
         xyz = _f(xyz).reshape(-1, 3)

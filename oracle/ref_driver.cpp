@@ -325,6 +325,29 @@ int ref_build_grids(void *h, const float *center, const float *size, float slope
 }
 }  // extern "C"
 
+extern "C" {
+// --user_grid: grid::init(gd, user_in, ug_scaling_factor) (grid.cpp:69-92) on the value lines of the file; the grid_dims
+// come from the caller (setup_user_gd lives in main.cpp, which this library does not compile).  Before ref_build_grids.
+int ref_set_user_grid(void *h, const float *begin, const float *end, const int *n, const char *value_lines, float scale) {
+  RTRY
+  Scene &s = *(Scene *)h;
+  if (!value_lines) {
+    s.user_grid = grid();
+    return 0;
+  }
+  grid_dims ugd;
+  VINA_FOR(i, 3) {
+    ugd[i].begin = begin[i];
+    ugd[i].end = end[i];
+    ugd[i].n = (sz)n[i];
+  }
+  std::istringstream in(value_lines);
+  s.user_grid.init(ugd, in, scale);
+  return 0;
+  RCATCH(1)
+}
+}  // extern "C"
+
 // cache::grids is private and cache has no test friend: read a grid back through the public evaluation instead --
 // at a lattice point trilinear interpolation returns the stored value exactly (weights 1 and 0).
 extern "C" {

@@ -196,6 +196,36 @@ class McParams(C.Structure):
                 ("authentic_v", C.c_float * 3)]
 
 
+def user_grid_data(begin, end, n, values, scale=1.0):
+    """grid::init(gd, user_in, scale) (grid.cpp:69-92) -> (GridDims, data[(nz+1)][(ny+1)][(nx+1)]): the file fills
+    [0, n)^3 with -(value * scale), the last plane of every dimension stays 0."""
+    gd = GridDims()
+    for i in range(3):
+        gd.begin[i], gd.end[i], gd.n[i] = float(begin[i]), float(end[i]), int(n[i])
+    data = np.zeros(gd.shape, dtype=np.float32)
+    v = np.asarray(values, dtype=np.float64).reshape(int(n[2]), int(n[1]), int(n[0]))
+    data[:n[2], :n[1], :n[0]] = (-(v * float(np.float32(scale)))).astype(np.float32)
+    return gd, data
+
+
+def set_user_grid(begin=None, end=None, n=None, values=None, scale=1.0, cache_slope=1e3):
+    """--user_grid for the functions of this library that see it in the reference: cache_populate (at lattice
+    indices, cache.cpp:177-179) and noncache_eval with derivatives (non_cache.cpp:168-173).  values [nz][ny][nx]
+    float64; None removes it.  Process-wide: tests reset it."""
+    f = _voxel.lib().ora_vina_set_user_grid
+    f.restype = None
+    f.argtypes = [_f32p, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_float, C.c_float]
+    if values is None:
+        f(None, None, None, None, 1.0, 1e3)
+        return
+    b = np.ascontiguousarray(begin, dtype=np.float32)
+    e = np.ascontiguousarray(end, dtype=np.float32)
+    nn = np.ascontiguousarray(n, dtype=np.int32)
+    v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+    f(_p(b), _p(e), nn.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_double)), float(scale),
+      float(cache_slope))
+
+
 def mc_chain(scene, corner1, corner2, seed, n_steps, max_iters, num_saved=50, temperature=1.2, amplitude=2.0,
              min_rmsd=1.0, rng_kind=1, conf0=None):
     """monte_carlo::operator() for one chain -> (energies [n], confs [n,7+T], coords [n,nh,3], evals).

@@ -249,6 +249,39 @@ void ora_vina_cell_bricks(const ora_grid_dims *gd, int d, float *lo, float *hi) 
 
 static float closest_between(float b, float e, float x) { return x <= b ? b : (x >= e ? e : x); } /* brick.h:28-35 */
 
+float ora_vina_grid_evaluate(const ora_grid_dims *gd, const float *data, const float *loc, float slope, float v,
+                             float *deriv);
+
+/* --user_grid (main.cpp:1342-1350; grid::init(gd, user_in, scale) grid.cpp:69-92): process-wide state of this test
+ * library, set by the test before it builds grids / evaluates.  values: the file's numbers, [nz][ny][nx]; the
+ * (n + 1)^3 array keeps 0 in the last plane of every dimension.  values == NULL removes it. */
+static struct {
+  int on;
+  ora_grid_dims gd;
+  float *data;
+  float cache_slope; /* slope of the cache the grid is baked into (cache::populate passes its own) */
+} g_ug;
+void ora_vina_set_user_grid(const float *begin, const float *end, const int *n, const double *values, float scale,
+                            float cache_slope) {
+  free(g_ug.data);
+  g_ug.data = NULL;
+  g_ug.on = 0;
+  if (!values) return;
+  for (int i = 0; i < 3; i++) g_ug.gd.begin[i] = begin[i], g_ug.gd.end[i] = end[i], g_ug.gd.n[i] = n[i];
+  const size_t d0 = n[0] + 1, d1 = n[1] + 1, d2 = n[2] + 1;
+  g_ug.data = (float *)calloc(d0 * d1 * d2, sizeof(float));
+  size_t k = 0;
+  for (int z = 0; z < n[2]; z++)
+    for (int y = 0; y < n[1]; y++)
+      for (int x = 0; x < n[0]; x++, k++) g_ug.data[x + d0 * (y + d1 * (size_t)z)] = (float)(-(values[k] * scale));
+  g_ug.cache_slope = cache_slope;
+  g_ug.on = 1;
+}
+/* grid::evaluate_user (grid.cpp:47-49) */
+static float user_grid_eval(const float *loc, float slope, float *deriv) {
+  return ora_vina_grid_evaluate(&g_ug.gd, g_ug.data, loc, slope, 1000.0f, deriv);
+}
+
 void ora_vina_cache_populate(const ora_vina_tables *T, const ora_grid_dims *gd, const float *rec_xyz,
                              const int32_t *rec_smt, int n_rec, int lig_type, float *data) {
   grid_geom g = geom_of(gd);
@@ -275,6 +308,10 @@ void ora_vina_cache_populate(const ora_vina_tables *T, const ora_grid_dims *gd, 
           float dx = a[0] - px, dy = a[1] - py, dz = a[2] - pz;
           float r2 = dx * dx + dy * dy + dz * dz; /* vec_distance_sqr: sqr(x)+sqr(y)+sqr(z) */
           if (r2 <= T->cutoff_sqr) aff += ora_vina_eval_fast(T, rec_smt[i], lig_type, r2);
+        }
+        if (g_ug.on) { /* cache.cpp:177-179: the lattice INDICES are the location handed to evaluate_user */
+          const float idx[3] = {(float)x, (float)y, (float)z};
+          aff += user_grid_eval(idx, g_ug.cache_slope, NULL);
         }
         data[(size_t)x + (size_t)g.dim[0] * ((size_t)y + (size_t)g.dim[1] * z)] = aff;
       }
@@ -756,6 +793,13 @@ float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const f
 
 /* instrumentation for the design notes: how many trials the line searches take (index = trials used, 0..10) */
 static long g_trial_hist[11];
+static long g_mc_stats[4]; /* steps, accepted, accepted with a second BFGS, rotation mutations */
+void ora_vina_mc_stats(long *out, int reset) {
+  for (int i = 0; i < 4; i++) {
+    out[i] = g_mc_stats[i];
+    if (reset) g_mc_stats[i] = 0;
+  }
+}
 void ora_vina_trial_hist(long *out, int reset) {
   for (int i = 0; i < 11; i++) {
     out[i] = g_trial_hist[i];
@@ -847,8 +891,16 @@ static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) 
   return f0;
 }
 
-/* model::eval with ig = cache (cache.cpp:52-63 + model.cu:22-36): energy only, used by the
- * Metropolis step (monte_carlo.cpp:44-47). */
+/* model::eval's own user-grid term (model.cu:125-134): every atom of the ligand, hydrogens included, at slope 1000,
+ * added one by one after the pair terms -- this is how the user grid reaches the final energies (eval_adjusted). */
+static float model_eval_user_term(const ora_ligand *L, const float *coords, float e) {
+  if (!g_ug.on) return e;
+  const int b = L->lig_end > L->lig_begin ? L->lig_begin : 0, en = L->lig_end > L->lig_begin ? L->lig_end : L->n_atoms;
+  for (int i = b; i < en; i++) e += user_grid_eval(coords + 3 * i, 1000.0f, NULL);
+  return e;
+}
+
+/* model::eval with ig = cache (cache.cpp:52-63 + model.cu:22-36): energy only (score_only / final energies). */
 float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const float *const *grids, float slope,
                     const ora_ligand *L, const float *conf, const float *v) {
   const int n = L->n_atoms;
@@ -881,6 +933,7 @@ float ora_vina_eval(const ora_vina_tables *T, const ora_grid_dims *gd, const flo
     }
     e += ie;
   }
+  e = model_eval_user_term(L, coords, e);
   free(coords);
   free(origin);
   free(axis);
@@ -913,13 +966,10 @@ float ora_vina_cache_eval(const ora_grid_dims *gd, const float *const *grids, fl
  * metropolis_accept (monte_carlo.cpp:38-42), conf randomize (conf.h:119-122,189-192),
  * add_to_output_container (coords.cpp:25-56).
  *
- * DEVIATION (documented, SURVEY "Hard parts"): the reference draws from boost::mt19937 through
- * boost's uniform_real / uniform_int / normal_distribution, whose exact algorithms depend on the
- * (unvendored) Boost version; trajectories cannot be reproduced without it.  The oracle and the
- * HIP kernel therefore share this small counter-based generator instead; parity for the MC row
- * is statistical.  Second deviation: gyration_radius and the Metropolis energy are taken at the
- * chain's current conformation (the reference reads whatever coordinates the last evaluation left
- * in `model`, identical except after a rejected BFGS).
+ * The chain draws from the reference's stream (rng kind 1 below: mt19937 + Boost's distributions restated, verified
+ * draw by draw against oracle/_ref) and keeps the reference's `model` state: gyration_radius and the Metropolis energy
+ * are taken at the last conformation bfgs evaluated (model_conf), as monte_carlo.cpp does.  tests/test_ref_vina.py
+ * compares whole chains with the reference bit for bit.
  * ------------------------------------------------------------------------------------------- */
 /* Two generators behind one interface.
  * kind 0: the counter-based splitmix64 stream shared with the HIP kernel (statistical parity with the reference).
@@ -1127,11 +1177,14 @@ int ora_vina_mc_chain_rng(const ora_vina_tables *T, const ora_grid_dims *gd, con
       float prob = expf((tmp_e - cand_e) / P->temperature);
       accept = rng_fl(&rng, 0, 1) < prob;
     }
+    g_mc_stats[0]++;
     if (accept) {
+      g_mc_stats[1]++;
       memcpy(tmp, cand, sizeof(float) * nc);
       tmp_e = cand_e;
       memcpy(model_conf, tmp, sizeof(float) * nc); /* m.set(tmp.c) */
       if (tmp_e < best_e || n_out < P->num_saved) {
+        g_mc_stats[2]++;
         bfgs_model(T, gd, grids, slope, L, tmp, P->authentic_v, P->max_iters, model_conf, &evals);
         tmp_e = ora_vina_cache_eval(gd, grids, slope, L, model_conf, P->authentic_v[1]);
         memcpy(model_conf, tmp, sizeof(float) * nc); /* m.set(tmp.c) */
@@ -1305,6 +1358,11 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
       }
     }
     if (deriv) {
+      if (g_ug.on) { /* non_cache.cpp:168-173 */
+        float ud[3] = {0, 0, 0};
+        this_e += user_grid_eval(coords + 3 * i, slope, ud);
+        for (int k = 0; k < 3; k++) d[k] += ud[k];
+      }
       curl3(&this_e, d, v[1]);
       for (int k = 0; k < 3; k++) forces[3 * i + k] = d[k] + slope * oob_d[k];
     } else {
@@ -1344,11 +1402,13 @@ float ora_vina_noncache_eval(const ora_vina_tables *T, const float *w, int exact
   if (deriv && change) all_derivatives(L, coords, forces, origin, axis, change);
   if (inter_out) *inter_out = e;
   if (intra_out) *intra_out = ie;
+  float total = e + ie;
+  if (!deriv) total = model_eval_user_term(L, coords, total);
   free(coords);
   free(forces);
   free(origin);
   free(axis);
-  return e + ie;
+  return total;
 }
 
 /* non_cache::within (non_cache.cpp:84-101), margin 0.0001 */

@@ -59,3 +59,16 @@ def random_confs(rng, conf0, k, spread=1.0, tors=3.0, small=False):
         c[7:] = rng.uniform(-tors, tors, len(c) - 7).astype(np.float32) * (0.2 if small else 1.0)
         out.append(c)
     return np.stack(out)
+
+
+def user_grid_text(center, nelem, spacing, seed=5, amplitude=3.0):
+    """A --user_grid file (AutoDock-map style header, main.cpp:635-670): three header lines, SPACING, NELEMENTS, CENTER,
+    then (nx+2)(ny+2)(nz+2)-ish value lines -- setup_user_gd turns NELEMENTS n into ceil((n + 1) * g / g) intervals.
+    Returns (text, value_lines) -- the latter is what grid::init reads after the header."""
+    rng = np.random.RandomState(seed)
+    n = [int(np.ceil(np.float32((k + 1) * spacing) / np.float32(spacing))) for k in nelem]
+    vals = rng.uniform(-amplitude, amplitude, size=n[0] * n[1] * n[2])
+    lines = "\n".join("%.5f" % v for v in vals) + "\n"
+    head = ("GRID_PARAMETER_FILE user.gpf\nGRID_DATA_FILE user.fld\nMACROMOLECULE rec.pdbqt\n"
+            "SPACING %.3f\nNELEMENTS %d %d %d\nCENTER %.3f %.3f %.3f\n" % ((spacing,) + tuple(nelem) + tuple(center)))
+    return head + lines, lines

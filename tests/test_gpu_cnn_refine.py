@@ -204,3 +204,42 @@ def test_monte_carlo_with_the_cnn_as_metropolis_energy(setup):
     assert np.array_equal(eA, eB) and np.array_equal(cfA, cfB)                      # deterministic
     assert all(np.all(np.diff(eA[b, :nA[b]]) >= 0) for b in range(8))               # containers sorted by CNN energy
     assert not np.array_equal(cfA[:, 0], cfV[:, 0])                                  # the CNN accepts differently
+
+
+@pytest.mark.parametrize("mix_force", [False, True])
+def test_cnn_eval_deriv_with_a_user_grid(setup, mix_force):
+    """--user_grid in non_cache_cnn::eval_deriv (non_cache_cnn.cpp:141-151): per heavy atom, curled on its own, also
+    part of the empirical blend; ::eval does not see it."""
+    from tests import ref_cases as RC
+    capi, sc, lig, v, olig = setup
+    name = "crossdock_default2018"
+    s = capi.Scorer([name])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    text, _ = RC.user_grid_text(sc["center"], (14, 14, 14), 1.0, seed=8, amplitude=5.0)
+    ub, ue, un, vals = capi.user_grid_parse(text)
+    rng = np.random.RandomState(22)
+    confs = random_confs(lig, rng, 2)
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    cen = np.stack([heavy_center(ovina.set_conf(olig, lig["conf0"])[0], lig["smt"])] * 2)
+    box = capi.CnnBox.make(23.5, lo, hi, slope=10.0, mix_emp_force=mix_force, empirical_weight=0.7, v=1000.0)
+    e_plain, ch_plain = v.cnn_eval_batch(s, confs, box, cen, deriv=True)
+    e0_plain, _ = v.cnn_eval_batch(s, confs, box, cen, deriv=False)
+    try:
+        v.set_user_grid(ub, ue, un, vals, 0.5)
+        e, ch = v.cnn_eval_batch(s, confs, box, cen, deriv=True)
+        e0, _ = v.cnn_eval_batch(s, confs, box, cen, deriv=False)
+    finally:
+        v.set_user_grid(None, None, None, None)
+    assert np.abs(e0 - e0_plain).max() < 1e-5 * np.abs(e0_plain).max()        # ::eval: no user grid
+    assert np.abs(ch - ch_plain).max() > 1e-3
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    nc = cnn_refine.NonCacheCnn([blob], sc["rec_xyz"], sc["rec_smt"], olig, (lo, hi), 23.5, mix_emp_force=mix_force,
+                                empirical_weight=0.7, tables=ovina.Tables(), v=1000.0)
+    nc.cnn_center = cen[0]
+    nc.slope = 10.0
+    nc.user_grid = ovina.user_grid_data(ub, ue, un, vals, 0.5)
+    for b in range(2):
+        eo, cho = nc.eval_deriv(confs[b])
+        assert abs(e[b] - eo) < 3e-4 * max(1.0, abs(eo)), (b, e[b], eo)
+        assert np.abs(ch[b] - cho).max() < 3e-3 * max(np.abs(cho).max(), 1e-3), (b, ch[b], cho)

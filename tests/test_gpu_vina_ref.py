@@ -200,3 +200,44 @@ def test_flexible_residues_in_the_search_on_the_device(capi):
     n, e, cf, xyz, ev = v.mc_batch(seeds[:8], list(G[P + "begin"]), list(G[P + "end"]), capi.McParams.default(150, mi, 20))
     assert (n >= 1).all() and np.isfinite(e[:, 0]).all()
     assert np.abs(cf[:, 0, 13:] - d["conf0"][13:]).max() > 1e-3            # the residue's torsions were searched too
+
+
+def test_user_grid_follows_the_reference(capi):
+    """--user_grid (main.cpp:1342-1350) against what oracle/_ref computes with the same file
+    (tests/golden/user_grid_goldens.npz, make_user_grid_goldens.py): baked into the cache lattice at the lattice
+    INDICES (cache.cpp:177-179), per heavy atom in non_cache::eval_deriv (non_cache.cpp:168-173), model::eval's own
+    sum over all ligand atoms (model.cu:125-134) and through it the final energies."""
+    U = np.load(os.path.join(os.path.dirname(__file__), "golden", "user_grid_goldens.npz"))
+    lig = capi.read_pdbqt_ligand(bytes(U["lig_text"]).decode(), is_text=True)
+    ub, ue, un, vals = capi.user_grid_parse(bytes(U["user_grid_text"]))
+    assert np.array_equal(ub, U["ub"]) and np.array_equal(ue, U["ue"]) and np.array_equal(un, U["un"])
+    v = capi.Vina()
+    v.set_receptor(U["rec_xyz"], U["rec_smt"])
+    v.set_user_grid(ub, ue, un, vals, float(U["scale"]))
+    v.build_cache(list(U["begin"]), list(U["end"]), [int(x) for x in U["n"]], [int(t) for t in U["types"]], 1e3)
+    v.set_ligand(lig)
+    idx = U["grid_idx"]
+    for k, t in enumerate(U["types"]):
+        g = v.cache_grid(int(t))
+        mine, want = g[idx[:, 2], idx[:, 1], idx[:, 0]], U["grid_val"][k]
+        assert np.abs(mine - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), t
+    confs = U["confs"]
+
+    def same(a, b, rel):
+        return all(abs(x - y) <= rel * max(1.0, abs(y)) for x, y in zip(a, b))
+
+    e, ch, _ = v.eval_batch(confs, V3, deriv=True, direct=True)                   # non_cache::eval_deriv
+    assert same(e, U["noncache/e"], 1e-4)
+    for b in range(len(confs)):
+        assert np.abs(ch[b] - U["noncache/change"][b]).max() <= 1e-3 * max(1.0, np.abs(U["noncache/change"][b]).max())
+    assert same(v.eval_batch(confs, V3, deriv=False, direct=True)[0], U["noncache/eval"], 1e-4)   # model::eval
+    e, ch, _ = v.eval_batch(confs, V3, deriv=True)                                # on the baked lattice
+    assert same(e, U["cache/e"], 1e-4)
+    for b in range(len(confs)):
+        assert np.abs(ch[b] - U["cache/change"][b]).max() <= 1e-3 * max(1.0, np.abs(U["cache/change"][b]).max())
+    assert same(v.eval_batch(confs, V3, deriv=False)[0], U["cache/eval"], 1e-4)
+    ef, intra = v.final_energies(confs, lig["num_tors"])
+    assert same(intra, U["final/intra"], 2e-4) and same(ef, U["final/e"], 2e-4)
+    # and without the grid the same engine gives other numbers
+    v.set_user_grid(None, None, None, None)
+    assert not same(v.eval_batch(confs, V3, deriv=True, direct=True)[0], U["noncache/e"], 1e-3)

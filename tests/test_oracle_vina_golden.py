@@ -138,3 +138,29 @@ def test_flexible_residues_in_the_search():
     e, cf, xyz, _ = V.mc_chain(S, G[P + "begin"], G[P + "end"], 1, 40, mi, num_saved=20, rng_kind=1, conf0=d["conf0"])
     assert np.array_equal(e, G[P + "mc/1_40/e"]) and np.array_equal(cf, G[P + "mc/1_40/conf"])
     assert np.array_equal(xyz, G[P + "mc/1_40/coords"])
+
+
+def test_user_grid_restatement_against_the_frozen_reference(capi):
+    """oracle/vina_ref.c's --user_grid terms against tests/golden/user_grid_goldens.npz (reference outputs)"""
+    U = np.load(os.path.join(os.path.dirname(__file__), "golden", "user_grid_goldens.npz"))
+    lig = capi.read_pdbqt_ligand(bytes(U["lig_text"]).decode(), is_text=True)
+    ub, ue, un, vals = capi.user_grid_parse(bytes(U["user_grid_text"]))
+    assert np.array_equal(ub, U["ub"]) and np.array_equal(ue, U["ue"]) and np.array_equal(un, U["un"])
+    try:
+        V.set_user_grid(ub, ue, un, vals, float(U["scale"]))
+        T, gd = V.Tables(), V.setup_grid_dims(U["center"], U["size"])
+        grids = {int(t): V.cache_populate(T, gd, U["rec_xyz"], U["rec_smt"], int(t)) for t in U["types"]}
+        idx = U["grid_idx"]
+        for k, t in enumerate(U["types"]):
+            assert np.array_equal(grids[int(t)][idx[:, 2], idx[:, 1], idx[:, 0]], U["grid_val"][k])
+        ora = V.Scene(T, gd, grids, V.LigandHandle(lig))
+        for b, conf in enumerate(U["confs"]):
+            e, ch, _, _ = V.noncache_eval(ora, U["rec_xyz"], U["rec_smt"], conf, (1000.0, 1000.0, 1000.0))
+            assert e == U["noncache/e"][b] and np.array_equal(ch, U["noncache/change"][b])
+            assert V.noncache_eval(ora, U["rec_xyz"], U["rec_smt"], conf, (1000.0, 1000.0, 1000.0), deriv=False)[0] == \
+                U["noncache/eval"][b]
+            e, ch, _, _ = ora.eval_deriv(conf, (1000.0, 1000.0, 1000.0))
+            assert e == U["cache/e"][b] and np.array_equal(ch, U["cache/change"][b])
+            assert ora.eval(conf, (1000.0, 1000.0, 1000.0)) == U["cache/eval"][b]
+    finally:
+        V.set_user_grid()

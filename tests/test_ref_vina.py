@@ -343,3 +343,64 @@ def test_flex_energies_bfgs_and_monte_carlo_bit_identical(flexcase):
         eo, co, xo, _ = V.mc_chain(ora, flexcase["b"], flexcase["e"], seed, steps, mi, num_saved=20, rng_kind=1,
                                    conf0=d["conf0"])
         assert np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
+
+
+def _setup_user_gd(center, nelem, spacing):
+    """main.cpp:635-670 in its own types (fl = float, atof = double)"""
+    g = np.float32(spacing)
+    size = [np.float32((float(k) + 1) * float(g)) for k in nelem]
+    ctr = [np.float32(float("%.3f" % c) + 0.5 * float(g)) for c in center]
+    n = [int(np.ceil(np.float32(s / g))) for s in size]
+    begin = [np.float32(c - np.float32(g * np.float32(k)) / np.float32(2)) for c, k in zip(ctr, n)]
+    end = [np.float32(b + np.float32(g * np.float32(k))) for b, k in zip(begin, n)]
+    return np.array(begin, np.float32), np.array(end, np.float32), np.array(n, np.int32)
+
+
+def test_user_grid_goes_into_the_cache_and_the_non_cache_derivative_like_the_reference(capi, rigid_text):
+    """--user_grid (main.cpp:1342-1350): cache::populate adds evaluate_user at every lattice point with the point's
+    INDICES as the location (cache.cpp:177-179); non_cache::eval_deriv adds it per heavy atom at the atom's coordinates
+    before the curl (non_cache.cpp:168-173); non_cache::eval does not see it, model::eval adds its own sum over all ligand atoms (model.cu:125-134).  Reader, restatement
+    and reference on the same file."""
+    lig_text = RC.cys_adduct_ligand()
+    lig = capi.read_pdbqt_ligand(lig_text, is_text=True)
+    center, size = RC.box_of(lig["coords0"])
+    text, value_lines = RC.user_grid_text(center, (18, 20, 16), 0.75)
+    b, e, n, vals = capi.user_grid_parse(text)
+    b0, e0, n0 = _setup_user_gd(center, (18, 20, 16), 0.75)
+    assert np.array_equal(n, n0) and np.array_equal(b, b0) and np.array_equal(e, e0)
+    assert vals.shape == (n[2], n[1], n[0]) and vals.ravel()[7] == float(value_lines.split("\n")[7])
+    scale = np.float32(1 - 0.25)                                  # --user_grid_lambda 0.25
+    plain = Case(capi, rigid_text, lig_text)                     # the same scene without the user grid
+    try:
+        s = ref.Scene(rigid_text, lig_text)
+        s.set_user_grid(b, e, n, value_lines, scale)
+        begin, end, nn = s.build_grids(center, size)
+        V.set_user_grid(b, e, n, vals, scale)
+        T, gd = V.Tables(), V.setup_grid_dims(center, size)
+        rec_xyz, rec_smt = s.grid_atoms()
+        types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+        grids = {t: V.cache_populate(T, gd, rec_xyz, rec_smt, t) for t in types}
+        rng = np.random.RandomState(4)
+        for t in types[:2]:
+            idx = rng.randint(0, [nn[0] + 1, nn[1] + 1, nn[2] + 1], size=(500, 3))
+            probe = s.cache_probe(t, _lattice(begin, end, nn, idx), v=3.4e38)   # not_max(v) false: no curl of the big values
+            assert np.array_equal(probe, grids[t][idx[:, 2], idx[:, 1], idx[:, 0]])
+        assert np.abs(grids[types[0]] - plain.grids[types[0]]).max() > 0.1
+        ora = V.Scene(T, gd, grids, V.LigandHandle(lig))
+        for conf in RC.random_confs(np.random.RandomState(5), lig["conf0"], 6):
+            er, cr, _, _ = s.eval_deriv(conf, V3, ig=1)         # non_cache::eval_deriv sees the user grid ...
+            eo, co, _, _ = V.noncache_eval(ora, rec_xyz, rec_smt, conf, V3)
+            assert er == eo and np.array_equal(cr, co)
+            ep, _, _, _ = plain.ref.eval_deriv(conf, V3, ig=1)
+            assert er != ep
+            # ... non_cache::eval does not (non_cache.cpp:76), but model::eval adds its own term over ALL ligand atoms
+            # (model.cu:125-134): that is how it reaches eval_adjusted / the final energies
+            assert s.ig_eval(conf, 1000.0, ig=1) == plain.ref.ig_eval(conf, 1000.0, ig=1)
+            assert s.eval(conf, V3, ig=1) != plain.ref.eval(conf, V3, ig=1)
+            assert s.eval(conf, V3, ig=1) == V.noncache_eval(ora, rec_xyz, rec_smt, conf, V3, deriv=False)[0]
+            assert s.eval(conf, V3) == ora.eval(conf, V3)
+            er, cr, _, _ = s.eval_deriv(conf, V3)                # cache: through the baked lattice
+            eo, co, _, _ = ora.eval_deriv(conf, V3)
+            assert er == eo and np.array_equal(cr, co)
+    finally:
+        V.set_user_grid()
