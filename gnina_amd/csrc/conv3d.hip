@@ -495,12 +495,15 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_tile = smem;
+  // [Q + 12] byte offset of every quad inside the halo tile (tap shift + channel quad); the entries behind the last
+  // quad repeat it: the K loop reads one step ahead and its last step may be partly padding (zero weights)
   int *s_qoff = reinterpret_cast<int *>(smem + (size_t)HV * CCs);
-  int *s_vox = s_qoff + Q;  // [HV] voxel index of every halo position inside the pose, -1 = padding
-  for (int q = tid; q < Q; q += NTHREADS) {
-    int tap = q / CC4, c4 = q - tap * CC4;
+  int *s_vox = s_qoff + Q + 12;  // [HV] float offset of every halo voxel's channel row inside the pose, -1 = padding
+  for (int q = tid; q < Q + 12; q += NTHREADS) {
+    const int qq = q < Q ? q : Q - 1;
+    int tap = qq / CC4, c4 = qq - tap * CC4;
     int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    s_qoff[q] = (p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4;
+    s_qoff[q] = ((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4) * 4;
   }
 
   const int NC = p.tcx * p.tcy * p.tcz;
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
     int cell = (wm * TM + m) * 2 + cell_in_mt;
     if (cell >= NC) cell = 0;
     int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
-    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs;
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs * 4;  // bytes
   }
   f32x4 acc[TM];
 #pragma unroll
@@ -523,66 +526,67 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
     const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
     const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
     const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
-    s_vox[hv] = in ? (x * S + y) * S + z : -1;
+    s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    if (!in)  // the zero padding is laid down once per workgroup; staging then touches the voxels inside the grid only
+      for (int c = 0; c < CCs; c += 4) *reinterpret_cast<float4 *>(s_tile + hv * CCs + c) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const unsigned inv_cc4 = ((1u << 20) + CC4 - 1) / CC4;  // it / CC4 == (it * inv_cc4) >> 20 for it < 2^20 / CC4
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
   const size_t wstride = (size_t)p.coutp * 4;  // 16 * 4 floats per quad row
-  const float *wq = p.wp + (size_t)row * 4;
 
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     __syncthreads();
     const int c_base = chunk * CC4 * 4;
-    // batched, division-free staging (see conv3d_mfma_kernel)
-    const int total_items = HV * CC4;
+    // voxel-major staging (see conv3d_mfma_kernel: every VALU instruction here is time taken from the MFMAs)
+    const float *src_c = in_b + c_base;
+    const int nq = min(CC4, p.cin4 - chunk * CC4);
     constexpr int U = 4;
-    for (int base = 0; base < total_items; base += NTHREADS * U) {
-      float4 val[U];
-      int dst[U], cq[U];
+    for (int hv = tid; hv < HV; hv += NTHREADS) {
+      const int off = s_vox[hv];
+      if (off < 0) continue;
+      float *dst = s_tile + hv * CCs;
+      for (int qb = 0; qb < nq; qb += U) {
+        float4 val[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int it = base + u * NTHREADS + tid;
-        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[u] = -1;
-        cq[u] = -1;
-        if (it < total_items) {
-          const int hv = (int)(((unsigned)it * inv_cc4) >> 20), c4 = it - hv * CC4;
-          const int vi = s_vox[hv];
-          dst[u] = hv * CCs + c4 * 4;
-          if (vi >= 0 && chunk * CC4 + c4 < p.cin4) {
-            cq[u] = c4;
-            val[u] = *reinterpret_cast<const float4 *>(in_b + (size_t)vi * p.in_cs + c_base + c4 * 4);
+        for (int u = 0; u < U; u++)
+          if (qb + u < nq) val[u] = *reinterpret_cast<const float4 *>(src_c + off + (qb + u) * 4);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (qb + u < nq) {
+            float4 x = val[u];
+            if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
+              const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c_base + (qb + u) * 4);
+              const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c_base + (qb + u) * 4);
+              x.x = x.x * sc.x + sh.x;
+              x.y = x.y * sc.y + sh.y;
+              x.z = x.z * sc.z + sh.z;
+              x.w = x.w * sc.w + sh.w;
+            }
+            *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
           }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (dst[u] < 0) continue;
-        float4 v = val[u];
-        if (p.bn_scale && cq[u] >= 0) {  // eval BatchNorm on the conv input; padding stays exactly 0
-          const int c = c_base + cq[u] * 4;
-          const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c);
-          const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c);
-          v.x = v.x * sc.x + sh.x;
-          v.y = v.y * sc.y + sh.y;
-          v.z = v.z * sc.z + sh.z;
-          v.w = v.w * sc.w + sh.w;
-        }
-        *reinterpret_cast<float4 *>(s_tile + dst[u]) = v;
       }
     }
+    if (nq < CC4)  // partial last chunk: its missing quads still hold the previous chunk's channels
+      for (int it = tid; it < HV * (CC4 - nq); it += NTHREADS) {
+        const int hv = it / (CC4 - nq), c4 = nq + it - hv * (CC4 - nq);
+        *reinterpret_cast<float4 *>(s_tile + hv * CCs + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     __syncthreads();
 
     // K loop over quad quartets, ping-pong operand sets (see conv3d_mfma_kernel); weights packed
-    // [chunk][quartet][4][16][4], pad quads have zero weights
-    const float *wchunk = wq + (size_t)chunk * P4 * 4 * wstride + (size_t)kq * wstride;
+    // [chunk][quartet][4][16][4] with one all-zero quartet behind the last (ConvArgs::wrows): pad quads multiply by
+    // zero, the read-ahead past the end needs no branch.  The tile offset of a lane's quad is read one step ahead;
+    // the weight row is affine in the step: uniform base in SGPRs + 32-bit lane offset.
+    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * p.wrows * wstride * 4;
+    const unsigned wlane = (unsigned)row * 16u + (unsigned)kq * (unsigned)wstride * 4u;
+    const unsigned wstep = 4u * (unsigned)wstride * 4u;  // bytes per quartet of rows
+    const int *lp = s_qoff + kq;
+    int e_next = lp[0];
     auto load_step = [&](int pr, float4 *aa, float4 &ww) {
-      int q = 4 * pr + kq;
-      q = q < Q ? q : Q - 1;
-      const int qo = s_qoff[q];
+      const int e = e_next;
 #pragma unroll
-      for (int m = 0; m < TM; m++) aa[m] = *reinterpret_cast<const float4 *>(s_tile + baseA[m] + qo);
-      ww = *reinterpret_cast<const float4 *>(wchunk + (size_t)pr * 4 * wstride);
+      for (int m = 0; m < TM; m++) aa[m] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_tile) + baseA[m] + e);
+      ww = *reinterpret_cast<const float4 *>(wbase + (wlane + (unsigned)pr * wstep));
+      e_next = lp[4 * pr + 4];
     };
     auto mfma_step = [&](const float4 *aa, const float4 &ww) {
 #pragma unroll
@@ -599,9 +603,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
     int pr = 0;
     for (; pr + 1 < P4; pr += 2) {
       load_step(pr + 1, a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
       mfma_step(a0, w0);
-      if (pr + 2 < P4) load_step(pr + 2, a0, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(pr + 2, a0, w0);  // (past the end: the zero quartet, unused)
+      __builtin_amdgcn_sched_barrier(0);
       mfma_step(a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (P4 & 1) mfma_step(a0, w0);
   }
@@ -634,8 +642,8 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  // (the N = 16 kernel keeps a [Q] offset table where this one has its [Q + 5] int2 list: sized for the larger)
-  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 5) + p.nchunks * p.cc4 + HV) * sizeof(int);
+  // (the N = 16 kernel keeps a [Q + 12] offset table where this one has its [Q + 5] int2 list: sized for the larger)
+  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 6) + p.nchunks * p.cc4 + HV) * sizeof(int);
   const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (p.coutp + 4) * sizeof(float) : 0;
   return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }

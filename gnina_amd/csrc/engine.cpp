@@ -210,7 +210,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   const int taps = o.ksize * o.ksize * o.ksize;
   const int kstep = n16 ? 4 : 2;  // quads per MFMA step: pairs for 32x32x2, quartets for 16x16x4
   // (the 32x32x2 kernel wants an all-zero row behind the last quad of every chunk: see ConvArgs::wrows)
-  const int Q = taps * a.cc4, P = n16 ? (Q + kstep - 1) / kstep : Q / kstep + 1;
+  const int Q = taps * a.cc4, P = n16 ? (Q + kstep - 1) / kstep + 1 : Q / kstep + 1;  // (+ a zero quartet / zero rows)
   a.wrows = P * kstep;
   std::vector<float> wp((size_t)a.nchunks * P * kstep * a.coutp * 4, 0.f);
   // forward: canonical [tap][cin][cout]; backward: W'[tap][co][ci] = W[taps-1-tap][ci][co] (flipped, transposed)
