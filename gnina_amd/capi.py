@@ -20,7 +20,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_sdf_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_sdf_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_vina_mc_cnnall_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -151,6 +151,8 @@ def lib():
         L.mi_vina_cache_eval_coords.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
         L.mi_cnn_eval_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]
         L.mi_vina_mc_cnn_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.mi_vina_mc_cnnall_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.mi_vina_mc_cnnall_batch.restype = C.c_int
         L.mi_cnn_refine_batch.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
         L.mi_scorer_score_flex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mi_model_supports_gradient.argtypes = [vp]
@@ -840,8 +842,9 @@ class Vina:
                                      _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev)))
         return n, e, cf, xyz, ev
 
-    def mc_cnn_batch(self, scorer, seeds, corner1, corner2, params, box):
-        """Monte-Carlo chains with the CNN as the Metropolis energy (metrorescore / metrorefine) ->
+    def mc_cnn_batch(self, scorer, seeds, corner1, corner2, params, box, level_all=False):
+        """Monte-Carlo chains with the CNN as the Metropolis energy (metrorescore / metrorefine), or -- level_all --
+        as the igrid of the minimiser too (--cnn_scoring all) ->
         (n_saved [B], energies [B,S], confs [B,S,7+T], coords [B,S,nh,3], evals [B], cnn_evals)"""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         B, S = len(seeds), params.num_saved
@@ -853,8 +856,9 @@ class Vina:
         xyz = np.zeros((B, S, nh, 3), dtype=np.float32)
         ev = np.zeros(B, dtype=np.int32)
         ce = C.c_int32()
-        check(lib().mi_vina_mc_cnn_batch(self.handle, scorer.handle, B, _ptr(seeds), _ptr(c1), _ptr(c2), C.byref(params),
-                                         C.byref(box), _ptr(n), _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev), C.byref(ce)))
+        fn = lib().mi_vina_mc_cnnall_batch if level_all else lib().mi_vina_mc_cnn_batch
+        check(fn(self.handle, scorer.handle, B, _ptr(seeds), _ptr(c1), _ptr(c2), C.byref(params),
+                 C.byref(box), _ptr(n), _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev), C.byref(ce)))
         return n, e, cf, xyz, ev, ce.value
 
     def bfgs_batch(self, confs, v=(1000.0, 1000.0, 1000.0), max_iters=None):

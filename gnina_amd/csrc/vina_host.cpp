@@ -1355,6 +1355,310 @@ mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t
   VCATCH_STATUS
 }
 
+namespace {
+
+// boost::mt19937 (= std::mt19937) under the restated Boost distributions, host side: the same stream as McRng
+// (vina.hip) and the reference's random.cpp:27-75
+struct HostRng {
+  unsigned mt[624];
+  int idx = 624;
+  explicit HostRng(unsigned seed) {
+    mt[0] = seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
+  }
+  unsigned u32() {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; i++) {
+        const unsigned y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    unsigned y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  float fl(float a, float b) {  // uniform_real<float>
+    for (;;) {
+      const float r = (float)u32() / 4294967296.0f * (b - a) + a;
+      if (r < b) return r;
+    }
+  }
+  int irange(int a, int b) {  // uniform_int<int>
+    const unsigned range = (unsigned)b - (unsigned)a, brange = 0xffffffffu;
+    if (range == 0) return a;
+    unsigned bucket = brange / (range + 1);
+    if (brange % (range + 1) == range) ++bucket;
+    for (;;) {
+      const unsigned q = u32() / bucket;
+      if (q <= range) return (int)(q + (unsigned)a);
+    }
+  }
+  float normal() {  // normal_distribution<float>(0, 1), a fresh distribution per call (random.cpp:37-42)
+    const float r1 = fl(0.f, 1.f), r2 = fl(0.f, 1.f);
+    return std::sqrt(-2.0f * std::log(1.0f - r2)) * std::cos(2.0f * 3.14159265358979323846f * r1);
+  }
+  void inside_sphere(float &x, float &y, float &z) {
+    for (;;) {
+      x = fl(-1, 1), y = fl(-1, 1), z = fl(-1, 1);
+      if (x * x + y * y + z * z < 1) return;
+    }
+  }
+};
+
+}  // namespace
+
+// Monte-Carlo with the CNN as the igrid of BOTH the minimiser and the Metropolis step: --cnn_scoring all
+// (parallel_mc.cpp:156-159: (*mc)(m, out, p, new_cnn, ..., new_cnn)).  The chain itself -- RNG stream, mutation, bfgs<> +
+// fast_line_search, Metropolis, container -- advances on the host (n <= 40 variables per chain: negligible arithmetic);
+// every evaluation the chains of the call ask for in a round, non_cache_cnn::eval_deriv inside the line searches and
+// non_cache_cnn::eval at the update_energy points, is ONE device batch (coordinates -> CNN forward [+ backward] ->
+// penalties -> fold).  The reference does the same work one chain, one evaluation, one B = 1 forward at a time.
+mi_status mi_vina_mc_cnnall_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t *seeds, const float *corner1,
+                                  const float *corner2, const mi_mc_params *P, const mi_cnn_box *box, int32_t *out_n,
+                                  float *out_e, float *out_conf, float *out_coords, int32_t *evals, int32_t *cnn_evals) {
+  VTRY
+  MIG_CHECK(vv && sc && seeds && corner1 && corner2 && P && box && out_n && out_e && B >= 0, 1, "bad arguments");
+  MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(v.have_lig, 4, "set the ligand first");
+  MIG_CHECK(v.lig.n_movable == v.lig.n_atoms, 1, "flexible residues are not supported with the CNN in the loop yet");
+  MIG_CHECK(P->num_saved > 0 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1, "bad Monte-Carlo parameters");
+  if (B == 0) return MI_OK;
+  const int nt = v.lig.n_nodes - 1, n = 6 + nt, nc = 7 + nt, na = v.lig.n_atoms, S = P->num_saved;
+  std::vector<int> heavy;
+  for (int i = 0; i < na; i++)
+    if (v.h_lig_smt[i] > 1) heavy.push_back(i);
+  const int nh = (int)heavy.size();
+  MIG_CHECK(nh > 0, 1, "the ligand has no heavy atoms");
+  struct Saved {
+    float e;
+    std::vector<float> conf, xyz;
+  };
+  struct Chain {
+    HostRng rng;
+    std::vector<float> tmp, cand, mconf;
+    float tmp_e = 0, best_e = 3.402823466e+38f, cand_e = 0;
+    std::vector<Saved> out;
+    BfgsChain bf;
+    std::vector<float> last_eval;
+    bool have_center = false, accepted = false, second = false;
+    float center[3] = {0, 0, 0};
+    long evals = 0;
+    explicit Chain(unsigned seed) : rng(seed) {}
+  };
+  std::vector<Chain> ch;
+  ch.reserve(B);
+  for (int b = 0; b < B; b++) {
+    ch.emplace_back((unsigned)seeds[b]);
+    Chain &c = ch.back();
+    c.tmp.assign(nc, 0.f);
+    // conf::randomize (conf.h:119-122,189-192)
+    for (int k = 0; k < 3; k++) c.tmp[k] = c.rng.fl(corner1[k], corner2[k]);
+    float q[4], nrm;
+    do {  // random_orientation; abs(qt) scales by the largest component (quaternion.h:169-190)
+      for (int k = 0; k < 4; k++) q[k] = c.rng.normal();
+      const float mx = std::max(std::max(std::fabs(q[0]), std::fabs(q[1])), std::max(std::fabs(q[2]), std::fabs(q[3])));
+      nrm = 0.f;
+      if (mx != 0.f) {
+        const float inv = (float)(1.0 / (double)mx);
+        float sum = (q[0] * inv) * (q[0] * inv);
+        sum += (q[1] * inv) * (q[1] * inv);
+        sum += (q[2] * inv) * (q[2] * inv);
+        sum += (q[3] * inv) * (q[3] * inv);
+        nrm = mx * std::sqrt(sum);
+      }
+    } while (!(nrm > kEps));
+    for (int k = 0; k < 4; k++) c.tmp[3 + k] = q[k] / nrm;
+    for (int t = 0; t < nt; t++) c.tmp[7 + t] = c.rng.fl(-kPi, kPi);
+    c.mconf.assign(nc, 0.f);  // before the first evaluation `model` holds the input pose (zero torsions; only the
+    c.mconf[3] = 1.f;         // gyration radius is read from it, which no rigid placement changes)
+  }
+  CnnEvalScratch scratch;
+  long n_cnn = 0;
+  std::vector<float> req, cen, e_out, g_out, xyz;
+  std::vector<int> idx;
+  // one batched evaluation for the chains in idx: confs from `pick`, energies (and changes) back
+  auto evaluate = [&](const std::vector<int> &who, auto pick, bool deriv, float vcap) -> mi_status {
+    const int nb = (int)who.size();
+    req.resize((size_t)nb * nc), cen.resize((size_t)nb * 3), e_out.resize(nb);
+    if (deriv) g_out.resize((size_t)nb * n);
+    bool centred = true;
+    for (int i = 0; i < nb; i++) {
+      const float *x = pick(ch[who[i]]);
+      std::copy(x, x + nc, req.begin() + (size_t)i * nc);
+      std::copy(ch[who[i]].center, ch[who[i]].center + 3, cen.begin() + (size_t)i * 3);
+      centred = centred && ch[who[i]].have_center;
+    }
+    mi_cnn_box bx = *box;
+    bx.v = vcap;
+    n_cnn += nb;
+    // (before a chain's first update_energy its non_cache_cnn has no cube yet: cnn_gd is default-constructed)
+    return cnn_eval(v, sc, req.data(), nb, &bx, centred ? cen.data() : nullptr, box->slope, deriv ? 1 : 0, e_out.data(),
+                    deriv ? g_out.data() : nullptr, scratch);
+  };
+  auto coords_of = [&](const std::vector<int> &who, auto pick) -> mi_status {
+    const int nb = (int)who.size();
+    req.resize((size_t)nb * nc), xyz.resize((size_t)nb * na * 3);
+    for (int i = 0; i < nb; i++) {
+      const float *x = pick(ch[who[i]]);
+      std::copy(x, x + nc, req.begin() + (size_t)i * nc);
+    }
+    return mi_vina_coords_batch(vv, req.data(), nb, xyz.data());
+  };
+  // quasi_newton on non_cache_cnn for the chains in `who`, in lock step; leaves bf.x / bf.f0 and last_eval
+  auto minimise = [&](const std::vector<int> &who, auto start_from, float vcap) -> mi_status {
+    for (int b : who) {
+      ch[b].bf.start(start_from(ch[b]), nt, P->max_iters);
+      ch[b].last_eval.assign(start_from(ch[b]), start_from(ch[b]) + nc);
+    }
+    std::vector<int> active = who;
+    while (!active.empty()) {
+      mi_status st = evaluate(active, [](Chain &c) { return c.bf.request(); }, true, vcap);
+      if (st != MI_OK) return st;
+      std::vector<int> next;
+      for (size_t i = 0; i < active.size(); i++) {
+        Chain &c = ch[active[i]];
+        c.last_eval.assign(c.bf.request(), c.bf.request() + nc);  // what `model` holds after this evaluation
+        c.bf.feed(e_out[i], &g_out[i * n]);
+        c.evals++;
+        if (c.bf.state != BfgsChain::Done) next.push_back(active[i]);
+      }
+      active.swap(next);
+    }
+    return MI_OK;
+  };
+  // update_energy (monte_carlo.cpp:44-47): adjust_center on what `model` holds, then ig_metropolis->eval
+  auto update_energy = [&](const std::vector<int> &who, float vcap) -> mi_status {
+    mi_status st = coords_of(who, [](Chain &c) { return c.mconf.data(); });
+    if (st != MI_OK) return st;
+    for (size_t i = 0; i < who.size(); i++) {  // DLScorer::set_center_from_model (dl_scorer.cpp:197-217)
+      Chain &c = ch[who[i]];
+      float s0 = 0, s1 = 0, s2 = 0;
+      for (int a : heavy) s0 += xyz[(i * na + a) * 3], s1 += xyz[(i * na + a) * 3 + 1], s2 += xyz[(i * na + a) * 3 + 2];
+      c.center[0] = s0 / (float)nh, c.center[1] = s1 / (float)nh, c.center[2] = s2 / (float)nh;
+      c.have_center = true;
+    }
+    return evaluate(who, [](Chain &c) { return c.mconf.data(); }, false, vcap);
+  };
+  std::vector<int> all(B);
+  for (int b = 0; b < B; b++) all[b] = b;
+  for (int step = 0; step < P->n_steps; step++) {
+    // mutate_conf (mutate.cpp:35-73); the rotation needs the gyration radius of what `model` holds
+    std::vector<int> which(B), need;
+    for (int b = 0; b < B; b++) {
+      ch[b].cand = ch[b].tmp;
+      which[b] = ch[b].rng.irange(0, 2 + nt - 1);
+      if (which[b] == 1) need.push_back(b);
+    }
+    if (!need.empty()) {
+      mi_status st = coords_of(need, [](Chain &c) { return c.mconf.data(); });
+      if (st != MI_OK) return st;
+    }
+    size_t ni = 0;
+    for (int b = 0; b < B; b++) {
+      Chain &c = ch[b];
+      if (which[b] == 0) {
+        float dx, dy, dz;
+        c.rng.inside_sphere(dx, dy, dz);
+        c.cand[0] += P->mutation_amplitude * dx, c.cand[1] += P->mutation_amplitude * dy, c.cand[2] += P->mutation_amplitude * dz;
+      } else if (which[b] == 1) {
+        const float *co = &xyz[ni++ * na * 3];
+        float acc = 0;  // model::gyration_radius (model.cpp:1002-1014): heavy atoms about the ligand's root origin
+        for (int a : heavy) {
+          const float dx = co[3 * a] - c.mconf[0], dy = co[3 * a + 1] - c.mconf[1], dz = co[3 * a + 2] - c.mconf[2];
+          acc += dx * dx + dy * dy + dz * dz;
+        }
+        const float gr = std::sqrt(acc / (float)nh);
+        if (gr > kEps) {
+          float dx, dy, dz;
+          c.rng.inside_sphere(dx, dy, dz);
+          const float sc_ = P->mutation_amplitude / gr;
+          const float rot[6] = {0.f, 0.f, 0.f, sc_ * dx, sc_ * dy, sc_ * dz};
+          conf_increment(c.cand.data(), rot, 1.0f, 0);
+        }
+      } else {
+        c.cand[7 + (which[b] - 2)] = c.rng.fl(-kPi, kPi);
+      }
+    }
+    mi_status st = minimise(all, [](Chain &c) { return c.cand.data(); }, P->hunt_cap[1]);
+    if (st != MI_OK) return st;
+    for (int b = 0; b < B; b++) ch[b].cand = ch[b].bf.x, ch[b].mconf = ch[b].last_eval;
+    st = update_energy(all, P->authentic_v[1]);
+    if (st != MI_OK) return st;
+    std::vector<int> again;
+    for (int b = 0; b < B; b++) {
+      Chain &c = ch[b];
+      c.cand_e = e_out[b];
+      bool accept = step == 0 || c.cand_e < c.tmp_e;
+      if (!accept) accept = c.rng.fl(0.f, 1.f) < std::exp((c.tmp_e - c.cand_e) / P->temperature);  // metropolis_accept
+      c.accepted = accept;
+      c.second = false;
+      if (!accept) continue;
+      c.tmp = c.cand, c.tmp_e = c.cand_e, c.mconf = c.tmp;  // m.set(tmp.c)
+      if (c.tmp_e < c.best_e || (int)c.out.size() < S) {
+        c.second = true;
+        again.push_back(b);
+      }
+    }
+    if (again.empty()) continue;
+    st = minimise(again, [](Chain &c) { return c.tmp.data(); }, P->authentic_v[1]);
+    if (st != MI_OK) return st;
+    for (int b : again) ch[b].tmp = ch[b].bf.x, ch[b].mconf = ch[b].last_eval;
+    st = update_energy(again, P->authentic_v[1]);
+    if (st != MI_OK) return st;
+    for (size_t i = 0; i < again.size(); i++) ch[again[i]].tmp_e = e_out[i], ch[again[i]].mconf = ch[again[i]].tmp;
+    st = coords_of(again, [](Chain &c) { return c.tmp.data(); });
+    if (st != MI_OK) return st;
+    for (size_t i = 0; i < again.size(); i++) {  // add_to_output_container (coords.cpp:25-56) + sort
+      Chain &c = ch[again[i]];
+      Saved sv;
+      sv.e = c.tmp_e;
+      sv.conf = c.tmp;
+      sv.xyz.resize((size_t)nh * 3);
+      for (int h = 0; h < nh; h++)
+        for (int k = 0; k < 3; k++) sv.xyz[3 * h + k] = xyz[(i * na + heavy[h]) * 3 + k];
+      size_t closest = c.out.size();
+      float closest_rmsd = 3.402823466e+38f;
+      for (size_t o = 0; o < c.out.size(); o++) {
+        float acc = 0;
+        for (int h = 0; h < nh; h++) {
+          const float dx = sv.xyz[3 * h] - c.out[o].xyz[3 * h], dy = sv.xyz[3 * h + 1] - c.out[o].xyz[3 * h + 1],
+                      dz = sv.xyz[3 * h + 2] - c.out[o].xyz[3 * h + 2];
+          acc += dx * dx + dy * dy + dz * dz;
+        }
+        const float r = std::sqrt(acc / (float)nh);
+        if (o == 0 || r < closest_rmsd) closest = o, closest_rmsd = r;
+      }
+      if (closest < c.out.size() && closest_rmsd < P->min_rmsd) {
+        if (sv.e < c.out[closest].e) c.out[closest] = sv;
+      } else if ((int)c.out.size() < S) {
+        c.out.push_back(sv);
+      } else if (!c.out.empty() && sv.e < c.out.back().e) {
+        c.out.back() = sv;
+      }
+      std::stable_sort(c.out.begin(), c.out.end(), [](const Saved &a, const Saved &b) { return a.e < b.e; });
+      if (c.tmp_e < c.best_e) c.best_e = c.tmp_e;
+    }
+  }
+  for (int b = 0; b < B; b++) {
+    const Chain &c = ch[b];
+    out_n[b] = (int32_t)c.out.size();
+    for (size_t o = 0; o < c.out.size(); o++) {
+      out_e[(size_t)b * S + o] = c.out[o].e;
+      if (out_conf) std::copy(c.out[o].conf.begin(), c.out[o].conf.end(), out_conf + ((size_t)b * S + o) * nc);
+      if (out_coords) std::copy(c.out[o].xyz.begin(), c.out[o].xyz.end(), out_coords + ((size_t)b * S + o) * 3 * nh);
+    }
+    if (evals) evals[b] = (int32_t)c.evals;
+  }
+  if (cnn_evals) *cnn_evals = (int32_t)std::min<long>(n_cnn, 2147483647L);
+  return MI_OK;
+  VCATCH_STATUS
+}
+
 mi_status mi_cnn_eval_batch(mi_vina *vv, mi_scorer *sc, const float *confs, int B, const mi_cnn_box *box,
                             const float *cnn_centers, int with_deriv, float *energy, float *change) {
   VTRY

@@ -383,9 +383,18 @@ mi_status mi_cnn_refine_batch(mi_vina *, mi_scorer *, float *confs, int B, const
  * non_cache_cnn::eval of what `model` holds: CNN loss of the scorer's ensemble + slope * out-of-box distances (search
  * box and the CNN cube re-centred on the pose, box->slope like non_cache's).  The chains of the call advance in lock
  * step; at each of the two update_energy points of a step ALL chains are scored in one CNN batch.  Stored energies
- * are CNN energies.  (--cnn_scoring all, where BFGS itself minimises the CNN, is mi_cnn_refine_batch's territory and
- * is not offered inside the search.)  cnn_evals (optional) = CNN forward passes spent. */
+ * are CNN energies.  cnn_evals (optional) = CNN forward passes spent.  (--cnn_scoring all: mi_vina_mc_cnnall_batch.) */
 mi_status mi_vina_mc_cnn_batch(mi_vina *, mi_scorer *, int B, const uint64_t *seeds, const float *corner1,
+                               const float *corner2, const mi_mc_params *params, const mi_cnn_box *box, int32_t *out_n,
+                               float *out_e, float *out_conf, float *out_coords, int32_t *evals, int32_t *cnn_evals);
+/* --cnn_scoring all (parallel_mc.cpp:156-159): the same chain with non_cache_cnn as the igrid of the minimiser too --
+ * quasi_newton inside the search minimises the CNN loss (+ penalties), monte_carlo.cpp:99-148 otherwise unchanged.  The
+ * chain logic (mt19937 stream, mutate_conf, bfgs<> + fast_line_search, Metropolis, container) runs on the host for all B
+ * chains in lock step; every round of evaluations -- eval_deriv inside the line searches, eval at the update_energy
+ * points -- is one device batch (B CNN forwards [+ backwards] at once where the reference does one at B = 1).  Before a
+ * chain's first update_energy its non_cache_cnn has no CNN cube (cnn_gd is default-constructed in the reference too).
+ * No cache grids needed.  evals [B] = eval_deriv calls per chain; cnn_evals = CNN passes in total. */
+mi_status mi_vina_mc_cnnall_batch(mi_vina *, mi_scorer *, int B, const uint64_t *seeds, const float *corner1,
                                const float *corner2, const mi_mc_params *params, const mi_cnn_box *box, int32_t *out_n,
                                float *out_e, float *out_conf, float *out_coords, int32_t *evals, int32_t *cnn_evals);
 /* Latency probe for tools/bench_vina.py: device time (ms) of `reps` dependent evaluations per wave. */

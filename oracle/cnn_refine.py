@@ -169,3 +169,154 @@ def refine_structure(nc, conf, max_iters):
     if not nc.within(conf):
         e = float(MAX_FL)
     return e, conf, tries
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# --cnn_scoring all: monte_carlo::operator() (monte_carlo.cpp:99-148) with non_cache_cnn as BOTH igrids
+# (parallel_mc.cpp:156-159).  Small cases only: every evaluation is a PyTorch CPU forward (+ backward).
+# ---------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+_libm = _C.CDLL("libm.so.6")
+for _n in ("logf", "cosf", "sqrtf", "expf"):
+    getattr(_libm, _n).restype = _C.c_float
+    getattr(_libm, _n).argtypes = [_C.c_float]
+
+
+class Mt19937:
+    """boost::mt19937 under the restated Boost distributions (oracle/ref_shims/boost/random.hpp, random.cpp:27-75)"""
+
+    def __init__(self, seed):
+        self.bg = np.random.MT19937()
+        self.bg._legacy_seeding(int(seed) & 0xffffffff)
+
+    def u32(self):
+        return int(self.bg.random_raw())
+
+    def fl(self, a, b):
+        a, b = np.float32(a), np.float32(b)
+        while True:
+            r = np.float32(np.float32(np.float32(self.u32()) / np.float32(4294967296.0)) * np.float32(b - a) + a)
+            if r < b:
+                return r
+
+    def irange(self, a, b):
+        rng, brange = b - a, 0xffffffff
+        if rng == 0:
+            return a
+        bucket = brange // (rng + 1)
+        if brange % (rng + 1) == rng:
+            bucket += 1
+        while True:
+            q = self.u32() // bucket
+            if q <= rng:
+                return q + a
+
+    def normal(self):
+        r1, r2 = self.fl(0, 1), self.fl(0, 1)
+        return np.float32(np.float32(_libm.sqrtf(np.float32(np.float32(-2.0) * np.float32(_libm.logf(np.float32(1) - r2))))) *
+                          np.float32(_libm.cosf(np.float32(np.float32(2.0) * np.float32(3.14159265358979323846) * r1))))
+
+    def inside_sphere(self):
+        while True:
+            v = np.array([self.fl(-1, 1), self.fl(-1, 1), self.fl(-1, 1)], dtype=np.float32)
+            if np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) < 1:
+                return v
+
+
+def mc_cnnall(nc, seed, n_steps, corner1, corner2, max_iters, num_saved=50, temperature=1.2, amplitude=2.0,
+              min_rmsd=1.0, hunt_v=10.0, auth_v=1000.0):
+    """-> list of (energy, conf, heavy coords) sorted by energy, and the number of eval_deriv calls"""
+    lig, smt = nc.lig, nc.smt
+    nt = lig.n_tors
+    heavy = [i for i in range(len(smt)) if smt[i] > 1]
+    rng = Mt19937(seed)
+    PI = np.float32(3.14159265358979323846)
+    tmp = np.zeros(7 + nt, dtype=np.float32)
+    for k in range(3):
+        tmp[k] = rng.fl(corner1[k], corner2[k])
+    while True:
+        q = np.array([rng.normal() for _ in range(4)], dtype=np.float32)
+        mx = np.abs(q).max()
+        nrm = np.float32(0)
+        if mx != 0:
+            inv = np.float32(1.0 / float(mx))
+            s = np.float32(0)
+            for k in range(4):
+                s = np.float32(s + np.float32(q[k] * inv) * np.float32(q[k] * inv))
+            nrm = np.float32(mx * np.float32(_libm.sqrtf(s)))
+        if nrm > np.float32(1.1920928955078125e-07):
+            break
+    tmp[3:7] = q / nrm
+    for t in range(nt):
+        tmp[7 + t] = rng.fl(-PI, PI)
+    mconf = np.zeros(7 + nt, dtype=np.float32)
+    mconf[3] = 1
+    nc.cnn_center = None                     # a fresh non_cache_cnn: no cube until the first adjust_center
+    tmp_e, best_e, out, evals = np.float32(0), MAX_FL, [], 0
+    last = {}
+
+    def fx(c):
+        last["c"] = np.array(c, dtype=np.float32, copy=True)
+        return nc.eval_deriv(c)
+
+    def minimise(x, v):
+        nonlocal evals
+        nc.v = v
+        last["c"] = np.array(x, dtype=np.float32, copy=True)
+        e, xo, _, ev = vina.bfgs_callback(lig, x, fx, max_iters)
+        evals += ev
+        return xo, last["c"]
+
+    def update_energy(m):
+        nc.adjust_center(m)
+        nc.v = auth_v
+        return np.float32(nc.eval(m))
+
+    for step in range(n_steps):
+        cand = tmp.copy()
+        which = rng.irange(0, 2 + nt - 1)
+        if which == 0:
+            cand[:3] = (cand[:3] + np.float32(amplitude) * rng.inside_sphere()).astype(np.float32)
+        elif which == 1:
+            co, _, _ = vina.set_conf(lig, mconf)
+            acc = np.float32(0)
+            for i in heavy:
+                d = (co[i] - mconf[:3]).astype(np.float32)
+                acc = np.float32(acc + np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+            gr = np.float32(_libm.sqrtf(np.float32(acc / np.float32(len(heavy)))))
+            if gr > np.float32(1.1920928955078125e-07):
+                rot = (np.float32(np.float32(amplitude) / gr) * rng.inside_sphere()).astype(np.float32)
+                cand = vina.conf_increment(cand, np.concatenate([np.zeros(3, np.float32), rot]), 1.0, 0)
+        else:
+            cand[7 + which - 2] = rng.fl(-PI, PI)
+        cand, mconf = minimise(cand, hunt_v)
+        cand_e = update_energy(mconf)
+        accept = step == 0 or cand_e < tmp_e
+        if not accept:
+            accept = rng.fl(0, 1) < np.float32(_libm.expf(np.float32((tmp_e - cand_e) / np.float32(temperature))))
+        if not accept:
+            continue
+        tmp, tmp_e, mconf = cand.copy(), cand_e, cand.copy()
+        if tmp_e < best_e or len(out) < num_saved:
+            tmp, mconf = minimise(tmp, auth_v)
+            tmp_e = update_energy(mconf)
+            mconf = tmp.copy()
+            co, _, _ = vina.set_conf(lig, tmp)
+            hc = co[heavy].copy()
+            closest, closest_rmsd = len(out), MAX_FL
+            for o, (_, _, x) in enumerate(out):
+                r = np.float32(np.sqrt(np.float32(((hc - x) ** 2).sum(dtype=np.float32) / np.float32(len(heavy)))))
+                if o == 0 or r < closest_rmsd:
+                    closest, closest_rmsd = o, r
+            if closest < len(out) and closest_rmsd < min_rmsd:
+                if tmp_e < out[closest][0]:
+                    out[closest] = (tmp_e, tmp.copy(), hc)
+            elif len(out) < num_saved:
+                out.append((tmp_e, tmp.copy(), hc))
+            elif out and tmp_e < out[-1][0]:
+                out[-1] = (tmp_e, tmp.copy(), hc)
+            out.sort(key=lambda t: t[0])
+            if tmp_e < best_e:
+                best_e = tmp_e
+    return out, evals
