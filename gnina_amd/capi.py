@@ -24,7 +24,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -195,6 +195,10 @@ def lib():
         L.mi_user_grid_parse.restype = C.c_int
         L.mi_vina_set_user_grid.argtypes = [vp, vp, vp, vp, vp, C.c_float]
         L.mi_vina_set_user_grid.restype = C.c_int
+        L.mi_vina_set_approximation.argtypes = [vp, C.c_int, C.c_float]
+        L.mi_vina_set_approximation.restype = C.c_int
+        L.mi_vina_pair_eval.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+        L.mi_vina_pair_eval.restype = C.c_int
         L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
         L.mi_vina_set_ligand.restype = C.c_int
         L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
@@ -641,6 +645,18 @@ class Vina:
         begin, end, n, lt = _f32(begin), _f32(end), _i32(n), _i32(lig_types)
         check(lib().mi_vina_build_cache(self.handle, _ptr(begin), _ptr(end), _ptr(n), _ptr(lt), len(lt), slope))
         self.grid_shape = (int(n[2]) + 1, int(n[1]) + 1, int(n[0]) + 1)
+
+    def set_approximation(self, kind, factor=10.0):
+        """--approximation: 0 linear (precalculate_linear(sf, 32)), 1 spline (precalculate_splines(sf, factor)); before
+        build_cache"""
+        check(lib().mi_vina_set_approximation(self.handle, int(kind), float(factor)))
+
+    def pair_eval(self, t1, t2, r2):
+        """(E, dE/dr / r) of the current approximation for a type pair at squared distances r2"""
+        r2 = _f32(r2).ravel()
+        e, d = np.zeros(len(r2), np.float32), np.zeros(len(r2), np.float32)
+        check(lib().mi_vina_pair_eval(self.handle, int(t1), int(t2), _ptr(r2), len(r2), _ptr(e), _ptr(d)))
+        return e, d
 
     def set_user_grid(self, begin, end, n, values, scaling_factor=1.0):
         """--user_grid: values = the file's numbers ([nz][ny][nx], float64), or None to remove it; before build_cache"""

@@ -32,6 +32,11 @@ struct VinaEnv {
   // direct (grid-free) receptor term = the non_cache igrid (non_cache.cpp:52-83,125-179), and the
   // exact pair functions = precalculate_exact (precalculate.h:452-494)
   int direct, exact;
+  // precalculate_splines (precalculate.h:277-449, splines.h): per type pair a clamped cubic spline of E(r) over
+  // [0, cutoff] in sp_n intervals, (a, b, c, d) per interval; null = the linear tables above
+  const float4 *spline;
+  int sp_n;
+  float sp_fraction, cutoff;
   int stage;  // copy the ligand description into LDS (set by the launchers)
   const float4 *rec;  // (x, y, z, smt bits)
   int n_rec;
@@ -136,6 +141,9 @@ struct VinaPopulateArgs {
   // per dimension and lattice index: the candidate brick of the point's 3 A cell (szv_grid_cache::get), see
   // mi_vina_build_cache.  [dimx + dimy + dimz] (lo, hi)
   const float2 *brick;
+  const float4 *spline;  // precalculate_splines instead of `fast` (see VinaEnv), or null
+  int sp_n;
+  float sp_fraction, cutoff;
   // --user_grid: added to every point (cache.cpp:177-179); null = none
   VinaGridGeom ug_geom;
   const float *ug_data;

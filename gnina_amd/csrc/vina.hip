@@ -99,8 +99,28 @@ __device__ float pair_energy_exact(const float *w, int t1, int t2, float r) {
   return acc;
 }
 
-// precalculate::eval_deriv: interpolated table (precalculate.h:97-133) or numeric exact (:467-490)
+// Spline::eval_deriv at r (splines.h:100-118) of the pair's spline: value and dE/dr
+__device__ __forceinline__ void spline_eval(const float4 *sp, int sp_n, float fraction, float cutoff, int t1, int t2, float r,
+                                            float &val, float &dx) {
+  val = dx = 0.f;
+  if (r >= cutoff) return;
+  int idx = (int)(r / fraction);
+  if (idx > sp_n - 1) idx = sp_n - 1;  // (r a rounding below the cutoff: the reference indexes one past its array here)
+  const float4 k = sp[(long)tri_idx(t1, t2) * sp_n + idx];
+  const float lx = r - (float)idx * fraction;
+  val = ((k.x * lx + k.y) * lx + k.z) * lx + k.w;
+  dx = (3 * k.x * lx + 2 * k.y) * lx + k.z;
+}
+
+// precalculate::eval_deriv: interpolated table (precalculate.h:97-133), numeric exact (:467-490) or splines (:413-442)
 __device__ __forceinline__ void prec_eval_deriv(const VinaEnv &env, int t1, int t2, float r2, float &e, float &dor) {
+  if (env.spline && !env.exact) {
+    const float r = sqrtf(r2);
+    float dx;
+    spline_eval(env.spline, env.sp_n, env.sp_fraction, env.cutoff, t1, t2, r, e, dx);
+    dor = dx / r;
+    return;
+  }
   if (env.exact) {
     const float delta = 0.000005f;
     const float r = sqrtf(r2);
@@ -125,6 +145,11 @@ __device__ __forceinline__ void prec_eval_deriv(const VinaEnv &env, int t1, int 
 // precalculate::eval = eval_fast: midpoint table (precalculate.h:90-95) or exact E(r)
 __device__ __forceinline__ float prec_eval(const VinaEnv &env, int t1, int t2, float r2) {
   if (env.exact) return pair_energy_exact(env.w5, t1, t2, sqrtf(r2));
+  if (env.spline) {  // precalculate_splines::eval_fast, precalculate.h:407-411
+    float e, dx;
+    spline_eval(env.spline, env.sp_n, env.sp_fraction, env.cutoff, t1, t2, sqrtf(r2), e, dx);
+    return e;
+  }
   return env.fast[(long)tri_idx(t1, t2) * env.n + (int)(env.factor * r2)];
 }
 
@@ -747,7 +772,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs PG at a time
   // (six: one group covers 384 pairs, a typical drug-like ligand) and issues their table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
   // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
-  if ((MODE < 2 || MODE == 4) && !env.exact) {
+  if ((MODE < 2 || MODE == 4) && !env.exact && !env.spline) {
     for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * PG) {
       float rx[PG], ry[PG], rz[PG], rem[PG], capv[PG];
       float2 s1[PG], s2[PG];
@@ -803,7 +828,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       }
     }
   }
-  for (int p = lane; (MODE < 2 || MODE == 4) && env.exact && p < L.n_pairs; p += 64) {
+  for (int p = lane; (MODE < 2 || MODE == 4) && (env.exact || env.spline) && p < L.n_pairs; p += 64) {
     const int2 ab = L.pairs[p];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
@@ -2155,7 +2180,13 @@ __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) 
                   cz = fminf(fmaxf(r.z, bz.x), bz.y) - r.z;
       if (r2 <= a.cutoff_sqr && cx * cx + cy * cy + cz * cz < a.cutoff_sqr) {
         const int t1 = __float_as_int(r.w);
-        aff += a.fast[(long)tri_idx(t1, a.lig_type) * a.n + (int)(a.factor * r2)];
+        if (a.spline) {
+          float e, dx;
+          spline_eval(a.spline, a.sp_n, a.sp_fraction, a.cutoff, t1, a.lig_type, sqrtf(r2), e, dx);
+          aff += e;
+        } else {
+          aff += a.fast[(long)tri_idx(t1, a.lig_type) * a.n + (int)(a.factor * r2)];
+        }
       }
     }
   }

@@ -85,6 +85,12 @@ struct Vina {
   DevBuf<float> d_grids;
   float slope = 1e3f;
   float box_begin[3] = {0, 0, 0}, box_end[3] = {0, 0, 0};
+  // precalculate_splines (--approximation spline; the default of --minimize, main.cpp:1162-1165)
+  bool use_spline = false;
+  int sp_n = 0;
+  float sp_fraction = 0, cutoff = 8;
+  DevBuf<float4> d_spline;
+  std::vector<float4> h_spline;
   // --user_grid
   bool have_ug = false;
   VinaGridGeom ug_geom{};
@@ -152,6 +158,73 @@ static void build_tables(Vina &v, const float *w, float cutoff, float factor) {
   MIG_HIP(hipStreamSynchronize(v.stream));
 }
 
+// precalculate_splines(sf, factor) (precalculate.h:277-449) + Spline::initialize (splines.h:36-96): per type pair
+// n = unsigned(factor * cutoff) samples of E(r) at r = i * (cutoff / n) plus (cutoff, 0); a cubic spline with zero first
+// derivative at both ends through them.  The reference solves the (n + 1) x (n + 1) system by inverting the dense
+// matrix in fp32 with Eigen (a third-party header library); the system is tridiagonal and diagonally dominant, here
+// it is solved directly (Thomas algorithm, double accumulation), coefficients rounded to fp32 in the reference's
+// formulas -- same spline to ~1e-6 of its scale, not bit-identical (stated in DESIGN.md section 4).
+static void build_splines(Vina &v, float cutoff, float factor) {
+  const unsigned n = (unsigned)(factor * cutoff);
+  MIG_CHECK(n >= 2 && n < 65536, 1, "spline approximation: factor * cutoff must give 2 .. 65535 intervals");
+  const float fraction = cutoff / (float)n;
+  const int np = kVinaTypes * (kVinaTypes + 1) / 2;
+  v.h_spline.assign((size_t)np * n, make_float4(0.f, 0.f, 0.f, 0.f));
+  std::vector<float> x(n + 1), y(n + 1), C(n + 1), ddy(n + 1);
+  std::vector<double> cp(n + 1), dp(n + 1);
+  for (unsigned i = 0; i < n; i++) x[i] = (float)i * fraction;
+  x[n] = cutoff;
+  const float hlast = x[n] - x[n - 1];
+  for (int t1 = 0; t1 < kVinaTypes; t1++)
+    for (int t2 = t1; t2 < kVinaTypes; t2++) {
+      bool nonzero = false;
+      for (unsigned i = 0; i < n; i++) {
+        y[i] = pair_energy(v.w5, t1, t2, x[i]);
+        nonzero = nonzero || y[i] != 0;
+      }
+      y[n] = 0;
+      if (!nonzero) continue;  // "worth interpolating" (precalculate.h:361): an uninitialised Spline evaluates to 0
+      const unsigned e = n;
+      // rows: sub[i] ddy[i-1] + diag[i] ddy[i] + sup[i] ddy[i+1] = C[i]
+      auto hi_of = [&](unsigned i) { return i == e - 1 ? hlast : fraction; };
+      C[0] = 6 * ((y[1] - y[0]) / fraction);
+      for (unsigned i = 1; i < e; i++) {
+        const float hi = hi_of(i);
+        C[i] = 6 * ((y[i + 1] - y[i]) / hi - (y[i] - y[i - 1]) / fraction);
+      }
+      C[e] = 6 * (-(y[e] - y[e - 1]) / hlast);
+      auto diag = [&](unsigned i) -> double { return i == 0 ? 2.0 * fraction : i == e ? 2.0 * hlast : 2.0 * ((double)fraction + hi_of(i)); };
+      auto sub = [&](unsigned i) -> double { return i == e ? hlast : hi_of(i); };   // coefficient of ddy[i-1] in row i
+      auto sup = [&](unsigned i) -> double { return i == 0 ? fraction : hi_of(i); };  // coefficient of ddy[i+1] in row i
+      cp[0] = sup(0) / diag(0);
+      dp[0] = C[0] / diag(0);
+      for (unsigned i = 1; i <= e; i++) {
+        const double m = diag(i) - sub(i) * cp[i - 1];
+        cp[i] = i < e ? sup(i) / m : 0.0;
+        dp[i] = (C[i] - sub(i) * dp[i - 1]) / m;
+      }
+      ddy[e] = (float)dp[e];
+      double nxt = dp[e];
+      for (int i = (int)e - 1; i >= 0; i--) {
+        nxt = dp[i] - cp[i] * nxt;
+        ddy[i] = (float)nxt;
+      }
+      float4 *out = &v.h_spline[(size_t)tri(t1, t2) * n];
+      for (unsigned i = 0; i < e; i++) {
+        const float hi = hi_of(i);
+        out[i].x = (ddy[i + 1] - ddy[i]) / (6 * hi);
+        out[i].y = ddy[i] / 2;
+        out[i].z = (y[i + 1] - y[i]) / hi - ddy[i + 1] * hi / 6 - ddy[i] * hi / 3;
+        out[i].w = y[i];
+      }
+    }
+  v.sp_n = (int)n;
+  v.sp_fraction = fraction;
+  v.cutoff = cutoff;
+  v.d_spline.upload(v.h_spline.data(), v.h_spline.size(), v.stream);
+  MIG_HIP(hipStreamSynchronize(v.stream));
+}
+
 static VinaEnv make_env(const Vina &v) {
   VinaEnv e{};
   e.smooth = v.d_smooth.p;
@@ -175,6 +248,10 @@ static VinaEnv make_env(const Vina &v) {
   }
   e.ug_geom = v.ug_geom;
   e.ug_data = v.have_ug ? v.d_ug.p : nullptr;
+  e.spline = v.use_spline ? v.d_spline.p : nullptr;
+  e.sp_n = v.sp_n;
+  e.sp_fraction = v.sp_fraction;
+  e.cutoff = v.cutoff;
   return e;
 }
 
@@ -316,11 +393,64 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
     a.ug_geom = v.ug_geom;
     a.ug_data = v.have_ug ? v.d_ug.p : nullptr;
     a.ug_slope = slope;
+    a.spline = v.use_spline ? v.d_spline.p : nullptr;
+    a.sp_n = v.sp_n;
+    a.sp_fraction = v.sp_fraction;
+    a.cutoff = v.cutoff;
     launch_vina_populate(a, v.stream);
   }
   MIG_HIP(hipGetLastError());
   MIG_HIP(hipStreamSynchronize(v.stream));
   v.have_cache = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// --approximation (main.cpp:989,1384-1391): which precalculate the handle evaluates pair terms with from now on.
+mi_status mi_vina_set_approximation(mi_vina *vv, int kind, float factor) {
+  VTRY
+  MIG_CHECK(vv, 1, "bad arguments");
+  Vina &v = *reinterpret_cast<Vina *>(vv);
+  MIG_CHECK(kind == MI_VINA_APPROX_LINEAR || kind == MI_VINA_APPROX_SPLINE, 1, "approximation: 0 (linear) or 1 (spline)");
+  if (kind == MI_VINA_APPROX_LINEAR) {
+    v.use_spline = false;
+    return MI_OK;
+  }
+  MIG_CHECK(factor > 1.1920928955078125e-07f, 1, "approximation factor must be positive");
+  build_splines(v, std::sqrt(v.cutoff_sqr), factor);
+  v.use_spline = true;
+  v.have_cache = false;  // grids of the other approximation are not this one's
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// precalculate::eval_deriv of the handle's current approximation for one type pair (host copies of the tables /
+// spline coefficients): (E, dE/dr / r) at squared distances r2 -- what the kernels look up.
+mi_status mi_vina_pair_eval(mi_vina *vv, int t1, int t2, const float *r2, int n, float *e, float *dor) {
+  VTRY
+  MIG_CHECK(vv && r2 && e && dor && n >= 0 && t1 >= 0 && t1 < kVinaTypes && t2 >= 0 && t2 < kVinaTypes, 1, "bad arguments");
+  const Vina &v = *reinterpret_cast<const Vina *>(vv);
+  for (int i = 0; i < n; i++) {
+    MIG_CHECK(r2[i] >= 0 && (v.use_spline || r2[i] <= v.cutoff_sqr), 1, "r2 outside the table");
+    if (v.use_spline) {
+      const float r = sqrtf(r2[i]);
+      e[i] = dor[i] = 0;
+      if (r >= v.cutoff) continue;  // Spline::eval_deriv, splines.h:100-118; dor = dx / r (precalculate.h:440)
+      int idx = (int)(r / v.sp_fraction);
+      if (idx > v.sp_n - 1) idx = v.sp_n - 1;
+      const float4 k = v.h_spline[(size_t)tri(t1, t2) * v.sp_n + idx];
+      const float lx = r - (float)idx * v.sp_fraction;
+      e[i] = ((k.x * lx + k.y) * lx + k.z) * lx + k.w;
+      dor[i] = ((3 * k.x * lx + 2 * k.y) * lx + k.z) / r;
+    } else {  // precalculate_linear_element::eval_deriv, precalculate.h:97-133
+      const float r2f = v.factor * r2[i];
+      const int i1 = (int)r2f;
+      const float rem = r2f - (float)i1;
+      const float *se = &v.h_se[(size_t)tri(t1, t2) * v.n], *sd = &v.h_sd[(size_t)tri(t1, t2) * v.n];
+      e[i] = se[i1] + rem * (se[i1 + 1] - se[i1]);
+      dor[i] = sd[i1] + rem * (sd[i1 + 1] - sd[i1]);
+    }
+  }
   return MI_OK;
   VCATCH_STATUS
 }

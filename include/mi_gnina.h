@@ -212,6 +212,18 @@ mi_status mi_vina_cache_grid(mi_vina *, int smt, float *out, size_t n_floats);
  * coordinates (non_cache.cpp:168-173, non_cache_cnn.cpp:141-150); the igrids' energy-only evaluations do not see it
  * (non_cache.cpp:76 has the term commented out), but model::eval (mi_vina_eval_batch with_deriv = 0, hence
  * mi_vina_final_energies) adds its own sum over ALL atoms of the ligand at slope 1000 (model.cu:125-134). */
+/* --approximation linear | spline (main.cpp:904-905,989-990,1384-1391): the `precalculate` behind every pair term of
+ * this handle -- cache::populate, model::eval / eval_deriv, non_cache, the minimiser and the search.  LINEAR =
+ * precalculate_linear(sf, 32), what mi_vina_create builds; SPLINE = precalculate_splines(sf, factor)
+ * (precalculate.h:277-449, splines.h): a clamped cubic spline of E(r) per type pair over factor * cutoff intervals --
+ * gnina's default for --minimize, with factor 10 (main.cpp:1162-1165).  Call before mi_vina_build_cache (a cache
+ * built under the other approximation is dropped).  MI_VINA_EXACT in a with_deriv argument still selects
+ * precalculate_exact for that call. */
+enum { MI_VINA_APPROX_LINEAR = 0, MI_VINA_APPROX_SPLINE = 1 };
+mi_status mi_vina_set_approximation(mi_vina *, int kind, float factor);
+/* precalculate::eval_deriv(a, b, r2) of the current approximation for one type pair: e[i], dor[i] = (E, (dE/dr) / r) at
+ * r2[i] (host arrays; linear: r2 <= cutoff^2). */
+mi_status mi_vina_pair_eval(mi_vina *, int t1, int t2, const float *r2, int n, float *e, float *dor);
 mi_status mi_user_grid_parse(const char *text, size_t len, float begin[3], float end[3], int32_t n[3], double *values,
                              size_t cap, size_t *n_values);
 mi_status mi_vina_set_user_grid(mi_vina *, const float begin[3], const float end[3], const int32_t n[3],

@@ -59,6 +59,8 @@ def lib():
         L.ref_build_grids.argtypes = [vp, _f32p, _f32p, C.c_float, C.c_int, _f32p, _f32p, _i32p, _i32p, C.c_int]
         L.ref_cache_probe.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_float, _f32p, _f32p]
         L.ref_set_user_grid.argtypes = [vp, _f32p, _f32p, _i32p, C.c_char_p, C.c_float]
+        L.ref_set_approximation.argtypes = [vp, C.c_int, C.c_float]
+        L.ref_prec_eval.argtypes = [vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p]
         L.ref_set_conf.argtypes = [vp, _f32p, _f32p]
         L.ref_initial_conf.argtypes = [vp, _f32p]
         L.ref_eval_deriv.argtypes = [vp, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p]
@@ -175,6 +177,17 @@ class Scene:
         _check(lib().ref_set_user_grid(self.h, _p(_f(begin)), _p(_f(end)), _p(nn, C.c_int32),
                                        value_lines.encode() if isinstance(value_lines, str) else value_lines,
                                        float(scale)))
+
+    def set_approximation(self, kind, factor=10.0):
+        """--approximation: 0 = precalculate_linear(wt, 32), 1 = precalculate_splines(wt, factor); before build_grids"""
+        _check(lib().ref_set_approximation(self.h, int(kind), float(factor)))
+
+    def prec_eval(self, t1, t2, r2):
+        """(E, dE/dr / r) of the run's precalculate for a type pair at squared distances r2"""
+        r2 = _f(r2)
+        e, d = np.zeros(len(r2), np.float32), np.zeros(len(r2), np.float32)
+        _check(lib().ref_prec_eval(self.h, int(t1), int(t2), _p(r2), len(r2), _p(e), _p(d)))
+        return e, d
 
     def cache_probe(self, t, xyz, v=1000.0, deriv=False):
         xyz = _f(xyz).reshape(-1, 3)

@@ -56,6 +56,7 @@ struct Scene {
   std::unique_ptr<precalculate_linear> prec;
   std::unique_ptr<precalculate_exact> exact;
   std::unique_ptr<precalculate_splines> splines;
+  std::unique_ptr<precalculate_splines> run_splines;  // --approximation spline: the run's precalculate (ref_set_approximation)
   grid_dims gd;
   grid user_grid;
   std::unique_ptr<cache> c;
@@ -115,13 +116,18 @@ igrid &pick_ig(Scene &s, int which) {
   if (!s.nc) throw std::runtime_error("non_cache not built");
   return *s.nc;
 }
+// the run's precalculate (main.cpp:1384-1391): linear unless ref_set_approximation chose splines
+const precalculate &run_prec(Scene &s) {
+  if (s.run_splines) return *s.run_splines;
+  return *s.prec;
+}
 const precalculate &pick_prec(Scene &s, int which) {
   if (which == 1) return *s.exact;
   if (which == 2) {
     if (!s.splines) s.splines.reset(new precalculate_splines(*s.wt, 10.0));
     return *s.splines;
   }
-  return *s.prec;
+  return run_prec(s);
 }
 }  // namespace
 
@@ -310,15 +316,43 @@ int ref_build_grids(void *h, const float *center, const float *size, float slope
     end[i] = s.gd[i].end;
     n[i] = (int)s.gd[i].n;
   }
-  s.gridcache.reset(new szv_grid_cache(s.m, s.prec->cutoff_sqr()));
-  s.nc.reset(new non_cache(*s.gridcache, s.gd, s.prec.get(), slope));
+  s.gridcache.reset(new szv_grid_cache(s.m, run_prec(s).cutoff_sqr()));
+  s.nc.reset(new non_cache(*s.gridcache, s.gd, &run_prec(s), slope));
   if (build_cache) {
     s.c.reset(new cache("scoring_function_version001", s.gd, slope));
     std::vector<smt> need;
     s.m.get_movable_atom_types(need);
     for (int i = 0; i < n_types; i++)
       if (!has(need, (smt)types[i])) need.push_back((smt)types[i]);
-    s.c->populate(s.m, *s.prec, need, s.user_grid, false);
+    s.c->populate(s.m, run_prec(s), need, s.user_grid, false);
+  }
+  return 0;
+  RCATCH(1)
+}
+}  // extern "C"
+
+extern "C" {
+// --approximation spline (main.cpp:1386-1387): the run's precalculate becomes precalculate_splines(wt, factor); kind 0
+// returns to precalculate_linear(wt, 32).  Before ref_build_grids.
+int ref_set_approximation(void *h, int kind, float factor) {
+  RTRY
+  Scene &s = *(Scene *)h;
+  if (kind == 1) s.run_splines.reset(new precalculate_splines(*s.wt, factor));
+  else s.run_splines.reset();
+  return 0;
+  RCATCH(1)
+}
+// one spline's value and derivative: precalculate_splines::eval_fast / eval_deriv through the run's precalculate
+int ref_prec_eval(void *h, int t1, int t2, const float *r2, int n, float *e, float *dor) {
+  RTRY
+  Scene &s = *(Scene *)h;
+  atom a, b;
+  a.sm = (smt)t1;
+  b.sm = (smt)t2;
+  for (int i = 0; i < n; i++) {
+    pr p = run_prec(s).eval_deriv(a, b, r2[i]);
+    e[i] = p.first;
+    dor[i] = p.second;
   }
   return 0;
   RCATCH(1)
@@ -444,7 +478,7 @@ int ref_bfgs(void *h, float *x, const float *v3, int ig, int max_iters, float *e
   quasi_newton qn(mp);
   output_type out(to_conf(s, x), 0);
   change g(s.m.get_size(), false);
-  qn(s.m, *s.prec, pick_ig(s, ig), out, g, vec(v3[0], v3[1], v3[2]), s.user_grid);
+  qn(s.m, run_prec(s), pick_ig(s, ig), out, g, vec(v3[0], v3[1], v3[2]), s.user_grid);
   from_conf(out.c, x);
   *energy = out.e;
   if (chg) from_change(g, chg);
@@ -491,7 +525,7 @@ int ref_mc(void *h, unsigned seed, int n_steps, int max_iters, int num_saved, fl
   output_container out;
   igrid &g = pick_ig(s, ig);
   s.m = s.m0;
-  mc(s.m, out, *s.prec, g, vec(corner1[0], corner1[1], corner1[2]), vec(corner2[0], corner2[1], corner2[2]), NULL,
+  mc(s.m, out, run_prec(s), g, vec(corner1[0], corner1[1], corner1[2]), vec(corner2[0], corner2[1], corner2[2]), NULL,
      generator, s.user_grid, g);
   int n = 0;
   VINA_FOR_IN(i, out) {

@@ -196,6 +196,17 @@ class McParams(C.Structure):
                 ("authentic_v", C.c_float * 3)]
 
 
+def set_approximation(kind=0, factor=10.0, cutoff=8.0, weights=None):
+    """--approximation: 0 = precalculate_linear (the tables), 1 = precalculate_splines(sf, factor): every table look-up of
+    this library (cache_populate, eval, eval_deriv, non_cache, bfgs, mc) then evaluates the pair's spline.
+    Process-wide: tests reset it."""
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+    f = _voxel.lib().ora_vina_set_approximation
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_float, C.c_float, _f32p]
+    f(int(kind), float(factor), float(cutoff), None if w is None else _p(w))
+
+
 def user_grid_data(begin, end, n, values, scale=1.0):
     """grid::init(gd, user_in, scale) (grid.cpp:69-92) -> (GridDims, data[(nz+1)][(ny+1)][(nx+1)]): the file fills
     [0, n)^3 with -(value * scale), the last plane of every dimension stays 0."""

@@ -148,13 +148,111 @@ void ora_vina_tables_get(const ora_vina_tables *T, int t1, int t2, float *fast, 
 }
 
 /* precalculate_linear_element::eval_fast, precalculate.h:90-95 */
+/* ---------------------------------------------------------------------------------------------
+ * precalculate_splines (precalculate.h:277-449) + Spline (splines.h): --approximation spline, the default of --minimize.
+ * Process-wide switch of this test library (like the user grid): while on, the two table entry points below evaluate
+ * the spline instead.  Spline::initialize inverts the dense (n + 1)^2 system in fp32 with Eigen (third-party, not
+ * restated: its LU rounding is not part of gnina); the system is tridiagonal, so it is solved directly here
+ * (elimination in double, coefficients rounded to fp32 in the reference's formulas).  Agreement with oracle/_ref:
+ * ~1e-6 of the spline's scale (tests/test_ref_vina.py), not bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+static struct {
+  int on, n;
+  float fraction, cutoff;
+  float *k; /* [npairs][n][4] a b c d */
+} g_sp;
+void ora_vina_set_approximation(int kind, float factor, float cutoff, const float *w) {
+  free(g_sp.k);
+  g_sp.k = NULL;
+  g_sp.on = 0;
+  if (kind != 1) return;
+  const unsigned n = (unsigned)(factor * cutoff);
+  const float fraction = cutoff / (float)n;
+  const int np = NT * (NT + 1) / 2;
+  g_sp.k = (float *)calloc((size_t)np * n * 4, sizeof(float));
+  float *x = (float *)malloc(sizeof(float) * (n + 1)), *y = (float *)malloc(sizeof(float) * (n + 1));
+  float *C = (float *)malloc(sizeof(float) * (n + 1)), *ddy = (float *)malloc(sizeof(float) * (n + 1));
+  double *cp = (double *)malloc(sizeof(double) * (n + 1)), *dp = (double *)malloc(sizeof(double) * (n + 1));
+  for (unsigned i = 0; i < n; i++) x[i] = (float)i * fraction;
+  x[n] = cutoff;
+  const float hlast = x[n] - x[n - 1];
+  const unsigned e = n;
+  for (int t1 = 0; t1 < NT; t1++)
+    for (int t2 = t1; t2 < NT; t2++) {
+      int nonzero = 0;
+      for (unsigned i = 0; i < n; i++) {
+        y[i] = ora_vina_pair_energy(w, t1, t2, x[i]);
+        if (y[i] != 0) nonzero = 1;
+      }
+      y[n] = 0;
+      if (!nonzero) continue;
+      C[0] = 6 * ((y[1] - y[0]) / fraction);
+      for (unsigned i = 1; i < e; i++) {
+        float hi = i == e - 1 ? hlast : fraction;
+        C[i] = 6 * ((y[i + 1] - y[i]) / hi - (y[i] - y[i - 1]) / fraction);
+      }
+      C[e] = 6 * (-(y[e] - y[e - 1]) / hlast);
+      /* column i of the reference's matrix: hi ddy[i-1] + 2 (fraction + hi) ddy[i] + hi ddy[i+1] = C[i] */
+      cp[0] = 0.5; /* fraction / (2 fraction) */
+      dp[0] = C[0] / (2.0 * fraction);
+      for (unsigned i = 1; i <= e; i++) {
+        double hi = i >= e - 1 ? hlast : fraction;
+        double diag = i == e ? 2.0 * hlast : 2.0 * ((double)fraction + hi);
+        double m = diag - hi * cp[i - 1];
+        cp[i] = i < e ? hi / m : 0.0;
+        dp[i] = (C[i] - hi * dp[i - 1]) / m;
+      }
+      double nxt = dp[e];
+      ddy[e] = (float)nxt;
+      for (int i = (int)e - 1; i >= 0; i--) {
+        nxt = dp[i] - cp[i] * nxt;
+        ddy[i] = (float)nxt;
+      }
+      float *out = g_sp.k + (size_t)tri(t1, t2) * n * 4;
+      for (unsigned i = 0; i < e; i++) {
+        float hi = i == e - 1 ? hlast : fraction;
+        out[4 * i] = (ddy[i + 1] - ddy[i]) / (6 * hi);
+        out[4 * i + 1] = ddy[i] / 2;
+        out[4 * i + 2] = (y[i + 1] - y[i]) / hi - ddy[i + 1] * hi / 6 - ddy[i] * hi / 3;
+        out[4 * i + 3] = y[i];
+      }
+    }
+  free(x), free(y), free(C), free(ddy), free(cp), free(dp);
+  g_sp.n = (int)n;
+  g_sp.fraction = fraction;
+  g_sp.cutoff = cutoff;
+  g_sp.on = 1;
+}
+/* Spline::eval_deriv (splines.h:100-118) */
+static void spline_eval(int t1, int t2, float r, float *val, float *dx) {
+  *val = *dx = 0;
+  if (r >= g_sp.cutoff) return;
+  int idx = (int)(r / g_sp.fraction);
+  if (idx > g_sp.n - 1) idx = g_sp.n - 1;
+  const float *k = g_sp.k + ((size_t)tri(t1, t2) * g_sp.n + idx) * 4;
+  float lx = r - (float)idx * g_sp.fraction;
+  *val = ((k[0] * lx + k[1]) * lx + k[2]) * lx + k[3];
+  *dx = (3 * k[0] * lx + 2 * k[1]) * lx + k[2];
+}
+
 float ora_vina_eval_fast(const ora_vina_tables *T, int t1, int t2, float r2) {
+  if (g_sp.on) { /* precalculate_splines::eval_fast, precalculate.h:407-411 */
+    float e, dx;
+    spline_eval(t1, t2, sqrtf(r2), &e, &dx);
+    return e;
+  }
   int i = (int)(T->factor * r2);
   return T->fast[(size_t)tri(t1, t2) * T->n + i];
 }
 
 /* precalculate_linear_element::eval_deriv, precalculate.h:97-133 (single component) */
 void ora_vina_table_eval_deriv(const ora_vina_tables *T, int t1, int t2, float r2, float *e, float *dor) {
+  if (g_sp.on) { /* precalculate_splines::eval_deriv, precalculate.h:413-442 (no slow terms in the default set) */
+    float r = sqrtf(r2), dx;
+    spline_eval(t1, t2, r, e, &dx);
+    *dor = dx / r;
+    return;
+  }
   float r2f = T->factor * r2;
   int i1 = (int)r2f, i2 = i1 + 1;
   float rem = r2f - (float)i1;

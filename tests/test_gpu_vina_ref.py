@@ -241,3 +241,54 @@ def test_user_grid_follows_the_reference(capi):
     # and without the grid the same engine gives other numbers
     v.set_user_grid(None, None, None, None)
     assert not same(v.eval_batch(confs, V3, deriv=True, direct=True)[0], U["noncache/e"], 1e-3)
+
+
+def test_spline_approximation_follows_the_reference(capi):
+    """--approximation spline = precalculate_splines(sf, 10), gnina's default for --minimize (main.cpp:1162-1165),
+    against oracle/_ref's outputs (tests/golden/spline_goldens.npz).  The reference inverts each spline's system in
+    fp32 with Eigen; the engine solves it directly: values to ~1e-5 of the spline's scale, the rest within the usual
+    bars of this file."""
+    U = np.load(os.path.join(os.path.dirname(__file__), "golden", "spline_goldens.npz"))
+    lig = capi.read_pdbqt_ligand(bytes(U["lig_text"]).decode(), is_text=True)
+    v = capi.Vina()
+    v.set_approximation(1, float(U["factor"]))
+    for k, (a, b) in enumerate(U["sp/pairs"]):
+        e, d = v.pair_eval(int(a), int(b), U["sp/r2"])
+        e0, d0 = U["sp/e"][k], U["sp/dor"][k]
+        assert np.abs(e - e0).max() <= 2e-5 * max(1e-3, np.abs(e0).max()), (a, b)
+        assert np.abs(d - d0).max() <= 2e-4 * max(1e-3, np.abs(d0).max()), (a, b)
+    v.set_receptor(U["rec_xyz"], U["rec_smt"])
+    v.build_cache(list(U["begin"]), list(U["end"]), [int(x) for x in U["n"]], [int(t) for t in U["types"]], 1e3)
+    v.set_ligand(lig)
+    idx = U["grid_idx"]
+    for k, t in enumerate(U["types"]):
+        g = v.cache_grid(int(t))
+        mine, want = g[idx[:, 2], idx[:, 1], idx[:, 0]], U["grid_val"][k]
+        assert np.abs(mine - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), t
+    confs = U["confs"]
+    for tag, cap in (("v1000", V3), ("v10", HUNT)):
+        e, ch, _ = v.eval_batch(confs, cap, deriv=True)
+        for b in range(len(confs)):
+            e0, g0 = U[tag + "/e"][b], U[tag + "/change"][b]
+            assert abs(e[b] - e0) <= 1e-4 * max(1.0, abs(e0)), (tag, b, e[b], e0)
+            assert np.abs(ch[b] - g0).max() <= 1e-3 * max(1.0, np.abs(g0).max()), (tag, b)
+        e2 = v.eval_batch(confs, cap, deriv=False)[0]
+        assert all(abs(x - y) <= 1e-4 * max(1.0, abs(y)) for x, y in zip(e2, U[tag + "/eval"]))
+    e, ch, _ = v.eval_batch(confs, V3, deriv=True, direct=True)
+    for b in range(len(confs)):
+        assert abs(e[b] - U["noncache/e"][b]) <= 1e-4 * max(1.0, abs(U["noncache/e"][b]))
+        assert np.abs(ch[b] - U["noncache/change"][b]).max() <= 1e-3 * max(1.0, np.abs(U["noncache/change"][b]).max())
+    e2 = v.eval_batch(confs, V3, deriv=False, direct=True)[0]
+    assert all(abs(x - y) <= 1e-4 * max(1.0, abs(y)) for x, y in zip(e2, U["noncache/eval"]))
+    # quasi_newton on the spline tables: the reference's minimum after 1 and 3 iterations for most starts
+    for iters, need in ((1, 9), (3, 6)):
+        e, cf, _, _ = v.bfgs_batch(confs, V3, max_iters=iters)
+        e0, c0 = U[f"bfgs/{iters}/e"], U[f"bfgs/{iters}/conf"]
+        same = sum(abs(e[b] - e0[b]) <= 1e-3 * max(1.0, abs(e0[b])) and np.abs(cf[b] - c0[b]).max() < 1e-2
+                   for b in range(len(confs)))
+        assert same >= need, (iters, same)
+    # and the linear tables give other numbers for the same conformations
+    v.set_approximation(0)
+    v.build_cache(list(U["begin"]), list(U["end"]), [int(x) for x in U["n"]], [int(t) for t in U["types"]], 1e3)
+    e_lin = v.eval_batch(confs, V3, deriv=True)[0]
+    assert np.abs(e_lin - U["v1000/e"]).max() > 1e-3

@@ -404,3 +404,49 @@ def test_user_grid_goes_into_the_cache_and_the_non_cache_derivative_like_the_ref
             assert er == eo and np.array_equal(cr, co)
     finally:
         V.set_user_grid()
+
+
+def test_spline_approximation_follows_the_reference(capi, rigid_text):
+    """--approximation spline = precalculate_splines(sf, factor) (precalculate.h:277-449, splines.h), gnina's default
+    for --minimize with factor 10 (main.cpp:1162-1165).  The reference builds each spline by inverting a dense fp32
+    matrix with Eigen; the restatement solves the same (tridiagonal) system directly -- so: close, not bit-identical
+    (spline values and derivatives to ~1e-6 of their scale), and everything built on them within the usual bars."""
+    lig_text = RC.cys_adduct_ligand()
+    lig = capi.read_pdbqt_ligand(lig_text, is_text=True)
+    center, size = RC.box_of(lig["coords0"])
+    s = ref.Scene(rigid_text, lig_text)
+    s.set_approximation(1, 10.0)
+    try:
+        V.set_approximation(1, 10.0)
+        T = V.Tables()
+        r2 = np.concatenate([np.linspace(0.05, 63.9, 400), [63.99, 64.0, 70.0]]).astype(np.float32)
+        for t1, t2 in ((2, 2), (2, 13), (7, 13), (10, 4), (3, 8)):
+            e0, d0 = s.prec_eval(t1, t2, r2)
+            e1 = np.array([T.eval_fast(t1, t2, float(x)) for x in r2], np.float32)
+            e2, d2 = np.zeros_like(r2), np.zeros_like(r2)
+            for k, x in enumerate(r2):
+                e2[k], d2[k] = T.eval_deriv(t1, t2, float(x))
+            scale = max(1e-3, np.abs(e0).max())
+            assert np.abs(e1 - e0).max() <= 2e-5 * scale and np.abs(e2 - e0).max() <= 2e-5 * scale, (t1, t2)
+            assert np.abs(d2 - d0).max() <= 2e-4 * max(1e-3, np.abs(d0).max()), (t1, t2)
+        begin, end, n = s.build_grids(center, size)
+        gd = V.setup_grid_dims(center, size)
+        rec_xyz, rec_smt = s.grid_atoms()
+        types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+        grids = {t: V.cache_populate(T, gd, rec_xyz, rec_smt, t) for t in types}
+        rng = np.random.RandomState(6)
+        t = types[0]
+        idx = rng.randint(0, [n[0] + 1, n[1] + 1, n[2] + 1], size=(400, 3))
+        probe = s.cache_probe(t, _lattice(begin, end, n, idx), v=3.4e38)
+        mine = grids[t][idx[:, 2], idx[:, 1], idx[:, 0]]
+        assert np.abs(mine - probe).max() <= 1e-5 * max(1.0, np.abs(probe).max())
+        ora = V.Scene(T, gd, grids, V.LigandHandle(lig))
+        for conf in RC.random_confs(np.random.RandomState(7), lig["conf0"], 5):
+            er, cr, _, _ = s.eval_deriv(conf, V3)
+            eo, co, _, _ = ora.eval_deriv(conf, V3)
+            assert abs(er - eo) <= 1e-5 * max(1.0, abs(er)) and np.abs(cr - co).max() <= 1e-4 * max(1.0, np.abs(cr).max())
+            er, cr, _, _ = s.eval_deriv(conf, V3, ig=1)
+            eo, co, _, _ = V.noncache_eval(ora, rec_xyz, rec_smt, conf, V3)
+            assert abs(er - eo) <= 1e-5 * max(1.0, abs(er)) and np.abs(cr - co).max() <= 1e-4 * max(1.0, np.abs(cr).max())
+    finally:
+        V.set_approximation(0)
