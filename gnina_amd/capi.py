@@ -24,7 +24,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -199,6 +199,8 @@ def lib():
         L.mi_vina_set_approximation.restype = C.c_int
         L.mi_vina_pair_eval.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
         L.mi_vina_pair_eval.restype = C.c_int
+        L.mi_vina_set_line_search.argtypes = [vp, C.c_int]
+        L.mi_vina_set_line_search.restype = C.c_int
         L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
         L.mi_vina_set_ligand.restype = C.c_int
         L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
@@ -650,6 +652,10 @@ class Vina:
         """--approximation: 0 linear (precalculate_linear(sf, 32)), 1 spline (precalculate_splines(sf, factor)); before
         build_cache"""
         check(lib().mi_vina_set_approximation(self.handle, int(kind), float(factor)))
+
+    def set_line_search(self, accurate):
+        """--accurate_line_search for every BFGS of this handle (False = fast_line_search, the default)"""
+        check(lib().mi_vina_set_line_search(self.handle, 1 if accurate else 0))
 
     def pair_eval(self, t1, t2, r2):
         """(E, dE/dr / r) of the current approximation for a type pair at squared distances r2"""

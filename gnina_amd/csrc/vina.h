@@ -32,6 +32,7 @@ struct VinaEnv {
   // direct (grid-free) receptor term = the non_cache igrid (non_cache.cpp:52-83,125-179), and the
   // exact pair functions = precalculate_exact (precalculate.h:452-494)
   int direct, exact;
+  int accurate_ls;  // minimization_params::BFGSAccurateLineSearch (--accurate_line_search) instead of fast_line_search
   // precalculate_splines (precalculate.h:277-449, splines.h): per type pair a clamped cubic spline of E(r) over
   // [0, cutoff] in sp_n intervals, (a, b, c, d) per interval; null = the linear tables above
   const float4 *spline;

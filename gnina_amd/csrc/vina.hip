@@ -1295,7 +1295,9 @@ struct WaveTeam {
 // The start point is evaluated by the same eval_conf call as the trials (step -1, a "search" of one trial that
 // is always accepted): eval_conf is inlined, and one call site keeps the minimiser kernels' code small enough
 // to stay in the instruction cache while every access keeps its address space (LDS reads stay ds_read).
-template <int HREG = kHReg, int PG = kPairGroup>
+// ACC: accurate_line_search compiled in (its own kernel instantiations: the search's extra live state costs the
+// register-budgeted default kernels spills otherwise)
+template <int HREG = kHReg, int PG = kPairGroup, bool ACC = false>
 __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand &L, const WaveWork &w, const BfgsWork &k,
                                            float v0, float v1, float v2, int max_iters, int &evals, const WaveTeam &tm,
                                            long long *eval_ticks = nullptr) {
@@ -1330,6 +1332,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
     return -sum;
   };
   float f0 = 0.f, f_orig = 0.f, g_r = 0.f, g_orig = 0.f;
+  float xl_r = x_r;  // the last conformation handed to eval_conf: what the reference's `model` holds afterwards
 
   for (int step = -1; step < max_iters; step++) {
     const bool start = step < 0;
@@ -1348,12 +1351,41 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       pg = dot_lanes(p_r, g_r, n);
     }
     lapb(2);
-    // line search: trials t0 .. t0 + W - 1 in parallel
     float f1 = 0.f;
     int t_acc = -1, winner = 0;  // accepted trial (10 = none of the ten), wave that evaluated it
+    // accurate_line_search (bfgs.h:104-180, after Numerical Recipes' lnsrch; --accurate_line_search): every trial's
+    // step comes from the energies of the previous ones, so the trials are sequential; the waves of a team each run
+    // the same search on their own workspace (identical results).  It shares the trial loop -- and with it the one
+    // inlined eval_conf call site -- with fast_line_search.  fl arithmetic; the literals 2.0 / 3.0 are double as written.
+    const bool acc_ls = ACC && !start;
+    float alpha_acc = 0.f;  // its result, 0 = "line direction was wrong, give up"
+    float ls_alpha = 1.0f, ls_alpha2 = 0.f, ls_f2 = 0.f, alamin = 0.f;
+    const float slope = pg;
+    if (acc_ls) {
+      if (slope >= 0) break;  // x_new = x, g_new cleared, alpha = 0 -> bfgs gives up (bfgs.h:116-122,417-426)
+      // compute_lambdamin (bfgs.h:93-102): max |p(i)| / max(|x(i)|, 1) with x in change indexing (conf.h:459-490):
+      // position, quaternion_to_angle(orientation) (quaternion.cu:46-62), torsions
+      const float qa = rl(x_r, 3), qb = rl(x_r, 4), qc = rl(x_r, 5), qd = rl(x_r, 6);
+      float ang0 = 0.f, ang1 = 0.f, ang2 = 0.f;
+      if (qa > -1 && qa < 1) {
+        float angle = 2 * acosf(qa);
+        if (angle > VPI) angle -= 2 * VPI;
+        const float sn = sinf(angle / 2);
+        if (!(fabsf(sn) < VEPS)) {
+          const float sc = angle / sn;
+          ang0 = qb * sc, ang1 = qc * sc, ang2 = qd * sc;
+        }
+      }
+      const float x_tor = __shfl_down(x_r, 1);  // change index 6 + k <-> conf index 7 + k
+      const float xi = lane < 3 ? x_r : lane == 3 ? ang0 : lane == 4 ? ang1 : lane == 5 ? ang2 : x_tor;
+      float test = lane < n ? fabsf(p_r) / fmaxf(fabsf(xi), 1.0f) : 0.f;
+      for (int m = 32; m >= 1; m >>= 1) test = fmaxf(test, __shfl_xor(test, m));
+      alamin = VEPS / test;
+    }
+    // fast_line_search: trials t0 .. t0 + W - 1 in parallel
     for (int t0 = 0; t_acc < 0; t0 += W) {
       const int t = t0 + wv < 10 ? t0 + wv : 9;
-      const float a_t = ldexpf(1.f, -t);  // 1 halved t times, exactly
+      const float a_t = acc_ls ? ls_alpha : ldexpf(1.f, -t);  // 1 halved t times, exactly
       const float xn = start ? x_r : increment_lanes(x_r, p_r, p_up, a_t, nt, lane);
       if (lane < nc) x_new[lane] = xn;
       wave_sync();
@@ -1364,6 +1396,39 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         t_acc = 0;
         winner = wv;
         f1 = f_t;
+      } else if (acc_ls) {
+        evals++;
+        xl_r = xn;
+        winner = wv;
+        f1 = f_t;
+        if (ls_alpha < alamin || !isfinite(ls_alpha)) {  // too small a step
+          t_acc = 0;
+        } else if (f_t <= f0 + 1.0e-4f * ls_alpha * slope) {  // sufficient decrease
+          alpha_acc = ls_alpha;
+          t_acc = 0;
+        } else {  // backtrack
+          float tmplam;
+          if (ls_alpha == 1.0f) {
+            tmplam = (float)(-(double)slope / (2.0 * (double)(f_t - f0 - slope)));
+          } else {
+            const float rhs1 = f_t - f0 - ls_alpha * slope, rhs2 = ls_f2 - f0 - ls_alpha2 * slope;
+            const float ca = (rhs1 / (ls_alpha * ls_alpha) - rhs2 / (ls_alpha2 * ls_alpha2)) / (ls_alpha - ls_alpha2);
+            const float cb = (-ls_alpha2 * rhs1 / (ls_alpha * ls_alpha) + ls_alpha * rhs2 / (ls_alpha2 * ls_alpha2)) /
+                             (ls_alpha - ls_alpha2);
+            if (ca == 0.0f) {
+              tmplam = (float)(-(double)slope / (2.0 * (double)cb));
+            } else {
+              const float disc = (float)((double)(cb * cb) - 3.0 * (double)ca * (double)slope);
+              if (disc < 0) tmplam = 0.5f * ls_alpha;
+              else if (cb <= 0) tmplam = (float)((double)(-cb + sqrtf(disc)) / (3.0 * (double)ca));
+              else tmplam = -slope / (cb + sqrtf(disc));
+            }
+            if (tmplam > 0.5f * ls_alpha) tmplam = 0.5f * ls_alpha;  // always at least cut in half
+          }
+          ls_alpha2 = ls_alpha;
+          ls_f2 = f_t;
+          ls_alpha = fmaxf(tmplam, 0.1f * ls_alpha);  // never smaller than a tenth
+        }
       } else if (W == 1) {
         if (f_t - f0 < 0.0001f * a_t * pg) {
           t_acc = t0;
@@ -1392,9 +1457,10 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         __syncthreads();
       }
     }
+    if (acc_ls && alpha_acc == 0.f) break;  // bfgs.h:417-426: give up (x, g, f0 stay)
     lapb(4);
-    const float alpha = ldexpf(1.f, -t_acc);
-    evals += t_acc < 10 ? t_acc + 1 : 10;
+    const float alpha = acc_ls ? alpha_acc : ldexpf(1.f, -t_acc);
+    if (!acc_ls) evals += t_acc < 10 ? t_acc + 1 : 10;
     // the accepted trial's conformation and gradient, from the workspace of the wave that evaluated it
     const float *xw = x_new + (long)(winner - wv) * tm.stride, *gw = g_new + (long)(winner - wv) * tm.stride;
     const float xn_r = lane < nc ? xw[lane] : 0.f;
@@ -1408,6 +1474,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
     const float y_r = gn_r - g_r;
     f0 = f1;
     x_r = xn_r;
+    if (ACC) xl_r = xn_r;
     g_r = gn_r;
     const float gradnormsq = dot_lanes(g_r, g_r, n);
     if (!(gradnormsq >= 1e-4f)) break;
@@ -1476,7 +1543,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
   // What `model` holds after the call is the conformation of the last evaluation: x before the revert below (every
   // iteration ends with x = x_new, accepted trial or not).  Monte-Carlo's update_energy and gyration_radius read it
   // (monte_carlo.cpp:44-47, mutate.cpp:55); it is left in k.x_new.
-  if (lane < nc) x_new[lane] = x_r;
+  if (lane < nc) x_new[lane] = ACC ? xl_r : x_r;  // (xl_r = x_r unless an accurate line search gave up after its trials)
   if (!(f0 <= f_orig)) {  // bfgs.h:491-495
     f0 = f_orig;
     x_r = x_orig;
@@ -1489,7 +1556,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
 }
 
 // TP: the throughput tuning (see kPairGroupTp / kHRegTp) with the register budget of three waves per SIMD
-template <bool TP>
+template <bool TP, bool ACC = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP ? 3 : 1, TP ? 3 : 2))) void vina_bfgs_kernel(
     VinaEnv env, VinaLigand L, float *confs, float v0, float v1, float v2, int max_iters, float *energy, float *grad_out,
     int *evals_out) {
@@ -1504,8 +1571,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP ? 3 : 1, 
   for (int i = lane; i < nc; i += 64) k.x[i] = confs[(size_t)b * nc + i];
   wave_sync();
   const WaveTeam solo{1, 0, 0, nullptr, nullptr};
-  const float f0 = bfgs_wave<TP ? kHRegTp : kHReg, TP ? kPairGroupTp : kPairGroup>(env, L, w, k, v0, v1, v2, max_iters,
-                                                                                  evals, solo);
+  const float f0 = bfgs_wave<TP ? kHRegTp : kHReg, TP ? kPairGroupTp : kPairGroup, ACC>(env, L, w, k, v0, v1, v2, max_iters,
+                                                                                       evals, solo);
   for (int i = lane; i < nc; i += 64) confs[(size_t)b * nc + i] = k.x[i];
   if (grad_out)
     for (int i = lane; i < n; i += 64) grad_out[(size_t)b * n + i] = k.g[i];
@@ -1519,6 +1586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP ? 3 : 1, 
 // refine_structure (main.cpp:131-171): BFGS on the direct receptor term; the out-of-box slope starts at
 // 10 and is raised 10x per try (at most 5) until every heavy atom is inside the box (non_cache::within,
 // non_cache.cpp:84-101); a pose that never gets in reports max_fl.
+template <bool ACC>
 __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand L, float *confs, float v0, float v1,
                                                          float v2, int max_iters, float *energy, int *tries_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1543,7 +1611,7 @@ __global__ __launch_bounds__(64) void vina_refine_kernel(VinaEnv env, VinaLigand
   bool inside = false;
   for (int p = 0; p < 5 && !inside; p++) {
     env.slope = slope;
-    e = bfgs_wave(env, L, w, k, v0, v1, v2, max_iters, evals, WaveTeam{1, 0, 0, nullptr, nullptr});
+    e = bfgs_wave<kHReg, kPairGroup, ACC>(env, L, w, k, v0, v1, v2, max_iters, evals, WaveTeam{1, 0, 0, nullptr, nullptr});
     (void)eval_conf<3>(env, L, k.x, 0.f, 0.f, 0.f, w, nullptr);  // m.set(out.c)
     int bad = 0;
     for (int i = lane; i < L.n_atoms; i += 64)
@@ -1568,9 +1636,15 @@ void launch_vina_refine(const VinaEnv &env0, const VinaLigand &lig, float *confs
   VinaEnv env = env0;
   env.stage = want_stage(B) ? 1 : 0;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
-  big_lds(vina_refine_kernel);
-  hipLaunchKernelGGL(vina_refine_kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
-                     tries);
+  if (env.accurate_ls) {
+    big_lds(vina_refine_kernel<true>);
+    hipLaunchKernelGGL(vina_refine_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
+                       tries);
+  } else {
+    big_lds(vina_refine_kernel<false>);
+    hipLaunchKernelGGL(vina_refine_kernel<false>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
+                       tries);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1802,7 +1876,7 @@ __device__ __forceinline__ void randomize_wave(McRng &rng, float *x, const float
 // W = blockDim.x / 64 waves per chain (see WaveTeam): every wave replays the whole chain -- same RNG stream,
 // same decisions -- and they share the work only inside the BFGS line searches.  Wave 0 alone owns the output
 // container (global memory) and publishes what the others need (the container's size) through LDS.
-template <bool PROF, bool TP>
+template <bool PROF, bool TP, bool ACC = false>
 __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a) {
   if (!PROF) a.prof = nullptr;  // the timing code folds away in the production instantiations
   constexpr int HR = TP ? kHRegTp : kHReg, PG = TP ? kPairGroupTp : kPairGroup;
@@ -1885,7 +1959,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
     float cand_e = 0.f;
     for (int pass = 0; pass < 2; pass++) {
       const float *cap = pass == 0 ? a.hunt : a.auth;
-      (void)bfgs_wave<HR, PG>(env, L, w, k, cap[0], cap[1], cap[2], a.max_iters, evals, tm, evt);
+      (void)bfgs_wave<HR, PG, ACC>(env, L, w, k, cap[0], cap[1], cap[2], a.max_iters, evals, tm, evt);
       lap(pass == 0 ? 1 : 3);
       // update_energy (monte_carlo.cpp:44-47): ig.eval on the coordinates `model` holds = the last evaluated
       // conformation (k.x_new), which is k.x unless bfgs reverted to its start
@@ -1958,9 +2032,9 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
 
 // The two instantiations: latency tuning for teams of waves (one workgroup of W waves per chain), throughput tuning
 // for one wave per chain with the register budget of two waves per SIMD.
-template <bool PROF>
+template <bool PROF, bool ACC = false>
 __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a) {
-  mc_chain<PROF, false>(env, L, a);
+  mc_chain<PROF, false, ACC>(env, L, a);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vina_mc_tp_kernel(VinaEnv env, VinaLigand L,
@@ -2134,7 +2208,10 @@ void launch_vina_mc(const VinaEnv &env0, const VinaLigand &lig, const VinaMcArgs
     W /= 2;
     lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, W);
   }
-  if (a.prof) {
+  if (env.accurate_ls) {  // --accurate_line_search: the team kernel at any chain count (sequential trials)
+    big_lds((vina_mc_kernel<false, true>));
+    hipLaunchKernelGGL((vina_mc_kernel<false, true>), dim3(B), dim3(64 * W), lds, s, env, lig, a);
+  } else if (a.prof) {
     big_lds(vina_mc_kernel<true>);
     hipLaunchKernelGGL(vina_mc_kernel<true>, dim3(B), dim3(64 * W), lds, s, env, lig, a);
   } else if (W == 1) {
@@ -2227,7 +2304,11 @@ void launch_vina_bfgs(const VinaEnv &env0, const VinaLigand &lig, float *confs, 
   VinaEnv env = env0;
   env.stage = want_stage(B) ? 1 : 0;
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, true, env.stage);
-  if (B > 2048) {  // thousands of chains: occupancy over per-chain latency
+  if (env.accurate_ls) {
+    big_lds((vina_bfgs_kernel<false, true>));
+    hipLaunchKernelGGL((vina_bfgs_kernel<false, true>), dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters,
+                       energy, grad, evals);
+  } else if (B > 2048) {  // thousands of chains: occupancy over per-chain latency
     big_lds(vina_bfgs_kernel<true>);
     hipLaunchKernelGGL(vina_bfgs_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, max_iters, energy,
                        grad, evals);

@@ -91,6 +91,7 @@ struct Vina {
   float sp_fraction = 0, cutoff = 8;
   DevBuf<float4> d_spline;
   std::vector<float4> h_spline;
+  bool accurate_ls = false;  // --accurate_line_search
   // --user_grid
   bool have_ug = false;
   VinaGridGeom ug_geom{};
@@ -248,6 +249,7 @@ static VinaEnv make_env(const Vina &v) {
   }
   e.ug_geom = v.ug_geom;
   e.ug_data = v.have_ug ? v.d_ug.p : nullptr;
+  e.accurate_ls = v.accurate_ls ? 1 : 0;
   e.spline = v.use_spline ? v.d_spline.p : nullptr;
   e.sp_n = v.sp_n;
   e.sp_fraction = v.sp_fraction;
@@ -402,6 +404,17 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
   MIG_HIP(hipGetLastError());
   MIG_HIP(hipStreamSynchronize(v.stream));
   v.have_cache = true;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// --accurate_line_search (minimization_params::BFGSAccurateLineSearch, main.cpp / bfgs.h:395-400): which line search
+// every BFGS of this handle runs from now on -- mi_vina_bfgs_batch, the refine entry points, the Monte-Carlo chains
+// and the CNN refinement's host state machine.
+mi_status mi_vina_set_line_search(mi_vina *vv, int kind) {
+  VTRY
+  MIG_CHECK(vv && (kind == 0 || kind == 1), 1, "line search: 0 (fast) or 1 (accurate)");
+  reinterpret_cast<Vina *>(vv)->accurate_ls = kind == 1;
   return MI_OK;
   VCATCH_STATUS
 }
@@ -1257,12 +1270,15 @@ struct BfgsChain {
   int n = 0, nt = 0, nc = 0, max_iters = 0;
   std::vector<float> x, x_new, x_orig, g, g_new, g_orig, p, y, mhy, h;
   float f0 = 0, f_orig = 0, alpha = 1, pg = 0;
+  bool accurate = false;  // accurate_line_search (bfgs.h:104-180) instead of fast_line_search
+  float ls_alpha2 = 0, ls_f2 = 0, alamin = 0;
   int step = 0, trial = 0;
   long evals = 0;
   enum { Init, Line, Done } state = Init;
 
-  void start(const float *conf, int nt_, int max_iters_) {
+  void start(const float *conf, int nt_, int max_iters_, bool accurate_ = false) {
     nt = nt_, n = 6 + nt_, nc = 7 + nt_, max_iters = max_iters_;
+    accurate = accurate_;
     x.assign(conf, conf + nc);
     x_new = x;
     g.assign(n, 0), g_new.assign(n, 0), p.assign(n, 0), y.assign(n, 0), mhy.assign(n, 0);
@@ -1286,6 +1302,31 @@ struct BfgsChain {
     alpha = 1;
     trial = 0;
     pg = dot_seq(p.data(), g.data(), n);
+    if (accurate) {
+      if (pg >= 0) {  // not a descent direction: alpha = 0, bfgs gives up (bfgs.h:116-122,417-426)
+        finish();
+        return;
+      }
+      // compute_lambdamin (bfgs.h:93-102) with x in change indexing (conf.h:459-490): position,
+      // quaternion_to_angle(orientation) (quaternion.cu:46-62), torsions
+      float ang[3] = {0, 0, 0};
+      const float c = x[3];
+      if (c > -1 && c < 1) {
+        float angle = 2 * std::acos(c);
+        if (angle > kPi) angle -= 2 * kPi;
+        const float sn = std::sin(angle / 2);
+        if (!(std::fabs(sn) < kEps))
+          for (int k = 0; k < 3; k++) ang[k] = x[4 + k] * (angle / sn);
+      }
+      float test = 0;
+      for (int i = 0; i < n; i++) {
+        const float xi = i < 3 ? x[i] : i < 6 ? ang[i - 3] : x[i + 1];
+        const float t = std::fabs(p[i]) / std::max(std::fabs(xi), 1.0f);
+        if (t > test) test = t;
+      }
+      alamin = kEps / test;
+      ls_alpha2 = 0, ls_f2 = 0;
+    }
     x_new = x;
     conf_increment(x_new.data(), p.data(), alpha, nt);
     state = Line;
@@ -1309,21 +1350,53 @@ struct BfgsChain {
       begin_step();
       return;
     }
-    // fast_line_search, bfgs.h:73-91
     g_new.assign(grad, grad + n);
     const float f1 = f;
-    bool leave = f1 - f0 < 0.0001f * alpha * pg;
-    if (!leave) {
-      alpha *= 0.5f;
-      if (++trial < 10) {
+    if (accurate) {  // accurate_line_search, bfgs.h:128-179 (fl arithmetic; the literals 2.0 / 3.0 are double as written)
+      const float slope = pg;
+      if (alpha < alamin || !std::isfinite(alpha)) {  // too small a step: alpha = 0, give up
+        finish();
+        return;
+      }
+      if (!(f1 <= f0 + 1.0e-4f * alpha * slope)) {  // backtrack
+        float tmplam;
+        if (alpha == 1.0f) {
+          tmplam = (float)(-(double)slope / (2.0 * (double)(f1 - f0 - slope)));
+        } else {
+          const float rhs1 = f1 - f0 - alpha * slope, rhs2 = ls_f2 - f0 - ls_alpha2 * slope;
+          const float ca = (rhs1 / (alpha * alpha) - rhs2 / (ls_alpha2 * ls_alpha2)) / (alpha - ls_alpha2);
+          const float cb = (-ls_alpha2 * rhs1 / (alpha * alpha) + alpha * rhs2 / (ls_alpha2 * ls_alpha2)) / (alpha - ls_alpha2);
+          if (ca == 0.0f) {
+            tmplam = (float)(-(double)slope / (2.0 * (double)cb));
+          } else {
+            const float disc = (float)((double)(cb * cb) - 3.0 * (double)ca * (double)slope);
+            if (disc < 0) tmplam = 0.5f * alpha;
+            else if (cb <= 0) tmplam = (float)((double)(-cb + std::sqrt(disc)) / (3.0 * (double)ca));
+            else tmplam = -slope / (cb + std::sqrt(disc));
+          }
+          if (tmplam > 0.5f * alpha) tmplam = 0.5f * alpha;
+        }
+        ls_alpha2 = alpha;
+        ls_f2 = f1;
+        alpha = std::max(tmplam, 0.1f * alpha);
         x_new = x;
         conf_increment(x_new.data(), p.data(), alpha, nt);
         return;  // next trial
       }
-    }
-    if (alpha == 0) {
-      finish();
-      return;
+    } else {  // fast_line_search, bfgs.h:73-91
+      bool leave = f1 - f0 < 0.0001f * alpha * pg;
+      if (!leave) {
+        alpha *= 0.5f;
+        if (++trial < 10) {
+          x_new = x;
+          conf_increment(x_new.data(), p.data(), alpha, nt);
+          return;  // next trial
+        }
+      }
+      if (alpha == 0) {
+        finish();
+        return;
+      }
     }
     for (int i = 0; i < n; i++) y[i] = g_new[i] - g[i];
     f0 = f1;
@@ -1371,6 +1444,7 @@ mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t
   MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
   Vina &v = *reinterpret_cast<Vina *>(vv);
   MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
+  MIG_CHECK(!v.accurate_ls, 1, "the device CNN Monte-Carlo chains run fast_line_search only (see mi_vina_set_line_search)");
   MIG_CHECK(v.lig.n_movable == v.lig.n_atoms, 1, "flexible residues are not supported with the CNN in the loop yet");
   MIG_CHECK(P->num_saved > 0 && P->num_saved <= 64 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1,
             "bad Monte-Carlo parameters (num_saved must be in [1, 64], n_steps >= 1)");
@@ -1642,7 +1716,7 @@ mi_status mi_vina_mc_cnnall_batch(mi_vina *vv, mi_scorer *sc, int B, const uint6
   // quasi_newton on non_cache_cnn for the chains in `who`, in lock step; leaves bf.x / bf.f0 and last_eval
   auto minimise = [&](const std::vector<int> &who, auto start_from, float vcap) -> mi_status {
     for (int b : who) {
-      ch[b].bf.start(start_from(ch[b]), nt, P->max_iters);
+      ch[b].bf.start(start_from(ch[b]), nt, P->max_iters, v.accurate_ls);
       ch[b].last_eval.assign(start_from(ch[b]), start_from(ch[b]) + nc);
     }
     std::vector<int> active = who;
@@ -1844,7 +1918,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
   std::vector<int> n_try(B, 0), active;
   std::vector<char> done(B, 0);
   std::vector<long> total_evals(B, 0);
-  for (int b = 0; b < B; b++) chain[b].start(confs + (size_t)b * nc, nt, max_iters);
+  for (int b = 0; b < B; b++) chain[b].start(confs + (size_t)b * nc, nt, max_iters, v.accurate_ls);
   std::vector<float> req, req_centers, e_out, g_out;
   for (;;) {
     // chains sharing a slope value are evaluated together (the slope is a kernel argument)
@@ -1889,7 +1963,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
       } else {
         slope[b] *= 10;
         std::vector<float> x = chain[b].x;
-        chain[b].start(x.data(), nt, max_iters);
+        chain[b].start(x.data(), nt, max_iters, v.accurate_ls);
       }
     }
   }

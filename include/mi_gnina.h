@@ -220,6 +220,12 @@ mi_status mi_vina_cache_grid(mi_vina *, int smt, float *out, size_t n_floats);
  * built under the other approximation is dropped).  MI_VINA_EXACT in a with_deriv argument still selects
  * precalculate_exact for that call. */
 enum { MI_VINA_APPROX_LINEAR = 0, MI_VINA_APPROX_SPLINE = 1 };
+/* --accurate_line_search (minimization_params::BFGSAccurateLineSearch, bfgs.h:395-400): kind 1 makes every BFGS of
+ * this handle -- mi_vina_bfgs_batch, mi_vina_refine_*, the Monte-Carlo chains, mi_cnn_refine_batch and the CNN
+ * Monte-Carlo -- use accurate_line_search (bfgs.h:104-180, backtracking with cubic interpolation after Numerical
+ * Recipes' lnsrch) instead of fast_line_search; 0 (default) returns to the fast one.  mi_vina_mc_cnn_batch's device
+ * chains support the fast search only. */
+mi_status mi_vina_set_line_search(mi_vina *, int kind);
 mi_status mi_vina_set_approximation(mi_vina *, int kind, float factor);
 /* precalculate::eval_deriv(a, b, r2) of the current approximation for one type pair: e[i], dor[i] = (E, (dE/dr) / r) at
  * r2[i] (host arrays; linear: r2 <= cutoff^2). */

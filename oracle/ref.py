@@ -60,6 +60,7 @@ def lib():
         L.ref_cache_probe.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_float, _f32p, _f32p]
         L.ref_set_user_grid.argtypes = [vp, _f32p, _f32p, _i32p, C.c_char_p, C.c_float]
         L.ref_set_approximation.argtypes = [vp, C.c_int, C.c_float]
+        L.ref_set_line_search.argtypes = [vp, C.c_int]
         L.ref_prec_eval.argtypes = [vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p]
         L.ref_set_conf.argtypes = [vp, _f32p, _f32p]
         L.ref_initial_conf.argtypes = [vp, _f32p]
@@ -181,6 +182,10 @@ class Scene:
     def set_approximation(self, kind, factor=10.0):
         """--approximation: 0 = precalculate_linear(wt, 32), 1 = precalculate_splines(wt, factor); before build_grids"""
         _check(lib().ref_set_approximation(self.h, int(kind), float(factor)))
+
+    def set_line_search(self, accurate):
+        """--accurate_line_search for bfgs() and mc() of this scene"""
+        _check(lib().ref_set_line_search(self.h, 1 if accurate else 0))
 
     def prec_eval(self, t1, t2, r2):
         """(E, dE/dr / r) of the run's precalculate for a type pair at squared distances r2"""

@@ -63,6 +63,7 @@ struct Scene {
   std::unique_ptr<szv_grid_cache> gridcache;
   std::unique_ptr<non_cache> nc;
   bool has_ligand = false;
+  bool accurate_ls = false;  // --accurate_line_search (minimization_params::BFGSAccurateLineSearch)
 };
 
 conf to_conf(const Scene &s, const float *x) {
@@ -342,6 +343,12 @@ int ref_set_approximation(void *h, int kind, float factor) {
   return 0;
   RCATCH(1)
 }
+int ref_set_line_search(void *h, int kind) {
+  RTRY
+  ((Scene *)h)->accurate_ls = kind == 1;
+  return 0;
+  RCATCH(1)
+}
 // one spline's value and derivative: precalculate_splines::eval_fast / eval_deriv through the run's precalculate
 int ref_prec_eval(void *h, int t1, int t2, const float *r2, int n, float *e, float *dor) {
   RTRY
@@ -475,6 +482,7 @@ int ref_bfgs(void *h, float *x, const float *v3, int ig, int max_iters, float *e
   Scene &s = *(Scene *)h;
   minimization_params mp;
   mp.maxiters = (unsigned)max_iters;
+  if (s.accurate_ls) mp.type = minimization_params::BFGSAccurateLineSearch;
   quasi_newton qn(mp);
   output_type out(to_conf(s, x), 0);
   change g(s.m.get_size(), false);
@@ -518,6 +526,7 @@ int ref_mc(void *h, unsigned seed, int n_steps, int max_iters, int num_saved, fl
   mc.temperature = temperature;
   mc.ssd_par.evals = (unsigned)max_iters;
   mc.ssd_par.minparm.maxiters = (unsigned)max_iters;
+  if (s.accurate_ls) mc.ssd_par.minparm.type = minimization_params::BFGSAccurateLineSearch;
   mc.min_rmsd = min_rmsd;
   mc.num_saved_mins = (sz)num_saved;
   mc.hunt_cap = vec(10, 10, 10);

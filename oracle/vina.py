@@ -196,6 +196,15 @@ class McParams(C.Structure):
                 ("authentic_v", C.c_float * 3)]
 
 
+def set_line_search(accurate=False):
+    """--accurate_line_search: every bfgs of this library (bfgs, bfgs_callback, refine, mc) then runs
+    accurate_line_search (bfgs.h:104-180).  Process-wide: tests reset it."""
+    f = _voxel.lib().ora_vina_set_line_search
+    f.restype = None
+    f.argtypes = [C.c_int]
+    f(1 if accurate else 0)
+
+
 def set_approximation(kind=0, factor=10.0, cutoff=8.0, weights=None):
     """--approximation: 0 = precalculate_linear (the tables), 1 = precalculate_splines(sf, factor): every table look-up of
     this library (cache_populate, eval, eval_deriv, non_cache, bfgs, mc) then evaluates the pair's spline.

@@ -905,6 +905,23 @@ void ora_vina_trial_hist(long *out, int reset) {
   }
 }
 
+/* --accurate_line_search (minimization_params::BFGSAccurateLineSearch): process-wide switch of this test library */
+static int g_accurate_ls;
+void ora_vina_set_line_search(int kind) { g_accurate_ls = kind == 1; }
+
+/* quaternion_to_angle (quaternion.cu:46-62) */
+static void quat_to_angle(const float *q, float *ang) {
+  ang[0] = ang[1] = ang[2] = 0;
+  const float c = q[0];
+  if (c > -1 && c < 1) {
+    float angle = 2 * acosf(c);
+    if (angle > V_PI) angle -= 2 * V_PI;
+    float sn = sinf(angle / 2);
+    if (fabsf(sn) < V_EPS) return;
+    for (int k = 0; k < 3; k++) ang[k] = q[1 + k] * (angle / sn);
+  }
+}
+
 static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) {
   const ora_ligand *L = ctxp->L;
   const int nt = L->n_nodes - 1, n = 6 + nt, nc = 7 + nt;
@@ -926,9 +943,54 @@ static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) 
       for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
       p[i] = -sum;
     }
-    /* fast_line_search, bfgs.h:73-91 */
     float f1 = 0, alpha = 1;
     const float pg = dotn(p, g, n);
+    if (g_accurate_ls) { /* accurate_line_search, bfgs.h:104-180 (fl arithmetic, the literals 2.0 / 3.0 are double) */
+      const float slope = pg;
+      alpha = 0;
+      if (!(slope >= 0)) {
+        float ang[3], test = 0;
+        quat_to_angle(conf + 3, ang);
+        for (int i = 0; i < n; i++) { /* compute_lambdamin, bfgs.h:93-102; conf(i) in change indexing, conf.h:459-490 */
+          float xi = i < 3 ? conf[i] : i < 6 ? ang[i - 3] : conf[i + 1];
+          float t = fabsf(p[i]) / fmaxf(fabsf(xi), 1.0f);
+          if (t > test) test = t;
+        }
+        const float alamin = V_EPS / test;
+        float a_ = 1.0f, alpha2 = 0, f2 = 0;
+        for (;;) {
+          memcpy(x_new, conf, sizeof(float) * nc);
+          ora_vina_conf_increment(x_new, p, a_, nt);
+          f1 = fx(&ctx, x_new, g_new);
+          if (a_ < alamin || !isfinite(a_)) break; /* alpha stays 0 */
+          if (f1 <= f0 + 1.0e-4f * a_ * slope) {
+            alpha = a_;
+            break;
+          }
+          float tmplam;
+          if (a_ == 1.0f) {
+            tmplam = (float)(-(double)slope / (2.0 * (double)(f1 - f0 - slope)));
+          } else {
+            float rhs1 = f1 - f0 - a_ * slope, rhs2 = f2 - f0 - alpha2 * slope;
+            float ca = (rhs1 / (a_ * a_) - rhs2 / (alpha2 * alpha2)) / (a_ - alpha2);
+            float cb = (-alpha2 * rhs1 / (a_ * a_) + a_ * rhs2 / (alpha2 * alpha2)) / (a_ - alpha2);
+            if (ca == 0.0f) {
+              tmplam = (float)(-(double)slope / (2.0 * (double)cb));
+            } else {
+              float disc = (float)((double)(cb * cb) - 3.0 * (double)ca * (double)slope);
+              if (disc < 0) tmplam = 0.5f * a_;
+              else if (cb <= 0) tmplam = (float)((double)(-cb + sqrtf(disc)) / (3.0 * (double)ca));
+              else tmplam = -slope / (cb + sqrtf(disc));
+            }
+            if (tmplam > 0.5f * a_) tmplam = 0.5f * a_;
+          }
+          alpha2 = a_;
+          f2 = f1;
+          a_ = fmaxf(tmplam, 0.1f * a_);
+        }
+      }
+    } else
+    /* fast_line_search, bfgs.h:73-91 */
     for (unsigned trial = 0; trial < 10; trial++) {
       memcpy(x_new, conf, sizeof(float) * nc);
       ora_vina_conf_increment(x_new, p, alpha, nt);

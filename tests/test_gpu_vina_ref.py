@@ -292,3 +292,39 @@ def test_spline_approximation_follows_the_reference(capi):
     v.build_cache(list(U["begin"]), list(U["end"]), [int(x) for x in U["n"]], [int(t) for t in U["types"]], 1e3)
     e_lin = v.eval_batch(confs, V3, deriv=True)[0]
     assert np.abs(e_lin - U["v1000/e"]).max() > 1e-3
+
+
+def test_accurate_line_search_follows_the_reference(capi):
+    """--accurate_line_search (mi_vina_set_line_search): quasi_newton and short Monte-Carlo chains against oracle/_ref's
+    outputs (tests/golden/als_goldens.npz).  Like the fast search: the reference's result after few iterations for most
+    starts (fp32 transcendentals differ in the last bits; the restatement is bit-identical on the CPU), and a
+    different result than fast_line_search gives."""
+    U = np.load(os.path.join(os.path.dirname(__file__), "golden", "als_goldens.npz"))
+    lig = capi.read_pdbqt_ligand(bytes(U["lig_text"]).decode(), is_text=True)
+    v = capi.Vina()
+    v.set_receptor(U["rec_xyz"], U["rec_smt"])
+    v.build_cache(list(U["begin"]), list(U["end"]), [int(x) for x in U["n"]], [int(t) for t in U["types"]], 1e3)
+    v.set_ligand(lig)
+    confs, mi = U["confs"], int(U["max_iters"])
+    e_fast, cf_fast, _, _ = v.bfgs_batch(confs, V3, max_iters=3)
+    v.set_line_search(True)
+    try:
+        def matches(e, cf, e0, c0):
+            return sum(abs(e[b] - e0[b]) <= 1e-3 * max(1.0, abs(e0[b])) and np.abs(cf[b] - c0[b]).max() < 1e-2
+                       for b in range(len(e0)))
+
+        for tag, cap in (("v1000", V3), ("v10", HUNT)):
+            for iters, need in ((1, 13), (3, 8)):
+                e, cf, _, ev = v.bfgs_batch(confs, cap, max_iters=iters)
+                assert matches(e, cf, U[f"bfgs/{tag}/{iters}/e"], U[f"bfgs/{tag}/{iters}/conf"]) >= need, (tag, iters)
+            e, cf, _, _ = v.bfgs_batch(confs, cap, max_iters=mi)                    # full length: a minimum of equal depth
+            e0 = U[f"bfgs/{tag}/{mi}/e"]
+            assert np.median(e) <= np.median(e0) + 0.5 * max(1.0, abs(np.median(e0)))
+        e3, cf3, _, _ = v.bfgs_batch(confs, V3, max_iters=3)
+        assert (np.abs(cf3 - cf_fast).max(1) > 1e-3).sum() >= 4                      # not the fast search
+        for steps, need in ((1, 14), (3, 5)):      # (measured: 18 of 32 one-step chains)
+            seeds = np.arange(100, 132, dtype=np.uint64)
+            n, e, cf, xyz, ev = v.mc_batch(seeds, list(U["begin"]), list(U["end"]), capi.McParams.default(steps, 2, 20))
+            assert matches(e[:, 0], cf[:, 0], U[f"mcshort/{steps}/e0"], U[f"mcshort/{steps}/conf0"]) >= need, steps
+    finally:
+        v.set_line_search(False)

@@ -450,3 +450,36 @@ def test_spline_approximation_follows_the_reference(capi, rigid_text):
             assert abs(er - eo) <= 1e-5 * max(1.0, abs(er)) and np.abs(cr - co).max() <= 1e-4 * max(1.0, np.abs(cr).max())
     finally:
         V.set_approximation(0)
+
+
+@pytest.mark.parametrize("which", ["adduct", "chain"])
+def test_accurate_line_search_runs_are_bit_identical(which, request):
+    """--accurate_line_search (bfgs.h:104-180, compute_lambdamin :93-102): whole quasi_newton runs and Monte-Carlo chains
+    of the restatement against the reference, on the cache and on non_cache."""
+    c = request.getfixturevalue(which)
+    s, lig = c.ref, c.lig
+    rng = np.random.RandomState(8)
+    confs = np.concatenate([RC.random_confs(rng, lig["conf0"], 3, small=True), RC.random_confs(rng, lig["conf0"], 3)])
+    try:
+        s.set_line_search(True)
+        V.set_line_search(True)
+        differs = 0
+        for conf in confs:
+            for v in (V3, HUNT):
+                for iters in (1, 4, c.max_iters):
+                    er, xr, gr = s.bfgs(conf, v, max_iters=iters)
+                    eo, xo, go, _ = c.ora.bfgs(conf, v, max_iters=iters)
+                    assert er == eo and np.array_equal(xr, xo) and np.array_equal(gr, go), (v, iters)
+            s.set_line_search(False)
+            ef, xf, _ = s.bfgs(conf, V3, max_iters=c.max_iters)
+            s.set_line_search(True)
+            ea, xa, _ = s.bfgs(conf, V3, max_iters=c.max_iters)
+            differs += int(not np.array_equal(xf, xa))
+        assert differs >= 3                                          # it really is another search
+        for seed, steps in ((1, 30), (2, 120)):
+            er, cr, xr = s.mc(seed, steps, c.begin, c.end, max_iters=c.max_iters, num_saved=20)
+            eo, co, xo, _ = V.mc_chain(c.ora, c.begin, c.end, seed, steps, c.max_iters, num_saved=20)
+            assert len(er) == len(eo) and np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
+    finally:
+        s.set_line_search(False)
+        V.set_line_search(False)
