@@ -525,7 +525,9 @@ __device__ __forceinline__ void fold_forces(const VinaLigand &L, const WaveWork 
 // MODE 0: model::eval_deriv (model.cu:202-225); MODE 1: model::eval (energy only, midpoint pair table);
 // MODE 2: cache::eval (cache.cpp:52-63: receptor-grid term only -- the energy gnina's Metropolis step
 // uses, monte_carlo.cpp:44-47); MODE 3: model::set only (coordinates); MODE 4: eval_intramolecular
-// (model.cu:352-399: ligand pairs only, energy only).  Returns the energy in every lane; MODE 0 writes change[6 + T] to LDS.
+// (model.cu:352-399: ligand pairs + flexible-residue atoms against the rigid receptor + pairs among flexible / inflex
+// atoms, energy only); MODE 5: the pair part of model::eval (other_pairs, then the ligand's -- all pairs).  Returns the
+// energy in every lane; MODE 0 writes change[6 + T] to LDS.
 template <int MODE, int PG = kPairGroup>
 __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand &L, const float *conf, float v0, float v1,
                                            float v2, const WaveWork &w, float *change) {
@@ -654,7 +656,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   // 2. atom coordinates (atom_frame::set_coords, tree.h:128-131) + 3. receptor term.  For the first
   // kTapIt * 64 atoms the grid look-up is split: the corner loads are issued here and interpolated after the
   // pair stage (3b below), so the two L2 round trips overlap.
-  constexpr bool GRID = MODE != 3 && MODE != 4;
+  constexpr bool GRID = MODE != 3 && MODE != 4 && MODE != 5;
   constexpr int kTapIt = 2;
   float e_part = 0.f;
   GridTap tap[kTapIt];
@@ -704,7 +706,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
   }
   wave_sync();
-  if (MODE != 3 && MODE != 4 && env.direct) {
+  if (MODE != 3 && MODE != 4 && MODE != 5 && env.direct) {
     // non_cache::eval / eval_deriv (non_cache.cpp:52-83,125-179): every ligand heavy atom against every
     // receptor atom within the cutoff -- the 64 lanes stride over the receptor, one ligand atom at a time
     for (int i = 0; i < L.n_movable; i++) {
@@ -772,7 +774,14 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   // 4. intramolecular pairs (model.cu:38-60 / :22-36).  Table mode: a lane takes its pairs PG at a time
   // (six: one group covers 384 pairs, a typical drug-like ligand) and issues their table look-ups (L2 latency) together; out-of-cutoff pairs read entry 0 and are discarded, so
   // the group is straight-line code.  Per lane the energies still add up in increasing pair order.
-  if ((MODE < 2 || MODE == 4) && !env.exact && !env.spline) {
+  // eval_intramolecular keeps, of other_pairs, those with neither atom in the ligand (model.cu:386-397)
+  const bool has_flex = L.lig_end > L.lig_begin && L.pair_cap != nullptr;
+  auto pair_counts = [&](int p, const int2 &ab) -> bool {
+    if (MODE != 4 || !has_flex || !L.pair_cap[p]) return true;
+    const bool a_lig = ab.x >= L.lig_begin && ab.x < L.lig_end, b_lig = ab.y >= L.lig_begin && ab.y < L.lig_end;
+    return !a_lig && !b_lig;
+  };
+  if ((MODE < 2 || MODE == 4 || MODE == 5) && !env.exact && !env.spline) {
     for (int p0 = lane; p0 < L.n_pairs; p0 += 64 * PG) {
       float rx[PG], ry[PG], rz[PG], rem[PG], capv[PG];
       float2 s1[PG], s2[PG];
@@ -790,7 +799,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         ry[u] = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1];
         rz[u] = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
         const float r2 = rx[u] * rx[u] + ry[u] * ry[u] + rz[u] * rz[u];
-        in[u] = valid && r2 < env.cutoff_sqr;
+        in[u] = valid && r2 < env.cutoff_sqr && pair_counts(valid ? p : 0, ab);
         const long base = (long)tri_idx(L.smt[ab.x], L.smt[ab.y]) * env.n;
         const float r2f = env.factor * r2;
         const int i1 = (int)r2f;
@@ -828,14 +837,14 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       }
     }
   }
-  for (int p = lane; (MODE < 2 || MODE == 4) && (env.exact || env.spline) && p < L.n_pairs; p += 64) {
+  for (int p = lane; (MODE < 2 || MODE == 4 || MODE == 5) && (env.exact || env.spline) && p < L.n_pairs; p += 64) {
     const int2 ab = L.pairs[p];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
     const float r2 = rx * rx + ry * ry + rz * rz;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     const float capx = (L.pair_cap && L.pair_cap[p]) ? v2 : v0;
-    if (r2 < env.cutoff_sqr) {
+    if (r2 < env.cutoff_sqr && pair_counts(p, ab)) {
       if (DERIV) {
         float pe, dor;
         prec_eval_deriv(env, L.smt[ab.x], L.smt[ab.y], r2, pe, dor);
@@ -853,6 +862,26 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       const int2 sl = L.pair_slots[p];
       w.cx[sl.x] = -out.x, w.cy[sl.x] = -out.y, w.cz[sl.x] = -out.z;
       w.cx[sl.y] = out.x, w.cy[sl.y] = out.y, w.cz[sl.y] = out.z;
+    }
+  }
+  if (MODE == 4 && has_flex && env.rec) {
+    // eval_intramolecular's flex-rigid term (model.cu:364-384): every heavy movable atom outside the ligand against
+    // every heavy atom of the rigid receptor, each PAIR curled with v[1] (the igrid curls an atom's sum instead)
+    for (int i = 0; i < L.n_movable; i++) {
+      if (i >= L.lig_begin && i < L.lig_end) continue;
+      const int t1 = L.smt[i];
+      if (t1 <= 1) continue;
+      const float ax = w.coords[3 * i], ay = w.coords[3 * i + 1], az = w.coords[3 * i + 2];
+      for (int j = lane; j < env.n_rec; j += 64) {
+        const float4 r = env.rec[j];
+        const float rx = ax - r.x, ry = ay - r.y, rz = az - r.z;
+        const float r2 = rx * rx + ry * ry + rz * rz;
+        if (r2 < env.cutoff_sqr) {
+          float pe = prec_eval(env, t1, __float_as_int(r.w), r2);
+          curl1(pe, v1);
+          e_part += pe;
+        }
+      }
     }
   }
   // 3b. interpolate the receptor grids whose corner loads were issued in stage 3
@@ -2284,7 +2313,8 @@ void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s) {
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s) {
   const size_t lds = vina_wave_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, false, false);
-  // with_deriv: 1 = model::eval_deriv, 0 = model::eval, 2 = cache::eval (grid term only)
+  // with_deriv: 1 = model::eval_deriv, 0 = model::eval, 2 = cache::eval (grid term only), 4 = eval_intramolecular,
+  // 5 = the pair part of model::eval
   auto go = [&](auto kernel) {
     big_lds(kernel);
     hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds, s, env, lig, confs, v0, v1, v2, energy, change, coords);
@@ -2295,6 +2325,8 @@ void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *co
     go(vina_eval_kernel<1>);
   else if (with_deriv == 4)
     go(vina_eval_kernel<4>);
+  else if (with_deriv == 5)
+    go(vina_eval_kernel<5>);
   else
     go(vina_eval_kernel<2>);
 }

@@ -1998,13 +1998,24 @@ mi_status mi_vina_final_energies(mi_vina *vv, const float *confs, int B, const f
   VTRY
   MIG_CHECK(vv && confs && v3 && e_final && B >= 0, 1, "bad arguments");
   if (B == 0) return MI_OK;
-  std::vector<float> inter(B), intra(B);
+  // e = model::eval(exact_prec, non_cache [linear]) = non_cache::eval + other_pairs + ligand pairs (+ user grid);
+  // intramolecular = eval_intramolecular(exact_prec) = ligand pairs + flexible atoms vs rigid receptor + pairs among
+  // flexible / inflex atoms (model.cu:352-399).  With a rigid receptor the two pair sums are the same number.
+  std::vector<float> inter(B), pairs(B), intra(B);
   mi_status st = mi_vina_eval_batch(vv, confs, B, v3, 2 | MI_VINA_DIRECT | MI_VINA_USER_TERM, inter.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
   st = mi_vina_eval_batch(vv, confs, B, v3, 4 | MI_VINA_EXACT, intra.data(), nullptr, nullptr);
   if (st != MI_OK) return st;
+  const Vina &v = *reinterpret_cast<const Vina *>(vv);
+  const bool flex = v.lig.n_movable != v.lig.n_atoms || v.lig.pair_cap != nullptr;
+  if (flex) {
+    st = mi_vina_eval_batch(vv, confs, B, v3, 5 | MI_VINA_EXACT, pairs.data(), nullptr, nullptr);
+    if (st != MI_OK) return st;
+  } else {
+    pairs = intra;
+  }
   for (int b = 0; b < B; b++) {
-    e_final[b] = conf_independent_default(inter[b] + intra[b], intra[b], num_tors);
+    e_final[b] = conf_independent_default(inter[b] + pairs[b], intra[b], num_tors);
     if (intramolecular) intramolecular[b] = intra[b];
   }
   return MI_OK;

@@ -196,6 +196,23 @@ class McParams(C.Structure):
                 ("authentic_v", C.c_float * 3)]
 
 
+def model_energies(scene, rec_xyz, rec_smt, conf, v=(1000.0, 1000.0, 1000.0), slope=None):
+    """do_search's two energies for any model, flexible residues included (main.cpp:339-344): (model::eval(exact_prec,
+    non_cache) before conf_independent, eval_intramolecular(exact_prec))"""
+    conf = np.ascontiguousarray(conf, dtype=np.float32)
+    vv = np.ascontiguousarray(v, dtype=np.float32)
+    rec_xyz = np.ascontiguousarray(rec_xyz, dtype=np.float32)
+    rec_smt = np.ascontiguousarray(rec_smt, dtype=np.int32)
+    intra = C.c_float()
+    f = _voxel.lib().ora_vina_model_energies
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, _f32p, C.POINTER(GridDims), C.c_float, _f32p, _i32p, C.c_int, C.POINTER(Ligand), _f32p, _f32p,
+                  C.POINTER(C.c_float)]
+    e = f(scene.tables.h, None, C.byref(scene.gd), scene.slope if slope is None else slope, _p(rec_xyz),
+          _p(rec_smt, C.c_int32), len(rec_smt), C.byref(scene.lig.c), _p(conf), _p(vv), C.byref(intra))
+    return e, intra.value
+
+
 def set_line_search(accurate=False):
     """--accurate_line_search: every bfgs of this library (bfgs, bfgs_callback, refine, mc) then runs
     accurate_line_search (bfgs.h:104-180).  Process-wide: tests reset it."""

@@ -1589,6 +1589,79 @@ int ora_vina_within(const ora_grid_dims *gd, const ora_ligand *L, const float *c
   return ok;
 }
 
+/* do_search's reported energies for the general model (flexible residues included), main.cpp:339-344:
+ *   intramolecular = model::eval_intramolecular(exact_prec, v, c)            (model.cu:352-399)
+ *                  = ligand pairs (v[0]) + flexible heavy atoms x rigid receptor heavy atoms, every PAIR curled with v[1]
+ *                    + those other_pairs that touch no ligand atom (v[2])
+ *   e = model::eval(exact_prec, non_cache, v, c) = non_cache::eval (its own LINEAR tables) + other_pairs + ligand pairs
+ *       (+ the user-grid sum), model.cu:112-136
+ * returns e (before conf_independent); *intra_out = intramolecular.  Sums in the reference's order. */
+float ora_vina_model_energies(const ora_vina_tables *T, const float *w, const ora_grid_dims *gd, float slope,
+                              const float *rec_xyz, const int32_t *rec_smt, int n_rec, const ora_ligand *L,
+                              const float *conf, const float *v, float *intra_out) {
+  const int n = L->n_atoms;
+  float *coords = (float *)malloc(sizeof(float) * 3 * n);
+  float *origin = (float *)malloc(sizeof(float) * 3 * L->n_nodes), *axis = (float *)malloc(sizeof(float) * 3 * L->n_nodes);
+  ora_vina_set_conf(L, conf, coords, origin, axis);
+  const int lb = L->lig_end > L->lig_begin ? L->lig_begin : 0, le = L->lig_end > L->lig_begin ? L->lig_end : n;
+  float pair_sum[2] = {0, 0}, flexflex = 0; /* eval_interacting_pairs sums on its own (model.cu:22-36) */
+  for (int kind = 0; kind < 2; kind++)
+    for (int p = 0; p < L->n_pairs; p++) {
+      if ((L->pair_kind ? L->pair_kind[p] : 0) != kind) continue;
+      int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+      float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
+            dz = coords[3 * a + 2] - coords[3 * b + 2];
+      float r2 = dx * dx + dy * dy + dz * dz;
+      if (!(r2 < T->cutoff_sqr)) continue;
+      float pe = prec_eval(T, w, 1, L->smt[a], L->smt[b], r2);
+      curl1(&pe, PAIR_CAP(L, p, v));
+      pair_sum[kind] += pe;
+    }
+  float intra = 0;
+  intra += pair_sum[0];
+  for (int i = 0; i < n_movable_of(L); i++) { /* flex-rigid */
+    if (i >= lb && i < le) continue;
+    int t1 = L->smt[i];
+    if (is_hydrogen(t1)) continue;
+    for (int j = 0; j < n_rec; j++) {
+      if (is_hydrogen(rec_smt[j])) continue;
+      float dx = coords[3 * i] - rec_xyz[3 * j], dy = coords[3 * i + 1] - rec_xyz[3 * j + 1],
+            dz = coords[3 * i + 2] - rec_xyz[3 * j + 2];
+      float r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 < T->cutoff_sqr) {
+        float pe = prec_eval(T, w, 1, t1, rec_smt[j], r2);
+        curl1(&pe, v[1]);
+        intra += pe;
+      }
+    }
+  }
+  for (int p = 0; p < L->n_pairs; p++) { /* flex-flex: other_pairs with no ligand atom, added one by one */
+    if (!(L->pair_kind && L->pair_kind[p])) continue;
+    int a = L->pairs[2 * p], b = L->pairs[2 * p + 1];
+    if ((a >= lb && a < le) || (b >= lb && b < le)) continue;
+    float dx = coords[3 * a] - coords[3 * b], dy = coords[3 * a + 1] - coords[3 * b + 1],
+          dz = coords[3 * a + 2] - coords[3 * b + 2];
+    float r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 < T->cutoff_sqr) {
+      float pe = prec_eval(T, w, 1, L->smt[a], L->smt[b], r2);
+      curl1(&pe, v[2]);
+      intra += pe;
+    }
+  }
+  (void)flexflex;
+  float inter = 0;
+  (void)ora_vina_noncache_eval(T, w, 0, gd, slope, rec_xyz, rec_smt, n_rec, L, conf, v, 0, NULL, &inter, NULL);
+  float e = inter;
+  e += pair_sum[1];
+  e += pair_sum[0];
+  e = model_eval_user_term(L, coords, e);
+  if (intra_out) *intra_out = intra;
+  free(coords);
+  free(origin);
+  free(axis);
+  return e;
+}
+
 /* num_tors_div (everything.h:796-814) with the default weight 5*0.05846/0.1 - 1 (main.cpp:1329):
  * e / (1 + w * num_tors / 5), w = 0.1 * (weight + 1) */
 float ora_vina_conf_independent(float e, float num_tors) {

@@ -185,6 +185,13 @@ def test_flexible_residues_in_the_search_on_the_device(capi):
     for b in range(len(confs)):
         assert abs(e[b] - G[P + "noncache/e"][b]) <= 1e-4 * max(1.0, abs(G[P + "noncache/e"][b]))
         assert np.abs(ch[b] - G[P + "noncache/change"][b]).max() <= 1e-3 * max(1.0, np.abs(G[P + "noncache/change"][b]).max())
+    # do_search's reported energies on the combined model (main.cpp:339-344; eval_intramolecular with its flex-rigid and
+    # flex-flex terms, model.cu:352-399): tests/golden/flex_final_goldens.npz
+    F = np.load(os.path.join(os.path.dirname(__file__), "golden", "flex_final_goldens.npz"))
+    ef, intra = v.final_energies(confs, float(F["num_tors"]))
+    for b in range(len(confs)):
+        assert abs(intra[b] - F["intra"][b]) <= 2e-4 * max(1.0, abs(F["intra"][b])), (b, intra[b], F["intra"][b])
+        assert abs(ef[b] - F["e"][b]) <= 2e-4 * max(1.0, abs(F["e"][b]), abs(F["intra"][b])), (b, ef[b], F["e"][b])
     mi = int(G[P + "max_iters"])
     for iters, need in ((1, 10), (3, 6)):   # (clashing random starts: see the chain case above)
         e, cf, g, ev = v.bfgs_batch(confs[:12], HUNT, max_iters=iters)

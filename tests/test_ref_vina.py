@@ -483,3 +483,25 @@ def test_accurate_line_search_runs_are_bit_identical(which, request):
     finally:
         s.set_line_search(False)
         V.set_line_search(False)
+
+
+def test_final_energies_with_flexible_residues(flexcase, adduct):
+    """main.cpp:339-344 on the combined model: eval_intramolecular (model.cu:352-399) = ligand pairs + flexible atoms
+    against the rigid receptor (every pair curled with v[1], exact tables) + other_pairs without a ligand atom;
+    e = model::eval(exact_prec, non_cache) = non_cache::eval (all movable atoms, linear tables) + other_pairs + ligand
+    pairs; reported = conf_independent(e - intramolecular).  Restatement vs the reference, and the rigid case as before."""
+    s, d, ora = flexcase["ref"], flexcase["d"], flexcase["ora"]
+    rng = np.random.RandomState(9)
+    nt = s.conf_independent(100.0)
+    for conf in np.concatenate([RC.random_confs(rng, d["conf0"], 4, small=True), RC.random_confs(rng, d["conf0"], 2)]):
+        ef, intra = s.final_energies(conf)
+        e, intra_o = V.model_energies(ora, flexcase["rx"], flexcase["rs"], conf, V3)
+        assert intra == intra_o
+        x = np.float32(np.float32(e) - np.float32(intra_o))
+        assert ef == s.conf_independent(float(x))
+    assert nt == s.conf_independent(100.0)
+    c = adduct                                              # a rigid receptor through the same function
+    for conf in RC.random_confs(rng, c.lig["conf0"], 3, small=True, spread=0.5):
+        ef, intra = c.ref.final_energies(conf)
+        e, intra_o = V.model_energies(c.ora, c.rec_xyz, c.rec_smt, conf, V3)
+        assert intra == intra_o and ef == V.conf_independent(np.float32(np.float32(e) - np.float32(intra_o)), c.lig["num_tors"])
