@@ -274,11 +274,22 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
       for (int c = 0; c < CC4; c++) n_act += s_flag[chunk * CC4 + c];
       if (n_act == 0) continue;
       J = taps * n_act;
+      // Channel-major order (all 27 taps of one surviving quad, then the next quad): the two quads of a pair are then
+      // the same four channels one tap apart, i.e. nearly the same voxels -- so that the per-M-tile zero test in the K
+      // loop below finds BOTH halves of an MFMA's A operand empty about as often as one.
       for (int j = tid; j < J; j += NTHREADS) {
-        int q = j;
+        const int a = j / taps;
+        int tap = j - a * taps;
+        if (taps == 27) {  // boustrophedon walk of the 3x3x3 taps: consecutive taps are always face neighbours
+          const int dx = tap / 9;
+          int r = tap - 9 * dx;
+          if (dx & 1) r = 8 - r;
+          const int dy = r / 3, k = r - 3 * dy;
+          tap = dx * 9 + dy * 3 + ((dy & 1) ? 2 - k : k);
+        }
+        int c4 = a;
         if (n_act != CC4) {
-          const int tap = j / n_act, a = j - tap * n_act;
-          int c4 = 0, seen = -1;
+          int seen = -1;
           for (int c = 0; c < CC4; c++) {
             seen += s_flag[chunk * CC4 + c];
             if (seen == a) {
@@ -286,8 +297,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
               break;
             }
           }
-          q = tap * CC4 + c4;
         }
+        const int q = tap * CC4 + c4;
         s_list[j] = list_entry(q, q);
       }
       if (tid < 5) s_list[J + tid] = list_entry(Q - 1, Q);  // the pad entries: zero weights
@@ -321,7 +332,17 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
     };
     auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
 #pragma unroll
-      for (int m = 0; m < TM; m++)
+      for (int m = 0; m < TM; m++) {
+        // Second level of zero-skipping (sparse inputs only): if the A operand of this M-tile -- 32 voxels x the four
+        // channels of both quads of the pair, at this tap -- is all zero in every lane, its four MFMAs add exact zeros
+        // to the accumulators and are skipped (results bit-identical to executing them).  Three VALU instructions and
+        // a wave-uniform branch against 4 x 64 cycles of MFMA; on the pooled voxel grid about half of the operands
+        // that survive the tile-level list are empty.
+        if (SPARSE) {
+          const unsigned any = __float_as_uint(aa[m].x) | __float_as_uint(aa[m].y) | __float_as_uint(aa[m].z) |
+                               __float_as_uint(aa[m].w);
+          if (!__any(any != 0u)) continue;
+        }
 #pragma unroll
         for (int n = 0; n < TN; n++) {
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].x, ww[n].x, acc[m][n], 0, 0, 0);
@@ -329,6 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].z, ww[n].z, acc[m][n], 0, 0, 0);
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].w, ww[n].w, acc[m][n], 0, 0, 0);
         }
+      }
     };
     float4 a0[TM], a1[TM], w0[TN], w1[TN];
     load_pair(0, a0, w0);
