@@ -14,8 +14,11 @@
 //    overlaps the pose's grid box -> a channel-sorted candidate list.
 //  * voxelize_tiles: one 64-lane wavefront per 8x8x8-voxel tile. Lanes cooperatively test
 //    64 candidates at a time against the tile (sphere/box), ballot the hits and broadcast each
-//    hit with v_readlane, so the atom data is wave-uniform (SGPR) and each lane owns a 2x2x2
-//    voxel cell in registers.  No atomics: per voxel the sum runs in atom order, which makes
+//    hit with v_readlane, so the atom data is wave-uniform (SGPR) and each lane owns eight
+//    voxels in registers: one per 4x4x4 sub-block of the tile while atoms are accumulated (an
+//    instruction's 64 evaluations are then one compact cube, skipped as a whole when the atom
+//    does not reach it), handed over through LDS to 2x2x2-cell ownership for the fused pooling.
+//    No atomics: per voxel the sum runs in atom order, which makes
 //    the result deterministic and equal to the oracle's up to the exp/sqrt approximations.
 //  * Output is either the reference layout [B][C][N][N][N] (export path, mi_voxelize_batch) or,
 //    for the CNN, the 2x2x2-pooled grid written channels-last [B][N/2][N/2][N/2][Cp] straight
@@ -216,11 +219,24 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   const int b = wg / (ntile * ntile * ntile);
   const int tile_id = wg - b * (ntile * ntile * ntile);
   const int tz = tile_id % ntile, ty = (tile_id / ntile) % ntile, tx = tile_id / (ntile * ntile);
-  const int cx = tx * 4 + (lane >> 4), cy = ty * 4 + ((lane >> 2) & 3), cz = tz * 4 + (lane & 3);
+  // Two lane <-> voxel maps.  While atoms are accumulated a lane owns the voxel at local position (lx, ly, lz) of each of
+  // the tile's eight 4x4x4 SUB-BLOCKS (acc[k], k = sub-block): the 64 evaluations of one instruction then are one compact
+  // 2 A cube, and an atom that touches the tile reaches only 3.2 of the 8 cubes on average -- the others are skipped by
+  // the wave-uniform exec-mask branches around density().  For pooling / output a lane owns the 2x2x2 CELL (cx, cy, cz);
+  // the accumulators change hands through a 2 KB LDS transpose per flushed channel (s_tr).
+  const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
 
   extern __shared__ __attribute__((aligned(16))) float s_stage[];  // MODE != 0: [64][Cp] (+ arg-max bytes)
   const int Cp = v.Cp;
-  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_stage + 64 * Cp);  // [64][Cp], only if argmax_out
+  float *s_tr = s_stage + 64 * Cp;                                              // [64 lanes][8 sub-blocks]
+  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + 512);         // [64][Cp], only if argmax_out
+  // where the r-th voxel (x*4 + y*2 + z) of this lane's pooling cell sits in s_tr
+  int taddr[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int x = 2 * (lane >> 4) + (r >> 2), y = 2 * ((lane >> 2) & 3) + ((r >> 1) & 1), z = 2 * (lane & 3) + (r & 1);
+    taddr[r] = ((x & 3) + 4 * (y & 3) + 16 * (z & 3)) * 8 + (x >> 2) * 4 + (y >> 2) * 2 + (z >> 2);
+  }
   if (MODE != 0) {
     for (int i = lane; i < 64 * Cp; i += 64) s_stage[i] = 0.f;
     if (MODE == 1 && v.argmax_out)
@@ -233,9 +249,9 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   float gx[2], gy[2], gz[2];
 #pragma unroll
   for (int d = 0; d < 2; d++) {
-    gx[d] = ox + (float)(2 * cx + d) * v.res;
-    gy[d] = oy + (float)(2 * cy + d) * v.res;
-    gz[d] = oz + (float)(2 * cz + d) * v.res;
+    gx[d] = ox + (float)(8 * tx + 4 * d + lx) * v.res;
+    gy[d] = oy + (float)(8 * ty + 4 * d + ly) * v.res;
+    gz[d] = oz + (float)(8 * tz + 4 * d + lz) * v.res;
   }
   // tile bounding box in space (first/last voxel of the 8x8x8 tile)
   const float tlox = ox + (float)(8 * tx) * v.res, thix = ox + (float)(8 * tx + 7) * v.res;
@@ -262,24 +278,36 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
           for (int dz = 0; dz < 2; dz++) {
-            int i = 2 * cx + dx, j = 2 * cy + dy, k = 2 * cz + dz;
+            int i = 8 * tx + 4 * dx + lx, j = 8 * ty + 4 * dy + ly, k = 8 * tz + 4 * dz + lz;
             if (i < v.N && j < v.N && k < v.N) o[((size_t)i * v.N + j) * v.N + k] = acc[dx * 4 + dy * 2 + dz];
           }
-    } else if (MODE == 1) {
-      float m = acc[0];
+      return;
+    }
+    // sub-block ownership -> cell ownership (wave-synchronous LDS round trip; LDS executes a wave's accesses in order)
+    *reinterpret_cast<float4 *>(s_tr + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(s_tr + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float cv[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) cv[r] = s_tr[taddr[r]];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (MODE == 1) {
+      float m = cv[0];
       int am = 0;
 #pragma unroll
       for (int i = 1; i < 8; i++)
-        if (acc[i] > m) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
-          m = acc[i];
+        if (cv[i] > m) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
+          m = cv[i];
           am = i;
         }
       s_stage[lane * Cp + c] = m;
       if (v.argmax_out) s_arg[lane * Cp + c] = (unsigned char)am;
     } else {
-      float s = acc[0];
+      float s = cv[0];
 #pragma unroll
-      for (int i = 1; i < 8; i++) s = s + acc[i];  // (kd,kh,kw) order, then /8 like avg_pool3d
+      for (int i = 1; i < 8; i++) s = s + cv[i];  // (kd,kh,kw) order, then /8 like avg_pool3d
       s_stage[lane * Cp + c] = s * 0.125f;
     }
   };
@@ -475,7 +503,7 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
-    size_t lds = (size_t)64 * v.Cp * sizeof(float) + (v.argmax_out ? (size_t)64 * v.Cp : 0);
+    size_t lds = (size_t)64 * v.Cp * sizeof(float) + 512 * sizeof(float) + (v.argmax_out ? (size_t)64 * v.Cp : 0);
     if (mode == 1)
       hipLaunchKernelGGL(voxelize_tiles<1>, grid, block, lds, s, v);
     else
