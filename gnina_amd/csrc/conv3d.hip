@@ -333,22 +333,20 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
     auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
 #pragma unroll
       for (int m = 0; m < TM; m++) {
-        // Second level of zero-skipping (sparse inputs only): if the A operand of this M-tile -- 32 voxels x the four
-        // channels of both quads of the pair, at this tap -- is all zero in every lane, its four MFMAs add exact zeros
-        // to the accumulators and are skipped (results bit-identical to executing them).  Three VALU instructions and
-        // a wave-uniform branch against 4 x 64 cycles of MFMA; on the pooled voxel grid about half of the operands
-        // that survive the tile-level list are empty.
-        if (SPARSE) {
-          const unsigned any = __float_as_uint(aa[m].x) | __float_as_uint(aa[m].y) | __float_as_uint(aa[m].z) |
-                               __float_as_uint(aa[m].w);
-          if (!__any(any != 0u)) continue;
-        }
+        // Second level of zero-skipping (sparse inputs only), per MFMA: the A operand of one instruction is ONE input
+        // channel at 32 voxels x the pair's two taps.  If it is zero in every lane the instruction would add exact
+        // zeros to the accumulators and is skipped (results bit-identical to executing it): one v_cmp and a wave-uniform
+        // branch against 64 cycles of MFMA.  The channels of the pooled voxel grid are individually sparse (one atom
+        // type each): of the operands that survive the tile-level quad list about a quarter are non-zero.
+        const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
 #pragma unroll
-        for (int n = 0; n < TN; n++) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].x, ww[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].y, ww[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].z, ww[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].w, ww[n].w, acc[m][n], 0, 0, 0);
+        for (int j = 0; j < 4; j++) {
+          if (SPARSE && !__any(__float_as_uint(ac[j]) != 0u)) continue;
+#pragma unroll
+          for (int n = 0; n < TN; n++) {
+            const float wc = j == 0 ? ww[n].x : j == 1 ? ww[n].y : j == 2 ? ww[n].z : ww[n].w;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], wc, acc[m][n], 0, 0, 0);
+          }
         }
       }
     };
