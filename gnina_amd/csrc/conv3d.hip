@@ -331,23 +331,46 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
       e_next = lp[2 * pr + 2];
     };
     auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
-#pragma unroll
-      for (int m = 0; m < TM; m++) {
-        // Second level of zero-skipping (sparse inputs only), per MFMA: the A operand of one instruction is ONE input
+      if constexpr (SPARSE) {
+        // Third level of zero-skipping (sparse inputs only), per MFMA: the A operand of one instruction is ONE input
         // channel at 32 voxels x the pair's two taps.  If it is zero in every lane the instruction would add exact
-        // zeros to the accumulators and is skipped (results bit-identical to executing it): one v_cmp and a wave-uniform
-        // branch against 64 cycles of MFMA.  The channels of the pooled voxel grid are individually sparse (one atom
-        // type each): of the operands that survive the tile-level quad list about a quarter are non-zero.
-        const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
+        // zeros to the accumulators and is skipped (results bit-identical to executing it).  The channels of the
+        // pooled voxel grid are individually sparse (one atom type each): of the operands that survive the tile-level
+        // quad list about a third are non-zero.  All eight lane masks are taken first, straight into SGPR pairs
+        // (v_cmp_ne_u32 with an SGPR destination; written as asm because the compiler turns `bits != 0` into
+        // v_cmp_class -> vcc -> s_cbranch_vccz, one VALU-to-branch round trip per MFMA, and a ballot of that into
+        // v_cndmask + v_cmp), then the branches are scalar compares that run beside the other waves' MFMAs.  The
+        // instructions of the two M-tiles alternate, so two dependent MFMAs are never adjacent.
+        unsigned long long live[TM][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (SPARSE && !__any(__float_as_uint(ac[j]) != 0u)) continue;
+        for (int m = 0; m < TM; m++) {
+          const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live[m][j]) : "v"(ac[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int m = 0; m < TM; m++) {
+            if (live[m][j] == 0ull) continue;
+            const float a = j == 0 ? aa[m].x : j == 1 ? aa[m].y : j == 2 ? aa[m].z : aa[m].w;
+#pragma unroll
+            for (int n = 0; n < TN; n++) {
+              const float wc = j == 0 ? ww[n].x : j == 1 ? ww[n].y : j == 2 ? ww[n].z : ww[n].w;
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wc, acc[m][n], 0, 0, 0);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < TM; m++)
 #pragma unroll
           for (int n = 0; n < TN; n++) {
-            const float wc = j == 0 ? ww[n].x : j == 1 ? ww[n].y : j == 2 ? ww[n].z : ww[n].w;
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], wc, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].x, ww[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].y, ww[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].z, ww[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[m].w, ww[n].w, acc[m][n], 0, 0, 0);
           }
-        }
       }
     };
     float4 a0[TM], a1[TM], w0[TN], w1[TN];
