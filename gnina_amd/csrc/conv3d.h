@@ -44,7 +44,8 @@ struct ConvArgs {
   // bf16 kernels (conv3d_bf16.hip) only: element type of the tensors behind in / out / in_act
   // (1 = fp32, 0 = bf16; cc4 / ccs / cin4 then count OCTETS of 8 channels and wp is a packed bf16 array)
   int in_f32, out_f32, act_f32;
-  int sparse;        // skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients)
+  int sparse;        // 1: skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients) and,
+                     // per MFMA, all-zero A operands; 2: the per-MFMA test only, every quad listed (ReLU'd activations)
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;

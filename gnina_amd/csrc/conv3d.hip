@@ -79,7 +79,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
     return make_int2(((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4) * 4, wrow * wstride_i * 4);
   };
 
-  for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = 0;
+  // sparse == 1: a flag is raised by the staging loops when the quad is non-zero somewhere in the tile.  sparse == 2
+  // (ReLU'd activations): every existing quad stays listed -- the K loop runs in the list's channel-major order with
+  // its per-MFMA zero test, and that order does not depend on the tile or its contents
+  const bool detect = SPARSE && p.sparse == 1;
+  for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = (SPARSE && p.sparse == 2 && i < p.cin4) ? 1 : 0;
   // Row Q of every chunk's packed weights is all zero (ConvArgs::wrows): the list entry behind the last quad points
   // there, so an odd number of quads needs no special case in the K loop (the idle half-wave multiplies by zeros).
   if (!SPARSE)  // dense: quad q multiplies weight row q
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
                 x.w = x.w * sc.w + sh.w;
               }
               *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
-              if (SPARSE && (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f)) s_flag[chunk * CC4 + qb + u] = 1;
+              if (detect && (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f)) s_flag[chunk * CC4 + qb + u] = 1;
             }
         }
       }
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
           }
         }
         *reinterpret_cast<float4 *>(s_tile + dst[u]) = v;
-        if (SPARSE && cq[u] >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) s_flag[chunk * CC4 + cq[u]] = 1;
+        if (detect && cq[u] >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) s_flag[chunk * CC4 + cq[u]] = 1;
       }
     }
     __syncthreads();

@@ -54,7 +54,7 @@ static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
   const long groups = cdiv(a.coutp / (cp.cfg == CONV_CFG_N16_TM4 || cp.cfg == CONV_CFG_N16_TM3 ? 16 : 32), wn * tn);
   const long blocks = (long)nb * a.ntx * a.nty * a.ntz * groups;
   if (blocks >= 512 || getenv("MI_GNINA_NO_LAT")) return;
-  if (a.sparse) return;  // the zero-quad skipping pairs up surviving quads per tile: keep one tiling so results do not depend on the batch size
+  if (a.sparse == 1) return;  // the zero-quad skipping pairs up surviving quads per tile: keep one tiling so results do not depend on the batch size
   if (a.post_w) {  // the fused 1x1 conv needs every mid channel inside one workgroup
     int lwm, lwn, ltm, ltn;
     conv_cfg_shape(cp.lat_cfg, &lwm, &lwn, &ltm, &ltn);
@@ -1172,6 +1172,10 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.out_cs = m->buf_cp[st.conv.dst];
         if (grad && a.pool == 1) a.argmax_out = arg_ptr(st.conv.dst);
         a.sparse = (st.conv.src == m->input_dst && !st.has_bn && !bf16) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
+        // ReLU'd activations (Default2017 / Default2018 convs behind the first one): channel-major K order with the
+        // per-MFMA zero test, no per-tile quad dropping (ConvArgs::sparse)
+        if (!a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !getenv("MI_GNINA_NO_RELU_SKIP"))
+          a.sparse = 2;
         if (getenv("MI_GNINA_NO_SPARSE")) a.sparse = 0;
         {
           const double S3 = (double)a.S * a.S * a.S;
@@ -1265,6 +1269,8 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           a.in_argmax = argm_buf(s, slot_of(dst), count_of(dst));
         } else {
           a.in_mode = st.conv.a.relu ? 1 : 0;
+          // a gradient masked by (activation > 0) is as sparse as the ReLU'd activation: per-MFMA zero test
+          a.sparse = (a.in_mode == 1 && a.ksize == 3 && !bf16 && !getenv("MI_GNINA_NO_RELU_SKIP")) ? 2 : 0;
         }
         a.out = g_ptr(src);
         a.out_cs = m->buf_cp[src];
