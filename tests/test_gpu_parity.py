@@ -172,9 +172,11 @@ def test_ensemble_mean_and_variance(capi, CG):
         assert np.abs(p - CG[n + "/pose"]).max() < 1e-4 and np.abs(a - CG[n + "/affinity"]).max() < 1e-4
 
 
-def test_chunking_and_batch_independence(capi, CG):
-    """A pose's score must not depend on batch size / chunking (poses are independent)."""
-    name = "default2017"
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "dense"])
+def test_chunking_and_batch_independence(capi, CG, name):
+    """A pose's score must not depend on batch size / chunking (poses are independent): the latency tiles of small
+    launches and the zero-skipping K loops (first conv: per-tile quad lists; ReLU'd layers: per-MFMA tests in a fixed
+    channel-major order) give bit-identical scores."""
     from gnina_amd import synth
     blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
     rmap, lmap = oracle_maps(blob)
@@ -188,6 +190,11 @@ def test_chunking_and_batch_independence(capi, CG):
     single = s.score_batch(poses[5:6], lig_smt)
     assert np.array_equal(full["pose"], chunked["pose"]) and np.array_equal(full["affinity"], chunked["affinity"])
     assert single["pose"][0] == full["pose"][5] and single["affinity"][0] == full["affinity"][5]
+    # 605 poses: every layer runs its throughput tile (>= 512 workgroups), the 11-pose calls above their latency tiles
+    s.set_chunk(1024)
+    big = s.score_batch(np.concatenate([poses] * 55), lig_smt)
+    for k in ("pose", "affinity"):
+        assert np.array_equal(big[k].reshape(55, 11), np.tile(full[k], (55, 1)))
     # and against the oracle end to end
     grids = np.stack([voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap)[0] for b in (0, 5, 10)])
     with torch.no_grad():
