@@ -51,6 +51,14 @@ struct ConvArgs {
   int nchunks;
   int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
   int wrows;         // fp32 32x32x2 kernel: quad rows per chunk of the packed weights, 2 * (Q / 2 + 1) >= Q + 1; rows >= Q are zero
+  // N = 16 kernel (Dense-block convs) with the per-MFMA zero test: korder 1 = the K loop walks the quads channel-major
+  // (all 27 taps of a channel quad in conv_snake_tap order, then the next quad; weights packed to match) so that the four
+  // k of an instruction are four neighbouring taps of ONE channel.  The block's eval-BatchNorm is then applied as
+  // x * scale only (bn_shift = zeros: a zero activation stays an exact zero in LDS) and its shift enters through
+  // bias_tab [27][16]: bias[co] + sum over the taps INSIDE the grid and all input channels of shift[c] * W[tap][c][co],
+  // one row per border class of the output voxel (3 x 3 x 3: first / interior / last plane per axis).
+  int korder;
+  const float *bias_tab;
   // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
   // 1 = they are stacked along x (tcx % 4 == 0).  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
@@ -72,6 +80,18 @@ __device__ __forceinline__ int xcd_contiguous_id(int wg, int n) {
   return wg >= (per << 3) ? wg : (wg & 7) * per + (wg >> 3);
 }
 #endif
+
+// i-th tap (dx * 9 + dy * 3 + dz) of the boustrophedon walk of the 3 x 3 x 3 taps: consecutive taps are face neighbours
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int conv_snake_tap(int i) {
+  const int dx = i / 9;
+  int r = i - 9 * dx;
+  if (dx & 1) r = 8 - r;
+  const int dy = r / 3, k = r - 3 * dy;
+  return dx * 9 + dy * 3 + ((dy & 1) ? 2 - k : k);
+}
 
 size_t conv_lds_bytes(const ConvArgs &p);
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn);

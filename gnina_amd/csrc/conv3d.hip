@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TM>
+template <int TM, bool SKIP>
 __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   constexpr int NTHREADS = 256;
   const int tid = threadIdx.x;
@@ -549,6 +549,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   for (int q = tid; q < Q + 12; q += NTHREADS) {
     const int qq = q < Q ? q : Q - 1;
     int tap = qq / CC4, c4 = qq - tap * CC4;
+    if (p.korder) {  // channel-major, snake walk over the taps (ConvArgs::korder)
+      c4 = qq / taps;
+      tap = qq - c4 * taps;
+      if (taps == 27) tap = conv_snake_tap(tap);
+    }
     int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
     s_qoff[q] = ((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c4 * 4) * 4;
   }
@@ -636,6 +641,28 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
       e_next = lp[4 * pr + 4];
     };
     auto mfma_step = [&](const float4 *aa, const float4 &ww) {
+      if constexpr (SKIP) {
+        // per-MFMA zero test (see conv3d_mfma_kernel): one instruction = one channel at 16 voxels x four neighbouring
+        // taps (korder 1); the lane masks go straight into SGPR pairs, the branches are scalar
+        unsigned long long live[TM][4];
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live[m][j]) : "v"(ac[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int m = 0; m < TM; m++) {
+            if (live[m][j] == 0ull) continue;
+            const float a = j == 0 ? aa[m].x : j == 1 ? aa[m].y : j == 2 ? aa[m].z : aa[m].w;
+            const float wc = j == 0 ? ww.x : j == 1 ? ww.y : j == 2 ? ww.z : ww.w;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wc, acc[m], 0, 0, 0);
+          }
+        return;
+      }
 #pragma unroll
       for (int m = 0; m < TM; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m].x, ww.x, acc[m], 0, 0, 0);
 #pragma unroll
@@ -678,6 +705,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
       for (int r = 0; r < 4; r++) {
         const int vx = 2 * gcx + (kq & 1), vy = 2 * gcy + (r >> 1), vz = 2 * gcz + (r & 1);
         float v = acc[m][r] + bias;
+        if (p.bias_tab) {  // BatchNorm shift of the input, by border class of the output voxel (ConvArgs::bias_tab)
+          const int cls = ((vx == 0 ? 0 : vx == S - 1 ? 2 : 1) * 3 + (vy == 0 ? 0 : vy == S - 1 ? 2 : 1)) * 3 +
+                          (vz == 0 ? 0 : vz == S - 1 ? 2 : 1);
+          v = acc[m][r] + p.bias_tab[cls * 16 + ch];
+        }
         if (p.relu) v = fmaxf(v, 0.f);
         out_b[(((size_t)vx * S + vy) * S + vz) * p.out_cs + ch] = v;
       }
@@ -739,22 +771,22 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_N16_TM1: {
       dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
       const size_t lds = conv_lds_bytes(p);
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma16_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma16_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
+      const bool skip = p.sparse == 2;
+      static bool attr_set[4][2] = {};
+      bool &set = attr_set[cfg == CONV_CFG_N16_TM4 ? 3 : cfg == CONV_CFG_N16_TM3 ? 2 : cfg == CONV_CFG_N16_TM2 ? 1 : 0][skip];
+      auto go = [&](auto kern) {
+        if (!set) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        set = true;
+        hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+      };
       if (cfg == CONV_CFG_N16_TM4)
-        hipLaunchKernelGGL(conv3d_mfma16_kernel<4>, grid, block, lds, s, p);
+        skip ? go(conv3d_mfma16_kernel<4, true>) : go(conv3d_mfma16_kernel<4, false>);
       else if (cfg == CONV_CFG_N16_TM3)
-        hipLaunchKernelGGL(conv3d_mfma16_kernel<3>, grid, block, lds, s, p);
+        skip ? go(conv3d_mfma16_kernel<3, true>) : go(conv3d_mfma16_kernel<3, false>);
       else if (cfg == CONV_CFG_N16_TM2)
-        hipLaunchKernelGGL(conv3d_mfma16_kernel<2>, grid, block, lds, s, p);
+        skip ? go(conv3d_mfma16_kernel<2, true>) : go(conv3d_mfma16_kernel<2, false>);
       else
-        hipLaunchKernelGGL(conv3d_mfma16_kernel<1>, grid, block, lds, s, p);
+        skip ? go(conv3d_mfma16_kernel<1, true>) : go(conv3d_mfma16_kernel<1, false>);
       break;
     }
     default: break;

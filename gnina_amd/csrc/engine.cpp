@@ -225,12 +225,17 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
           wT[((size_t)t * fco + co) * fci + ci] = w[((size_t)(taps - 1 - t) * fci + ci) * fco + co];
     w = wT.data();
   }
+  // Dense-block convs (N = 16 kernel, BatchNorm on the input): channel-major K order + per-MFMA zero test, the BN shift
+  // through a border-class bias table (ConvArgs::korder / bias_tab)
+  const bool n16_skip = n16 && o.ksize == 3 && o.bn_scale_off >= 0 && !getenv("MI_GNINA_NO_RELU_SKIP");
+  a.korder = n16_skip ? 1 : 0;
   for (int ch = 0; ch < a.nchunks; ch++)
     for (int pr = 0; pr < P; pr++)
       for (int kh = 0; kh < kstep; kh++) {
         int q = kstep * pr + kh;
         if (q >= Q) continue;
         int tap = q / a.cc4, c4 = q % a.cc4;
+        if (a.korder) c4 = q / taps, tap = taps == 27 ? conv_snake_tap(q % taps) : q % taps;
         for (int j = 0; j < 4; j++) {
           int c = (ch * a.cc4 + c4) * 4 + j;
           if (c >= o.cin) continue;
@@ -243,6 +248,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   if (!backward) std::copy(m.d.data.begin() + o.b_off, m.d.data.begin() + o.b_off + o.cout, bias.begin());
   a.bias = push_dev(m, bias);
   a.bn_scale = a.bn_shift = nullptr;
+  a.bias_tab = nullptr;
   a.in_mode = 0;
   a.sparse = 0;
   a.in_argmax = nullptr;
@@ -260,6 +266,29 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     std::vector<float> sc(cin4 * 4, 0.f), sh(cin4 * 4, 0.f);
     std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
     std::copy(m.d.data.begin() + o.bn_shift_off, m.d.data.begin() + o.bn_shift_off + o.cin, sh.begin());
+    if (n16_skip) {
+      // y = sum (x * sc + sh) * W = sum (x * sc) * W + sum_{taps inside the grid} sh * W: the second sum depends on the
+      // output voxel only through which of its 27 taps fall outside the zero-padded grid (padding is 0 AFTER BatchNorm)
+      std::vector<float> tab(27 * 16, 0.f);
+      for (int cls = 0; cls < 27; cls++) {
+        const int e[3] = {cls / 9, (cls / 3) % 3, cls % 3};  // per axis: 0 first plane, 1 interior, 2 last plane
+        for (int n = 0; n < o.cout; n++) {
+          double acc = bias[n];
+          for (int t = 0; t < 27; t++) {
+            const int d[3] = {t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1};
+            bool inside = true;
+            for (int ax = 0; ax < 3; ax++)
+              if ((e[ax] == 0 && d[ax] < 0) || (e[ax] == 2 && d[ax] > 0)) inside = false;
+            if (!inside) continue;
+            for (int c = 0; c < o.cin; c++) acc += (double)sh[c] * (double)w[((size_t)t * o.cin + c) * o.cout + n];
+          }
+          tab[cls * 16 + n] = (float)acc;
+        }
+      }
+      a.bias_tab = push_dev(m, tab);
+      std::fill(sh.begin(), sh.end(), 0.f);
+      a.sparse = 2;
+    }
     a.bn_scale = push_dev(m, sc);
     a.bn_shift = push_dev(m, sh);
   }
@@ -1176,6 +1205,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         // per-MFMA zero test, no per-tile quad dropping (ConvArgs::sparse)
         if (!a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !getenv("MI_GNINA_NO_RELU_SKIP"))
           a.sparse = 2;
+        if (a.korder) a.sparse = 2;  // Dense-block conv planned with the channel-major K order: per-MFMA test on
         if (getenv("MI_GNINA_NO_SPARSE")) a.sparse = 0;
         {
           const double S3 = (double)a.S * a.S * a.S;
