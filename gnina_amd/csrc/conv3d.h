@@ -45,12 +45,14 @@ struct ConvArgs {
   // (1 = fp32, 0 = bf16; cc4 / ccs / cin4 then count OCTETS of 8 channels and wp is a packed bf16 array)
   int in_f32, out_f32, act_f32;
   int sparse;        // 1: skip channel quads that are all-zero inside a tile (first conv: pooled voxel grid; un-pooled gradients) and,
-                     // per MFMA, all-zero A operands; 2: the per-MFMA test only, every quad listed (ReLU'd activations)
+                     // per MFMA, all-zero A operands; 2: the per-MFMA test only, every quad listed (ReLU'd activations).
+                     // (0 with korder = 1 runs the K order of 2 without the test: same bits, for inputs that are not sparse enough)
   int cc4;           // channel quads per K chunk
   int ccs;           // LDS floats per halo voxel (>= 4*cc4, padded against bank conflicts)
   int nchunks;
   int cin4;          // input-channel quads actually present (the last chunk may hold fewer than cc4)
   int wrows;         // fp32 32x32x2 kernel: quad rows per chunk of the packed weights, 2 * (Q / 2 + 1) >= Q + 1; rows >= Q are zero
+  // korder 1 = the K loop walks the quads channel-major (the order of the listed / sparse K loop) instead of tap-major.
   // N = 16 kernel (Dense-block convs) with the per-MFMA zero test: korder 1 = the K loop walks the quads channel-major
   // (all 27 taps of a channel quad in conv_snake_tap order, then the next quad; weights packed to match) so that the four
   // k of an instruction are four neighbouring taps of ONE channel.  The block's eval-BatchNorm is then applied as
@@ -103,6 +105,7 @@ void launch_gmax_bf16(const void *in, float *out, int B, int C, int in_cs, int o
 void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
                                int S, hipStream_t s);
 
+void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s);
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);
 void launch_pool_cl(const float *in, float *out, int B, int C, int in_cs, int out_cs, int S, int mode,
                     hipStream_t s);

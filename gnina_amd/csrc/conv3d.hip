@@ -36,8 +36,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // (second launch bound = waves per SIMD the register allocation must leave room for: the two-accumulator shapes run
 // four workgroups per CU, i.e. <= 128 VGPRs; the TM = 7 shape two)
-template <int WM, int WN, int TM, int TN, bool SPARSE, bool MTX>
+// SP: 0 dense K loop (every quad, order by ConvArgs::korder); 1 K loop over the per-chunk list of surviving quads
+// (channel-major) with the per-MFMA zero test
+template <int WM, int WN, int TM, int TN, int SP, bool MTX>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 : 1)) void conv3d_mfma_kernel(ConvArgs p) {
+  constexpr bool SPARSE = SP != 0;
   constexpr int NWAVES = WM * WN;
   constexpr int NTHREADS = 64 * NWAVES;
   const int tid = threadIdx.x;
@@ -86,8 +89,16 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
   for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = (SPARSE && p.sparse == 2 && i < p.cin4) ? 1 : 0;
   // Row Q of every chunk's packed weights is all zero (ConvArgs::wrows): the list entry behind the last quad points
   // there, so an odd number of quads needs no special case in the K loop (the idle half-wave multiplies by zeros).
-  if (!SPARSE)  // dense: quad q multiplies weight row q
-    for (int q = tid; q < Q + 5; q += NTHREADS) s_list[q] = list_entry(q < Q ? q : Q - 1, q < Q ? q : Q);
+  if (!SPARSE)  // dense: every quad, tap-major -- or (korder 1) in the channel-major order of the listed K loop, so that a
+                // layer gives the same bits with and without the per-MFMA test (ConvArgs::korder)
+    for (int q = tid; q < Q + 5; q += NTHREADS) {
+      int qq = q < Q ? q : Q - 1;
+      if (p.korder) {
+        const int c4 = qq / taps, i = qq - c4 * taps;
+        qq = (taps == 27 ? conv_snake_tap(i) : i) * CC4 + c4;
+      }
+      s_list[q] = list_entry(qq, q < Q ? qq : Q);
+    }
 
   // A-row geometry of this lane for each of its M-tiles
   const int NC = p.tcx * p.tcy * p.tcz;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
       e_next = lp[2 * pr + 2];
     };
     auto mfma_pair = [&](const float4 *aa, const float4 *ww) {
-      if constexpr (SPARSE) {
+      if constexpr (SP == 1) {
         // Third level of zero-skipping (sparse inputs only), per MFMA: the A operand of one instruction is ONE input
         // channel at 32 voxels x the pair's two taps.  If it is zero in every lane the instruction would add exact
         // zeros to the accumulators and is skipped (results bit-identical to executing it).  The channels of the
@@ -345,27 +356,31 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 
         // v_cmp_class -> vcc -> s_cbranch_vccz, one VALU-to-branch round trip per MFMA, and a ballot of that into
         // v_cndmask + v_cmp), then the branches are scalar compares that run beside the other waves' MFMAs.  The
         // instructions of the two M-tiles alternate, so two dependent MFMAs are never adjacent.
-        unsigned long long live[TM][4];
-#pragma unroll
-        for (int m = 0; m < TM; m++) {
-          const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
-#pragma unroll
-          for (int j = 0; j < 4; j++) asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live[m][j]) : "v"(ac[j]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
+        {
+          unsigned long long live[TM][4];
 #pragma unroll
           for (int m = 0; m < TM; m++) {
-            if (live[m][j] == 0ull) continue;
-            const float a = j == 0 ? aa[m].x : j == 1 ? aa[m].y : j == 2 ? aa[m].z : aa[m].w;
+            const float ac[4] = {aa[m].x, aa[m].y, aa[m].z, aa[m].w};
 #pragma unroll
-            for (int n = 0; n < TN; n++) {
-              const float wc = j == 0 ? ww[n].x : j == 1 ? ww[n].y : j == 2 ? ww[n].z : ww[n].w;
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wc, acc[m][n], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; j++) asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live[m][j]) : "v"(ac[j]));
           }
-      } else {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int m = 0; m < TM; m++) {
+              if (live[m][j] == 0ull) continue;
+              const float a = j == 0 ? aa[m].x : j == 1 ? aa[m].y : j == 2 ? aa[m].z : aa[m].w;
+#pragma unroll
+              for (int n = 0; n < TN; n++) {
+                const float wc = j == 0 ? ww[n].x : j == 1 ? ww[n].y : j == 2 ? ww[n].z : ww[n].w;
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wc, acc[m][n], 0, 0, 0);
+              }
+            }
+          return;
+        }
+      }
+      {
 #pragma unroll
         for (int m = 0; m < TM; m++)
 #pragma unroll
@@ -727,17 +742,17 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }
 
-template <int WM, int WN, int TM, int TN, bool SPARSE, bool MTX> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int SP, bool MTX> static void launch_one(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE, MTX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SP, MTX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SPARSE, MTX>), grid, block, lds, s, p);
+  hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SP, MTX>), grid, block, lds, s, p);
 }
 
 // MTX (ConvArgs::mt_x, M-tiles stacked along x) is compiled only where the engine asks for it (the 4x1/2x1 first-conv
@@ -746,15 +761,15 @@ template <int WM, int WN, int TM, int TN, bool MTX_OK = false> static void launc
   if (p.mt_x && !MTX_OK) throw std::runtime_error("launch_conv: mt_x is not compiled for this tile configuration");
   if (MTX_OK && p.mt_x) {
     if (p.sparse)
-      launch_one<WM, WN, TM, TN, true, MTX_OK>(p, B, s);
+      launch_one<WM, WN, TM, TN, 1, MTX_OK>(p, B, s);
     else
-      launch_one<WM, WN, TM, TN, false, MTX_OK>(p, B, s);
+      launch_one<WM, WN, TM, TN, 0, MTX_OK>(p, B, s);
     return;
   }
   if (p.sparse)
-    launch_one<WM, WN, TM, TN, true, false>(p, B, s);
+    launch_one<WM, WN, TM, TN, 1, false>(p, B, s);
   else
-    launch_one<WM, WN, TM, TN, false, false>(p, B, s);
+    launch_one<WM, WN, TM, TN, 0, false>(p, B, s);
 }
 
 void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
@@ -843,6 +858,45 @@ __global__ void pool_input_ncdhw_kernel(const float *in, float *out, int C, int 
     res = mode == 1 ? acc : acc * 0.125f;
   }
   out[i] = res;
+}
+
+// How sparse is a channels-last activation tensor [B][S]^3[cs]?  out[0] += (2x2x2 cell, channel) groups that are
+// all-zero, out[1] += groups looked at.  The engine asks once per ReLU'd conv layer (first launch of >= 32 poses) and
+// keeps the per-MFMA zero test on that layer only if it pays (ConvArgs::sparse 2 vs 3).
+__global__ __launch_bounds__(256) void zero_cell_probe_kernel(const float *in, long n_items, int S, int cs, int C4, unsigned *out) {
+  const long it = (long)blockIdx.x * 256 + threadIdx.x;
+  unsigned zeros = 0, groups = 0;
+  if (it < n_items) {
+    const int q = (int)(it % C4);
+    long cell = it / C4;
+    const int H = S / 2;
+    const int cz = (int)(cell % H);
+    cell /= H;
+    const int cy = (int)(cell % H);
+    cell /= H;
+    const int cx = (int)(cell % H);
+    const long b = cell / H;
+    unsigned o[4] = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < 8; r++) {
+      const int x = 2 * cx + (r >> 2), y = 2 * cy + ((r >> 1) & 1), z = 2 * cz + (r & 1);
+      const float4 v = *reinterpret_cast<const float4 *>(in + (((b * S + x) * S + y) * S + z) * cs + q * 4);
+      o[0] |= __float_as_uint(v.x), o[1] |= __float_as_uint(v.y), o[2] |= __float_as_uint(v.z), o[3] |= __float_as_uint(v.w);
+    }
+    for (int j = 0; j < 4; j++) zeros += o[j] == 0u;
+    groups = 4;
+  }
+  for (int d = 32; d; d >>= 1) zeros += __shfl_down(zeros, d), groups += __shfl_down(groups, d);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, zeros);
+    atomicAdd(out + 1, groups);
+  }
+}
+
+void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s) {
+  const int C4 = C / 4;  // whole quads only (padding channels are zero by construction)
+  const long n = (long)B * (S / 2) * (S / 2) * (S / 2) * C4;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(zero_cell_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, S, cs, C4, out);
 }
 
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s) {

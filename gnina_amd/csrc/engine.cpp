@@ -83,6 +83,10 @@ struct Step {
   int n_in = 0;
   int post_cout = 0;      // Conv with a fused 1x1x1 conv behind it: that conv's output channels
   bool src_bf16 = false;  // bf16 program: GMax reads a bf16 tensor
+  // ReLU'd conv layer: is its input sparse enough for the per-MFMA zero test to pay?  0 = not measured yet, 1 = yes,
+  // 2 = no.  Measured once, on the first launch of >= 32 poses (launch_zero_cell_probe); either answer gives the same
+  // bits (ConvArgs::sparse 2 / 3), so the plain int shared by the scorers of a model is a benign race.
+  mutable int relu_skip = 0;
 };
 
 struct Model {
@@ -703,6 +707,7 @@ struct Scorer {
   std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
   std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
   DevBuf<float> d_raw3, d_lig_grad, d_ave;
+  DevBuf<unsigned> d_probe;             // zero-cell counters of launch_zero_cell_probe
   int lig_cache_group = -1, lig_cache_n = 0;  // setup_ligand cache: group / ligand types the device arrays describe
   std::vector<int32_t> lig_cache_smt;
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
@@ -1203,9 +1208,21 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         a.sparse = (st.conv.src == m->input_dst && !st.has_bn && !bf16) ? 1 : 0;  // the pooled voxel grid is ~12 % dense
         // ReLU'd activations (Default2017 / Default2018 convs behind the first one): channel-major K order with the
         // per-MFMA zero test, no per-tile quad dropping (ConvArgs::sparse)
-        if (!a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !getenv("MI_GNINA_NO_RELU_SKIP"))
-          a.sparse = 2;
-        if (a.korder) a.sparse = 2;  // Dense-block conv planned with the channel-major K order: per-MFMA test on
+        if (!a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !getenv("MI_GNINA_NO_RELU_SKIP")) {
+          if (st.relu_skip == 0 && nb >= 32) {
+            s.d_probe.ensure(2);
+            MIG_HIP(hipMemsetAsync(s.d_probe.p, 0, 2 * sizeof(unsigned), s.stream));
+            launch_zero_cell_probe(a.in, 32, st.conv.cin, a.in_cs, a.S, s.d_probe.p, s.stream);
+            unsigned cnt[2] = {0u, 0u};
+            MIG_HIP(hipMemcpyAsync(cnt, s.d_probe.p, sizeof cnt, hipMemcpyDeviceToHost, s.stream));
+            MIG_HIP(hipStreamSynchronize(s.stream));
+            // measured break-even: Default2017 (cells 50 % zero) gains 25 %, Default2018 (13-20 %) loses 1-2 %
+            st.relu_skip = (cnt[1] && (double)cnt[0] >= 0.30 * (double)cnt[1]) ? 1 : 2;
+          }
+          a.korder = 1;  // either way the channel-major K order: same bits with and without the test
+          a.sparse = st.relu_skip == 2 ? 0 : 2;
+        }
+        if (st.conv.a.korder) a.sparse = 2;  // Dense-block conv planned with the channel-major K order: per-MFMA test on
         if (getenv("MI_GNINA_NO_SPARSE")) a.sparse = 0;
         {
           const double S3 = (double)a.S * a.S * a.S;
