@@ -349,3 +349,24 @@ def test_rotated_scoring_equals_scoring_the_rotated_complex(capi, CG):
     with pytest.raises(capi.MiGninaError):
         s.score_batch(poses, lig_smt)                                  # pose count mismatch
     assert np.allclose(s.score_batch(poses, lig_smt, centers=centers)["pose"], plain["pose"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "dense"])
+def test_zero_skipping_k_order_against_the_plain_order(capi, name, monkeypatch):
+    """The per-MFMA zero test runs the K loop channel-major (and, for the Dense blocks, takes the BatchNorm shift out of
+    the loop into a border-class bias table): same sums, re-associated.  MI_GNINA_NO_RELU_SKIP=1 is the plain tap-major
+    path of round 1; the two must agree to rounding."""
+    from gnina_amd import synth
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rec_xyz, rec_smt, lig_smt, poses = synth.make_complex(7, synth.mapped_types(rmap[0]),
+                                                          synth.mapped_types(lmap[0]), 1500, 24, 40)
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    new = s.score_batch(poses, lig_smt)
+    monkeypatch.setenv("MI_GNINA_NO_RELU_SKIP", "1")
+    s0 = capi.Scorer([name])          # a fresh model: the Dense-block plan reads the switch when it packs its weights
+    s0.set_receptor(rec_xyz, rec_smt)
+    old = s0.score_batch(poses, lig_smt)
+    assert np.abs(new["pose"] - old["pose"]).max() < 5e-6
+    assert np.abs(new["affinity"] - old["affinity"]).max() < 2e-5
