@@ -30,6 +30,8 @@
 //    bit-identical to the sqrtf-based reference arithmetic.
 #include "voxelize.h"
 
+#include <cstdlib>
+
 #include "conv3d.h"  // xcd_contiguous_id
 
 namespace mig {
@@ -229,7 +231,7 @@ __device__ __forceinline__ float density(float rsq, float t2, float g2, float ke
 }
 
 template <int MODE>  // 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last
-__global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
+__global__ __launch_bounds__(64, 7) void voxelize_tiles(VoxArgs v) {
   const int lane = threadIdx.x;
   const int ntile = v.tiles_per_axis;
   // 1-D grid of B * tiles workgroups, re-numbered so that an XCD (private L2) sees whole poses: the 216 tile
@@ -245,10 +247,17 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   // the accumulators change hands through a 2 KB LDS transpose per flushed channel (s_tr).
   const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
 
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // MODE != 0: [64][Cp] (+ arg-max bytes)
+  // MODE != 0: the pooled tile is staged for 16-byte stores one WINDOW of kWin channels at a time ([64 cells][kWin]); the
+  // candidate list is sorted by channel, so a window is complete when the first atom of a later window arrives.  (The
+  // whole [64][Cp] tile was 9 KB: 14 single-wave workgroups per CU.  The kernel is latency-bound -- its time is inversely
+  // proportional to the waves in flight, measured by padding the LDS request -- and 5 KB lets the 68-VGPR limit of 7
+  // waves per SIMD decide.)
+  constexpr int kWin = 12;
+  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [64][kWin] (+ transpose buffer, arg-max bytes)
   const int Cp = v.Cp;
-  float *s_tr = s_stage + 64 * Cp;                                              // [64 lanes][8 sub-blocks]
-  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + 512);         // [64][Cp], only if argmax_out
+  const int nwin = (Cp + kWin - 1) / kWin;
+  float *s_tr = s_stage + 64 * kWin;                                            // [64 lanes][8 sub-blocks]
+  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + 512);         // [64][kWin], only if argmax_out
   // where the r-th voxel (x*4 + y*2 + z) of this lane's pooling cell sits in s_tr
   int taddr[8];
 #pragma unroll
@@ -256,11 +265,14 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
     const int x = 2 * (lane >> 4) + (r >> 2), y = 2 * ((lane >> 2) & 3) + ((r >> 1) & 1), z = 2 * (lane & 3) + (r & 1);
     taddr[r] = ((x & 3) + 4 * (y & 3) + 16 * (z & 3)) * 8 + (x >> 2) * 4 + (y >> 2) * 2 + (z >> 2);
   }
-  if (MODE != 0) {
-    for (int i = lane; i < 64 * Cp; i += 64) s_stage[i] = 0.f;
+  auto clear_window = [&]() {
+#pragma unroll
+    for (int k = 0; k < kWin / 4; k++) *reinterpret_cast<float4 *>(s_stage + (lane * (kWin / 4) + k) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 1 && v.argmax_out)
-      for (int i = lane; i < 16 * Cp; i += 64) reinterpret_cast<unsigned *>(s_arg)[i] = 0u;
-  }
+#pragma unroll
+      for (int k = 0; k < kWin / 4; k++) reinterpret_cast<unsigned *>(s_arg)[lane * (kWin / 4) + k] = 0u;
+  };
+  if (MODE != 0) clear_window();
 
   const float ctrx = v.centers[3 * b + 0], ctry = v.centers[3 * b + 1], ctrz = v.centers[3 * b + 2];
   const float ox = ctrx - v.half_dim, oy = ctry - v.half_dim, oz = ctrz - v.half_dim;
@@ -287,6 +299,30 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   for (int i = 0; i < 8; i++) acc[i] = 0.f;
   int cur = -1;
 
+  int cur_w = 0;
+  // window cur_w of the staged tile -> out[b][cx][cy][cz][cur_w * kWin ...]: 64 cells x kWin / 4 float4, then cleared
+  auto emit_window = [&]() {
+    __builtin_amdgcn_s_waitcnt(0);  // wave-synchronous: the LDS writes of flush() complete before the reads
+    __builtin_amdgcn_wave_barrier();
+    const int S = v.N / 2;
+    const int c0 = cur_w * kWin;
+#pragma unroll
+    for (int k = 0; k < kWin / 4; k++) {
+      const int i = lane + 64 * k;
+      const int cell = i / (kWin / 4), part = i - cell * (kWin / 4);  // cell = cx * 16 + cy * 4 + cz, like the owner lane
+      const int rx = tx * 4 + (cell >> 4), ry = ty * 4 + ((cell >> 2) & 3), rz = tz * 4 + (cell & 3);
+      if (rx < S && ry < S && rz < S && c0 + 4 * part < Cp) {
+        const size_t o = ((((size_t)b * S + rx) * S + ry) * S + rz) * Cp + c0 + 4 * part;
+        *reinterpret_cast<float4 *>(v.out + o) = *reinterpret_cast<const float4 *>(s_stage + cell * kWin + 4 * part);
+        if (MODE == 1 && v.argmax_out)
+          *reinterpret_cast<unsigned *>(v.argmax_out + o) = *reinterpret_cast<const unsigned *>(s_arg + cell * kWin + 4 * part);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    clear_window();
+    cur_w++;
+  };
   auto flush = [&](int c) {
     if (c < 0) return;
     if (MODE == 0) {
@@ -321,13 +357,15 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
           m = cv[i];
           am = i;
         }
-      s_stage[lane * Cp + c] = m;
-      if (v.argmax_out) s_arg[lane * Cp + c] = (unsigned char)am;
+      while (cur_w < c / kWin) emit_window();
+      s_stage[lane * kWin + (c - cur_w * kWin)] = m;
+      if (v.argmax_out) s_arg[lane * kWin + (c - cur_w * kWin)] = (unsigned char)am;
     } else {
       float s = cv[0];
 #pragma unroll
       for (int i = 1; i < 8; i++) s = s + cv[i];  // (kd,kh,kw) order, then /8 like avg_pool3d
-      s_stage[lane * Cp + c] = s * 0.125f;
+      while (cur_w < c / kWin) emit_window();
+      s_stage[lane * kWin + (c - cur_w * kWin)] = s * 0.125f;
     }
   };
 
@@ -386,28 +424,8 @@ __global__ __launch_bounds__(64) void voxelize_tiles(VoxArgs v) {
   }
   flush(cur);
 
-  if (MODE != 0) {
-    // staged tile [4][4][4][Cp] -> out[b][cx][cy][cz][Cp]: 16 (x,y) rows of 4*Cp contiguous floats
-    __builtin_amdgcn_s_waitcnt(0);  // wave-synchronous: LDS writes above complete before reads
-    __builtin_amdgcn_wave_barrier();
-    const int S = v.N / 2;
-    const int row_f4 = Cp;  // float4 per row = 4*Cp/4
-    for (int i = lane; i < 16 * row_f4; i += 64) {
-      int row = i / row_f4, w = i - row * row_f4;
-      int rx = tx * 4 + (row >> 2), ry = ty * 4 + (row & 3), rz0 = tz * 4;
-      int zc = (4 * w) / Cp;  // which z cell this float4 starts in
-      if (rx < S && ry < S && rz0 + zc < S) {
-        float4 val = *reinterpret_cast<const float4 *>(&s_stage[(row * 4) * Cp + 4 * w]);
-        float *dst = v.out + ((((size_t)b * S + rx) * S + ry) * S + rz0) * Cp + 4 * w;
-        *reinterpret_cast<float4 *>(dst) = val;
-        if (MODE == 1 && v.argmax_out) {
-          const unsigned word = *reinterpret_cast<const unsigned *>(&s_arg[(row * 4) * Cp + 4 * w]);
-          unsigned char *ad = v.argmax_out + ((((size_t)b * S + rx) * S + ry) * S + rz0) * Cp + 4 * w;
-          *reinterpret_cast<unsigned *>(ad) = word;
-        }
-      }
-    }
-  }
+  if (MODE != 0)
+    while (cur_w < nwin) emit_window();  // the last window, and windows no atom of this tile belongs to (zeros)
 }
 
 
@@ -522,7 +540,8 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
-    size_t lds = (size_t)64 * v.Cp * sizeof(float) + 512 * sizeof(float) + (v.argmax_out ? (size_t)64 * v.Cp : 0);
+    size_t lds = (size_t)64 * 12 * sizeof(float) + 512 * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
+    if (getenv("MI_VOX_LDS_PAD")) lds += (size_t)atoi(getenv("MI_VOX_LDS_PAD")) * 1024;  // occupancy experiment
     if (mode == 1)
       hipLaunchKernelGGL(voxelize_tiles<1>, grid, block, lds, s, v);
     else
