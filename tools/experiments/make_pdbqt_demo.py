@@ -1,4 +1,4 @@
-"""Writes a synthetic rigid receptor and a small ligand as .pdbqt files (tools/scratch/_gen/, git-ignored) so that
+"""Writes a synthetic rigid receptor and a small ligand as .pdbqt files (tools/experiments/_gen/, git-ignored) so that
 tools/dock_demo.py --receptor/--ligand/--out can be exercised on a GPU box without any reference data."""
 import os
 import sys

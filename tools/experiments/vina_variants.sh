@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build libmi_gnina variants with different -D switches for vina.hip (A/B latency experiments).
-# usage: tools/scratch/vina_variants.sh name1:"-DFOO=1 -DBAR=0" name2:"..."   -> gnina_amd/lib/variants/libmi_<name>.so
+# usage: tools/experiments/vina_variants.sh name1:"-DFOO=1 -DBAR=0" name2:"..."   -> gnina_amd/lib/variants/libmi_<name>.so
 set -e
 cd "$(dirname "$0")/../.."
 python -c "from gnina_amd import build; build.build()"
