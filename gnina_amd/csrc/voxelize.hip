@@ -40,6 +40,16 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// The candidate lists seen through the CONSTANT address space: they were written by gather_pose_atoms, an earlier
+// launch, so inside voxelize_tiles they are read-only -- which the compiler cannot prove for a plain pointer (the output
+// might alias it).  A uniform-address load through these pointers is an s_load into SGPRs (scalar data cache): the
+// record of a hit then costs no VGPRs (nine v_readlane from a per-lane copy otherwise, which has to stay live through the
+// hit loop -- the difference between 72 and 64 VGPRs, i.e. 7 and 8 waves per SIMD).
+static_assert(sizeof(AtomRec) == 32, "AtomRec is read as one 8-dword scalar load");
+typedef float f32x8 __attribute__((ext_vector_type(8)));  // one AtomRec: x y z ar t2 g2 kexp inv_ar
+typedef const __attribute__((address_space(4))) f32x8 *ConstRecPtr;
+typedef const __attribute__((address_space(4))) int *ConstIntPtr;
+
 // Rotation of libmolgrid's Transform (rotate about the grid centre, no translation): rows of R(q) for a unit
 // quaternion q = a + bi + cj + dk.
 struct Rot3 {
@@ -231,7 +241,7 @@ __device__ __forceinline__ float density(float rsq, float t2, float g2, float ke
 }
 
 template <int MODE>  // 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last
-__global__ __launch_bounds__(64, 7) void voxelize_tiles(VoxArgs v) {
+__global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   const int lane = threadIdx.x;
   const int ntile = v.tiles_per_axis;
   // 1-D grid of B * tiles workgroups, re-numbered so that an XCD (private L2) sees whole poses: the 216 tile
@@ -293,6 +303,8 @@ __global__ __launch_bounds__(64, 7) void voxelize_tiles(VoxArgs v) {
   const AtomRec *cand = v.cand + ((size_t)b * v.n_slab + slab) * v.cap;
   const int *cand_chan = v.cand_chan + ((size_t)b * v.n_slab + slab) * v.cap;
   const int n = v.cand_n[(size_t)b * v.n_slab + slab];
+  const ConstRecPtr candc = (ConstRecPtr)(const void *)cand;
+  const ConstIntPtr chanc = (ConstIntPtr)(const void *)cand_chan;
 
   float acc[8];
 #pragma unroll
@@ -371,15 +383,9 @@ __global__ __launch_bounds__(64, 7) void voxelize_tiles(VoxArgs v) {
 
   for (int base = 0; base < n; base += 64) {
     const int idx = base + lane;
-    AtomRec a;
-    a.x = a.y = a.z = 0.f;
-    a.ar = 1.f;
-    a.t2 = a.g2 = a.kexp = a.inv_ar = 0.f;
-    int ch = -1;
     bool hit = false;
     if (idx < n) {
-      a = cand[idx];
-      ch = cand_chan[idx];
+      const AtomRec a = cand[idx];
       float ddx = fmaxf(0.f, fmaxf(tlox - a.x, a.x - thix));
       float ddy = fmaxf(0.f, fmaxf(tloy - a.y, a.y - thiy));
       float ddz = fmaxf(0.f, fmaxf(tloz - a.z, a.z - thiz));
@@ -387,13 +393,26 @@ __global__ __launch_bounds__(64, 7) void voxelize_tiles(VoxArgs v) {
       hit = d2 <= a.t2 * 1.0001f + 1e-4f;  // conservative superset of "some voxel has rsq < t2"
     }
     unsigned long long mask = __ballot(hit);
-    while (mask) {
+    // the record of a hit comes back through the scalar cache, the next hit's record is requested before this one is
+    // evaluated
+    f32x8 rec_n = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+    int c_n = -1;
+    if (mask) {
       const int src = __builtin_ctzll(mask);
+      rec_n = candc[base + src];
+      c_n = chanc[base + src];
+    }
+    while (mask) {
       mask &= mask - 1;
-      const float ax = rl_f(a.x, src), ay = rl_f(a.y, src), az = rl_f(a.z, src);
-      const float t2 = rl_f(a.t2, src), g2 = rl_f(a.g2, src), kexp = rl_f(a.kexp, src);
-      const float inv_ar = rl_f(a.inv_ar, src), ar = rl_f(a.ar, src);
-      const int c = __builtin_amdgcn_readlane(ch, src);
+      const f32x8 rec = rec_n;
+      const int c = c_n;
+      if (mask) {
+        const int src = __builtin_ctzll(mask);
+        rec_n = candc[base + src];
+        c_n = chanc[base + src];
+      }
+      const float ax = rec[0], ay = rec[1], az = rec[2], ar = rec[3], t2 = rec[4], g2 = rec[5], kexp = rec[6],
+                  inv_ar = rec[7];
       if (c != cur) {
         flush(cur);
         cur = c;

@@ -1,6 +1,6 @@
-# usage: run_env.sh "<ENV=1 ...>" [bench args]   -- one bench line summary per env setting
+# usage: run_env.sh "ENV=1 [ENV2=..]" ...   -- one bench.py summary line per environment setting (BENCH_ARGS adds flags)
 for e in "$@"; do
-  env $e python bench.py --no-configs --no-cpu-baseline --steps 20 > gpurun_out/env.json 2>gpurun_out/env.err
+  env $e python bench.py --no-configs --no-cpu-baseline --steps 20 $BENCH_ARGS > gpurun_out/env.json 2>gpurun_out/env.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/env.json").read().strip().splitlines()[-1])
