@@ -200,6 +200,8 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   size_t budget = 40 * 1024;
   if (!sparse_budget && getenv("MI_GNINA_LDS_KB") && atoi(getenv("MI_GNINA_LDS_KB")) > 0)
     budget = (size_t)atoi(getenv("MI_GNINA_LDS_KB")) * 1024;
+  if (sparse_budget && getenv("MI_GNINA_SPARSE_LDS_KB") && atoi(getenv("MI_GNINA_SPARSE_LDS_KB")) > 0)
+    budget = (size_t)atoi(getenv("MI_GNINA_SPARSE_LDS_KB")) * 1024;
   int best = 1;
   for (int c = 1; c <= cin4; c++) {
     if (!sparse_budget && cin4 % c) continue;  // dense layers: equal chunks only (no wasted MFMAs)
