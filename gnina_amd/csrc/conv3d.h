@@ -68,7 +68,7 @@ struct ConvArgs {
   int mt_x;
 };
 
-enum { CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
+enum { CONV_CFG_4x1_1x3 = 1 /* 1x1 96 -> 96 with one M-tile per wave: <= 128 VGPRs, four waves per SIMD */, CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
        CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6, CONV_CFG_2x2_3x1 = 7,
        CONV_CFG_4x1_1x1 = 8, CONV_CFG_N16_TM1 = 9, CONV_CFG_N16_TM2 = 10 /* latency variants: one M-tile per wave */ };
 

@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // SP: 0 dense K loop (every quad, order by ConvArgs::korder); 1 K loop over the per-chunk list of surviving quads
 // (channel-major) with the per-MFMA zero test
 template <int WM, int WN, int TM, int TN, int SP, bool MTX>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 4 : TM * TN <= 7 ? 2 : 1)) void conv3d_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3)) ? 4 : TM * TN <= 7 ? 2 : 1)) void conv3d_mfma_kernel(ConvArgs p) {
   constexpr bool SPARSE = SP != 0;
   constexpr int NWAVES = WM * WN;
   constexpr int NTHREADS = 64 * NWAVES;
@@ -777,6 +777,7 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_2x1: launch_cfg<4, 1, 2, 1, true>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_cfg<1, 4, 7, 1>(p, B, s); break;
     case CONV_CFG_4x1_2x3: launch_cfg<4, 1, 2, 3>(p, B, s); break;
+    case CONV_CFG_4x1_1x3: launch_cfg<4, 1, 1, 3>(p, B, s); break;
     case CONV_CFG_2x2_3x1: launch_cfg<2, 2, 3, 1>(p, B, s); break;
     case CONV_CFG_4x1_1x1: launch_cfg<4, 1, 1, 1>(p, B, s); break;
     case CONV_CFG_4x1_1x5: launch_cfg<4, 1, 1, 5>(p, B, s); break;
@@ -812,6 +813,7 @@ void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
     case CONV_CFG_4x1_2x3: *wm = 4, *wn = 1, *tm = 2, *tn = 3; break;
+    case CONV_CFG_4x1_1x3: *wm = 4, *wn = 1, *tm = 1, *tn = 3; break;
     case CONV_CFG_2x2_3x1: *wm = 2, *wn = 2, *tm = 3, *tn = 1; break;
     case CONV_CFG_4x1_1x1: *wm = 4, *wn = 1, *tm = 1, *tn = 1; break;
     case CONV_CFG_N16_TM1: *wm = 4, *wn = 1, *tm = 1, *tn = 1; break;
