@@ -370,3 +370,43 @@ def test_zero_skipping_k_order_against_the_plain_order(capi, name, monkeypatch):
     old = s0.score_batch(poses, lig_smt)
     assert np.abs(new["pose"] - old["pose"]).max() < 5e-6
     assert np.abs(new["affinity"] - old["affinity"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018", "dense"])
+def test_scores_on_nearly_empty_grids(capi, name):
+    """Edge cases of the zero-skipping paths: a ligand 60 A away from the receptor (only ligand channels populated: most
+    channel quads of most tiles empty, whole staging windows of the voxelizer written as zeros), a ligand with no typed
+    atom (receptor channels only), and a single typed atom next to the box corner."""
+    from gnina_amd import synth
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    rmap, lmap = oracle_maps(blob)
+    rng = np.random.RandomState(11)
+    rec_xyz, rec_smt = synth.make_receptor(rng, 1200, synth.mapped_types(rmap[0]))
+    lig_types = synth.mapped_types(lmap[0])
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    L = 12
+    lig_smt = rng.choice(lig_types, L).astype(np.int32)
+    base = rng.normal(0, 2.0, (L, 3)).astype(np.float32)
+    far = base + np.array([60.0, -45.0, 30.0], dtype=np.float32)
+    cases = [(far, lig_smt), (base, np.zeros(L, dtype=np.int32) + 0)]
+    untyped = [t for t in range(28) if lmap[0][t] < 0]
+    if untyped:
+        cases[1] = (base, np.full(L, untyped[0], dtype=np.int32))
+    one = base.copy()
+    one_smt = np.full(L, untyped[0] if untyped else lig_smt[0], dtype=np.int32)
+    one_smt[0] = lig_smt[0]
+    cases.append((one, one_smt))
+    for xyz, smt in cases:
+        got = s.score_batch(xyz[None], smt)
+        grid, _ = voxel.voxelize_pose(rec_xyz, rec_smt, xyz, smt, rmap, lmap)
+        with torch.no_grad():
+            p, a, _ = cnn_ref.scores(blob, grid[None])
+        assert abs(float(got["pose"][0]) - float(p[0])) < 1e-4
+        assert abs(float(got["affinity"][0]) - float(a[0])) < 1e-4
+    # the same three poses inside one large launch (throughput tiles, sparsity probe has run): identical bits
+    xyz3 = np.stack([c[0] for c in cases])
+    big_smt = cases[0][1]
+    alone = s.score_batch(xyz3[:1], big_smt)
+    many = s.score_batch(np.concatenate([xyz3[:1]] * 600), big_smt)
+    assert np.all(many["pose"] == alone["pose"][0]) and np.all(many["affinity"] == alone["affinity"][0])
