@@ -45,7 +45,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   constexpr int NTHREADS = 64 * NWAVES;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  // (readfirstlane: the wave index is uniform, which the compiler cannot see through threadIdx -- with it the M-tile /
+  // cell arithmetic below, divisions by run-time tile dimensions included, runs on the scalar unit)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int kh = lane >> 5;   // which k of the 32x32x2 MFMA this lane feeds
   const int row = lane & 31;  // A row / B column
@@ -135,8 +137,12 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
   // halo position -> voxel, once per workgroup: the per-chunk staging loops then run without integer divisions
+  // hv / HZ and (hv / HZ) / HY by multiply-shift (exact for hv < 2^20 / 16; HV is a few hundred): a generic 32-bit
+  // division is ~25 VALU instructions, and this loop runs them per halo voxel
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
   for (int hv = tid; hv < HV; hv += NTHREADS) {
-    const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+    const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
     const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
     const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
     int v = -1;
