@@ -486,6 +486,18 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
         const int ch = n_base + n * 32 + row;
         if (ch >= p.cout) continue;
         const float bias = bias_ptr[ch];
+        if (p.pool == 1 && !p.argmax_out) {
+          // forward-only max pool: rounding and ReLU are monotonic, so max_r relu(fl(acc_r + b)) = relu(fl(max_r acc_r + b))
+          // exactly -- 6 VALU instructions per cell instead of 37 (the arg-max bookkeeping is for the gradient pass only)
+          const f32x16 &ac = acc[m][n];
+          const int h8 = half * 8;
+          float mx = fmaxf(fmaxf(fmaxf(ac[h8 + 0], ac[h8 + 1]), fmaxf(ac[h8 + 2], ac[h8 + 3])),
+                           fmaxf(fmaxf(ac[h8 + 4], ac[h8 + 5]), fmaxf(ac[h8 + 6], ac[h8 + 7])));
+          mx = mx + bias;
+          if (relu_flag) mx = fmaxf(mx, 0.f);
+          out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = mx;
+          continue;
+        }
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
