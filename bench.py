@@ -400,6 +400,12 @@ def main():
         avg_ms = dom_conv["ms_total"] / dom_conv["launches"]
         achieved = dom_conv["flops"] / dom_conv["launches"] / (avg_ms * 1e-3) / 1e12
         total_kernel_ms = sum(r["ms_total"] for r in prof) / args.steps
+        if dom_conv.get("mfma_counted_launches"):
+            exec_flops = 4096.0 * dom_conv["mfma_executed"] / dom_conv["mfma_counted_launches"]
+            exec_src = "device counters of this run (mi_scorer_enable_profile)"
+        else:  # a library without the counters: fall back to the committed rocprofv3 PMC summary
+            exec_flops = (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch")
+            exec_src = "profiles/latest_pmc.json (SQ_INSTS_VALU_MFMA_MOPS_F32)"
         vox = [r for r in prof if r["kernel"].startswith("voxelize")][0]
         vox_ms = vox["ms_total"] / vox["launches"]
         res = {
@@ -436,10 +442,12 @@ def main():
                 "note": "achieved = ALGORITHMIC (dense) FLOPs / launch time; the kernel skips channel quads that are "
                         "all-zero inside a tile (exact-zero products; the rest keep their order), so the MFMA pipe executes fewer: see "
                         "mfma_executed_*",
-                "mfma_executed_flops_per_launch": (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch"),
-                "mfma_executed_tflops": (round((pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch", 0)
-                                               / (avg_ms * 1e-3) / 1e12, 2)
-                                         if (pmc_entry(dom_conv["kernel"]) or {}).get("mfma_executed_flops_per_launch") else None),
+                # measured in THIS run: the zero-skipping kernels count the MFMA instructions they execute into device
+                # counters while the scorer's profile mode is on (32x32x2 fp32: 4,096 FLOPs per instruction)
+                "mfma_executed_flops_per_launch": exec_flops,
+                "mfma_executed_tflops": round(exec_flops / (avg_ms * 1e-3) / 1e12, 2) if exec_flops else None,
+                "mfma_executed_fraction": round(exec_flops / (dom_conv["flops"] / dom_conv["launches"]), 4) if exec_flops else None,
+                "mfma_executed_source": exec_src,
             },
             "kernels": [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
                          "ms_per_step": round(r["ms_total"] / args.steps, 4),

@@ -61,12 +61,17 @@ struct ConvArgs {
   // one row per border class of the output voxel (3 x 3 x 3: first / interior / last plane per axis).
   int korder;
   const float *bias_tab;
+  // profiling only (mi_scorer_enable_profile): [kMfmaCountSlots] counters the zero-skipping kernels add the number of MFMA
+  // instructions they EXECUTED to (slot = workgroup % kMfmaCountSlots); nullptr otherwise
+  unsigned long long *mfma_count;
   // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
   // 1 = they are stacked along x (tcx % 4 == 0).  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
   // the raster order costs 3 LDS cycles per group) -- see DESIGN.md section 3.1.
   int mt_x;
 };
+
+constexpr int kMfmaCountSlots = 1024;
 
 enum { CONV_CFG_4x1_1x3 = 1 /* 1x1 96 -> 96 with one M-tile per wave: <= 128 VGPRs, four waves per SIMD */, CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
        CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6, CONV_CFG_2x2_3x1 = 7,

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
   const size_t wstride = (size_t)p.coutp * 4;           // floats per quad row of packed weights
 
+  unsigned n_exec = 0;  // MFMA instructions this wave executed (SP == 1; a scalar counter, read in profile mode only)
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     __syncthreads();  // previous chunk's reads done (and s_list / s_vox visible on the first pass)
     // ---- stage the halo tile of this channel chunk into LDS (zero padded; BN folded in) ----
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
 #pragma unroll
             for (int m = 0; m < TM; m++) {
               if (live[m][j] == 0ull) continue;
+              n_exec += TN;
               const float a = j == 0 ? aa[m].x : j == 1 ? aa[m].y : j == 2 ? aa[m].z : aa[m].w;
 #pragma unroll
               for (int n = 0; n < TN; n++) {
@@ -468,6 +470,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
     bias_ptr = p.post_bias;
     relu_flag = p.post_relu;
   }
+
+  if (SP == 1 && p.mfma_count && lane == 0)
+    atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec);
 
   // ---- epilogue: bias, ReLU, optional 2x2x2 pool, store channels-last ----
   const int So = p.pool ? S / 2 : S;

@@ -732,7 +732,10 @@ struct Scorer {
     double flops, bytes;
     int poses;
     hipEvent_t e0, e1;
+    int cnt_slot = -1;  // index of this launch's block of executed-MFMA counters in d_mfma_cnt (zero-skipping convs)
   };
+  DevBuf<unsigned long long> d_mfma_cnt;  // [kProfCntLaunches][kMfmaCountSlots], profile mode only
+  int cnt_used = 0;
   bool profile = false;
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -795,6 +798,18 @@ struct ProfScope {
     s.prof.push_back(r);
   }
 };
+
+constexpr int kProfCntLaunches = 256;  // launches with an executed-MFMA counter block per profile drain
+
+// a zeroed counter block for the launch `ps` brackets (nullptr when profiling is off or the blocks are used up)
+static unsigned long long *prof_counter(Scorer &s, ProfScope &ps) {
+  if (!ps.on || s.cnt_used >= kProfCntLaunches) return nullptr;
+  s.d_mfma_cnt.ensure((size_t)kProfCntLaunches * kMfmaCountSlots);
+  unsigned long long *p = s.d_mfma_cnt.p + (size_t)s.cnt_used * kMfmaCountSlots;
+  (void)hipMemsetAsync(p, 0, kMfmaCountSlots * sizeof(unsigned long long), ps.st);
+  ps.r.cnt_slot = s.cnt_used++;
+  return p;
+}
 
 constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
 constexpr size_t kPooledSlot2 = 4096;  // second pooled-grid buffer of the two-stream pipeline
@@ -1242,6 +1257,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           } else {
             int cfg;
             pick_tile(st.conv, nb, a, cfg);
+            a.mfma_count = (a.sparse && !a.bias_tab) ? prof_counter(s, ps) : nullptr;  // (32-wide zero-skipping kernels)
             launch_conv(a, cfg, nb, s.stream);
           }
         }
@@ -1967,9 +1983,12 @@ const char *mi_scorer_profile_json(mi_scorer *sc) {
   MIG_HIP(hipStreamSynchronize(s.stream));
   struct Agg {
     std::string name;
-    double ms = 0, flops = 0, bytes = 0;
-    long launches = 0, poses = 0;
+    double ms = 0, flops = 0, bytes = 0, mfma = 0;
+    long launches = 0, poses = 0, counted = 0;
   };
+  std::vector<unsigned long long> cnt((size_t)s.cnt_used * kMfmaCountSlots);
+  if (s.cnt_used) MIG_HIP(hipMemcpy(cnt.data(), s.d_mfma_cnt.p, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  s.cnt_used = 0;
   std::vector<Agg> aggs;
   for (auto &r : s.prof) {
     float ms = 0.f;
@@ -1987,6 +2006,10 @@ const char *mi_scorer_profile_json(mi_scorer *sc) {
     a->bytes += r.bytes;
     a->launches++;
     a->poses += r.poses;
+    if (r.cnt_slot >= 0) {
+      for (int i = 0; i < kMfmaCountSlots; i++) a->mfma += (double)cnt[(size_t)r.cnt_slot * kMfmaCountSlots + i];
+      a->counted++;
+    }
     s.ev_pool.push_back(r.e0);
     s.ev_pool.push_back(r.e1);
   }
@@ -1996,9 +2019,9 @@ const char *mi_scorer_profile_json(mi_scorer *sc) {
     char buf[512];
     snprintf(buf, sizeof buf,
              "%s{\"kernel\": \"%s\", \"launches\": %ld, \"poses\": %ld, \"ms_total\": %.6f, \"flops\": %.6e, "
-             "\"bytes\": %.6e}",
+             "\"bytes\": %.6e, \"mfma_counted_launches\": %ld, \"mfma_executed\": %.6e}",
              i ? ", " : "", aggs[i].name.c_str(), aggs[i].launches, aggs[i].poses, aggs[i].ms, aggs[i].flops,
-             aggs[i].bytes);
+             aggs[i].bytes, aggs[i].counted, aggs[i].mfma);
     j += buf;
   }
   j += "]";
