@@ -490,9 +490,12 @@ const char *mi_pdbqt_last_error(void);
 
 /* Per-kernel profiling for bench.py's roofline object: when enabled, every kernel launch of this
  * scorer is bracketed by HIP events on the scorer's stream.  mi_scorer_profile_json drains the
- * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes}], where
- * flops / bytes are the ALGORITHMIC work of those launches (2*MACs with unpadded channel counts;
- * bytes as stated in DESIGN.md).  The string stays valid until the next call on this scorer. */
+ * records and returns a JSON array [{kernel, launches, poses, ms_total, flops, bytes,
+ * mfma_counted_launches, mfma_executed}], where flops / bytes are the ALGORITHMIC work of those
+ * launches (2*MACs with unpadded channel counts; bytes as stated in DESIGN.md) and mfma_executed is
+ * the number of 32x32x2 fp32 MFMA instructions (4,096 FLOPs each) the zero-skipping conv kernels
+ * actually issued in mfma_counted_launches of them (device counters, this mode only; 0 / 0 for
+ * kernels that execute every instruction).  The string stays valid until the next call on this scorer. */
 mi_status mi_scorer_enable_profile(mi_scorer *, int on);
 const char *mi_scorer_profile_json(mi_scorer *);
 
