@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
   constexpr int NTHREADS = 256;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wm = tid >> 6;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: M-tile / cell arithmetic on the scalar unit
   const int kq = lane >> 4;   // which of the four quads of a step this lane feeds
   const int row = lane & 15;  // A row / B column
 
@@ -612,8 +612,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;  // (see conv3d_mfma_kernel)
   for (int hv = tid; hv < HV; hv += NTHREADS) {
-    const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+    const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
     const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
     const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
     s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
