@@ -2066,7 +2066,10 @@ __global__ __launch_bounds__(256) void vina_mc_kernel(VinaEnv env, VinaLigand L,
   mc_chain<PROF, false, ACC>(env, L, a);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vina_mc_tp_kernel(VinaEnv env, VinaLigand L,
+#ifndef MI_MC_TP_WAVES
+#define MI_MC_TP_WAVES 2  // waves per SIMD the throughput instantiation is register-allocated for (A/B: tools/experiments)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_MC_TP_WAVES, MI_MC_TP_WAVES))) void vina_mc_tp_kernel(VinaEnv env, VinaLigand L,
                                                                                                    VinaMcArgs a) {
   mc_chain<false, true>(env, L, a);
 }
