@@ -22,6 +22,15 @@
 //     the 32x32x2 instruction), each with its own LDS address, so K needs no padding beyond a
 //     multiple of 4 channels and an even quad count.
 //   * A workgroup is WM x WN waves, each wave owning TM M-tiles x TN 32-wide N-tiles.
+//
+// Zero-skipping (exact: a skipped instruction would only have added +-0 to accumulators that cannot hold -0):
+//   1. per tile: channel quads that are all-zero in the whole halo tile are left out of the K-loop list (first conv on
+//      the pooled voxel grid, transposed convs on un-pooled gradients: ConvArgs::sparse == 1);
+//   2. per MFMA: the lane mask "A component != 0" of every instruction is taken with one v_cmp into an SGPR pair, and
+//      the instruction is branched around when the mask is empty (sparse == 1 and == 2; the latter is the mode of
+//      ReLU'd activations: every quad listed, so the K order -- channel-major, ConvArgs::korder -- and with it the
+//      rounding does not depend on the tile);
+//   the N = 16 kernel of the Dense blocks does 2. on x * bn_scale, with the BatchNorm shift folded into a bias table.
 #include "conv3d.h"
 
 #include <stdexcept>
