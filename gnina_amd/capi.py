@@ -6,6 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2  # include/mi_gnina.h MI_GNINA_ABI_VERSION: the struct layouts this binding was written against
 LIB_PATH = os.environ.get("MI_GNINA_LIB", os.path.join(_HERE, "lib", "libmi_gnina.so"))
 
 MI_OK = 0
@@ -24,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -48,16 +49,18 @@ class CnnBox(C.Structure):
     """mi_cnn_box (include/mi_gnina.h): the two out-of-box penalty regions of non_cache_cnn"""
     _fields_ = [("use_search_box", C.c_int32), ("box_begin", C.c_float * 3), ("box_end", C.c_float * 3),
                 ("cnn_dimension", C.c_float), ("slope", C.c_float), ("mix_emp_force", C.c_int32),
-                ("mix_emp_energy", C.c_int32), ("empirical_weight", C.c_float), ("v", C.c_float)]
+                ("mix_emp_energy", C.c_int32), ("empirical_weight", C.c_float), ("v", C.c_float),
+                ("per_atom_forces", C.c_int32)]
 
     @classmethod
     def make(cls, cnn_dimension, box_begin=None, box_end=None, slope=10.0, mix_emp_force=False,
-             mix_emp_energy=False, empirical_weight=1.0, v=1000.0):
+             mix_emp_energy=False, empirical_weight=1.0, v=1000.0, per_atom_forces=False):
+        """per_atom_forces False (default) = the reference's model::add_minus_forces indexing, see mi_gnina.h"""
         use = box_begin is not None
         bb = (C.c_float * 3)(*(box_begin if use else (0, 0, 0)))
         be = (C.c_float * 3)(*(box_end if use else (0, 0, 0)))
         return cls(1 if use else 0, bb, be, cnn_dimension, slope, int(mix_emp_force), int(mix_emp_energy),
-                   empirical_weight, v)
+                   empirical_weight, v, int(per_atom_forces))
 
 
 class McParams(C.Structure):
@@ -89,6 +92,9 @@ def lib():
         L.mi_gnina_init.restype = C.c_int
         L.mi_gnina_device_count.restype = C.c_int
         L.mi_gnina_abi_version.restype = C.c_int
+        if L.mi_gnina_abi_version() != ABI_VERSION:
+            raise MiGninaError(f"{LIB_PATH} has ABI version {L.mi_gnina_abi_version()}, this binding expects {ABI_VERSION} "
+                               "(struct layouts differ): rebuild with `python __graft_entry__.py build`")
         L.mi_last_error.restype = C.c_char_p
         L.mi_model_load.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
         L.mi_model_load.restype = vp
@@ -201,6 +207,12 @@ def lib():
         L.mi_vina_pair_eval.restype = C.c_int
         L.mi_vina_set_line_search.argtypes = [vp, C.c_int]
         L.mi_vina_set_line_search.restype = C.c_int
+        L.mi_vina_set_strict_order.argtypes = [vp, C.c_int]
+        L.mi_vina_set_strict_order.restype = C.c_int
+        L.mi_debug_sincos.argtypes = [f32p, C.c_int, f32p, f32p]
+        L.mi_debug_sincos.restype = C.c_int
+        L.mi_debug_explog.argtypes = [f32p, C.c_int, f32p, f32p]
+        L.mi_debug_explog.restype = C.c_int
         L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
         L.mi_vina_set_ligand.restype = C.c_int
         L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
@@ -657,6 +669,10 @@ class Vina:
         """--accurate_line_search for every BFGS of this handle (False = fast_line_search, the default)"""
         check(lib().mi_vina_set_line_search(self.handle, 1 if accurate else 0))
 
+    def set_strict_order(self, on=True):
+        """energy sums in the reference's order: trajectories bit-identical to the reference's (mi_gnina.h)"""
+        check(lib().mi_vina_set_strict_order(self.handle, 1 if on else 0))
+
     def pair_eval(self, t1, t2, r2):
         """(E, dE/dr / r) of the current approximation for a type pair at squared distances r2"""
         r2 = _f32(r2).ravel()
@@ -928,6 +944,18 @@ def rank_poses(cnnscore, cnnaffinity, energy, coords, sort_order=0, min_rmsd=1.0
     check(lib().mi_rank_poses(_ptr(cs), _ptr(ca), _ptr(en), _ptr(coords), n, nh, sort_order, min_rmsd, _ptr(order),
                               C.byref(n_out)))
     return order[:n_out.value].copy()
+
+
+def device_libm(x):
+    """(sinf, cosf, expf, logf(|x|)) of float32 x as the Vina kernels compute them: glibc's algorithms restated in fp64
+    (vina.hip sincos_ref / expf_ref / logf_ref) so that they give the bits of the reference's host libm"""
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    f32p = C.POINTER(C.c_float)
+    o = [np.empty_like(x) for _ in range(4)]
+    p = [a.ctypes.data_as(f32p) for a in [x] + o]
+    check(lib().mi_debug_sincos(p[0], len(x), p[1], p[2]))
+    check(lib().mi_debug_explog(p[0], len(x), p[3], p[4]))
+    return tuple(o)
 
 
 def init(device=0):

@@ -1865,6 +1865,7 @@ mi_status mi_voxelize_batch(mi_scorer *sc, int mi, const float *lig_xyz, const i
   MIG_CHECK(mi >= 0 && mi < (int)s.models.size(), 1, "model index out of range");
   MIG_CHECK(B >= 0 && L >= 0 && grid_out && (B == 0 || (lig_xyz && lig_smt)), 1, "bad arguments");
   if (B == 0) return MI_OK;
+  RotScope rot_scope(s, B);  // mi_scorer_set_rotations applies to this call too (and is consumed by it)
   const VoxGroup *grp = nullptr;
   for (auto &g : s.groups)
     for (int m : g.models)

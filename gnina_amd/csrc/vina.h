@@ -39,6 +39,7 @@ struct VinaEnv {
   int sp_n;
   float sp_fraction, cutoff;
   int stage;  // copy the ligand description into LDS (set by the launchers)
+  int strict;  // energy sums in the reference's order instead of the butterfly (mi_vina_set_strict_order; vina.hip seq_add)
   const float4 *rec;  // (x, y, z, smt bits)
   int n_rec;
   float w5[5];
@@ -128,6 +129,11 @@ struct VinaExtArgs {  // non_cache_cnn: externally computed receptor term (CNN l
   // cnn_options::mix_emp_force / mix_emp_energy / empirical_weight (user_opts.h:46-51); v = curl cap
   int mix_force, mix_energy;
   float weight, v;
+  // model::add_minus_forces (model.cu:247-259) hands the scorer's gradient -- one entry per movable atom, hydrogens
+  // included (cnn_torch_scorer.cpp:208-228) -- to the non-hydrogen atoms with a counter that only advances on
+  // non-hydrogen atoms: the k-th heavy atom receives entry k, not its own.  0 = exactly that (the reference's
+  // behaviour: what non_cache_cnn::eval_deriv sees in m.minus_forces); 1 = every atom its own gradient.
+  int per_atom_forces;
 };
 
 struct VinaPopulateArgs {
@@ -153,6 +159,8 @@ struct VinaPopulateArgs {
 
 size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, bool stage);
 void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
+void launch_vina_sincos_probe(const float *x, int n, float *sn, float *cs, hipStream_t s);
+void launch_vina_explog_probe(const float *x, int n, float *ex, float *lg, hipStream_t s);
 // confs [B][7+T]; energy [B]; change [B][6+T] or null; coords [B][n_atoms][3] or null
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);

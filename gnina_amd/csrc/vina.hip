@@ -83,14 +83,15 @@ __device__ __forceinline__ float slope_step_d(float x_bad, float x_good, float x
   return (x - x_bad) / (x_good - x_bad);
 }
 
+__device__ __forceinline__ float expf_ref(float x);  // glibc's expf restated, below
 // weighted_terms::eval_fast for the default Vina term set (weighted_terms.cpp:54-68; everything.h)
 __device__ float pair_energy_exact(const float *w, int t1, int t2, float r) {
   const float opt = c_xs_radius[t1] + c_xs_radius[t2];
   float acc = 0.f;
   float q = (r - (opt + 0.0f)) / 0.5f;
-  acc += w[0] * expf(-(q * q));
+  acc += w[0] * expf_ref(-(q * q));
   q = (r - (opt + 3.0f)) / 2.0f;
-  acc += w[1] * expf(-(q * q));
+  acc += w[1] * expf_ref(-(q * q));
   const float d = r - (opt + 0.0f);
   acc += w[2] * (d > 0 ? 0.0f : d * d);
   acc += w[3] * ((c_hyd[t1] && c_hyd[t2]) ? slope_step_d(1.5f, 0.5f, r - opt) : 0.0f);
@@ -244,6 +245,104 @@ __device__ __forceinline__ float norm_angle(float x) {  // g_normalize_angle, qu
   return x;
 }
 
+// sinf / cosf exactly as the reference's host computes them.  gnina's tree.h / quaternion.h call std::sin / std::cos
+// on fl = float, i.e. glibc's sinf / cosf (2.35: sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h,
+// s_sincosf_data.c -- the ARM optimized-routines algorithm; on x86-64 with FMA the multiarch build, whose mul-adds are
+// fused).  Those are NOT correctly rounded (worst case 0.56 ulp): rounding an accurate fp64 sine differs from them on
+// 0.1 % of the arguments, ocml's sincosf on more -- and one differing last bit sends a BFGS trajectory elsewhere.  So
+// the algorithm is restated here operation by operation in fp64: one reduction step x - n * (pi/2) with
+// n = round(x * 2/pi) taken from a 2^24-scaled integer conversion, then the degree-7 sine or degree-8 cosine
+// polynomial of the quadrant.  Checked against the host's sinf / cosf for all 2.24e9 floats of [-100, 100]
+// (tools/microbench/glibc_sincosf_check.c: 0 mismatches) and on the device by tests/test_gpu_vina_ref.py.
+// Domain: |y| < 120 (glibc switches to a 192-bit reduction above; every caller passes half of a normalised angle).
+__device__ __forceinline__ void sincos_ref(float y, float &sn, float &cs) {
+  const double x = (double)y;
+  const double r = x * 0x1.45F306DC9C883p+23;                         // 2/pi * 2^24
+  const int n = ((int)r + 0x800000) >> 24;                             // quadrant, rounded to nearest
+  const double xr = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);  // x - n * pi/2, |xr| <= pi/4
+  const double xs = (n & 1) ^ ((n >> 1) & 1) ? -xr : xr;               // sign[n & 3] = {1, -1, -1, 1}
+  const double x2 = xr * xr;
+  // sine polynomial (sinf_poly, n even)
+  const double x3 = xs * x2;
+  const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+  const double x7 = x3 * x2;
+  const double s = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
+  const float sp = (float)__builtin_fma(x7, s1, s);
+  // cosine polynomial (sinf_poly, n odd); the table's second entry (quadrants 2, 3) negates every coefficient
+  const double x4 = x2 * x2;
+  const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+  const double x6 = x4 * x2;
+  const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+  float cp = (float)__builtin_fma(x6, c2, c);
+  if (n & 2) cp = -cp;
+  sn = (n & 1) ? cp : sp;
+  cs = (n & 1) ? sp : cp;
+  const unsigned top = (__float_as_uint(y) >> 20) & 0x7ff;
+  if (top < 0x398u) {  // |y| < 2^-12: sinf returns y, cosf returns 1
+    sn = y;
+    cs = 1.0f;
+  }
+}
+
+// expf / logf exactly as the reference's host computes them (std::exp / std::log on fl = float: glibc 2.35's
+// e_expf.c / e_logf.c, again the ARM optimized-routines algorithms with their mul-adds fused as the x86-64 FMA build
+// has them): restated in fp64 like sincos_ref and checked the same way -- tools/microbench/glibc_expf_logf_check.c
+// compares these operations with the host's libm for every float of expf's [-87, 88) and every positive normal float
+// of logf: 0 mismatches.  Users: the Metropolis criterion (monte_carlo.cpp:38-42), random_normal's Box-Muller
+// (conf::randomize, through oracle/ref_shims' boost::normal_distribution) and precalculate_exact's Gaussians.
+__constant__ unsigned long long c_exp2f_tab[32] = {  // asuint64(2^(i/32)) - (i << 47), 2^(i/32) correctly rounded
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+__device__ __forceinline__ float expf_ref(float x) {
+  if (x < -0x1.9fe368p6f) return 0.f;        // below log(2^-150): glibc's __math_uflowf
+  if (x > 0x1.62e42ep6f) return __builtin_inff();  // above log(2^128)
+  const double xd = (double)x;
+  const double z = 0x1.71547652b82fep+0 * 32 * xd;             // x * N / ln 2, N = 32
+  double kd = z + 0x1.8p+52;                                    // round to nearest integer: low mantissa bits = k
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= 0x1.8p+52;
+  const double r = __builtin_fma(0x1.71547652b82fep+0 * 32, xd, -kd);
+  const double s = __longlong_as_double((long long)(c_exp2f_tab[ki & 31] + (ki << 47)));
+  const double zz = __builtin_fma(0x1.c6af84b912394p-5 / 32 / 32 / 32, r, 0x1.ebfce50fac4f3p-3 / 32 / 32);
+  const double r2 = r * r;
+  double y = __builtin_fma(0x1.62e42ff0c52d6p-1 / 32, r, 1.0);
+  y = __builtin_fma(zz, r2, y);
+  return (float)(y * s);
+}
+
+__constant__ double c_logf_tab[16][2] = {  // (1/c, log c) of the sixteen sub-intervals of [0x1.66p-1, 0x1.66p0)
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+__device__ __forceinline__ float logf_ref(float x) {  // x positive and normal (the callers' arguments are in (2^-24, 1])
+  const unsigned ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.f;
+  const unsigned tmp = ix - 0x3f330000u;
+  const int i = (tmp >> 19) & 15;
+  const int k = (int)tmp >> 23;
+  const double z = (double)__uint_as_float(ix - (tmp & (0x1ffu << 23)));
+  const double r = __builtin_fma(z, c_logf_tab[i][0], -1.0);
+  const double y0 = __builtin_fma((double)k, 0x1.62e42fefa39efp-1, c_logf_tab[i][1]);
+  const double r2 = r * r;
+  double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+  y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
+  y = __builtin_fma(y, r2, y0 + r);
+  return (float)y;
+}
+
 __device__ __forceinline__ void angle_to_quat(float ax, float ay, float az, float angle, float *q) {
   angle = norm_angle(angle);
   float c, s;
@@ -251,7 +350,7 @@ __device__ __forceinline__ void angle_to_quat(float ax, float ay, float az, floa
   s = __sinf(angle / 2);
   c = __cosf(angle / 2);
 #else
-  sincosf(angle / 2, &s, &c);  // one shared argument reduction; same values as sinf / cosf
+  sincos_ref(angle / 2, s, c);
 #endif
   q[0] = c;
   q[1] = s * ax;
@@ -440,6 +539,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+__device__ __forceinline__ float rl_any(float v, int lane) {  // lane: any wave-uniform value
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(lane)));
+}
+
+// Strict-order sums (VinaEnv::strict, mi_vina_set_strict_order): the reference adds energies one after the other --
+// atoms in index order (cache.cpp:65-83), pairs in list order (model.cu:38-60) -- and fp32 addition does not
+// associate, so the butterfly above gives the same energy only to the last bits.  With the flag set every energy sum
+// of eval_conf runs in the reference's order instead: `v` holds one term per lane, `mask` (wave-uniform) the lanes
+// whose term the reference would add; skipped lanes would add +0 to a sum that can never be -0, i.e. nothing.
+// Together with sincos_ref this makes energies, forces and with them whole BFGS / Monte-Carlo trajectories
+// bit-identical to the reference's (tests/test_gpu_vina_ref.py); it costs ~1 us per evaluation, hence a mode.
+__device__ __forceinline__ void seq_add(float &acc, float v, unsigned long long mask) {
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    acc += rl_any(v, l);
+    mask &= mask - 1;
+  }
+}
+
 // ligands.derivative(coords, minus_forces, g) (model.cu:223; tree.h:133-140,293-401): per-atom forces in
 // w.forces + the node frames of the conformation just set -> change[6 + T].
 __device__ __forceinline__ float rl(float v, int lane) {
@@ -551,7 +669,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     par_r = L.parent[k];
     if (k > 0) {
       const float angle = norm_angle(conf[7 + (k - 1)]);  // angle_to_quaternion, quaternion.h:284-291
-      sincosf(angle / 2, &sn_r, &cn_r);
+      sincos_ref(angle / 2, sn_r, cn_r);
     }
   }
   if (5 * L.n_levels <= 4 * L.n_nodes) {
@@ -659,6 +777,12 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   constexpr bool GRID = MODE != 3 && MODE != 4 && MODE != 5;
   constexpr int kTapIt = 2;
   float e_part = 0.f;
+  // strict mode (seq_add): the receptor term, the other_pairs sum, the ligand-pair sum and model::eval's user-grid
+  // term, each accumulated in the reference's order, wave-uniform
+  // (eval_intramolecular of a model with flexible residues keeps the butterfly: model.cu:352-399 adds the flex-rigid
+  // terms and the flex-flex pairs one by one onto the ligand's pair sum)
+  const bool strict = env.strict != 0 && !(MODE == 4 && L.lig_end > L.lig_begin && L.pair_cap != nullptr);
+  float s_rec = 0.f, s_p1 = 0.f, s_p0 = 0.f;
   GridTap tap[kTapIt];
   bool tap_on[kTapIt];
   auto place_atom = [&](int i, float &cx, float &cy, float &cz) {
@@ -682,7 +806,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       float cx, cy, cz;
       place_atom(i, cx, cy, cz);
       const int t = L.smt[i];
-      if (GRID && !env.direct && i < L.n_movable && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
+      if (GRID && !env.direct && !strict && i < L.n_movable && t > 1 && env.grid_off[t] >= 0) {  // hydrogens / types without a grid are skipped (cache.cpp:69-75)
         grid_fetch(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, tap[it]);
         tap_on[it] = true;
       } else if (DERIV) {
@@ -697,7 +821,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     place_atom(i, cx, cy, cz);
     const int t = L.smt[i];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (GRID && !env.direct && i < L.n_movable && t > 1 && env.grid_off[t] >= 0)
+    if (GRID && !env.direct && !strict && i < L.n_movable && t > 1 && env.grid_off[t] >= 0)
       e_part += grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], cx, cy, cz, env.slope, v1, fx, fy, fz);
     if (DERIV) {
       w.forces[3 * i] = fx;
@@ -706,6 +830,25 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     }
   }
   wave_sync();
+  if (GRID && !env.direct && strict) {  // cache::eval / eval_deriv with e summed in atom order (cache.cpp:52-83)
+    for (int base = 0; base < L.n_movable; base += 64) {
+      const int i = base + lane;
+      float eg = 0.f;
+      bool on = false;
+      if (i < L.n_movable) {
+        const int t = L.smt[i];
+        if (t > 1 && env.grid_off[t] >= 0) {
+          float fx, fy, fz;
+          eg = grid_evaluate<DERIV>(env.geom, env.grid_data + env.grid_off[t], w.coords[3 * i], w.coords[3 * i + 1],
+                                    w.coords[3 * i + 2], env.slope, v1, fx, fy, fz);
+          on = true;
+          if (DERIV) w.forces[3 * i] = fx, w.forces[3 * i + 1] = fy, w.forces[3 * i + 2] = fz;
+        }
+      }
+      seq_add(s_rec, eg, __builtin_amdgcn_ballot_w64(on));
+    }
+    wave_sync();
+  }
   if (MODE != 3 && MODE != 4 && MODE != 5 && env.direct) {
     // non_cache::eval / eval_deriv (non_cache.cpp:52-83,125-179): every ligand heavy atom against every
     // receptor atom within the cutoff -- the 64 lanes stride over the receptor, one ligand atom at a time
@@ -729,6 +872,36 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       }
       oob *= env.slope;
       float pe = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+      if (strict) {  // receptor atoms in index order (non_cache.cpp:60-75,140-160)
+        for (int jb = 0; jb < env.n_rec; jb += 64) {
+          const int j = jb + lane;
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+          bool on = false;
+          if (j < env.n_rec) {
+            const float4 r = env.rec[j];
+            const float rx = adj[0] - r.x, ry = adj[1] - r.y, rz = adj[2] - r.z;
+            const float r2 = rx * rx + ry * ry + rz * rz;
+            if (r2 < env.cutoff_sqr) {
+              on = true;
+              const int t2 = __float_as_int(r.w);
+              if (DERIV) {
+                float dor;
+                prec_eval_deriv(env, t1, t2, r2, c0, dor);
+                c1 = dor * rx, c2 = dor * ry, c3 = dor * rz;
+              } else {
+                c0 = prec_eval(env, t1, t2, r2);
+              }
+            }
+          }
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+          seq_add(pe, c0, m);
+          if (DERIV) {
+            seq_add(dx, c1, m);
+            seq_add(dy, c2, m);
+            seq_add(dz, c3, m);
+          }
+        }
+      } else {
       for (int j = lane; j < env.n_rec; j += 64) {
         const float4 r = env.rec[j];
         const float rx = adj[0] - r.x, ry = adj[1] - r.y, rz = adj[2] - r.z;
@@ -748,10 +921,13 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         }
       }
       pe = wave_sum(pe);
+      }
       if (DERIV) {
-        dx = wave_sum(dx);
-        dy = wave_sum(dy);
-        dz = wave_sum(dz);
+        if (!strict) {
+          dx = wave_sum(dx);
+          dy = wave_sum(dy);
+          dz = wave_sum(dz);
+        }
         if (env.ug_data) {  // user grid at the atom's own coordinates, before the curl (non_cache.cpp:168-173)
           float ux, uy, uz;
           pe += grid_evaluate<true>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
@@ -767,7 +943,10 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       } else {
         curl1(pe, v1);
       }
-      if (lane == 0) e_part += pe + oob;
+      if (strict)
+        s_rec += pe + oob;
+      else if (lane == 0)
+        e_part += pe + oob;
     }
     wave_sync();
   }
@@ -788,12 +967,15 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       float fastv[PG];
       int2 sl[PG];
       bool in[PG];
+      unsigned other = 0;  // bit u: pair u of this lane belongs to model::other_pairs
 #pragma unroll
       for (int u = 0; u < PG; u++) {
         const int p = p0 + 64 * u;
         const bool valid = p < L.n_pairs;
         const int2 ab = L.pairs[valid ? p : 0];
-        capv[u] = (L.pair_cap && L.pair_cap[valid ? p : 0]) ? v2 : v0;
+        const bool oth = L.pair_cap && L.pair_cap[valid ? p : 0];
+        other |= oth ? 1u << u : 0u;
+        capv[u] = oth ? v2 : v0;
         if (DERIV) sl[u] = L.pair_slots[valid ? p : 0];
         rx[u] = w.coords[3 * ab.y] - w.coords[3 * ab.x];
         ry[u] = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1];
@@ -816,19 +998,25 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       for (int u = 0; u < PG; u++) {
         const int p = p0 + 64 * u;
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        float pe = 0.f;
         if (in[u]) {
           if (DERIV) {
-            float pe = s1[u].x + rem[u] * (s2[u].x - s1[u].x);
+            pe = s1[u].x + rem[u] * (s2[u].x - s1[u].x);
             const float dor = s1[u].y + rem[u] * (s2[u].y - s1[u].y);
             float fx = dor * rx[u], fy = dor * ry[u], fz = dor * rz[u];
             curl3(pe, fx, fy, fz, capv[u]);
             out = make_float4(fx, fy, fz, pe);
-            e_part += pe;
           } else {
-            float pe = fastv[u];
+            pe = fastv[u];
             curl1(pe, capv[u]);
-            e_part += pe;
           }
+        }
+        if (strict) {  // pairs in list order, other_pairs and the ligand's own summed apart (model.cu:206-216)
+          const bool oth = (other >> u) & 1;
+          if (L.pair_cap) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in[u] && oth));
+          seq_add(s_p0, pe, __builtin_amdgcn_ballot_w64(in[u] && !oth));
+        } else {
+          e_part += pe;
         }
         if (DERIV && p < L.n_pairs) {  // forces[a] -= f; forces[b] += f, as entries of the two atoms' lists
           w.cx[sl[u].x] = -out.x, w.cy[sl[u].x] = -out.y, w.cz[sl[u].x] = -out.z;
@@ -837,28 +1025,37 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       }
     }
   }
-  for (int p = lane; (MODE < 2 || MODE == 4 || MODE == 5) && (env.exact || env.spline) && p < L.n_pairs; p += 64) {
-    const int2 ab = L.pairs[p];
+  for (int pb = 0; (MODE < 2 || MODE == 4 || MODE == 5) && (env.exact || env.spline) && pb < L.n_pairs; pb += 64) {
+    const int p = pb + lane;
+    const bool valid = p < L.n_pairs;
+    const int2 ab = L.pairs[valid ? p : 0];
     const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
                 rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
     const float r2 = rx * rx + ry * ry + rz * rz;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float capx = (L.pair_cap && L.pair_cap[p]) ? v2 : v0;
-    if (r2 < env.cutoff_sqr && pair_counts(p, ab)) {
+    const bool oth = L.pair_cap && L.pair_cap[valid ? p : 0];
+    const float capx = oth ? v2 : v0;
+    const bool in = valid && r2 < env.cutoff_sqr && pair_counts(valid ? p : 0, ab);
+    float pe = 0.f;
+    if (in) {
       if (DERIV) {
-        float pe, dor;
+        float dor;
         prec_eval_deriv(env, L.smt[ab.x], L.smt[ab.y], r2, pe, dor);
         float fx = dor * rx, fy = dor * ry, fz = dor * rz;
         curl3(pe, fx, fy, fz, capx);
         out = make_float4(fx, fy, fz, pe);
-        e_part += pe;
       } else {
-        float pe = prec_eval(env, L.smt[ab.x], L.smt[ab.y], r2);
+        pe = prec_eval(env, L.smt[ab.x], L.smt[ab.y], r2);
         curl1(pe, capx);
-        e_part += pe;
       }
     }
-    if (DERIV) {
+    if (strict) {
+      if (L.pair_cap) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in && oth));
+      seq_add(s_p0, pe, __builtin_amdgcn_ballot_w64(in && !oth));
+    } else {
+      e_part += pe;
+    }
+    if (DERIV && valid) {
       const int2 sl = L.pair_slots[p];
       w.cx[sl.x] = -out.x, w.cy[sl.x] = -out.y, w.cz[sl.x] = -out.z;
       w.cx[sl.y] = out.x, w.cy[sl.y] = out.y, w.cz[sl.y] = out.z;
@@ -921,17 +1118,34 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     wave_sync();
     fold_forces(L, w, change);
   }
+  float e_strict = 0.f;
+  if (strict) {
+    // compose the sums the way the reference's callers do (the pair loop above is not wave-uniform: lane 0 stays in
+    // it longest and holds the complete sums)
+    s_p1 = rl(s_p1, 0), s_p0 = rl(s_p0, 0);
+    if (MODE == 0) e_strict = s_rec + ((0.f + s_p1) + s_p0);  // model::eval_deriv: e = ig.eval_deriv; ie = ...; e += ie
+    else if (MODE == 1) e_strict = (s_rec + s_p1) + s_p0;      // model::evale adds other_pairs, model::eval the ligand's
+    else if (MODE == 2) e_strict = s_rec;
+    else e_strict = (0.f + s_p1) + s_p0;
+  }
   if ((MODE == 1 || (MODE == 2 && env.ug_model)) && env.ug_data) {
     // model::eval's own user-grid term (model.cu:125-134): every atom of the ligand, hydrogens included, at slope
     // 1000 -- this (not the igrid) is how --user_grid reaches eval_adjusted and the final energies
     const int lb = L.lig_end > L.lig_begin ? L.lig_begin : 0, le = L.lig_end > L.lig_begin ? L.lig_end : L.n_atoms;
-    for (int i = lb + lane; i < le; i += 64) {
-      float ux, uy, uz;
-      e_part += grid_evaluate<false>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
-                                     1000.f, 1000.f, ux, uy, uz);
+    for (int base = lb; base < le; base += 64) {
+      const int i = base + lane;
+      float ux, uy, uz, t = 0.f;
+      if (i < le)
+        t = grid_evaluate<false>(env.ug_geom, env.ug_data, w.coords[3 * i], w.coords[3 * i + 1], w.coords[3 * i + 2],
+                                 1000.f, 1000.f, ux, uy, uz);
+      if (strict)
+        seq_add(e_strict, t, __builtin_amdgcn_ballot_w64(i < le));
+      else
+        e_part += t;
     }
   }
   wave_sync();
+  if (strict) return e_strict;
   return wave_sum(e_part);
 }
 
@@ -996,12 +1210,20 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
   wave_sync();
   eval_conf<3>(env, L, conf, 0.f, 0.f, 0.f, w, change);
   float pen = 0.f;
-  for (int i = lane; i < L.n_atoms; i += 64) {
+  int heavy_before = 0;  // non-hydrogen movable atoms in front of this 64-atom block (add_minus_forces' counter j)
+  for (int base = 0; base < L.n_atoms; base += 64) {
+    const int i = base + lane;
+    if (i >= L.n_atoms) continue;  // (only in the last block: the ballot below then counts the live lanes, all it needs)
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (L.smt[i] > 1) {  // hydrogens: minus_forces = 0, no penalty (non_cache_cnn.cpp:92-96)
+    const bool heavy = L.smt[i] > 1;
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy && i < L.n_movable);
+    const int rank = heavy_before + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
+    heavy_before += __builtin_popcountll(hm);
+    if (heavy) {  // hydrogens: minus_forces = 0, no penalty (non_cache_cnn.cpp:92-96)
       float f[3] = {0.f, 0.f, 0.f}, dist = 0.f;
       if (a.forces) {
-        const float *g = a.forces + ((size_t)b * L.n_atoms + i) * 3;
+        // model::add_minus_forces (model.cu:247-259): the k-th non-hydrogen atom takes gradient entry k
+        const float *g = a.forces + ((size_t)b * L.n_atoms + (a.per_atom_forces ? i : rank)) * 3;
         f[0] = g[0], f[1] = g[1], f[2] = g[2];
       }
 #pragma unroll
@@ -1399,7 +1621,8 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       if (qa > -1 && qa < 1) {
         float angle = 2 * acosf(qa);
         if (angle > VPI) angle -= 2 * VPI;
-        const float sn = sinf(angle / 2);
+        float sn, cs_unused;
+        sincos_ref(angle / 2, sn, cs_unused);  // (acosf above stays ocml's: it only feeds the step-size floor alamin)
         if (!(fabsf(sn) < VEPS)) {
           const float sc = angle / sn;
           ang0 = qb * sc, ang1 = qc * sc, ang2 = qd * sc;
@@ -1751,7 +1974,9 @@ struct McRng {
   // distribution object per call, random.cpp:37-42)
   __device__ __forceinline__ float normal() {
     const float r1 = fl(0.f, 1.f), r2 = fl(0.f, 1.f);
-    return sqrtf(-2.0f * logf(1.0f - r2)) * cosf(2.0f * 3.14159265358979323846f * r1);
+    float sn, cs;
+    sincos_ref(2.0f * 3.14159265358979323846f * r1, sn, cs);
+    return sqrtf(-2.0f * logf_ref(1.0f - r2)) * cs;
   }
   __device__ __forceinline__ void inside_sphere(float &x, float &y, float &z) {  // random.cpp:66-75
     for (;;) {
@@ -2000,7 +2225,7 @@ __device__ __forceinline__ void mc_chain(VinaEnv env, VinaLigand L, VinaMcArgs a
         cand_e = e_now;
         bool accept = step == 0 || cand_e < tmp_e;
         if (!accept) {  // metropolis_accept, monte_carlo.cpp:38-42
-          const float prob = expf((tmp_e - cand_e) / a.temperature);
+          const float prob = expf_ref((tmp_e - cand_e) / a.temperature);
           accept = rng.fl(0.f, 1.f) < prob;
         }
         lap(2);
@@ -2128,7 +2353,7 @@ __global__ __launch_bounds__(64) void vina_mc_cnn_kernel(VinaEnv env, VinaLigand
     const float cand_e = st.ext_e[b];
     bool accept = st.step == 0 || cand_e < tmp_e;
     if (!accept) {
-      const float prob = expf((tmp_e - cand_e) / a.temperature);
+      const float prob = expf_ref((tmp_e - cand_e) / a.temperature);
       accept = rng.fl(0.f, 1.f) < prob;
     }
     flag = 1;  // rejected: `model` keeps the candidate's last evaluation (already in mconf)
@@ -2306,6 +2531,22 @@ __global__ __launch_bounds__(256) void vina_populate_kernel(VinaPopulateArgs a) 
     aff += grid_evaluate<false>(a.ug_geom, a.ug_data, (float)x, (float)y, (float)z, a.ug_slope, 1000.f, ux, uy, uz);
   }
   if (live) a.out[idx] = aff;
+}
+
+// diagnostic: sincos_ref on n arguments (mi_debug_sincos; the -m gpu test compares it with the host's libm)
+__global__ void vina_sincos_probe_kernel(const float *x, int n, float *sn, float *cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sincos_ref(x[i], sn[i], cs[i]);
+}
+void launch_vina_sincos_probe(const float *x, int n, float *sn, float *cs, hipStream_t s) {
+  hipLaunchKernelGGL(vina_sincos_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, sn, cs);
+}
+__global__ void vina_explog_probe_kernel(const float *x, int n, float *ex, float *lg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ex[i] = expf_ref(x[i]), lg[i] = logf_ref(fabsf(x[i]));
+}
+void launch_vina_explog_probe(const float *x, int n, float *ex, float *lg, hipStream_t s) {
+  hipLaunchKernelGGL(vina_explog_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, ex, lg);
 }
 
 void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s) {

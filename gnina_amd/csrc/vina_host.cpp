@@ -92,6 +92,7 @@ struct Vina {
   DevBuf<float4> d_spline;
   std::vector<float4> h_spline;
   bool accurate_ls = false;  // --accurate_line_search
+  bool strict = false;       // mi_vina_set_strict_order: energy sums in the reference's order
   // --user_grid
   bool have_ug = false;
   VinaGridGeom ug_geom{};
@@ -250,6 +251,7 @@ static VinaEnv make_env(const Vina &v) {
   e.ug_geom = v.ug_geom;
   e.ug_data = v.have_ug ? v.d_ug.p : nullptr;
   e.accurate_ls = v.accurate_ls ? 1 : 0;
+  e.strict = v.strict ? 1 : 0;
   e.spline = v.use_spline ? v.d_spline.p : nullptr;
   e.sp_n = v.sp_n;
   e.sp_fraction = v.sp_fraction;
@@ -419,6 +421,49 @@ mi_status mi_vina_set_line_search(mi_vina *vv, int kind) {
   VCATCH_STATUS
 }
 
+// Diagnostic: the device's sinf / cosf (vina.hip sincos_ref, glibc's algorithm restated) on n host arguments.
+mi_status mi_debug_sincos(const float *x, int n, float *sn, float *cs) {
+  VTRY
+  MIG_CHECK(x && sn && cs && n >= 0, 1, "bad arguments");
+  if (n == 0) return MI_OK;
+  DevBuf<float> dx, ds, dc;
+  dx.upload(x, (size_t)n, nullptr);
+  ds.ensure((size_t)n);
+  dc.ensure((size_t)n);
+  launch_vina_sincos_probe(dx.p, n, ds.p, dc.p, nullptr);
+  MIG_HIP(hipMemcpy(sn, ds.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  MIG_HIP(hipMemcpy(cs, dc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// Diagnostic: ex[i] = the device's expf(x[i]), lg[i] = its logf(|x[i]|) (vina.hip expf_ref / logf_ref).
+mi_status mi_debug_explog(const float *x, int n, float *ex, float *lg) {
+  VTRY
+  MIG_CHECK(x && ex && lg && n >= 0, 1, "bad arguments");
+  if (n == 0) return MI_OK;
+  DevBuf<float> dx, de, dl;
+  dx.upload(x, (size_t)n, nullptr);
+  de.ensure((size_t)n);
+  dl.ensure((size_t)n);
+  launch_vina_explog_probe(dx.p, n, de.p, dl.p, nullptr);
+  MIG_HIP(hipMemcpy(ex, de.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  MIG_HIP(hipMemcpy(lg, dl.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// Energy sums of every evaluation of this handle in the reference's order (vina.hip seq_add) instead of the DPP
+// butterfly: with it, energies / gradients / BFGS and Monte-Carlo trajectories are bit-identical to the reference's
+// (tests/test_gpu_vina_ref.py); ~1 us per evaluation, so a mode.
+mi_status mi_vina_set_strict_order(mi_vina *vv, int on) {
+  VTRY
+  MIG_CHECK(vv && (on == 0 || on == 1), 1, "strict order: 0 or 1");
+  reinterpret_cast<Vina *>(vv)->strict = on == 1;
+  return MI_OK;
+  VCATCH_STATUS
+}
+
 // --approximation (main.cpp:989,1384-1391): which precalculate the handle evaluates pair terms with from now on.
 mi_status mi_vina_set_approximation(mi_vina *vv, int kind, float factor) {
   VTRY
@@ -426,13 +471,14 @@ mi_status mi_vina_set_approximation(mi_vina *vv, int kind, float factor) {
   Vina &v = *reinterpret_cast<Vina *>(vv);
   MIG_CHECK(kind == MI_VINA_APPROX_LINEAR || kind == MI_VINA_APPROX_SPLINE, 1, "approximation: 0 (linear) or 1 (spline)");
   if (kind == MI_VINA_APPROX_LINEAR) {
+    if (v.use_spline) v.have_cache = false;  // the lattice was populated from spline energies
     v.use_spline = false;
     return MI_OK;
   }
   MIG_CHECK(factor > 1.1920928955078125e-07f, 1, "approximation factor must be positive");
   build_splines(v, std::sqrt(v.cutoff_sqr), factor);
   v.use_spline = true;
-  v.have_cache = false;  // grids of the other approximation are not this one's
+  v.have_cache = false;  // grids of the other approximation (or of another spline factor) are not this one's
   return MI_OK;
   VCATCH_STATUS
 }
@@ -619,11 +665,15 @@ static void build_ligand(const mi_ligand_desc *d, LigandDev &out, hipStream_t st
   // contribution slots: atom i's list, in pair order, padded to a multiple of four (vina.h: slot_start / pair_slots)
   std::vector<int> aps(na + 1, 0), apl(2 * (size_t)np, 0), fill(na, 0);
   for (int i = 0; i < na; i++) aps[i + 1] = aps[i] + ((degree[i] + 3) & ~3);
-  for (int p = 0; p < np; p++) {
-    const int a = d->pairs[2 * p], b = d->pairs[2 * p + 1];
-    apl[2 * p] = aps[a] + fill[a]++;
-    apl[2 * p + 1] = aps[b] + fill[b]++;
-  }
+  // (model::eval_deriv adds the forces of other_pairs before the ligand's own, model.cu:209-216: an atom's list takes
+  // its other_pairs entries first, whatever the order of the caller's pair list)
+  for (int kind = 1; kind >= 0; kind--)
+    for (int p = 0; p < np; p++) {
+      if ((d->pair_kind ? (d->pair_kind[p] != 0 ? 1 : 0) : 0) != kind) continue;
+      const int a = d->pairs[2 * p], b = d->pairs[2 * p + 1];
+      apl[2 * p] = aps[a] + fill[a]++;
+      apl[2 * p + 1] = aps[b] + fill[b]++;
+    }
   // pack ints: smt, node_of, parent, abeg, aend, child_start, child_list, pairs, aps, apl
   std::vector<int> ints;
   auto pushi = [&](const int *p, size_t n) {
@@ -1186,6 +1236,7 @@ mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_c
     a.cnn_half = box->cnn_dimension / 2.0f;
   }
   a.slope = slope;
+  a.per_atom_forces = box && box->per_atom_forces ? 1 : 0;
   a.v = box && box->v > 0 ? box->v : 1000.0f;  // the curl cap `v` of eval_deriv(m, v, user_grid): user-grid term, blend
   if (box && with_deriv && (box->mix_emp_force || box->mix_emp_energy)) {
     MIG_CHECK(v.n_rec > 0, 4, "mix_emp_force / mix_emp_energy need the receptor (mi_vina_set_receptor)");

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI_GNINA_ABI_VERSION 1
+#define MI_GNINA_ABI_VERSION 2 /* 2: mi_ligand_desc gained n_movable / pair_kind / lig_begin / lig_end; mi_cnn_box per_atom_forces */
 
 typedef int mi_status;
 enum {
@@ -226,6 +226,19 @@ enum { MI_VINA_APPROX_LINEAR = 0, MI_VINA_APPROX_SPLINE = 1 };
  * Recipes' lnsrch) instead of fast_line_search; 0 (default) returns to the fast one.  mi_vina_mc_cnn_batch's device
  * chains support the fast search only. */
 mi_status mi_vina_set_line_search(mi_vina *, int kind);
+/* Strict summation order (on = 1): every energy sum of this handle's evaluations -- cache::eval / eval_deriv over the
+ * atoms (cache.cpp:52-83), non_cache over the receptor atoms (non_cache.cpp:52-83,125-179), the interacting pairs
+ * (model.cu:22-60) -- is added in the reference's order instead of a wavefront butterfly.  Forces, coordinates and
+ * sinf / cosf already follow the reference bit for bit in either mode; with strict order the energies do too, so BFGS
+ * runs and Monte-Carlo chains reproduce the reference's trajectories exactly (about 1 us more per evaluation; default
+ * 0).  Not covered: eval_intramolecular of a model with flexible residues. */
+mi_status mi_vina_set_strict_order(mi_vina *, int on);
+/* Diagnostic: sn[i], cs[i] = the device's sinf(x[i]), cosf(x[i]) as the Vina kernels compute them -- glibc's
+ * algorithm restated in fp64 so that tree.h / quaternion.h's std::sin / std::cos give the host's bits (|x| < 120). */
+mi_status mi_debug_sincos(const float *x, int n, float *sn, float *cs);
+/* ex[i] = the device's expf(x[i]) (Metropolis criterion, precalculate_exact), lg[i] = its logf(|x[i]|) (random_normal),
+ * likewise glibc's algorithms restated; logf for positive normal arguments. */
+mi_status mi_debug_explog(const float *x, int n, float *ex, float *lg);
 mi_status mi_vina_set_approximation(mi_vina *, int kind, float factor);
 /* precalculate::eval_deriv(a, b, r2) of the current approximation for one type pair: e[i], dor[i] = (E, (dE/dr) / r) at
  * r2[i] (host arrays; linear: r2 <= cutoff^2). */
@@ -375,6 +388,15 @@ typedef struct mi_cnn_box {
   int32_t mix_emp_force, mix_emp_energy;
   float empirical_weight;        /* default 1 */
   float v;                       /* authentic_v[1] = 1000 */
+  /* How the CNN's atom gradient reaches model::minus_forces.  0 (default) = as the reference does it:
+   * CNNTorchScorer::getGradient fills one entry per movable atom, hydrogens included (cnn_torch_scorer.cpp:208-228), and
+   * model::add_minus_forces (model.cu:247-259) walks the movable atoms with a counter that advances only on
+   * non-hydrogen atoms -- the k-th heavy atom receives entry k.  For a ligand whose hydrogens all follow its heavy
+   * atoms that is every atom's own gradient; with polar hydrogens in between (the usual PDBQT order) heavy atoms
+   * behind the first hydrogen receive a neighbour's.  gnina's own code running on HipCNNScorer through the DLScorer seam
+   * (tests/cpp/test_cnn_dropin.cpp) does exactly this, so the batched entry points default to it.
+   * 1 = every heavy atom its own gradient (what the formula intends; NOT what gnina computes). */
+  int32_t per_atom_forces;
 } mi_cnn_box;
 /* The `igrid` seam itself (igrid.h:32-46) for the cache igrid: cache::eval (minus_forces = NULL) / cache::eval_deriv
  * (cache.cpp:50-83) on B coordinate sets coords [B][n_atoms][3] of atoms with smina types smt [n_atoms] -- what a caller

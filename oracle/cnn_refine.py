@@ -13,7 +13,7 @@ class NonCacheCnn:
     """dl_scorer + the two penalty boxes.  blobs: list of cnn_ref.Blob (the ensemble)."""
 
     def __init__(self, blobs, rec_xyz, rec_smt, lig, search_box=None, cnn_dimension=23.5, mix_emp_force=False,
-                 mix_emp_energy=False, empirical_weight=1.0, tables=None, v=1000.0):
+                 mix_emp_energy=False, empirical_weight=1.0, tables=None, v=1000.0, per_atom_forces=False):
         self.blobs, self.rec_xyz, self.rec_smt, self.lig = blobs, rec_xyz, rec_smt, lig
         self.mix_emp_force, self.mix_emp_energy, self.weight = mix_emp_force, mix_emp_energy, empirical_weight
         self.tables, self.v = tables, v       # precalculate_linear tables (oracle.vina.Tables) for the empirical term
@@ -24,6 +24,7 @@ class NonCacheCnn:
         self.slope = 10.0
         self.evals = 0
         self.user_grid = None                 # (vina.GridDims, data [(n+1)^3]) of --user_grid, or None
+        self.per_atom_forces = per_atom_forces   # False = model::add_minus_forces' indexing (see eval_deriv)
 
     def adjust_center(self, conf):
         """DLScorer::set_center_from_model (dl_scorer.cpp:197-217): fp32 mean of the heavy movable atoms"""
@@ -101,11 +102,16 @@ class NonCacheCnn:
         e = np.float32(loss)
         forces = np.zeros_like(coords)
         w = np.float32(self.weight)
+        rank = 0                               # model::add_minus_forces' counter j (model.cu:247-259)
         for i in range(len(self.smt)):
             if self.smt[i] <= 1:
                 continue                       # hydrogens: minus_forces = 0
             pen, f = self._bounds(coords[i])
-            forces[i] = grad[i] + f
+            # the scorer's gradient has one entry per movable atom, hydrogens included (cnn_torch_scorer.cpp:208-228);
+            # add_minus_forces gives the k-th NON-HYDROGEN atom entry k -- pinned by gnina's own code running on
+            # HipCNNScorer (tests/cpp/test_cnn_dropin.cpp).  per_atom_forces: each atom its own entry instead.
+            forces[i] = grad[i if self.per_atom_forces else rank] + f
+            rank += 1
             emp_e = np.float32(0)
             uge, ugd = np.float32(0), np.zeros(3, dtype=np.float32)
             if self.user_grid is not None:      # non_cache_cnn.cpp:141-151: this_e / deriv, curled on their own

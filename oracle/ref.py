@@ -28,7 +28,7 @@ def build(force=False):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
     # the igrid drop-in test links the reference's objects with libmi_gnina.so: only once that exists
     if os.path.exists(os.path.join(os.path.dirname(HERE), "gnina_amd", "lib", "libmi_gnina.so")):
-        subprocess.run(cmd + ["dropin"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(cmd + ["dropin", "dropin_cnn"], check=True, stdout=subprocess.DEVNULL)
     return LIB
 
 
@@ -72,6 +72,8 @@ def lib():
         L.ref_conf_increment.argtypes = [vp, _f32p, _f32p, C.c_float]
         L.ref_mc.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int,
                              C.c_int, C.c_int, _f32p, _f32p, _f32p]
+        L.ref_mc_parallel.argtypes = [vp, C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
+                                      C.c_int, C.POINTER(C.c_double), _f32p]
         L.ref_mutate.argtypes = [vp, _f32p, C.c_uint, C.c_float]
         L.ref_within.argtypes = [vp, _f32p]
         L.ref_conf_independent.restype = C.c_float
@@ -269,6 +271,19 @@ class Scene:
                                 _p(_f(corner1)), _p(_f(corner2)), ig, self.conf_len, n_heavy, _p(e), _p(cf), _p(xyz)),
                    lambda r: r < 0)
         return e[:n], cf[:n], xyz[:n]
+
+    def mc_parallel(self, seeds, n_threads, n_steps, corner1, corner2, max_iters=None, num_saved=50, ig=0):
+        """parallel_mc's fan-out (parallel_mc.cpp:183-214): len(seeds) chains, private model copies, n_threads workers
+        over the shared cache.  Returns (wall seconds, best energy per chain)."""
+        if max_iters is None:
+            max_iters = (25 + self.n_movable) // 3
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        best = np.zeros(len(sd), dtype=np.float32)
+        sec = C.c_double(0.0)
+        _check(lib().ref_mc_parallel(self.h, sd.ctypes.data_as(C.POINTER(C.c_uint)), len(sd), int(n_threads), int(n_steps),
+                                     int(max_iters), int(num_saved), _p(_f(corner1)), _p(_f(corner2)), ig, C.byref(sec),
+                                     _p(best)))
+        return sec.value, best
 
     def mutate(self, conf, seed, amplitude=2.0):
         x = np.array(conf, dtype=np.float32, copy=True)

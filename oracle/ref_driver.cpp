@@ -12,6 +12,10 @@
 //   conf   = [position 3][orientation quaternion a,b,c,d][ligand torsions T_lig][flex torsions, residue by residue]
 //   change = [force 3][torque 3][ligand torsion derivatives][flex torsion derivatives]
 #include <cxxabi.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -547,6 +551,51 @@ int ref_mc(void *h, unsigned seed, int n_steps, int max_iters, int num_saved, fl
   }
   return n;
   RCATCH(-1)
+}
+// parallel_mc's threading model (parallel_mc.cpp:183-214, main.cpp:1418-1442): n_chains Monte-Carlo tasks, each with its
+// own copy of the model and its own generator, over ONE shared precalculate and igrid (both const), handed to
+// n_threads workers.  bench.py's C3 CPU baseline: returns the wall-clock seconds of the whole fan-out in *seconds
+// and every chain's best energy in best_e [n_chains] (so the work cannot be optimised away).
+int ref_mc_parallel(void *h, const unsigned *seeds, int n_chains, int n_threads, int n_steps, int max_iters,
+                    int num_saved, const float *corner1, const float *corner2, int ig, double *seconds, float *best_e) {
+  RTRY
+  Scene &s = *(Scene *)h;
+  igrid &g = pick_ig(s, ig);
+  const precalculate &p = run_prec(s);
+  const vec c1(corner1[0], corner1[1], corner1[2]), c2(corner2[0], corner2[1], corner2[2]);
+  std::atomic<int> next(0);
+  std::atomic<int> failed(0);
+  auto worker = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n_chains) return;
+      try {
+        monte_carlo mc;
+        mc.num_steps = (unsigned)n_steps;
+        mc.temperature = 1.2;
+        mc.ssd_par.evals = (unsigned)max_iters;
+        mc.ssd_par.minparm.maxiters = (unsigned)max_iters;
+        mc.min_rmsd = 1.0;
+        mc.num_saved_mins = (sz)num_saved;
+        mc.hunt_cap = vec(10, 10, 10);
+        rng generator(static_cast<rng::result_type>(seeds[i]));
+        output_container out;
+        model m = s.m0;  // parallel_mc_task holds its own model (parallel_mc.cpp:66-70)
+        mc(m, out, p, g, c1, c2, NULL, generator, s.user_grid, g);
+        best_e[i] = out.empty() ? 0.f : (float)out[0].e;
+      } catch (...) {
+        failed++;
+      }
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
+  for (auto &t : pool) t.join();
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (failed) throw std::runtime_error("a Monte-Carlo task threw");
+  return 0;
+  RCATCH(1)
 }
 // mutate_conf (mutate.cpp:35-73) with a seeded generator: one mutation of x, in place
 int ref_mutate(void *h, float *x, unsigned seed, float amplitude) {

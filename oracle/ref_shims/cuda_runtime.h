@@ -38,7 +38,8 @@ enum cudaMemcpyKind { cudaMemcpyHostToHost, cudaMemcpyHostToDevice, cudaMemcpyDe
 typedef void *cudaStream_t;
 typedef void *cudaEvent_t;
 #define cudaStreamPerThread ((cudaStream_t)0)
-struct cudaDeviceProp { size_t totalGlobalMem; char name[256]; int major, minor; };
+enum { cudaComputeModeDefault = 0, cudaComputeModeProhibited = 2 };
+struct cudaDeviceProp { size_t totalGlobalMem; char name[256]; int major, minor, computeMode; };
 inline cudaError_t cudaGetLastError() { return cudaSuccess; }
 inline cudaError_t cudaPeekAtLastError() { return cudaSuccess; }
 inline const char *cudaGetErrorString(cudaError_t) { return "no CUDA in oracle/_ref"; }

@@ -890,8 +890,8 @@ float ora_vina_refine(const ora_vina_tables *T, const ora_grid_dims *gd, const f
 }
 
 /* instrumentation for the design notes: how many trials the line searches take (index = trials used, 0..10) */
-static long g_trial_hist[11];
-static long g_mc_stats[4]; /* steps, accepted, accepted with a second BFGS, rotation mutations */
+static __thread long g_trial_hist[11]; /* per thread: bench.py runs chains on many threads */
+static __thread long g_mc_stats[4]; /* steps, accepted, accepted with a second BFGS, rotation mutations */
 void ora_vina_mc_stats(long *out, int reset) {
   for (int i = 0; i < 4; i++) {
     out[i] = g_mc_stats[i];

@@ -332,6 +332,10 @@ def test_rotated_scoring_equals_scoring_the_rotated_complex(capi, CG):
     assert abs(out["pose"][0] - plain["pose"][0]) < 1e-6 and np.abs(out["pose"][1:] - plain["pose"][1:]).max() > 1e-5
     s.set_rotations(q)
     g_rot = s.score_grad(poses, lig_smt, centers=centers)
+    s.set_rotations(q)
+    grids_rot, _ = s.voxelize_batch(poses, lig_smt, centers=centers)    # the exported grid is rotated as well ...
+    grids_plain, _ = s.voxelize_batch(poses, lig_smt, centers=centers)  # ... and the rotations are consumed by that call
+    assert np.abs(grids_rot[0] - grids_plain[0]).max() < 1e-5 and np.abs(grids_rot[1:] - grids_plain[1:]).max() > 1e-2   # (q[0] = identity)
     for b in range(B):
         R = _rot_matrix(q[b])
         c = centers[b].astype(np.float64)
@@ -339,6 +343,8 @@ def test_rotated_scoring_equals_scoring_the_rotated_complex(capi, CG):
         s2.set_receptor(((rec_xyz - c) @ R.T + c).astype(np.float32), rec_smt)
         lig_r = ((poses[b] - c) @ R.T + c).astype(np.float32)
         o2 = s2.score_grad(lig_r[None], lig_smt, centers=centers[b:b + 1])
+        g2, _ = s2.voxelize_batch(lig_r[None], lig_smt, centers=centers[b:b + 1])
+        assert np.abs(grids_rot[b] - g2[0]).max() < 2e-4                 # (atoms rotated in fp32 on the device, fp64 here)
         assert abs(out["pose"][b] - o2["pose"][0]) < 2e-5 and abs(out["affinity"][b] - o2["affinity"][0]) < 2e-4
         back = o2["lig_grad"][0] @ R                                   # R^T g, row-vector form
         scale = max(1e-6, np.abs(back).max())

@@ -259,3 +259,41 @@ def test_reference_code_runs_on_the_hip_igrid(tmp_path):
     mc = {l[1]: l for l in lines if l[0] == "mc_on"}
     assert int(mc["ref_cache"][3]) >= 1 and int(mc["hip_cache"][3]) >= 1
     assert np.isfinite(float(mc["hip_cache"][5]))
+
+
+@pytest.mark.gpu
+def test_reference_cnn_code_runs_on_the_hip_scorer(tmp_path):
+    """oracle/_ref/test_cnn_dropin: the PRIMARY seam against gnina's real headers.  HipCNNScorer derives from gnina's
+    own DLScorer (dl_scorer.h) and uses gnina's own setLigand / setReceptor (dl_scorer.cpp, unmodified); gnina's
+    non_cache_cnn::eval / eval_deriv (non_cache_cnn.cpp:33-169), model::eval_deriv (the CNN gradient folded by gnina's
+    tree code) and quasi_newton inside refine_structure's loop run on it -- next to the batched C-ABI entry points
+    (mi_cnn_eval_batch, mi_cnn_refine_batch, mi_scorer_score_batch) on the same real complex (GSK3B + adduct ligand)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_cnn_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_cnn_dropin is built where /root/reference exists (make -f oracle/Makefile.ref dropin_cnn)")
+    F = np.load(os.path.join(ROOT, "tests", "golden", "real_complex.npz"))
+    rec, lig = tmp_path / "rec.pdbqt", tmp_path / "lig.pdbqt"
+    rec.write_bytes(bytes(F["rec_pdbqt"]))
+    lig.write_bytes(bytes(F["lig_adduct_pdbqt"]))
+    r = subprocess.run([exe, str(rec), str(lig), os.path.join(ROOT, "gnina_amd", "weights"), "default2017"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n")]
+    ev = [l for l in lines if l[0] == "cnn_eval"]
+    assert len(ev) == 4
+    for l in ev:
+        g_eval, a_eval, g_der, a_der, dch, scale = (float(l[i]) for i in (3, 5, 7, 9, 11, 13))
+        assert abs(g_eval - a_eval) <= 1e-4 * max(1.0, abs(g_eval)), l        # non_cache_cnn::eval
+        assert abs(g_der - a_der) <= 1e-4 * max(1.0, abs(g_der)), l          # non_cache_cnn::eval_deriv (energy)
+        assert dch <= 2e-3 * max(1e-3, scale), l                              # ... folded into change by gnina's tree code
+    assert float(ev[3][3]) > float(ev[0][3]) + 1.0                            # the out-of-box pose pays the slope penalty
+    sc = [l for l in lines if l[0] == "score"][0]
+    seam, abi = [float(x) for x in sc[2:5]], [float(x) for x in sc[6:9]]
+    assert max(abs(a - b) for a, b in zip(seam, abi)) <= 1e-5                 # DLScorer::score == the batched entry point
+    rf = [l for l in lines if l[0] == "refine"][0]
+    start, on_seam, on_abi = float(rf[2]), float(rf[4]), float(rf[8])
+    assert np.isfinite(on_seam) and np.isfinite(on_abi)
+    assert on_seam < start and on_abi < start                                 # both minimise the CNN loss from the same start
+    assert abs(on_seam - on_abi) <= 0.1 * abs(start) + 0.05                   # ... to equivalent minima (CNN gradients amplify)
+    fc = [l for l in lines if l[0] == "fresh_copy"][0]
+    assert float(fc[1]) == float(fc[4]) and float(fc[2]) == float(fc[5])      # fresh_copy shares the device weights
