@@ -373,6 +373,13 @@ def config_c3_real(capi, cpu_seconds):
                 sample = int(max(20, min(steps, cpu_seconds / (sec / 40 * rounds))))
                 sec, best = sc.mc_parallel((seeds % np.uint64(2 ** 32)).astype(np.uint32), threads, sample, begin, end,
                                            max_iters=iters)
+                # parity at the full BASELINE size: the same chains in strict-order mode must END where the reference's end
+                vina.set_strict_order(True)
+                _, es, _, _, _ = vina.mc_batch(seeds, begin, end, capi.McParams.default(sample, iters, 50))
+                vina.set_strict_order(False)
+                same = int((es[:, 0].astype(np.float32).view(np.uint32) == best.view(np.uint32)).sum())
+                res["chains_bit_identical_to_reference"] = f"{same} of {len(seeds)} (strict-order mode, {sample} steps each: " \
+                                                           f"best energy of every chain compared bit for bit)"
                 res["cpu_baseline"] = {
                     "value": round(sec * steps / sample, 2), "unit": "s for the Monte-Carlo stage (64 chains)",
                     "cores": threads, "kind": "reference", "best_energy": float(best.min()),
@@ -640,6 +647,61 @@ def main():
             assert rccl["allgather_equals_single_rank"], "sharded scores differ from single-rank scores"
         dist.barrier()
 
+    # strong scaling beside the weak-scaling headline: ONE batch of 8,192 poses, contiguous shards over the ranks
+    # (SURVEY 8e), inputs resident in HBM, barrier + max over ranks like the timed region above
+    strong = None
+    try:
+        S_TOTAL = 8192
+        sp = synth.make_poses(np.random.RandomState(777), lig_xyz, S_TOTAL)
+        lo, hi = shard.shard_range(S_TOTAL, rank, world)
+        d_sp = torch.from_numpy(np.ascontiguousarray(sp[lo:hi])).to(dev)
+        d_so = torch.empty(4, hi - lo, dtype=torch.float32, device=dev)
+
+        def sstep():
+            scorer.score_batch_device(d_sp.data_ptr(), lig_smt, hi - lo, L, d_so[0].data_ptr(), d_so[1].data_ptr(),
+                                      d_so[2].data_ptr(), d_so[3].data_ptr())
+        sstep()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sstep()
+        scorer.synchronize()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / 3
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        strong = {"total_poses": S_TOTAL, "ranks": world, "ms": round(1e3 * dt_s, 3), "poses_per_s": round(S_TOTAL / dt_s, 1),
+                  "note": "one fixed batch, contiguous pose shards, max over ranks"}
+    except Exception as e:      # the headline line must still print
+        strong = {"error": f"{type(e).__name__}: {e}"}
+
+    # the C++ in-process pool (mi_pool: one host thread + scorer per GPU, RCCL scatter / gather for device-resident
+    # poses) over the same GPUs, driven by its C++ test driver in a child process while the ranks wait: pool sizes
+    # 1, 2, 4 .. N on one 8,192-pose batch, bit-equality with the single scorer checked inside the driver
+    pool_res = None
+    if rank == 0:
+        import subprocess
+        exe = os.path.join(ROOT, "gnina_amd", "lib", "test_pool")
+        try:
+            env = dict(os.environ)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), str(world), "8192"], capture_output=True,
+                               text=True, timeout=240, env=env)
+            rows = [l.split() for l in r.stdout.split("\n") if l.startswith("pool ")]
+            pool_res = {"driver": "tests/cpp/test_pool.cpp (C++ only)", "returncode": r.returncode,
+                        "sizes": [{"devices": int(l[2]), "host_path_equal": l[6] == "1", "host_path_poses_per_s": float(l[8]),
+                                   "device_path_equal": l[10] == "1", "device_path_poses_per_s": float(l[12])} for l in rows]}
+            if r.returncode != 0:
+                pool_res["stderr"] = r.stderr[-400:]
+        except Exception as e:
+            pool_res = {"error": f"{type(e).__name__}: {e}"}
+    if dist is not None:
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -697,6 +759,8 @@ def main():
         }
         if rccl is not None:
             res["rccl"] = rccl
+        res["strong_scaling"] = strong
+        res["pool_in_process"] = pool_res
         if world == 1:
             res["also"] = other_models(args, capi, synth, torch, dev)
             res["roofline"]["dense_no_skip"] = conv1_dense(args, scorer, step, max(3, min(args.steps, 10)))

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi_gnina.so")
-SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "vina.hip", "vina_host.cpp",
+SOURCES = ["engine.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "vina.hip", "vina_host.cpp", "pool.cpp",
            "../host/typed_atoms.cpp", "../host/pdbqt.cpp"]
 # -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
 # bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).
@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
             subprocess.run(cmd, check=True)
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -66,6 +66,15 @@ def build_host(force=False, verbose=False):
     if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", exe] + srcs + ["-L" + LIBDIR, "-lmi_gnina",
                                                                       "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    # the multi-device pool's C++ driver (tests/cpp/test_pool.cpp): C ABI + the HIP runtime API for its device buffers
+    pexe = os.path.join(LIBDIR, "test_pool")
+    psrc = os.path.join(root, "tests", "cpp", "test_pool.cpp")
+    if force or not os.path.exists(pexe) or os.path.getmtime(pexe) < max(os.path.getmtime(psrc), os.path.getmtime(LIB)):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", pexe, psrc,
+               "-L" + LIBDIR, "-lmi_gnina", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

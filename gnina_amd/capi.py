@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -213,6 +213,20 @@ def lib():
         L.mi_debug_sincos.restype = C.c_int
         L.mi_debug_explog.argtypes = [f32p, C.c_int, f32p, f32p]
         L.mi_debug_explog.restype = C.c_int
+        L.mi_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_char_p), C.c_int]
+        L.mi_pool_create.restype = vp
+        L.mi_pool_destroy.argtypes = [vp]
+        L.mi_pool_destroy.restype = None
+        L.mi_pool_size.argtypes = [vp]
+        L.mi_pool_size.restype = C.c_int
+        L.mi_pool_set_receptor.argtypes = [vp, vp, vp, C.c_int]
+        L.mi_pool_set_receptor.restype = C.c_int
+        L.mi_pool_score_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint]
+        L.mi_pool_score_batch.restype = C.c_int
+        L.mi_pool_score_ragged.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.mi_pool_score_ragged.restype = C.c_int
+        L.mi_pool_info_json.argtypes = [vp]
+        L.mi_pool_info_json.restype = C.c_char_p
         L.mi_vina_set_ligand.argtypes = [vp, C.POINTER(LigandDesc)]
         L.mi_vina_set_ligand.restype = C.c_int
         L.mi_vina_eval_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
@@ -944,6 +958,57 @@ def rank_poses(cnnscore, cnnaffinity, energy, coords, sort_order=0, min_rmsd=1.0
     check(lib().mi_rank_poses(_ptr(cs), _ptr(ca), _ptr(en), _ptr(coords), n, nh, sort_order, min_rmsd, _ptr(order),
                               C.byref(n_out)))
     return order[:n_out.value].copy()
+
+
+class Pool:
+    """mi_pool: one scorer per listed GPU in THIS process (C++ worker threads), pose shards run concurrently.
+    models: names of built-in blobs or paths."""
+
+    def __init__(self, models, devices=None):
+        if devices is None:
+            devices = list(range(lib().mi_gnina_device_count()))
+        paths = [m if os.path.exists(m) else os.path.join(_HERE, "weights", m + ".mgw") for m in models]
+        dv = (C.c_int * len(devices))(*devices)
+        pv = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        self.handle = lib().mi_pool_create(dv, len(devices), pv, len(paths))
+        if not self.handle:
+            raise MiGninaError(lib().mi_last_error().decode())
+        self.devices = list(devices)
+
+    def set_receptor(self, xyz, smt):
+        xyz, smt = _f32(xyz), _i32(smt)
+        check(lib().mi_pool_set_receptor(self.handle, _ptr(xyz), _ptr(smt), len(smt)))
+
+    def score_batch(self, lig_xyz, lig_smt, centers=None):
+        lig_xyz, lig_smt, centers = _f32(lig_xyz), _i32(lig_smt), _f32(centers)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        o = [np.empty(B, dtype=np.float32) for _ in range(4)]
+        check(lib().mi_pool_score_batch(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(o[0]),
+                                        _ptr(o[1]), _ptr(o[2]), _ptr(o[3]), 0))
+        return {"pose": o[0], "affinity": o[1], "loss": o[2], "variance": o[3]}
+
+    def score_batch_device(self, lig_ptr, lig_smt, B, L, pose_ptr, aff_ptr, loss_ptr, var_ptr=None, centers_ptr=None):
+        """poses / outputs resident on devices[0] (raw pointers): RCCL scatter / gather when the pool has > 1 device"""
+        lig_smt = _i32(lig_smt)
+        check(lib().mi_pool_score_batch(self.handle, lig_ptr, _ptr(lig_smt), B, L, centers_ptr, pose_ptr, aff_ptr, loss_ptr,
+                                        var_ptr, 3))
+
+    def score_ragged(self, lig_xyz, lig_smt, centers=None):
+        lig_xyz, lig_smt, centers = _f32(lig_xyz), _i32(lig_smt), _f32(centers)
+        B, L = lig_xyz.shape[0], lig_xyz.shape[1]
+        o = [np.empty(B, dtype=np.float32) for _ in range(4)]
+        check(lib().mi_pool_score_ragged(self.handle, _ptr(lig_xyz), _ptr(lig_smt), B, L, _ptr(centers), _ptr(o[0]),
+                                         _ptr(o[1]), _ptr(o[2]), _ptr(o[3])))
+        return {"pose": o[0], "affinity": o[1], "loss": o[2], "variance": o[3]}
+
+    def info(self):
+        import json
+        return json.loads(lib().mi_pool_info_json(self.handle).decode())
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().mi_pool_destroy(self.handle)
+            self.handle = None
 
 
 def device_libm(x):

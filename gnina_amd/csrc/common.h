@@ -55,4 +55,8 @@ template <typename T> struct DevBuf {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Kernels whose dynamic LDS request can exceed the 64 KB default need their limit raised -- once per DEVICE (the
+// attribute lives in the device's copy of the code object; a pool drives several devices from one process).
+void ensure_max_lds(const void *kernel, int bytes);
+
 }  // namespace mig

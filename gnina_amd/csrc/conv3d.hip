@@ -31,6 +31,7 @@
 //      ReLU'd activations: every quad listed, so the K order -- channel-major, ConvArgs::korder -- and with it the
 //      rounding does not depend on the tile);
 //   the N = 16 kernel of the Dense blocks does 2. on x * bn_scale, with the BatchNorm shift folded into a bias table.
+#include "common.h"
 #include "conv3d.h"
 
 #include <stdexcept>
@@ -780,12 +781,7 @@ template <int WM, int WN, int TM, int TN, int SP, bool MTX> static void launch_o
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_lds_bytes(p);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SP, MTX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  ensure_max_lds(reinterpret_cast<const void *>(conv3d_mfma_kernel<WM, WN, TM, TN, SP, MTX>), 160 * 1024);
   hipLaunchKernelGGL((conv3d_mfma_kernel<WM, WN, TM, TN, SP, MTX>), grid, block, lds, s, p);
 }
 
@@ -822,11 +818,8 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
       dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
       const size_t lds = conv_lds_bytes(p);
       const bool skip = p.sparse == 2;
-      static bool attr_set[4][2] = {};
-      bool &set = attr_set[cfg == CONV_CFG_N16_TM4 ? 3 : cfg == CONV_CFG_N16_TM3 ? 2 : cfg == CONV_CFG_N16_TM2 ? 1 : 0][skip];
       auto go = [&](auto kern) {
-        if (!set) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
+        ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
         hipLaunchKernelGGL(kern, grid, block, lds, s, p);
       };
       if (cfg == CONV_CFG_N16_TM4)

@@ -14,6 +14,7 @@
 // At the bf16 rate the MFMA pipe (32 cycles per instruction) is no longer the bound: every MFMA needs 1 KB of
 // A operand from LDS (128 B/clk/CU = one MFMA per SIMD per 32 clk with TN = 1), and the 16-output-channel
 // Dense-block layers fill half of a 32-wide tile, so the kernel is LDS-bandwidth / staging bound.
+#include "common.h"
 #include "conv3d.h"
 
 namespace mig {
@@ -339,12 +340,7 @@ size_t conv_bf16_lds_bytes(const ConvArgs &p) {
 template <int WM, int WN, int TM, int TN> static void launch_bf16(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_kernel<WM, WN, TM, TN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  ensure_max_lds(reinterpret_cast<const void *>(conv3d_bf16_kernel<WM, WN, TM, TN>), 160 * 1024);
   hipLaunchKernelGGL((conv3d_bf16_kernel<WM, WN, TM, TN>), grid, block, conv_bf16_lds_bytes(p), s, p);
 }
 

@@ -17,6 +17,9 @@
 #include <mutex>
 #include <numeric>
 
+#include <mutex>
+#include <set>
+
 #include "../../include/mi_gnina.h"
 #include "common.h"
 #include "conv3d.h"
@@ -28,6 +31,16 @@ namespace mig {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+void ensure_max_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({dev, kernel}).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 // -------------------------------------------------------------------------------------------
 // Model: parsed program + device weights

@@ -1,0 +1,409 @@
+// pool.cpp -- one node, many GPUs, ONE process: the C++ multi-device host path.
+//
+// What it replaces: gnina fans work out to worker threads, each with its own fresh_copy() of the scorer
+// (main.cpp:1418-1442, parallel_mc.cpp:183-214).  Here the fan-out is over devices: mi_pool owns one worker thread, one
+// HIP stream and one mi_scorer per GPU (weights and receptor replicated -- a few MB), a batch of poses is split into
+// contiguous shards [g*B/G, (g+1)*B/G) and the shards run concurrently; nothing is reduced across poses, so the data
+// path has no collective.
+//
+// Where the bytes travel:
+//  * host buffers (the DLScorer seam's case): every worker copies its own shard H2D and its scores D2H -- each GPU
+//    has its own PCIe link, so this is the fastest path and needs no GPU-to-GPU traffic at all;
+//  * device-resident poses (MI_LIG_ON_DEVICE: the docking kernels produced them on devices[0]): the shards are
+//    scattered from devices[0] and the scores gathered back to it over xGMI with RCCL point-to-point calls
+//    (ncclSend / ncclRecv inside one group: 12 B per pose back -- launch latency, not bandwidth), so a caller that
+//    keeps everything in HBM never touches the host.
+// librccl.so (570 MB) is opened on demand, only when a pool of more than one device takes the device-resident path;
+// single-GPU users and the host-buffer path never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+#include <vector>
+
+#include "../../include/mi_gnina.h"
+#include "common.h"
+
+namespace mig {
+
+namespace {
+
+// the handful of RCCL entry points the pool uses, bound at run time
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string &err) {
+    if (h) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) {
+      err = std::string("cannot open librccl.so: ") + dlerror();
+      return false;
+    }
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !Broadcast || !GetErrorString) {
+      err = "librccl.so lacks an expected symbol";
+      return false;
+    }
+    return true;
+  }
+};
+
+struct Worker {
+  int device = 0, rank = 0;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::packaged_task<std::string()>> q;
+  bool stop = false;
+  mi_scorer *scorer = nullptr;
+  std::vector<mi_model *> models;
+  hipStream_t stream = nullptr;  // for the RCCL scatter / gather and staging copies (the scorer has its own)
+  ncclComm_t comm = nullptr;
+  DevBuf<float> d_lig, d_cen, d_out;  // staging on this device for the device-resident path
+  void loop() {
+    for (;;) {
+      std::packaged_task<std::string()> t;
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        t = std::move(q.front());
+        q.pop_front();
+      }
+      t();
+    }
+  }
+  std::future<std::string> post(std::function<std::string()> f) {
+    std::packaged_task<std::string()> t(std::move(f));
+    auto fut = t.get_future();
+    {
+      std::lock_guard<std::mutex> l(mu);
+      q.push_back(std::move(t));
+    }
+    cv.notify_one();
+    return fut;
+  }
+};
+
+struct Pool {
+  std::vector<std::unique_ptr<Worker>> w;
+  Rccl rccl;
+  bool comms_ready = false;
+  long calls_host = 0, calls_device = 0;
+  std::string info;
+};
+
+// run f(worker) on every worker's thread; the first error message wins ("" = ok)
+std::string on_all(Pool &p, const std::function<std::string(Worker &)> &f) {
+  std::vector<std::future<std::string>> futs;
+  for (auto &wk : p.w) {
+    Worker *x = wk.get();
+    futs.push_back(x->post([x, &f] { return f(*x); }));
+  }
+  std::string err;
+  for (auto &fu : futs) {
+    std::string e = fu.get();
+    if (err.empty() && !e.empty()) err = e;
+  }
+  return err;
+}
+
+std::string last(const char *what) { return std::string(what) + ": " + mi_last_error(); }
+
+void shard(int B, int G, int g, int &b0, int &nb) {  // contiguous [g*B/G, (g+1)*B/G), SURVEY 8e
+  b0 = (int)((long)B * g / G);
+  nb = (int)((long)B * (g + 1) / G) - b0;
+}
+
+}  // namespace
+}  // namespace mig
+
+using namespace mig;
+
+#define PTRY try {
+#define PCATCH_STATUS                 \
+  }                                   \
+  catch (const mig::Error &e) {       \
+    mig::set_last_error(e.what());    \
+    return (mi_status)e.code;         \
+  }                                   \
+  catch (const std::exception &e) {   \
+    mig::set_last_error(e.what());    \
+    return MI_ERR_DEVICE;             \
+  }
+
+extern "C" {
+
+mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *model_paths, int n_models) {
+  try {
+    MIG_CHECK(devices && n_devices > 0 && model_paths && n_models > 0, 1, "bad arguments");
+    const int have = mi_gnina_device_count();
+    for (int g = 0; g < n_devices; g++) {
+      MIG_CHECK(devices[g] >= 0 && devices[g] < have, 1, "device index out of range");
+      for (int k = 0; k < g; k++) MIG_CHECK(devices[k] != devices[g], 1, "a device is listed twice");
+    }
+    auto p = std::make_unique<Pool>();
+    for (int g = 0; g < n_devices; g++) {
+      auto wk = std::make_unique<Worker>();
+      wk->device = devices[g];
+      wk->rank = g;
+      Worker *x = wk.get();
+      x->th = std::thread([x] { x->loop(); });
+      p->w.push_back(std::move(wk));
+    }
+    std::vector<std::string> paths(model_paths, model_paths + n_models);
+    const std::string err = on_all(*p, [&](Worker &x) -> std::string {
+      if (mi_gnina_init(x.device) != MI_OK) return last("mi_gnina_init");  // hipSetDevice for this worker thread
+      if (hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+      for (const std::string &path : paths) {
+        mi_model *m = mi_model_load_file(path.c_str());  // weights are replicated: one device-resident copy per GPU
+        if (!m) return last("mi_model_load_file");
+        x.models.push_back(m);
+      }
+      x.scorer = mi_scorer_create(x.models.data(), (int)x.models.size());
+      if (!x.scorer) return last("mi_scorer_create");
+      return "";
+    });
+    if (!err.empty()) {
+      mi_pool_destroy(reinterpret_cast<mi_pool *>(p.release()));
+      throw mig::Error(3, err);
+    }
+    return reinterpret_cast<mi_pool *>(p.release());
+  } catch (const mig::Error &e) {
+    mig::set_last_error(e.what());
+  } catch (const std::exception &e) {
+    mig::set_last_error(e.what());
+  }
+  return nullptr;
+}
+
+void mi_pool_destroy(mi_pool *pp) {
+  if (!pp) return;
+  Pool *p = reinterpret_cast<Pool *>(pp);
+  (void)on_all(*p, [&](Worker &x) -> std::string {
+    if (x.comm && p->rccl.CommDestroy) p->rccl.CommDestroy(x.comm);
+    if (x.scorer) mi_scorer_destroy(x.scorer);
+    for (mi_model *m : x.models) mi_model_release(m);
+    x.d_lig.release();
+    x.d_cen.release();
+    x.d_out.release();
+    if (x.stream) (void)hipStreamDestroy(x.stream);
+    return "";
+  });
+  for (auto &wk : p->w) {
+    {
+      std::lock_guard<std::mutex> l(wk->mu);
+      wk->stop = true;
+    }
+    wk->cv.notify_one();
+    if (wk->th.joinable()) wk->th.join();
+  }
+  delete p;
+}
+
+int mi_pool_size(const mi_pool *pp) { return pp ? (int)reinterpret_cast<const Pool *>(pp)->w.size() : 0; }
+
+mi_status mi_pool_set_receptor(mi_pool *pp, const float *xyz, const int32_t *smt, int n_atoms) {
+  PTRY
+  MIG_CHECK(pp && xyz && smt && n_atoms > 0, 1, "bad arguments");
+  Pool &p = *reinterpret_cast<Pool *>(pp);
+  // replicated: every GPU types and uploads the same 16 B per atom over its own PCIe link (tens of KB -- a broadcast
+  // over xGMI would only add a hop)
+  const std::string err = on_all(p, [&](Worker &x) -> std::string {
+    return mi_scorer_set_receptor(x.scorer, xyz, smt, n_atoms) == MI_OK ? "" : last("mi_scorer_set_receptor");
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+static void ensure_comms(Pool &p) {
+  if (p.comms_ready) return;
+  std::string err;
+  MIG_CHECK(p.rccl.load(err), 3, err);
+  std::vector<int> devs;
+  for (auto &wk : p.w) devs.push_back(wk->device);
+  std::vector<ncclComm_t> comms(devs.size());
+  const ncclResult_t r = p.rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+  MIG_CHECK(r == ncclSuccess, 3, std::string("ncclCommInitAll: ") + p.rccl.GetErrorString(r));
+  for (size_t g = 0; g < devs.size(); g++) p.w[g]->comm = comms[g];
+  p.comms_ready = true;
+}
+
+mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                              const float *centers, float *pose, float *affinity, float *loss, float *aff_var,
+                              unsigned flags) {
+  PTRY
+  MIG_CHECK(pp && B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)) && pose && affinity && loss, 1, "bad arguments");
+  Pool &p = *reinterpret_cast<Pool *>(pp);
+  const int G = (int)p.w.size();
+  const bool in_dev = (flags & MI_LIG_ON_DEVICE) != 0, out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
+  MIG_CHECK(in_dev == out_dev || G == 1, 1,
+            "a multi-device pool takes host inputs with host outputs, or device inputs with device outputs (on devices[0])");
+  if (B == 0) return MI_OK;
+  if (G == 1) {  // nothing to shard: the single scorer, same bits as mi_scorer_score_batch
+    const std::string err = on_all(p, [&](Worker &x) -> std::string {
+      if (mi_scorer_score_batch_ex(x.scorer, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, flags) != MI_OK)
+        return last("mi_scorer_score_batch_ex");
+      if (out_dev && mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
+      return "";
+    });
+    MIG_CHECK(err.empty(), 3, err);
+    return MI_OK;
+  }
+  if (!in_dev) {  // host buffers: every worker moves its own shard over its own PCIe link
+    p.calls_host++;
+    const std::string err = on_all(p, [&](Worker &x) -> std::string {
+      int b0, nb;
+      shard(B, G, x.rank, b0, nb);
+      if (nb == 0) return "";
+      return mi_scorer_score_batch(x.scorer, lig_xyz + (size_t)b0 * L * 3, lig_smt, nb, L,
+                                   centers ? centers + (size_t)b0 * 3 : nullptr, pose + b0, affinity + b0, loss + b0,
+                                   aff_var ? aff_var + b0 : nullptr) == MI_OK
+                 ? ""
+                 : last("mi_scorer_score_batch");
+    });
+    MIG_CHECK(err.empty(), 3, err);
+    return MI_OK;
+  }
+  // device-resident: poses / centres / outputs live on devices[0]; scatter and gather over xGMI with RCCL
+  ensure_comms(p);
+  p.calls_device++;
+  Rccl &R = p.rccl;
+  const std::string err = on_all(p, [&](Worker &x) -> std::string {
+    auto nc = [&](ncclResult_t r, const char *what) -> std::string {
+      return r == ncclSuccess ? "" : std::string(what) + ": " + R.GetErrorString(r);
+    };
+    try {
+      int b0, nb;
+      shard(B, G, x.rank, b0, nb);
+      const float *my_lig = lig_xyz, *my_cen = centers;
+      // 1. scatter: rank 0 sends shard g to rank g, rank g receives it (one group per rank = one fused transfer set)
+      std::string e = nc(R.GroupStart(), "ncclGroupStart");
+      if (!e.empty()) return e;
+      if (x.rank == 0) {
+        for (int g = 1; g < G; g++) {
+          int c0, cn;
+          shard(B, G, g, c0, cn);
+          if (cn == 0) continue;
+          if (!(e = nc(R.Send(lig_xyz + (size_t)c0 * L * 3, (size_t)cn * L * 3, ncclFloat, g, x.comm, x.stream), "ncclSend")).empty()) return e;
+          if (centers && !(e = nc(R.Send(centers + (size_t)c0 * 3, (size_t)cn * 3, ncclFloat, g, x.comm, x.stream), "ncclSend")).empty()) return e;
+        }
+      } else if (nb > 0) {
+        x.d_lig.ensure((size_t)nb * L * 3);
+        if (!(e = nc(R.Recv(x.d_lig.p, (size_t)nb * L * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv")).empty()) return e;
+        my_lig = x.d_lig.p;
+        if (centers) {
+          x.d_cen.ensure((size_t)nb * 3);
+          if (!(e = nc(R.Recv(x.d_cen.p, (size_t)nb * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv")).empty()) return e;
+          my_cen = x.d_cen.p;
+        }
+      }
+      if (!(e = nc(R.GroupEnd(), "ncclGroupEnd")).empty()) return e;
+      MIG_HIP(hipStreamSynchronize(x.stream));
+      // 2. score the shard on this device (device in, device out)
+      float *o_pose, *o_aff, *o_loss, *o_var;
+      if (x.rank == 0) {
+        o_pose = pose, o_aff = affinity, o_loss = loss, o_var = aff_var;
+      } else {
+        x.d_out.ensure((size_t)4 * std::max(nb, 1));
+        o_pose = x.d_out.p, o_aff = o_pose + nb, o_loss = o_aff + nb, o_var = aff_var ? o_loss + nb : nullptr;
+      }
+      if (nb > 0) {
+        if (mi_scorer_score_batch_ex(x.scorer, x.rank == 0 ? lig_xyz : my_lig, lig_smt, nb, L, x.rank == 0 ? centers : my_cen,
+                                     o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
+          return last("mi_scorer_score_batch_ex");
+        if (mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
+      }
+      // 3. gather the scores on devices[0], straight into the caller's arrays
+      if (!(e = nc(R.GroupStart(), "ncclGroupStart")).empty()) return e;
+      const int n_arr = aff_var ? 4 : 3;
+      if (x.rank == 0) {
+        float *dst[4] = {pose, affinity, loss, aff_var};
+        for (int g = 1; g < G; g++) {
+          int c0, cn;
+          shard(B, G, g, c0, cn);
+          for (int a = 0; a < n_arr && cn > 0; a++)
+            if (!(e = nc(R.Recv(dst[a] + c0, (size_t)cn, ncclFloat, g, x.comm, x.stream), "ncclRecv")).empty()) return e;
+        }
+      } else if (nb > 0) {
+        for (int a = 0; a < n_arr; a++)
+          if (!(e = nc(R.Send(x.d_out.p + (size_t)a * nb, (size_t)nb, ncclFloat, 0, x.comm, x.stream), "ncclSend")).empty()) return e;
+      }
+      if (!(e = nc(R.GroupEnd(), "ncclGroupEnd")).empty()) return e;
+      MIG_HIP(hipStreamSynchronize(x.stream));
+      return "";
+    } catch (const std::exception &ex) {
+      return ex.what();
+    }
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+// The virtual-screen seam (config C4): B poses of DIFFERENT ligands, rows padded to Lmax with smt = -1
+// (mi_scorer_score_ragged's layout), host buffers; contiguous pose shards, results in input order.
+mi_status mi_pool_score_ragged(mi_pool *pp, const float *lig_xyz, const int32_t *lig_smt, int B, int Lmax,
+                               const float *centers, float *pose, float *affinity, float *loss, float *aff_var) {
+  PTRY
+  MIG_CHECK(pp && B >= 0 && Lmax >= 0 && (B == 0 || (lig_xyz && lig_smt)) && pose && affinity && loss, 1, "bad arguments");
+  Pool &p = *reinterpret_cast<Pool *>(pp);
+  const int G = (int)p.w.size();
+  if (B == 0) return MI_OK;
+  p.calls_host++;
+  const std::string err = on_all(p, [&](Worker &x) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);
+    if (nb == 0) return "";
+    return mi_scorer_score_ragged(x.scorer, lig_xyz + (size_t)b0 * Lmax * 3, lig_smt + (size_t)b0 * Lmax, nb, Lmax,
+                                  centers ? centers + (size_t)b0 * 3 : nullptr, pose + b0, affinity + b0, loss + b0,
+                                  aff_var ? aff_var + b0 : nullptr) == MI_OK
+               ? ""
+               : last("mi_scorer_score_ragged");
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+const char *mi_pool_info_json(mi_pool *pp) {
+  if (!pp) return "{}";
+  Pool &p = *reinterpret_cast<Pool *>(pp);
+  std::ostringstream o;
+  o << "{\"devices\": [";
+  for (size_t g = 0; g < p.w.size(); g++) o << (g ? ", " : "") << p.w[g]->device;
+  o << "], \"ranks\": " << p.w.size() << ", \"rccl_loaded\": " << (p.rccl.h ? "true" : "false")
+    << ", \"rccl_comms\": " << (p.comms_ready ? "true" : "false") << ", \"calls_host_path\": " << p.calls_host
+    << ", \"calls_device_path\": " << p.calls_device << "}";
+  p.info = o.str();
+  return p.info.c_str();
+}
+
+}  // extern "C"

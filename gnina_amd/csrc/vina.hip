@@ -30,6 +30,7 @@
 #include <mutex>
 #include <set>
 
+#include "common.h"
 #include "vina.h"
 
 namespace mig {
@@ -489,12 +490,7 @@ __device__ __forceinline__ VinaLigand stage_ligand(const VinaLigand &G, float *&
 constexpr size_t kVinaMaxLds = 160 * 1024;
 template <class K>
 static void big_lds(K kernel) {
-  static std::mutex mu;
-  static std::set<const void *> done;  // kernels of one signature share this instantiation: key by address
-  const void *fn = reinterpret_cast<const void *>(kernel);
-  std::lock_guard<std::mutex> lock(mu);
-  if (done.insert(fn).second)
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVinaMaxLds);
+  ensure_max_lds(reinterpret_cast<const void *>(kernel), (int)kVinaMaxLds);  // once per device and kernel
 }
 
 static size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
@@ -2071,13 +2067,27 @@ __device__ __forceinline__ void mutate_wave(const VinaEnv &env, const VinaLigand
     float acc = 0.f;
     int n_gyr = 0;
     for (int i = L.lig_begin; i < L.lig_end; i++) n_gyr += L.smt[i] > 1;
-    for (int i = L.lig_begin + lane; i < L.lig_end; i += 64)
-      if (L.smt[i] > 1) {
-        const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
-                    dz = w.coords[3 * i + 2] - w.origin[2];
-        acc += dx * dx + dy * dy + dz * dz;
+    if (env.strict) {  // the reference's loop adds the atoms one after the other (model.cpp:1002-1014)
+      for (int base = L.lig_begin; base < L.lig_end; base += 64) {
+        const int i = base + lane;
+        const bool on = i < L.lig_end && L.smt[i < L.lig_end ? i : base] > 1;
+        float d2 = 0.f;
+        if (on) {
+          const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
+                      dz = w.coords[3 * i + 2] - w.origin[2];
+          d2 = dx * dx + dy * dy + dz * dz;
+        }
+        seq_add(acc, d2, __builtin_amdgcn_ballot_w64(on));
       }
-    acc = wave_sum(acc);
+    } else {
+      for (int i = L.lig_begin + lane; i < L.lig_end; i += 64)
+        if (L.smt[i] > 1) {
+          const float dx = w.coords[3 * i] - w.origin[0], dy = w.coords[3 * i + 1] - w.origin[1],
+                      dz = w.coords[3 * i + 2] - w.origin[2];
+          acc += dx * dx + dy * dy + dz * dz;
+        }
+      acc = wave_sum(acc);
+    }
     const float gr = n_gyr > 0 ? sqrtf(acc / (float)n_gyr) : 0.f;  // model::gyration_radius, model.cpp:1002-1014
     if (gr > VEPS) {
       float dx, dy, dz;

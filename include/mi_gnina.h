@@ -172,6 +172,31 @@ mi_status mi_model_forward_grids(mi_scorer *, int m, const float *grids, int B, 
 /* Stream plumbing for benchmarks: the hipStream_t all work of this scorer is enqueued on. */
 void *mi_scorer_stream(mi_scorer *);
 mi_status mi_scorer_synchronize(mi_scorer *);
+
+/* ---- one node, many GPUs, one process ---------------------------------------------------------------
+ * Replaces the worker / thread-pool fan-out of gnina (one DLScorer::fresh_copy() per worker thread, main.cpp:1418-1442;
+ * parallel_mc.cpp:183-214) by a fan-out over devices: mi_pool owns one host thread, one stream and one mi_scorer per
+ * listed GPU -- model weights and the receptor are replicated (a few MB) -- and splits a batch of B poses into
+ * contiguous shards [g B/G, (g+1) B/G) that run concurrently.  Poses are independent: no collective on the data path;
+ * results land in the caller's arrays in pose order and equal, bit for bit, what one mi_scorer returns for the batch.
+ *   host buffers    every worker moves its own shard over its own PCIe link (no GPU-to-GPU traffic);
+ *   MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE
+ *                   poses / centres / outputs live on devices[0]: shards are scattered and the scores gathered over
+ *                   xGMI with RCCL (ncclSend / ncclRecv groups); librccl.so is opened on first use of this path only.
+ * A pool of one device forwards to its single scorer (any flag combination).  Not thread-safe: one caller at a time. */
+typedef struct mi_pool mi_pool;
+mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *model_paths, int n_models);
+void mi_pool_destroy(mi_pool *);
+int mi_pool_size(const mi_pool *);
+mi_status mi_pool_set_receptor(mi_pool *, const float *xyz, const int32_t *smt, int n_atoms);
+/* mi_scorer_score_batch_ex over the pool's devices (flags as above) */
+mi_status mi_pool_score_batch(mi_pool *, const float *lig_xyz, const int32_t *lig_smt, int B, int L, const float *centers,
+                              float *pose, float *affinity, float *loss, float *aff_var, unsigned flags);
+/* mi_scorer_score_ragged over the pool's devices: the virtual-screen seam (config C4), host buffers */
+mi_status mi_pool_score_ragged(mi_pool *, const float *lig_xyz, const int32_t *lig_smt, int B, int Lmax,
+                               const float *centers, float *pose, float *affinity, float *loss, float *aff_var);
+/* {"devices": [...], "ranks": G, "rccl_loaded": bool, "rccl_comms": bool, "calls_host_path": n, "calls_device_path": n} */
+const char *mi_pool_info_json(mi_pool *);
 /* Max poses processed per internal chunk (activation workspace is sized for it). */
 mi_status mi_scorer_set_chunk(mi_scorer *, int poses_per_chunk);
 /* Per-stage device time of the last score call, milliseconds, measured with HIP events on the

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for sym in declared_functions():
         assert hasattr(L, sym), f"libmi_gnina.so does not export {sym}"
-    assert L.mi_gnina_abi_version() == 1
+    assert L.mi_gnina_abi_version() == capi.ABI_VERSION == 2
 
 
 def test_no_torch_or_oracle_dependency(capi):

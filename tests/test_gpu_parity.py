@@ -43,7 +43,7 @@ def oracle_maps(blob):
 
 def test_library_loaded_and_device(capi):
     assert capi.lib().mi_gnina_device_count() >= 1
-    assert capi.lib().mi_gnina_abi_version() == 1
+    assert capi.lib().mi_gnina_abi_version() == capi.ABI_VERSION
 
 
 def test_typer_bit_exact(capi):

@@ -297,3 +297,52 @@ def test_reference_cnn_code_runs_on_the_hip_scorer(tmp_path):
     assert abs(on_seam - on_abi) <= 0.1 * abs(start) + 0.05                   # ... to equivalent minima (CNN gradients amplify)
     fc = [l for l in lines if l[0] == "fresh_copy"][0]
     assert float(fc[1]) == float(fc[4]) and float(fc[2]) == float(fc[5])      # fresh_copy shares the device weights
+
+
+@pytest.mark.gpu
+def test_multi_device_pool_from_cpp():
+    """mi_pool (the C++ multi-device host path): tests/cpp/test_pool.cpp creates a pool over every visible
+    GPU from C++ (worker thread + scorer per device, contiguous pose shards) and scores one batch through the host-buffer
+    path and the device-resident path (RCCL scatter / gather over xGMI when there is more than one device): both must
+    equal the single-scorer result bit for bit.  One GPU here: the pool forwards to its single scorer; with N > 1
+    visible the same binary exercises the sharded paths and prints strong-scaling rates."""
+    exe = os.path.join(ROOT, "gnina_amd", "lib", "test_pool")
+    assert os.path.exists(exe), "run `python __graft_entry__.py build`"
+    r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), "0", "600"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("pool ")]
+    assert rows, r.stdout
+    for l in rows:
+        assert l[6] == "1" and l[10] == "1", l          # host_path_equal, device_path_equal
+    n_vis = int([l for l in r.stdout.split("\n") if l.startswith("devices_visible")][0].split()[1])
+    assert int(rows[-1][2]) == n_vis                    # the largest pool spans every visible device
+
+
+@pytest.mark.gpu
+def test_pool_python_binding_matches_single_scorer():
+    from gnina_amd import capi, synth
+    capi.init(0)
+    m = capi.Model("crossdock_default2018")
+    rng = np.random.RandomState(3)
+    rx, rs = synth.make_receptor(rng, 1500, synth.mapped_types(m.chan_of_smt(False)))
+    lx, ls = synth.make_ligand(rng, 24, synth.mapped_types(m.chan_of_smt(True)))
+    poses = synth.make_poses(rng, lx, 77)
+    s = capi.Scorer([m])
+    s.set_receptor(rx, rs)
+    want = s.score_batch(poses, ls)
+    p = capi.Pool(["crossdock_default2018"])
+    p.set_receptor(rx, rs)
+    got = p.score_batch(poses, ls)
+    for k in ("pose", "affinity", "loss"):
+        assert np.array_equal(want[k], got[k]), k
+    # ragged (virtual-screen) seam through the pool
+    Lmax = 30
+    xyz = np.zeros((40, Lmax, 3), np.float32)
+    smt = np.full((40, Lmax), -1, np.int32)
+    for b in range(40):
+        L = rng.randint(10, Lmax + 1)
+        a, t = synth.make_ligand(rng, L, synth.mapped_types(m.chan_of_smt(True)))
+        xyz[b, :L], smt[b, :L] = a, t
+    w2, g2 = s.score_ragged(xyz, smt), p.score_ragged(xyz, smt)
+    assert np.array_equal(w2["pose"], g2["pose"]) and np.array_equal(w2["affinity"], g2["affinity"])
+    assert p.info()["ranks"] == len(p.devices)
