@@ -1852,6 +1852,10 @@ mi_status mi_scorer_score_flex(mi_scorer *sc, const float *lig_xyz, const int32_
   MI_CATCH_STATUS
 }
 
+int mi_scorer_flex_count(const mi_scorer *sc) {
+  return sc ? (int)reinterpret_cast<const Scorer *>(sc)->flex_rows.size() : 0;
+}
+
 int mi_model_supports_gradient(const mi_model *m) {
   return m && reinterpret_cast<const Model *>(m)->grad_supported ? 1 : 0;
 }

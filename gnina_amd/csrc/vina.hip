@@ -1211,8 +1211,8 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
     const int i = base + lane;
     if (i >= L.n_atoms) continue;  // (only in the last block: the ballot below then counts the live lanes, all it needs)
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    const bool heavy = L.smt[i] > 1;
-    const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy && i < L.n_movable);
+    const bool heavy = L.smt[i] > 1 && i < L.n_movable;  // (inflex atoms: no minus_forces entry)
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy);
     const int rank = heavy_before + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
     heavy_before += __builtin_popcountll(hm);
     if (heavy) {  // hydrogens: minus_forces = 0, no penalty (non_cache_cnn.cpp:92-96)
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(64) void vina_extforce_kernel(VinaEnv env, VinaLiga
     // its coordinates clamped to the search box, curl-capped, is blended into the CNN force:
     //   minus_forces = (cnn + penalties + w (emp_deriv + search-box penalty force)) / (1 + w)
     // The 64 lanes stride the receptor for one ligand atom at a time (like the non_cache igrid).
-    for (int i = 0; i < L.n_atoms; i++) {
+    for (int i = 0; i < L.n_movable; i++) {
       const int t1 = L.smt[i];
       if (t1 <= 1) continue;
       float adj[3], oobd[3] = {0.f, 0.f, 0.f};

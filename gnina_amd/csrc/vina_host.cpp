@@ -1197,6 +1197,7 @@ namespace {
 // the fold into change.  Scratch vectors live in the caller so the refinement loop does not reallocate.
 struct CnnEvalScratch {
   std::vector<float> coords, lig_grad, pose, aff, loss, var;
+  std::vector<float> lig_xyz, flex_xyz, lg, fg;  // combined model: ligand / side-chain rows and their gradients
 };
 
 mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_cnn_box *box, const float *cnn_centers,
@@ -1207,13 +1208,45 @@ mi_status cnn_eval(Vina &v, mi_scorer *sc, const float *confs, int B, const mi_c
   mi_status st = mi_vina_coords_batch(reinterpret_cast<mi_vina *>(&v), confs, B, s.coords.data());
   if (st != MI_OK) return st;
   // grid centre = NaN -> recomputed from the ligand on every forward (cnn_torch_scorer.cpp:137-142)
-  if (with_deriv) {
-    s.lig_grad.resize((size_t)B * na * 3);
-    st = mi_scorer_score_grad(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
-                              s.loss.data(), s.var.data(), s.lig_grad.data());
+  const int lb = v.lig.lig_begin, le = v.lig.lig_end;
+  const bool combined = le - lb != na;  // gnina's combined model: atoms = [flexible side chains | ligand | inflex]
+  if (!combined) {
+    if (with_deriv) {
+      s.lig_grad.resize((size_t)B * na * 3);
+      st = mi_scorer_score_grad(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
+                                s.loss.data(), s.var.data(), s.lig_grad.data());
+    } else {
+      st = mi_scorer_score_batch(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
+                                 s.loss.data(), s.var.data());
+    }
   } else {
-    st = mi_scorer_score_batch(sc, s.coords.data(), v.h_lig_smt.data(), B, na, nullptr, s.pose.data(), s.aff.data(),
-                               s.loss.data(), s.var.data());
+    // DLScorer::setLigand takes the ligand's atoms, setReceptor refreshes the movable side-chain atoms -- the first rows
+    // of the scorer's receptor, declared with mi_scorer_set_flex (dl_scorer.cpp:36-193) -- and getGradient sends both
+    // gradients back by movable-atom index (cnn_torch_scorer.cpp:208-228): s.lig_grad ends up indexed like the model's
+    // atoms, [side chains | ligand | inflex (no force)].
+    const int nl = le - lb, nf = lb;
+    MIG_CHECK(mi_scorer_flex_count(sc) == nf, 1,
+              "the combined model has " + std::to_string(nf) + " movable side-chain atoms but the scorer declares " +
+                  std::to_string(mi_scorer_flex_count(sc)) + " flexible receptor rows (mi_scorer_set_flex: the first rows of "
+                  "mi_pdbqt_read_receptor_flex's output)");
+    s.lig_xyz.resize((size_t)B * nl * 3), s.flex_xyz.resize((size_t)B * nf * 3);
+    for (int b = 0; b < B; b++) {
+      const float *c = &s.coords[(size_t)b * na * 3];
+      std::copy(c, c + 3 * nf, s.flex_xyz.begin() + (size_t)b * nf * 3);
+      std::copy(c + 3 * lb, c + 3 * le, s.lig_xyz.begin() + (size_t)b * nl * 3);
+    }
+    if (with_deriv) s.lg.resize((size_t)B * nl * 3), s.fg.resize((size_t)B * nf * 3);
+    st = mi_scorer_score_flex(sc, s.lig_xyz.data(), v.h_lig_smt.data() + lb, B, nl, nullptr, nf ? s.flex_xyz.data() : nullptr,
+                              s.pose.data(), s.aff.data(), s.loss.data(), s.var.data(), with_deriv ? s.lg.data() : nullptr,
+                              with_deriv && nf ? s.fg.data() : nullptr);
+    if (st == MI_OK && with_deriv) {
+      s.lig_grad.assign((size_t)B * na * 3, 0.f);
+      for (int b = 0; b < B; b++) {
+        float *g = &s.lig_grad[(size_t)b * na * 3];
+        std::copy(s.fg.begin() + (size_t)b * nf * 3, s.fg.begin() + (size_t)(b + 1) * nf * 3, g);
+        std::copy(s.lg.begin() + (size_t)b * nl * 3, s.lg.begin() + (size_t)(b + 1) * nl * 3, g + 3 * lb);
+      }
+    }
   }
   if (st != MI_OK) return st;
   // penalties + fold (confs are still in v.d_confs from the coordinate launch)
@@ -1496,7 +1529,6 @@ mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t
   Vina &v = *reinterpret_cast<Vina *>(vv);
   MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
   MIG_CHECK(!v.accurate_ls, 1, "the device CNN Monte-Carlo chains run fast_line_search only (see mi_vina_set_line_search)");
-  MIG_CHECK(v.lig.n_movable == v.lig.n_atoms, 1, "flexible residues are not supported with the CNN in the loop yet");
   MIG_CHECK(P->num_saved > 0 && P->num_saved <= 64 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1,
             "bad Monte-Carlo parameters (num_saved must be in [1, 64], n_steps >= 1)");
   if (B == 0) return MI_OK;
@@ -1568,7 +1600,7 @@ mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t
       float s0 = 0, s1_ = 0, s2 = 0;
       unsigned cnt = 0;
       const float *xyz = &coords[(size_t)b * na * 3];
-      for (int i = 0; i < na; i++)
+      for (int i = 0; i < v.lig.n_movable; i++)  // get_heavy_atom_movable_coords: flexible side chains included
         if (v.h_lig_smt[i] > 1) s0 += xyz[3 * i], s1_ += xyz[3 * i + 1], s2 += xyz[3 * i + 2], cnt++;
       centers[3 * b] = s0 / (float)cnt, centers[3 * b + 1] = s1_ / (float)cnt, centers[3 * b + 2] = s2 / (float)cnt;
     }
@@ -1680,12 +1712,11 @@ mi_status mi_vina_mc_cnnall_batch(mi_vina *vv, mi_scorer *sc, int B, const uint6
   MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
   Vina &v = *reinterpret_cast<Vina *>(vv);
   MIG_CHECK(v.have_lig, 4, "set the ligand first");
-  MIG_CHECK(v.lig.n_movable == v.lig.n_atoms, 1, "flexible residues are not supported with the CNN in the loop yet");
   MIG_CHECK(P->num_saved > 0 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1, "bad Monte-Carlo parameters");
   if (B == 0) return MI_OK;
   const int nt = v.lig.n_nodes - 1, n = 6 + nt, nc = 7 + nt, na = v.lig.n_atoms, S = P->num_saved;
   std::vector<int> heavy;
-  for (int i = 0; i < na; i++)
+  for (int i = 0; i < v.lig.n_movable; i++)  // the movable non-hydrogen atoms (flexible side chains included)
     if (v.h_lig_smt[i] > 1) heavy.push_back(i);
   const int nh = (int)heavy.size();
   MIG_CHECK(nh > 0, 1, "the ligand has no heavy atoms");
@@ -1822,12 +1853,15 @@ mi_status mi_vina_mc_cnnall_batch(mi_vina *vv, mi_scorer *sc, int B, const uint6
         c.cand[0] += P->mutation_amplitude * dx, c.cand[1] += P->mutation_amplitude * dy, c.cand[2] += P->mutation_amplitude * dz;
       } else if (which[b] == 1) {
         const float *co = &xyz[ni++ * na * 3];
-        float acc = 0;  // model::gyration_radius (model.cpp:1002-1014): heavy atoms about the ligand's root origin
+        float acc = 0;  // model::gyration_radius (model.cpp:1002-1014): the LIGAND's heavy atoms about its root origin
+        unsigned n_gyr = 0;
         for (int a : heavy) {
+          if (a < v.lig.lig_begin || a >= v.lig.lig_end) continue;  // (side-chain atoms are in `heavy` for the container)
           const float dx = co[3 * a] - c.mconf[0], dy = co[3 * a + 1] - c.mconf[1], dz = co[3 * a + 2] - c.mconf[2];
           acc += dx * dx + dy * dy + dz * dz;
+          n_gyr++;
         }
-        const float gr = std::sqrt(acc / (float)nh);
+        const float gr = n_gyr > 0 ? std::sqrt(acc / (float)n_gyr) : 0.f;
         if (gr > kEps) {
           float dx, dy, dz;
           c.rng.inside_sphere(dx, dy, dz);
@@ -1945,7 +1979,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
   auto heavy_center = [&](const float *xyz, float *c) {
     float s0 = 0, s1 = 0, s2 = 0;
     unsigned cnt = 0;
-    for (int i = 0; i < na; i++)
+    for (int i = 0; i < v.lig.n_movable; i++)
       if (v.h_lig_smt[i] > 1) s0 += xyz[3 * i], s1 += xyz[3 * i + 1], s2 += xyz[3 * i + 2], cnt++;
     c[0] = s0 / (float)cnt, c[1] = s1 / (float)cnt, c[2] = s2 / (float)cnt;
   };
@@ -1953,7 +1987,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
   const float margin = 0.0001f, half = box->cnn_dimension / 2.0f;
   auto within = [&](const float *xyz, const float *cen) {  // non_cache_cnn::within = cube OR search box (:74-76)
     bool in_cnn = true, in_box = true;
-    for (int i = 0; i < na; i++) {
+    for (int i = 0; i < v.lig.n_movable; i++) {
       if (v.h_lig_smt[i] <= 1) continue;
       for (int k = 0; k < 3; k++) {
         const float c = xyz[3 * i + k];

@@ -142,6 +142,7 @@ int mi_model_supports_gradient(const mi_model *);
  * [B][L][3] and flex_grad [B][n_flex][3] are optional outputs (both NULL: forward only).  Gradients of
  * untyped rows are 0.  Host pointers. */
 mi_status mi_scorer_set_flex(mi_scorer *, const int32_t *rec_rows, int n_flex);
+int mi_scorer_flex_count(const mi_scorer *); /* rows declared by the last mi_scorer_set_flex */
 /* TorchModel::forward's `rotate` (torch_model.cpp:170-173,204-206; used for --cnn_rotation averaging,
  * cnn_torch_scorer.cpp:130-141): libmolgrid's Transform(gcenter, 0, rotate) turns every atom -- receptor and ligand --
  * about the grid centre, x' = R(q)(x - c) + c, before GridMaker::forward, and Transform::backward turns the atom

@@ -25,29 +25,49 @@ class NonCacheCnn:
         self.evals = 0
         self.user_grid = None                 # (vina.GridDims, data [(n+1)^3]) of --user_grid, or None
         self.per_atom_forces = per_atom_forces   # False = model::add_minus_forces' indexing (see eval_deriv)
+        # gnina's combined model (tree.h / model.h): atoms = [movable side chains | ligand | inflex]; a plain ligand
+        # has lig_begin = 0, lig_end = n_movable = n_atoms.  rec_xyz / rec_smt are then DLScorer::setReceptor's rows:
+        # [movable side-chain atoms | inflex | rigid].
+        self.n_movable = lig.n_movable
+        self.lig_begin = int(lig.c.lig_begin) if lig.c.lig_end > lig.c.lig_begin else 0
+        self.lig_end = int(lig.c.lig_end) if lig.c.lig_end > lig.c.lig_begin else lig.n_atoms
 
     def adjust_center(self, conf):
         """DLScorer::set_center_from_model (dl_scorer.cpp:197-217): fp32 mean of the heavy movable atoms"""
         coords, _, _ = vina.set_conf(self.lig, conf)
         c = np.zeros(3, dtype=np.float32)
         cnt = 0
-        for i in range(len(self.smt)):
+        for i in range(self.n_movable):
             if self.smt[i] > 1:
                 c = (c + coords[i]).astype(np.float32)
                 cnt += 1
         self.cnn_center = (c / np.float32(cnt)).astype(np.float32)
 
     def _cnn(self, coords, deriv):
+        """-> (loss, gradient indexed like the model's atoms).  Combined model (flexible residues): the movable
+        side-chain atoms are the first rows of the scorer's receptor and are refreshed from the model on every call
+        (DLScorer::setReceptor, dl_scorer.cpp:150-193), the ligand is atoms [lig_begin, lig_end)
+        (setLigand, :71-87); both gradients return by movable-atom index (cnn_torch_scorer.cpp:208-228)."""
         loss_sum, grad = 0.0, np.zeros((len(self.smt), 3), dtype=np.float64)
+        lb, le = self.lig_begin, self.lig_end
+        rec_xyz = self.rec_xyz
+        if lb > 0:
+            rec_xyz = self.rec_xyz.copy()
+            rec_xyz[:lb] = coords[:lb]
+        lig_xyz, lig_smt = coords[lb:le], self.smt[lb:le]
         for blob in self.blobs:
             rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
-            grid, cen = voxel.voxelize_pose(self.rec_xyz, self.rec_smt, coords, self.smt, rmap, lmap)
+            grid, cen = voxel.voxelize_pose(rec_xyz, self.rec_smt, lig_xyz, lig_smt, rmap, lmap)
             if deriv:
                 loss, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None])
-                ch, rad = voxel.type_atoms(self.smt, lmap[0])
+                ch, rad = voxel.type_atoms(lig_smt, lmap[0])
                 ch = np.where(ch >= 0, ch + rmap[1], -1)
-                grad += voxel.grid_backward(cen, coords, ch, rad, rmap[1] + lmap[1], gg[0].numpy(), blob.resolution,
-                                            blob.dimension, blob.radius_scaling)
+                grad[lb:le] += voxel.grid_backward(cen, lig_xyz, ch, rad, rmap[1] + lmap[1], gg[0].numpy(), blob.resolution,
+                                                   blob.dimension, blob.radius_scaling)
+                if lb > 0:
+                    chr_, radr = voxel.type_atoms(self.rec_smt[:lb], rmap[0])
+                    grad[:lb] += voxel.grid_backward(cen, rec_xyz[:lb], chr_, radr, rmap[1] + lmap[1], gg[0].numpy(),
+                                                     blob.resolution, blob.dimension, blob.radius_scaling)
                 loss_sum += float(loss[0])
             else:
                 loss_sum += float(cnn_ref.scores(blob, grid[None])[2][0])
@@ -103,7 +123,7 @@ class NonCacheCnn:
         forces = np.zeros_like(coords)
         w = np.float32(self.weight)
         rank = 0                               # model::add_minus_forces' counter j (model.cu:247-259)
-        for i in range(len(self.smt)):
+        for i in range(self.n_movable):
             if self.smt[i] <= 1:
                 continue                       # hydrogens: minus_forces = 0
             pen, f = self._bounds(coords[i])
@@ -142,7 +162,7 @@ class NonCacheCnn:
         coords, _, _ = vina.set_conf(self.lig, conf)
         loss, _ = self._cnn(coords, False)
         e = np.float32(loss)
-        for i in range(len(self.smt)):
+        for i in range(self.n_movable):
             if self.smt[i] > 1:
                 e += self._bounds(coords[i])[0]
         return float(e)
@@ -150,7 +170,7 @@ class NonCacheCnn:
     def within(self, conf, margin=1e-4):
         """non_cache_cnn::within = gd_within(cnn_gd) || non_cache::within (non_cache_cnn.cpp:74-76)"""
         coords, _, _ = vina.set_conf(self.lig, conf)
-        heavy = coords[self.smt > 1]
+        heavy = coords[:self.n_movable][self.smt[:self.n_movable] > 1]
         h = self.cnn_dimension / 2.0
         in_cnn = bool(((heavy >= self.cnn_center - h - margin) & (heavy <= self.cnn_center + h + margin)).all())
         in_box = True

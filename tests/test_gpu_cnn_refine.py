@@ -297,3 +297,81 @@ def test_monte_carlo_with_the_cnn_as_the_minimisers_igrid(setup):
                 and np.abs(out[0][1] - cf[b, 0]).max() < 2e-2):
             same += 1
     assert same >= 1, same
+
+
+def test_cnn_with_flexible_residues_in_eval_refinement_and_monte_carlo():
+    """SURVEY 8f row 4 completed: flexible receptor residues together with the CNN inside the search.  gnina's combined
+    model -- atoms [movable side chain | ligand | inflex], conf [7 + T_ligand + T_flex] -- on the reference's own
+    fixture (GSK3B + test/gnina/data/flex_res_side_chain.pdbqt): DLScorer::setReceptor refreshes the side-chain rows
+    from the model, getGradient returns their gradient through receptor_map (cnn_torch_scorer.cpp:208-228),
+    add_minus_forces / non_cache_cnn::eval_deriv put it next to the ligand's and flex.derivative (tree.h:383-393) folds
+    it into the side chain's torsions.  mi_cnn_eval_batch vs oracle/cnn_refine.py on the same model; then
+    refine_structure and both CNN Monte-Carlo levels run on it and move the side chain."""
+    from gnina_amd import capi
+    from tests import ref_cases
+    capi.init(0)
+    F = np.load(os.path.join(ROOT, "tests", "golden", "real_complex.npz"))
+    rigid, flex = bytes(F["rec_pdbqt"]).decode(), bytes(F["flex_pdbqt"]).decode()
+    lig_text = ref_cases.long_chain_ligand(n=8, origin=(-9.0, 12.0, 3.0))
+    rec_xyz, rec_smt, n_mov, n_inf = capi.read_pdbqt_receptor_flex(rigid, flex, is_text=True)
+    _, _, d = capi.read_pdbqt_model(rigid, flex, lig_text, is_text=True)
+    nf, le = int(d["lig_begin"]), int(d["lig_end"])
+    assert nf == n_mov and le == int(d["n_movable"]) and np.array_equal(d["smt"][:nf], rec_smt[:nf])
+    name = "crossdock_default2018"
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    s.set_flex(np.arange(nf, dtype=np.int32))
+    v = capi.Vina()
+    v.set_ligand(d)
+    olig = ovina.LigandHandle(d)
+    T = len(d["conf0"]) - 7
+    T_flex = T - 6                                      # the 8-carbon chain has 6 torsions, the residue the rest
+    assert T_flex >= 1
+    rng = np.random.RandomState(5)
+    confs = np.stack([d["conf0"]] * 3).astype(np.float32)
+    confs[1:, :3] += rng.uniform(-0.5, 0.5, (2, 3))
+    confs[1:, 7:] += rng.uniform(-0.4, 0.4, (2, T))     # ligand AND side-chain torsions move
+    co = v.coords_batch(confs)
+    lo = co[0, :le].min(0) - 4.0
+    hi = co[0, :le].max(0) + 4.0
+    smt = d["smt"]
+    cen = np.stack([heavy_center(co[0, :le], smt[:le])] * 3)
+    box = capi.CnnBox.make(23.5, lo, hi, slope=10.0)
+    e, ch = v.cnn_eval_batch(s, confs, box, cen, deriv=True)
+    e0, _ = v.cnn_eval_batch(s, confs, box, cen, deriv=False)
+    assert np.abs(e - e0).max() < 1e-4 * np.abs(e).max()
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    nc = cnn_refine.NonCacheCnn([blob], rec_xyz, rec_smt, olig, (lo, hi), 23.5)
+    nc.cnn_center = cen[0]
+    nc.slope = 10.0
+    for b in range(3):
+        eo, cho = nc.eval_deriv(confs[b])
+        assert abs(e[b] - eo) < 3e-4 * max(1.0, abs(eo)), (b, e[b], eo)
+        assert np.abs(ch[b] - cho).max() < 3e-3 * max(np.abs(cho).max(), 1e-3), (b, ch[b], cho)
+        assert np.abs(cho[6 + 6:]).max() > 1e-4        # the CNN does pull on the side chain's torsions
+    # a scorer without the declaration is refused, not silently wrong
+    s2 = capi.Scorer([name])
+    s2.set_receptor(rec_xyz, rec_smt)
+    with pytest.raises(capi.MiGninaError):
+        v.cnn_eval_batch(s2, confs, box, cen, deriv=True)
+    # refine_structure on the combined model: the loss goes down and the side chain's torsions take part
+    start = confs[1:2].copy()
+    er, cr, tries, evs = v.cnn_refine_batch(s, start, box, max_iters=8)
+    e_start, _ = v.cnn_eval_batch(s, start, box, cen[:1], deriv=False)
+    assert np.isfinite(er).all() and er[0] < e_start[0] and np.abs(cr[0, 13:] - start[0, 13:]).max() > 1e-4
+    # CNN as the Metropolis energy (device chains) and as the minimiser's igrid too (--cnn_scoring all)
+    rv_xyz, rv_smt = rec_xyz[nf + n_inf:], rec_smt[nf + n_inf:]      # the rigid part is the Vina receptor
+    v.set_receptor(rv_xyz, rv_smt)
+    n_pts = np.ceil((hi - lo) / 0.375).astype(np.int32)
+    end = lo + n_pts * np.float32(0.375)
+    types = sorted(set(int(t) for t in smt[:le] if t > 1))
+    v.build_cache(list(lo), list(end), [int(k) for k in n_pts], types, 1e3)
+    seeds = np.arange(3, 9, dtype=np.uint64)
+    bx = capi.CnnBox.make(23.5, list(lo), list(end), slope=1e3)
+    P = capi.McParams.default(4, 4, 5)
+    for level_all in (False, True):
+        n1, e1, cf1, xyz1, ev1, cnn1 = v.mc_cnn_batch(s, seeds, list(lo), list(end), P, bx, level_all=level_all)
+        n2, e2, cf2, _, _, _ = v.mc_cnn_batch(s, seeds, list(lo), list(end), P, bx, level_all=level_all)
+        assert (n1 >= 1).all() and np.isfinite(e1[:, 0]).all() and cnn1 > 0
+        assert np.array_equal(n1, n2) and np.array_equal(cf1, cf2)                  # deterministic
+        assert np.abs(cf1[:, 0, 13:] - d["conf0"][13:]).max() > 1e-3              # the residue's torsions were searched
