@@ -689,14 +689,24 @@ def main():
             env = dict(os.environ)
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
-            r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), str(world), "8192"], capture_output=True,
-                               text=True, timeout=240, env=env)
-            rows = [l.split() for l in r.stdout.split("\n") if l.startswith("pool ")]
-            pool_res = {"driver": "tests/cpp/test_pool.cpp (C++ only)", "returncode": r.returncode,
-                        "sizes": [{"devices": int(l[2]), "host_path_equal": l[6] == "1", "host_path_poses_per_s": float(l[8]),
-                                   "device_path_equal": l[10] == "1", "device_path_poses_per_s": float(l[12])} for l in rows]}
-            if r.returncode != 0:
-                pool_res["stderr"] = r.stderr[-400:]
+            out_txt, rc, err_txt = "", None, ""
+            try:
+                r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), str(world), "8192"],
+                                   capture_output=True, text=True, timeout=150, env=env)
+                out_txt, rc, err_txt = r.stdout, r.returncode, r.stderr
+            except subprocess.TimeoutExpired as te:       # keep what the driver printed before it stalled
+                out_txt = te.stdout.decode() if isinstance(te.stdout, bytes) else (te.stdout or "")
+                err_txt = "timeout after 150 s"
+            rows = [l.split() for l in out_txt.split("\n") if l.startswith("pool ")]
+            hrows = [l.split() for l in out_txt.split("\n") if l.startswith("pool_host ")]
+            pool_res = {"driver": "tests/cpp/test_pool.cpp (C++ only: mi_pool over the visible GPUs, one 8,192-pose batch)",
+                        "returncode": rc,
+                        "host_path": [{"devices": int(l[2]), "equal_to_single_scorer": l[6] == "1", "poses_per_s": float(l[8])}
+                                      for l in hrows],
+                        "device_path_rccl": [{"devices": int(l[2]), "equal_to_single_scorer": l[10] == "1",
+                                              "poses_per_s": float(l[12])} for l in rows]}
+            if rc != 0:
+                pool_res["stderr"] = err_txt[-400:]
         except Exception as e:
             pool_res = {"error": f"{type(e).__name__}: {e}"}
     if dist is not None:

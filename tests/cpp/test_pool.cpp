@@ -124,6 +124,8 @@ int main(int argc, char **argv) {
     for (int r = 0; r < reps; r++)
       CK(mi_pool_score_batch(pool, poses.data(), lig_smt.data(), B, L, nullptr, p1.data(), a1.data(), l1.data(), v1.data(), 0));
     const double dt_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    std::printf("pool_host devices %d B %d host_path_equal %d poses_per_s %.1f\n", G, B, (int)host_equal, B / dt_host);
+    std::fflush(stdout);  // (the host path's result survives whatever the RCCL path below does)
     // (c) everything on devices[0]
     HK(hipSetDevice(0));
     float *d_lig = nullptr, *d_out = nullptr;
@@ -144,6 +146,7 @@ int main(int argc, char **argv) {
     const double dt_dev = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
     std::printf("pool devices %d B %d host_path_equal %d poses_per_s %.1f device_path_equal %d poses_per_s %.1f info %s\n", G,
                 B, (int)host_equal, B / dt_host, (int)dev_equal, B / dt_dev, mi_pool_info_json(pool));
+    std::fflush(stdout);
     HK(hipFree(d_lig));
     HK(hipFree(d_out));
     mi_pool_destroy(pool);
