@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -213,6 +213,8 @@ def lib():
         L.mi_debug_sincos.restype = C.c_int
         L.mi_debug_explog.argtypes = [f32p, C.c_int, f32p, f32p]
         L.mi_debug_explog.restype = C.c_int
+        L.mi_debug_acos.argtypes = [f32p, C.c_int, f32p]
+        L.mi_debug_acos.restype = C.c_int
         L.mi_scorer_flex_count.argtypes = [vp]
         L.mi_scorer_flex_count.restype = C.c_int
         L.mi_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_char_p), C.c_int]
@@ -681,9 +683,10 @@ class Vina:
         build_cache"""
         check(lib().mi_vina_set_approximation(self.handle, int(kind), float(factor)))
 
-    def set_line_search(self, accurate):
-        """--accurate_line_search for every BFGS of this handle (False = fast_line_search, the default)"""
-        check(lib().mi_vina_set_line_search(self.handle, 1 if accurate else 0))
+    def set_line_search(self, accurate, simple=False):
+        """--accurate_line_search for every BFGS of this handle (False = fast_line_search, the default);
+        simple: --simple_ascent (minimization_params::Simple) instead of bfgs<>"""
+        check(lib().mi_vina_set_line_search(self.handle, 2 if simple else 1 if accurate else 0))
 
     def set_strict_order(self, on=True):
         """energy sums in the reference's order: trajectories bit-identical to the reference's (mi_gnina.h)"""
@@ -1023,6 +1026,15 @@ def device_libm(x):
     check(lib().mi_debug_sincos(p[0], len(x), p[1], p[2]))
     check(lib().mi_debug_explog(p[0], len(x), p[3], p[4]))
     return tuple(o)
+
+
+def device_acosf(x):
+    """acosf of float32 x as the accurate line search's quaternion_to_angle computes it on the device"""
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    f32p = C.POINTER(C.c_float)
+    o = np.empty_like(x)
+    check(lib().mi_debug_acos(x.ctypes.data_as(f32p), len(x), o.ctypes.data_as(f32p)))
+    return o
 
 
 def init(device=0):

@@ -410,6 +410,41 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
           }
       }
     };
+#if MI_CONV_EXPERIMENT == 3 || MI_CONV_EXPERIMENT == 4
+    // (tools/conv_experiments.sh) What would a K loop cost whose liveness bits come for free (precomputed per chunk
+    // from an occupancy bitmap) and which touches live pairs only?  Pseudo-random bits on the scalar unit with the
+    // measured statistics -- 35 % of the pairs entirely dead, half of the eight MFMAs of the others live (0.33
+    // executed overall); x3 skips dead pairs before their loads, x4 also drops the loads' address adds by fetching
+    // a fixed entry.  Wrong results by construction.
+    if constexpr (SP == 1) {
+      float4 a0[TM], w0[TN];
+      for (int pr = 0; pr < NP; pr++) {
+        unsigned h = (unsigned)pr * 2654435761u ^ (unsigned)wg * 40503u ^ (unsigned)(chunk * 97 + wave * 13);
+        h ^= h >> 13;
+        h *= 0x5bd1e995u;
+        h ^= h >> 15;
+        h = __builtin_amdgcn_readfirstlane(h);
+        if ((h & 0xfffffu) < 367001u) continue;  // 35 % of the pairs: nothing live, nothing loaded
+        const unsigned bits = (h >> 20) & 0xffu;  // each MFMA live with probability 1/2
+        e_next = lp[2 * pr];
+        load_pair(pr, a0, w0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int m = 0; m < TM; m++) {
+            if (!((bits >> (2 * j + m)) & 1u)) continue;
+            n_exec += TN;
+            const float a = j == 0 ? a0[m].x : j == 1 ? a0[m].y : j == 2 ? a0[m].z : a0[m].w;
+#pragma unroll
+            for (int n = 0; n < TN; n++) {
+              const float wc = j == 0 ? w0[n].x : j == 1 ? w0[n].y : j == 2 ? w0[n].z : w0[n].w;
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wc, acc[m][n], 0, 0, 0);
+            }
+          }
+      }
+      continue;
+    }
+#endif
     float4 a0[TM], a1[TM], w0[TN], w1[TN];
     load_pair(0, a0, w0);
     int pr = 0;

@@ -161,6 +161,7 @@ size_t vina_wave_lds_bytes(int n_atoms, int n_nodes, int n_pairs, bool bfgs, boo
 void launch_vina_populate(const VinaPopulateArgs &a, hipStream_t s);
 void launch_vina_sincos_probe(const float *x, int n, float *sn, float *cs, hipStream_t s);
 void launch_vina_explog_probe(const float *x, int n, float *ex, float *lg, hipStream_t s);
+void launch_vina_acos_probe(const float *x, int n, float *ac, hipStream_t s);
 // confs [B][7+T]; energy [B]; change [B][6+T] or null; coords [B][n_atoms][3] or null
 void launch_vina_eval(const VinaEnv &env, const VinaLigand &lig, const float *confs, int B, float v0, float v1,
                       float v2, int with_deriv, float *energy, float *change, float *coords, hipStream_t s);

@@ -344,6 +344,45 @@ __device__ __forceinline__ float logf_ref(float x) {  // x positive and normal (
   return (float)y;
 }
 
+// acosf as the host computes it (glibc 2.35 sysdeps/ieee754/flt-32/e_acosf.c = fdlibm's rational approximation in
+// plain fp32 arithmetic, no fused operations): quaternion_to_angle (quaternion.cu:46-62) inside compute_lambdamin.
+// Checked against the host for every float of [-1, 1] (tools/microbench/glibc_acosf_check.c: 0 mismatches).
+__device__ __forceinline__ float acosf_ref(float x) {
+  const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+  const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+              pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,
+              qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+  const int hx = __float_as_int(x), ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+  if (ix > 0x3f800000) return (x - x) / (x - x);
+  if (ix < 0x3f000000) {  // |x| < 0.5
+    if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+    const float z = x * x;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    return pio2_hi - (x - (pio2_lo - x * r));
+  }
+  if (hx < 0) {  // x < -0.5
+    const float z = (1.0f + x) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float s = sqrtf(z);
+    const float r = p / q;
+    const float w = r * s - pio2_lo;
+    return pi - 2.0f * (s + w);
+  }
+  const float z = (1.0f - x) * 0.5f;  // x > 0.5
+  const float s = sqrtf(z);
+  const float df = __int_as_float(__float_as_int(s) & 0xfffff000);
+  const float c = (z - df * df) / (s + df);
+  const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const float r = p / q;
+  const float w = r * s + c;
+  return 2.0f * (df + w);
+}
+
 __device__ __forceinline__ void angle_to_quat(float ax, float ay, float az, float angle, float *q) {
   angle = norm_angle(angle);
   float c, s;
@@ -1592,8 +1631,11 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
         tb = t;
       }
     };
+    // minimization_params::Simple (--simple_ascent; simple_gradient_ascent, bfgs.h:234-355): steepest descent with the
+    // accurate line search -- p = -g every iteration, no quasi-Newton update (env.accurate_ls == 2, ACC kernels)
+    const bool simple = ACC && env.accurate_ls == 2;
     if (!start) {
-      p_r = hreg ? minus_hrow_times(g_r) : (lane < n ? minus_h_times(h, g_r, n, row) : 0.f);
+      p_r = simple ? (lane < n ? -g_r : 0.f) : hreg ? minus_hrow_times(g_r) : (lane < n ? minus_h_times(h, g_r, n, row) : 0.f);
       p_up = __shfl_up(p_r, 1);
       pg = dot_lanes(p_r, g_r, n);
     }
@@ -1615,10 +1657,10 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
       const float qa = rl(x_r, 3), qb = rl(x_r, 4), qc = rl(x_r, 5), qd = rl(x_r, 6);
       float ang0 = 0.f, ang1 = 0.f, ang2 = 0.f;
       if (qa > -1 && qa < 1) {
-        float angle = 2 * acosf(qa);
+        float angle = 2 * acosf_ref(qa);
         if (angle > VPI) angle -= 2 * VPI;
         float sn, cs_unused;
-        sincos_ref(angle / 2, sn, cs_unused);  // (acosf above stays ocml's: it only feeds the step-size floor alamin)
+        sincos_ref(angle / 2, sn, cs_unused);
         if (!(fabsf(sn) < VEPS)) {
           const float sc = angle / sn;
           ang0 = qb * sc, ang1 = qc * sc, ang2 = qd * sc;
@@ -1726,6 +1768,7 @@ __device__ __forceinline__ float bfgs_wave(const VinaEnv &env, const VinaLigand 
     g_r = gn_r;
     const float gradnormsq = dot_lanes(g_r, g_r, n);
     if (!(gradnormsq >= 1e-4f)) break;
+    if (simple) continue;
     if (step == 0) {
       const float yy = dot_lanes(y_r, y_r, n);
       if (fabsf(yy) > VEPS) {
@@ -2554,6 +2597,13 @@ void launch_vina_sincos_probe(const float *x, int n, float *sn, float *cs, hipSt
 __global__ void vina_explog_probe_kernel(const float *x, int n, float *ex, float *lg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ex[i] = expf_ref(x[i]), lg[i] = logf_ref(fabsf(x[i]));
+}
+__global__ void vina_acos_probe_kernel(const float *x, int n, float *ac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ac[i] = acosf_ref(x[i]);
+}
+void launch_vina_acos_probe(const float *x, int n, float *ac, hipStream_t s) {
+  hipLaunchKernelGGL(vina_acos_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, ac);
 }
 void launch_vina_explog_probe(const float *x, int n, float *ex, float *lg, hipStream_t s) {
   hipLaunchKernelGGL(vina_explog_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, ex, lg);

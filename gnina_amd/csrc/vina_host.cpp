@@ -91,7 +91,8 @@ struct Vina {
   float sp_fraction = 0, cutoff = 8;
   DevBuf<float4> d_spline;
   std::vector<float4> h_spline;
-  bool accurate_ls = false;  // --accurate_line_search
+  bool accurate_ls = false;  // --accurate_line_search (also set for --simple_ascent, which uses the same search)
+  bool simple_ascent = false;  // minimization_params::Simple: steepest descent, no quasi-Newton update
   bool strict = false;       // mi_vina_set_strict_order: energy sums in the reference's order
   // --user_grid
   bool have_ug = false;
@@ -250,7 +251,7 @@ static VinaEnv make_env(const Vina &v) {
   }
   e.ug_geom = v.ug_geom;
   e.ug_data = v.have_ug ? v.d_ug.p : nullptr;
-  e.accurate_ls = v.accurate_ls ? 1 : 0;
+  e.accurate_ls = v.simple_ascent ? 2 : v.accurate_ls ? 1 : 0;
   e.strict = v.strict ? 1 : 0;
   e.spline = v.use_spline ? v.d_spline.p : nullptr;
   e.sp_n = v.sp_n;
@@ -415,8 +416,9 @@ mi_status mi_vina_build_cache(mi_vina *vv, const float *begin3, const float *end
 // and the CNN refinement's host state machine.
 mi_status mi_vina_set_line_search(mi_vina *vv, int kind) {
   VTRY
-  MIG_CHECK(vv && (kind == 0 || kind == 1), 1, "line search: 0 (fast) or 1 (accurate)");
-  reinterpret_cast<Vina *>(vv)->accurate_ls = kind == 1;
+  MIG_CHECK(vv && kind >= 0 && kind <= 2, 1, "minimiser: 0 (bfgs, fast line search), 1 (bfgs, accurate line search) or 2 (simple ascent)");
+  reinterpret_cast<Vina *>(vv)->accurate_ls = kind >= 1;
+  reinterpret_cast<Vina *>(vv)->simple_ascent = kind == 2;
   return MI_OK;
   VCATCH_STATUS
 }
@@ -449,6 +451,20 @@ mi_status mi_debug_explog(const float *x, int n, float *ex, float *lg) {
   launch_vina_explog_probe(dx.p, n, de.p, dl.p, nullptr);
   MIG_HIP(hipMemcpy(ex, de.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   MIG_HIP(hipMemcpy(lg, dl.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_OK;
+  VCATCH_STATUS
+}
+
+// Diagnostic: ac[i] = the device's acosf(x[i]) (vina.hip acosf_ref).
+mi_status mi_debug_acos(const float *x, int n, float *ac) {
+  VTRY
+  MIG_CHECK(x && ac && n >= 0, 1, "bad arguments");
+  if (n == 0) return MI_OK;
+  DevBuf<float> dx, da;
+  dx.upload(x, (size_t)n, nullptr);
+  da.ensure((size_t)n);
+  launch_vina_acos_probe(dx.p, n, da.p, nullptr);
+  MIG_HIP(hipMemcpy(ac, da.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return MI_OK;
   VCATCH_STATUS
 }
@@ -1355,14 +1371,16 @@ struct BfgsChain {
   std::vector<float> x, x_new, x_orig, g, g_new, g_orig, p, y, mhy, h;
   float f0 = 0, f_orig = 0, alpha = 1, pg = 0;
   bool accurate = false;  // accurate_line_search (bfgs.h:104-180) instead of fast_line_search
+  bool simple = false;    // simple_gradient_ascent (bfgs.h:234-355): p = -g every iteration, no Hessian estimate
   float ls_alpha2 = 0, ls_f2 = 0, alamin = 0;
   int step = 0, trial = 0;
   long evals = 0;
   enum { Init, Line, Done } state = Init;
 
-  void start(const float *conf, int nt_, int max_iters_, bool accurate_ = false) {
+  void start(const float *conf, int nt_, int max_iters_, bool accurate_ = false, bool simple_ = false) {
     nt = nt_, n = 6 + nt_, nc = 7 + nt_, max_iters = max_iters_;
-    accurate = accurate_;
+    accurate = accurate_ || simple_;
+    simple = simple_;
     x.assign(conf, conf + nc);
     x_new = x;
     g.assign(n, 0), g_new.assign(n, 0), p.assign(n, 0), y.assign(n, 0), mhy.assign(n, 0);
@@ -1378,6 +1396,9 @@ struct BfgsChain {
       finish();
       return;
     }
+    if (simple) {
+      for (int i = 0; i < n; i++) p[i] = -g[i];  // set_to_neg, bfgs.h:262
+    } else
     for (int i = 0; i < n; i++) {  // minus_mat_vec_product, bfgs.h:34-43
       float sum = 0;
       for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
@@ -1488,6 +1509,11 @@ struct BfgsChain {
     g = g_new;
     if (!(dot_seq(g.data(), g.data(), n) >= 1e-4f)) {  // bfgs.h:474
       finish();
+      return;
+    }
+    if (simple) {  // simple_gradient_ascent has no Hessian estimate to maintain
+      step++;
+      begin_step();
       return;
     }
     if (step == 0) {  // initial Hessian scaling, bfgs.h:478-483
@@ -1798,7 +1824,7 @@ mi_status mi_vina_mc_cnnall_batch(mi_vina *vv, mi_scorer *sc, int B, const uint6
   // quasi_newton on non_cache_cnn for the chains in `who`, in lock step; leaves bf.x / bf.f0 and last_eval
   auto minimise = [&](const std::vector<int> &who, auto start_from, float vcap) -> mi_status {
     for (int b : who) {
-      ch[b].bf.start(start_from(ch[b]), nt, P->max_iters, v.accurate_ls);
+      ch[b].bf.start(start_from(ch[b]), nt, P->max_iters, v.accurate_ls, v.simple_ascent);
       ch[b].last_eval.assign(start_from(ch[b]), start_from(ch[b]) + nc);
     }
     std::vector<int> active = who;
@@ -2003,7 +2029,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
   std::vector<int> n_try(B, 0), active;
   std::vector<char> done(B, 0);
   std::vector<long> total_evals(B, 0);
-  for (int b = 0; b < B; b++) chain[b].start(confs + (size_t)b * nc, nt, max_iters, v.accurate_ls);
+  for (int b = 0; b < B; b++) chain[b].start(confs + (size_t)b * nc, nt, max_iters, v.accurate_ls, v.simple_ascent);
   std::vector<float> req, req_centers, e_out, g_out;
   for (;;) {
     // chains sharing a slope value are evaluated together (the slope is a kernel argument)
@@ -2048,7 +2074,7 @@ mi_status mi_cnn_refine_batch(mi_vina *vv, mi_scorer *sc, float *confs, int B, c
       } else {
         slope[b] *= 10;
         std::vector<float> x = chain[b].x;
-        chain[b].start(x.data(), nt, max_iters, v.accurate_ls);
+        chain[b].start(x.data(), nt, max_iters, v.accurate_ls, v.simple_ascent);
       }
     }
   }

@@ -249,7 +249,10 @@ enum { MI_VINA_APPROX_LINEAR = 0, MI_VINA_APPROX_SPLINE = 1 };
 /* --accurate_line_search (minimization_params::BFGSAccurateLineSearch, bfgs.h:395-400): kind 1 makes every BFGS of
  * this handle -- mi_vina_bfgs_batch, mi_vina_refine_*, the Monte-Carlo chains, mi_cnn_refine_batch and the CNN
  * Monte-Carlo -- use accurate_line_search (bfgs.h:104-180, backtracking with cubic interpolation after Numerical
- * Recipes' lnsrch) instead of fast_line_search; 0 (default) returns to the fast one.  mi_vina_mc_cnn_batch's device
+ * Recipes' lnsrch) instead of fast_line_search; 0 (default) returns to the fast one.  kind 2 = --simple_ascent
+ * (minimization_params::Simple, quasi_newton.cpp:77-79): simple_gradient_ascent (bfgs.h:234-355), steepest descent under
+ * the accurate line search with no quasi-Newton update.  (The enum's fourth value, ConjugateGradient, has no
+ * implementation in the reference either: quasi_newton.cpp runs bfgs<> for it.)  mi_vina_mc_cnn_batch's device
  * chains support the fast search only. */
 mi_status mi_vina_set_line_search(mi_vina *, int kind);
 /* Strict summation order (on = 1): every energy sum of this handle's evaluations -- cache::eval / eval_deriv over the
@@ -265,6 +268,8 @@ mi_status mi_debug_sincos(const float *x, int n, float *sn, float *cs);
 /* ex[i] = the device's expf(x[i]) (Metropolis criterion, precalculate_exact), lg[i] = its logf(|x[i]|) (random_normal),
  * likewise glibc's algorithms restated; logf for positive normal arguments. */
 mi_status mi_debug_explog(const float *x, int n, float *ex, float *lg);
+/* ac[i] = the device's acosf(x[i]) (quaternion_to_angle inside the accurate line search): fdlibm's fp32 algorithm. */
+mi_status mi_debug_acos(const float *x, int n, float *ac);
 mi_status mi_vina_set_approximation(mi_vina *, int kind, float factor);
 /* precalculate::eval_deriv(a, b, r2) of the current approximation for one type pair: e[i], dor[i] = (E, (dE/dr) / r) at
  * r2[i] (host arrays; linear: r2 <= cutoff^2). */

@@ -185,9 +185,9 @@ class Scene:
         """--approximation: 0 = precalculate_linear(wt, 32), 1 = precalculate_splines(wt, factor); before build_grids"""
         _check(lib().ref_set_approximation(self.h, int(kind), float(factor)))
 
-    def set_line_search(self, accurate):
-        """--accurate_line_search for bfgs() and mc() of this scene"""
-        _check(lib().ref_set_line_search(self.h, 1 if accurate else 0))
+    def set_line_search(self, accurate, simple=False):
+        """--accurate_line_search (or, simple: --simple_ascent = minimization_params::Simple) for bfgs() and mc()"""
+        _check(lib().ref_set_line_search(self.h, 2 if simple else 1 if accurate else 0))
 
     def prec_eval(self, t1, t2, r2):
         """(E, dE/dr / r) of the run's precalculate for a type pair at squared distances r2"""

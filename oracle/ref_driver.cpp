@@ -68,6 +68,7 @@ struct Scene {
   std::unique_ptr<non_cache> nc;
   bool has_ligand = false;
   bool accurate_ls = false;  // --accurate_line_search (minimization_params::BFGSAccurateLineSearch)
+  bool simple = false;       // --simple_ascent (minimization_params::Simple)
 };
 
 conf to_conf(const Scene &s, const float *x) {
@@ -350,6 +351,7 @@ int ref_set_approximation(void *h, int kind, float factor) {
 int ref_set_line_search(void *h, int kind) {
   RTRY
   ((Scene *)h)->accurate_ls = kind == 1;
+  ((Scene *)h)->simple = kind == 2;
   return 0;
   RCATCH(1)
 }
@@ -487,6 +489,7 @@ int ref_bfgs(void *h, float *x, const float *v3, int ig, int max_iters, float *e
   minimization_params mp;
   mp.maxiters = (unsigned)max_iters;
   if (s.accurate_ls) mp.type = minimization_params::BFGSAccurateLineSearch;
+  if (s.simple) mp.type = minimization_params::Simple;
   quasi_newton qn(mp);
   output_type out(to_conf(s, x), 0);
   change g(s.m.get_size(), false);
@@ -531,6 +534,7 @@ int ref_mc(void *h, unsigned seed, int n_steps, int max_iters, int num_saved, fl
   mc.ssd_par.evals = (unsigned)max_iters;
   mc.ssd_par.minparm.maxiters = (unsigned)max_iters;
   if (s.accurate_ls) mc.ssd_par.minparm.type = minimization_params::BFGSAccurateLineSearch;
+  if (s.simple) mc.ssd_par.minparm.type = minimization_params::Simple;
   mc.min_rmsd = min_rmsd;
   mc.num_saved_mins = (sz)num_saved;
   mc.hunt_cap = vec(10, 10, 10);

@@ -213,13 +213,14 @@ def model_energies(scene, rec_xyz, rec_smt, conf, v=(1000.0, 1000.0, 1000.0), sl
     return e, intra.value
 
 
-def set_line_search(accurate=False):
+def set_line_search(accurate=False, simple=False):
     """--accurate_line_search: every bfgs of this library (bfgs, bfgs_callback, refine, mc) then runs
-    accurate_line_search (bfgs.h:104-180).  Process-wide: tests reset it."""
+    accurate_line_search (bfgs.h:104-180); simple: --simple_ascent, simple_gradient_ascent (bfgs.h:234-355) instead of
+    bfgs<>.  Process-wide: tests reset it."""
     f = _voxel.lib().ora_vina_set_line_search
     f.restype = None
     f.argtypes = [C.c_int]
-    f(1 if accurate else 0)
+    f(2 if simple else 1 if accurate else 0)
 
 
 def set_approximation(kind=0, factor=10.0, cutoff=8.0, weights=None):

@@ -906,8 +906,11 @@ void ora_vina_trial_hist(long *out, int reset) {
 }
 
 /* --accurate_line_search (minimization_params::BFGSAccurateLineSearch): process-wide switch of this test library */
-static int g_accurate_ls;
-void ora_vina_set_line_search(int kind) { g_accurate_ls = kind == 1; }
+static int g_accurate_ls, g_simple; /* kind 2: minimization_params::Simple (simple_gradient_ascent, bfgs.h:234-355) */
+void ora_vina_set_line_search(int kind) {
+  g_accurate_ls = kind >= 1;
+  g_simple = kind == 2;
+}
 
 /* quaternion_to_angle (quaternion.cu:46-62) */
 static void quat_to_angle(const float *q, float *ang) {
@@ -938,6 +941,9 @@ static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) 
   memcpy(x_orig, conf, sizeof(float) * nc);
   memcpy(g_new, g, sizeof(float) * n);
   for (int step = 0; step < max_iters; step++) {
+    if (g_simple) {
+      for (int i = 0; i < n; i++) p[i] = -g[i]; /* set_to_neg, bfgs.h:262 */
+    } else
     for (int i = 0; i < n; i++) { /* minus_mat_vec_product, bfgs.h:34-43 */
       float sum = 0;
       for (int j = 0; j < n; j++) sum += h[hidx(i, j)] * g[j];
@@ -1009,6 +1015,7 @@ static float bfgs_run(bfgs_ctx *ctxp, float *conf, int max_iters, float *g_out) 
     memcpy(g, g_new, sizeof(float) * n);
     float gradnormsq = dotn(g, g, n);
     if (!(gradnormsq >= 1e-4f)) break;
+    if (g_simple) continue; /* no Hessian estimate */
     if (step == 0) {
       const float yy = dotn(y, y, n);
       if (fabsf(yy) > V_EPS) {

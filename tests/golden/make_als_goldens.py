@@ -47,6 +47,15 @@ def main():
         rows = [s.mc(seed_, steps, b, e, max_iters=2, num_saved=20) for seed_ in range(100, 132)]
         G[f"mcshort/{steps}/e0"] = np.array([r[0][0] for r in rows], np.float32)
         G[f"mcshort/{steps}/conf0"] = np.stack([r[1][0] for r in rows])
+    # --simple_ascent (minimization_params::Simple: simple_gradient_ascent under the same accurate line search)
+    s.set_line_search(False, simple=True)
+    for iters in (1, 3, mi):
+        r = [s.bfgs(c, HUNT, max_iters=iters) for c in confs]
+        G[f"simple/v10/{iters}/e"] = np.array([x[0] for x in r], np.float32)
+        G[f"simple/v10/{iters}/conf"] = np.stack([x[1] for x in r])
+    rows = [s.mc(seed_, 3, b, e, max_iters=2, num_saved=20) for seed_ in range(100, 132)]
+    G["simple/mcshort/3/e0"] = np.array([r[0][0] for r in rows], np.float32)
+    G["simple/mcshort/3/conf0"] = np.stack([r[1][0] for r in rows])
     np.savez_compressed(OUT, **G)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

@@ -430,5 +430,29 @@ def test_accurate_line_search_follows_the_reference(capi):
             seeds = np.arange(100, 132, dtype=np.uint64)
             n, e, cf, xyz, ev = v.mc_batch(seeds, list(U["begin"]), list(U["end"]), capi.McParams.default(steps, 2, 20))
             assert matches(e[:, 0], cf[:, 0], U[f"mcshort/{steps}/e0"], U[f"mcshort/{steps}/conf0"]) >= need, steps
+        # strict order (+ glibc's acosf restated for quaternion_to_angle): the reference's results bit for bit
+        v.set_strict_order(True)
+        for tag, cap in (("v1000", V3), ("v10", HUNT)):
+            for iters in (1, 3, mi):
+                e, cf, _, ev = v.bfgs_batch(confs, cap, max_iters=iters)
+                assert biteq(e, U[f"bfgs/{tag}/{iters}/e"]) and biteq(cf, U[f"bfgs/{tag}/{iters}/conf"]), (tag, iters)
+        for steps in (1, 3):
+            n, e, cf, xyz, ev = v.mc_batch(seeds, list(U["begin"]), list(U["end"]), capi.McParams.default(steps, 2, 20))
+            assert biteq(e[:, 0], U[f"mcshort/{steps}/e0"]) and biteq(cf[:, 0], U[f"mcshort/{steps}/conf0"]), steps
+        # --simple_ascent (minimization_params::Simple): steepest descent under the same search
+        v.set_line_search(False, simple=True)
+        for iters in (1, 3, mi):
+            e, cf, _, ev = v.bfgs_batch(confs, HUNT, max_iters=iters)
+            assert biteq(e, U[f"simple/v10/{iters}/e"]) and biteq(cf, U[f"simple/v10/{iters}/conf"]), iters
+        n, e, cf, xyz, ev = v.mc_batch(seeds, list(U["begin"]), list(U["end"]), capi.McParams.default(3, 2, 20))
+        assert biteq(e[:, 0], U["simple/mcshort/3/e0"]) and biteq(cf[:, 0], U["simple/mcshort/3/conf0"])
+        e_s, cf_s, _, _ = v.bfgs_batch(confs, V3, max_iters=3)
+        assert (np.abs(cf_s - cf3).max(1) > 1e-4).sum() >= 4                       # not bfgs<> with the accurate search
     finally:
         v.set_line_search(False)
+        v.set_strict_order(False)
+    acs = np.concatenate([np.linspace(-1, 1, 4001), np.random.RandomState(1).uniform(-1, 1, 20000)]).astype(np.float32)
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.acosf.restype, libm.acosf.argtypes = C.c_float, [C.c_float]
+    assert biteq(capi.device_acosf(acs), np.array([libm.acosf(float(t)) for t in acs], np.float32))

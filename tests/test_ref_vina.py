@@ -485,6 +485,40 @@ def test_accurate_line_search_runs_are_bit_identical(which, request):
         V.set_line_search(False)
 
 
+@pytest.mark.parametrize("which", ["adduct", "chain"])
+def test_simple_ascent_runs_are_bit_identical(which, request):
+    """--simple_ascent = minimization_params::Simple (quasi_newton.cpp:77-79): simple_gradient_ascent (bfgs.h:234-355),
+    steepest descent under the accurate line search, no quasi-Newton update -- restatement vs the reference over whole
+    minimisations and Monte-Carlo chains; and it is neither of the two bfgs<> variants."""
+    c = request.getfixturevalue(which)
+    s, lig = c.ref, c.lig
+    rng = np.random.RandomState(9)
+    confs = np.concatenate([RC.random_confs(rng, lig["conf0"], 3, small=True), RC.random_confs(rng, lig["conf0"], 2)])
+    try:
+        differs = 0
+        for conf in confs:
+            s.set_line_search(False, simple=True)
+            V.set_line_search(False, simple=True)
+            for v in (V3, HUNT):
+                for iters in (1, 4, c.max_iters):
+                    er, xr, gr = s.bfgs(conf, v, max_iters=iters)
+                    eo, xo, go, _ = c.ora.bfgs(conf, v, max_iters=iters)
+                    assert er == eo and np.array_equal(xr, xo) and np.array_equal(gr, go), (v, iters)
+            es, xs, _ = s.bfgs(conf, V3, max_iters=c.max_iters)
+            s.set_line_search(True)
+            ea, xa, _ = s.bfgs(conf, V3, max_iters=c.max_iters)
+            differs += int(not np.array_equal(xs, xa))
+        assert differs >= 3
+        s.set_line_search(False, simple=True)
+        V.set_line_search(False, simple=True)
+        er, cr, xr = s.mc(3, 60, c.begin, c.end, max_iters=c.max_iters, num_saved=20)
+        eo, co, xo, _ = V.mc_chain(c.ora, c.begin, c.end, 3, 60, c.max_iters, num_saved=20)
+        assert len(er) == len(eo) and np.array_equal(er, eo) and np.array_equal(cr, co) and np.array_equal(xr, xo)
+    finally:
+        s.set_line_search(False)
+        V.set_line_search(False)
+
+
 def test_final_energies_with_flexible_residues(flexcase, adduct):
     """main.cpp:339-344 on the combined model: eval_intramolecular (model.cu:352-399) = ligand pairs + flexible atoms
     against the rigid receptor (every pair curled with v[1], exact tables) + other_pairs without a ligand atom;
