@@ -65,8 +65,20 @@ HipCache::HipCache(const model &m, const grid_dims &gd_in, const std::vector<smt
   for (size_t i = 0; i < smt_.size(); i++) smt_[i] = (int32_t)mov[i].sm;
 }
 
+// cache::eval reads the types of the model it is GIVEN (m.atoms[i].get(), cache.cpp:55-58), which need not be the model
+// the grids were populated for -- as long as its atom types have grids.  The types are refreshed from `m` on every
+// call (a few dozen ints), so reusing the igrid with another ligand gives that ligand's energies, like `cache`.
+void HipCache::types_of(const model &m) const {
+  const atomv &mov = m.get_movable_atoms();
+  const size_t n = m.m_num_movable_atoms;
+  if (m.coordinates().size() < n) throw internal_error("HipCache: the model has fewer coordinates than movable atoms", 0);
+  smt_.resize(n);
+  for (size_t i = 0; i < n; i++) smt_[i] = (int32_t)mov[i].sm;
+}
+
 // cache::eval (cache.cpp:50-63): sum over the movable heavy atoms of their type grid at m.coords
 fl HipCache::eval(model &m, fl v) const {
+  types_of(m);
   const size_t n = smt_.size();
   xyz_.resize(n * 3);
   const vecv &c = m.coordinates();
@@ -84,6 +96,7 @@ fl HipCache::eval_deriv(model &m, fl v, const grid &user_grid) const {
   // (cache.cpp:65-83,177-179).  Same here -- but only if this cache was built with it.
   if (user_grid.initialized() && !have_user_grid_)
     throw internal_error("HipCache was built without the user grid (pass its file text to the constructor)", 0);
+  types_of(m);
   const size_t n = smt_.size();
   xyz_.resize(n * 3);
   forces_.resize(n * 3);
@@ -201,7 +214,8 @@ bool HipQuasiNewton::operator()(model &m, const precalculate &, igrid &ig, outpu
   unflatten(x, out.c);
   unflatten(grad, g);
   out.e = e;
-  m.set(out.c);  // the reference's CPU path leaves the model on the last evaluated conformation
+  m.set(out.c);  // the model ends on the RETURNED conformation (what refine_structure's "m.set(out.c); // just to be sure"
+                 // establishes anyway, main.cpp:152); the reference's CPU bfgs<> leaves it on the last trial it evaluated
   return true;
 }
 #endif

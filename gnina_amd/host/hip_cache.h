@@ -47,7 +47,8 @@ void unflatten(const std::vector<float> &g, change &c);
 
 class HipCache : public igrid {
   std::shared_ptr<mi_vina> v_;
-  std::vector<int32_t> smt_;       // smina types of the movable atoms the igrid is asked about
+  mutable std::vector<int32_t> smt_;  // smina types of the movable atoms of the model being evaluated (refreshed per call)
+  void types_of(const model &m) const;
   mutable std::vector<float> xyz_, forces_;
   fl slope_ = 1e3;
   bool have_ligand_ = false, have_user_grid_ = false;
