@@ -66,16 +66,20 @@ def main():
     scorer.set_receptor(rec_xyz, rec_smt)
     mine = shard.round_robin(args.ligands, rank, world)
     P = 9
+    # the screen's input: generated before the clock starts (a real job reads prepared ligand files; making synthetic
+    # molecules is not part of it)
+    batches = []
+    for b0 in range(0, len(mine), args.batch):
+        ids = mine[b0:b0 + args.batch]
+        lig = [ligand(int(i), lig_types, synth, P) for i in ids]
+        batches.append((b0, len(ids), np.concatenate([l[0] for l in lig]), np.concatenate([l[1] for l in lig])))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     local = np.zeros((len(mine), 3 * P), dtype=np.float32)          # per ligand: 9 x (pose, affinity, variance)
-    for b0 in range(0, len(mine), args.batch):
-        ids = mine[b0:b0 + args.batch]
-        lig = [ligand(int(i), lig_types, synth, P) for i in ids]
-        xyz = np.concatenate([l[0] for l in lig])
-        smt = np.concatenate([l[1] for l in lig])
+    for b0, nb, xyz, smt in batches:
+        ids = mine[b0:b0 + nb]
         o = scorer.score_ragged(xyz, smt)
         local[b0:b0 + len(ids)] = np.stack([o["pose"], o["affinity"], o["variance"]], 1).reshape(len(ids), P, 3).reshape(len(ids), -1)
     full = shard.gather_round_robin(local, args.ligands, dist, dev)
@@ -89,7 +93,7 @@ def main():
                                     f"round-robin over {world} rank(s)",
                           "n_gpus": world, "seconds": round(dt, 3), "ligands_per_s": round(args.ligands / dt, 1),
                           "poses_per_s": round(args.ligands * P / dt, 1),
-                          "note": "ligand generation on the host is inside the timed region",
+                          "note": "ligands prepared before the timed region; host pointers, PCIe and per-call set-up inside it",
                           "checksum": float(np.float64(full.astype(np.float64).sum())),
                           "best_cnnscore_mean": float(best.mean())}))
     if dist is not None:
