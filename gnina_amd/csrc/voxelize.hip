@@ -214,13 +214,16 @@ __device__ __forceinline__ float div_rn(float a, float b, float y) {
   return __builtin_fmaf(__builtin_fmaf(-q1, b, a), y, q1);
 }
 
-// density of one atom (wave-uniform constants) at squared distance rsq; SURVEY App. A.2.
-__device__ __forceinline__ float density(float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
-                                         float qa, float qb, float qc) {
-  float v = 0.f;
+// acc += density of one atom (wave-uniform constants) at squared distance rsq; SURVEY App. A.2.  The accumulation sits
+// INSIDE the zone branches: a lane outside the atom's support executes nothing after the range test -- written as
+// "v = 0; if (...) v = ...; acc += v" the compiler emits a zero-initialisation and an add for every sub-block an atom
+// does not reach (five of eight on average), on a kernel whose time is its VALU instruction count.  Adding nothing and
+// adding +0 give the same bits (the accumulators are sums of non-negative terms and start at +0).
+__device__ __forceinline__ void density_add(float &acc, float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
+                                            float qa, float qb, float qc) {
   if (rsq < t2) {
     if (rsq <= g2) {
-      v = __builtin_amdgcn_exp2f(rsq * kexp);
+      acc = acc + __builtin_amdgcn_exp2f(rsq * kexp);
     } else {
       float dr = __builtin_amdgcn_sqrtf(rsq) * inv_ar;
       float q = (qa * dr + qb) * dr + qc;
@@ -234,10 +237,9 @@ __device__ __forceinline__ float density(float rsq, float t2, float g2, float ke
         float dre = div_rn(sqrt_rn(rsq), ar, inv_ar);
         q = (qa * dre + qb) * dre + qc;
       }
-      v = q > 0.f ? q : 0.f;
+      if (q > 0.f) acc = acc + q;
     }
   }
-  return v;
 }
 
 template <int MODE>  // 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   // Two lane <-> voxel maps.  While atoms are accumulated a lane owns the voxel at local position (lx, ly, lz) of each of
   // the tile's eight 4x4x4 SUB-BLOCKS (acc[k], k = sub-block): the 64 evaluations of one instruction then are one compact
   // 2 A cube, and an atom that touches the tile reaches only 3.2 of the 8 cubes on average -- the others are skipped by
-  // the wave-uniform exec-mask branches around density().  For pooling / output a lane owns the 2x2x2 CELL (cx, cy, cz);
+  // the wave-uniform exec-mask branches around density_add().  For pooling / output a lane owns the 2x2x2 CELL (cx, cy, cz);
   // the accumulators change hands through a 2 KB LDS transpose per flushed channel (s_tr).
   const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
 
@@ -268,12 +270,24 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   const int nwin = (Cp + kWin - 1) / kWin;
   float *s_tr = s_stage + 64 * kWin;                                            // [64 lanes][8 sub-blocks]
   unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + 512);         // [64][kWin], only if argmax_out
-  // where the r-th voxel (x*4 + y*2 + z) of this lane's pooling cell sits in s_tr
-  int taddr[8];
+  // where the r-th voxel (x*4 + y*2 + z) of this lane's pooling cell (cx, cy, cz) sits in s_tr: the voxel is (2 cx + rx,
+  // 2 cy + ry, 2 cz + rz), written by lane (x & 3) + 4 (y & 3) + 16 (z & 3) as its sub-block (x >> 2, y >> 2, z >> 2) --
+  // one per-lane base plus a compile-time offset per r (an immediate of the ds_read), not eight address registers
+  const int tbase = (2 * ((lane >> 4) & 1) + 8 * ((lane >> 2) & 1) + 32 * (lane & 1)) * 8 + ((lane >> 5) & 1) * 4 +
+                    ((lane >> 3) & 1) * 2 + ((lane >> 1) & 1);
+  // pooled output, tile-invariant per lane: item i = lane + 64 k of a window is float4 `part` of cell i / (kWin / 4)
+  // (staged at s_stage + 4 i); eo[k] = its float offset inside the pose without the window's channel base, part in
+  // the two low bits (the offset is a multiple of 4), all ones = outside the grid
+  unsigned eo[kWin / 4];
+  if (MODE != 0) {
+    const int S = v.N / 2;
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int x = 2 * (lane >> 4) + (r >> 2), y = 2 * ((lane >> 2) & 3) + ((r >> 1) & 1), z = 2 * (lane & 3) + (r & 1);
-    taddr[r] = ((x & 3) + 4 * (y & 3) + 16 * (z & 3)) * 8 + (x >> 2) * 4 + (y >> 2) * 2 + (z >> 2);
+    for (int k = 0; k < kWin / 4; k++) {
+      const int i = lane + 64 * k;
+      const int cell = i / (kWin / 4), part = i - cell * (kWin / 4);  // cell = cx * 16 + cy * 4 + cz, like the owner lane
+      const int rx = tx * 4 + (cell >> 4), ry = ty * 4 + ((cell >> 2) & 3), rz = tz * 4 + (cell & 3);
+      eo[k] = (rx < S && ry < S && rz < S) ? ((unsigned)(((rx * S + ry) * S + rz) * Cp + 4 * part) | (unsigned)part) : 0xffffffffu;
+    }
   }
   auto clear_window = [&]() {
 #pragma unroll
@@ -318,16 +332,20 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     __builtin_amdgcn_wave_barrier();
     const int S = v.N / 2;
     const int c0 = cur_w * kWin;
+    // (uniform 64-bit base of the pose + a 32-bit offset inside it -- a pooled pose is at most 48^3 x 36 floats: the
+    // store's address is then an SGPR base and one VGPR offset instead of 64-bit multiplies per lane and window; this
+    // kernel's time is its VALU instruction count)
+    const size_t pose_off = (size_t)b * S * S * S * Cp;
+    float *out_pose = v.out + pose_off;
 #pragma unroll
     for (int k = 0; k < kWin / 4; k++) {
-      const int i = lane + 64 * k;
-      const int cell = i / (kWin / 4), part = i - cell * (kWin / 4);  // cell = cx * 16 + cy * 4 + cz, like the owner lane
-      const int rx = tx * 4 + (cell >> 4), ry = ty * 4 + ((cell >> 2) & 3), rz = tz * 4 + (cell & 3);
-      if (rx < S && ry < S && rz < S && c0 + 4 * part < Cp) {
-        const size_t o = ((((size_t)b * S + rx) * S + ry) * S + rz) * Cp + c0 + 4 * part;
-        *reinterpret_cast<float4 *>(v.out + o) = *reinterpret_cast<const float4 *>(s_stage + cell * kWin + 4 * part);
+      const int part = (int)(eo[k] & 3u);
+      if (eo[k] != 0xffffffffu && c0 + 4 * part < Cp) {
+        const unsigned o = (eo[k] & ~3u) + (unsigned)c0;
+        // (cell * kWin + 4 * part == 4 * i: the staged tile is read back in item order)
+        *reinterpret_cast<float4 *>(out_pose + o) = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
         if (MODE == 1 && v.argmax_out)
-          *reinterpret_cast<unsigned *>(v.argmax_out + o) = *reinterpret_cast<const unsigned *>(s_arg + cell * kWin + 4 * part);
+          *reinterpret_cast<unsigned *>(v.argmax_out + pose_off + o) = *reinterpret_cast<const unsigned *>(s_arg + 4 * (lane + 64 * k));
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -357,18 +375,29 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     __builtin_amdgcn_wave_barrier();
     float cv[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) cv[r] = s_tr[taddr[r]];
+    for (int r = 0; r < 8; r++) cv[r] = s_tr[tbase + ((r >> 2) + 4 * ((r >> 1) & 1) + 16 * (r & 1)) * 8];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (MODE == 1) {
-      float m = cv[0];
+      float m;
       int am = 0;
+      if (v.argmax_out) {  // gradient program: the arg-max travels with the value
+        m = cv[0];
 #pragma unroll
-      for (int i = 1; i < 8; i++)
-        if (cv[i] > m) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
-          m = cv[i];
-          am = i;
-        }
+        for (int i = 1; i < 8; i++)
+          if (cv[i] > m) {  // first maximum in (kd,kh,kw) scan order, like max_pool3d
+            m = cv[i];
+            am = i;
+          }
+      } else {
+        // forward only: the same maximum from three v_max3_f32 (densities are finite and non-negative; the compare
+        // chain above costs a v_cmp, a v_cndmask and the SGPR hazard slots between them per voxel)
+        float m1, m2;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(cv[0]), "v"(cv[1]), "v"(cv[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(cv[3]), "v"(cv[4]), "v"(cv[5]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(m1), "v"(cv[6]), "v"(cv[7]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m1), "v"(m2));
+      }
       while (cur_w < c / kWin) emit_window();
       s_stage[lane * kWin + (c - cur_w * kWin)] = m;
       if (v.argmax_out) s_arg[lane * kWin + (c - cur_w * kWin)] = (unsigned char)am;
@@ -436,8 +465,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
 #pragma unroll
           for (int dz = 0; dz < 2; dz++) {
             float rsq = (dxx[dx] + dyy[dy]) + dzz[dz];
-            acc[dx * 4 + dy * 2 + dz] =
-                acc[dx * 4 + dy * 2 + dz] + density(rsq, t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
+            density_add(acc[dx * 4 + dy * 2 + dz], rsq, t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
           }
     }
   }
