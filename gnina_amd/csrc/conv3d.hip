@@ -87,6 +87,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   int2 *s_list = reinterpret_cast<int2 *>(smem + (size_t)HV * CCs);
   int *s_flag = reinterpret_cast<int *>(s_list + Q + 5);  // [nchunks][CC4] "this channel quad is non-zero in the tile"
   int *s_vox = s_flag + p.nchunks * CC4;                 // [HV] voxel index of every halo position inside the pose, -1 = padding
+  // [27] sparse list building: .x = byte offset of snake tap i inside the halo tile, .y = its tap index (weight row)
+  int2 *s_tap = reinterpret_cast<int2 *>((reinterpret_cast<size_t>(s_vox + HV) + 7) & ~(size_t)7);  // (8-byte aligned)
   const int wstride_i = p.coutp * 4;                     // floats per quad row of packed weights
   auto list_entry = [&](int q, int wrow) -> int2 {
     const int tap = q / CC4, c4 = q - tap * CC4;
@@ -98,6 +100,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   // (ReLU'd activations): every existing quad stays listed -- the K loop runs in the list's channel-major order with
   // its per-MFMA zero test, and that order does not depend on the tile or its contents
   const bool detect = SPARSE && p.sparse == 1;
+  if (SPARSE && tid < taps) {  // the tap walk of the per-chunk lists, once per workgroup (the list loop then has no divisions)
+    const int tap = taps == 27 ? conv_snake_tap(tid) : tid;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_tap[tid] = make_int2(p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs * 4 : 0, tap);
+  }
   for (int i = tid; i < p.nchunks * CC4; i += NTHREADS) s_flag[i] = (SPARSE && p.sparse == 2 && i < p.cin4) ? 1 : 0;
   // Row Q of every chunk's packed weights is all zero (ConvArgs::wrows): the list entry behind the last quad points
   // there, so an odd number of quads needs no special case in the K loop (the idle half-wave multiplies by zeros).
@@ -309,16 +316,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
       // Channel-major order (all 27 taps of one surviving quad, then the next quad): the two quads of a pair are then
       // the same four channels one tap apart, i.e. nearly the same voxels -- so that the per-M-tile zero test in the K
       // loop below finds BOTH halves of an MFMA's A operand empty about as often as one.
+      // (boustrophedon walk of the 3x3x3 taps, conv_snake_tap: consecutive taps are always face neighbours; its tile
+      // offsets come from s_tap -- this loop runs on the first J threads while the rest of the workgroup waits)
       for (int j = tid; j < J; j += NTHREADS) {
-        const int a = j / taps;
-        int tap = j - a * taps;
-        if (taps == 27) {  // boustrophedon walk of the 3x3x3 taps: consecutive taps are always face neighbours
-          const int dx = tap / 9;
-          int r = tap - 9 * dx;
-          if (dx & 1) r = 8 - r;
-          const int dy = r / 3, k = r - 3 * dy;
-          tap = dx * 9 + dy * 3 + ((dy & 1) ? 2 - k : k);
-        }
+        const int a = taps == 27 ? (int)(((unsigned)j * 2428u) >> 16) : j;  // j / 27 for j < 4,000
+        const int2 tp = s_tap[j - a * taps];
         int c4 = a;
         if (n_act != CC4) {
           int seen = -1;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
             }
           }
         }
-        const int q = tap * CC4 + c4;
-        s_list[j] = list_entry(q, q);
+        const int q = tp.y * CC4 + c4;
+        s_list[j] = make_int2(tp.x + c4 * 16, q * wstride_i * 4);
       }
       if (tid < 5) s_list[J + tid] = list_entry(Q - 1, Q);  // the pad entries: zero weights
       __syncthreads();
@@ -807,7 +809,7 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   // (the N = 16 kernel keeps a [Q + 12] offset table where this one has its [Q + 5] int2 list: sized for the larger)
-  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 6) + p.nchunks * p.cc4 + HV) * sizeof(int);
+  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 6) + p.nchunks * p.cc4 + HV + 1 + 2 * 27) * sizeof(int);
   const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (p.coutp + 4) * sizeof(float) : 0;
   return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }
