@@ -16,6 +16,7 @@
 // librccl.so (570 MB) is opened on demand, only when a pool of more than one device takes the device-resident path;
 // single-GPU users and the host-buffer path never load it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <condition_variable>
@@ -115,6 +116,12 @@ struct Pool {
   std::vector<std::unique_ptr<Worker>> w;
   Rccl rccl;
   bool comms_ready = false;
+  // transport of the device-resident path: RCCL point-to-point (default), or plain device-to-device copies
+  // (hipMemcpyAsync between the devices' buffers: xGMI DMA with peer access) when MI_POOL_NO_RCCL is set, when librccl
+  // cannot be initialised, or when a device is listed twice (MI_POOL_ALLOW_DUPLICATE_DEVICES=1: a test hook that lets a
+  // one-GPU box run several workers and so exercise every shard / offset of both paths)
+  bool use_rccl = true, duplicates = false;
+  std::string rccl_note;
   long calls_host = 0, calls_device = 0;
   std::string info;
 };
@@ -164,11 +171,18 @@ mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *mo
   try {
     MIG_CHECK(devices && n_devices > 0 && model_paths && n_models > 0, 1, "bad arguments");
     const int have = mi_gnina_device_count();
+    const bool allow_dup = getenv("MI_POOL_ALLOW_DUPLICATE_DEVICES") != nullptr;
+    bool dup = false;
     for (int g = 0; g < n_devices; g++) {
       MIG_CHECK(devices[g] >= 0 && devices[g] < have, 1, "device index out of range");
-      for (int k = 0; k < g; k++) MIG_CHECK(devices[k] != devices[g], 1, "a device is listed twice");
+      for (int k = 0; k < g; k++) {
+        MIG_CHECK(devices[k] != devices[g] || allow_dup, 1, "a device is listed twice");
+        dup = dup || devices[k] == devices[g];
+      }
     }
     auto p = std::make_unique<Pool>();
+    p->duplicates = dup;
+    p->use_rccl = !dup && getenv("MI_POOL_NO_RCCL") == nullptr;
     for (int g = 0; g < n_devices; g++) {
       auto wk = std::make_unique<Worker>();
       wk->device = devices[g];
@@ -292,9 +306,57 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
     MIG_CHECK(err.empty(), 3, err);
     return MI_OK;
   }
-  // device-resident: poses / centres / outputs live on devices[0]; scatter and gather over xGMI with RCCL
-  ensure_comms(p);
+  // device-resident: poses / centres / outputs live on devices[0]; scatter and gather over xGMI
   p.calls_device++;
+  if (p.use_rccl) {
+    try {
+      ensure_comms(p);
+    } catch (const std::exception &e) {  // no usable librccl: the copy transport does the same job
+      p.use_rccl = false;
+      p.rccl_note = e.what();
+    }
+  }
+  if (!p.use_rccl) {
+    // every worker pulls its shard from devices[0] and pushes its scores back with device-to-device copies; no
+    // rendezvous between workers at all
+    const std::string err = on_all(p, [&](Worker &x) -> std::string {
+      try {
+        int b0, nb;
+        shard(B, G, x.rank, b0, nb);
+        if (nb == 0) return "";
+        const float *my_lig = lig_xyz, *my_cen = centers;
+        float *o_pose = pose, *o_aff = affinity, *o_loss = loss, *o_var = aff_var;
+        if (x.rank != 0) {
+          x.d_lig.ensure((size_t)nb * L * 3);
+          MIG_HIP(hipMemcpyAsync(x.d_lig.p, lig_xyz + (size_t)b0 * L * 3, (size_t)nb * L * 3 * sizeof(float), hipMemcpyDefault, x.stream));
+          my_lig = x.d_lig.p;
+          if (centers) {
+            x.d_cen.ensure((size_t)nb * 3);
+            MIG_HIP(hipMemcpyAsync(x.d_cen.p, centers + (size_t)b0 * 3, (size_t)nb * 3 * sizeof(float), hipMemcpyDefault, x.stream));
+            my_cen = x.d_cen.p;
+          }
+          MIG_HIP(hipStreamSynchronize(x.stream));
+          x.d_out.ensure((size_t)4 * nb);
+          o_pose = x.d_out.p, o_aff = o_pose + nb, o_loss = o_aff + nb, o_var = aff_var ? o_loss + nb : nullptr;
+        }
+        if (mi_scorer_score_batch_ex(x.scorer, my_lig, lig_smt, nb, L, my_cen, o_pose, o_aff, o_loss, o_var,
+                                     MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
+          return last("mi_scorer_score_batch_ex");
+        if (mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
+        if (x.rank != 0) {
+          float *dst[4] = {pose, affinity, loss, aff_var};
+          for (int a = 0; a < (aff_var ? 4 : 3); a++)
+            MIG_HIP(hipMemcpyAsync(dst[a] + b0, x.d_out.p + (size_t)a * nb, (size_t)nb * sizeof(float), hipMemcpyDefault, x.stream));
+          MIG_HIP(hipStreamSynchronize(x.stream));
+        }
+        return "";
+      } catch (const std::exception &ex) {
+        return ex.what();
+      }
+    });
+    MIG_CHECK(err.empty(), 3, err);
+    return MI_OK;
+  }
   Rccl &R = p.rccl;
   const std::string err = on_all(p, [&](Worker &x) -> std::string {
     auto nc = [&](ncclResult_t r, const char *what) -> std::string {
@@ -399,7 +461,8 @@ const char *mi_pool_info_json(mi_pool *pp) {
   std::ostringstream o;
   o << "{\"devices\": [";
   for (size_t g = 0; g < p.w.size(); g++) o << (g ? ", " : "") << p.w[g]->device;
-  o << "], \"ranks\": " << p.w.size() << ", \"rccl_loaded\": " << (p.rccl.h ? "true" : "false")
+  o << "], \"ranks\": " << p.w.size() << ", \"device_path_transport\": \"" << (p.use_rccl ? "rccl" : "copies") << "\""
+    << ", \"rccl_loaded\": " << (p.rccl.h ? "true" : "false")
     << ", \"rccl_comms\": " << (p.comms_ready ? "true" : "false") << ", \"calls_host_path\": " << p.calls_host
     << ", \"calls_device_path\": " << p.calls_device << "}";
   p.info = o.str();

@@ -183,7 +183,8 @@ mi_status mi_scorer_synchronize(mi_scorer *);
  *   host buffers    every worker moves its own shard over its own PCIe link (no GPU-to-GPU traffic);
  *   MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE
  *                   poses / centres / outputs live on devices[0]: shards are scattered and the scores gathered over
- *                   xGMI with RCCL (ncclSend / ncclRecv groups); librccl.so is opened on first use of this path only.
+ *                   xGMI with RCCL (ncclSend / ncclRecv groups); librccl.so is opened on first use of this path only
+ *                   (MI_POOL_NO_RCCL, or a librccl that cannot be initialised: plain device-to-device copies instead).
  * A pool of one device forwards to its single scorer (any flag combination).  Not thread-safe: one caller at a time. */
 typedef struct mi_pool mi_pool;
 mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *model_paths, int n_models);

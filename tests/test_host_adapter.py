@@ -346,3 +346,56 @@ def test_pool_python_binding_matches_single_scorer():
     w2, g2 = s.score_ragged(xyz, smt), p.score_ragged(xyz, smt)
     assert np.array_equal(w2["pose"], g2["pose"]) and np.array_equal(w2["affinity"], g2["affinity"])
     assert p.info()["ranks"] == len(p.devices)
+
+
+@pytest.mark.gpu
+def test_pool_shards_with_several_workers_on_one_gpu(monkeypatch):
+    """Every shard boundary and offset of mi_pool's host-buffer and device-resident paths, on a one-GPU box: the test hook
+    MI_POOL_ALLOW_DUPLICATE_DEVICES lets devices = [0, 0, 0] run three workers (three scorers, three streams) on the same
+    GPU; the device-resident path then moves the shards with device-to-device copies (RCCL refuses duplicate devices --
+    with distinct devices the same shards travel through ncclSend / ncclRecv).  Results must equal one scorer's bits."""
+    from gnina_amd import capi, synth
+    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
+    capi.init(0)
+    name = "default2017"
+    m = capi.Model(name)
+    rng = np.random.RandomState(8)
+    rx, rs = synth.make_receptor(rng, 1800, synth.mapped_types(m.chan_of_smt(False)))
+    lx, ls = synth.make_ligand(rng, 20, synth.mapped_types(m.chan_of_smt(True)))
+    B = 203                                                       # 67 / 68 / 68: uneven contiguous shards
+    poses = synth.make_poses(rng, lx, B)
+    centers = (poses.mean(1) + rng.uniform(-0.5, 0.5, (B, 3))).astype(np.float32)
+    s = capi.Scorer([m])
+    s.set_receptor(rx, rs)
+    want = s.score_batch(poses, ls, centers=centers)
+    p = capi.Pool([name], devices=[0, 0, 0])
+    p.set_receptor(rx, rs)
+    got = p.score_batch(poses, ls, centers=centers)
+    for k in ("pose", "affinity", "loss"):
+        assert np.array_equal(want[k], got[k]), k
+    # device buffers straight from the HIP runtime (no torch in this test: plain C ABI + hipMalloc, like a C++ caller)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes, hip.hipMemcpy.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def dmalloc(nbytes):
+        ptr = C.c_void_p()
+        assert hip.hipSetDevice(0) == 0 and hip.hipMalloc(C.byref(ptr), nbytes) == 0
+        return ptr
+
+    d_lig, d_cen, d_out = dmalloc(poses.nbytes), dmalloc(centers.nbytes), dmalloc(4 * B * 4)
+    assert hip.hipMemcpy(d_lig, poses.ctypes.data_as(C.c_void_p), poses.nbytes, 1) == 0       # hipMemcpyHostToDevice
+    assert hip.hipMemcpy(d_cen, centers.ctypes.data_as(C.c_void_p), centers.nbytes, 1) == 0
+    outp = [C.c_void_p(d_out.value + 4 * B * a) for a in range(4)]
+    p.score_batch_device(d_lig, ls, B, poses.shape[1], outp[0], outp[1], outp[2], outp[3], centers_ptr=d_cen)
+    o = np.empty((4, B), dtype=np.float32)
+    assert hip.hipMemcpy(o.ctypes.data_as(C.c_void_p), d_out, o.nbytes, 2) == 0                # hipMemcpyDeviceToHost
+    for ptr in (d_lig, d_cen, d_out):
+        hip.hipFree(ptr)
+    assert np.array_equal(o[0], want["pose"]) and np.array_equal(o[1], want["affinity"]) and np.array_equal(o[2], want["loss"])
+    info = p.info()
+    assert info["ranks"] == 3 and info["device_path_transport"] == "copies" and info["calls_device_path"] == 1
+    with pytest.raises(capi.MiGninaError):                        # without the hook a duplicate is an error
+        monkeypatch.delenv("MI_POOL_ALLOW_DUPLICATE_DEVICES")
+        capi.Pool([name], devices=[0, 0])
