@@ -44,6 +44,14 @@ namespace mig {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// "some component is not +0" on the bit patterns: v_or3 + v_or + v_cmp.  (Written as x.x != 0.f || x.y != 0.f || ... the
+// compiler materialises four booleans with v_cmp / v_cndmask pairs and merges them with 16-bit shifts: 16 VALU
+// instructions and their SGPR hazard slots per staged float4.  -0 counts as non-zero here, as in the K loop's own test;
+// either answer is exact: a skipped +-0 operand would only have added +-0 to accumulators that cannot hold -0.)
+__device__ __forceinline__ bool any_bits(const float4 &x) {
+  return (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) != 0u;
+}
+
 // (second launch bound = waves per SIMD the register allocation must leave room for: the two-accumulator shapes run
 // four workgroups per CU, i.e. <= 128 VGPRs; the TM = 7 shape two)
 // SP: 0 dense K loop (every quad, order by ConvArgs::korder); 1 K loop over the per-chunk list of surviving quads
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
                 x.w = x.w * sc.w + sh.w;
               }
               *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
-              if (detect && (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f)) s_flag[chunk * CC4 + qb + u] = 1;
+              if (detect && any_bits(x)) s_flag[chunk * CC4 + qb + u] = 1;
             }
         }
       }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
           }
         }
         *reinterpret_cast<float4 *>(s_tile + dst[u]) = v;
-        if (detect && cq[u] >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) s_flag[chunk * CC4 + cq[u]] = 1;
+        if (detect && cq[u] >= 0 && any_bits(v)) s_flag[chunk * CC4 + cq[u]] = 1;
       }
     }
     __syncthreads();
