@@ -32,6 +32,8 @@
 //      rounding does not depend on the tile);
 //   the N = 16 kernel of the Dense blocks does 2. on x * bn_scale, with the BatchNorm shift folded into a bias table.
 #include "common.h"
+
+#include <type_traits>
 #include "conv3d.h"
 
 #include <stdexcept>
@@ -50,6 +52,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // either answer is exact: a skipped +-0 operand would only have added +-0 to accumulators that cannot hold -0.)
 __device__ __forceinline__ bool any_bits(const float4 &x) {
   return (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) != 0u;
+}
+
+// Eval BatchNorm of one staged channel quad.  The quad index is wave-uniform, so scale and shift are read through the
+// constant address space: two s_load_dwordx4 into SGPRs (the tables are written once at model load).  As plain global
+// loads they sat in the vector memory queue BEHIND the batch of activation loads and were waited on with vmcnt(0) per
+// quad -- one full L2 latency per staged float4, and the "U loads in flight" batching gone.
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) bn_f32x4 *ConstQuadPtr;
+struct BnQuad {
+  bn_f32x4 sc, sh;
+};
+__device__ __forceinline__ BnQuad bn_load(const float *scale, const float *shift, int c) {
+  return {*(ConstQuadPtr)(const void *)(scale + c), *(ConstQuadPtr)(const void *)(shift + c)};
+}
+__device__ __forceinline__ void bn_apply(float4 &x, const BnQuad &q) {
+  x.x = x.x * q.sc.x + q.sh.x;
+  x.y = x.y * q.sc.y + q.sh.y;
+  x.z = x.z * q.sc.z + q.sh.z;
+  x.w = x.w * q.sc.w + q.sh.w;
 }
 
 // (second launch bound = waves per SIMD the register allocation must leave room for: the two-accumulator shapes run
@@ -199,38 +220,63 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
       // lanes on gfx950: every VALU instruction here is time taken from the K loops of the co-resident waves).
       const float *src_c = in_b + c_base;
       const int nq = min(CC4, p.cin4 - chunk * CC4);  // quads of this chunk that exist in the input
-      for (int hv = tid; hv < HV; hv += NTHREADS) {
-        const int off = s_vox[hv];
-        if (off < 0) continue;  // zero padding, already in place
-        float *dst = s_tile + hv * CCs;
-        for (int qb = 0; qb < nq; qb += U) {
-          float4 val[U];
+      // (two copies of the loop, with and without BatchNorm, and full groups of U quads apart from the tail: straight-line
+      // code lets the compiler issue the U vector loads and the 2 U scalar loads together and feed the SGPRs to
+      // v_pk_mul / v_pk_add directly)
+      auto stage = [&](auto has_bn) {
+        constexpr bool BN = decltype(has_bn)::value;
+        for (int hv = tid; hv < HV; hv += NTHREADS) {
+          const int off = s_vox[hv];
+          if (off < 0) continue;  // zero padding, already in place
+          float *dst = s_tile + hv * CCs;
+          const float *src = src_c + off;
+          int qb = 0;
+          for (; qb + U <= nq; qb += U) {
+            float4 val[U];
+            BnQuad bn[U];
 #pragma unroll
-          for (int u = 0; u < U; u++)
-            if (qb + u < nq) {
+            for (int u = 0; u < U; u++) {
 #if MI_CONV_EXPERIMENT == 1  // (tools/conv_experiments.sh: staging without its global loads)
               val[u] = make_float4(1.f, 0.5f, 0.25f, 2.f);
 #else
-              val[u] = *reinterpret_cast<const float4 *>(src_c + off + (qb + u) * 4);
+              val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
 #endif
+              if constexpr (BN) bn[u] = bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4);
             }
 #pragma unroll
-          for (int u = 0; u < U; u++)
-            if (qb + u < nq) {
+            for (int u = 0; u < U; u++) {
               float4 x = val[u];
-              if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
-                const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c_base + (qb + u) * 4);
-                const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c_base + (qb + u) * 4);
-                x.x = x.x * sc.x + sh.x;
-                x.y = x.y * sc.y + sh.y;
-                x.z = x.z * sc.z + sh.z;
-                x.w = x.w * sc.w + sh.w;
-              }
+              if constexpr (BN) bn_apply(x, bn[u]);  // eval BatchNorm on the conv input; padding stays exactly 0
               *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
               if (detect && any_bits(x)) s_flag[chunk * CC4 + qb + u] = 1;
             }
+          }
+          if (qb < nq) {  // the tail of 1 .. U - 1 quads, its loads batched as well
+            float4 val[U - 1];
+#pragma unroll
+            for (int u = 0; u < U - 1; u++)
+              if (qb + u < nq) {
+#if MI_CONV_EXPERIMENT == 1
+                val[u] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+#else
+                val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+#endif
+              }
+#pragma unroll
+            for (int u = 0; u < U - 1; u++)
+              if (qb + u < nq) {
+                float4 x = val[u];
+                if constexpr (BN) bn_apply(x, bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4));
+                *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
+                if (detect && any_bits(x)) s_flag[chunk * CC4 + qb + u] = 1;
+              }
+          }
         }
-      }
+      };
+      if (p.bn_scale)
+        stage(std::true_type{});
+      else
+        stage(std::false_type{});
       if (nq < CC4)  // partial last chunk: its missing quads still hold the previous chunk's channels
         for (int it = tid; it < HV * (CC4 - nq); it += NTHREADS) {
           const int hv = it / (CC4 - nq), c4 = nq + it - hv * (CC4 - nq);
@@ -687,31 +733,48 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
     const float *src_c = in_b + c_base;
     const int nq = min(CC4, p.cin4 - chunk * CC4);
     constexpr int U = 4;
-    for (int hv = tid; hv < HV; hv += NTHREADS) {
-      const int off = s_vox[hv];
-      if (off < 0) continue;
-      float *dst = s_tile + hv * CCs;
-      for (int qb = 0; qb < nq; qb += U) {
-        float4 val[U];
+    auto stage = [&](auto has_bn) {
+      constexpr bool BN = decltype(has_bn)::value;
+      for (int hv = tid; hv < HV; hv += NTHREADS) {
+        const int off = s_vox[hv];
+        if (off < 0) continue;
+        float *dst = s_tile + hv * CCs;
+        const float *src = src_c + off;
+        int qb = 0;
+        for (; qb + U <= nq; qb += U) {
+          float4 val[U];
+          BnQuad bn[U];
 #pragma unroll
-        for (int u = 0; u < U; u++)
-          if (qb + u < nq) val[u] = *reinterpret_cast<const float4 *>(src_c + off + (qb + u) * 4);
+          for (int u = 0; u < U; u++) {
+            val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+            if constexpr (BN) bn[u] = bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4);
+          }
 #pragma unroll
-        for (int u = 0; u < U; u++)
-          if (qb + u < nq) {
+          for (int u = 0; u < U; u++) {
             float4 x = val[u];
-            if (p.bn_scale) {  // eval BatchNorm on the conv input; padding stays exactly 0
-              const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + c_base + (qb + u) * 4);
-              const float4 sh = *reinterpret_cast<const float4 *>(p.bn_shift + c_base + (qb + u) * 4);
-              x.x = x.x * sc.x + sh.x;
-              x.y = x.y * sc.y + sh.y;
-              x.z = x.z * sc.z + sh.z;
-              x.w = x.w * sc.w + sh.w;
-            }
+            if constexpr (BN) bn_apply(x, bn[u]);  // eval BatchNorm on the conv input; padding stays exactly 0
             *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
           }
+        }
+        if (qb < nq) {  // the tail of 1 .. U - 1 quads, its loads batched as well
+          float4 val[U - 1];
+#pragma unroll
+          for (int u = 0; u < U - 1; u++)
+            if (qb + u < nq) val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+#pragma unroll
+          for (int u = 0; u < U - 1; u++)
+            if (qb + u < nq) {
+              float4 x = val[u];
+              if constexpr (BN) bn_apply(x, bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4));
+              *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
+            }
+        }
       }
-    }
+    };
+    if (p.bn_scale)
+      stage(std::true_type{});
+    else
+      stage(std::false_type{});
     if (nq < CC4)  // partial last chunk: its missing quads still hold the previous chunk's channels
       for (int it = tid; it < HV * (CC4 - nq); it += NTHREADS) {
         const int hv = it / (CC4 - nq), c4 = nq + it - hv * (CC4 - nq);
