@@ -546,8 +546,10 @@ class Scorer:
         return {"pose": pose, "affinity": aff, "loss": loss, "variance": var, "lig_grad": grad}
 
     def set_precision(self, bf16):
-        """False: exact fp32 (parity path); True: bf16-MFMA convolutions (forward only)."""
-        check(lib().mi_scorer_set_precision(self.handle, 1 if bf16 else 0))
+        """False / 0 / "fp32": the parity path (split-fp16 forward convolutions where planned); True / 1 / "bf16": the bf16
+        path; 2 / "fp32_mfma": fp32 MFMA for every layer (include/mi_gnina.h, mi_scorer_set_precision)."""
+        code = {"fp32": 0, "bf16": 1, "fp32_mfma": 2}.get(bf16, bf16)
+        check(lib().mi_scorer_set_precision(self.handle, int(code)))
 
     def set_rotations(self, quats):
         """per-pose unit quaternions (a, b, c, d) for the NEXT scoring call (TorchModel::forward's `rotate`)"""

@@ -69,6 +69,10 @@ struct ConvArgs {
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
   // the raster order costs 3 LDS cycles per group) -- see DESIGN.md section 3.1.
   int mt_x;
+  // split-fp16 kernels (conv3d_h2.hip) only: cc4 counts OCTETS per K chunk, ccs fp16 elements per halo voxel in LDS, cin4
+  // stays the input's channel QUADS, wp is the packed [chunk][pair][2][coutp][h0..h7 | l0..l7] fp16 array of the weights
+  // times 1 / h2_unscale (a power of two); sparse != 0 = skip the MFMAs of an all-zero A operand
+  float h2_unscale;
 };
 
 constexpr int kMfmaCountSlots = 1024;
@@ -109,6 +113,10 @@ void launch_conv_bf16(const ConvArgs &p, int cfg, int B, hipStream_t s);
 void launch_gmax_bf16(const void *in, float *out, int B, int C, int in_cs, int out_cs, int S, hipStream_t s);
 void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in, int B, int C, int in_cs, int out_cs,
                                int S, hipStream_t s);
+
+size_t conv_h2_lds_bytes(const ConvArgs &p);
+bool conv_h2_has_cfg(int cfg);
+void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);
 
 void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s);
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);

@@ -1,0 +1,362 @@
+// conv3d_h2.hip -- the split-fp16 forward convolution: fp32 tensors, fp32 accumulation, f16 MFMA rate.
+//
+// gfx950 runs v_mfma_f32_32x32x16_f16 at 16x the rate of v_mfma_f32_32x32x2_f32, and the product of two fp16 numbers is
+// exact in the fp32 accumulator.  Every fp32 operand is written as  a = h + l  with  h = RN_f16(a),  l = RN_f16(a - h)
+// (22-23 significant bits between them) and the product as
+//     a * w  ~=  h_a * h_w  +  h_a * l_w  +  l_a * h_w                      (dropped: l_a * l_w, relative 2^-22)
+// = three MFMAs where the fp32 kernels (conv3d.hip) issue eight for the same K = 16: 5.3x their matrix rate.  Weights are
+// split once at model load, scaled by a per-layer power of two (exact; it keeps their low parts out of the fp16 subnormal
+// range) that the epilogue takes out again; activations are split while the halo tile is staged (after the eval
+// BatchNorm, which stays fp32), so HBM holds plain fp32 tensors and this kernel is interchangeable, layer by layer, with
+// the fp32 kernels of the same program.  Measured against the float64 forward of the same operands the scores move by
+// <= 1e-6 (tools/experiments/split_precision_probe.py; the parity bar is 1e-4) -- unlike the bf16 kernels
+// (conv3d_bf16.hip: 4e-2), this IS a parity path.  Forward only: the transposed convolutions of the gradient pass stay on
+// the fp32 kernels.
+//
+// Decomposition as in conv3d.hip: a workgroup owns a box of 2x2x2 cells of one pose and all (or a group of) output
+// channels; an M-tile is 32 voxels = four cells, so ReLU + pooling stay register-local in the 32x32 accumulator layout.
+// K runs over OCTETS (8 consecutive input channels at one tap), channel-major inside a K chunk; lanes 0-31 feed k = 0..7
+// of an instruction from octet 2p, lanes 32-63 k = 8..15 from octet 2p + 1.  LDS holds the halo tile as
+// [voxel][octet][h0..h7 | l0..l7] fp16: one lane's A operands of a step are 32 contiguous bytes (two ds_read_b128).
+#include "common.h"
+#include "conv3d.h"
+
+#include <type_traits>
+
+namespace mig {
+
+typedef float h2_f32x16 __attribute__((ext_vector_type(16)));
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) h2_f32x4 *H2ConstQuadPtr;
+
+// a -> (h, l), four channels at a time: h = RN_f16(a), l = RN_f16(a - h).  12 VALU instructions per quad: four clamps (an
+// activation beyond the fp16 range -- |a| > 65504, not a value these networks produce -- stays a large finite number
+// instead of inf - inf = NaN), two packed conversions, four v_fma_mix_f32 (a - h with h read as fp16: exact, one
+// instruction instead of v_cvt_f32_f16 + v_sub_f32), two packed conversions.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  const h2_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &l) {
+  const float c0 = __builtin_amdgcn_fmed3f(x.x, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(x.y, -65504.f, 65504.f);
+  const float c2 = __builtin_amdgcn_fmed3f(x.z, -65504.f, 65504.f), c3 = __builtin_amdgcn_fmed3f(x.w, -65504.f, 65504.f);
+  h.x = pk_f16(c0, c1);
+  h.y = pk_f16(c2, c3);
+  float r0, r1, r2, r3;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h.x), "v"(c0));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h.x), "v"(c1));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h.y), "v"(c2));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h.y), "v"(c3));
+  l.x = pk_f16(r0, r1);
+  l.y = pk_f16(r2, r3);
+}
+
+template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 : 1)) void conv3d_h2_kernel(ConvArgs p) {
+  constexpr int NTHREADS = 64 * WM * WN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int kh = lane >> 5;
+  const int row = lane & 31;
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+  const int n_base = (blockIdx.y * WN + wn) * TN * 32;
+
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const int HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo;
+  const int HV = HX * HY * HZ;
+  const int CC8 = p.cc4, CCs = p.ccs;  // octets per K chunk / fp16 elements per halo voxel in LDS (16 per octet + pad)
+  const int taps = p.ksize == 3 ? 27 : 1;
+  const int Qmax = taps * CC8;
+
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h2[];
+  _Float16 *s_tile = smem_h2;                                                              // [HV][CCs]
+  int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HV * CCs + 7) & ~(size_t)7));  // [Qmax + 4] byte offsets
+  int *s_vox = s_qoff + ((Qmax + 4 + 3) & ~3);  // [HV] float offset of every halo voxel's channel row, -1 = padding
+
+  // octet q of a chunk (channel-major: all taps of octet 0, then octet 1, ...) -> byte offset inside the halo tile.  The
+  // four entries behind the last octet repeat it: an odd octet count leaves the second half-wave of the last step on real
+  // (finite) data, which its all-zero weight rows cancel, and the K loop reads the table one step ahead.
+  for (int q = tid; q < Qmax + 4; q += NTHREADS) {
+    const int qq = q < Qmax ? q : Qmax - 1;
+    const int c8 = qq / taps, tap = qq - c8 * taps;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = ((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c8 * 16) * 2;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
+  const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
+  auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) -> bool {  // (ConvArgs::mt_x, as in conv3d.hip)
+    if (MTX) {
+      cz = mt % p.tcz;
+      cy = (mt / p.tcz) % p.tcy;
+      cx = 4 * (mt / (p.tcz * p.tcy)) + cim;
+      return cx < p.tcx;
+    }
+    const int cell = mt * 4 + cim;
+    cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    return cell < NC;
+  };
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cx, cy, cz;
+    if (!cell_of(wm * TM + m, cell_in_mt, cx, cy, cz)) cx = cy = cz = 0;
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs * 2;  // bytes
+  }
+
+  h2_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; m++)
+#pragma unroll
+    for (int n = 0; n < TN; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;  // (see conv3d_mfma_kernel)
+  for (int hv = tid; hv < HV; hv += NTHREADS) {
+    const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    if (!in)  // the zero padding is laid down once per workgroup; staging then touches the voxels inside the grid only
+      for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + hv * CCs + c) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
+  const size_t wstride = (size_t)p.coutp * 16;  // fp16 elements per octet row of the packed weights
+  const int Pmax = (Qmax + 1) >> 1;
+
+  // ---- staging, software-pipelined over the K chunks: the fp32 quads of chunk k + 1 are loaded into registers before the
+  // K loop of chunk k and split / written to LDS after it.  (A load -> split -> ds_write chain per halo voxel exposes one
+  // L2 latency per voxel and chunk; at the f16 MFMA rate that was longer than the K loop itself: 116 KB of LDS = one
+  // workgroup per CU, nothing to overlap with, ran the first conv at 4.3 ms against 2.25 ms with three per CU.)
+  // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them (the plans keep HV <= VPT * NTHREADS), NQ quads each.
+  constexpr int VPT = 3, NQ = 4;
+  float4 pre[VPT][NQ];
+  auto issue = [&](int chunk) {
+    const float *src_c = in_b + chunk * CC8 * 8;
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);  // channel quads of this chunk that exist in the input
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+      const int hv = tid + v * NTHREADS;
+      const int off = hv < HV ? s_vox[hv] : -1;
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+        if (off >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + off + q * 4);
+    }
+  };
+  auto commit = [&](int chunk) {
+    const int c_base = chunk * CC8 * 8;
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+      const int hv = tid + v * NTHREADS;
+      const int off = hv < HV ? s_vox[hv] : -1;
+      if (off < 0) continue;  // zero padding, laid down once
+      _Float16 *dst = s_tile + hv * CCs;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        if (q >= 2 * CC8) continue;
+        _Float16 *d = dst + (q >> 1) * 16 + (q & 1) * 4;
+        uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+        // quads the input does not have (channel padding of the last octet, a partial last chunk's unused octets --
+        // which the pad entries of s_qoff may point at) are zero, not the previous chunk's channels
+        if (q < nq) {
+          float4 x = pre[v][q];
+          if (p.bn_scale) {  // eval BatchNorm on the conv input (scalar loads: the quad is wave-uniform); padding stays 0
+            const h2_f32x4 sc = *(H2ConstQuadPtr)(const void *)(p.bn_scale + c_base + q * 4);
+            const h2_f32x4 sh = *(H2ConstQuadPtr)(const void *)(p.bn_shift + c_base + q * 4);
+            x.x = x.x * sc.x + sh.x;
+            x.y = x.y * sc.y + sh.y;
+            x.z = x.z * sc.z + sh.z;
+            x.w = x.w * sc.w + sh.w;
+          }
+          // the pooled voxel grid and ReLU'd activations are mostly zeros: a quad that is zero in all 64 voxels of the wave
+          // (3 VALU + a scalar branch to find out) needs no arithmetic
+          const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
+          if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) split4(x, h, l);
+        }
+        *reinterpret_cast<uint2 *>(d) = h;
+        *reinterpret_cast<uint2 *>(d + 8) = l;
+      }
+    }
+  };
+  __syncthreads();  // s_vox
+  issue(0);
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    if (chunk > 0) __syncthreads();  // every wave is through the previous chunk's K loop: the tile may be overwritten
+    commit(chunk);
+    if (chunk + 1 < p.nchunks) issue(chunk + 1);
+    __syncthreads();
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
+
+    // ---- K loop over octet pairs, ping-pong operand sets (see conv3d_bf16.hip) ----
+    const int cc8_here = min(CC8, (nq + 1) >> 1);      // octets of this chunk that carry input channels
+    const int P = (cc8_here * taps + 1) >> 1;          // its octet pairs (the packed weights hold Pmax per chunk)
+    // weight rows: uniform chunk base in SGPRs + a 32-bit lane offset that is affine in the step
+    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * Pmax * 2 * wstride * 2;
+    const unsigned wlane = ((unsigned)(n_base + row) * 16u + (unsigned)kh * (unsigned)wstride) * 2u;
+    const unsigned wstep = 2u * (unsigned)wstride * 2u;  // bytes per octet pair
+    const int *lp = s_qoff + kh;
+    int qo_next = lp[0];  // the tile offset of a lane's octet is read one step ahead of its use
+    uint4 wh0[TN], wl0[TN], wh1[TN], wl1[TN], ah0[TM], al0[TM], ah1[TM], al1[TM];
+    auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 *wh, uint4 *wl) {
+      const int qo = qo_next;
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const char *a = reinterpret_cast<const char *>(s_tile) + baseA[m] + qo;
+        ah[m] = *reinterpret_cast<const uint4 *>(a);
+        al[m] = *reinterpret_cast<const uint4 *>(a + 16);
+      }
+#pragma unroll
+      for (int n = 0; n < TN; n++) {
+        const char *w = wbase + (wlane + (unsigned)pr * wstep + (unsigned)n * 32u * 32u);
+        wh[n] = *reinterpret_cast<const uint4 *>(w);
+        wl[n] = *reinterpret_cast<const uint4 *>(w + 16);
+      }
+      qo_next = lp[2 * pr + 2];  // (behind the last pair: a pad entry, or the next octet's first tap -- unused either way)
+    };
+    auto mfma_pair = [&](const uint4 *ah, const uint4 *al, const uint4 *wh, const uint4 *wl) {
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        if constexpr (SKIP) {
+          // all 32 voxels x 16 k of this step zero (h = 0 implies l = 0): nothing to add.  One v_or3 + v_or + v_cmp into
+          // an SGPR pair and a scalar branch against three (x TN) MFMAs
+          const unsigned any = ah[m].x | ah[m].y | ah[m].z | ah[m].w;
+          unsigned long long live;
+          asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live) : "v"(any));
+          if (live == 0ull) continue;
+        }
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh[n]), acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl[n]), acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh[n]), acc[m][n], 0, 0, 0);
+        }
+      }
+    };
+    load_pair(0, ah0, al0, wh0, wl0);
+    int pr = 0;
+    for (; pr + 1 < P; pr += 2) {
+      load_pair(pr + 1, ah1, al1, wh1, wl1);
+      mfma_pair(ah0, al0, wh0, wl0);
+      if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
+      mfma_pair(ah1, al1, wh1, wl1);
+    }
+    if (P & 1) mfma_pair(ah0, al0, wh0, wl0);
+  }
+
+  // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last fp32 ----
+  const float unscale = p.h2_unscale;
+  const int So = p.pool ? S / 2 : S;
+  const size_t out_pose = (size_t)b * So * So * So * p.out_cs + p.out_c0;
+  float *out_f = p.out + out_pose;
+  const int ncx = S / 2;
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      int cx, cy, cz;
+      if (!cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz)) continue;
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+#pragma unroll
+      for (int n = 0; n < TN; n++) {
+        const int ch = n_base + n * 32 + row;
+        if (ch >= p.cout) continue;
+        const float bias = p.bias[ch];
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const float tt = acc[m][n][half * 8 + r] * unscale + bias;
+          v[r] = p.relu ? fmaxf(tt, 0.f) : tt;
+        }
+        if (p.pool == 1) {
+          float mx = v[0];
+          int am = 0;
+#pragma unroll
+          for (int r = 1; r < 8; r++)
+            if (v[r] > mx) mx = v[r], am = r;
+          const size_t o = (((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch;
+          out_f[o] = mx;
+          if (p.argmax_out) p.argmax_out[out_pose + o] = (unsigned char)am;
+        } else if (p.pool == 2) {
+          float s = v[0];
+#pragma unroll
+          for (int r = 1; r < 8; r++) s = s + v[r];
+          out_f[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+            out_f[(((size_t)vx * So + vy) * So + vz) * p.out_cs + ch] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+size_t conv_h2_lds_bytes(const ConvArgs &p) {
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
+  const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
+  return ((HV * p.ccs + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 4 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+}
+
+template <int WM, int WN, int TM, int TN, bool MTX> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {
+  const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
+  dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
+  if (p.sparse) {
+    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_kernel<WM, WN, TM, TN, MTX, true>), 160 * 1024);
+    hipLaunchKernelGGL((conv3d_h2_kernel<WM, WN, TM, TN, MTX, true>), grid, block, conv_h2_lds_bytes(p), s, p);
+  } else {
+    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_kernel<WM, WN, TM, TN, MTX, false>), 160 * 1024);
+    hipLaunchKernelGGL((conv3d_h2_kernel<WM, WN, TM, TN, MTX, false>), grid, block, conv_h2_lds_bytes(p), s, p);
+  }
+}
+
+bool conv_h2_has_cfg(int cfg) {
+  switch (cfg) {
+    case CONV_CFG_4x1_2x1:
+    case CONV_CFG_2x2_3x1:
+    case CONV_CFG_1x4_7x1:
+    case CONV_CFG_4x1_1x3:
+    case CONV_CFG_4x1_1x5:
+    case CONV_CFG_4x1_1x1: return true;
+    default: return false;
+  }
+}
+
+void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
+  switch (cfg) {
+    case CONV_CFG_4x1_2x1:
+      if (p.mt_x) launch_h2<4, 1, 2, 1, true>(p, B, s);
+      else launch_h2<4, 1, 2, 1, false>(p, B, s);
+      break;
+    case CONV_CFG_2x2_3x1: launch_h2<2, 2, 3, 1, false>(p, B, s); break;
+    case CONV_CFG_1x4_7x1: launch_h2<1, 4, 7, 1, false>(p, B, s); break;
+    case CONV_CFG_4x1_1x3: launch_h2<4, 1, 1, 3, false>(p, B, s); break;
+    case CONV_CFG_4x1_1x5: launch_h2<4, 1, 1, 5, false>(p, B, s); break;
+    case CONV_CFG_4x1_1x1: launch_h2<4, 1, 1, 1, false>(p, B, s); break;
+    default: throw Error(2, "launch_conv_h2: tile configuration not compiled");
+  }
+}
+
+}  // namespace mig

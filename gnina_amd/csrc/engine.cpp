@@ -55,6 +55,9 @@ struct ConvPlan {
   bool has_lat = false;
   int lat_cfg = 0;
   int lat_tc[3] = {0, 0, 0};
+  // the same layer on the split-fp16 kernels (conv3d_h2.hip; forward, same tiles, own K chunking and packed weights)
+  bool has_h2 = false;
+  ConvArgs h2{};
 };
 
 // Tile geometry of a launch of `nb` poses: the throughput plan, or the latency variant when the throughput
@@ -112,6 +115,7 @@ struct Model {
   std::vector<int> buf_cp;          // padded channel stride per buffer (0 = never materialised)
   std::vector<Step> steps;          // executable program after fusion
   std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
+  std::vector<char> op_h2;          // per op of the description: the forward program runs it on the split-fp16 kernels
   std::vector<Step> hsteps;         // bf16-MFMA forward program (built on first use, mi_scorer_set_precision)
   std::vector<Step> hgsteps;        // bf16-MFMA gradient program (max-pool networks: Default2017, Dense)
   std::once_flag hsteps_once, hgsteps_once;
@@ -339,6 +343,102 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
 }
 
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp);
+
+// ---- split-fp16 twin of a forward conv plan (conv3d_h2.hip) ----
+static unsigned short host_f2h(float f) {  // fp32 -> fp16, round to nearest even, subnormals and overflow handled
+  unsigned u;
+  memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x7f800000u) return (unsigned short)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);  // rounds to >= 2^16: infinity
+  if (u < 0x33000001u) return (unsigned short)sign;               // <= 2^-25: rounds to zero
+  int e = (int)(u >> 23) - 127;
+  unsigned man = (u & 0x7fffffu) | 0x800000u;  // 24 significant bits
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);  // bits dropped (subnormal results drop more)
+  unsigned q = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  // q holds the implicit bit for normals (bit 10): adding the biased exponent minus one folds a carry in correctly
+  const unsigned out = e >= -14 ? ((unsigned)(e + 15 - 1) << 10) + q : q;
+  return (unsigned short)(sign | out);
+}
+static float host_h2f(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+  const int e = (h >> 10) & 0x1f;
+  const unsigned man = h & 0x3ffu;
+  float v;
+  if (e == 0) v = ldexpf((float)man, -24);
+  else if (e == 31) v = man ? NAN : INFINITY;
+  else v = ldexpf((float)(man | 0x400u), e - 25);
+  return sign ? -v : v;
+}
+
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
+  if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
+  if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
+  ConvArgs a = cp.a;  // geometry, tiles, bias, BatchNorm, ReLU / pool, output slice
+  const int taps = o.ksize * o.ksize * o.ksize;
+  const int halo = o.ksize == 3 ? 1 : 0;
+  const int cin8 = cdiv(o.cin, 8);
+  // K chunking over octets.  The throughput tile and the latency tile share the packed weights, i.e. the chunking: sized
+  // for the larger halo
+  size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
+  if (cp.has_lat)
+    HV = std::max(HV, (size_t)(2 * cp.lat_tc[0] + 2 * halo) * (2 * cp.lat_tc[1] + 2 * halo) * (2 * cp.lat_tc[2] + 2 * halo));
+  size_t budget = 52 * 1024;
+  if (const char *ev = getenv("MI_GNINA_H2_LDS_KB"))
+    if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
+  {  // the kernel's staging registers: three halo voxels per thread, two octets per chunk (conv3d_h2.hip: VPT, NQ)
+    int wm, wn, tm, tn;
+    conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
+    if (HV > (size_t)3 * 64 * wm * wn) return;
+  }
+  int best = 1;
+  for (int c = 1; c <= cin8 && c <= 2; c++)
+    if (HV * (16 * c + 8) * 2 + (size_t)(taps * c + 8) * 4 + HV * 4 <= budget) best = c;
+  const int nchunks = cdiv(cin8, best);
+  best = cdiv(cin8, nchunks);  // equal chunks (the last one may still be an octet short)
+  a.cc4 = best;
+  a.ccs = 16 * best + 8;  // odd number of 16-byte slots per voxel: neighbouring voxels land on different slots
+  a.nchunks = nchunks;
+  a.cin4 = cdiv(o.cin, 4);
+  const int Pmax = (taps * best + 1) / 2;
+  const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
+  float wmax = 0.f;
+  for (size_t i = 0; i < (size_t)taps * o.cin * o.cout; i++) wmax = std::max(wmax, fabsf(w[i]));
+  // per-layer power of two that lifts the weights to ~2^14: their low halves stay normal fp16 numbers
+  const float sw = wmax > 0.f ? ldexpf(1.f, 14 - (int)floorf(log2f(wmax)) - 1) : 1.f;
+  std::vector<unsigned short> wp((size_t)nchunks * Pmax * 2 * a.coutp * 16, 0);
+  for (int ch = 0; ch < nchunks; ch++)
+    for (int c8 = 0; c8 < best && ch * best + c8 < cin8; c8++)
+      for (int tap = 0; tap < taps; tap++) {
+        const int q = c8 * taps + tap, pr = q >> 1, kh = q & 1;
+        for (int j = 0; j < 8; j++) {
+          const int c = (ch * best + c8) * 8 + j;
+          if (c >= o.cin) continue;
+          for (int n = 0; n < o.cout; n++) {
+            const float v = w[((size_t)tap * o.cin + c) * o.cout + n] * sw;
+            const unsigned short hi = host_f2h(v), lo = host_f2h(v - host_h2f(hi));
+            const size_t idx = ((((size_t)ch * Pmax + pr) * 2 + kh) * a.coutp + n) * 16;
+            wp[idx + j] = hi;
+            wp[idx + 8 + j] = lo;
+          }
+        }
+      }
+  std::vector<float> wpf((wp.size() + 1) / 2, 0.f);
+  memcpy(wpf.data(), wp.data(), wp.size() * sizeof(unsigned short));
+  a.wp = push_dev(m, wpf);
+  a.h2_unscale = 1.f / sw;
+  a.sparse = 0;
+  a.korder = 0;
+  a.bias_tab = nullptr;
+  a.mfma_count = nullptr;
+  MIG_CHECK(conv_h2_lds_bytes(a) <= 160 * 1024, 2, "split-fp16 conv tile exceeds LDS");
+  cp.h2 = a;
+  cp.has_h2 = true;
+}
+
 // ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
 static unsigned short host_f2bf(float f) {
   unsigned u;
@@ -547,6 +647,7 @@ static Model *build_model(ModelDesc &&desc) {
   m->input_pool = d.ops[0].pool_mode;
   m->input_dst = d.ops[0].dst;
   m->buf_cp[m->input_dst] = round_up(d.bufs[m->input_dst].C, 4);
+  m->op_h2.assign(d.ops.size(), 0);
   auto build_steps = [&](bool grad) {
     std::vector<Step> out;
     for (size_t i = 1; i < d.ops.size(); i++) {
@@ -558,6 +659,7 @@ static Model *build_model(ModelDesc &&desc) {
         // (gradient program: only max pools are fused -- their arg-max is saved; avg pools keep the
         // pre-pool activation, which the ReLU backward needs)
         int pool_mode = 0, dst = o.dst, dst_c0 = o.dst_c0;
+        const size_t conv_op_index = i;
         // fuse "conv3 -> ReLU -> conv1 (same width) -> ..." (Default2018's unit pairs): the 1x1x1 conv runs as a
         // second MFMA pass on the LDS-transposed tile inside the first conv's kernel (forward program only --
         // the gradient program needs the intermediate activation)
@@ -590,6 +692,11 @@ static Model *build_model(ModelDesc &&desc) {
           }
         }
         plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
+        // the split-fp16 twin (not for the Dense blocks' 16-wide layers, not with a fused 1x1 conv).  The gradient
+        // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
+        // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
+        if (!post && st.conv.a.coutp % 32 == 0 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
+        if (!grad) m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
         if (post) {
           {
             int wm_, wn_, tm_, tn_;
@@ -706,6 +813,9 @@ struct Scorer {
   std::vector<Model *> models;
   hipStream_t stream = nullptr;
   int precision = 0;  // 0 = fp32 (parity path), 1 = bf16-MFMA forward (mi_scorer_set_precision)
+  // fp32 forward convolutions: 1 = on the split-fp16 kernels where a layer has that plan (conv3d_h2.hip), 0 = fp32 MFMA only
+  // (MI_PRECISION_FP32_MFMA, or MI_GNINA_CONV_PATH=f32 in the environment)
+  int conv_path = (getenv("MI_GNINA_CONV_PATH") && !strcmp(getenv("MI_GNINA_CONV_PATH"), "f32")) ? 0 : 1;
   int cap = 1024;    // poses per launch of the call in flight: min(chunk, B, what the activation budget allows)
   int chunk = 1024;  // poses per launch: fewer, larger launches win (93.6k vs 87.1k poses/s at 256); 2.4 MB/pose of HBM
   bool have_receptor = false;
@@ -1266,10 +1376,22 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s%s", a.ksize, a.S, st.conv.cin, a.cout,
                    a.post_w ? "+conv1" : "", a.pool ? "_pool" : "");
           if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
+          if (!bf16 && st.conv.has_h2 && s.conv_path != 0) strncat(nm, "_h2", sizeof nm - strlen(nm) - 1);
           ProfScope ps(s, nm, 2.0 * nb * S3 * (taps * st.conv.cin * a.cout + (a.post_w ? (double)a.cout * st.post_cout : 0.0)),
                        (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
           if (bf16) {
             launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
+          } else if (st.conv.has_h2 && s.conv_path != 0) {
+            // split-fp16 kernel: same tensors, same tiles (pick_tile), own K chunking and weights
+            ConvArgs h = st.conv.h2;
+            h.in = a.in, h.in_cs = a.in_cs, h.out = a.out, h.out_cs = a.out_cs, h.argmax_out = a.argmax_out;
+            h.sparse = a.sparse ? 1 : 0;
+            if (getenv("MI_GNINA_H2_NO_SKIP")) h.sparse = 0;
+            int cfg;
+            ConvArgs geo = a;
+            pick_tile(st.conv, nb, geo, cfg);
+            h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
+            launch_conv_h2(h, cfg, nb, s.stream);
           } else {
             int cfg;
             pick_tile(st.conv, nb, a, cfg);
@@ -1798,8 +1920,11 @@ mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_
 mi_status mi_scorer_set_precision(mi_scorer *sc, int precision) {
   MI_TRY
   MIG_CHECK(sc, 1, "NULL scorer");
-  MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16, 1, "unknown precision");
-  reinterpret_cast<Scorer *>(sc)->precision = precision;
+  MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16 || precision == MI_PRECISION_FP32_MFMA, 1,
+            "unknown precision");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  s.precision = precision == MI_PRECISION_BF16 ? 1 : 0;
+  if (precision != MI_PRECISION_BF16) s.conv_path = precision == MI_PRECISION_FP32_MFMA ? 0 : 1;
   return MI_OK;
   MI_CATCH_STATUS
 }

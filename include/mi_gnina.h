@@ -108,12 +108,16 @@ mi_status mi_scorer_score_batch(mi_scorer *, const float *lig_xyz, const int32_t
 mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                    const float *centers, float *pose, float *affinity, float *loss,
                                    float *aff_var, unsigned flags);
-/* Arithmetic of the CNN forward pass.  MI_PRECISION_FP32 (default) is the parity path: exact fp32 MFMA,
- * scores within 1e-4 of the reference.  MI_PRECISION_BF16 (BASELINE config 5, "bf16 MFMA path") runs the
- * convolutions on v_mfma_f32_32x32x16_bf16 with bf16 activations / weights and fp32 accumulation; voxelization,
- * the fully connected heads and the score post-processing stay fp32.  Its deviation from the fp32 path is a
- * measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.  Gradient calls always run in fp32. */
-enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1 };
+/* Arithmetic of the CNN forward pass.  MI_PRECISION_FP32 (default) is the parity path, scores within 1e-4 of the
+ * reference: fp32 tensors and fp32 accumulation everywhere; the forward convolutions run on the split-fp16 kernels
+ * (each fp32 operand = the sum of two fp16 numbers, three v_mfma_f32_32x32x16_f16 per product, exact products:
+ * <= 1e-6 from the fp32-MFMA result on the scores) where a layer has that plan, on fp32 MFMA otherwise.
+ * MI_PRECISION_FP32_MFMA forces v_mfma_f32_32x32x2_f32 / 16x16x4_f32 for every layer (the round-2 path).
+ * MI_PRECISION_BF16 (BASELINE config 5, "bf16 MFMA path") runs the convolutions on v_mfma_f32_32x32x16_bf16 with bf16
+ * activations / weights and fp32 accumulation; voxelization, the fully connected heads and the score post-processing
+ * stay fp32.  Its deviation from the fp32 path is a measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.
+ * Gradient calls always run on the fp32-MFMA kernels. */
+enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 };
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading

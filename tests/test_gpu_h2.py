@@ -1,0 +1,83 @@
+"""The split-fp16 forward convolutions (gnina_amd/csrc/conv3d_h2.hip) against the fp32-MFMA kernels of the same layers.
+
+Both are the parity path (MI_PRECISION_FP32 picks the split kernels where a layer has that plan, MI_PRECISION_FP32_MFMA
+forces fp32 MFMA): every product of the split path is exact and the accumulation is fp32, so the scores may differ by
+rounding noise only.  The bar here is 1e-5, a tenth of the parity bar against the reference; the measured differences are
+printed.  Parity against the reference's own outputs is what tests/test_gpu_parity.py checks -- on the default path,
+i.e. on these kernels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["default2017", "crossdock_default2018", "crossdock_default2018_KD_4", "dense", "dense_1_3", "dense_1_3_PT_KD_3"]
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from gnina_amd import capi as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def CG(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_goldens.npz"))
+
+
+def _both(capi, models, rec_xyz, rec_smt, poses, lig_smt):
+    s = capi.Scorer(models)
+    s.set_receptor(rec_xyz, rec_smt)
+    s.set_precision("fp32_mfma")
+    ref = s.score_batch(poses, lig_smt)
+    s.set_precision("fp32")
+    new = s.score_batch(poses, lig_smt)
+    return ref, new
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("B", [4, 96])
+def test_split_fp16_scores_equal_fp32_mfma_scores(capi, CG, name, B):
+    from gnina_amd import synth
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    if B > len(poses):  # 4 poses take the latency tiles, 96 the throughput tiles
+        poses = np.concatenate([poses, synth.make_poses(np.random.RandomState(5), poses[0] - poses[0].mean(0), B - len(poses))])
+    ref, new = _both(capi, [name], rec_xyz, rec_smt, poses, lig_smt)
+    dp, da = np.abs(new["pose"] - ref["pose"]).max(), np.abs(new["affinity"] - ref["affinity"]).max()
+    print(f"{name} B={B}: split-fp16 vs fp32 MFMA max|d pose| {dp:.2e} max|d affinity| {da:.2e}")
+    assert np.isfinite(new["pose"]).all() and np.isfinite(new["affinity"]).all()
+    assert dp <= TOL and da <= TOL
+    if B == 4:  # and the default path meets the reference's own outputs
+        assert np.abs(new["pose"][:4] - CG[name + "/pose"]).max() < 1e-4
+        assert np.abs(new["affinity"][:4] - CG[name + "/affinity"]).max() < 1e-4 * max(1.0, np.abs(CG[name + "/affinity"]).max())
+
+
+def test_split_fp16_is_independent_of_the_batch_size_and_tiling(capi, CG):
+    """the latency tiles (small launches) and the throughput tiles walk K in the same order: same bits"""
+    from gnina_amd import synth
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = np.concatenate([poses, synth.make_poses(np.random.RandomState(7), poses[0] - poses[0].mean(0), 92)])
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    big = s.score_batch(many, lig_smt)
+    one = s.score_batch(many[:1], lig_smt)
+    assert one["pose"][0] == big["pose"][0] and one["affinity"][0] == big["affinity"][0]
+
+
+def test_split_fp16_on_nearly_empty_and_crowded_grids(capi, CG):
+    """zero skipping on an (almost) empty grid; many atoms on one spot (large density values)"""
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    far = poses.copy()
+    far[0] += 200.0
+    crowded = (np.repeat(poses[:, :1], poses.shape[1], axis=1) +
+               0.01 * np.arange(poses.shape[1], dtype=np.float32)[None, :, None]).astype(np.float32)
+    for batch in (far, crowded):
+        ref, new = _both(capi, [name], rec_xyz, rec_smt, batch, lig_smt)
+        assert np.abs(new["pose"] - ref["pose"]).max() <= TOL
+        assert np.abs(new["affinity"] - ref["affinity"]).max() <= TOL * max(1.0, float(np.abs(ref["affinity"]).max()))

@@ -15,6 +15,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_fetch -o p -- $BENC
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -f csv -d $OUT/pmc_inst -o p -- $BENCH > $OUT/pmc_inst.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -f csv -d $OUT/pmc_grbm -o p -- $BENCH > $OUT/pmc_grbm.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace -f csv -d $OUT/pmc_occ -o p -- $BENCH > $OUT/pmc_occ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace -f csv -d $OUT/pmc_occ -o p -- $BENCH > $OUT/pmc_occ.log 2>&1
 find $OUT -name "*.csv" | head -40
 tail -3 $OUT/pmc_sq.log | cut -c1-300
