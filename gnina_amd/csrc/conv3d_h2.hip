@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   // L2 latency per voxel and chunk; at the f16 MFMA rate that was longer than the K loop itself: 116 KB of LDS = one
   // workgroup per CU, nothing to overlap with, ran the first conv at 4.3 ms against 2.25 ms with three per CU.)
   // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them (the plans keep HV <= VPT * NTHREADS), NQ quads each.
-  constexpr int VPT = 3, NQ = 4;
+  // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them, NQ channel quads each (the plans keep
+  // HV <= VPT * NTHREADS and 2 CC8 <= NQ).  The tile shapes with three or five N-tiles per wave exist for the 1x1x1
+  // bottlenecks only (no halo: 128 voxels, one per thread, up to six octets of it).
+  constexpr bool K1 = TN >= 3;
+  constexpr int VPT = K1 ? 1 : 3, NQ = K1 ? 12 : 4;
   float4 pre[VPT][NQ];
   auto issue = [&](int chunk) {
     const float *src_c = in_b + chunk * CC8 * 8;
@@ -313,11 +317,208 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-output-channel variant for the Dense blocks (Cout = 16): v_mfma_f32_16x16x32_f16.  An M-tile is 16 voxels = two cells
+// (row = cell * 8 + x * 4 + y * 2 + z, as in conv3d_mfma16_kernel); the 32 k of an instruction are four octets, lane
+// group l >> 4 feeding the fourth it owns.  Eval BatchNorm (scale and shift, fp32) is applied while staging; no zero test
+// (three 16-cycle MFMAs per test are not worth one, and BatchNorm'ed activations are not zeros).
+// ---------------------------------------------------------------------------------------------
+template <int TM>
+__global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(ConvArgs p) {
+  constexpr int NTHREADS = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4;   // which of the four octets of a step this lane feeds
+  const int row = lane & 15;  // A row / B column
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+
+  const int halo = p.ksize == 3 ? 1 : 0;
+  const int HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo;
+  const int HV = HX * HY * HZ;
+  const int CC8 = p.cc4, CCs = p.ccs;
+  const int taps = p.ksize == 3 ? 27 : 1;
+  const int Qmax = taps * CC8;
+  const int Smax = (Qmax + 3) >> 2;  // steps (octet quartets) per chunk of the packed weights
+
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h2[];
+  _Float16 *s_tile = smem_h2;
+  int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HV * CCs + 7) & ~(size_t)7));  // [Qmax + 8] byte offsets
+  int *s_vox = s_qoff + ((Qmax + 8 + 3) & ~3);
+  for (int q = tid; q < Qmax + 8; q += NTHREADS) {
+    const int qq = q < Qmax ? q : Qmax - 1;
+    const int c8 = qq / taps, tap = qq - c8 * taps;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = ((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c8 * 16) * 2;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 2) & 1, cell_in_mt = row >> 3;
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cell = (wm * TM + m) * 2 + cell_in_mt;
+    if (cell >= NC) cell = 0;
+    const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs * 2;  // bytes
+  }
+  h2_f32x4 acc[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) acc[m] = {0.f, 0.f, 0.f, 0.f};
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
+  for (int hv = tid; hv < HV; hv += NTHREADS) {
+    const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    if (!in)
+      for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + hv * CCs + c) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
+
+  // staging, software-pipelined over the K chunks (see conv3d_h2_kernel)
+  constexpr int VPT = 3, NQ = 4;
+  float4 pre[VPT][NQ];
+  auto issue = [&](int chunk) {
+    const float *src_c = in_b + chunk * CC8 * 8;
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);  // channel quads of this chunk that exist in the input
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+      const int hv = tid + v * NTHREADS;
+      const int off = hv < HV ? s_vox[hv] : -1;
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+        if (off >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + off + q * 4);
+    }
+  };
+  auto commit = [&](int chunk) {
+    const int c_base = chunk * CC8 * 8;
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+      const int hv = tid + v * NTHREADS;
+      const int off = hv < HV ? s_vox[hv] : -1;
+      if (off < 0) continue;  // zero padding, laid down once
+      _Float16 *dst = s_tile + hv * CCs;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        if (q >= 2 * CC8) continue;
+        _Float16 *d = dst + (q >> 1) * 16 + (q & 1) * 4;
+        uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+        // quads the input does not have (channel padding of the last octet, a partial last chunk's unused octets --
+        // which the pad entries of s_qoff may point at) are zero, not the previous chunk's channels
+        if (q < nq) {
+          float4 x = pre[v][q];
+          if (p.bn_scale) {  // eval BatchNorm on the conv input (scalar loads: the quad is wave-uniform); padding stays 0
+            const h2_f32x4 sc = *(H2ConstQuadPtr)(const void *)(p.bn_scale + c_base + q * 4);
+            const h2_f32x4 sh = *(H2ConstQuadPtr)(const void *)(p.bn_shift + c_base + q * 4);
+            x.x = x.x * sc.x + sh.x;
+            x.y = x.y * sc.y + sh.y;
+            x.z = x.z * sc.z + sh.z;
+            x.w = x.w * sc.w + sh.w;
+          }
+          split4(x, h, l);
+        }
+        *reinterpret_cast<uint2 *>(d) = h;
+        *reinterpret_cast<uint2 *>(d + 8) = l;
+      }
+    }
+  };
+  __syncthreads();  // s_vox
+  issue(0);
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    if (chunk > 0) __syncthreads();
+    commit(chunk);
+    if (chunk + 1 < p.nchunks) issue(chunk + 1);
+    __syncthreads();
+    const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
+    const int cc8_here = min(CC8, (nq + 1) >> 1);
+    const int NS = (cc8_here * taps + 3) >> 2;  // steps of this chunk (the packed weights hold Smax per chunk)
+
+    // K loop over octet quartets, ping-pong operand sets; weights packed [chunk][step][4][16][h8 | l8], zero rows behind
+    // the last octet of a chunk
+    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * Smax * 4 * 16 * 32;
+    const unsigned wlane = ((unsigned)kg * 16u + (unsigned)row) * 32u;
+    const int *lp = s_qoff + kg;
+    int qo_next = lp[0];
+    uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
+    auto load_step = [&](int st, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
+      const int qo = qo_next;
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const char *a = reinterpret_cast<const char *>(s_tile) + baseA[m] + qo;
+        ah[m] = *reinterpret_cast<const uint4 *>(a);
+        al[m] = *reinterpret_cast<const uint4 *>(a + 16);
+      }
+      const char *w = wbase + (wlane + (unsigned)st * (4u * 16u * 32u));
+      wh = *reinterpret_cast<const uint4 *>(w);
+      wl = *reinterpret_cast<const uint4 *>(w + 16);
+      qo_next = lp[4 * st + 4];
+    };
+    auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) {
+      // (three independent passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+    };
+    load_step(0, ah0, al0, wh0, wl0);
+    int st = 0;
+    for (; st + 1 < NS; st += 2) {
+      load_step(st + 1, ah1, al1, wh1, wl1);
+      mfma_step(ah0, al0, wh0, wl0);
+      if (st + 2 < NS) load_step(st + 2, ah0, al0, wh0, wl0);
+      mfma_step(ah1, al1, wh1, wl1);
+    }
+    if (NS & 1) mfma_step(ah0, al0, wh0, wl0);
+  }
+
+  // epilogue: accumulator row = 4 * (lane >> 4) + reg, column = lane & 15
+  const float unscale = p.h2_unscale;
+  float *out_b = p.out + (size_t)b * S * S * S * p.out_cs + p.out_c0;
+  const int ncx = S / 2;
+  const int ch = row;
+  if (ch < p.cout) {
+    const float bias = p.bias[ch];
+#pragma unroll
+    for (int m = 0; m < TM; m++) {
+      const int cell = (wm * TM + m) * 2 + (kg >> 1);
+      if (cell >= NC) continue;
+      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int vx = 2 * gcx + (kg & 1), vy = 2 * gcy + (r >> 1), vz = 2 * gcz + (r & 1);
+        float v = acc[m][r] * unscale + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        out_b[(((size_t)vx * S + vy) * S + vz) * p.out_cs + ch] = v;
+      }
+    }
+  }
+}
+
 size_t conv_h2_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  return ((HV * p.ccs + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 4 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+  return ((HV * p.ccs + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
 }
 
 template <int WM, int WN, int TM, int TN, bool MTX> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {
@@ -332,6 +533,12 @@ template <int WM, int WN, int TM, int TN, bool MTX> static void launch_h2(const 
   }
 }
 
+template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t s) {
+  dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
+  ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_kernel<TM>), 160 * 1024);
+  hipLaunchKernelGGL((conv3d_h2_16_kernel<TM>), grid, block, conv_h2_lds_bytes(p), s, p);
+}
+
 bool conv_h2_has_cfg(int cfg) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1:
@@ -339,7 +546,11 @@ bool conv_h2_has_cfg(int cfg) {
     case CONV_CFG_1x4_7x1:
     case CONV_CFG_4x1_1x3:
     case CONV_CFG_4x1_1x5:
-    case CONV_CFG_4x1_1x1: return true;
+    case CONV_CFG_4x1_1x1:
+    case CONV_CFG_N16_TM1:
+    case CONV_CFG_N16_TM2:
+    case CONV_CFG_N16_TM3:
+    case CONV_CFG_N16_TM4: return true;
     default: return false;
   }
 }
@@ -355,6 +566,10 @@ void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_1x3: launch_h2<4, 1, 1, 3, false>(p, B, s); break;
     case CONV_CFG_4x1_1x5: launch_h2<4, 1, 1, 5, false>(p, B, s); break;
     case CONV_CFG_4x1_1x1: launch_h2<4, 1, 1, 1, false>(p, B, s); break;
+    case CONV_CFG_N16_TM1: launch_h2_16<1>(p, B, s); break;
+    case CONV_CFG_N16_TM2: launch_h2_16<2>(p, B, s); break;
+    case CONV_CFG_N16_TM3: launch_h2_16<3>(p, B, s); break;
+    case CONV_CFG_N16_TM4: launch_h2_16<4>(p, B, s); break;
     default: throw Error(2, "launch_conv_h2: tile configuration not compiled");
   }
 }

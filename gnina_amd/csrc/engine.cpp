@@ -389,13 +389,17 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   size_t budget = 52 * 1024;
   if (const char *ev = getenv("MI_GNINA_H2_LDS_KB"))
     if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
-  {  // the kernel's staging registers: three halo voxels per thread, two octets per chunk (conv3d_h2.hip: VPT, NQ)
+  // the kernel's staging registers (conv3d_h2.hip: VPT halo voxels per thread x NQ channel quads per chunk -- 3 x 4, or
+  // 1 x 12 on the tile shapes of the 1x1x1 bottlenecks)
+  int vpt = 3, max_c = 2;
+  {
     int wm, wn, tm, tn;
     conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
-    if (HV > (size_t)3 * 64 * wm * wn) return;
+    if (a.coutp != 16 && tn >= 3) vpt = 1, max_c = 6;
+    if (HV > (size_t)vpt * 64 * wm * wn) return;
   }
   int best = 1;
-  for (int c = 1; c <= cin8 && c <= 2; c++)
+  for (int c = 1; c <= cin8 && c <= max_c; c++)
     if (HV * (16 * c + 8) * 2 + (size_t)(taps * c + 8) * 4 + HV * 4 <= budget) best = c;
   const int nchunks = cdiv(cin8, best);
   best = cdiv(cin8, nchunks);  // equal chunks (the last one may still be an octet short)
@@ -403,29 +407,39 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   a.ccs = 16 * best + 8;  // odd number of 16-byte slots per voxel: neighbouring voxels land on different slots
   a.nchunks = nchunks;
   a.cin4 = cdiv(o.cin, 4);
-  const int Pmax = (taps * best + 1) / 2;
+  // octets per MFMA step: two for 32x32x16 (rows [chunk][pair][2][coutp]), four for the 16-wide 16x16x32 ([chunk][step][4][16])
+  const bool n16 = a.coutp == 16;
+  const int kstep = n16 ? 4 : 2;
+  const int Pmax = (taps * best + kstep - 1) / kstep;
   const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
   float wmax = 0.f;
   for (size_t i = 0; i < (size_t)taps * o.cin * o.cout; i++) wmax = std::max(wmax, fabsf(w[i]));
   // per-layer power of two that lifts the weights to ~2^14: their low halves stay normal fp16 numbers
   const float sw = wmax > 0.f ? ldexpf(1.f, 14 - (int)floorf(log2f(wmax)) - 1) : 1.f;
-  std::vector<unsigned short> wp((size_t)nchunks * Pmax * 2 * a.coutp * 16, 0);
+  std::vector<unsigned short> wp((size_t)nchunks * Pmax * kstep * a.coutp * 16, 0);
   for (int ch = 0; ch < nchunks; ch++)
     for (int c8 = 0; c8 < best && ch * best + c8 < cin8; c8++)
       for (int tap = 0; tap < taps; tap++) {
-        const int q = c8 * taps + tap, pr = q >> 1, kh = q & 1;
+        const int q = c8 * taps + tap, pr = q / kstep, kh = q % kstep;
         for (int j = 0; j < 8; j++) {
           const int c = (ch * best + c8) * 8 + j;
           if (c >= o.cin) continue;
           for (int n = 0; n < o.cout; n++) {
             const float v = w[((size_t)tap * o.cin + c) * o.cout + n] * sw;
             const unsigned short hi = host_f2h(v), lo = host_f2h(v - host_h2f(hi));
-            const size_t idx = ((((size_t)ch * Pmax + pr) * 2 + kh) * a.coutp + n) * 16;
+            const size_t idx = ((((size_t)ch * Pmax + pr) * kstep + kh) * a.coutp + n) * 16;
             wp[idx + j] = hi;
             wp[idx + 8 + j] = lo;
           }
         }
       }
+  if (o.bn_scale_off >= 0) {  // the BatchNorm itself (the fp32 plan of a Dense-block layer may carry the zero-shift variant)
+    std::vector<float> sc(a.cin4 * 4, 0.f), sh(a.cin4 * 4, 0.f);
+    std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+    std::copy(m.d.data.begin() + o.bn_shift_off, m.d.data.begin() + o.bn_shift_off + o.cin, sh.begin());
+    a.bn_scale = push_dev(m, sc);
+    a.bn_shift = push_dev(m, sh);
+  }
   std::vector<float> wpf((wp.size() + 1) / 2, 0.f);
   memcpy(wpf.data(), wp.data(), wp.size() * sizeof(unsigned short));
   a.wp = push_dev(m, wpf);
@@ -692,10 +706,10 @@ static Model *build_model(ModelDesc &&desc) {
           }
         }
         plan_conv(*m, o, st.conv, pool_mode, dst, dst_c0);
-        // the split-fp16 twin (not for the Dense blocks' 16-wide layers, not with a fused 1x1 conv).  The gradient
+        // the split-fp16 twin (not with a fused 1x1 conv).  The gradient
         // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
-        if (!post && st.conv.a.coutp % 32 == 0 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
+        if (!post && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
         if (!grad) m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
         if (post) {
           {
@@ -1390,6 +1404,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             int cfg;
             ConvArgs geo = a;
             pick_tile(st.conv, nb, geo, cfg);
+            if (cfg != st.conv.cfg && h.cc4 > 2) cfg = st.conv.cfg, geo = a;  // (1x1x1 bottlenecks: their K chunks need the throughput kernel's staging registers)
             h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
             launch_conv_h2(h, cfg, nb, s.stream);
           } else {
