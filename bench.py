@@ -24,7 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same guide)
+PEAK_F16_MFMA_TFLOPS = 2500.0
+DTYPE_NOTE = ("f32 (fp32 tensors and fp32 accumulation; forward convolutions on f16 MFMA with every operand split into two fp16 "
+              "halves, products exact: scores <= 1e-5 from the fp32-MFMA kernels, see also.fp32_mfma_only)")
+H2_SPLIT = 3.0                  # split-fp16 kernels (conv3d_h2.hip): f16 MFMA FLOPs executed per algorithmic (fp32-product) FLOP
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_POSE = {"default2017": 1122895872, "crossdock_default2018": 998148096, "dense": 4541572416,
                  "dense_1_3@96": 36.33e9}   # SURVEY 8d / BASELINE.md section 2 (2 * MACs, unpadded)
@@ -128,18 +132,22 @@ def roofline_block(dom_conv, avg_ms, exec_flops, exec_src):
     fraction of anything the hardware did), and `dense_no_skip` times the same kernel with skipping off."""
     algo = dom_conv["flops"] / dom_conv["launches"]
     algo_tf = algo / (avg_ms * 1e-3) / 1e12
-    ex = exec_flops if exec_flops else algo          # a kernel without counters executes everything
+    h2 = is_h2(dom_conv["kernel"])
+    peak = PEAK_F16_MFMA_TFLOPS if h2 else PEAK_FP32_MFMA_TFLOPS
+    ex = exec_flops if exec_flops else algo * (H2_SPLIT if h2 else 1.0)   # a kernel without counters executes everything
     ex_tf = ex / (avg_ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
-        "kernel": dom_conv["kernel"] + " (conv3d_mfma_kernel)",
+        "kernel": dom_conv["kernel"] + (" (conv3d_h2_kernel)" if h2 else " (conv3d_mfma_kernel)"),
         "achieved": round(ex_tf, 2),
-        "peak": PEAK_FP32_MFMA_TFLOPS,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": round(ex_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-        "achieved_is": "executed MFMA FLOPs (32x32x2 fp32: 4,096 per instruction) / HIP-event launch time",
+        "frac": round(ex_tf / peak, 4),
+        "achieved_is": ("executed f16-MFMA FLOPs (split-fp16 path: three v_mfma_f32_32x32x16_f16 of 32,768 FLOPs per K = 16 "
+                        "of fp32 products) / HIP-event launch time; peak = dense f16 MFMA") if h2 else
+                       "executed MFMA FLOPs (32x32x2 fp32: 4,096 per instruction) / HIP-event launch time",
         "executed_flops_per_launch": ex,
-        "executed_source": exec_src if exec_flops else "no device counters: executed == algorithmic",
+        "executed_source": exec_src if exec_flops else "no device counters: executed == algorithmic" + (" x 3" if h2 else ""),
         "traffic": None,
         "traffic_from_committed_pmc": pmc_traffic_committed(dom_conv["kernel"]),
         "traffic_note": "HBM bytes per launch from profiles/latest_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / "
@@ -149,24 +157,32 @@ def roofline_block(dom_conv, avg_ms, exec_flops, exec_src):
         "poses_per_launch": dom_conv["poses"] // dom_conv["launches"],
         "algorithmic_flops_per_launch": algo,
         "algorithmic_equivalent_tflops": round(algo_tf, 2),
-        "algorithmic_equivalent_over_peak": round(algo_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-        "mfma_executed_fraction": round(ex / algo, 4),
+        "algorithmic_equivalent_over_fp32_mfma_peak": round(algo_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+        "mfma_executed_fraction": round(ex / (algo * (H2_SPLIT if h2 else 1.0)), 4),
     }
 
 
+def is_h2(kernel_name):
+    return kernel_name.endswith("_h2")
+
+
 def profiled_conv_flops(prof):
-    """(executed, algorithmic) MFMA FLOPs of the conv launches of a profile pass: counted kernels report what they
-    issued, the others execute every algorithmic FLOP."""
-    ex = al = 0.0
+    """(executed, algorithmic, pipe_seconds) of the conv launches of a profile pass: counted kernels report what they
+    issued, the others execute every algorithmic FLOP (x 3 on the split-fp16 kernels); pipe_seconds = the time the MFMA
+    pipes need for the executed work at peak (fp32 MFMA and f16 MFMA launches priced at their own peaks)."""
+    ex = al = pipe = 0.0
     for r in prof:
         if not r["kernel"].startswith("conv"):
             continue
         al += r["flops"]
+        h2 = is_h2(r["kernel"])
         if r.get("mfma_counted_launches"):
-            ex += 4096.0 * r["mfma_executed"] * r["launches"] / r["mfma_counted_launches"]
+            e = 4096.0 * r["mfma_executed"] * r["launches"] / r["mfma_counted_launches"]
         else:
-            ex += r["flops"]
-    return ex, al
+            e = r["flops"] * (H2_SPLIT if h2 else 1.0)
+        ex += e
+        pipe += e / ((PEAK_F16_MFMA_TFLOPS if h2 else PEAK_FP32_MFMA_TFLOPS) * 1e12)
+    return ex, al, pipe
 
 
 def other_models(args, capi, synth, torch, dev):
@@ -174,8 +190,8 @@ def other_models(args, capi, synth, torch, dev):
     (BASELINE.json quotes "48^3 x 28ch": crossdock_default2018 is the shipped 28-channel network; default2017
     as shipped has 35 channels).  Same step/fence structure, same batch, a handful of steps each."""
     out = {}
-    for name in ("crossdock_default2018", "dense"):
-        if name == args.model:
+    for name in (args.model, "crossdock_default2018", "dense"):
+        if name in out:
             continue
         try:
             m = capi.Model(name)
@@ -200,10 +216,30 @@ def other_models(args, capi, synth, torch, dev):
             sc.synchronize()
             dt = time.perf_counter() - t0
             out[name] = {"poses_per_s": round(args.batch * k / dt, 1), "channels": m.n_channels,
-                         "grid": m.grid_points, "steps": k, "dtype": "f32"}
+                         "grid": m.grid_points, "steps": k, "dtype": "f32 (split-fp16 forward convolutions)"}
+            # the same model with fp32 MFMA in every layer (MI_PRECISION_FP32_MFMA), and how far the scores are apart
+            s_split = d_o[:2].cpu().numpy().copy()
+            sc.set_precision("fp32_mfma")
+            for _ in range(2):
+                step()
+            sc.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sc.synchronize()
+            dt2 = time.perf_counter() - t0
+            s_f32 = d_o[:2].cpu().numpy()
+            out[name]["fp32_mfma_only"] = {"poses_per_s": round(args.batch * k / dt2, 1),
+                                           "max_abs_dpose": float(np.abs(s_split[0] - s_f32[0]).max()),
+                                           "max_abs_daffinity": float(np.abs(s_split[1] - s_f32[1]).max())}
             del sc, m
         except Exception as e:  # the headline line must still print
             out[name] = {"error": str(e)}
+    # the headline model's fp32-MFMA-only figures under their own key
+    if args.model in out and "fp32_mfma_only" in out[args.model]:
+        out["fp32_mfma_only"] = dict(out.pop(args.model)["fp32_mfma_only"], model=args.model,
+                                     note="the headline workload with v_mfma_f32_32x32x2_f32 / 16x16x4_f32 in every layer "
+                                          "(the round-2 path); score differences are split-fp16 minus fp32 MFMA on this batch")
     return out
 
 
@@ -225,9 +261,16 @@ def conv1_dense(args, scorer, step, steps):
     conv = max((r for r in prof if r["kernel"].startswith("conv")), key=lambda r: r["ms_total"])
     ms = conv["ms_total"] / conv["launches"]
     tf = conv["flops"] / conv["launches"] / (ms * 1e-3) / 1e12
-    return {"kernel": conv["kernel"], "avg_launch_ms": round(ms, 4), "tflops": round(tf, 2),
-            "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-            "note": "no zero-skipping: executed == algorithmic FLOPs"}
+    h2 = is_h2(conv["kernel"])
+    out = {"kernel": conv["kernel"], "avg_launch_ms": round(ms, 4), "tflops": round(tf, 2),
+           "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+           "note": "no zero-skipping: executed == algorithmic FLOPs"}
+    if h2:
+        out["executed_f16_mfma_tflops"] = round(H2_SPLIT * tf, 2)
+        out["frac_of_f16_mfma_peak"] = round(H2_SPLIT * tf / PEAK_F16_MFMA_TFLOPS, 4)
+        out["note"] = ("no zero-skipping: executed f16-MFMA FLOPs == 3 x algorithmic; `tflops` is the algorithmic "
+                       "(fp32-product) rate, which may exceed the fp32-MFMA peak -- the roofline of this kernel is the f16 one")
+    return out
 
 
 def config_c3(capi, cpu_seconds=0.0):
@@ -496,19 +539,21 @@ def config_c4(capi, synth):
     tf = fwd * FLOP_PER_POSE["crossdock_default2018"] / 1e12
     s.enable_profile(True)                       # one more pass, untimed: what the MFMA pipe executed
     s.score_ragged(xyz, smt)
-    ex, al = profiled_conv_flops(s.profile())
+    ex, al, pipe_s = profiled_conv_flops(s.profile())
     s.enable_profile(False)
     ex_tf = ex / dt / 1e12
     return {"workload": f"C4 (one GPU's shard): 1,024 ligands x 9 poses, L ~ U{{16..48}}, ragged, 15 x Default2018 "
                         f"({len(have)} distinct weight blobs), host pointers",
             "ligands_per_s": round(n_lig / dt, 1), "poses_per_s": round(n_lig * P / dt, 1),
             "model_forwards_per_s": round(fwd, 1), "s_per_100k_ligands_1gpu": round(1e5 / (n_lig / dt), 1),
-            "roofline": {"bound": "mfma", "achieved": round(ex_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ex_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "achieved_is": "executed MFMA FLOPs of all conv launches / wall time of the call",
+            "roofline": {"bound": "mfma", "achieved": round(ex_tf, 2), "peak": round(ex / pipe_s / 1e12, 1) if pipe_s else None,
+                         "unit": "TFLOP/s", "frac": round(pipe_s / dt, 4),
+                         "achieved_is": "executed MFMA FLOPs of all conv launches / wall time of the call; peak = the same "
+                                        "FLOPs / the time the pipes need for them at peak (f16-MFMA launches of the "
+                                        "split-fp16 path and fp32-MFMA launches priced at their own peaks)",
                          "mfma_executed_fraction": round(ex / al, 4) if al else None,
                          "algorithmic_equivalent_tflops": round(tf, 2),
-                         "algorithmic_equivalent_over_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "algorithmic_equivalent_over_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "note": "end to end incl. voxelization, PCIe and host set-up"}}
 
 
@@ -538,13 +583,19 @@ def config_c5(capi, synth):
         tf = B / dt * gf / 1e12
         s.enable_profile(True)
         s.score_batch(poses, ls)
-        ex, al = profiled_conv_flops(s.profile())
+        ex, al, pipe_s = profiled_conv_flops(s.profile())
         s.enable_profile(False)
-        ex_tf = (ex / al if al else 1.0) * tf      # executed share of the algorithmic rate (bf16 kernels: no counters, 1.0)
+        if bf:      # bf16 kernels: no counters, executed == algorithmic, priced at the bf16 peak
+            ach, pk, frac = tf, peak, tf / peak
+        else:       # parity path: split-fp16 (f16 peak) and fp32-MFMA launches, each priced at its own peak
+            ach = ex / dt / 1e12
+            pk = ex / pipe_s / 1e12 if pipe_s else peak
+            frac = pipe_s / dt
         out[tag] = {"poses_per_s_forward": round(B / dt, 1), "poses_per_s_forward_backward": round(B / dg, 1),
-                    "roofline": {"bound": "mfma", "achieved": round(min(tf, ex_tf), 2), "peak": peak, "unit": "TFLOP/s",
-                                 "frac": round(min(tf, ex_tf) / peak, 4),
-                                 "achieved_is": "executed MFMA FLOPs / wall time of the forward call",
+                    "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(pk, 1), "unit": "TFLOP/s",
+                                 "frac": round(frac, 4),
+                                 "achieved_is": "executed MFMA FLOPs / wall time of the forward call (peak: the launches' own "
+                                                "MFMA peaks, FLOP-weighted)",
                                  "algorithmic_equivalent_tflops": round(tf, 2),
                                  "mfma_executed_fraction": round(ex / al, 4) if al else None,
                                  "note": "forward, end to end (voxelization, PCIe, host set-up included)"}}
@@ -740,7 +791,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_NOTE if os.environ.get("MI_GNINA_CONV_PATH") != "f32" else "f32",
             "data": "synthetic atoms (SURVEY 8d C2, seeded); real reference weights extracted from the shipped .pt",
             "config": {
                 "workload": f"C2: {B} poses/GPU/step, receptor {args.n_rec} atoms, ligand {args.n_lig} atoms, "

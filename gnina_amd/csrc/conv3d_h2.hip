@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
     for (int n = 0; n < TN; n++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+  unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; a scalar counter, read in profile mode only)
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           unsigned long long live;
           asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(live) : "v"(any));
           if (live == 0ull) continue;
+          n_exec++;
         }
 #pragma unroll
         for (int n = 0; n < TN; n++) {
@@ -265,6 +267,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
     }
     if (P & 1) mfma_pair(ah0, al0, wh0, wl0);
   }
+
+  // profile mode: executed MFMA work in units of 4,096 FLOPs (the fp32 kernels count 32x32x2 instructions): an executed
+  // (M-tile, step) is 3 TN instructions of 32,768 FLOPs
+  if (SKIP && p.mfma_count && lane == 0)
+    atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec * (3u * TN * 8u));
 
   // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last fp32 ----
   const float unscale = p.h2_unscale;
@@ -344,19 +351,22 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
   const int HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo;
   const int HV = HX * HY * HZ;
   const int CC8 = p.cc4, CCs = p.ccs;
+  // LDS strides in fp16 elements: voxel, z-row, x-plane.  Rows and planes may carry pad slots of 16 bytes
+  // (ConvArgs::h2_pad_y / h2_pad_x, chosen with tools/microbench/lds_bank_sim_h2.py against bank conflicts)
+  const int SZ = CCs, SY = HZ * SZ + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;
   const int taps = p.ksize == 3 ? 27 : 1;
   const int Qmax = taps * CC8;
   const int Smax = (Qmax + 3) >> 2;  // steps (octet quartets) per chunk of the packed weights
 
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_h2[];
   _Float16 *s_tile = smem_h2;
-  int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HV * CCs + 7) & ~(size_t)7));  // [Qmax + 8] byte offsets
+  int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HX * SX + 7) & ~(size_t)7));  // [Qmax + 8] byte offsets
   int *s_vox = s_qoff + ((Qmax + 8 + 3) & ~3);
   for (int q = tid; q < Qmax + 8; q += NTHREADS) {
     const int qq = q < Qmax ? q : Qmax - 1;
     const int c8 = qq / taps, tap = qq - c8 * taps;
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    s_qoff[q] = ((p.ksize == 3 ? ((dx * HY + dy) * HZ + dz) * CCs : 0) + c8 * 16) * 2;
+    s_qoff[q] = ((p.ksize == 3 ? dx * SX + dy * SY + dz * SZ : 0) + c8 * 16) * 2;
   }
 
   const int NC = p.tcx * p.tcy * p.tcz;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
     int cell = (wm * TM + m) * 2 + cell_in_mt;
     if (cell >= NC) cell = 0;
     const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
-    baseA[m] = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * CCs * 2;  // bytes
+    baseA[m] = ((2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz) * SZ) * 2;  // bytes
   }
   h2_f32x4 acc[TM];
 #pragma unroll
@@ -376,19 +386,25 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
   const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
-  for (int hv = tid; hv < HV; hv += NTHREADS) {
+  constexpr int VPT = 3, NQ = 4;  // staging: halo voxels per thread x channel quads per chunk (see conv3d_h2_kernel)
+  int st_dst[VPT];                // LDS element of this thread's v-th halo voxel
+#pragma unroll
+  for (int v = 0; v < VPT; v++) {
+    const int hv = tid + v * NTHREADS;
+    st_dst[v] = 0;
+    if (hv >= HV) continue;
     const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
     const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
     const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
     const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
     s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    st_dst[v] = hx * SX + hy * SY + hz * SZ;
     if (!in)
-      for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + hv * CCs + c) = make_uint4(0u, 0u, 0u, 0u);
+      for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + st_dst[v] + c) = make_uint4(0u, 0u, 0u, 0u);
   }
   const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
 
   // staging, software-pipelined over the K chunks (see conv3d_h2_kernel)
-  constexpr int VPT = 3, NQ = 4;
   float4 pre[VPT][NQ];
   auto issue = [&](int chunk) {
     const float *src_c = in_b + chunk * CC8 * 8;
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
       const int hv = tid + v * NTHREADS;
       const int off = hv < HV ? s_vox[hv] : -1;
       if (off < 0) continue;  // zero padding, laid down once
-      _Float16 *dst = s_tile + hv * CCs;
+      _Float16 *dst = s_tile + st_dst[v];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         if (q >= 2 * CC8) continue;
@@ -516,9 +532,10 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
 
 size_t conv_h2_lds_bytes(const ConvArgs &p) {
   const int halo = p.ksize == 3 ? 1 : 0;
-  const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
+  const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
-  return ((HV * p.ccs + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+  const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // (pads: 16-wide kernel only)
+  return ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
 }
 
 template <int WM, int WN, int TM, int TN, bool MTX> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {

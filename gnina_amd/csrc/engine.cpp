@@ -398,6 +398,9 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
     if (a.coutp != 16 && tn >= 3) vpt = 1, max_c = 6;
     if (HV > (size_t)vpt * 64 * wm * wn) return;
   }
+  a.h2_pad_y = a.h2_pad_x = 0;
+  if (a.coutp == 16 && o.ksize == 3)  // MI_GNINA_H2_PADS=y,x: LDS pad slots of the 16-wide kernel (tuning)
+    if (const char *ev = getenv("MI_GNINA_H2_PADS")) sscanf(ev, "%d,%d", &a.h2_pad_y, &a.h2_pad_x);
   int best = 1;
   for (int c = 1; c <= cin8 && c <= max_c; c++)
     if (HV * (16 * c + 8) * 2 + (size_t)(taps * c + 8) * 4 + HV * 4 <= budget) best = c;
@@ -1406,6 +1409,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             pick_tile(st.conv, nb, geo, cfg);
             if (cfg != st.conv.cfg && h.cc4 > 2) cfg = st.conv.cfg, geo = a;  // (1x1x1 bottlenecks: their K chunks need the throughput kernel's staging registers)
             h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
+            h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
           } else {
             int cfg;
