@@ -113,7 +113,8 @@ struct Model {
   int input_pool = 0;    // 1 max, 2 avg: first op, fused into the voxelizer
   int input_dst = -1;    // buffer receiving the pooled grid
   std::vector<int> buf_cp;          // padded channel stride per buffer (0 = never materialised)
-  std::vector<Step> steps;          // executable program after fusion
+  std::vector<Step> steps;          // executable program after fusion (split-fp16 kernels where planned)
+  std::vector<Step> steps32;        // the same with fp32 MFMA in every layer and the fused 3x3x3 + 1x1x1 pairs (MI_PRECISION_FP32_MFMA)
   std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
   std::vector<char> op_h2;          // per op of the description: the forward program runs it on the split-fp16 kernels
   std::vector<Step> hsteps;         // bf16-MFMA forward program (built on first use, mi_scorer_set_precision)
@@ -665,7 +666,11 @@ static Model *build_model(ModelDesc &&desc) {
   m->input_dst = d.ops[0].dst;
   m->buf_cp[m->input_dst] = round_up(d.bufs[m->input_dst].C, 4);
   m->op_h2.assign(d.ops.size(), 0);
-  auto build_steps = [&](bool grad) {
+  // f32only: no split-fp16 plans, and "conv3 -> ReLU -> conv1" pairs fused into one fp32 kernel (the intermediate tensor
+  // never reaches HBM).  The default forward program runs such a pair as two split-fp16 kernels instead: at the f16 MFMA
+  // rate the round trip of the intermediate tensor costs less than the fused fp32 kernel's MFMAs.
+  auto build_steps = [&](bool grad, bool f32only) {
+    const bool no_h2 = f32only || getenv("MI_GNINA_NO_H2");
     std::vector<Step> out;
     for (size_t i = 1; i < d.ops.size(); i++) {
       const Op &o = d.ops[i];
@@ -681,7 +686,7 @@ static Model *build_model(ModelDesc &&desc) {
         // second MFMA pass on the LDS-transposed tile inside the first conv's kernel (forward program only --
         // the gradient program needs the intermediate activation)
         const Op *post = nullptr;
-        if (!grad && o.ksize == 3 && i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Conv) {
+        if (!grad && no_h2 && o.ksize == 3 && i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Conv) {
           const Op &o2 = d.ops[i + 1];
           bool used_elsewhere = false;
           for (size_t j = i + 2; j < d.ops.size(); j++)
@@ -712,8 +717,8 @@ static Model *build_model(ModelDesc &&desc) {
         // the split-fp16 twin (not with a fused 1x1 conv).  The gradient
         // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
-        if (!post && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
-        if (!grad) m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
+        if (!post && !no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
+        if (!grad && !f32only) m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
         if (post) {
           {
             int wm_, wn_, tm_, tn_;
@@ -771,7 +776,8 @@ static Model *build_model(ModelDesc &&desc) {
     }
     return out;
   };
-  m->steps = build_steps(false);
+  m->steps = build_steps(false, false);
+  m->steps32 = getenv("MI_GNINA_NO_H2") ? m->steps : build_steps(false, true);
   // gradient program: conv / pool stacks (Default2017 / Default2018 families) and the Dense family
   // (BatchNorm-on-input convs growing a concat buffer, global max pool)
   m->grad_supported = !d.skip_softmax && !d.apply_logistic_loss;
@@ -792,7 +798,7 @@ static Model *build_model(ModelDesc &&desc) {
       }
     }
   }
-  if (m->grad_supported) m->gsteps = build_steps(true);
+  if (m->grad_supported) m->gsteps = build_steps(true, false);
   for (const Step &st : m->steps) {
     int s = st.kind == OpKind::Conv ? st.conv.src : st.src;
     MIG_CHECK(s >= 0 && m->buf_cp[s] > 0, 2, "layer program reads a buffer nothing produced");
@@ -1346,7 +1352,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
     return;
   }
   const bool bf16 = use_bf16(s, *m, grad);
-  const std::vector<Step> &steps = bf16 ? (grad ? m->hgsteps : m->hsteps) : (grad ? m->gsteps : m->steps);
+  const std::vector<Step> &steps = bf16 ? (grad ? m->hgsteps : m->hsteps) : (grad ? m->gsteps : (s.conv_path != 0 ? m->steps : m->steps32));
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
