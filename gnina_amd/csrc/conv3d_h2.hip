@@ -10,8 +10,8 @@
 // BatchNorm, which stays fp32), so HBM holds plain fp32 tensors and this kernel is interchangeable, layer by layer, with
 // the fp32 kernels of the same program.  Measured against the float64 forward of the same operands the scores move by
 // <= 1e-6 (tools/experiments/split_precision_probe.py; the parity bar is 1e-4) -- unlike the bf16 kernels
-// (conv3d_bf16.hip: 4e-2), this IS a parity path.  Forward only: the transposed convolutions of the gradient pass stay on
-// the fp32 kernels.
+// (conv3d_bf16.hip: 4e-2), this IS a parity path.  Forward only (scoring calls and the forward half of gradient calls):
+// the transposed convolutions of the backward pass stay on the fp32 kernels.
 //
 // Decomposition as in conv3d.hip: a workgroup owns a box of 2x2x2 cells of one pose and all (or a group of) output
 // channels; an M-tile is 32 voxels = four cells, so ReLU + pooling stay register-local in the 32x32 accumulator layout.

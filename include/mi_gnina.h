@@ -116,7 +116,9 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * MI_PRECISION_BF16 (BASELINE config 5, "bf16 MFMA path") runs the convolutions on v_mfma_f32_32x32x16_bf16 with bf16
  * activations / weights and fp32 accumulation; voxelization, the fully connected heads and the score post-processing
  * stay fp32.  Its deviation from the fp32 path is a measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.
- * Gradient calls always run on the fp32-MFMA kernels. */
+ * Gradient calls (MI_PRECISION_FP32 / _FP32_MFMA; never bf16): the forward pass takes the same kernels as a scoring
+ * call of the same precision -- a pose scores the same bits with and without its gradient -- and the transposed
+ * convolutions of the backward pass run on fp32 MFMA. */
 enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 };
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a

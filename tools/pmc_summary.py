@@ -46,6 +46,9 @@ def to_json(d, out):
         if e.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
             # one MOP = 512 FLOP (a 32x32x2 fp32 MFMA = 4096 FLOP = 8 MOPs)
             e["mfma_executed_flops_per_launch"] = e["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
+        if e.get("SQ_INSTS_VALU_MFMA_MOPS_F16"):
+            # split-fp16 kernels: a 32x32x16 f16 MFMA = 32,768 FLOP = 64 MOPs
+            e["mfma_executed_flops_per_launch"] = e.get("mfma_executed_flops_per_launch", 0.0) + e["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0
         res[k] = e
     # bench.py's label of the dominant kernel -> profiler kernel name (first conv of the default workload)
     kmap = {}
@@ -53,6 +56,10 @@ def to_json(d, out):
     if first:
         kmap["conv3_s24_35to32_pool"] = first[0]
         kmap["conv3_s24_28to32"] = first[0]
+    h2 = sorted((k for k in res if k.startswith("conv3d_h2_kernel<4, 1, 2, 1")), key=lambda k: "true, true" not in k)
+    if h2:  # the default path's first conv (zero-skipping, x-stacked M-tiles)
+        kmap["conv3_s24_35to32_pool_h2"] = h2[0]
+        kmap["conv3_s24_28to32_h2"] = h2[0]
     json.dump({"source": d, "command": "tools/profile_gpu.sh (bench.py --steps 3 --warmup 1 --no-cpu-baseline)",
                "roofline_kernel_map": kmap, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
