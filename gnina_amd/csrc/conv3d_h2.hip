@@ -23,6 +23,10 @@
 
 #include <type_traits>
 
+#ifndef MI_H2_EXPERIMENT
+#define MI_H2_EXPERIMENT 0  // tools/h2_experiments.sh: 1 = no K loop, 2 = no staging loads, 3 = neither (timing only, wrong results)
+#endif
+
 namespace mig {
 
 typedef float h2_f32x16 __attribute__((ext_vector_type(16)));
@@ -163,7 +167,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
       const int off = hv < HV ? s_vox[hv] : -1;
 #pragma unroll
       for (int q = 0; q < NQ; q++)
-        if (off >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + off + q * 4);
+        if (off >= 0 && q < nq) {
+#if MI_H2_EXPERIMENT & 2
+          pre[v][q] = make_float4(1.f, 0.f, 0.25f, 0.f);
+#else
+          pre[v][q] = *reinterpret_cast<const float4 *>(src_c + off + q * 4);
+#endif
+        }
     }
   };
   auto commit = [&](int chunk) {
@@ -257,14 +267,23 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
         }
       }
     };
+#if MI_H2_EXPERIMENT & 1
+    if (p.nchunks > 1000)
+#endif
     load_pair(0, ah0, al0, wh0, wl0);
     int pr = 0;
+#if MI_H2_EXPERIMENT & 1
+    if (p.nchunks > 1000)
+#endif
     for (; pr + 1 < P; pr += 2) {
       load_pair(pr + 1, ah1, al1, wh1, wl1);
       mfma_pair(ah0, al0, wh0, wl0);
       if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
       mfma_pair(ah1, al1, wh1, wl1);
     }
+#if MI_H2_EXPERIMENT & 1
+    if (p.nchunks > 1000)
+#endif
     if (P & 1) mfma_pair(ah0, al0, wh0, wl0);
   }
 
