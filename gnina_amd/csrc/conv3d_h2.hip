@@ -59,7 +59,8 @@ __device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &l) {
   l.y = pk_f16(r2, r3);
 }
 
-template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP>
+// K1: the staging shape of the 1x1x1 convolutions (no halo: at most one voxel per thread, up to six octets of it per chunk)
+template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP, bool K1 = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 : 1)) void conv3d_h2_kernel(ConvArgs p) {
   constexpr int NTHREADS = 64 * WM * WN;
   const int tid = threadIdx.x;
@@ -153,9 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   // workgroup per CU, nothing to overlap with, ran the first conv at 4.3 ms against 2.25 ms with three per CU.)
   // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them (the plans keep HV <= VPT * NTHREADS), NQ quads each.
   // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them, NQ channel quads each (the plans keep
-  // HV <= VPT * NTHREADS and 2 CC8 <= NQ).  The tile shapes with three or five N-tiles per wave exist for the 1x1x1
-  // bottlenecks only (no halo: 128 voxels, one per thread, up to six octets of it).
-  constexpr bool K1 = TN >= 3;
+  // HV <= VPT * NTHREADS and 2 CC8 <= NQ): 3 x 4 under a 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv.
   constexpr int VPT = K1 ? 1 : 3, NQ = K1 ? 12 : 4;
   float4 pre[VPT][NQ];
   auto issue = [&](int chunk) {
@@ -557,15 +556,23 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
   return ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
 }
 
-template <int WM, int WN, int TM, int TN, bool MTX> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool MTX, bool K1ONLY = false> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
-  if (p.sparse) {
-    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_kernel<WM, WN, TM, TN, MTX, true>), 160 * 1024);
-    hipLaunchKernelGGL((conv3d_h2_kernel<WM, WN, TM, TN, MTX, true>), grid, block, conv_h2_lds_bytes(p), s, p);
+  const size_t lds = conv_h2_lds_bytes(p);
+  auto go = [&](auto kern) {
+    ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+  };
+  if (p.ksize == 1) {  // (no zero test on the 1x1x1 layers: one step per octet pair, nothing to skip ahead of)
+    if constexpr (!MTX) go(conv3d_h2_kernel<WM, WN, TM, TN, false, false, true>);
+    else throw Error(2, "launch_conv_h2: x-stacked M-tiles are a 3x3x3 layout");
+  } else if constexpr (K1ONLY) {
+    throw Error(2, "launch_conv_h2: tile configuration compiled for 1x1x1 convolutions only");
+  } else if (p.sparse) {
+    go(conv3d_h2_kernel<WM, WN, TM, TN, MTX, true, false>);
   } else {
-    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_kernel<WM, WN, TM, TN, MTX, false>), 160 * 1024);
-    hipLaunchKernelGGL((conv3d_h2_kernel<WM, WN, TM, TN, MTX, false>), grid, block, conv_h2_lds_bytes(p), s, p);
+    go(conv3d_h2_kernel<WM, WN, TM, TN, MTX, false, false>);
   }
 }
 
@@ -599,8 +606,8 @@ void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
       break;
     case CONV_CFG_2x2_3x1: launch_h2<2, 2, 3, 1, false>(p, B, s); break;
     case CONV_CFG_1x4_7x1: launch_h2<1, 4, 7, 1, false>(p, B, s); break;
-    case CONV_CFG_4x1_1x3: launch_h2<4, 1, 1, 3, false>(p, B, s); break;
-    case CONV_CFG_4x1_1x5: launch_h2<4, 1, 1, 5, false>(p, B, s); break;
+    case CONV_CFG_4x1_1x3: launch_h2<4, 1, 1, 3, false, true>(p, B, s); break;
+    case CONV_CFG_4x1_1x5: launch_h2<4, 1, 1, 5, false, true>(p, B, s); break;
     case CONV_CFG_4x1_1x1: launch_h2<4, 1, 1, 1, false>(p, B, s); break;
     case CONV_CFG_N16_TM1: launch_h2_16<1>(p, B, s); break;
     case CONV_CFG_N16_TM2: launch_h2_16<2>(p, B, s); break;

@@ -390,18 +390,17 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   size_t budget = 52 * 1024;
   if (const char *ev = getenv("MI_GNINA_H2_LDS_KB"))
     if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
-  // the kernel's staging registers (conv3d_h2.hip: VPT halo voxels per thread x NQ channel quads per chunk -- 3 x 4, or
-  // 1 x 12 on the tile shapes of the 1x1x1 bottlenecks)
+  // the kernel's staging registers (conv3d_h2.hip: VPT halo voxels per thread x NQ channel quads per chunk -- 3 x 4 under a
+  // 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv)
   int vpt = 3, max_c = 2;
+  if (a.coutp != 16 && o.ksize == 1) vpt = 1, max_c = 6;
   {
     int wm, wn, tm, tn;
     conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
-    if (a.coutp != 16 && tn >= 3) vpt = 1, max_c = 6;
-    if (HV > (size_t)vpt * 64 * wm * wn) return;
+    if (HV > (size_t)vpt * 64 * wm * wn) return;  // (HV covers the latency tile too)
+    if (a.coutp != 16 && o.ksize != 1 && tn >= 3) return;  // tile shapes compiled for the 1x1x1 bottlenecks only
+    if (a.coutp != 16 && o.ksize == 1 && a.mt_x) return;
   }
-  a.h2_pad_y = a.h2_pad_x = 0;
-  if (a.coutp == 16 && o.ksize == 3)  // MI_GNINA_H2_PADS=y,x: LDS pad slots of the 16-wide kernel (tuning)
-    if (const char *ev = getenv("MI_GNINA_H2_PADS")) sscanf(ev, "%d,%d", &a.h2_pad_y, &a.h2_pad_x);
   int best = 1;
   for (int c = 1; c <= cin8 && c <= max_c; c++)
     if (HV * (16 * c + 8) * 2 + (size_t)(taps * c + 8) * 4 + HV * 4 <= budget) best = c;
@@ -1413,7 +1412,6 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             int cfg;
             ConvArgs geo = a;
             pick_tile(st.conv, nb, geo, cfg);
-            if (cfg != st.conv.cfg && h.cc4 > 2) cfg = st.conv.cfg, geo = a;  // (1x1x1 bottlenecks: their K chunks need the throughput kernel's staging registers)
             h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
             h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
