@@ -73,6 +73,7 @@ struct ConvArgs {
   // stays the input's channel QUADS, wp is the packed [chunk][pair][2][coutp][h0..h7 | l0..l7] fp16 array of the weights
   // times 1 / h2_unscale (a power of two); sparse != 0 = skip the MFMAs of an all-zero A operand
   float h2_unscale;
+  float h2_post_unscale;  // fused 1x1x1 conv on the split-fp16 kernel: post_w = its packed [pair][2][coutp][h | l] weights, post_cc4 its OCTETS
   int h2_pad_y, h2_pad_x;  // 16-wide split-fp16 kernel: 16-byte pad slots behind every z-row / x-plane of the LDS halo tile
 };
 

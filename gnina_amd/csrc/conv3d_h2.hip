@@ -21,6 +21,7 @@
 #include "common.h"
 #include "conv3d.h"
 
+#include <algorithm>
 #include <type_traits>
 
 #ifndef MI_H2_EXPERIMENT
@@ -286,13 +287,68 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
     if (P & 1) mfma_pair(ah0, al0, wh0, wl0);
   }
 
+  // ---- fused 1x1x1 conv behind this one (Default2018: conv3 -> ReLU -> conv1 -> ReLU -> pool; ConvArgs::post_w): the ReLU'd
+  // tile is split and laid down in LDS as [voxel row][octet][h | l] -- what the stand-alone 1x1x1 kernel's staging would
+  // build from the tensor in HBM, which therefore never exists -- and a second, short K loop runs over its channels.  Same
+  // operands, same MFMA order as the two separate kernels: same bits (the gradient program runs them separately).
+  float unscale = p.h2_unscale;
+  const float *bias_ptr = p.bias;
+  int relu_flag = p.relu;
+  if constexpr (!K1 && TN == 1 && TM <= 3) {
+    if (p.post_w) {
+      __syncthreads();  // every wave is through its last K loop: the halo tile may be overwritten
+      const int CCm = 2 * p.coutp + 8;  // fp16 elements per voxel row of the mid tile (odd number of 16-byte slots)
+      _Float16 *s_mid = smem_h2;
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const int ch = n_base + row;
+        const float b1 = p.bias[ch];
+        _Float16 *dcol = s_mid + (ch >> 3) * 16 + (ch & 7);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rowl = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          float t = acc[m][0][r] * unscale + b1;
+          if (p.relu) t = fmaxf(t, 0.f);
+          const float c = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+          const _Float16 hi = (_Float16)c;
+          dcol[rowl * CCm] = hi;
+          dcol[rowl * CCm + 8] = (_Float16)(c - (float)hi);
+          acc[m][0][r] = 0.f;
+        }
+      }
+      __syncthreads();
+      const int npairs = p.post_cc4 >> 1;  // octet pairs = steps of the second K loop
+      const char *w2 = reinterpret_cast<const char *>(p.post_w) + ((size_t)kh * p.coutp + n_base + row) * 32;
+      for (int pr = 0; pr < npairs; pr++) {
+        uint4 ah[TM], al[TM], wh[1], wl[1];
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          const char *a = reinterpret_cast<const char *>(s_mid) + (((wm * TM + m) * 32 + row) * CCm + (2 * pr + kh) * 16) * 2;
+          ah[m] = *reinterpret_cast<const uint4 *>(a);
+          al[m] = *reinterpret_cast<const uint4 *>(a + 16);
+        }
+        const char *w = w2 + (size_t)pr * 2 * p.coutp * 32;
+        wh[0] = *reinterpret_cast<const uint4 *>(w);
+        wl[0] = *reinterpret_cast<const uint4 *>(w + 16);
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh[0]), acc[m][0], 0, 0, 0);
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl[0]), acc[m][0], 0, 0, 0);
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh[0]), acc[m][0], 0, 0, 0);
+        }
+      }
+      unscale = p.h2_post_unscale;
+      bias_ptr = p.post_bias;
+      relu_flag = p.post_relu;
+    }
+  }
+
   // profile mode: executed MFMA work in units of 4,096 FLOPs (the fp32 kernels count 32x32x2 instructions): an executed
   // (M-tile, step) is 3 TN instructions of 32,768 FLOPs
   if (SKIP && p.mfma_count && lane == 0)
     atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec * (3u * TN * 8u));
 
   // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last fp32 ----
-  const float unscale = p.h2_unscale;
   const int So = p.pool ? S / 2 : S;
   const size_t out_pose = (size_t)b * So * So * So * p.out_cs + p.out_c0;
   float *out_f = p.out + out_pose;
@@ -309,12 +365,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
       for (int n = 0; n < TN; n++) {
         const int ch = n_base + n * 32 + row;
         if (ch >= p.cout) continue;
-        const float bias = p.bias[ch];
+        const float bias = bias_ptr[ch];
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           const float tt = acc[m][n][half * 8 + r] * unscale + bias;
-          v[r] = p.relu ? fmaxf(tt, 0.f) : tt;
+          v[r] = relu_flag ? fmaxf(tt, 0.f) : tt;
         }
         if (p.pool == 1) {
           float mx = v[0];
@@ -553,7 +609,9 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // (pads: 16-wide kernel only)
-  return ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+  const size_t main_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+  const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (2 * p.coutp + 8) * sizeof(_Float16) : 0;  // fused 1x1x1 conv
+  return std::max(main_bytes, mid_bytes);
 }
 
 template <int WM, int WN, int TM, int TN, bool MTX, bool K1ONLY = false> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {

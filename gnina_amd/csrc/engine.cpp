@@ -685,7 +685,10 @@ static Model *build_model(ModelDesc &&desc) {
         // second MFMA pass on the LDS-transposed tile inside the first conv's kernel (forward program only --
         // the gradient program needs the intermediate activation)
         const Op *post = nullptr;
-        if (!grad && no_h2 && o.ksize == 3 && i + 1 < d.ops.size() && d.ops[i + 1].kind == OpKind::Conv) {
+        // (the default forward program fuses too -- conv3d_h2.hip carries the pair on the f16 pipe -- unless
+        // MI_GNINA_H2_NO_FUSE1X1 asks for two launches)
+        if (!grad && (no_h2 || !getenv("MI_GNINA_H2_NO_FUSE1X1")) && o.ksize == 3 && i + 1 < d.ops.size() &&
+            d.ops[i + 1].kind == OpKind::Conv) {
           const Op &o2 = d.ops[i + 1];
           bool used_elsewhere = false;
           for (size_t j = i + 2; j < d.ops.size(); j++)
@@ -716,8 +719,33 @@ static Model *build_model(ModelDesc &&desc) {
         // the split-fp16 twin (not with a fused 1x1 conv).  The gradient
         // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
-        if (!post && !no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
-        if (!grad && !f32only) m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
+        if (!no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
+        if (post && st.conv.has_h2) {
+          // the 1x1x1 conv's own split-fp16 plan supplies the packed weights of the fused second pass: its K chunks must
+          // be consecutive whole octet pairs ([chunk][pairs][2][coutp][h | l] is then one [pair][2][coutp][h | l] array)
+          int wm_, wn_, tm_, tn_;
+          conv_cfg_shape(st.conv.cfg, &wm_, &wn_, &tm_, &tn_);
+          ConvPlan p2;
+          plan_conv(*m, *post, p2, 0, post->dst, 0);
+          plan_conv_h2(*m, *post, p2);
+          const bool ok = p2.has_h2 && tm_ <= 3 && tn_ == 1 && st.conv.a.coutp / 32 <= wn_ && p2.h2.cc4 % 2 == 0 &&
+                          p2.h2.cc4 * p2.h2.nchunks * 8 == st.conv.a.coutp;
+          if (ok) {
+            st.conv.h2.post_w = p2.h2.wp;
+            st.conv.h2.post_cc4 = p2.h2.cc4 * p2.h2.nchunks;  // octets
+            st.conv.h2.post_bias = p2.h2.bias;
+            st.conv.h2.post_relu = post->relu;
+            st.conv.h2.h2_post_unscale = p2.h2.h2_unscale;
+            st.conv.h2.post_rows = wm_ * tm_ * 32;
+            if (conv_h2_lds_bytes(st.conv.h2) > 160 * 1024) st.conv.has_h2 = false;
+          } else {
+            st.conv.has_h2 = false;  // (this pair stays on the fused fp32 kernel)
+          }
+        }
+        if (!grad && !f32only) {
+          m->op_h2[conv_op_index] = st.conv.has_h2 ? 1 : 0;
+          if (post) m->op_h2[conv_op_index + 1] = st.conv.has_h2 ? 1 : 0;
+        }
         if (post) {
           {
             int wm_, wn_, tm_, tn_;
@@ -1413,6 +1441,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             ConvArgs geo = a;
             pick_tile(st.conv, nb, geo, cfg);
             h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
+            if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
             h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
           } else {
