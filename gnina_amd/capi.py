@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -215,6 +215,8 @@ def lib():
         L.mi_debug_explog.restype = C.c_int
         L.mi_debug_acos.argtypes = [f32p, C.c_int, f32p]
         L.mi_debug_acos.restype = C.c_int
+        L.mi_debug_split_f16.argtypes = [f32p, C.c_int, C.c_float, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), f32p]
+        L.mi_debug_split_f16.restype = C.c_int
         L.mi_scorer_flex_count.argtypes = [vp]
         L.mi_scorer_flex_count.restype = C.c_int
         L.mi_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_char_p), C.c_int]
@@ -1028,6 +1030,18 @@ def device_libm(x):
     check(lib().mi_debug_sincos(p[0], len(x), p[1], p[2]))
     check(lib().mi_debug_explog(p[0], len(x), p[3], p[4]))
     return tuple(o)
+
+
+def split_f16(x, scale=0.0):
+    """(hi, lo, scale): the fp16 operand split of the split-fp16 conv kernels as the model loader applies it to weights
+    (host code, no device needed); hi / lo are float16 arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    hi, lo = np.empty(len(x), dtype=np.uint16), np.empty(len(x), dtype=np.uint16)
+    used = C.c_float()
+    u16p, f32p = C.POINTER(C.c_uint16), C.POINTER(C.c_float)
+    check(lib().mi_debug_split_f16(x.ctypes.data_as(f32p), len(x), float(scale), hi.ctypes.data_as(u16p),
+                                   lo.ctypes.data_as(u16p), C.byref(used)))
+    return hi.view(np.float16), lo.view(np.float16), used.value
 
 
 def device_acosf(x):

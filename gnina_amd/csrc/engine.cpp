@@ -375,6 +375,13 @@ static float host_h2f(unsigned short h) {
   return sign ? -v : v;
 }
 
+// per-layer power of two that lifts max |w| into [2^13, 2^14): the weights' low halves stay normal fp16 numbers
+static float h2_weight_scale(const float *w, size_t n) {
+  float wmax = 0.f;
+  for (size_t i = 0; i < n; i++) wmax = std::max(wmax, fabsf(w[i]));
+  return wmax > 0.f ? ldexpf(1.f, 14 - (int)floorf(log2f(wmax)) - 1) : 1.f;
+}
+
 static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
   if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
@@ -415,10 +422,7 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   const int kstep = n16 ? 4 : 2;
   const int Pmax = (taps * best + kstep - 1) / kstep;
   const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
-  float wmax = 0.f;
-  for (size_t i = 0; i < (size_t)taps * o.cin * o.cout; i++) wmax = std::max(wmax, fabsf(w[i]));
-  // per-layer power of two that lifts the weights to ~2^14: their low halves stay normal fp16 numbers
-  const float sw = wmax > 0.f ? ldexpf(1.f, 14 - (int)floorf(log2f(wmax)) - 1) : 1.f;
+  const float sw = h2_weight_scale(w, (size_t)taps * o.cin * o.cout);
   std::vector<unsigned short> wp((size_t)nchunks * Pmax * kstep * a.coutp * 16, 0);
   for (int ch = 0; ch < nchunks; ch++)
     for (int c8 = 0; c8 < best && ch * best + c8 < cin8; c8++)
@@ -1965,6 +1969,20 @@ mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_
   MIG_CHECK(sc, 1, "NULL scorer");
   score_batch_grad(*reinterpret_cast<Scorer *>(sc), lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var,
                    lig_grad, MI_MEM_HOST);
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, uint16_t *lo, float *scale_out) {
+  MI_TRY
+  MIG_CHECK(n >= 0 && (n == 0 || (x && hi && lo)), 1, "bad arguments");
+  const float sw = scale != 0.f ? scale : h2_weight_scale(x, (size_t)n);
+  if (scale_out) *scale_out = sw;
+  for (int i = 0; i < n; i++) {
+    const float v = x[i] * sw;
+    hi[i] = host_f2h(v);
+    lo[i] = host_f2h(v - host_h2f(hi[i]));
+  }
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -121,6 +121,11 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * convolutions of the backward pass run on fp32 MFMA. */
 enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 };
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
+/* Diagnostic, host only (no device needed): the operand split of the split-fp16 kernels as the model loader applies it
+ * to the weights -- hi[i] = RN_fp16(x[i] * scale), lo[i] = RN_fp16(x[i] * scale - hi[i]) as IEEE binary16 bit patterns
+ * (round to nearest even, subnormals kept).  scale = 0 picks the per-layer power of two the loader would: the one that
+ * lifts max |x| into [2^13, 2^14); the scale used is returned in *scale_out (may be NULL). */
+mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, uint16_t *lo, float *scale_out);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
  * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as

@@ -159,3 +159,30 @@ def test_gninatypes_round_trip_and_errors(capi, tmp_path):
         capi.read_gninatypes(str(b))
     with pytest.raises(capi.MiGninaError, match="could not open"):
         capi.read_gninatypes(str(tmp_path / "nope.gninatypes"))
+
+
+def test_fp16_operand_split_of_the_conv_weights(capi):
+    """The split-fp16 kernels (conv3d_h2.hip) write every fp32 operand as hi + lo, two fp16 numbers.  The loader's host
+    code does it for the weights: round to nearest even like numpy's float16 (subnormals, ties, overflow included), a
+    per-layer power-of-two scale, and hi + lo within 2^-21 of the scaled weight (22-23 significant bits)."""
+    rng = np.random.RandomState(3)
+    w = np.concatenate([rng.normal(0, 0.05, 5000), rng.uniform(-1, 1, 2000) * 10.0 ** rng.uniform(-9, 0, 2000),
+                        [0.0, -0.0, 1.0, -1.0, 0.1, 6.1e-5, 5.96e-8, 2.98e-8, 3.0e-8, 65504.0, 65519.9, 1e-30]]).astype(np.float32)
+    # explicit scale 1: plain conversions, compared bit for bit with numpy (values beyond fp16's range saturate to inf there too)
+    hi, lo, used = capi.split_f16(w, scale=1.0)
+    assert used == 1.0
+    with np.errstate(over="ignore"):
+        ref_hi = w.astype(np.float16)
+        ref_lo = (w - ref_hi.astype(np.float32)).astype(np.float16)
+    fin = np.isfinite(ref_hi)
+    assert np.array_equal(hi.view(np.uint16), ref_hi.view(np.uint16))
+    assert np.array_equal(lo.view(np.uint16)[fin], ref_lo.view(np.uint16)[fin])
+    # the loader's own scale: a power of two, max |w| * scale in [2^13, 2^14), reconstruction to 2^-21 relative
+    layer = rng.normal(0, 0.03, 4096).astype(np.float32)
+    hi, lo, sw = capi.split_f16(layer)
+    assert sw == 2.0 ** round(np.log2(sw)) and 2.0 ** 13 <= np.abs(layer).max() * sw < 2.0 ** 14
+    back = (hi.astype(np.float64) + lo.astype(np.float64)) / sw
+    big = np.abs(layer) > 1e-4
+    assert (np.abs(back - layer)[big] <= 2.0 ** -21 * np.abs(layer)[big]).all()
+    assert np.abs(back - layer).max() <= 2.0 ** -21 * np.abs(layer).max()
+    assert capi.lib().mi_debug_split_f16(None, 4, 1.0, None, None, None) != capi.MI_OK
