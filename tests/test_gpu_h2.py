@@ -81,3 +81,24 @@ def test_split_fp16_on_nearly_empty_and_crowded_grids(capi, CG):
         ref, new = _both(capi, [name], rec_xyz, rec_smt, batch, lig_smt)
         assert np.abs(new["pose"] - ref["pose"]).max() <= TOL
         assert np.abs(new["affinity"] - ref["affinity"]).max() <= TOL * max(1.0, float(np.abs(ref["affinity"]).max()))
+
+
+def test_fused_1x1_conv_gives_the_bits_of_two_launches(capi, CG, monkeypatch):
+    """Default2018's "3x3x3 conv -> ReLU -> 1x1x1 conv" pairs run as one split-fp16 kernel (the ReLU'd tile is split and
+    laid down in LDS, never in HBM); as two launches (MI_GNINA_H2_NO_FUSE1X1, read when a model is loaded) the operands and
+    the MFMA order are the same, so the scores must be too -- which is what lets the gradient program, which needs the
+    intermediate activation, run the pair separately and still score a pose like the forward program."""
+    from gnina_amd import synth
+    name = "crossdock_default2018"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = np.concatenate([poses, synth.make_poses(np.random.RandomState(11), poses[0] - poses[0].mean(0), 60)])
+    out = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("MI_GNINA_H2_NO_FUSE1X1", "1")
+        s = capi.Scorer([capi.Model(name)])
+        s.set_receptor(rec_xyz, rec_smt)
+        out.append(s.score_batch(many, lig_smt))
+        monkeypatch.delenv("MI_GNINA_H2_NO_FUSE1X1", raising=False)
+    assert np.array_equal(out[0]["pose"], out[1]["pose"]) and np.array_equal(out[0]["affinity"], out[1]["affinity"])
+    assert np.abs(out[0]["pose"][:4] - CG[name + "/pose"]).max() < 1e-4
