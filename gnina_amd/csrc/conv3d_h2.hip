@@ -91,6 +91,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   _Float16 *s_tile = smem_h2;                                                              // [HV][CCs]
   int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HV * CCs + 7) & ~(size_t)7));  // [Qmax + 4] byte offsets
   int *s_vox = s_qoff + ((Qmax + 4 + 3) & ~3);  // [HV] float offset of every halo voxel's channel row, -1 = padding
+  // SKIP: [2] "the halo tile of the chunk staged last has a non-zero somewhere" (one flag per chunk parity).  The ligand's
+  // channels are zero in every workgroup tile away from the ligand: such a chunk's whole K loop is skipped, by all waves
+  // alike, instead of finding its steps dead one LDS round trip at a time.
+  int *s_live = s_vox + HV;
+  if (SKIP && tid < 2) s_live[tid] = 0;
 
   // octet q of a chunk (channel-major: all taps of octet 0, then octet 1, ...) -> byte offset inside the halo tile.  The
   // four entries behind the last octet repeat it: an odd octet count leaves the second half-wave of the last step on real
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   auto commit = [&](int chunk) {
     const int c_base = chunk * CC8 * 8;
     const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
+    bool wave_nonzero = false;
 #pragma unroll
     for (int v = 0; v < VPT; v++) {
       const int hv = tid + v * NTHREADS;
@@ -205,12 +211,18 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           // the pooled voxel grid and ReLU'd activations are mostly zeros: a quad that is zero in all 64 voxels of the wave
           // (3 VALU + a scalar branch to find out) needs no arithmetic
           const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
-          if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) split4(x, h, l);
+          if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
+            split4(x, h, l);
+            wave_nonzero = true;
+          }
         }
         *reinterpret_cast<uint2 *>(d) = h;
         *reinterpret_cast<uint2 *>(d + 8) = l;
       }
     }
+    // (wave_nonzero is a per-lane variable: it was set in the lanes that were staging a voxel at that moment -- not
+    // necessarily in lane 0, whose halo voxel may be padding)
+    if (SKIP && __builtin_amdgcn_ballot_w64(wave_nonzero) != 0ull && lane == 0) s_live[chunk & 1] = 1;
   };
   __syncthreads();  // s_vox
   issue(0);
@@ -219,6 +231,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
     commit(chunk);
     if (chunk + 1 < p.nchunks) issue(chunk + 1);
     __syncthreads();
+    if (SKIP) {
+      const int live = s_live[chunk & 1];
+      if (tid == 0) s_live[(chunk + 1) & 1] = 0;  // (last read in the previous chunk's K loop, next written behind the next barrier)
+      if (__builtin_amdgcn_readfirstlane(live) == 0) continue;
+    }
     const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
 
     // ---- K loop over octet pairs, ping-pong operand sets (see conv3d_bf16.hip) ----
@@ -609,7 +626,7 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // (pads: 16-wide kernel only)
-  const size_t main_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + HV * sizeof(int);
+  const size_t main_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + (HV + 4) * sizeof(int);
   const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (2 * p.coutp + 8) * sizeof(_Float16) : 0;  // fused 1x1x1 conv
   return std::max(main_bytes, mid_bytes);
 }
