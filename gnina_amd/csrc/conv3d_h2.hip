@@ -158,7 +158,6 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   // K loop of chunk k and split / written to LDS after it.  (A load -> split -> ds_write chain per halo voxel exposes one
   // L2 latency per voxel and chunk; at the f16 MFMA rate that was longer than the K loop itself: 116 KB of LDS = one
   // workgroup per CU, nothing to overlap with, ran the first conv at 4.3 ms against 2.25 ms with three per CU.)
-  // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them (the plans keep HV <= VPT * NTHREADS), NQ quads each.
   // A thread owns halo voxels tid, tid + NTHREADS, ...: VPT of them, NQ channel quads each (the plans keep
   // HV <= VPT * NTHREADS and 2 CC8 <= NQ): 3 x 4 under a 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv.
   constexpr int VPT = K1 ? 1 : 3, NQ = K1 ? 12 : 4;
