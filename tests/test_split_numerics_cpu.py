@@ -1,0 +1,73 @@
+"""The arithmetic claim behind the split-fp16 convolution kernels (gnina_amd/csrc/conv3d_h2.hip), checked on CPU.
+
+Every fp32 operand is written as a = h + l with h = RN_fp16(a), l = RN_fp16(a - h); a product keeps h_a*h_w + h_a*l_w +
+l_a*h_w.  Products of fp16 numbers are exact in fp32 and the sum is accumulated in fp32 on the device; here it is
+accumulated in float64, so what is measured is the split's own error:
+  * the three kept terms reproduce a 3x3x3 convolution to ~2^-22 of sum |a||w| (the dropped l*l term and the two
+    roundings of the halves), i.e. fp32-accumulation grade -- while two bf16 halves, also three MFMAs, are 60x worse;
+  * the weights need their per-layer power-of-two scale: without it the low halves of small weights are fp16 subnormals;
+  * the loader's split (mi_debug_split_f16, host code of libmi_gnina.so) gives the same halves as this emulation.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _split(x, dt, scale=1.0):
+    h = (x * scale).to(torch.float32).to(dt)
+    l = ((x * scale).to(torch.float32) - h.to(torch.float32)).to(dt)
+    return h.to(torch.float64), l.to(torch.float64)
+
+
+def _conv_split(a, w, dt, sw=1.0):
+    ah, al = _split(a, dt)
+    wh, wl = _split(w, dt, sw)
+    y = F.conv3d(ah, wh, padding=1) + F.conv3d(ah, wl, padding=1) + F.conv3d(al, wh, padding=1)
+    return y / sw
+
+
+@pytest.fixture(scope="module")
+def layer():
+    g = torch.Generator().manual_seed(7)
+    a = torch.relu(torch.randn(2, 24, 10, 10, 10, generator=g)) * torch.rand(2, 24, 10, 10, 10, generator=g) * 3.0
+    w = torch.randn(16, 24, 3, 3, 3, generator=g) * 0.03
+    a, w = a.to(torch.float32).to(torch.float64), w.to(torch.float32).to(torch.float64)
+    exact = F.conv3d(a, w, padding=1)
+    mag = F.conv3d(a.abs(), w.abs(), padding=1)   # sum |a||w| per output: the scale rounding errors live on
+    return a, w, exact, mag
+
+
+def test_two_fp16_halves_and_three_products_are_fp32_grade(layer):
+    a, w, exact, mag = layer
+    sw = 2.0 ** (13 - np.floor(np.log2(float(w.abs().max()))))   # the loader's scale: max |w| * sw in [2^13, 2^14)
+    err = ((_conv_split(a, w, torch.float16, sw) - exact).abs() / mag).max().item()
+    assert err <= 2.0 ** -21, err
+    # the same three MFMAs on bf16 halves keep 16 bits, not 22
+    err_bf = ((_conv_split(a, w, torch.bfloat16) - exact).abs() / mag).max().item()
+    assert err_bf > 30 * err
+    # and fp32's own rounding of each product-sum is of the order the split costs: the split is not a precision class
+    y32 = F.conv3d(a.float(), w.float(), padding=1).double()
+    err32 = ((y32 - exact).abs() / mag).max().item()
+    assert err <= 8 * err32 + 2.0 ** -22
+
+
+def test_weights_need_their_power_of_two_scale(layer):
+    a, w, exact, mag = layer
+    tiny = w * 2.0 ** -6          # weights around 5e-4: their low halves are fp16 subnormals without the scale
+    ex = F.conv3d(a, tiny, padding=1)
+    mg = F.conv3d(a.abs(), tiny.abs(), padding=1)
+    sw = 2.0 ** (13 - np.floor(np.log2(float(tiny.abs().max()))))
+    scaled = ((_conv_split(a, tiny, torch.float16, sw) - ex).abs() / mg).max().item()
+    unscaled = ((_conv_split(a, tiny, torch.float16, 1.0) - ex).abs() / mg).max().item()
+    assert scaled <= 2.0 ** -21 and unscaled > 8 * scaled
+
+
+def test_the_loaders_split_is_this_split(layer):
+    from gnina_amd import capi
+    _, w, _, _ = layer
+    w32 = w.float().numpy().ravel()
+    hi, lo, sw = capi.split_f16(w32)
+    h, l = _split(torch.from_numpy(w32).double(), torch.float16, sw)
+    assert sw == 2.0 ** (13 - np.floor(np.log2(np.abs(w32).max())))
+    assert np.array_equal(hi.astype(np.float64), h.numpy()) and np.array_equal(lo.astype(np.float64), l.numpy())
