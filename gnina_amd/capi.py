@@ -21,7 +21,7 @@ SYMBOLS = [
     "mi_model_name", "mi_model_type_channel",
     "mi_scorer_create", "mi_scorer_destroy", "mi_scorer_num_models", "mi_scorer_set_receptor",
     "mi_scorer_score_batch", "mi_scorer_score_batch_ex", "mi_scorer_last_model_outputs",
-    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_sdf_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_vina_mc_cnnall_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize",
+    "mi_voxelize_batch", "mi_model_forward_grids", "mi_scorer_score_grad", "mi_scorer_score_ragged", "mi_read_gninatypes", "mi_pdbqt_read_receptor", "mi_pdbqt_read_receptor_flex", "mi_pdbqt_model_open", "mi_pdbqt_model_close", "mi_pdbqt_model_sizes", "mi_pdbqt_model_desc", "mi_pdbqt_ligand_open", "mi_pdbqt_ligand_close", "mi_pdbqt_ligand_sizes", "mi_pdbqt_ligand_num_tors", "mi_pdbqt_ligand_desc", "mi_pdbqt_write_pose", "mi_sdf_write_pose", "mi_pdbqt_last_error", "mi_write_gninatypes", "mi_io_last_error", "mi_scorer_set_precision", "mi_model_supports_gradient", "mi_vina_coords_batch", "mi_vina_cache_eval_coords", "mi_cnn_eval_batch", "mi_vina_mc_cnn_batch", "mi_vina_mc_cnnall_batch", "mi_cnn_refine_batch", "mi_scorer_set_flex", "mi_scorer_set_rotations", "mi_scorer_score_flex", "mi_scorer_stream", "mi_scorer_synchronize", "mi_scorer_h2_fallbacks",
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
@@ -173,6 +173,8 @@ def lib():
         L.mi_scorer_stream.restype = vp
         L.mi_scorer_synchronize.argtypes = [vp]
         L.mi_scorer_synchronize.restype = C.c_int
+        L.mi_scorer_h2_fallbacks.argtypes = [vp]
+        L.mi_scorer_h2_fallbacks.restype = C.c_int
         L.mi_scorer_set_chunk.argtypes = [vp, C.c_int]
         L.mi_scorer_set_chunk.restype = C.c_int
         L.mi_scorer_enable_timing.argtypes = [vp, C.c_int]
@@ -633,6 +635,10 @@ class Scorer:
 
     def synchronize(self):
         check(lib().mi_scorer_synchronize(self.handle))
+
+    def h2_fallbacks(self):
+        """calls repeated on the fp32-MFMA kernels because an activation left the split-fp16 kernels' range"""
+        return int(lib().mi_scorer_h2_fallbacks(self.handle))
 
     def __del__(self):
         if getattr(self, "handle", None) and _lib is not None:

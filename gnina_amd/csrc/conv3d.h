@@ -65,7 +65,7 @@ struct ConvArgs {
   // instructions they EXECUTED to (slot = workgroup % kMfmaCountSlots); nullptr otherwise
   unsigned long long *mfma_count;
   // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
-  // 1 = they are stacked along x (tcx % 4 == 0).  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
+  // 1 = they are stacked along x (tcx % 4 == 0); 2 (conv3d_h2_kernel only) = a 2 x 2 square in (x, y), tcx == tcy == 2.  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
   // the raster order costs 3 LDS cycles per group) -- see DESIGN.md section 3.1.
   int mt_x;
@@ -74,7 +74,17 @@ struct ConvArgs {
   // times 1 / h2_unscale (a power of two); sparse != 0 = skip the MFMAs of an all-zero A operand
   float h2_unscale;
   float h2_post_unscale;  // fused 1x1x1 conv on the split-fp16 kernel: post_w = its packed [pair][2][coutp][h | l] weights, post_cc4 its OCTETS
-  int h2_pad_y, h2_pad_x;  // 16-wide split-fp16 kernel: 16-byte pad slots behind every z-row / x-plane of the LDS halo tile
+  int h2_pad_y, h2_pad_x;  // split-fp16 kernels: 16-byte pad slots behind every z-row / x-plane of the LDS halo tile
+  // 32-wide 3x3x3 split-fp16 kernel (conv3d_h2_kernel): activation tensors may live in HBM already split by their producer
+  // ("split format": [pose][octet of 8 channels][x][y][z][h0..h7 | l0..l7] fp16, h = RN_f16(a), l = RN_f16(a - h) -- the bytes
+  // of an fp32 tensor of cs = 8 * octets channels, octet-major so that the halo tile of a K chunk, one octet, is a box of a
+  // dense array).  in_split: `in` is such a tensor (in_cs = 8 * octets) and the halo tile is staged by LDS-DMA, no
+  // registers, no arithmetic; out_split: the epilogue writes one.
+  int in_split, out_split;
+  // sticky flag (one word per scorer): an activation left the fp16 range (|a| > 65504, or NaN) where a split-fp16 kernel
+  // produced or consumed it -- the call's scores are then recomputed on the fp32-MFMA kernels (engine.cpp)
+  unsigned *h2_overflow;
+  int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging
 };
 
 constexpr int kMfmaCountSlots = 1024;
@@ -118,6 +128,8 @@ void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in,
 
 size_t conv_h2_lds_bytes(const ConvArgs &p);
 bool conv_h2_has_cfg(int cfg);
+int conv_h2_mt_mask(int cfg);  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
+void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl);
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);
 
 void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s);

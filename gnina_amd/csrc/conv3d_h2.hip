@@ -59,10 +59,34 @@ __device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &l) {
   l.x = pk_f16(r0, r1);
   l.y = pk_f16(r2, r3);
 }
+// The same with the range check of a CONSUMER: amax = running maximum of |x| over everything this lane staged (two
+// v_maximum3_f32 per quad; compared with 65504 once, at the end of the kernel -- h2_report_overflow).  Producers (the epilogues
+// below, the voxelizer) check the values they write, NaN included; this catches what reaches a split-fp16 kernel from
+// elsewhere: an eval BatchNorm applied while staging, the output of an fp32-MFMA layer.
+__device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &l, float &amax) {
+  // (v_maximum3_f32: the IEEE-754-2019 maximum -- a NaN operand gives NaN, which the final comparison reports as well)
+  asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x.x), "v"(x.y));
+  asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x.z), "v"(x.w));
+  split4(x, h, l);
+}
+// one value: (h, l) packed as h | l << 16
+__device__ __forceinline__ unsigned split1(float x) {
+  const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  const unsigned hp = pk_f16(c, 0.f);
+  float r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(c));
+  return pk_f16(c, r);
+}
+// sticky range flag of the scorer (ConvArgs::h2_overflow): raised by any lane of the wave
+__device__ __forceinline__ void h2_report_overflow(unsigned *flag, bool lane_overflow) {
+  if (flag && __builtin_amdgcn_ballot_w64(lane_overflow) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
 
-// K1: the staging shape of the 1x1x1 convolutions (no halo: at most one voxel per thread, up to six octets of it per chunk)
+// conv3d_h2_k1_kernel: the 1x1x1 convolutions (instantiated with K1 = true only: no halo, at most one voxel per thread, up
+// to six octets of it per chunk; the 3x3x3 layers run on conv3d_h2_kernel below).  Single-buffered [voxel][octet][h | l]
+// tile, fp32 input split while staging.
 template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP, bool K1 = false>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 : 1)) void conv3d_h2_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 : 1)) void conv3d_h2_k1_kernel(ConvArgs p) {
   constexpr int NTHREADS = 64 * WM * WN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -137,6 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
   unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; a scalar counter, read in profile mode only)
+  float amax = 0.f;     // running maximum of |staged value| (range check, see split4)
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           // (3 VALU + a scalar branch to find out) needs no arithmetic
           const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
           if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
-            split4(x, h, l);
+            split4(x, h, l, amax);
             wave_nonzero = true;
           }
         }
@@ -325,6 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           const int rowl = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           float t = acc[m][0][r] * unscale + b1;
           if (p.relu) t = fmaxf(t, 0.f);
+          asm("v_maximum3_f32 %0, %0, |%1|, |%1|" : "+v"(amax) : "v"(t));
           const float c = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
           const _Float16 hi = (_Float16)c;
           dcol[rowl * CCm] = hi;
@@ -412,6 +438,436 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
       }
     }
   }
+  h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3d_h2_kernel: the 3x3x3 convolutions, 32 output channels per wave column.
+//
+// One K chunk = ONE octet of input channels (27 taps = 14 instruction steps: lanes 0-31 feed tap 2p, lanes 32-63 tap
+// 2p + 1).  The halo tile of a chunk is PLANAR in LDS -- [h plane | l plane], a plane = one 16-byte slot (the eight h or
+// the eight l of the octet) per halo voxel, slot = x * SX + y * SY + z with pad slots behind z-rows / x-planes
+// (ConvArgs::h2_pad_*, chosen against bank conflicts: a ds_read_b128 lane group then hits sixteen different slots) -- and
+// DOUBLE-BUFFERED: chunk k + 1 lands in the other buffer while the K loop of chunk k runs, one barrier per chunk.
+//
+// INSPLIT (ConvArgs::in_split): the input tensor is already split in HBM by its producer -- [octet][voxel][h8 | l8]: a
+// slot of an LDS plane is 16 of those bytes, and a chunk's halo tile is a box of ONE dense array, z-rows of 32-byte voxels
+// (channels-last tensors cost a cache line per voxel and chunk) -- so staging is a copy, and the copy is LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no
+// VALU).  The DMA writes 64 consecutive slots per wave-instruction, lane i -> slot base + i, whatever the lanes' source
+// addresses: a lane computes once which (voxel, half) its slots hold and keeps the byte offsets of their sources; voxels
+// outside the grid and pad slots take an out-of-range offset, for which a buffer load returns zeros (the zero padding).
+// !INSPLIT: fp32 input (the gradient program's forward pass, tensors of fp32-MFMA layers): the octet of chunk k + 1 is
+// loaded into registers before the K loop of chunk k and split / written to the other buffer after it (split4).
+// Either way the LDS image and the K loop are the same: a pose scores the same bits on both.
+//
+// MT: which four cells form an M-tile -- 0 raster neighbours, 1 stacked along x (tcx % 4 == 0), 2 a 2 x 2 square in (x, y)
+// (tcx == tcy == 2); the epilogue follows, the results do not depend on it.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *LdsPtr;
+
+template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT>
+__global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3 : 1) : (TM <= 2 ? 3 : TM <= 3 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
+  constexpr int NW = WM * WN, NTHREADS = 64 * NW;
+  static_assert(NW == 4, "staging is laid out for four waves");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int kh = lane >> 5;
+  const int row = lane & 31;
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+  const int n_base = (blockIdx.y * WN + wn) * 32;
+
+  const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
+  const int HV = HX * HY * HZ;
+  const int SY = HZ + p.h2_pad_y, SX = HY * SY + p.h2_pad_x;  // strides in 16-byte slots
+  const int PL = (HX * SX + 31) & ~31;                        // slots per plane; a buffer = 2 PL slots = whole wave-DMAs
+  const int PLB = PL * 16, BUFB = 2 * PLB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_h2c[];
+  char *const s_buf = smem_h2c;                                   // [2 buffers][h plane | l plane]
+  int *const s_qoff = reinterpret_cast<int *>(smem_h2c + 2 * BUFB);  // [32] byte offset of tap q inside a plane (q >= 27: tap 26)
+  int *const s_live = s_qoff + 32;                                // [nchunks][4]: wave w found a non-zero in chunk c's tile (SKIP)
+
+  if (tid < 32) {
+    const int tap = tid < 27 ? tid : 26;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[tid] = (dx * SX + dy * SY + dz) * 16;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
+  const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
+  auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) -> bool {
+    if (MT == 1) {
+      cz = mt % p.tcz;
+      cy = (mt / p.tcz) % p.tcy;
+      cx = 4 * (mt / (p.tcz * p.tcy)) + cim;
+      return cx < p.tcx;
+    }
+    if (MT == 2) {
+      cz = mt, cy = cim & 1, cx = cim >> 1;
+      return mt < p.tcz;
+    }
+    const int cell = mt * 4 + cim;
+    cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    return cell < NC;
+  };
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cx, cy, cz;
+    if (!cell_of(wm * TM + m, cell_in_mt, cx, cy, cz)) cx = cy = cz = 0;
+    baseA[m] = ((2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz)) * 16;  // bytes inside a plane
+  }
+
+  h2_f32x16 acc[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+  unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; read in profile mode only)
+  float amax = 0.f;     // !INSPLIT: running maximum of |staged value| (range check, see split4)
+  bool ovf_out = false; // out_split: a value this lane wrote left the fp16 range
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
+  const size_t pose_floats = (size_t)S * S * S * p.in_cs;
+  const float *in_b = p.in + (size_t)b * pose_floats;
+
+  // ---- staging set-up ----
+  // INSPLIT: NS wave-DMAs per thread and chunk; slot j = tid + i * NTHREADS of a buffer is half j / PL of plane slot j % PL
+  constexpr int NS = 5;  // (plans keep 2 PL <= NS * NTHREADS)
+  unsigned voff[NS];
+  // !INSPLIT: a thread owns halo voxels tid, tid + NTHREADS, ... (plans keep HV <= VPT * NTHREADS)
+  constexpr int VPT = 3;
+  int st_slot[VPT], st_off[VPT];
+  float4 pre[VPT][2];
+  __amdgpu_buffer_rsrc_t rsrc;
+  if constexpr (INSPLIT) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b), 0, (int)(pose_floats * 4), 0x00020000);
+    const unsigned inv_sx = ((1u << 20) + SX - 1) / SX, inv_sy = ((1u << 20) + SY - 1) / SY;  // exact for n < 2^20 / d
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int j = tid + i * NTHREADS;
+      const int half = j >= PL ? 1 : 0;
+      const int ps = j - half * PL;
+      const int hx = (int)(((unsigned)ps * inv_sx) >> 20);
+      const int r1 = ps - hx * SX;
+      const int hy = (int)(((unsigned)r1 * inv_sy) >> 20), hz = r1 - hy * SY;
+      const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+      const bool ok = hx < HX && hy < HY && hz < HZ && (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+      voff[i] = ok ? (unsigned)((x * S + y) * S + z) * 32u + (unsigned)half * 16u : 0x80000000u;  // inside an octet's [voxel][h | l] array
+    }
+  } else {
+    const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+      const int hv = tid + v * NTHREADS;
+      st_slot[v] = 0, st_off[v] = -1;
+      if (hv >= HV) continue;
+      const int t1 = (int)(((unsigned)hv * inv_hz) >> 20), hz = hv - t1 * HZ;
+      const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+      const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+      const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+      st_slot[v] = (hx * SX + hy * SY + hz) * 16;
+      if (in) {
+        st_off[v] = ((x * S + y) * S + z) * p.in_cs;
+      } else {  // the zero padding is laid down once, in both buffers; staging then touches the voxels inside the grid only
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(s_buf + (k >> 1) * BUFB + (k & 1) * PLB + st_slot[v]) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+  const int octet_bytes = S * S * S * 32;  // split format: one octet's [voxel][h8 | l8] array
+  auto issue_dma = [&](int chunk) {
+    if constexpr (INSPLIT) {
+      if (p.h2_dbg & 4) return;
+      char *dst = s_buf + (chunk & 1) * BUFB + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < NS; i++)
+        if ((i * NW + wave) * 64 < 2 * PL)  // (wave-uniform; 2 PL is a multiple of 64)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(dst + i * NW * 1024), 16, voff[i], chunk * octet_bytes, 0, 0);
+    }
+  };
+  auto issue_ld = [&](int chunk) {
+    if constexpr (!INSPLIT) {
+      if (p.h2_dbg & 4) return;
+      const float *src_c = in_b + chunk * 8;
+      const int nq = min(2, p.cin4 - chunk * 2);  // channel quads of this octet that exist in the input
+#pragma unroll
+      for (int v = 0; v < VPT; v++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          if (st_off[v] >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + st_off[v] + q * 4);
+    }
+  };
+  auto commit = [&](int chunk) {
+    if constexpr (!INSPLIT) {
+      const int c_base = chunk * 8;
+      const int nq = min(2, p.cin4 - chunk * 2);
+      char *dstb = s_buf + (chunk & 1) * BUFB;
+      bool lane_nonzero = false;
+#pragma unroll
+      for (int v = 0; v < VPT; v++) {
+        if (st_off[v] < 0) continue;
+        uint2 h[2], l[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          h[q] = make_uint2(0u, 0u), l[q] = make_uint2(0u, 0u);
+          if (q < nq) {  // (a quad the input does not have -- channel padding of the last octet -- is zero)
+            float4 x = pre[v][q];
+            if (p.bn_scale) {  // eval BatchNorm on the conv input (scalar loads: the quad is wave-uniform); padding stays 0
+              const h2_f32x4 sc = *(H2ConstQuadPtr)(const void *)(p.bn_scale + c_base + q * 4);
+              const h2_f32x4 sh = *(H2ConstQuadPtr)(const void *)(p.bn_shift + c_base + q * 4);
+              x.x = x.x * sc.x + sh.x;
+              x.y = x.y * sc.y + sh.y;
+              x.z = x.z * sc.z + sh.z;
+              x.w = x.w * sc.w + sh.w;
+            }
+            const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
+            if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {  // (a quad that is zero in all 64 voxels needs no arithmetic)
+              split4(x, h[q], l[q], amax);
+              lane_nonzero = true;
+            }
+          }
+        }
+        *reinterpret_cast<uint4 *>(dstb + st_slot[v]) = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+        *reinterpret_cast<uint4 *>(dstb + PLB + st_slot[v]) = make_uint4(l[0].x, l[0].y, l[1].x, l[1].y);
+      }
+      if (SKIP && lane == 0) s_live[chunk * 4 + wave] = 0;
+      if (SKIP && __builtin_amdgcn_ballot_w64(lane_nonzero) != 0ull && lane == 0) s_live[chunk * 4 + wave] = 1;
+    }
+  };
+  // INSPLIT + SKIP: is there a non-zero in the slots of chunk `chunk` this wave's DMAs wrote?  (h = 0 implies l = 0: the
+  // h plane decides.  A wave may read what its OWN DMAs wrote once its vmcnt covers them, no barrier needed.)
+  auto probe_dma = [&](int chunk) {
+    if constexpr (INSPLIT && SKIP) {
+      const char *src = s_buf + (chunk & 1) * BUFB;
+      unsigned any = 0u;
+#pragma unroll
+      for (int i = 0; i < (NS + 1) / 2; i++) {
+        const int j = tid + i * NTHREADS;
+        if (j < PL) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(src + j * 16);
+          any |= q.x | q.y | q.z | q.w;
+        }
+      }
+      const bool live = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
+      if (lane == 0) s_live[chunk * 4 + wave] = live ? 1 : 0;
+    }
+  };
+
+  const size_t wstride = (size_t)p.coutp * 16;  // fp16 elements per (step, half-wave) row block of the packed weights
+  constexpr int P = 14;                         // steps per chunk: 27 taps in pairs (the 28th tap's weight rows are zero)
+  const unsigned wlane = ((unsigned)(n_base + row) * 16u + (unsigned)kh * (unsigned)wstride) * 2u;
+  const unsigned wstep = 2u * (unsigned)wstride * 2u;  // bytes per step
+  const int *lp = s_qoff + kh;
+
+  if constexpr (INSPLIT) issue_dma(0);
+  else issue_ld(0);
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    // ---- chunk `chunk` becomes visible in buffer chunk & 1; behind the barrier every wave is also through the K loop of
+    // chunk - 1, i.e. through with the other buffer, which the staging of chunk + 1 may now overwrite ----
+    if constexpr (INSPLIT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      probe_dma(chunk);
+    } else {
+      commit(chunk);
+      if (chunk + 1 < p.nchunks) issue_ld(chunk + 1);
+    }
+    __syncthreads();
+    const char *tile = s_buf + (chunk & 1) * BUFB;
+    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * P * 2 * wstride * 2;
+    bool live = true;
+    if constexpr (SKIP) {
+      const int4 lv = *reinterpret_cast<const int4 *>(s_live + chunk * 4);
+      live = __builtin_amdgcn_readfirstlane(lv.x | lv.y | lv.z | lv.w) != 0;
+      if (p.h2_dbg & 1) live = true;
+    }
+    if (p.h2_dbg & 2) live = false;
+
+    // ---- K loop over tap pairs, ping-pong operand sets.  The weights of the first step are requested BEFORE the DMAs of
+    // the next chunk (memory operations return in order: a weight load queued behind the DMAs would wait for them) ----
+    int qo_next = lp[0];
+    uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
+    auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
+      const int qo = qo_next;
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const char *a = tile + baseA[m] + qo;
+        ah[m] = *reinterpret_cast<const uint4 *>(a);
+        al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
+      }
+      const char *w = wbase + (wlane + (unsigned)pr * wstep);
+      wh = *reinterpret_cast<const uint4 *>(w);
+      wl = *reinterpret_cast<const uint4 *>(w + 16);
+      qo_next = lp[2 * pr + 2];  // (behind the last pair: a pad entry -- unused)
+    };
+    auto mfma_pair = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) {
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        if constexpr (SKIP) {
+          // all 32 voxels x 16 k of this step zero (h = 0 implies l = 0): nothing to add.  One v_or3 + v_or + v_cmp into
+          // an SGPR pair and a scalar branch against three MFMAs
+          const unsigned any = ah[m].x | ah[m].y | ah[m].z | ah[m].w;
+          unsigned long long lv;
+          asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv) : "v"(any));
+          if (lv == 0ull) continue;
+          n_exec++;
+        }
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+      }
+    };
+    if (live) {
+      load_pair(0, ah0, al0, wh0, wl0);
+      load_pair(1, ah1, al1, wh1, wl1);
+    }
+    // (a ds_read behind an LDS-DMA waits for it -- the compiler cannot tell the two buffers apart -- so the DMAs of the next
+    // chunk go out once the operands of the first two steps are on their way)
+    if (chunk + 1 < p.nchunks) issue_dma(chunk + 1);
+    if (!live) continue;
+#pragma unroll 1
+    for (int pr = 0; pr < P; pr += 2) {
+      mfma_pair(ah0, al0, wh0, wl0);
+      if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
+      mfma_pair(ah1, al1, wh1, wl1);
+      if (pr + 3 < P) load_pair(pr + 3, ah1, al1, wh1, wl1);
+    }
+  }
+
+  // ---- fused 1x1x1 conv behind this one (Default2018: conv3 -> ReLU -> conv1 -> ReLU -> pool; ConvArgs::post_w): the ReLU'd
+  // tile is split and laid down in LDS as [voxel row][octet][h | l] -- what the stand-alone 1x1x1 kernel's staging would
+  // build from the tensor in HBM, which therefore never exists -- and a second, short K loop runs over its channels.  Same
+  // operands, same MFMA order as the two separate kernels: same bits (the gradient program runs them separately).
+  float unscale = p.h2_unscale;
+  const float *bias_ptr = p.bias;
+  int relu_flag = p.relu;
+  if constexpr (TM <= 3) {
+    if (p.post_w) {
+      __syncthreads();  // every wave is through its last K loop: the buffers may be overwritten
+      const int CCm = 2 * p.coutp + 8;  // fp16 elements per voxel row of the mid tile (odd number of 16-byte slots)
+      _Float16 *s_mid = reinterpret_cast<_Float16 *>(smem_h2c);
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const int ch = n_base + row;
+        const float b1 = p.bias[ch];
+        _Float16 *dcol = s_mid + (ch >> 3) * 16 + (ch & 7);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rowl = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          float tt = acc[m][r] * unscale + b1;
+          if (p.relu) tt = fmaxf(tt, 0.f);
+          asm("v_maximum3_f32 %0, %0, |%1|, |%1|" : "+v"(amax) : "v"(tt));
+          const float c = __builtin_amdgcn_fmed3f(tt, -65504.f, 65504.f);
+          const _Float16 hi = (_Float16)c;
+          dcol[rowl * CCm] = hi;
+          dcol[rowl * CCm + 8] = (_Float16)(c - (float)hi);
+          acc[m][r] = 0.f;
+        }
+      }
+      __syncthreads();
+      const int npairs = p.post_cc4 >> 1;  // octet pairs = steps of the second K loop
+      const char *w2 = reinterpret_cast<const char *>(p.post_w) + ((size_t)kh * p.coutp + n_base + row) * 32;
+      for (int pr = 0; pr < npairs; pr++) {
+        uint4 ah[TM], al[TM], wh, wl;
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          const char *a = reinterpret_cast<const char *>(s_mid) + (((wm * TM + m) * 32 + row) * CCm + (2 * pr + kh) * 16) * 2;
+          ah[m] = *reinterpret_cast<const uint4 *>(a);
+          al[m] = *reinterpret_cast<const uint4 *>(a + 16);
+        }
+        const char *w = w2 + (size_t)pr * 2 * p.coutp * 32;
+        wh = *reinterpret_cast<const uint4 *>(w);
+        wl = *reinterpret_cast<const uint4 *>(w + 16);
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+        }
+      }
+      unscale = p.h2_post_unscale;
+      bias_ptr = p.post_bias;
+      relu_flag = p.post_relu;
+    }
+  }
+
+  // profile mode: executed MFMA work in units of 4,096 FLOPs (the fp32 kernels count 32x32x2 instructions): an executed
+  // (M-tile, step) is 3 instructions of 32,768 FLOPs
+  if (SKIP && p.mfma_count && lane == 0)
+    atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec * (3u * 8u));
+
+  // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last -- fp32, or split (out_split): the lanes of
+  // channels 2j and 2j + 1 trade halves (one DPP move), the even lane stores the two h, the odd lane the two l ----
+  const int So = p.pool ? S / 2 : S;
+  const size_t out_pose = (size_t)b * So * So * So * p.out_cs + p.out_c0;
+  float *out_f = p.out + out_pose;
+  const int ncx = S / 2;
+  const int ch = n_base + row;
+  // split format (out_c0 = 0, whole octets): [octet][voxel][h8 | l8]; dword of this lane's store inside a voxel's 32 bytes
+  const int ch_sp = ((ch & 7) >> 1) + (row & 1) * 4;
+  const size_t oct_sp = (size_t)(ch >> 3) * So * So * So;
+  auto store = [&](size_t vox, float v) {  // vox = voxel index inside the pose
+    if (p.out_split) {
+      ovf_out |= !(fabsf(v) <= 65504.f);
+      const unsigned mine = split1(v);
+      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+      // even lane: h(mine) | h(other) << 16; odd lane: l(other) | l(mine) << 16
+      const unsigned w = (row & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+      if (ch < p.coutp) reinterpret_cast<unsigned *>(out_f)[(oct_sp + vox) * 8 + ch_sp] = w;
+    } else if (ch < p.cout) {
+      out_f[vox * p.out_cs + ch] = v;
+    }
+  };
+  const float bias = ch < p.coutp ? bias_ptr[ch] : 0.f;
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      int cx, cy, cz;
+      if (!cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz)) continue;
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const float tt = acc[m][half * 8 + r] * unscale + bias;
+        v[r] = relu_flag ? fmaxf(tt, 0.f) : tt;
+      }
+      if (p.pool == 1) {
+        float mx = v[0];
+        int am = 0;
+#pragma unroll
+        for (int r = 1; r < 8; r++)
+          if (v[r] > mx) mx = v[r], am = r;
+        const size_t vox = ((size_t)gcx * So + gcy) * So + gcz;
+        store(vox, mx);
+        if (p.argmax_out && ch < p.cout) p.argmax_out[out_pose + vox * p.out_cs + ch] = (unsigned char)am;
+      } else if (p.pool == 2) {
+        float sum = v[0];
+#pragma unroll
+        for (int r = 1; r < 8; r++) sum = sum + v[r];
+        store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+          store(((size_t)vx * So + vy) * So + vz, v[r]);
+        }
+      }
+    }
+  }
+  h2_report_overflow(p.h2_overflow, ovf_out || !(amax <= 65504.f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,6 +928,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
   h2_f32x4 acc[TM];
 #pragma unroll
   for (int m = 0; m < TM; m++) acc[m] = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;  // running maximum of |staged value| (range check, see split4)
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
@@ -534,7 +991,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
             x.z = x.z * sc.z + sh.z;
             x.w = x.w * sc.w + sh.w;
           }
-          split4(x, h, l);
+          split4(x, h, l, amax);
         }
         *reinterpret_cast<uint2 *>(d) = h;
         *reinterpret_cast<uint2 *>(d + 8) = l;
@@ -618,36 +1075,73 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
       }
     }
   }
+  h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
+}
+
+// geometry of conv3d_h2_kernel's planar halo tile (16-byte slots): z-row and x-plane strides, slots per plane
+void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl) {
+  const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
+  *sy = HZ + p.h2_pad_y;
+  *sx = HY * *sy + p.h2_pad_x;
+  *pl = (HX * *sx + 31) & ~31;
 }
 
 size_t conv_h2_lds_bytes(const ConvArgs &p) {
+  const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (2 * p.coutp + 8) * sizeof(_Float16) : 0;  // fused 1x1x1 conv
+  if (p.ksize == 3 && p.coutp != 16) {  // conv3d_h2_kernel: two buffers of two planes, tap offsets, live flags
+    int sy, sx, pl;
+    conv_h2_planar_geo(p, &sy, &sx, &pl);
+    return std::max((size_t)4 * pl * 16 + 32 * sizeof(int) + (size_t)p.nchunks * 4 * sizeof(int), mid_bytes);
+  }
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // (pads: 16-wide kernel only)
   const size_t main_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + (HV + 4) * sizeof(int);
-  const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (2 * p.coutp + 8) * sizeof(_Float16) : 0;  // fused 1x1x1 conv
   return std::max(main_bytes, mid_bytes);
 }
 
-template <int WM, int WN, int TM, int TN, bool MTX, bool K1ONLY = false> static void launch_h2(const ConvArgs &p, int B, hipStream_t s) {
+// 1x1x1 layers (conv3d_h2_k1_kernel; no zero test: one step per octet pair, nothing to skip ahead of)
+template <int WM, int WN, int TM, int TN> static void launch_h2_k1(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
+  auto kern = conv3d_h2_k1_kernel<WM, WN, TM, TN, false, false, true>;
+  ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+  hipLaunchKernelGGL(kern, grid, block, conv_h2_lds_bytes(p), s, p);
+}
+
+// 3x3x3 layers (conv3d_h2_kernel).  MT = the M-tile geometries compiled for this shape besides raster order (ConvArgs::mt_x);
+// SKIP_OK: the zero-skipping variant exists (the throughput tile of a first conv: the pooled voxel grid)
+template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2_k3(const ConvArgs &p, int B, hipStream_t s) {
+  const int ngroups = (p.coutp / 32 + WN - 1) / WN;
+  dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_h2_lds_bytes(p);
+  int sy, sx, pl;
+  conv_h2_planar_geo(p, &sy, &sx, &pl);
+  if (2 * pl > 5 * 64 * WM * WN || (2 * p.tcx + 2) * (2 * p.tcy + 2) * (2 * p.tcz + 2) > 3 * 64 * WM * WN)
+    throw Error(2, "launch_conv_h2: halo tile larger than the kernel's staging covers");
+  if (p.in_split && (p.in_cs % 8 || p.bn_scale)) throw Error(2, "launch_conv_h2: split-format input needs whole octets and no BatchNorm");
+  if (p.out_split && (p.out_cs % 8 || p.out_c0 || p.coutp != p.cout || p.argmax_out))
+    throw Error(2, "launch_conv_h2: split-format output needs whole octets, no channel offset, no arg-max");
   auto go = [&](auto kern) {
     ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
   };
-  if (p.ksize == 1) {  // (no zero test on the 1x1x1 layers: one step per octet pair, nothing to skip ahead of)
-    if constexpr (!MTX) go(conv3d_h2_kernel<WM, WN, TM, TN, false, false, true>);
-    else throw Error(2, "launch_conv_h2: x-stacked M-tiles are a 3x3x3 layout");
-  } else if constexpr (K1ONLY) {
-    throw Error(2, "launch_conv_h2: tile configuration compiled for 1x1x1 convolutions only");
-  } else if (p.sparse) {
-    go(conv3d_h2_kernel<WM, WN, TM, TN, MTX, true, false>);
-  } else {
-    go(conv3d_h2_kernel<WM, WN, TM, TN, MTX, false, false>);
-  }
+  auto by_input = [&](auto mt, auto skip) {
+    constexpr int MT = decltype(mt)::value;
+    constexpr bool SK = decltype(skip)::value;
+    if (p.in_split) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true>);
+    else go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false>);
+  };
+  auto by_skip = [&](auto mt) {
+    if constexpr (SKIP_OK) {
+      if (p.sparse) return by_input(mt, std::true_type{});
+    }
+    by_input(mt, std::false_type{});
+  };
+  if (p.mt_x == 0) by_skip(std::integral_constant<int, 0>{});
+  else if (MTALT != 0 && p.mt_x == MTALT) by_skip(std::integral_constant<int, MTALT>{});
+  else throw Error(2, "launch_conv_h2: M-tile geometry not compiled for this tile shape");
 }
 
 template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t s) {
@@ -672,17 +1166,42 @@ bool conv_h2_has_cfg(int cfg) {
   }
 }
 
+int conv_h2_mt_mask(int cfg) {
+  switch (cfg) {
+    case CONV_CFG_4x1_2x1: return 1 | 2;
+    case CONV_CFG_2x2_3x1: return 1 | 4;
+    case CONV_CFG_4x1_1x1: return 1 | 4;
+    default: return 1;
+  }
+}
+
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
+  const bool k1 = p.ksize == 1;
   switch (cfg) {
     case CONV_CFG_4x1_2x1:
-      if (p.mt_x) launch_h2<4, 1, 2, 1, true>(p, B, s);
-      else launch_h2<4, 1, 2, 1, false>(p, B, s);
+      if (k1) launch_h2_k1<4, 1, 2, 1>(p, B, s);
+      else launch_h2_k3<4, 1, 2, 1, true>(p, B, s);
       break;
-    case CONV_CFG_2x2_3x1: launch_h2<2, 2, 3, 1, false>(p, B, s); break;
-    case CONV_CFG_1x4_7x1: launch_h2<1, 4, 7, 1, false>(p, B, s); break;
-    case CONV_CFG_4x1_1x3: launch_h2<4, 1, 1, 3, false, true>(p, B, s); break;
-    case CONV_CFG_4x1_1x5: launch_h2<4, 1, 1, 5, false, true>(p, B, s); break;
-    case CONV_CFG_4x1_1x1: launch_h2<4, 1, 1, 1, false>(p, B, s); break;
+    case CONV_CFG_2x2_3x1:
+      if (k1) launch_h2_k1<2, 2, 3, 1>(p, B, s);
+      else launch_h2_k3<2, 2, 3, 2, false>(p, B, s);
+      break;
+    case CONV_CFG_1x4_7x1:
+      if (k1) launch_h2_k1<1, 4, 7, 1>(p, B, s);
+      else launch_h2_k3<1, 4, 7, 0, false>(p, B, s);
+      break;
+    case CONV_CFG_4x1_1x1:
+      if (k1) launch_h2_k1<4, 1, 1, 1>(p, B, s);
+      else launch_h2_k3<4, 1, 1, 2, false>(p, B, s);
+      break;
+    case CONV_CFG_4x1_1x3:
+      if (!k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 1x1x1 convolutions only");
+      launch_h2_k1<4, 1, 1, 3>(p, B, s);
+      break;
+    case CONV_CFG_4x1_1x5:
+      if (!k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 1x1x1 convolutions only");
+      launch_h2_k1<4, 1, 1, 5>(p, B, s);
+      break;
     case CONV_CFG_N16_TM1: launch_h2_16<1>(p, B, s); break;
     case CONV_CFG_N16_TM2: launch_h2_16<2>(p, B, s); break;
     case CONV_CFG_N16_TM3: launch_h2_16<3>(p, B, s); break;

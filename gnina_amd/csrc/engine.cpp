@@ -58,6 +58,10 @@ struct ConvPlan {
   // the same layer on the split-fp16 kernels (conv3d_h2.hip; forward, same tiles, own K chunking and packed weights)
   bool has_h2 = false;
   ConvArgs h2{};
+  // 3x3x3 layers on conv3d_h2_kernel (planar, double-buffered halo tile; may read / write split-format tensors): M-tile
+  // geometry and LDS pad slots of the throughput tile live in h2 (mt_x, h2_pad_*), those of the latency tile here
+  bool h2_planar = false;
+  int h2_lat_mt = 0, h2_lat_pad[2] = {0, 0};
 };
 
 // Tile geometry of a launch of `nb` poses: the throughput plan, or the latency variant when the throughput
@@ -117,6 +121,13 @@ struct Model {
   std::vector<Step> steps32;        // the same with fp32 MFMA in every layer and the fused 3x3x3 + 1x1x1 pairs (MI_PRECISION_FP32_MFMA)
   std::vector<Step> gsteps;         // gradient-capable program (avg pools unfused, transposed convs planned)
   std::vector<char> op_h2;          // per op of the description: the forward program runs it on the split-fp16 kernels
+  // Split-format tensors of the forward program `steps` (ConvArgs::in_split): buf_split[id] = activation buffer id is
+  // written split by its producer (a conv3d_h2_kernel epilogue) because every layer reading it is a conv3d_h2_kernel layer
+  // without BatchNorm; pooled_split_ok = the same holds for the pooled voxel grid, which the voxelizer then writes split
+  // with a channel stride of Cp8 (whole octets).  Every other program (fp32 MFMA, gradient, bf16) keeps fp32 tensors.
+  std::vector<char> buf_split;
+  bool pooled_split_ok = false;
+  int Cp8 = 0;
   std::vector<Step> hsteps;         // bf16-MFMA forward program (built on first use, mi_scorer_set_precision)
   std::vector<Step> hgsteps;        // bf16-MFMA gradient program (max-pool networks: Default2017, Dense)
   std::once_flag hsteps_once, hgsteps_once;
@@ -382,6 +393,72 @@ static float h2_weight_scale(const float *w, size_t n) {
   return wmax > 0.f ? ldexpf(1.f, 14 - (int)floorf(log2f(wmax)) - 1) : 1.f;
 }
 
+// LDS layout of conv3d_h2_kernel's planar halo tile for a tile of tc cells and a workgroup of wm x tm M-tiles: which four
+// cells form an M-tile (0 raster, 1 stacked along x, 2 a 2 x 2 square in (x, y)) and how many 16-byte pad slots follow every
+// z-row / x-plane, chosen with the bank model of the A-operand reads (MI355X: a ds_read_b128 is served in four groups of 16
+// lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- and a group takes as many LDS cycles as the
+// largest number of its lanes that hit one slot modulo 16 at different addresses).  All lanes of a half-wave add the same
+// tap offset, so the model only needs the lanes' base slots.  Smallest mean cycles, then smallest tile.
+static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt_out, int &pad_y, int &pad_x, double *cycles_out = nullptr) {
+  static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  const int tcx = tc[0], tcy = tc[1], tcz = tc[2], NC = tcx * tcy * tcz;
+  const int HX = 2 * tcx + 2, HY = 2 * tcy + 2, HZ = 2 * tcz + 2;
+  double best = 1e30;
+  long best_size = 0;
+  mt_out = 0, pad_y = 0, pad_x = 0;
+  for (int mt = 0; mt < 3; mt++) {
+    if (!((mt_mask >> mt) & 1)) continue;  // (geometries compiled for the kernel shape: conv_h2_mt_mask)
+    if (mt == 1 && (tcx % 4 != 0 || getenv("MI_GNINA_NO_MT_X"))) continue;
+    if (mt == 2 && !(tcx == 2 && tcy == 2)) continue;
+    const int n_mt = mt == 1 ? tcx / 4 * tcy * tcz : mt == 2 ? tcz : cdiv(NC, 4);
+    if (n_mt > n_mtiles) continue;
+    for (int py = 0; py < 16; py++)
+      for (int px = 0; px < 16; px++) {
+        const int SY = HZ + py, SX = HY * SY + px;
+        const long size = (long)((HX * SX + 31) & ~31);
+        if (2 * size > 5 * 256) continue;  // (the kernel's staging: five wave-DMAs per thread and chunk)
+        double tot = 0;
+        for (int mtile = 0; mtile < n_mt; mtile++) {
+          int base[32];
+          for (int row = 0; row < 32; row++) {
+            const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1, cim = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
+            int cx, cy, cz;
+            if (mt == 1) cz = mtile % tcz, cy = (mtile / tcz) % tcy, cx = 4 * (mtile / (tcz * tcy)) + cim;
+            else if (mt == 2) cz = mtile, cy = cim & 1, cx = cim >> 1;
+            else {
+              const int cell = std::min(mtile * 4 + cim, NC - 1);
+              cz = cell % tcz, cy = (cell / tcz) % tcy, cx = cell / (tcz * tcy);
+            }
+            base[row] = (2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz);
+          }
+          for (int g = 0; g < 2; g++) {
+            int worst = 0;
+            for (int i = 0; i < 16; i++) {
+              int distinct = 0;  // different addresses of this group in lane i's slot class, counted once (at their first lane)
+              bool first = true;
+              for (int j = 0; j < i; j++)
+                if (base[kGroup[g][j]] == base[kGroup[g][i]]) first = false;
+              if (!first) continue;
+              for (int j = 0; j < 16; j++) {
+                if ((base[kGroup[g][j]] - base[kGroup[g][i]]) % 16 != 0) continue;
+                bool seen = false;
+                for (int k = 0; k < j; k++)
+                  if (base[kGroup[g][k]] == base[kGroup[g][j]]) seen = true;
+                if (!seen) distinct++;
+              }
+              worst = std::max(worst, distinct);
+            }
+            tot += worst;
+          }
+        }
+        const double mean = tot / (2.0 * n_mt);
+        if (mean < best - 1e-9 || (mean < best + 1e-9 && size < best_size)) best = mean, best_size = size, mt_out = mt, pad_y = py, pad_x = px;
+      }
+  }
+  if (cycles_out) *cycles_out = best;
+}
+
 static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
   if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
@@ -389,6 +466,8 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   const int taps = o.ksize * o.ksize * o.ksize;
   const int halo = o.ksize == 3 ? 1 : 0;
   const int cin8 = cdiv(o.cin, 8);
+  // 3x3x3 layers with 32-wide output tiles: conv3d_h2_kernel -- one octet per K chunk, planar double-buffered halo tile
+  const bool planar = o.ksize == 3 && a.coutp != 16;
   // K chunking over octets.  The throughput tile and the latency tile share the packed weights, i.e. the chunking: sized
   // for the larger halo
   size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
@@ -401,16 +480,33 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   // 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv)
   int vpt = 3, max_c = 2;
   if (a.coutp != 16 && o.ksize == 1) vpt = 1, max_c = 6;
+  if (planar) max_c = 1;
   {
     int wm, wn, tm, tn;
     conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
     if (HV > (size_t)vpt * 64 * wm * wn) return;  // (HV covers the latency tile too)
     if (a.coutp != 16 && o.ksize != 1 && tn >= 3) return;  // tile shapes compiled for the 1x1x1 bottlenecks only
     if (a.coutp != 16 && o.ksize == 1 && a.mt_x) return;
+    if (planar) {
+      if (wm * wn != 4) return;
+      const int tc[3] = {a.tcx, a.tcy, a.tcz};
+      int mt, py, px;
+      h2_choose_layout(tc, wm * tm, conv_h2_mt_mask(cp.cfg), mt, py, px);
+      a.mt_x = mt, a.h2_pad_y = py, a.h2_pad_x = px;
+      if (cp.has_lat) {
+        int lwm, lwn, ltm, ltn;
+        conv_cfg_shape(cp.lat_cfg, &lwm, &lwn, &ltm, &ltn);
+        if (lwm * lwn != 4) return;
+        h2_choose_layout(cp.lat_tc, lwm * ltm, conv_h2_mt_mask(cp.lat_cfg), mt, py, px);
+        cp.h2_lat_mt = mt;
+        cp.h2_lat_pad[0] = py, cp.h2_lat_pad[1] = px;
+      }
+    }
   }
   int best = 1;
   for (int c = 1; c <= cin8 && c <= max_c; c++)
     if (HV * (16 * c + 8) * 2 + (size_t)(taps * c + 8) * 4 + HV * 4 <= budget) best = c;
+  if (planar) best = 1;
   const int nchunks = cdiv(cin8, best);
   best = cdiv(cin8, nchunks);  // equal chunks (the last one may still be an octet short)
   a.cc4 = best;
@@ -458,6 +554,7 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   MIG_CHECK(conv_h2_lds_bytes(a) <= 160 * 1024, 2, "split-fp16 conv tile exceeds LDS");
   cp.h2 = a;
   cp.has_h2 = true;
+  cp.h2_planar = planar;
 }
 
 // ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
@@ -809,6 +906,30 @@ static Model *build_model(ModelDesc &&desc) {
   };
   m->steps = build_steps(false, false);
   m->steps32 = getenv("MI_GNINA_NO_H2") ? m->steps : build_steps(false, true);
+  // tensor formats of the forward program (see Model::buf_split)
+  m->Cp8 = round_up(m->C, 8);
+  m->buf_split.assign(d.bufs.size(), 0);
+  if (!getenv("MI_GNINA_NO_H2") && !getenv("MI_GNINA_H2_NO_SPLIT_TENSORS")) {
+    std::vector<int> readers(d.bufs.size(), 0), split_readers(d.bufs.size(), 0), producers(d.bufs.size(), 0), split_producers(d.bufs.size(), 0);
+    for (const Step &st : m->steps) {
+      if (st.kind == OpKind::Conv) {
+        const bool k3 = st.conv.has_h2 && st.conv.h2_planar;
+        readers[st.conv.src]++;
+        if (k3 && !st.has_bn) split_readers[st.conv.src]++;
+        producers[st.conv.dst]++;
+        const ConvArgs &h = st.conv.h2;
+        if (k3 && h.out_c0 == 0 && h.cout == h.coutp && h.cout == d.bufs[st.conv.dst].C && h.cout % 8 == 0) split_producers[st.conv.dst]++;
+      } else {
+        if (st.src >= 0) readers[st.src]++;
+        if (st.dst >= 0) producers[st.dst]++;
+      }
+    }
+    for (size_t id = 0; id < d.bufs.size(); id++) {
+      if ((int)id == m->input_dst) continue;
+      m->buf_split[id] = readers[id] > 0 && readers[id] == split_readers[id] && producers[id] == 1 && split_producers[id] == 1;
+    }
+    m->pooled_split_ok = readers[m->input_dst] > 0 && readers[m->input_dst] == split_readers[m->input_dst] && m->input_pool != 0;
+  }
   // gradient program: conv / pool stacks (Default2017 / Default2018 families) and the Dense family
   // (BatchNorm-on-input convs growing a concat buffer, global max pool)
   m->grad_supported = !d.skip_softmax && !d.apply_logistic_loss;
@@ -892,6 +1013,13 @@ struct Scorer {
   std::vector<std::unique_ptr<DevBuf<unsigned char>>> argm;    // arg-max of fused max pools
   DevBuf<float> d_raw3, d_lig_grad, d_ave;
   DevBuf<unsigned> d_probe;             // zero-cell counters of launch_zero_cell_probe
+  // split-fp16 range flag (ConvArgs::h2_overflow): cleared when a call starts, raised by any split-fp16 kernel (or the
+  // voxelizer writing a split tensor) that meets an activation beyond +-65504 or a NaN; a call that finds it raised
+  // recomputes its scores on the fp32-MFMA kernels (score_batch / score_batch_grad)
+  DevBuf<unsigned> d_ovf;
+  unsigned *h_ovf = nullptr;            // pinned copy
+  int h2_fallbacks = 0;                 // calls recomputed because of it (mi_scorer_h2_fallbacks)
+  bool ovf_pending = false;             // device-output calls in flight whose flag mi_scorer_synchronize still has to read
   int lig_cache_group = -1, lig_cache_n = 0;  // setup_ligand cache: group / ligand types the device arrays describe
   std::vector<int32_t> lig_cache_smt;
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
@@ -997,6 +1125,9 @@ constexpr size_t kPooledSlot2 = 4096;  // second pooled-grid buffer of the two-s
 // Poses per launch for a call on B poses: the user's chunk, clipped to B and to an activation-memory budget
 // (96 GB of the 288 GB by default, MI_GNINA_ACT_GB overrides) -- a 96^3 Dense pose keeps ~110 MB of
 // activations (x2.25 with gradients), a 48^3 Default2017 pose 2.4 MB.
+// channel stride the pooled voxel grid's buffer is sized for: the fp32 layout (buf_cp) or the split layout (whole octets)
+static int pooled_stride(const Model *m) { return std::max(m->buf_cp[m->input_dst], m->Cp8); }
+
 static void set_call_capacity(Scorer &s, int B, bool grad) {
   double per_pose = 0;
   size_t max_bufs = 0;
@@ -1006,7 +1137,7 @@ static void set_call_capacity(Scorer &s, int B, bool grad) {
     for (Model *m : s.models)
       if (id < m->d.bufs.size() && m->buf_cp[id] > 0) {
         const BufDecl &bd = m->d.bufs[id];
-        worst = std::max(worst, (double)bd.S * bd.S * bd.S * m->buf_cp[id] * 4.0);
+        worst = std::max(worst, (double)bd.S * bd.S * bd.S * ((int)id == m->input_dst ? pooled_stride(m) : m->buf_cp[id]) * 4.0);
       }
     per_pose += worst;
   }
@@ -1263,7 +1394,7 @@ static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_sm
 // gather + voxelize poses [b0, b0+nb) of the batch for one group. mode: 0 full grid, 1/2 pooled.
 static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, const float *d_lig_xyz, int L,
                            const float *d_centers_in, unsigned flags, int b0, int nb, int mode, float *out,
-                           unsigned char *argmax_out = nullptr, hipStream_t vs = nullptr, int set = 0) {
+                           unsigned char *argmax_out = nullptr, hipStream_t vs = nullptr, int set = 0, bool split = false) {
   if (!vs) vs = s.stream;
   DevBuf<AtomRec> &cand = set ? s.d_cand2 : s.d_cand;
   DevBuf<int> &cand_chan = set ? s.d_cand_chan2 : s.d_cand_chan;
@@ -1333,6 +1464,13 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   va.qc = m->qc;
   va.out = out;
   va.argmax_out = argmax_out;
+  if (split) {  // the pooled grid in split format (Model::pooled_split_ok): whole octets, h | l halves
+    MIG_CHECK(mode != 0 && !argmax_out, 2, "split-format voxel grid: pooled forward output only");
+    va.split = 1;
+    va.Cp = m->Cp8;
+    s.d_ovf.ensure(1);
+    va.overflow = s.d_ovf.p;
+  }
   {
     // algorithmic bytes: the un-fused figure C*N^3*4 written once per pose
     ProfScope ps(s, mode == 0 ? "voxelize_tiles<full>" : "voxelize_tiles<pooled>", 0.0,
@@ -1371,7 +1509,7 @@ static bool use_bf16(Scorer &s, Model &m, bool grad) {
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
 // act[input_dst]; writes pose/aff/loss at out offsets.
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
-                        size_t pooled_slot = 0) {
+                        size_t pooled_slot = 0, bool pooled_split = false) {
   Model *m = s.models[mi];
   if (m->overlap) {
     const long N3 = (long)m->N * m->N * m->N;
@@ -1393,8 +1531,12 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
     const BufDecl &bd = m->d.bufs[id];
     // the pooled voxel grid lives in a dedicated slot shared by all models of a voxelization group
     const size_t slot = id == m->input_dst ? pooled_slot : (size_t)id;
-    return act_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id]);
+    return act_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * (id == m->input_dst ? pooled_stride(m) : m->buf_cp[id]));
   };
+  // split-format tensors (Model::buf_split) exist in the split-fp16 forward program only
+  const bool fwd_h2 = !bf16 && !grad && s.conv_path != 0;
+  MIG_CHECK(!pooled_split || (fwd_h2 && m->pooled_split_ok), 2, "pooled grid written split for a program that reads fp32");
+  auto is_split = [&](int id) { return fwd_h2 && (id == m->input_dst ? pooled_split : (bool)m->buf_split[id]); };
   for (const Step &st : steps) {
     switch (st.kind) {
       case OpKind::Conv: {
@@ -1449,6 +1591,20 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             pick_tile(st.conv, nb, geo, cfg);
             h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
             if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
+            if (st.conv.h2_planar) {  // conv3d_h2_kernel: its own M-tile geometry and LDS pads per tile; tensor formats
+              const bool lat = cfg != st.conv.cfg;
+              h.mt_x = lat ? st.conv.h2_lat_mt : st.conv.h2.mt_x;
+              h.h2_pad_y = lat ? st.conv.h2_lat_pad[0] : st.conv.h2.h2_pad_y;
+              h.h2_pad_x = lat ? st.conv.h2_lat_pad[1] : st.conv.h2.h2_pad_x;
+              h.in_split = is_split(st.conv.src) ? 1 : 0;
+              h.out_split = is_split(st.conv.dst) ? 1 : 0;
+              if (h.in_split && st.conv.src == m->input_dst) h.in_cs = m->Cp8;
+            } else {
+              MIG_CHECK(!is_split(st.conv.src) && !is_split(st.conv.dst), 2, "split-format tensor at a layer that cannot take it");
+            }
+            s.d_ovf.ensure(1);
+            h.h2_overflow = s.d_ovf.p;
+            if (const char *ev = getenv("MI_GNINA_H2_DBG")) h.h2_dbg = atoi(ev);
             h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
           } else {
@@ -1581,10 +1737,22 @@ static float *run_backward(Scorer &s, int mi, int nb) {
 // CNNTorchScorer::score(m, compute_gradient = true, ...) (cnn_torch_scorer.cpp:105-198): forward,
 // loss.backward() and GridMaker::backward (torch_model.cpp:197-221) for B poses; ligand-atom
 // gradients are averaged over the ensemble like m.scale_minus_forces(1 / cnt).
-static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
-                             const float *centers, float *pose, float *aff, float *loss, float *var,
-                             float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
-                             float *flex_grad = nullptr) {
+// ---- the split-fp16 range flag (Scorer::d_ovf) ----
+static void h2_flag_reset(Scorer &s) {
+  s.d_ovf.ensure(1);
+  if (!s.h_ovf) MIG_HIP(hipHostMalloc((void **)&s.h_ovf, sizeof(unsigned), hipHostMallocDefault));
+  if (s.ovf_pending) return;  // device-output calls since the last synchronize: the flag stays sticky across them
+  MIG_HIP(hipMemsetAsync(s.d_ovf.p, 0, sizeof(unsigned), s.stream));
+}
+// after the call's work is enqueued; the caller synchronizes the stream before reading *s.h_ovf
+static void h2_flag_fetch(Scorer &s) {
+  MIG_HIP(hipMemcpyAsync(s.h_ovf, s.d_ovf.p, sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
+}
+
+static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                                  const float *centers, float *pose, float *aff, float *loss, float *var,
+                                  float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
+                                  float *flex_grad = nullptr) {
   MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
   MIG_CHECK(pose && aff && loss && (lig_grad || flex_grad), 1, "output arrays must not be NULL");
@@ -1592,7 +1760,6 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   for (Model *m : s.models)
     MIG_CHECK(m->grad_supported, 1, "gradient not supported for model " + m->d.name + ": " + m->grad_unsupported_reason);
   if (B == 0) return;
-  RotScope rot_scope(s, B);
   set_call_capacity(s, B, true);
   const int nm = (int)s.models.size();
   s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
@@ -1624,7 +1791,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
     Model *m0 = s.models[g.first_model];
     LigSetup ls = setup_ligand(s, g, lig_smt, L);
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
-    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
+    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);  // (one size per slot: DevBuf::ensure re-allocates when asked for more)
     for (int b0 = 0; b0 < B; b0 += s.cap) {
       const int nb = std::min(s.cap, B - b0);
       float *pooled = act_buf(s, kPooledSlot, pooled_n);
@@ -1693,17 +1860,39 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   if (var) MIG_HIP(hipMemcpyAsync(var, s.d_var.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   if (lig_grad)
     MIG_HIP(hipMemcpyAsync(lig_grad, s.d_lig_grad.p, (size_t)B * L * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  h2_flag_fetch(s);
   MIG_HIP(hipStreamSynchronize(s.stream));
 }
 
-static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
-                        const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags,
-                        bool ragged = false) {
+// A call whose split-fp16 kernels met an activation outside the fp16 range (|a| > 65504: a user model with large
+// activations, a pathological input; NaN too) is repeated on the fp32-MFMA kernels -- the reference runs any model in fp32
+// (torch_model.cpp:185).  The shipped models never get here (their activations stay below ~1e3).
+static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                             const float *centers, float *pose, float *aff, float *loss, float *var,
+                             float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
+                             float *flex_grad = nullptr) {
+  if (B <= 0) return score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
+  RotScope rot_scope(s, B);
+  h2_flag_reset(s);
+  score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
+  if (s.conv_path == 0 || *s.h_ovf == 0u || s.ovf_pending) return;
+  s.h2_fallbacks++;
+  struct PathGuard {
+    Scorer &s;
+    int saved;
+    ~PathGuard() { s.conv_path = saved; }
+  } guard{s, s.conv_path};
+  s.conv_path = 0;
+  score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
+}
+
+static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                             const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags,
+                             bool ragged = false) {
   MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
   MIG_CHECK(B >= 0 && L >= 0 && (B == 0 || (lig_xyz && lig_smt)), 1, "bad ligand arguments");
   MIG_CHECK(pose && aff && loss, 1, "output arrays must not be NULL");
   if (B == 0) return;
-  RotScope rot_scope(s, B);
   set_call_capacity(s, B, false);
   const int nm = (int)s.models.size();
   const float *d_lig = lig_xyz;
@@ -1732,8 +1921,11 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
     // Two-stream pipeline: chunk i+1 is voxelized (VALU-bound) on vox_stream while the CNN of chunk i
     // (MFMA-bound) runs on the main stream; the pooled grid and candidate lists are double buffered.
-    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst];
+    const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);
     const bool ov = s.overlap && B > s.cap;
+    // the pooled grid goes out in split format when every model of the group reads it with a split-fp16 first conv
+    bool split = s.conv_path != 0 && s.precision != 1 && !getenv("MI_GNINA_H2_NO_SPLIT_TENSORS");
+    for (int mi : g.models) split = split && s.models[mi]->pooled_split_ok;
     if (ov) {
       MIG_HIP(hipEventRecord(s.ev_inputs, s.stream));  // ligand / centre uploads are visible to vox_stream
       MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_inputs, 0));
@@ -1746,17 +1938,17 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
       float *pooled = act_buf(s, slot, pooled_n);
       if (ov) {
         if (ci >= 2) MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_cnn_done[set], 0));  // buffer set free again
-        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, s.vox_stream, set);
+        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, s.vox_stream, set, split);
         MIG_HIP(hipEventRecord(s.ev_vox_done[set], s.vox_stream));
         MIG_HIP(hipStreamWaitEvent(s.stream, s.ev_vox_done[set], 0));
       } else {
         if (m0->input_pool == 0)
           MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
-        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled);
+        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, nullptr, 0, split);
       }
       for (int mi : g.models)
         run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
-                    s.d_loss_m.p + (size_t)mi * B + b0, false, slot);
+                    s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
       if (ov) MIG_HIP(hipEventRecord(s.ev_cnn_done[set], s.stream));
     }
     if (ov) {  // the next group's ligand set-up rewrites buffers the voxelizer reads
@@ -1780,6 +1972,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
       s.h_out4_n = (size_t)4 * B;
     }
     MIG_HIP(hipMemcpyAsync(s.h_out4, s.d_out4.p, (size_t)4 * B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    h2_flag_fetch(s);
     MIG_HIP(hipStreamSynchronize(s.stream));
     memcpy(pose, s.h_out4, B * sizeof(float));
     memcpy(aff, s.h_out4 + B, B * sizeof(float));
@@ -1787,6 +1980,32 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
     if (var) memcpy(var, s.h_out4 + 3 * (size_t)B, B * sizeof(float));
     if (s.timing) MIG_HIP(hipEventElapsedTime(&s.last_ms[2], s.ev[0], s.ev[2]));
   }
+}
+
+// (see score_batch_grad.)  A device-output call (MI_OUT_ON_DEVICE) returns before its kernels ran: the flag then stays
+// sticky until mi_scorer_synchronize, which reports it as MI_ERR_RANGE -- the caller repeats those calls under
+// MI_PRECISION_FP32_MFMA (mi_pool_score_batch does).
+static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
+                        const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags,
+                        bool ragged = false) {
+  if (B <= 0) return score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
+  RotScope rot_scope(s, B);
+  h2_flag_reset(s);
+  score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
+  if (s.conv_path == 0) return;
+  if (flags & MI_OUT_ON_DEVICE) {
+    s.ovf_pending = true;
+    return;
+  }
+  if (*s.h_ovf == 0u || s.ovf_pending) return;
+  s.h2_fallbacks++;
+  struct PathGuard {
+    Scorer &s;
+    int saved;
+    ~PathGuard() { s.conv_path = saved; }
+  } guard{s, s.conv_path};
+  s.conv_path = 0;
+  score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
 }
 
 }  // namespace mig
@@ -2140,7 +2359,7 @@ mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int 
     const int nb = std::min(s.cap, B - b0);
     MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
                            hipMemcpyHostToDevice, s.stream));
-    float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * m->buf_cp[m->input_dst]);
+    float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m));
     if (m->overlap)  // the full grid is the network input
       MIG_HIP(hipMemcpyAsync(pooled, d_grid.p, (size_t)nb * per_pose * sizeof(float), hipMemcpyDeviceToDevice, s.stream));
     else
@@ -2161,11 +2380,22 @@ mi_status mi_scorer_synchronize(mi_scorer *sc) {
   MI_TRY
   MIG_CHECK(sc, 1, "NULL scorer");
   Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  if (s.ovf_pending) h2_flag_fetch(s);
   MIG_HIP(hipStreamSynchronize(s.stream));
   if (s.timing && s.ev[2]) (void)hipEventElapsedTime(&s.last_ms[2], s.ev[0], s.ev[2]);
+  if (s.ovf_pending) {
+    s.ovf_pending = false;
+    if (*s.h_ovf != 0u) {
+      s.h2_fallbacks++;
+      throw Error(MI_ERR_RANGE, "an activation left the fp16 range of the split-fp16 kernels in a device-output call since the last "
+                                "synchronize: repeat those calls under MI_PRECISION_FP32_MFMA");
+    }
+  }
   return MI_OK;
   MI_CATCH_STATUS
 }
+
+int mi_scorer_h2_fallbacks(const mi_scorer *sc) { return sc ? reinterpret_cast<const Scorer *>(sc)->h2_fallbacks : 0; }
 
 mi_status mi_scorer_set_chunk(mi_scorer *sc, int poses_per_chunk) {
   MI_TRY

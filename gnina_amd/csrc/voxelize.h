@@ -71,6 +71,11 @@ struct VoxArgs {
   float qa, qb, qc;      // quadratic tail coefficients (4 e^-2, -12 e^-2, 9 e^-2)
   float *out;
   unsigned char *argmax_out;  // pooled max mode: arg-max voxel (x*4+y*2+z) per (cell, channel), or nullptr
+  // pooled modes: write the grid in the split-fp16 kernels' tensor format (conv3d.h ConvArgs::in_split) -- Cp a multiple of
+  // 8, [pose][octet][cell][h0..h7 | l0..l7] fp16 with h = RN_f16(v), l = RN_f16(v - h) -- so that the first convolution
+  // stages it by LDS-DMA.  overflow: the scorer's sticky range flag (a density beyond 65504, or a NaN).
+  int split;
+  unsigned *overflow;
 };
 
 struct VoxBackArgs {

@@ -36,6 +36,8 @@
 
 namespace mig {
 
+constexpr int kVoxSplitWin = 8;  // channels per staged window of the split-format output: one octet (the format is octet-major)
+
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -242,8 +244,24 @@ __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, flo
   }
 }
 
-template <int MODE>  // 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last
+// one pooled value in the split-fp16 tensor format: h | l << 16, h = RN_f16(x), l = RN_f16(x - h) (x - h is exact in fp32;
+// v_fma_mix_f32 reads h as fp16).  Densities are sums of at most a few hundred terms <= 1: no clamp, but the caller flags
+// anything beyond the fp16 range.
+typedef _Float16 vox_f16x2 __attribute__((ext_vector_type(2)));
+typedef float vox_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vox_split1(float x) {
+  const vox_f32x2 a = {x, 0.f};
+  const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(a, vox_f16x2));
+  float r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+  const vox_f32x2 b = {x, r};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(b, vox_f16x2));
+}
+
+// MODE 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last.  SPLIT (pooled modes): VoxArgs::split.
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
+  static_assert(!SPLIT || MODE != 0, "the split format is a pooled, channels-last format");
   const int lane = threadIdx.x;
   const int ntile = v.tiles_per_axis;
   // 1-D grid of B * tiles workgroups, re-numbered so that an XCD (private L2) sees whole poses: the 216 tile
@@ -264,7 +282,8 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   // whole [64][Cp] tile was 9 KB: 14 single-wave workgroups per CU.  The kernel is latency-bound -- its time is inversely
   // proportional to the waves in flight, measured by padding the LDS request -- and 5 KB lets the 68-VGPR limit of 7
   // waves per SIMD decide.)
-  constexpr int kWin = 12;
+  // (split format: a window is whole octets -- one: 4 KB of LDS with the transpose buffer, like the fp32 windows' 5 KB)
+  constexpr int kWin = SPLIT ? kVoxSplitWin : 12;
   extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [64][kWin] (+ transpose buffer, arg-max bytes)
   const int Cp = v.Cp;
   const int nwin = (Cp + kWin - 1) / kWin;
@@ -286,7 +305,8 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       const int i = lane + 64 * k;
       const int cell = i / (kWin / 4), part = i - cell * (kWin / 4);  // cell = cx * 16 + cy * 4 + cz, like the owner lane
       const int rx = tx * 4 + (cell >> 4), ry = ty * 4 + ((cell >> 2) & 3), rz = tz * 4 + (cell & 3);
-      eo[k] = (rx < S && ry < S && rz < S) ? ((unsigned)(((rx * S + ry) * S + rz) * Cp + 4 * part) | (unsigned)part) : 0xffffffffu;
+      // (split format: [octet][cell][8 words], a window = one octet: the cell's stride is 8 words, the window's S^3 * 8)
+      eo[k] = (rx < S && ry < S && rz < S) ? ((unsigned)(((rx * S + ry) * S + rz) * (SPLIT ? kWin : Cp) + 4 * part) | (unsigned)part) : 0xffffffffu;
     }
   }
   auto clear_window = [&]() {
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     for (int k = 0; k < kWin / 4; k++) {
       const int part = (int)(eo[k] & 3u);
       if (eo[k] != 0xffffffffu && c0 + 4 * part < Cp) {
-        const unsigned o = (eo[k] & ~3u) + (unsigned)c0;
+        const unsigned o = (eo[k] & ~3u) + (SPLIT ? (unsigned)(cur_w * S * S * S * kWin) : (unsigned)c0);
         // (cell * kWin + 4 * part == 4 * i: the staged tile is read back in item order)
         *reinterpret_cast<float4 *>(out_pose + o) = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
         if (MODE == 1 && v.argmax_out)
@@ -352,6 +372,20 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     __builtin_amdgcn_wave_barrier();
     clear_window();
     cur_w++;
+  };
+  // channel cw of the window under construction, this lane's cell: an fp32 word, or (SPLIT) the h and l halves at their
+  // places in the cell's [octet][h8 | l8] row
+  bool ovf = false;
+  auto stage_put = [&](int cw, float val) {
+    if constexpr (SPLIT) {
+      ovf |= !(val <= 65504.f);
+      const unsigned hl = vox_split1(val);
+      unsigned short *row = reinterpret_cast<unsigned short *>(s_stage) + lane * (2 * kWin) + (cw >> 3) * 16 + (cw & 7);
+      row[0] = (unsigned short)(hl & 0xffffu);
+      row[8] = (unsigned short)(hl >> 16);
+    } else {
+      s_stage[lane * kWin + cw] = val;
+    }
   };
   auto flush = [&](int c) {
     if (c < 0) return;
@@ -399,14 +433,14 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
         asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m1), "v"(m2));
       }
       while (cur_w < c / kWin) emit_window();
-      s_stage[lane * kWin + (c - cur_w * kWin)] = m;
-      if (v.argmax_out) s_arg[lane * kWin + (c - cur_w * kWin)] = (unsigned char)am;
+      stage_put(c - cur_w * kWin, m);
+      if (!SPLIT && v.argmax_out) s_arg[lane * kWin + (c - cur_w * kWin)] = (unsigned char)am;
     } else {
       float s = cv[0];
 #pragma unroll
       for (int i = 1; i < 8; i++) s = s + cv[i];  // (kd,kh,kw) order, then /8 like avg_pool3d
       while (cur_w < c / kWin) emit_window();
-      s_stage[lane * kWin + (c - cur_w * kWin)] = s * 0.125f;
+      stage_put(c - cur_w * kWin, s * 0.125f);
     }
   };
 
@@ -473,6 +507,8 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
 
   if (MODE != 0)
     while (cur_w < nwin) emit_window();  // the last window, and windows no atom of this tile belongs to (zeros)
+  if constexpr (SPLIT)
+    if (v.overflow && __ballot(ovf) != 0ull && lane == 0) atomicOr(v.overflow, 1u);
 }
 
 
@@ -589,7 +625,11 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   } else {
     size_t lds = (size_t)64 * 12 * sizeof(float) + 512 * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
     if (getenv("MI_VOX_LDS_PAD")) lds += (size_t)atoi(getenv("MI_VOX_LDS_PAD")) * 1024;  // occupancy experiment
-    if (mode == 1)
+    if (v.split) {
+      lds = (size_t)64 * kVoxSplitWin * sizeof(float) + 512 * sizeof(float);
+      if (mode == 1) hipLaunchKernelGGL((voxelize_tiles<1, true>), grid, block, lds, s, v);
+      else hipLaunchKernelGGL((voxelize_tiles<2, true>), grid, block, lds, s, v);
+    } else if (mode == 1)
       hipLaunchKernelGGL(voxelize_tiles<1>, grid, block, lds, s, v);
     else
       hipLaunchKernelGGL(voxelize_tiles<2>, grid, block, lds, s, v);

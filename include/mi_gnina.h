@@ -29,7 +29,9 @@ enum {
   MI_ERR_INVALID = 1,    /* bad argument (reference: internal_error / VINA_CHECK, common.h:280-288) */
   MI_ERR_MODEL = 2,      /* unreadable / unsupported model (reference: usage_error, torch_model.cpp:115-117) */
   MI_ERR_DEVICE = 3,     /* HIP runtime failure */
-  MI_ERR_STATE = 4       /* call order violated (e.g. score before set_receptor) */
+  MI_ERR_STATE = 4,      /* call order violated (e.g. score before set_receptor) */
+  MI_ERR_RANGE = 5       /* mi_scorer_synchronize: a device-output call met an activation outside the fp16 range of the
+                            split-fp16 kernels (see MI_PRECISION_FP32); repeat it under MI_PRECISION_FP32_MFMA */
 };
 
 typedef struct mi_model mi_model;   /* one network: weights + metadata, device resident, refcounted */
@@ -118,9 +120,21 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * stay fp32.  Its deviation from the fp32 path is a measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.
  * Gradient calls (MI_PRECISION_FP32 / _FP32_MFMA; never bf16): the forward pass takes the same kernels as a scoring
  * call of the same precision -- a pose scores the same bits with and without its gradient -- and the transposed
- * convolutions of the backward pass run on fp32 MFMA. */
+ * convolutions of the backward pass run on fp32 MFMA.
+ * Range of the split-fp16 kernels: the high half of an activation is an fp16 number, so a model (or an input) that
+ * produces |activation| > 65504 cannot run on them -- the reference runs any --cnn_model in fp32
+ * (torch_model.cpp:49-118,185).  Every split-fp16 kernel and the voxelizer feeding one raise a per-scorer flag when a
+ * value they produce or consume leaves that range (NaN included); a call that ends with the flag raised is REPEATED on
+ * the fp32-MFMA kernels before it returns (scoring, gradient, CNN-in-the-loop calls alike; mi_scorer_h2_fallbacks
+ * counts them).  Device-output calls (MI_OUT_ON_DEVICE) return before their kernels ran: mi_scorer_synchronize then
+ * returns MI_ERR_RANGE and the caller repeats them under MI_PRECISION_FP32_MFMA (mi_pool_score_batch does).
+ * Small values: an activation below 2^-14 has a subnormal high half, below 2^-24 it is taken as zero -- an absolute
+ * error of at most 2^-25 per activation, far below the parity bar for weights of any sane magnitude
+ * (tests/test_gpu_h2_range.py drives both ends). */
 enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 };
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
+/* calls of this scorer that were repeated on the fp32-MFMA kernels because of the range flag (diagnostics, tests) */
+int mi_scorer_h2_fallbacks(const mi_scorer *);
 /* Diagnostic, host only (no device needed): the operand split of the split-fp16 kernels as the model loader applies it
  * to the weights -- hi[i] = RN_fp16(x[i] * scale), lo[i] = RN_fp16(x[i] * scale - hi[i]) as IEEE binary16 bit patterns
  * (round to nearest even, subnormals kept).  scale = 0 picks the per-layer power of two the loader would: the one that
