@@ -24,6 +24,12 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef MI_H2_OCC2
+#define MI_H2_OCC2 4  // conv3d_h2_kernel, split-format input: waves per SIMD the register allocation aims at, TM <= 2 ...
+#endif
+#ifndef MI_H2_OCC3
+#define MI_H2_OCC3 3  // ... and TM = 3
+#endif
 #ifndef MI_H2_EXPERIMENT
 #define MI_H2_EXPERIMENT 0  // tools/h2_experiments.sh: 1 = no K loop, 2 = no staging loads, 3 = neither (timing only, wrong results)
 #endif
@@ -464,11 +470,19 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
 // (tcx == tcy == 2); the epilogue follows, the results do not depend on it.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void *LdsPtr;
+// staging extents of conv3d_h2_kernel: at most kH2NS wave-DMAs per thread and chunk (2 PL <= kH2NS * 256 slots), at most
+// kH2VPT halo voxels per thread on the fp32 path (HV <= kH2VPT * 256).  (Plain constants: with extents that depend on a
+// template parameter hipcc 7.2 silently drops the host stubs of the INSPLIT instantiations.)
+constexpr int kH2NS = 8, kH2VPT = 4;
 
-template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT>
-__global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3 : 1) : (TM <= 2 ? 3 : TM <= 3 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
+template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT, bool WLDS = false, int NP = 1>
+__global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H2_OCC2 : TM <= 3 ? MI_H2_OCC3 : TM <= 4 ? 2 : 1) : (TM <= 2 ? 3 : TM <= 4 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
   constexpr int NW = WM * WN, NTHREADS = 64 * NW;
   static_assert(NW == 4, "staging is laid out for four waves");
+  static_assert(!WLDS || WN == 1, "weights in LDS: the four waves of a workgroup share one set of 32 output channels");
+  // NP poses per workgroup (WLDS + INSPLIT): the same tile of NP consecutive poses, one after the other, on ONE copy of the
+  // chunk's weights in LDS -- the weights are most of what a workgroup pulls out of L2 (143 KB against a 97 KB halo tile)
+  static_assert(NP == 1 || (WLDS && INSPLIT && TM <= 2), "several poses per workgroup: weights-in-LDS variant, split-format input");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -478,8 +492,9 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
 
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
   const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int b = wg / tiles_per_pose;
-  int t = wg - b * tiles_per_pose;
+  const int b = (wg / tiles_per_pose) * NP;                      // first pose of this workgroup
+  const int npose = NP == 1 ? 1 : min(NP, p.nposes - b);         // (the last workgroups of an odd batch have one)
+  int t = wg - (wg / tiles_per_pose) * tiles_per_pose;
   const int tz = t % p.ntz;
   t /= p.ntz;
   const int ty = t % p.nty, tx = t / p.nty;
@@ -491,11 +506,14 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
   const int PL = (HX * SX + 31) & ~31;                        // slots per plane; a buffer = 2 PL slots = whole wave-DMAs
   const int PLB = PL * 16, BUFB = 2 * PLB;
 
+  constexpr int P = 14;          // steps per chunk: 27 taps in pairs (the 28th tap's weight rows are zero)
+  constexpr int NBUF = WLDS ? 1 : 2;
+  constexpr int WBYTES = WLDS ? P * 2048 : 0;  // WLDS: the chunk's B operands, [step][h | l][half-wave][32 couts][8 fp16]
   extern __shared__ __attribute__((aligned(16))) char smem_h2c[];
-  char *const s_buf = smem_h2c;                                   // [2 buffers][h plane | l plane]
-  int *const s_qoff = reinterpret_cast<int *>(smem_h2c + 2 * BUFB);  // [32] byte offset of tap q inside a plane (q >= 27: tap 26)
+  char *const s_buf = smem_h2c;                                   // [NBUF buffers][h plane | l plane]
+  char *const s_w = smem_h2c + NBUF * BUFB;                       // [WBYTES]
+  int *const s_qoff = reinterpret_cast<int *>(s_w + WBYTES);      // [32] byte offset of tap q inside a plane (q >= 27: tap 26)
   int *const s_live = s_qoff + 32;                                // [nchunks][4]: wave w found a non-zero in chunk c's tile (SKIP)
-
   if (tid < 32) {
     const int tap = tid < 27 ? tid : 26;
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
   const int NC = p.tcx * p.tcy * p.tcz;
   const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
   const int cell_in_mt = ((row >> 2) & 1) + 2 * ((row >> 4) & 1);
-  auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) -> bool {
+  auto cell_of = [&](int mt, int cim, int &cx, int &cy, int &cz) __attribute__((always_inline)) -> bool {
     if (MT == 1) {
       cz = mt % p.tcz;
       cy = (mt / p.tcz) % p.tcy;
@@ -528,11 +546,13 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
     baseA[m] = ((2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz)) * 16;  // bytes inside a plane
   }
 
-  h2_f32x16 acc[TM];
+  h2_f32x16 acc[NP][TM];
 #pragma unroll
-  for (int m = 0; m < TM; m++)
+  for (int tp = 0; tp < NP; tp++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    for (int m = 0; m < TM; m++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[tp][m][r] = 0.f;
   unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; read in profile mode only)
   float amax = 0.f;     // !INSPLIT: running maximum of |staged value| (range check, see split4)
   bool ovf_out = false; // out_split: a value this lane wrote left the fp16 range
@@ -542,12 +562,48 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
   const size_t pose_floats = (size_t)S * S * S * p.in_cs;
   const float *in_b = p.in + (size_t)b * pose_floats;
 
+  // ---- which chunks (octets) have a non-zero in this workgroup's halo tile?  With the voxelizer's occupancy bytes
+  // (ConvArgs::in_occ: one byte per pose, 4 x 4 x 4-cell block of the pooled grid and octet) that is known before anything
+  // is staged, and an all-zero chunk -- the ligand's channels in every tile away from the ligand -- costs no DMA, no
+  // barrier, nothing.  Without them the staging finds out (s_live, one flag per chunk and wave). ----
+  unsigned todo = p.nchunks >= 32 ? 0xffffffffu : ((1u << p.nchunks) - 1u);
+  bool occ_known = false;
+  if constexpr (SKIP && INSPLIT) {
+    if (NP == 1 && p.in_occ && p.nchunks <= 8) {
+      // blocks the halo tile touches, per axis: voxels [x0, x0 + HX) -> blocks (x0 >> 2) .. ((x0 + HX - 1) >> 2)
+      const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
+      const int nbx = ((x0 + HX - 1) >> 2) - bx0 + 1, nby = ((y0 + HY - 1) >> 2) - by0 + 1, nbz = ((z0 + HZ - 1) >> 2) - bz0 + 1;
+      if (nbx * nby * nbz <= 64) {
+        uint2 o8 = make_uint2(0u, 0u);
+        if (tid < nbx * nby * nbz) {
+          const int bz = bz0 + tid % nbz, by = by0 + (tid / nbz) % nby, bx = bx0 + tid / (nbz * nby);
+          const int nt = p.occ_nt;
+          if ((unsigned)bx < (unsigned)nt && (unsigned)by < (unsigned)nt && (unsigned)bz < (unsigned)nt)
+            o8 = *reinterpret_cast<const uint2 *>(p.in_occ + (((size_t)b * nt + bx) * nt + by) * nt * 8 + (size_t)bz * 8);
+        }
+        if (wave == 0) {
+          unsigned m = 0u;
+#pragma unroll
+          for (int o = 0; o < 8; o++) {
+            const unsigned byte = ((o < 4 ? o8.x : o8.y) >> (8 * (o & 3))) & 0xffu;
+            if (__builtin_amdgcn_ballot_w64(byte != 0u) != 0ull) m |= 1u << o;
+          }
+          if (lane == 0) s_live[0] = (int)m;
+        }
+        __syncthreads();
+        todo &= (unsigned)__builtin_amdgcn_readfirstlane(s_live[0]);
+        occ_known = true;
+        __syncthreads();  // (s_live is reused below when a later launch path writes it: keep the read ahead of any write)
+      }
+    }
+  }
+
   // ---- staging set-up ----
   // INSPLIT: NS wave-DMAs per thread and chunk; slot j = tid + i * NTHREADS of a buffer is half j / PL of plane slot j % PL
-  constexpr int NS = 5;  // (plans keep 2 PL <= NS * NTHREADS)
+  constexpr int NS = kH2NS;  // (plans keep 2 PL <= NS * NTHREADS)
   unsigned voff[NS];
   // !INSPLIT: a thread owns halo voxels tid, tid + NTHREADS, ... (plans keep HV <= VPT * NTHREADS)
-  constexpr int VPT = 3;
+  constexpr int VPT = kH2VPT;
   int st_slot[VPT], st_off[VPT];
   float4 pre[VPT][2];
   __amdgpu_buffer_rsrc_t rsrc;
@@ -582,26 +638,26 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
         st_off[v] = ((x * S + y) * S + z) * p.in_cs;
       } else {  // the zero padding is laid down once, in both buffers; staging then touches the voxels inside the grid only
 #pragma unroll
-        for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(s_buf + (k >> 1) * BUFB + (k & 1) * PLB + st_slot[v]) = make_uint4(0u, 0u, 0u, 0u);
+        for (int k = 0; k < 2 * NBUF; k++) *reinterpret_cast<uint4 *>(s_buf + (k >> 1) * BUFB + (k & 1) * PLB + st_slot[v]) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
   }
   const int octet_bytes = S * S * S * 32;  // split format: one octet's [voxel][h8 | l8] array
-  auto issue_dma = [&](int chunk) {
+  auto issue_dma = [&](int chunk, int bsel, int tp = 0) {
     if constexpr (INSPLIT) {
-      if (p.h2_dbg & 4) return;
-      char *dst = s_buf + (chunk & 1) * BUFB + wave * 1024;
+      __amdgpu_buffer_rsrc_t rs = rsrc;
+      if (NP > 1 && tp > 0) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b + (size_t)tp * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
+      char *dst = s_buf + bsel * BUFB + wave * 1024;
 #pragma unroll
       for (int i = 0; i < NS; i++)
-        if ((i * NW + wave) * 64 < 2 * PL)  // (wave-uniform; 2 PL is a multiple of 64)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(dst + i * NW * 1024), 16, voff[i], chunk * octet_bytes, 0, 0);
+        if ((i * NW + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LdsPtr)(dst + i * NW * 1024), 16, voff[i], chunk * octet_bytes, 0, 0);
     }
   };
   auto issue_ld = [&](int chunk) {
     if constexpr (!INSPLIT) {
-      if (p.h2_dbg & 4) return;
       const float *src_c = in_b + chunk * 8;
-      const int nq = min(2, p.cin4 - chunk * 2);  // channel quads of this octet that exist in the input
+      const int nq = (p.h2_dbg & 4) ? 0 : min(2, p.cin4 - chunk * 2);  // channel quads of this octet that exist in the input
 #pragma unroll
       for (int v = 0; v < VPT; v++)
 #pragma unroll
@@ -609,11 +665,11 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
           if (st_off[v] >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + st_off[v] + q * 4);
     }
   };
-  auto commit = [&](int chunk) {
+  auto commit = [&](int chunk, int bsel) {
     if constexpr (!INSPLIT) {
       const int c_base = chunk * 8;
       const int nq = min(2, p.cin4 - chunk * 2);
-      char *dstb = s_buf + (chunk & 1) * BUFB;
+      char *dstb = s_buf + bsel * BUFB;
       bool lane_nonzero = false;
 #pragma unroll
       for (int v = 0; v < VPT; v++) {
@@ -648,9 +704,10 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
   };
   // INSPLIT + SKIP: is there a non-zero in the slots of chunk `chunk` this wave's DMAs wrote?  (h = 0 implies l = 0: the
   // h plane decides.  A wave may read what its OWN DMAs wrote once its vmcnt covers them, no barrier needed.)
-  auto probe_dma = [&](int chunk) {
+  auto probe_dma = [&](int chunk, int bsel) {
     if constexpr (INSPLIT && SKIP) {
-      const char *src = s_buf + (chunk & 1) * BUFB;
+      if (occ_known) return;
+      const char *src = s_buf + bsel * BUFB;
       unsigned any = 0u;
 #pragma unroll
       for (int i = 0; i < (NS + 1) / 2; i++) {
@@ -665,27 +722,37 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
     }
   };
 
-  const size_t wstride = (size_t)p.coutp * 16;  // fp16 elements per (step, half-wave) row block of the packed weights
-  constexpr int P = 14;                         // steps per chunk: 27 taps in pairs (the 28th tap's weight rows are zero)
-  const unsigned wlane = ((unsigned)(n_base + row) * 16u + (unsigned)kh * (unsigned)wstride) * 2u;
-  const unsigned wstep = 2u * (unsigned)wstride * 2u;  // bytes per step
+  // packed weights [chunk][step][h | l][half-wave][cout][8 fp16]: a lane's h row and, 2 coutp rows on, its l row
+  const unsigned wlane = ((unsigned)kh * (unsigned)p.coutp + (unsigned)(n_base + row)) * 16u;
+  const unsigned wl_off = 2u * (unsigned)p.coutp * 16u;
+  const unsigned wstep = 2u * wl_off;  // bytes per step
   const int *lp = s_qoff + kh;
-
-  if constexpr (INSPLIT) issue_dma(0);
-  else issue_ld(0);
-  for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    // ---- chunk `chunk` becomes visible in buffer chunk & 1; behind the barrier every wave is also through the K loop of
-    // chunk - 1, i.e. through with the other buffer, which the staging of chunk + 1 may now overwrite ----
-    if constexpr (INSPLIT) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      probe_dma(chunk);
-    } else {
-      commit(chunk);
-      if (chunk + 1 < p.nchunks) issue_ld(chunk + 1);
+  uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
+  if (p.h2_dbg & 24) {  // (timing experiments: operands that are not loaded)
+    wh0 = wl0 = wh1 = wl1 = make_uint4(0x3c003c00u, 0u, 0x3c003c00u, 0u);
+#pragma unroll
+    for (int m = 0; m < TM; m++) ah0[m] = al0[m] = ah1[m] = al1[m] = make_uint4(0x3c003c00u, 1u, 0u, 0u);
+  }
+  // (the pose index is a compile-time constant everywhere: a pointer into acc[][] sends the accumulators to scratch)
+  auto mfma_pair = [&](auto tpc, const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) __attribute__((always_inline)) {
+    constexpr int tp = decltype(tpc)::value;
+#pragma unroll
+    for (int m = 0; m < TM; m++) {
+      if constexpr (SKIP) {
+        // all 32 voxels x 16 k of this step zero (h = 0 implies l = 0): nothing to add.  One v_or3 + v_or + v_cmp into
+        // an SGPR pair and a scalar branch against three MFMAs
+        const unsigned any = ah[m].x | ah[m].y | ah[m].z | ah[m].w;
+        unsigned long long lv;
+        asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv) : "v"(any));
+        if (lv == 0ull) continue;
+        n_exec++;
+      }
+      acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[tp][m], 0, 0, 0);
+      acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[tp][m], 0, 0, 0);
+      acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[tp][m], 0, 0, 0);
     }
-    __syncthreads();
-    const char *tile = s_buf + (chunk & 1) * BUFB;
-    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * P * 2 * wstride * 2;
+  };
+  auto chunk_live = [&](int chunk) -> bool {
     bool live = true;
     if constexpr (SKIP) {
       const int4 lv = *reinterpret_cast<const int4 *>(s_live + chunk * 4);
@@ -693,180 +760,272 @@ __global__ __launch_bounds__(64 * WM * WN, (INSPLIT ? (TM <= 2 ? 4 : TM <= 3 ? 3
       if (p.h2_dbg & 1) live = true;
     }
     if (p.h2_dbg & 2) live = false;
+    return live;
+  };
 
-    // ---- K loop over tap pairs, ping-pong operand sets.  The weights of the first step are requested BEFORE the DMAs of
-    // the next chunk (memory operations return in order: a weight load queued behind the DMAs would wait for them) ----
-    int qo_next = lp[0];
-    uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
-    auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
-      const int qo = qo_next;
+  if constexpr (WLDS) {
+    // ---- B operands through LDS.  Read straight from L1 / L2, the weights are the K loop's bottleneck (measured: 0.5 of
+    // the first conv's 1.8 ms; more of them in flight does not help -- it is the vector memory path's throughput, every
+    // wave of a workgroup fetching the same 2 KB per step).  Here the four waves share them: a chunk's 28 KB go to LDS
+    // by DMA, once per workgroup, next to a SINGLE halo-tile buffer (48 KB in all: three workgroups per CU, whose DMA and
+    // K-loop phases overlap), and the K loop reads nothing but LDS. ----
+    __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, (int)(p.nchunks * P * wstep), 0x00020000);
+    auto issue_w = [&](int chunk) {
+      // piece q = (step, h | l) = 1 KB = one wave-DMA: lane (kh, n) fetches its 16 bytes of row kh * coutp + n_base + n
 #pragma unroll
-      for (int m = 0; m < TM; m++) {
-        const char *a = tile + baseA[m] + qo;
-        ah[m] = *reinterpret_cast<const uint4 *>(a);
-        al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
-      }
-      const char *w = wbase + (wlane + (unsigned)pr * wstep);
-      wh = *reinterpret_cast<const uint4 *>(w);
-      wl = *reinterpret_cast<const uint4 *>(w + 16);
-      qo_next = lp[2 * pr + 2];  // (behind the last pair: a pad entry -- unused)
-    };
-    auto mfma_pair = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) {
-#pragma unroll
-      for (int m = 0; m < TM; m++) {
-        if constexpr (SKIP) {
-          // all 32 voxels x 16 k of this step zero (h = 0 implies l = 0): nothing to add.  One v_or3 + v_or + v_cmp into
-          // an SGPR pair and a scalar branch against three MFMAs
-          const unsigned any = ah[m].x | ah[m].y | ah[m].z | ah[m].w;
-          unsigned long long lv;
-          asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv) : "v"(any));
-          if (lv == 0ull) continue;
-          n_exec++;
-        }
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+      for (int i = 0; i < 2 * P / NW; i++) {
+        const int q = i * NW + wave;
+        if (!(p.h2_dbg & 8))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LdsPtr)(s_w + q * 1024), 16, wlane, chunk * (int)(P * wstep) + q * (int)wl_off, 0, 0);
       }
     };
-    if (live) {
-      load_pair(0, ah0, al0, wh0, wl0);
-      load_pair(1, ah1, al1, wh1, wl1);
-    }
-    // (a ds_read behind an LDS-DMA waits for it -- the compiler cannot tell the two buffers apart -- so the DMAs of the next
-    // chunk go out once the operands of the first two steps are on their way)
-    if (chunk + 1 < p.nchunks) issue_dma(chunk + 1);
-    if (!live) continue;
+    static_assert(2 * P % NW == 0, "weight pieces per wave");
+    int chunk = todo ? __builtin_ctz(todo) : -1;
+    if constexpr (!INSPLIT)
+      if (chunk >= 0) issue_ld(chunk);
+    bool first = true;
+    while (chunk >= 0) {
+      const unsigned rest = chunk >= 31 ? 0u : (todo & ~((2u << chunk) - 1u));
+      const int next = rest ? __builtin_ctz(rest) : -1;
+      auto pose_pass = [&](auto tpc) __attribute__((always_inline)) {
+        constexpr int tp = decltype(tpc)::value;
+        if (!first) __syncthreads();  // every wave is through the previous K loop: tile (and weights) may be overwritten
+        first = false;
+        if constexpr (INSPLIT) issue_dma(chunk, 0, tp);
+        else commit(chunk, 0);
+        if (tp == 0) issue_w(chunk);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if constexpr (INSPLIT) probe_dma(chunk, 0);
+        __syncthreads();
+        if constexpr (!INSPLIT)
+          if (next >= 0) issue_ld(next);  // (in flight during the K loop, which waits for nothing but LDS)
+        const bool live = occ_known ? !(p.h2_dbg & 2) : chunk_live(chunk);
+        if (live) {
+          const char *tile = s_buf;
+          const char *wl_ = s_w + lane * 16;
+          int qo_next = lp[0];
+          auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
+            const int qo = qo_next;
+#pragma unroll
+            for (int m = 0; m < TM; m++) {
+              const char *a = tile + baseA[m] + qo;
+              if (p.h2_dbg & 16) continue;
+              ah[m] = *reinterpret_cast<const uint4 *>(a);
+              al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
+            }
+            wh = *reinterpret_cast<const uint4 *>(wl_ + pr * 2048);
+            wl = *reinterpret_cast<const uint4 *>(wl_ + pr * 2048 + 1024);
+            qo_next = lp[2 * pr + 2];
+          };
+          load_pair(0, ah0, al0, wh0, wl0);
 #pragma unroll 1
-    for (int pr = 0; pr < P; pr += 2) {
-      mfma_pair(ah0, al0, wh0, wl0);
-      if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
-      mfma_pair(ah1, al1, wh1, wl1);
-      if (pr + 3 < P) load_pair(pr + 3, ah1, al1, wh1, wl1);
+          for (int pr = 0; pr < P; pr += 2) {
+            load_pair(pr + 1, ah1, al1, wh1, wl1);
+            mfma_pair(tpc, ah0, al0, wh0, wl0);
+            if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
+            mfma_pair(tpc, ah1, al1, wh1, wl1);
+          }
+        }
+      };
+      pose_pass(std::integral_constant<int, 0>{});
+      if constexpr (NP > 1)
+        if (npose > 1) pose_pass(std::integral_constant<int, 1>{});
+      chunk = next;
+    }
+  } else {
+    // the chunks to do, in order; chunk number it of them lands in buffer it & 1
+    int chunk = todo ? __builtin_ctz(todo) : -1;
+    if (chunk >= 0) {
+      if constexpr (INSPLIT) issue_dma(chunk, 0);
+      else issue_ld(chunk);
+    }
+    int it = 0;
+    while (chunk >= 0) {
+      const unsigned rest = chunk >= 31 ? 0u : (todo & ~((2u << chunk) - 1u));
+      const int next = rest ? __builtin_ctz(rest) : -1;
+      const int bsel = it & 1;
+      // ---- `chunk` becomes visible in buffer bsel; behind the barrier every wave is also through the previous K loop,
+      // i.e. through with the other buffer, which the staging of the next chunk may now overwrite ----
+      if constexpr (INSPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        probe_dma(chunk, bsel);
+      } else {
+        commit(chunk, bsel);
+        if (next >= 0) issue_ld(next);
+      }
+      __syncthreads();
+      const char *tile = s_buf + bsel * BUFB;
+      const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * P * wstep;
+      const bool live = occ_known ? !(p.h2_dbg & 2) : chunk_live(chunk);
+
+      // ---- K loop over tap pairs, ping-pong operand sets.  The operands of the first two steps are requested BEFORE the
+      // DMAs of the next chunk (memory operations return in order: a weight load queued behind the DMAs would wait for
+      // them; a ds_read behind an LDS-DMA waits for it too -- the compiler cannot tell the two buffers apart) ----
+      int qo_next = lp[0];
+      auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
+        const int qo = qo_next;
+#pragma unroll
+        for (int m = 0; m < TM; m++) {
+          const char *a = tile + baseA[m] + qo;
+          if (p.h2_dbg & 16) continue;
+          ah[m] = *reinterpret_cast<const uint4 *>(a);
+          al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
+        }
+        const char *w = wbase + (wlane + (unsigned)pr * wstep);
+        if (!(p.h2_dbg & 8)) {
+          wh = *reinterpret_cast<const uint4 *>(w);
+          wl = *reinterpret_cast<const uint4 *>(w + wl_off);
+        }
+        qo_next = lp[2 * pr + 2];  // (behind the last pair: a pad entry -- unused)
+      };
+      if (live) {
+        load_pair(0, ah0, al0, wh0, wl0);
+        load_pair(1, ah1, al1, wh1, wl1);
+      }
+      if (next >= 0) issue_dma(next, bsel ^ 1);
+      if (live) {
+#pragma unroll 1
+        for (int pr = 0; pr < P; pr += 2) {
+          mfma_pair(std::integral_constant<int, 0>{}, ah0, al0, wh0, wl0);
+          if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
+          mfma_pair(std::integral_constant<int, 0>{}, ah1, al1, wh1, wl1);
+          if (pr + 3 < P) load_pair(pr + 3, ah1, al1, wh1, wl1);
+        }
+      }
+      chunk = next;
+      it++;
     }
   }
 
   // ---- fused 1x1x1 conv behind this one (Default2018: conv3 -> ReLU -> conv1 -> ReLU -> pool; ConvArgs::post_w): the ReLU'd
   // tile is split and laid down in LDS as [voxel row][octet][h | l] -- what the stand-alone 1x1x1 kernel's staging would
   // build from the tensor in HBM, which therefore never exists -- and a second, short K loop runs over its channels.  Same
-  // operands, same MFMA order as the two separate kernels: same bits (the gradient program runs them separately).
-  float unscale = p.h2_unscale;
-  const float *bias_ptr = p.bias;
-  int relu_flag = p.relu;
-  if constexpr (TM <= 3) {
-    if (p.post_w) {
-      __syncthreads();  // every wave is through its last K loop: the buffers may be overwritten
-      const int CCm = 2 * p.coutp + 8;  // fp16 elements per voxel row of the mid tile (odd number of 16-byte slots)
-      _Float16 *s_mid = reinterpret_cast<_Float16 *>(smem_h2c);
-#pragma unroll
-      for (int m = 0; m < TM; m++) {
-        const int ch = n_base + row;
-        const float b1 = p.bias[ch];
-        _Float16 *dcol = s_mid + (ch >> 3) * 16 + (ch & 7);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int rowl = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          float tt = acc[m][r] * unscale + b1;
-          if (p.relu) tt = fmaxf(tt, 0.f);
-          asm("v_maximum3_f32 %0, %0, |%1|, |%1|" : "+v"(amax) : "v"(tt));
-          const float c = __builtin_amdgcn_fmed3f(tt, -65504.f, 65504.f);
-          const _Float16 hi = (_Float16)c;
-          dcol[rowl * CCm] = hi;
-          dcol[rowl * CCm + 8] = (_Float16)(c - (float)hi);
-          acc[m][r] = 0.f;
-        }
-      }
-      __syncthreads();
-      const int npairs = p.post_cc4 >> 1;  // octet pairs = steps of the second K loop
-      const char *w2 = reinterpret_cast<const char *>(p.post_w) + ((size_t)kh * p.coutp + n_base + row) * 32;
-      for (int pr = 0; pr < npairs; pr++) {
-        uint4 ah[TM], al[TM], wh, wl;
-#pragma unroll
-        for (int m = 0; m < TM; m++) {
-          const char *a = reinterpret_cast<const char *>(s_mid) + (((wm * TM + m) * 32 + row) * CCm + (2 * pr + kh) * 16) * 2;
-          ah[m] = *reinterpret_cast<const uint4 *>(a);
-          al[m] = *reinterpret_cast<const uint4 *>(a + 16);
-        }
-        const char *w = w2 + (size_t)pr * 2 * p.coutp * 32;
-        wh = *reinterpret_cast<const uint4 *>(w);
-        wl = *reinterpret_cast<const uint4 *>(w + 16);
-#pragma unroll
-        for (int m = 0; m < TM; m++) {
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
-        }
-      }
-      unscale = p.h2_post_unscale;
-      bias_ptr = p.post_bias;
-      relu_flag = p.post_relu;
-    }
-  }
-
+  // operands, same MFMA order as the two separate kernels: same bits (the gradient program runs them separately).  (Inside
+  // the per-pose loop below.)
   // profile mode: executed MFMA work in units of 4,096 FLOPs (the fp32 kernels count 32x32x2 instructions): an executed
   // (M-tile, step) is 3 instructions of 32,768 FLOPs
   if (SKIP && p.mfma_count && lane == 0)
     atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec * (3u * 8u));
 
-  // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last -- fp32, or split (out_split): the lanes of
-  // channels 2j and 2j + 1 trade halves (one DPP move), the even lane stores the two h, the odd lane the two l ----
   const int So = p.pool ? S / 2 : S;
-  const size_t out_pose = (size_t)b * So * So * So * p.out_cs + p.out_c0;
-  float *out_f = p.out + out_pose;
   const int ncx = S / 2;
   const int ch = n_base + row;
   // split format (out_c0 = 0, whole octets): [octet][voxel][h8 | l8]; dword of this lane's store inside a voxel's 32 bytes
   const int ch_sp = ((ch & 7) >> 1) + (row & 1) * 4;
   const size_t oct_sp = (size_t)(ch >> 3) * So * So * So;
-  auto store = [&](size_t vox, float v) {  // vox = voxel index inside the pose
-    if (p.out_split) {
-      ovf_out |= !(fabsf(v) <= 65504.f);
-      const unsigned mine = split1(v);
-      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-      // even lane: h(mine) | h(other) << 16; odd lane: l(other) | l(mine) << 16
-      const unsigned w = (row & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
-      if (ch < p.coutp) reinterpret_cast<unsigned *>(out_f)[(oct_sp + vox) * 8 + ch_sp] = w;
-    } else if (ch < p.cout) {
-      out_f[vox * p.out_cs + ch] = v;
-    }
-  };
-  const float bias = ch < p.coutp ? bias_ptr[ch] : 0.f;
+  auto finish_pose = [&](auto tpc) __attribute__((always_inline)) {  // the poses of this workgroup, one after the other
+    constexpr int tp = decltype(tpc)::value;
+    float unscale = p.h2_unscale;
+    bool post_done = false;
+    int relu_flag = p.relu;
+    if constexpr (TM <= 3) {
+      if (p.post_w) {
+        __syncthreads();  // every wave is through its last K loop (the previous pose's second pass): LDS may be overwritten
+        const int CCm = 2 * p.coutp + 8;  // fp16 elements per voxel row of the mid tile (odd number of 16-byte slots)
+        _Float16 *s_mid = reinterpret_cast<_Float16 *>(smem_h2c);
 #pragma unroll
-  for (int m = 0; m < TM; m++) {
+        for (int m = 0; m < TM; m++) {
+          const float b1 = p.bias[ch];
+          _Float16 *dcol = s_mid + (ch >> 3) * 16 + (ch & 7);
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      int cx, cy, cz;
-      if (!cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz)) continue;
-      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
-      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
-      float v[8];
+          for (int r = 0; r < 16; r++) {
+            const int rowl = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float tt = acc[tp][m][r] * unscale + b1;
+            if (p.relu) tt = fmaxf(tt, 0.f);
+            asm("v_maximum3_f32 %0, %0, |%1|, |%1|" : "+v"(amax) : "v"(tt));
+            const float c = __builtin_amdgcn_fmed3f(tt, -65504.f, 65504.f);
+            const _Float16 hi = (_Float16)c;
+            dcol[rowl * CCm] = hi;
+            dcol[rowl * CCm + 8] = (_Float16)(c - (float)hi);
+            acc[tp][m][r] = 0.f;
+          }
+        }
+        __syncthreads();
+        const int npairs = p.post_cc4 >> 1;  // octet pairs = steps of the second K loop
+        const char *w2 = reinterpret_cast<const char *>(p.post_w) + ((size_t)kh * p.coutp + n_base + row) * 32;
+        for (int pr = 0; pr < npairs; pr++) {
+          uint4 ah[TM], al[TM], wh, wl;
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const float tt = acc[m][half * 8 + r] * unscale + bias;
-        v[r] = relu_flag ? fmaxf(tt, 0.f) : tt;
+          for (int m = 0; m < TM; m++) {
+            const char *a = reinterpret_cast<const char *>(s_mid) + (((wm * TM + m) * 32 + row) * CCm + (2 * pr + kh) * 16) * 2;
+            ah[m] = *reinterpret_cast<const uint4 *>(a);
+            al[m] = *reinterpret_cast<const uint4 *>(a + 16);
+          }
+          const char *w = w2 + (size_t)pr * 2 * p.coutp * 32;
+          wh = *reinterpret_cast<const uint4 *>(w);
+          wl = *reinterpret_cast<const uint4 *>(w + 16);
+#pragma unroll
+          for (int m = 0; m < TM; m++) {
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[tp][m], 0, 0, 0);
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[tp][m], 0, 0, 0);
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[tp][m], 0, 0, 0);
+          }
+        }
+        unscale = p.h2_post_unscale;
+        post_done = true;
+        relu_flag = p.post_relu;
       }
-      if (p.pool == 1) {
-        float mx = v[0];
-        int am = 0;
+    }
+
+    // ---- epilogue: un-scale, bias, ReLU, optional 2x2x2 pool, store channels-last -- fp32, or split (out_split): the lanes
+    // of channels 2j and 2j + 1 trade halves (one DPP move), the even lane stores the two h, the odd lane the two l ----
+    const size_t out_pose = (size_t)(b + tp) * So * So * So * p.out_cs + p.out_c0;
+    float *out_f = p.out + out_pose;
+    auto store = [&](size_t vox, float v) __attribute__((always_inline)) {  // vox = voxel index inside the pose
+      if (p.out_split) {
+        ovf_out |= !(fabsf(v) <= 65504.f);
+        const unsigned mine = split1(v);
+        const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        // even lane: h(mine) | h(other) << 16; odd lane: l(other) | l(mine) << 16
+        const unsigned w = (row & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+        if (ch < p.coutp) reinterpret_cast<unsigned *>(out_f)[(oct_sp + vox) * 8 + ch_sp] = w;
+      } else if (ch < p.cout) {
+        out_f[vox * p.out_cs + ch] = v;
+      }
+    };
+    // (two loads and a select: a pointer chosen at run time would live in scratch)
+    const float bias = ch < p.coutp ? (post_done ? p.post_bias[ch] : p.bias[ch]) : 0.f;
 #pragma unroll
-        for (int r = 1; r < 8; r++)
-          if (v[r] > mx) mx = v[r], am = r;
-        const size_t vox = ((size_t)gcx * So + gcy) * So + gcz;
-        store(vox, mx);
-        if (p.argmax_out && ch < p.cout) p.argmax_out[out_pose + vox * p.out_cs + ch] = (unsigned char)am;
-      } else if (p.pool == 2) {
-        float sum = v[0];
+    for (int m = 0; m < TM; m++) {
 #pragma unroll
-        for (int r = 1; r < 8; r++) sum = sum + v[r];
-        store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
-      } else {
+      for (int half = 0; half < 2; half++) {
+        int cx, cy, cz;
+        if (!cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz)) continue;
+        const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+        if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+        float v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-          const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-          store(((size_t)vx * So + vy) * So + vz, v[r]);
+          const float tt = acc[tp][m][half * 8 + r] * unscale + bias;
+          v[r] = relu_flag ? fmaxf(tt, 0.f) : tt;
+        }
+        if (p.pool == 1) {
+          float mx = v[0];
+          int am = 0;
+#pragma unroll
+          for (int r = 1; r < 8; r++)
+            if (v[r] > mx) mx = v[r], am = r;
+          const size_t vox = ((size_t)gcx * So + gcy) * So + gcz;
+          store(vox, mx);
+          if (p.argmax_out && ch < p.cout) p.argmax_out[out_pose + vox * p.out_cs + ch] = (unsigned char)am;
+        } else if (p.pool == 2) {
+          float sum = v[0];
+#pragma unroll
+          for (int r = 1; r < 8; r++) sum = sum + v[r];
+          store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+            store(((size_t)vx * So + vy) * So + vz, v[r]);
+          }
         }
       }
     }
-  }
+  };
+  finish_pose(std::integral_constant<int, 0>{});
+  if constexpr (NP > 1)
+    if (npose > 1) finish_pose(std::integral_constant<int, 1>{});
   h2_report_overflow(p.h2_overflow, ovf_out || !(amax <= 65504.f));
 }
 
@@ -1091,7 +1250,9 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
   if (p.ksize == 3 && p.coutp != 16) {  // conv3d_h2_kernel: two buffers of two planes, tap offsets, live flags
     int sy, sx, pl;
     conv_h2_planar_geo(p, &sy, &sx, &pl);
-    return std::max((size_t)4 * pl * 16 + 32 * sizeof(int) + (size_t)p.nchunks * 4 * sizeof(int), mid_bytes);
+    // (h2_wlds: one buffer and the chunk's weights, 14 steps of 2 KB; else two buffers)
+    const size_t tiles = p.h2_wlds ? (size_t)2 * pl * 16 + 14 * 2048 : (size_t)4 * pl * 16;
+    return std::max(tiles + 32 * sizeof(int) + (size_t)p.nchunks * 4 * sizeof(int), mid_bytes);
   }
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
@@ -1112,13 +1273,14 @@ template <int WM, int WN, int TM, int TN> static void launch_h2_k1(const ConvArg
 
 // 3x3x3 layers (conv3d_h2_kernel).  MT = the M-tile geometries compiled for this shape besides raster order (ConvArgs::mt_x);
 // SKIP_OK: the zero-skipping variant exists (the throughput tile of a first conv: the pooled voxel grid)
-template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2_k3(const ConvArgs &p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2_k3(ConvArgs p, int B, hipStream_t s) {
+  p.nposes = B;
   const int ngroups = (p.coutp / 32 + WN - 1) / WN;
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
   const size_t lds = conv_h2_lds_bytes(p);
   int sy, sx, pl;
   conv_h2_planar_geo(p, &sy, &sx, &pl);
-  if (2 * pl > 5 * 64 * WM * WN || (2 * p.tcx + 2) * (2 * p.tcy + 2) * (2 * p.tcz + 2) > 3 * 64 * WM * WN)
+  if (2 * pl > kH2NS * 64 * WM * WN || (2 * p.tcx + 2) * (2 * p.tcy + 2) * (2 * p.tcz + 2) > kH2VPT * 64 * WM * WN)
     throw Error(2, "launch_conv_h2: halo tile larger than the kernel's staging covers");
   if (p.in_split && (p.in_cs % 8 || p.bn_scale)) throw Error(2, "launch_conv_h2: split-format input needs whole octets and no BatchNorm");
   if (p.out_split && (p.out_cs % 8 || p.out_c0 || p.coutp != p.cout || p.argmax_out))
@@ -1130,6 +1292,21 @@ template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2
   auto by_input = [&](auto mt, auto skip) {
     constexpr int MT = decltype(mt)::value;
     constexpr bool SK = decltype(skip)::value;
+    if constexpr (WN == 1 && TM <= 2) {  // (weights through LDS: the shapes whose four waves share their output channels)
+      if (p.h2_wlds) {
+        if constexpr (TM == 2) {  // (the throughput shape) two poses per workgroup on one copy of the weights
+          if (p.in_split && p.h2_wlds >= 2 && B >= 2) {
+            grid.x = (unsigned)((B + 1) / 2 * p.ntx * p.nty * p.ntz);
+            go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true, true, 2>);
+            return;
+          }
+        }
+        if (p.in_split) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true, true>);
+        else go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false, true>);
+        return;
+      }
+    }
+    if (p.h2_wlds) throw Error(2, "launch_conv_h2: weights-in-LDS variant not compiled for this tile shape");
     if (p.in_split) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true>);
     else go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false>);
   };
@@ -1153,6 +1330,7 @@ template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t
 bool conv_h2_has_cfg(int cfg) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1:
+    case CONV_CFG_4x1_4x1:
     case CONV_CFG_2x2_3x1:
     case CONV_CFG_1x4_7x1:
     case CONV_CFG_4x1_1x3:
@@ -1168,7 +1346,8 @@ bool conv_h2_has_cfg(int cfg) {
 
 int conv_h2_mt_mask(int cfg) {
   switch (cfg) {
-    case CONV_CFG_4x1_2x1: return 1 | 2;
+    case CONV_CFG_4x1_2x1:
+    case CONV_CFG_4x1_4x1: return 1 | 2;
     case CONV_CFG_2x2_3x1: return 1 | 4;
     case CONV_CFG_4x1_1x1: return 1 | 4;
     default: return 1;
@@ -1181,6 +1360,10 @@ void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_2x1:
       if (k1) launch_h2_k1<4, 1, 2, 1>(p, B, s);
       else launch_h2_k3<4, 1, 2, 1, true>(p, B, s);
+      break;
+    case CONV_CFG_4x1_4x1:
+      if (k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 3x3x3 convolutions only");
+      launch_h2_k3<4, 1, 4, 1, true>(p, B, s);
       break;
     case CONV_CFG_2x2_3x1:
       if (k1) launch_h2_k1<2, 2, 3, 1>(p, B, s);

@@ -62,6 +62,7 @@ struct ConvPlan {
   // geometry and LDS pad slots of the throughput tile live in h2 (mt_x, h2_pad_*), those of the latency tile here
   bool h2_planar = false;
   int h2_lat_mt = 0, h2_lat_pad[2] = {0, 0};
+  int h2_cfg = -1;  // >= 0: the throughput launch takes this kernel shape and h2's own tile (tc*, nt*) instead of the fp32 plan's
 };
 
 // Tile geometry of a launch of `nb` poses: the throughput plan, or the latency variant when the throughput
@@ -400,6 +401,7 @@ static float h2_weight_scale(const float *w, size_t n) {
 // largest number of its lanes that hit one slot modulo 16 at different addresses).  All lanes of a half-wave add the same
 // tap offset, so the model only needs the lanes' base slots.  Smallest mean cycles, then smallest tile.
 static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt_out, int &pad_y, int &pad_x, double *cycles_out = nullptr) {
+  const long max_slots = 8 * 256;  // the kernel's staging: at most eight wave-DMAs per thread and chunk (conv3d_h2.hip kH2NS)
   static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                     {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
   const int tcx = tc[0], tcy = tc[1], tcz = tc[2], NC = tcx * tcy * tcz;
@@ -417,7 +419,7 @@ static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt
       for (int px = 0; px < 16; px++) {
         const int SY = HZ + py, SX = HY * SY + px;
         const long size = (long)((HX * SX + 31) & ~31);
-        if (2 * size > 5 * 256) continue;  // (the kernel's staging: five wave-DMAs per thread and chunk)
+        if (2 * size > max_slots) continue;
         double tot = 0;
         for (int mtile = 0; mtile < n_mt; mtile++) {
           int base[32];
@@ -484,14 +486,26 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
   {
     int wm, wn, tm, tn;
     conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
-    if (HV > (size_t)vpt * 64 * wm * wn) return;  // (HV covers the latency tile too)
+    if (HV > (size_t)(planar ? 4 : vpt) * 64 * wm * wn) return;  // (HV covers the latency tile too; conv3d_h2_kernel checks its own limits at launch)
     if (a.coutp != 16 && o.ksize != 1 && tn >= 3) return;  // tile shapes compiled for the 1x1x1 bottlenecks only
     if (a.coutp != 16 && o.ksize == 1 && a.mt_x) return;
     if (planar) {
       if (wm * wn != 4) return;
+      // the pooled-grid-sized layers (8 M-tile workgroups of 4 x 4 x 2 cells): 4 x 4 x 4 cells with FOUR M-tiles per wave
+      // instead -- a wave's B operands (weights, from L1 / L2: the K loop's bottleneck, measured) then feed 128 voxels, and
+      // the halo shrinks from 2.34x to 1.95x.  Not with a fused 1x1x1 conv behind it (its mid tile is sized for 3 M-tiles).
+      int cfg_here = cp.cfg;
+      const int cells = a.S / 2;
+      if (cp.cfg == CONV_CFG_4x1_2x1 && cells % 4 == 0 && a.tcx == 4 && a.tcy == 4 && a.tcz == 2 && getenv("MI_GNINA_H2_TM4")) {
+        cp.h2_cfg = cfg_here = CONV_CFG_4x1_4x1;
+        a.tcz = 4;
+        a.ntz = cdiv(cells, 4);
+        tm = 4;
+        HV = std::max(HV, (size_t)10 * 10 * 10);
+      }
       const int tc[3] = {a.tcx, a.tcy, a.tcz};
       int mt, py, px;
-      h2_choose_layout(tc, wm * tm, conv_h2_mt_mask(cp.cfg), mt, py, px);
+      h2_choose_layout(tc, wm * tm, conv_h2_mt_mask(cfg_here), mt, py, px);
       a.mt_x = mt, a.h2_pad_y = py, a.h2_pad_x = px;
       if (cp.has_lat) {
         int lwm, lwn, ltm, ltn;
@@ -530,6 +544,14 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
           for (int n = 0; n < o.cout; n++) {
             const float v = w[((size_t)tap * o.cin + c) * o.cout + n] * sw;
             const unsigned short hi = host_f2h(v), lo = host_f2h(v - host_h2f(hi));
+            if (planar) {
+              // conv3d_h2_kernel: [chunk][step][h | l][half-wave][cout][8] -- the 64 lanes of a B-operand load read 1 KB of
+              // consecutive bytes (eight full cache lines; interleaved h | l rows cost sixteen half-used ones per load)
+              const size_t row = (((size_t)ch * Pmax + pr) * 2 * kstep + kh) * a.coutp + n;
+              wp[row * 8 + j] = hi;
+              wp[(row + (size_t)kstep * a.coutp) * 8 + j] = lo;
+              continue;
+            }
             const size_t idx = ((((size_t)ch * Pmax + pr) * kstep + kh) * a.coutp + n) * 16;
             wp[idx + j] = hi;
             wp[idx + 8 + j] = lo;
@@ -1016,6 +1038,7 @@ struct Scorer {
   // split-fp16 range flag (ConvArgs::h2_overflow): cleared when a call starts, raised by any split-fp16 kernel (or the
   // voxelizer writing a split tensor) that meets an activation beyond +-65504 or a NaN; a call that finds it raised
   // recomputes its scores on the fp32-MFMA kernels (score_batch / score_batch_grad)
+  DevBuf<unsigned char> d_occ[2];       // occupancy bytes of the split-format pooled grid (VoxArgs::occ), per buffer set
   DevBuf<unsigned> d_ovf;
   unsigned *h_ovf = nullptr;            // pinned copy
   int h2_fallbacks = 0;                 // calls recomputed because of it (mi_scorer_h2_fallbacks)
@@ -1470,6 +1493,9 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
     va.Cp = m->Cp8;
     s.d_ovf.ensure(1);
     va.overflow = s.d_ovf.p;
+    const size_t nt3 = (size_t)va.tiles_per_axis * va.tiles_per_axis * va.tiles_per_axis;
+    s.d_occ[set].ensure((size_t)s.cap * nt3 * 8);
+    va.occ = s.d_occ[set].p;
   }
   {
     // algorithmic bytes: the un-fused figure C*N^3*4 written once per pose
@@ -1593,12 +1619,33 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
             if (st.conv.h2_planar) {  // conv3d_h2_kernel: its own M-tile geometry and LDS pads per tile; tensor formats
               const bool lat = cfg != st.conv.cfg;
+              if (!lat && st.conv.h2_cfg >= 0 && !h.post_w) {  // its own throughput tile
+                cfg = st.conv.h2_cfg;
+                h.tcx = st.conv.h2.tcx, h.tcy = st.conv.h2.tcy, h.tcz = st.conv.h2.tcz;
+                h.ntx = st.conv.h2.ntx, h.nty = st.conv.h2.nty, h.ntz = st.conv.h2.ntz;
+              }
               h.mt_x = lat ? st.conv.h2_lat_mt : st.conv.h2.mt_x;
               h.h2_pad_y = lat ? st.conv.h2_lat_pad[0] : st.conv.h2.h2_pad_y;
               h.h2_pad_x = lat ? st.conv.h2_lat_pad[1] : st.conv.h2.h2_pad_x;
+              {  // weights through LDS where the kernel shape has that variant (conv3d_h2.hip launch_h2_k3)
+                int wm_, wn_, tm_, tn_;
+                conv_cfg_shape(cfg, &wm_, &wn_, &tm_, &tn_);
+                // (default 2: weights through LDS, two poses per workgroup -- measured 1.76 against 1.94 (one pose) and
+                // 1.9-2.0 ms (weights from L1 / L2, double-buffered tile) on the headline's first conv; MI_GNINA_H2_WLDS=0/1/2)
+                const char *ev = getenv("MI_GNINA_H2_WLDS");
+                h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
+              }
               h.in_split = is_split(st.conv.src) ? 1 : 0;
               h.out_split = is_split(st.conv.dst) ? 1 : 0;
-              if (h.in_split && st.conv.src == m->input_dst) h.in_cs = m->Cp8;
+              if (h.in_split && st.conv.src == m->input_dst) {
+                h.in_cs = m->Cp8;
+                // the voxelizer's occupancy bytes of this buffer set -- opt-in (MI_GNINA_H2_OCC=1): on the headline workload a
+                // quarter of the (tile, octet) chunks is empty, and reading the bytes ahead of the first DMA costs as much
+                if (getenv("MI_GNINA_H2_OCC") && atoi(getenv("MI_GNINA_H2_OCC"))) {
+                  h.in_occ = s.d_occ[pooled_slot == kPooledSlot2 ? 1 : 0].p;
+                  h.occ_nt = cdiv(cdiv(m->N, 2), 4);
+                }
+              }
             } else {
               MIG_CHECK(!is_split(st.conv.src) && !is_split(st.conv.dst), 2, "split-format tensor at a layer that cannot take it");
             }

@@ -76,6 +76,9 @@ struct VoxArgs {
   // stages it by LDS-DMA.  overflow: the scorer's sticky range flag (a density beyond 65504, or a NaN).
   int split;
   unsigned *overflow;
+  // split mode: occupancy bytes for the first convolution's zero skipping, [pose][tiles_per_axis]^3[8] -- byte w of a tile
+  // (= a 4 x 4 x 4-cell block of the pooled grid) is non-zero iff window (octet) w of the tile holds a non-zero value
+  unsigned char *occ;
 };
 
 struct VoxBackArgs {

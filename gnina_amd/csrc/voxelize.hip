@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   const int b = wg / (ntile * ntile * ntile);
   const int tile_id = wg - b * (ntile * ntile * ntile);
   const int tz = tile_id % ntile, ty = (tile_id / ntile) % ntile, tx = tile_id / (ntile * ntile);
+  const int tile_occ = (tx * ntile + ty) * ntile + tz;  // index of this tile's occupancy bytes (VoxArgs::occ)
   // Two lane <-> voxel maps.  While atoms are accumulated a lane owns the voxel at local position (lx, ly, lz) of each of
   // the tile's eight 4x4x4 SUB-BLOCKS (acc[k], k = sub-block): the 64 evaluations of one instruction then are one compact
   // 2 A cube, and an atom that touches the tile reaches only 3.2 of the 8 cubes on average -- the others are skipped by
@@ -357,15 +358,24 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     // kernel's time is its VALU instruction count)
     const size_t pose_off = (size_t)b * S * S * S * Cp;
     float *out_pose = v.out + pose_off;
+    unsigned any_bits = 0u;
 #pragma unroll
     for (int k = 0; k < kWin / 4; k++) {
       const int part = (int)(eo[k] & 3u);
       if (eo[k] != 0xffffffffu && c0 + 4 * part < Cp) {
         const unsigned o = (eo[k] & ~3u) + (SPLIT ? (unsigned)(cur_w * S * S * S * kWin) : (unsigned)c0);
         // (cell * kWin + 4 * part == 4 * i: the staged tile is read back in item order)
-        *reinterpret_cast<float4 *>(out_pose + o) = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
+        const float4 item = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
+        if constexpr (SPLIT) any_bits |= __float_as_uint(item.x) | __float_as_uint(item.y) | __float_as_uint(item.z) | __float_as_uint(item.w);
+        *reinterpret_cast<float4 *>(out_pose + o) = item;
         if (MODE == 1 && v.argmax_out)
           *reinterpret_cast<unsigned *>(v.argmax_out + pose_off + o) = *reinterpret_cast<const unsigned *>(s_arg + 4 * (lane + 64 * k));
+      }
+    }
+    if constexpr (SPLIT) {  // occupancy byte of this (tile, octet): the first convolution stages only what has content
+      if (v.occ && cur_w < 8) {
+        const bool nz = __ballot(any_bits != 0u) != 0ull;
+        if (lane == 0) v.occ[((size_t)b * ntile * ntile * ntile + tile_occ) * 8 + cur_w] = nz ? 1 : 0;
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
