@@ -278,7 +278,7 @@ def config_c3(capi, cpu_seconds=0.0):
     """BASELINE config C3 as specified: ONE complex, exhaustiveness 64, gnina's step count, Monte-Carlo + BFGS on the
     cache grids, then merge -> refine -> CNN rescore (default ensemble) -> final energies -> rank.  A latency
     workload: 64 chains on a chip with 4,096 wave slots (evaluations/s is the figure SURVEY 8d asks for)."""
-    from tests import vina_scene
+    from gnina_amd import vina_scene
     sc = vina_scene.build(0)
     lig = sc["lig"]
     T = lig["n_tors"]

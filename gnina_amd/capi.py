@@ -30,6 +30,8 @@ SYMBOLS = [
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
     "mi_vina_refine_batch", "mi_vina_final_energies", "mi_rank_poses", "mi_merge_mc_outputs", "mi_vina_eval_latency",
+    "mi_vina_pool_create", "mi_vina_pool_destroy", "mi_vina_pool_size", "mi_vina_pool_configure", "mi_vina_pool_mc_batch",
+    "mi_vina_pool_mc_screen", "mi_vina_pool_info_json",
 ]
 
 _lib = None
@@ -941,8 +943,19 @@ class Vina:
                                        _ptr(ev)))
         return e, confs, g, ev
 
+    @classmethod
+    def _borrow(cls, handle):
+        """a view on a handle someone else owns (VinaPool's per-device handles)"""
+        v = cls.__new__(cls)
+        v.handle = handle
+        v._borrowed = True
+        v.n = lib().mi_vina_table_size(handle)
+        v.grid_shape = None
+        v.n_atoms = v.n_tors = 0
+        return v
+
     def __del__(self):
-        if getattr(self, "handle", None) and _lib is not None:
+        if getattr(self, "handle", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.mi_vina_destroy(self.handle)
             self.handle = None
 
@@ -1023,6 +1036,81 @@ class Pool:
     def __del__(self):
         if getattr(self, "handle", None):
             lib().mi_pool_destroy(self.handle)
+            self.handle = None
+
+
+class VinaPool:
+    """mi_vina_pool: one mi_vina handle per listed GPU in THIS process; Monte-Carlo chains split by chain id (a screen's
+    by ligand), set-up replicated through configure()."""
+
+    _CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
+    def __init__(self, devices=None, weights=None, cutoff=8.0, factor=32.0):
+        L = lib()
+        L.mi_vina_pool_create.restype = C.c_void_p
+        L.mi_vina_pool_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float]
+        L.mi_vina_pool_destroy.argtypes = [C.c_void_p]
+        L.mi_vina_pool_destroy.restype = None
+        L.mi_vina_pool_size.argtypes = [C.c_void_p]
+        L.mi_vina_pool_configure.argtypes = [C.c_void_p, self._CB, C.c_void_p]
+        L.mi_vina_pool_mc_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.mi_vina_pool_mc_screen.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.mi_vina_pool_info_json.argtypes = [C.c_void_p]
+        L.mi_vina_pool_info_json.restype = C.c_char_p
+        if devices is None:
+            devices = list(range(L.mi_gnina_device_count()))
+        dv = (C.c_int * len(devices))(*devices)
+        w = _f32(weights)
+        self.handle = L.mi_vina_pool_create(dv, len(devices), _ptr(w), cutoff, factor)
+        if not self.handle:
+            raise MiGninaError(L.mi_last_error().decode())
+        self.devices = list(devices)
+        self.views = {}
+
+    def configure(self, fn):
+        """fn(vina, rank) once per device, on that device's worker thread: the same set-up calls for every rank"""
+        errors = []
+
+        def tramp(h, rank, _user):
+            try:
+                if rank not in self.views:
+                    self.views[rank] = Vina._borrow(h)
+                fn(self.views[rank], rank)
+                return 0
+            except Exception as e:  # noqa: BLE001 (reported to the caller below)
+                errors.append(e)
+                return 1
+
+        cb = self._CB(tramp)
+        st = lib().mi_vina_pool_configure(self.handle, cb, None)
+        if errors:
+            raise errors[0]
+        check(st)
+
+    def mc_batch(self, seeds, corner1, corner2, params):
+        """Vina.mc_batch over the pool: chains split by chain id"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        v0 = self.views[0]
+        B, S = len(seeds), params.num_saved
+        nh = lib().mi_vina_ligand_heavy_atoms(v0.handle)
+        cs = 7 + v0.n_tors
+        c1, c2 = _f32(corner1), _f32(corner2)
+        n, ev = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        e = np.zeros((B, S), dtype=np.float32)
+        cf = np.zeros((B, S, cs), dtype=np.float32)
+        xyz = np.zeros((B, S, nh, 3), dtype=np.float32)
+        check(lib().mi_vina_pool_mc_batch(self.handle, B, _ptr(seeds), _ptr(c1), _ptr(c2), C.addressof(params), cs, nh,
+                                          _ptr(n), _ptr(e), _ptr(cf), _ptr(xyz), _ptr(ev)))
+        return n, e, cf, xyz, ev
+
+    def info(self):
+        import json
+        return json.loads(lib().mi_vina_pool_info_json(self.handle).decode())
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.views = {}
+            lib().mi_vina_pool_destroy(self.handle)
             self.handle = None
 
 

@@ -59,4 +59,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // attribute lives in the device's copy of the code object; a pool drives several devices from one process).
 void ensure_max_lds(const void *kernel, int bytes);
 
+// setenv("GPU_MAX_HW_QUEUES") exactly once per process (engine.cpp); called by mi_gnina_init and, ahead of its worker
+// threads, by the pools
+void process_env_once();
+
 }  // namespace mig

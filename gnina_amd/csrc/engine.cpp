@@ -32,6 +32,14 @@ namespace mig {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
+// The one environment variable this library WRITES, once per process and -- when a pool starts worker threads -- on the
+// caller's thread before they exist (mi_pool_create): glibc does not make setenv safe against getenv in other threads,
+// and the engine reads its MI_GNINA_* switches with getenv while models load.
+void process_env_once() {
+  static std::once_flag once;
+  std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+}
+
 void ensure_max_lds(const void *kernel, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<int, const void *>> done;
@@ -2097,7 +2105,7 @@ mi_status mi_gnina_init(int device) {
   // Scorers and mi_vina handles each own a HIP stream so that independent ligands overlap on the device.  The
   // HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its
   // kernels in order: ask for 16 unless the user chose (only effective before the first HIP call of the process).
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  process_env_once();
   int n = 0;
   MIG_HIP(hipGetDeviceCount(&n));
   MIG_CHECK(n > 0, 3, "no HIP device visible");

@@ -42,6 +42,7 @@ struct Rccl {
   void *h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -61,6 +62,7 @@ struct Rccl {
     auto sym = [&](const char *n) { return dlsym(h, n); };
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(sym("ncclCommAbort"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
@@ -131,7 +133,17 @@ std::string on_all(Pool &p, const std::function<std::string(Worker &)> &f) {
   std::vector<std::future<std::string>> futs;
   for (auto &wk : p.w) {
     Worker *x = wk.get();
-    futs.push_back(x->post([x, &f] { return f(*x); }));
+    // (a task that throws would leave the other workers running on references to a frame that is being unwound: every
+    // task reports through its string)
+    futs.push_back(x->post([x, &f]() -> std::string {
+      try {
+        return f(*x);
+      } catch (const std::exception &e) {
+        return std::string("worker ") + std::to_string(x->rank) + ": " + e.what();
+      } catch (...) {
+        return std::string("worker ") + std::to_string(x->rank) + ": unknown exception";
+      }
+    }));
   }
   std::string err;
   for (auto &fu : futs) {
@@ -142,6 +154,23 @@ std::string on_all(Pool &p, const std::function<std::string(Worker &)> &f) {
 }
 
 std::string last(const char *what) { return std::string(what) + ": " + mi_last_error(); }
+
+// one device-resident shard on its worker's scorer, complete on return.  A device-output call cannot repeat itself when
+// an activation leaves the split-fp16 kernels' range (mi_scorer_synchronize reports MI_ERR_RANGE, include/mi_gnina.h):
+// the shard is scored again on the fp32-MFMA kernels.
+std::string score_resident(Worker &x, const float *lig, const int32_t *smt, int nb, int L, const float *cen, float *o_pose,
+                           float *o_aff, float *o_loss, float *o_var) {
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (mi_scorer_score_batch_ex(x.scorer, lig, smt, nb, L, cen, o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
+      return last("mi_scorer_score_batch_ex");
+    const mi_status st = mi_scorer_synchronize(x.scorer);
+    if (attempt == 1) (void)mi_scorer_set_precision(x.scorer, MI_PRECISION_FP32);
+    if (st == MI_OK) return "";
+    if (st != MI_ERR_RANGE || attempt == 1) return last("mi_scorer_synchronize");
+    if (mi_scorer_set_precision(x.scorer, MI_PRECISION_FP32_MFMA) != MI_OK) return last("mi_scorer_set_precision");
+  }
+  return "";
+}
 
 void shard(int B, int G, int g, int &b0, int &nb) {  // contiguous [g*B/G, (g+1)*B/G), SURVEY 8e
   b0 = (int)((long)B * g / G);
@@ -180,6 +209,7 @@ mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *mo
         dup = dup || devices[k] == devices[g];
       }
     }
+    process_env_once();  // (before the worker threads exist: see common.h)
     auto p = std::make_unique<Pool>();
     p->duplicates = dup;
     p->use_rccl = !dup && getenv("MI_POOL_NO_RCCL") == nullptr;
@@ -283,6 +313,7 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
   if (B == 0) return MI_OK;
   if (G == 1) {  // nothing to shard: the single scorer, same bits as mi_scorer_score_batch
     const std::string err = on_all(p, [&](Worker &x) -> std::string {
+      if (in_dev && out_dev) return score_resident(x, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var);
       if (mi_scorer_score_batch_ex(x.scorer, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, flags) != MI_OK)
         return last("mi_scorer_score_batch_ex");
       if (out_dev && mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
@@ -339,10 +370,8 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
           x.d_out.ensure((size_t)4 * nb);
           o_pose = x.d_out.p, o_aff = o_pose + nb, o_loss = o_aff + nb, o_var = aff_var ? o_loss + nb : nullptr;
         }
-        if (mi_scorer_score_batch_ex(x.scorer, my_lig, lig_smt, nb, L, my_cen, o_pose, o_aff, o_loss, o_var,
-                                     MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
-          return last("mi_scorer_score_batch_ex");
-        if (mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
+        const std::string se = score_resident(x, my_lig, lig_smt, nb, L, my_cen, o_pose, o_aff, o_loss, o_var);
+        if (!se.empty()) return se;
         if (x.rank != 0) {
           float *dst[4] = {pose, affinity, loss, aff_var};
           for (int a = 0; a < (aff_var ? 4 : 3); a++)
@@ -357,75 +386,101 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
     MIG_CHECK(err.empty(), 3, err);
     return MI_OK;
   }
+  // RCCL transport, in phases separated by host-side rendezvous (on_all returns when every worker is through): a rank
+  // that fails -- its shard's scoring, an allocation -- must not leave its peers inside an ncclGroupEnd waiting for a
+  // send or receive that is never posted, so nothing but the point-to-point calls themselves sits between a GroupStart
+  // and its GroupEnd, every rank runs every group, and the gather is posted only once ALL ranks have scored.
   Rccl &R = p.rccl;
-  const std::string err = on_all(p, [&](Worker &x) -> std::string {
-    auto nc = [&](ncclResult_t r, const char *what) -> std::string {
-      return r == ncclSuccess ? "" : std::string(what) + ": " + R.GetErrorString(r);
-    };
-    try {
-      int b0, nb;
-      shard(B, G, x.rank, b0, nb);
-      const float *my_lig = lig_xyz, *my_cen = centers;
-      // 1. scatter: rank 0 sends shard g to rank g, rank g receives it (one group per rank = one fused transfer set)
-      std::string e = nc(R.GroupStart(), "ncclGroupStart");
-      if (!e.empty()) return e;
-      if (x.rank == 0) {
-        for (int g = 1; g < G; g++) {
-          int c0, cn;
-          shard(B, G, g, c0, cn);
-          if (cn == 0) continue;
-          if (!(e = nc(R.Send(lig_xyz + (size_t)c0 * L * 3, (size_t)cn * L * 3, ncclFloat, g, x.comm, x.stream), "ncclSend")).empty()) return e;
-          if (centers && !(e = nc(R.Send(centers + (size_t)c0 * 3, (size_t)cn * 3, ncclFloat, g, x.comm, x.stream), "ncclSend")).empty()) return e;
-        }
-      } else if (nb > 0) {
-        x.d_lig.ensure((size_t)nb * L * 3);
-        if (!(e = nc(R.Recv(x.d_lig.p, (size_t)nb * L * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv")).empty()) return e;
-        my_lig = x.d_lig.p;
-        if (centers) {
-          x.d_cen.ensure((size_t)nb * 3);
-          if (!(e = nc(R.Recv(x.d_cen.p, (size_t)nb * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv")).empty()) return e;
-          my_cen = x.d_cen.p;
-        }
-      }
-      if (!(e = nc(R.GroupEnd(), "ncclGroupEnd")).empty()) return e;
-      MIG_HIP(hipStreamSynchronize(x.stream));
-      // 2. score the shard on this device (device in, device out)
-      float *o_pose, *o_aff, *o_loss, *o_var;
-      if (x.rank == 0) {
-        o_pose = pose, o_aff = affinity, o_loss = loss, o_var = aff_var;
-      } else {
-        x.d_out.ensure((size_t)4 * std::max(nb, 1));
-        o_pose = x.d_out.p, o_aff = o_pose + nb, o_loss = o_aff + nb, o_var = aff_var ? o_loss + nb : nullptr;
-      }
-      if (nb > 0) {
-        if (mi_scorer_score_batch_ex(x.scorer, x.rank == 0 ? lig_xyz : my_lig, lig_smt, nb, L, x.rank == 0 ? centers : my_cen,
-                                     o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
-          return last("mi_scorer_score_batch_ex");
-        if (mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
-      }
-      // 3. gather the scores on devices[0], straight into the caller's arrays
-      if (!(e = nc(R.GroupStart(), "ncclGroupStart")).empty()) return e;
-      const int n_arr = aff_var ? 4 : 3;
-      if (x.rank == 0) {
-        float *dst[4] = {pose, affinity, loss, aff_var};
-        for (int g = 1; g < G; g++) {
-          int c0, cn;
-          shard(B, G, g, c0, cn);
-          for (int a = 0; a < n_arr && cn > 0; a++)
-            if (!(e = nc(R.Recv(dst[a] + c0, (size_t)cn, ncclFloat, g, x.comm, x.stream), "ncclRecv")).empty()) return e;
-        }
-      } else if (nb > 0) {
-        for (int a = 0; a < n_arr; a++)
-          if (!(e = nc(R.Send(x.d_out.p + (size_t)a * nb, (size_t)nb, ncclFloat, 0, x.comm, x.stream), "ncclSend")).empty()) return e;
-      }
-      if (!(e = nc(R.GroupEnd(), "ncclGroupEnd")).empty()) return e;
-      MIG_HIP(hipStreamSynchronize(x.stream));
+  auto nc = [&](ncclResult_t r, const char *what) -> std::string {
+    return r == ncclSuccess ? "" : std::string(what) + ": " + R.GetErrorString(r);
+  };
+  auto abandon_rccl = [&](const std::string &why) {  // a failed group: the communicators are not reusable
+    (void)on_all(p, [&](Worker &x) -> std::string {
+      if (x.comm && R.CommAbort) (void)R.CommAbort(x.comm);
+      x.comm = nullptr;
       return "";
-    } catch (const std::exception &ex) {
-      return ex.what();
+    });
+    p.comms_ready = false;
+    p.use_rccl = false;
+    p.rccl_note = why;
+  };
+  const int n_arr = aff_var ? 4 : 3;
+  // phase 0: staging buffers (may fail: before any RCCL call)
+  std::string err = on_all(p, [&](Worker &x) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);
+    if (x.rank != 0 && nb > 0) {
+      x.d_lig.ensure((size_t)nb * L * 3);
+      if (centers) x.d_cen.ensure((size_t)nb * 3);
+      x.d_out.ensure((size_t)4 * nb);
     }
+    return "";
   });
   MIG_CHECK(err.empty(), 3, err);
+  // phase 1: scatter -- rank 0 sends shard g to rank g, rank g receives it (one group per rank = one fused transfer set)
+  err = on_all(p, [&](Worker &x) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);
+    std::string e = nc(R.GroupStart(), "ncclGroupStart"), e1;
+    if (!e.empty()) return e;
+    if (x.rank == 0) {
+      for (int g = 1; g < G; g++) {
+        int c0, cn;
+        shard(B, G, g, c0, cn);
+        if (cn == 0) continue;
+        if (e.empty()) e = nc(R.Send(lig_xyz + (size_t)c0 * L * 3, (size_t)cn * L * 3, ncclFloat, g, x.comm, x.stream), "ncclSend");
+        if (e.empty() && centers) e = nc(R.Send(centers + (size_t)c0 * 3, (size_t)cn * 3, ncclFloat, g, x.comm, x.stream), "ncclSend");
+      }
+    } else if (nb > 0) {
+      e = nc(R.Recv(x.d_lig.p, (size_t)nb * L * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv");
+      if (e.empty() && centers) e = nc(R.Recv(x.d_cen.p, (size_t)nb * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv");
+    }
+    e1 = nc(R.GroupEnd(), "ncclGroupEnd");  // (always: the group must be closed on this thread)
+    if (e.empty()) e = e1;
+    if (e.empty() && hipStreamSynchronize(x.stream) != hipSuccess) e = "hipStreamSynchronize failed after the scatter";
+    return e;
+  });
+  if (!err.empty()) {
+    abandon_rccl(err);
+    throw mig::Error(3, err);
+  }
+  // phase 2: every rank scores its shard (device in, device out); no RCCL call in here
+  err = on_all(p, [&](Worker &x) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);
+    if (nb == 0) return "";
+    if (x.rank == 0) return score_resident(x, lig_xyz, lig_smt, nb, L, centers, pose, affinity, loss, aff_var);
+    float *o = x.d_out.p;
+    return score_resident(x, x.d_lig.p, lig_smt, nb, L, centers ? x.d_cen.p : nullptr, o, o + nb, o + 2 * (size_t)nb, aff_var ? o + 3 * (size_t)nb : nullptr);
+  });
+  MIG_CHECK(err.empty(), 3, err);  // (nothing is pending in RCCL: the call fails as a whole, the pool stays usable)
+  // phase 3: gather the scores on devices[0], straight into the caller's arrays
+  err = on_all(p, [&](Worker &x) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);
+    std::string e = nc(R.GroupStart(), "ncclGroupStart"), e1;
+    if (!e.empty()) return e;
+    if (x.rank == 0) {
+      float *dst[4] = {pose, affinity, loss, aff_var};
+      for (int g = 1; g < G; g++) {
+        int c0, cn;
+        shard(B, G, g, c0, cn);
+        for (int a = 0; a < n_arr && cn > 0; a++)
+          if (e.empty()) e = nc(R.Recv(dst[a] + c0, (size_t)cn, ncclFloat, g, x.comm, x.stream), "ncclRecv");
+      }
+    } else if (nb > 0) {
+      for (int a = 0; a < n_arr; a++)
+        if (e.empty()) e = nc(R.Send(x.d_out.p + (size_t)a * nb, (size_t)nb, ncclFloat, 0, x.comm, x.stream), "ncclSend");
+    }
+    e1 = nc(R.GroupEnd(), "ncclGroupEnd");
+    if (e.empty()) e = e1;
+    if (e.empty() && hipStreamSynchronize(x.stream) != hipSuccess) e = "hipStreamSynchronize failed after the gather";
+    return e;
+  });
+  if (!err.empty()) {
+    abandon_rccl(err);
+    throw mig::Error(3, err);
+  }
   return MI_OK;
   PCATCH_STATUS
 }
@@ -453,6 +508,209 @@ mi_status mi_pool_score_ragged(mi_pool *pp, const float *lig_xyz, const int32_t 
   MIG_CHECK(err.empty(), 3, err);
   return MI_OK;
   PCATCH_STATUS
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mi_vina_pool: the Vina / Monte-Carlo half of the path over the node's GPUs.  gnina runs the `exhaustiveness` chains of a
+// dock as tasks of a thread pool, every task with its own copy of the model and one seed (parallel_mc.cpp:183-214), and
+// merges the per-chain containers afterwards; chains never exchange anything.  Here the tasks go to devices: every GPU
+// holds its own mi_vina handle -- pair tables, receptor, cache grids, ligand(s): all of it set up by the SAME calls on every
+// device (mi_vina_pool_configure runs a caller-supplied function once per handle, on that device's worker thread) -- and
+// a launch of B chains is split by chain id into contiguous shards (a screen: by ligand, round robin, so that a ligand's
+// chains share a device).  A chain is a function of its seed and the handle's state only: the pool's outputs equal a
+// single handle's bit for bit, whatever the number of devices.  No collective: per-chain containers come back to the
+// host arrays of the caller, who merges them (mi_merge_mc_outputs) as parallel_mc.cpp:165-181 does.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mig {
+namespace {
+struct VinaPool {
+  std::vector<std::unique_ptr<Worker>> w;  // (scorer / models / comm unused)
+  std::vector<mi_vina *> h;
+  std::string info;
+};
+std::string on_all_vina(VinaPool &p, const std::function<std::string(Worker &, mi_vina *)> &f) {
+  std::vector<std::future<std::string>> futs;
+  for (size_t g = 0; g < p.w.size(); g++) {
+    Worker *x = p.w[g].get();
+    mi_vina *hv = p.h[g];
+    futs.push_back(x->post([x, hv, &f]() -> std::string {
+      try {
+        return f(*x, hv);
+      } catch (const std::exception &e) {
+        return std::string("worker ") + std::to_string(x->rank) + ": " + e.what();
+      } catch (...) {
+        return std::string("worker ") + std::to_string(x->rank) + ": unknown exception";
+      }
+    }));
+  }
+  std::string err;
+  for (auto &fu : futs) {
+    std::string e = fu.get();
+    if (err.empty() && !e.empty()) err = e;
+  }
+  return err;
+}
+}  // namespace
+}  // namespace mig
+
+extern "C" {
+
+mi_vina_pool *mi_vina_pool_create(const int *devices, int n_devices, const float *weights5, float cutoff, float factor) {
+  try {
+    MIG_CHECK(devices && n_devices > 0, 1, "bad arguments");
+    const int have = mi_gnina_device_count();
+    const bool allow_dup = getenv("MI_POOL_ALLOW_DUPLICATE_DEVICES") != nullptr;
+    for (int g = 0; g < n_devices; g++) {
+      MIG_CHECK(devices[g] >= 0 && devices[g] < have, 1, "device index out of range");
+      for (int k = 0; k < g; k++) MIG_CHECK(devices[k] != devices[g] || allow_dup, 1, "a device is listed twice");
+    }
+    process_env_once();
+    auto p = std::make_unique<VinaPool>();
+    for (int g = 0; g < n_devices; g++) {
+      auto wk = std::make_unique<Worker>();
+      wk->device = devices[g];
+      wk->rank = g;
+      Worker *x = wk.get();
+      x->th = std::thread([x] { x->loop(); });
+      p->w.push_back(std::move(wk));
+      p->h.push_back(nullptr);
+    }
+    std::vector<float> w5;
+    if (weights5) w5.assign(weights5, weights5 + 5);
+    std::vector<std::future<std::string>> futs;
+    for (int g = 0; g < n_devices; g++) {
+      Worker *x = p->w[g].get();
+      mi_vina **slot = &p->h[g];
+      futs.push_back(x->post([x, slot, &w5, cutoff, factor]() -> std::string {
+        if (mi_gnina_init(x->device) != MI_OK) return last("mi_gnina_init");
+        *slot = mi_vina_create(w5.empty() ? nullptr : w5.data(), cutoff, factor);
+        return *slot ? "" : last("mi_vina_create");
+      }));
+    }
+    std::string err;
+    for (auto &fu : futs) {
+      const std::string e = fu.get();
+      if (err.empty() && !e.empty()) err = e;
+    }
+    if (!err.empty()) {
+      mi_vina_pool_destroy(reinterpret_cast<mi_vina_pool *>(p.release()));
+      throw mig::Error(3, err);
+    }
+    return reinterpret_cast<mi_vina_pool *>(p.release());
+  } catch (const std::exception &e) {
+    mig::set_last_error(e.what());
+  }
+  return nullptr;
+}
+
+void mi_vina_pool_destroy(mi_vina_pool *pp) {
+  if (!pp) return;
+  VinaPool *p = reinterpret_cast<VinaPool *>(pp);
+  (void)on_all_vina(*p, [](Worker &, mi_vina *hv) -> std::string {
+    if (hv) mi_vina_destroy(hv);
+    return "";
+  });
+  for (auto &wk : p->w) {
+    {
+      std::lock_guard<std::mutex> l(wk->mu);
+      wk->stop = true;
+    }
+    wk->cv.notify_one();
+    if (wk->th.joinable()) wk->th.join();
+  }
+  delete p;
+}
+
+int mi_vina_pool_size(const mi_vina_pool *pp) { return pp ? (int)reinterpret_cast<const VinaPool *>(pp)->w.size() : 0; }
+
+mi_status mi_vina_pool_configure(mi_vina_pool *pp, mi_vina_pool_fn fn, void *user) {
+  PTRY
+  MIG_CHECK(pp && fn, 1, "bad arguments");
+  VinaPool &p = *reinterpret_cast<VinaPool *>(pp);
+  const std::string err = on_all_vina(p, [&](Worker &x, mi_vina *hv) -> std::string {
+    return fn(hv, x.rank, user) == MI_OK ? "" : last("mi_vina_pool_configure callback");
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+mi_status mi_vina_pool_mc_batch(mi_vina_pool *pp, int B, const uint64_t *seeds, const float *corner1, const float *corner2,
+                                const mi_mc_params *params, int conf_size, int n_heavy, int32_t *out_n, float *out_e,
+                                float *out_conf, float *out_coords, int32_t *evals) {
+  PTRY
+  MIG_CHECK(pp && B >= 0 && (B == 0 || (seeds && corner1 && corner2 && params && out_n && out_e && out_conf && out_coords)) &&
+                conf_size > 0 && n_heavy >= 0, 1, "bad arguments");
+  VinaPool &p = *reinterpret_cast<VinaPool *>(pp);
+  const int G = (int)p.w.size();
+  if (B == 0) return MI_OK;
+  const size_t ns = (size_t)params->num_saved;
+  const std::string err = on_all_vina(p, [&](Worker &x, mi_vina *hv) -> std::string {
+    int b0, nb;
+    shard(B, G, x.rank, b0, nb);  // chains [b0, b0 + nb): split by chain id
+    if (nb == 0) return "";
+    return mi_vina_mc_batch(hv, nb, seeds + b0, corner1, corner2, params, out_n + b0, out_e + (size_t)b0 * ns,
+                            out_conf + (size_t)b0 * ns * conf_size, out_coords + (size_t)b0 * ns * n_heavy * 3,
+                            evals ? evals + b0 : nullptr) == MI_OK
+               ? ""
+               : last("mi_vina_mc_batch");
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+mi_status mi_vina_pool_mc_screen(mi_vina_pool *pp, int B, const int32_t *chain_ligand, const uint64_t *seeds,
+                                 const float *corner1, const float *corner2, const mi_mc_params *params, int max_conf,
+                                 int max_heavy, int32_t *out_n, float *out_e, float *out_conf, float *out_coords,
+                                 int32_t *evals) {
+  PTRY
+  MIG_CHECK(pp && B >= 0 && (B == 0 || (chain_ligand && seeds && corner1 && corner2 && params && out_n && out_e && out_conf && out_coords)) &&
+                max_conf > 0 && max_heavy >= 0, 1, "bad arguments");
+  VinaPool &p = *reinterpret_cast<VinaPool *>(pp);
+  const int G = (int)p.w.size();
+  if (B == 0) return MI_OK;
+  const size_t ns = (size_t)params[0].num_saved, cs = ns * max_conf, xs = ns * (size_t)max_heavy * 3;
+  const std::string err = on_all_vina(p, [&](Worker &x, mi_vina *hv) -> std::string {
+    // ligand l goes to device l % G: this device's chains, in launch order
+    std::vector<int> idx;
+    for (int b = 0; b < B; b++)
+      if (chain_ligand[b] % G == x.rank) idx.push_back(b);
+    const int nb = (int)idx.size();
+    if (nb == 0) return "";
+    std::vector<int32_t> cl(nb), on(nb), ev(nb);
+    std::vector<uint64_t> sd(nb);
+    std::vector<float> oe((size_t)nb * ns), oc((size_t)nb * cs), ox((size_t)nb * xs);
+    for (int i = 0; i < nb; i++) cl[i] = chain_ligand[idx[i]], sd[i] = seeds[idx[i]];
+    if (mi_vina_mc_screen(hv, nb, cl.data(), sd.data(), corner1, corner2, params, on.data(), oe.data(), oc.data(), ox.data(),
+                          ev.data()) != MI_OK)
+      return last("mi_vina_mc_screen");
+    for (int i = 0; i < nb; i++) {  // (disjoint rows of the caller's arrays: no two workers write the same chain)
+      const size_t b = (size_t)idx[i];
+      out_n[b] = on[i];
+      if (evals) evals[b] = ev[i];
+      std::memcpy(out_e + b * ns, oe.data() + (size_t)i * ns, ns * sizeof(float));
+      std::memcpy(out_conf + b * cs, oc.data() + (size_t)i * cs, cs * sizeof(float));
+      std::memcpy(out_coords + b * xs, ox.data() + (size_t)i * xs, xs * sizeof(float));
+    }
+    return "";
+  });
+  MIG_CHECK(err.empty(), 3, err);
+  return MI_OK;
+  PCATCH_STATUS
+}
+
+const char *mi_vina_pool_info_json(mi_vina_pool *pp) {
+  if (!pp) return "{}";
+  VinaPool &p = *reinterpret_cast<VinaPool *>(pp);
+  std::ostringstream o;
+  o << "{\"devices\": [";
+  for (size_t g = 0; g < p.w.size(); g++) o << (g ? ", " : "") << p.w[g]->device;
+  o << "], \"ranks\": " << p.w.size() << ", \"sharding\": \"chains by chain id (contiguous); screens by ligand, round robin\"}";
+  p.info = o.str();
+  return p.info.c_str();
 }
 
 const char *mi_pool_info_json(mi_pool *pp) {

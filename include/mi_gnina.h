@@ -412,6 +412,31 @@ mi_status mi_vina_refine_screen(mi_vina *, const int32_t *item_ligand, float *co
                                 const int32_t *max_iters, float *energy, int32_t *tries);
 mi_status mi_vina_final_energies_screen(mi_vina *, const int32_t *item_ligand, const float *confs, int B,
                                         const float *v3, const float *num_tors, float *e_final, float *intramolecular);
+/* ---- the same for the Vina / Monte-Carlo half of the path -------------------------------------------------------------
+ * Replaces parallel_mc's fan-out of chains over a thread pool (parallel_mc.cpp:183-214: one task per chain, each with
+ * its own model copy and seed; containers merged afterwards, :165-181) by a fan-out over devices.  mi_vina_pool owns one
+ * host thread and one mi_vina handle per listed GPU.  Set-up is REPLICATED: mi_vina_pool_configure runs fn(handle, rank,
+ * user) once per device, on that device's thread -- call mi_vina_set_receptor / mi_vina_build_cache / mi_vina_set_ligand
+ * (or mi_vina_set_screen) / option setters in it, identically for every rank; the cache grids are built per device
+ * (a few MB each; faster than shipping them).  mi_vina_pool_mc_batch = mi_vina_mc_batch with the B chains split by chain
+ * id into contiguous shards; mi_vina_pool_mc_screen = mi_vina_mc_screen with ligand l's chains on device l % G.  conf_size
+ * = 7 + T (+ flexible-residue torsions), n_heavy = mi_vina_ligand_heavy_atoms; max_conf / max_heavy = mi_vina_screen_dims.
+ * A chain depends on its seed and the handle's state only: the outputs equal those of one handle bit for bit for any
+ * number of devices.  Host arrays in, host arrays out; merge with mi_merge_mc_outputs.  No collective. */
+typedef struct mi_vina_pool mi_vina_pool;
+mi_vina_pool *mi_vina_pool_create(const int *devices, int n_devices, const float *weights5, float cutoff, float factor);
+void mi_vina_pool_destroy(mi_vina_pool *);
+int mi_vina_pool_size(const mi_vina_pool *);
+typedef int (*mi_vina_pool_fn)(mi_vina *handle, int rank, void *user); /* returns an mi_status (MI_OK = 0) */
+mi_status mi_vina_pool_configure(mi_vina_pool *, mi_vina_pool_fn fn, void *user);
+mi_status mi_vina_pool_mc_batch(mi_vina_pool *, int B, const uint64_t *seeds, const float *corner1, const float *corner2,
+                                const mi_mc_params *params, int conf_size, int n_heavy, int32_t *out_n, float *out_e,
+                                float *out_conf, float *out_coords, int32_t *evals);
+mi_status mi_vina_pool_mc_screen(mi_vina_pool *, int B, const int32_t *chain_ligand, const uint64_t *seeds,
+                                 const float *corner1, const float *corner2, const mi_mc_params *params, int max_conf,
+                                 int max_heavy, int32_t *out_n, float *out_e, float *out_conf, float *out_coords,
+                                 int32_t *evals);
+const char *mi_vina_pool_info_json(mi_vina_pool *);
 /* do_search's ranking tail (main.cpp:348-361): sort (pose_sort_order: CNNscore / CNNaffinity descending,
  * Energy ascending) then remove_redundant(out_cont, out_min_rmsd) (main.cpp:182-192).  Host only.
  * coords [n_poses][n_heavy][3]; order_out [n_poses] receives the kept pose indices, best first. */

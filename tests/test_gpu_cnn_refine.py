@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import cnn_ref, cnn_refine, vina as ovina
-from tests import vina_scene
+from gnina_amd import vina_scene
 
 pytestmark = pytest.mark.gpu
 

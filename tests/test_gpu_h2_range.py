@@ -137,3 +137,27 @@ def test_values_at_the_edge_of_the_range_do_not_raise_the_flag(capi, CG, tmp_pat
     assert s.h2_fallbacks() == 0
     assert np.abs(got["pose"] - want_pose).max() < 1e-4
     assert np.abs(got["affinity"] - want_aff).max() < 1e-4 * max(1.0, float(np.abs(want_aff).max()))
+
+
+def test_pool_repeats_a_device_resident_shard_on_fp32_mfma(capi, CG, tmp_path, monkeypatch):
+    """mi_pool's device-resident path cannot see the range flag until mi_scorer_synchronize returns MI_ERR_RANGE: the
+    worker then scores its shard again under MI_PRECISION_FP32_MFMA (pool.cpp score_resident) -- the caller gets the
+    fp32 bits, from a pool of one device and from a sharded pool alike."""
+    name = "default2017"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    path = scaled_blob(name, 2.0 ** 18, tmp_path)
+    s = capi.Scorer([capi.Model(path)])
+    s.set_receptor(rec_xyz, rec_smt)
+    s.set_precision("fp32_mfma")
+    want = s.score_batch(poses, lig_smt)
+    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
+    d_lig = torch.from_numpy(poses).cuda()
+    for devices in ([0], [0, 0]):
+        pool = capi.Pool([path], devices)
+        pool.set_receptor(rec_xyz, rec_smt)
+        d_out = torch.zeros(4, len(poses), dtype=torch.float32, device="cuda")
+        pool.score_batch_device(d_lig.data_ptr(), lig_smt, len(poses), poses.shape[1], d_out[0].data_ptr(), d_out[1].data_ptr(),
+                                d_out[2].data_ptr(), d_out[3].data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[0], want["pose"]) and np.array_equal(got[1], want["affinity"]), devices

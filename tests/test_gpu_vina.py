@@ -8,7 +8,7 @@ import pytest
 
 from gnina_amd import synth
 from oracle import vina as V
-from tests import vina_scene
+from gnina_amd import vina_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -393,3 +393,38 @@ def test_screen_launch_matches_per_ligand_chains(capi, T):
         assert np.array_equal(er[idx], e2) and np.array_equal(rcf[idx][:, :nc], cf2) and np.array_equal(tr[idx], t2)
         e3, i3 = vina.final_energies(cf2, float(lig["n_tors"]))
         assert np.array_equal(ef[idx], e3) and np.array_equal(intra[idx], i3)
+
+
+def test_vina_pool_splits_chains_by_chain_id_and_returns_the_single_handle_bits(setup, capi, monkeypatch):
+    """mi_vina_pool (include/mi_gnina.h): parallel_mc's fan-out of chains (parallel_mc.cpp:183-214) over devices.  On a
+    one-GPU box MI_POOL_ALLOW_DUPLICATE_DEVICES lets three workers share device 0 -- every shard offset of the chain
+    arrays is exercised -- and a chain depends on its seed and the handle's state only, so the pool must return the bits
+    of the single handle, whatever the number of workers (19 chains over 3 workers: shards of 6, 6 and 7)."""
+    vina, S, sc, gd, types, grids = setup
+    c1, c2 = list(gd.begin), list(gd.end)
+    seeds = np.arange(900, 919, dtype=np.uint64)
+    P = capi.McParams.default(40, (25 + vina.n_atoms) // 3, 10)
+    ref = vina.mc_batch(seeds, c1, c2, P)
+    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
+    ndev = capi.lib().mi_gnina_device_count()
+    devices = list(range(ndev)) if ndev >= 2 else [0, 0, 0]
+    pool = capi.VinaPool(devices)
+
+    def configure(v, rank):  # the same set-up on every device
+        v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+        v.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+        v.set_ligand(sc["lig"])
+
+    pool.configure(configure)
+    out = pool.mc_batch(seeds, c1, c2, P)
+    assert np.array_equal(ref[0], out[0]) and np.array_equal(ref[4], out[4])          # saved minima, evaluation counts
+    for b in range(len(seeds)):                                                       # (rows past out_n are not written)
+        k = ref[0][b]
+        for a in (1, 2, 3):
+            assert np.array_equal(ref[a][b, :k], out[a][b, :k]), (b, a)
+    assert pool.info()["ranks"] == len(devices)
+    # an error inside the callback of one rank is reported, and the pool survives it
+    with pytest.raises(Exception):
+        pool.configure(lambda v, rank: v.set_ligand({"bogus": 1}) if rank == len(devices) - 1 else None)
+    out2 = pool.mc_batch(seeds[:5], c1, c2, P)
+    assert np.array_equal(out2[0], ref[0][:5]) and np.array_equal(out2[1][:, 0], ref[1][:5, 0])

@@ -6,7 +6,7 @@ import pytest
 
 from gnina_amd import synth
 from oracle import vina as V
-from tests import vina_scene
+from gnina_amd import vina_scene
 
 C_H, N_D, O_A, HYD = 2, 7, 13, 0
 

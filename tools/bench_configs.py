@@ -86,7 +86,7 @@ def main():
                           "tflops_forward": B / dt * gf / 1e12, "poses_per_s_forward_backward": B / dg}), flush=True)
         del s
     if want("refine"):
-        from tests import vina_scene
+        from gnina_amd import vina_scene
         sc = vina_scene.build(seed=3)
         lig = sc["lig"]
         v = capi.Vina()

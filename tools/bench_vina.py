@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gnina_amd import capi, synth  # noqa: E402
-from tests import vina_scene  # noqa: E402
+from gnina_amd import vina_scene  # noqa: E402
 
 
 def main():

@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gnina_amd import capi, synth  # noqa: E402
-from tests import vina_scene  # noqa: E402
+from gnina_amd import vina_scene  # noqa: E402
 
 
 def setup_grid_dims(center, size, gran=0.375):   # main.cpp:622-634

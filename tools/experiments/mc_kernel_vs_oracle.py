@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from gnina_amd import capi
 from oracle import vina as V
-from tests import vina_scene
+from gnina_amd import vina_scene
 capi.init(0)
 sc = vina_scene.build(0)
 lig = sc["lig"]

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gnina_amd import capi, synth
-from tests import vina_scene
+from gnina_amd import vina_scene
 from oracle import vina as V
 capi.init(0)
 sc = vina_scene.build(0); lig = sc["lig"]
