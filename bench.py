@@ -318,6 +318,47 @@ def config_c3(capi, cpu_seconds=0.0):
            "total_s": round(t_setup + t_mc + t_tail, 3), "setup_s": round(t_setup, 3), "mc_s": round(t_mc, 3),
            "tail_s": round(t_tail, 3), "mc_evals": int(ev.sum()), "mc_evals_per_s": round(float(ev.sum()) / t_mc),
            "poses_reported": int(len(keep)), "bound": "latency (dependent evaluations); no roofline fraction, SURVEY 8d"}
+    # the bit-exact configuration: mi_vina_set_strict_order (energy sums in the reference's order -- whole chains are then
+    # bit-identical to gnina's, tests/test_gpu_vina_ref.py); timed on steps // 8 of the same 64 chains, both modes
+    try:
+        Ps = capi.McParams.default(max(steps // 8, 50), iters, 50)
+        t0 = time.perf_counter()
+        _, _, _, _, ev_d = vina.mc_batch(seeds, begin, end, Ps)
+        t_def = time.perf_counter() - t0
+        vina.set_strict_order(True)
+        t0 = time.perf_counter()
+        _, _, _, _, ev_s = vina.mc_batch(seeds, begin, end, Ps)
+        t_str = time.perf_counter() - t0
+        vina.set_strict_order(False)
+        res["strict_mode"] = {"steps": int(Ps.n_steps), "default_mode_s": round(t_def, 3), "strict_mode_s": round(t_str, 3),
+                              "strict_over_default": round(t_str / t_def, 3),
+                              "strict_mode_s_full_run_estimate": round(t_mc * t_str / t_def, 2),
+                              "evals_per_s_strict": round(float(ev_s.sum()) / t_str)}
+    except Exception as e:
+        res["strict_mode"] = {"error": f"{type(e).__name__}: {e}"}
+    # the chains over every visible GPU (mi_vina_pool: split by chain id, parallel_mc.cpp:183-214's fan-out over devices)
+    try:
+        ndev = capi.lib().mi_gnina_device_count()
+        if ndev > 1:
+            pool = capi.VinaPool(list(range(ndev)))
+
+            def configure(v, rank):
+                v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+                v.build_cache(begin, end, n, types, 1e3)
+                v.set_ligand(lig)
+
+            t0 = time.perf_counter()
+            pool.configure(configure)
+            t_cfg = time.perf_counter() - t0
+            pool.mc_batch(seeds[:ndev], begin, end, capi.McParams.default(20, iters, 50))
+            t0 = time.perf_counter()
+            pc, pe, _, _, pev = pool.mc_batch(seeds, begin, end, P)
+            t_pool = time.perf_counter() - t0
+            same = bool(np.array_equal(pc, cnt) and all(np.array_equal(pe[b, :cnt[b]], e[b, :cnt[b]]) for b in range(len(seeds))))
+            res["vina_pool"] = {"devices": ndev, "configure_s": round(t_cfg, 3), "mc_s": round(t_pool, 3),
+                                "speedup_over_one_device": round(t_mc / t_pool, 2), "equal_to_one_handle": same}
+    except Exception as e:
+        res["vina_pool"] = {"error": f"{type(e).__name__}: {e}"}
     if cpu_seconds > 0:
         try:
             res["cpu_baseline"] = c3_cpu_port(vina, lig, types, begin, end, n, seeds, steps, iters, cpu_seconds)
@@ -507,6 +548,60 @@ def config_real_complex(capi, synth, torch, dev, args):
             "roofline": {kk: rb[kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                                "mfma_executed_fraction", "algorithmic_equivalent_tflops")},
             "score_delta_vs_cpu_oracle": {"poses": nchk, "max_abs_dpose": dp, "max_abs_daffinity": da}}
+
+
+def config_seam_b1(capi, synth):
+    """What an UNMODIFIED gnina sees through the DLScorer seam: one pose per call (DLScorer::score, cnn_torch_scorer.cpp:105-198;
+    do_search's rescoring tail makes up to 50 of them per ligand, main.cpp:324-361), host pointers, synchronous.  Per-call
+    latency on the default (split-fp16) path, forward and forward + backward, from one thread and from four threads with
+    one scorer each (gnina's threading model: one fresh_copy() per worker, main.cpp:1438)."""
+    import threading
+    rng = np.random.RandomState(0)
+    m0 = capi.Model("crossdock_default2018")
+    rt, lt = synth.mapped_types(m0.chan_of_smt(False)), synth.mapped_types(m0.chan_of_smt(True))
+    rec_xyz, rec_smt = synth.make_receptor(rng, 2500, rt)
+    lx, ls = synth.make_ligand(rng, 32, lt)
+    pose1 = synth.make_poses(rng, lx, 1)
+    out = {"note": "B = 1 per call, host pointers, synchronous; median of 60 calls after 10 warm-up calls; microseconds"}
+    for label, models in (("default2017", ["default2017"]),
+                          ("default_ensemble", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])):
+        s = capi.Scorer(models)
+        s.set_receptor(rec_xyz, rec_smt)
+        row = {}
+        for grad in (False, True):
+            f = (lambda: s.score_grad(pose1, ls)) if grad else (lambda: s.score_batch(pose1, ls))
+            for _ in range(10):
+                f()
+            ts = []
+            for _ in range(60):
+                t0 = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t0)
+            row["fwd_bwd_us" if grad else "fwd_us"] = round(float(np.median(ts)) * 1e6, 1)
+        # four worker threads, one scorer each (ctypes releases the GIL during the call)
+        scorers = []
+        for _ in range(4):
+            si = capi.Scorer(models)
+            si.set_receptor(rec_xyz, rec_smt)
+            si.score_batch(pose1, ls)
+            scorers.append(si)
+        n_calls = 40
+
+        def work(si):
+            for _ in range(n_calls):
+                si.score_batch(pose1, ls)
+
+        th = [threading.Thread(target=work, args=(si,)) for si in scorers]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        row["four_threads_poses_per_s"] = round(4 * n_calls / dt, 1)
+        row["one_thread_poses_per_s"] = round(1e6 / row["fwd_us"], 1)
+        out[label] = row
+    return out
 
 
 def config_c4(capi, synth):
@@ -830,7 +925,8 @@ def main():
                 cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
                 for key, fn in (("real_complex", lambda: config_real_complex(capi, synth, torch, dev, args)),
                                 ("c3", lambda: config_c3(capi, cpu_s)), ("c3_real", lambda: config_c3_real(capi, cpu_s)),
-                                ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth))):
+                                ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth)),
+                                ("seam_b1", lambda: config_seam_b1(capi, synth))):
                     try:
                         res["also"][key] = fn()
                     except Exception as e:  # the headline line must still print

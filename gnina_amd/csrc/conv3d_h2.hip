@@ -1273,7 +1273,7 @@ template <int WM, int WN, int TM, int TN> static void launch_h2_k1(const ConvArg
 
 // 3x3x3 layers (conv3d_h2_kernel).  MT = the M-tile geometries compiled for this shape besides raster order (ConvArgs::mt_x);
 // SKIP_OK: the zero-skipping variant exists (the throughput tile of a first conv: the pooled voxel grid)
-template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2_k3(ConvArgs p, int B, hipStream_t s) {
+template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h2_k3(ConvArgs p, int B, hipStream_t s) {
   p.nposes = B;
   const int ngroups = (p.coutp / 32 + WN - 1) / WN;
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
@@ -1316,9 +1316,13 @@ template <int WM, int WN, int TM, int MTALT, bool SKIP_OK> static void launch_h2
     }
     by_input(mt, std::false_type{});
   };
-  if (p.mt_x == 0) by_skip(std::integral_constant<int, 0>{});
-  else if (MTALT != 0 && p.mt_x == MTALT) by_skip(std::integral_constant<int, MTALT>{});
-  else throw Error(2, "launch_conv_h2: M-tile geometry not compiled for this tile shape");
+  bool launched = false;
+  if (p.mt_x == 0) by_skip(std::integral_constant<int, 0>{}), launched = true;
+  if constexpr ((MTMASK & 2) != 0)
+    if (p.mt_x == 1) by_skip(std::integral_constant<int, 1>{}), launched = true;
+  if constexpr ((MTMASK & 4) != 0)
+    if (p.mt_x == 2) by_skip(std::integral_constant<int, 2>{}), launched = true;
+  if (!launched) throw Error(2, "launch_conv_h2: M-tile geometry not compiled for this tile shape");
 }
 
 template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t s) {
@@ -1346,7 +1350,7 @@ bool conv_h2_has_cfg(int cfg) {
 
 int conv_h2_mt_mask(int cfg) {
   switch (cfg) {
-    case CONV_CFG_4x1_2x1:
+    case CONV_CFG_4x1_2x1: return 1 | 2 | 4;
     case CONV_CFG_4x1_4x1: return 1 | 2;
     case CONV_CFG_2x2_3x1: return 1 | 4;
     case CONV_CFG_4x1_1x1: return 1 | 4;
@@ -1359,23 +1363,23 @@ void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1:
       if (k1) launch_h2_k1<4, 1, 2, 1>(p, B, s);
-      else launch_h2_k3<4, 1, 2, 1, true>(p, B, s);
+      else launch_h2_k3<4, 1, 2, 1 | 2 | 4, true>(p, B, s);
       break;
     case CONV_CFG_4x1_4x1:
       if (k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 3x3x3 convolutions only");
-      launch_h2_k3<4, 1, 4, 1, true>(p, B, s);
+      launch_h2_k3<4, 1, 4, 1 | 2, true>(p, B, s);
       break;
     case CONV_CFG_2x2_3x1:
       if (k1) launch_h2_k1<2, 2, 3, 1>(p, B, s);
-      else launch_h2_k3<2, 2, 3, 2, false>(p, B, s);
+      else launch_h2_k3<2, 2, 3, 1 | 4, false>(p, B, s);
       break;
     case CONV_CFG_1x4_7x1:
       if (k1) launch_h2_k1<1, 4, 7, 1>(p, B, s);
-      else launch_h2_k3<1, 4, 7, 0, false>(p, B, s);
+      else launch_h2_k3<1, 4, 7, 1, false>(p, B, s);
       break;
     case CONV_CFG_4x1_1x1:
       if (k1) launch_h2_k1<4, 1, 1, 1>(p, B, s);
-      else launch_h2_k3<4, 1, 1, 2, false>(p, B, s);
+      else launch_h2_k3<4, 1, 1, 1 | 4, false>(p, B, s);
       break;
     case CONV_CFG_4x1_1x3:
       if (!k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 1x1x1 convolutions only");

@@ -364,7 +364,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
 }
 
-static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp);
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post = false);
 
 // ---- split-fp16 twin of a forward conv plan (conv3d_h2.hip) ----
 static unsigned short host_f2h(float f) {  // fp32 -> fp16, round to nearest even, subnormals and overflow handled
@@ -469,7 +469,7 @@ static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt
   if (cycles_out) *cycles_out = best;
 }
 
-static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post) {
   if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
   if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
   ConvArgs a = cp.a;  // geometry, tiles, bias, BatchNorm, ReLU / pool, output slice
@@ -510,6 +510,23 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp) {
         a.ntz = cdiv(cells, 4);
         tm = 4;
         HV = std::max(HV, (size_t)10 * 10 * 10);
+      }
+      // the 6^3 layers (1 x 4 waves x 7 M-tiles, one workgroup per pose): on the split-fp16 kernel the SAME tile as 4 x 1
+      // waves x 2 M-tiles of ONE 32-channel group (the other groups along blockIdx.y: the small input tile is staged once
+      // per group) -- every wave of a workgroup then wants the same B operands, which go through LDS once per workgroup
+      // (and per two poses) instead of through L1 / L2 once per wave, and the launch has four times the workgroups:
+      // 0.35 -> 0.27 ms for 64 -> 128 at 6^3.  (The 12^3 layers, 2 x 2 waves x 3 M-tiles of a 2 x 2 x 6-cell tile, lose
+      // with it -- 0.49 -> 0.58 ms: six M-tiles leave two of the eight slots idle and the tile is staged twice;
+      // MI_GNINA_H2_WN1=all tries them.)  Not with a fused 1x1x1 conv behind it (all its input channels must sit in one
+      // workgroup).
+      const char *wn1 = getenv("MI_GNINA_H2_WN1");
+      const bool wn1_all = wn1 && !strcmp(wn1, "all"), wn1_off = wn1 && !strcmp(wn1, "0");
+      if (!fused_post && !wn1_off && (cp.cfg == CONV_CFG_1x4_7x1 || (wn1_all && cp.cfg == CONV_CFG_2x2_3x1))) {
+        const int n_mt_raster = cdiv(a.tcx * a.tcy * a.tcz, 4);
+        if (n_mt_raster <= 8) {
+          cp.h2_cfg = cfg_here = CONV_CFG_4x1_2x1;
+          wm = 4, wn = 1, tm = 2;
+        }
       }
       const int tc[3] = {a.tcx, a.tcy, a.tcz};
       int mt, py, px;
@@ -850,7 +867,7 @@ static Model *build_model(ModelDesc &&desc) {
         // the split-fp16 twin (not with a fused 1x1 conv).  The gradient
         // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
-        if (!no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv);
+        if (!no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv, post != nullptr);
         if (post && st.conv.has_h2) {
           // the 1x1x1 conv's own split-fp16 plan supplies the packed weights of the fused second pass: its K chunks must
           // be consecutive whole octet pairs ([chunk][pairs][2][coutp][h | l] is then one [pair][2][coutp][h | l] array)
