@@ -492,25 +492,23 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0.f;
       }
-      float dxx[2], dyy[2], dzz[2];
+      // squared distances of this lane's eight voxels, two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations
+      // as the scalar forms, in the same order -- (dx^2 + dy^2) + dz^2 -- at half the instruction count; the kernel's time
+      // is its VALU instruction count)
+      const vox_f32x2 gx2 = {gx[0], gx[1]}, gy2 = {gy[0], gy[1]}, gz2 = {gz[0], gz[1]};
+      const vox_f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+      vox_f32x2 dxx = gx2 - ax2, dyy = gy2 - ay2, dzz = gz2 - az2;
+      dxx = dxx * dxx, dyy = dyy * dyy, dzz = dzz * dzz;
+      const vox_f32x2 dy0 = {dyy[0], dyy[0]}, dy1 = {dyy[1], dyy[1]}, dz0 = {dzz[0], dzz[0]}, dz1 = {dzz[1], dzz[1]};
+      const vox_f32x2 xy0 = dxx + dy0, xy1 = dxx + dy1;          // [dx] for dy = 0 / 1
+      const vox_f32x2 r00 = xy0 + dz0, r01 = xy0 + dz1, r10 = xy1 + dz0, r11 = xy1 + dz1;  // r<dy><dz>[dx]
 #pragma unroll
-      for (int d = 0; d < 2; d++) {
-        float t = gx[d] - ax;
-        dxx[d] = t * t;
-        t = gy[d] - ay;
-        dyy[d] = t * t;
-        t = gz[d] - az;
-        dzz[d] = t * t;
+      for (int dx = 0; dx < 2; dx++) {
+        density_add(acc[dx * 4 + 0], r00[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
+        density_add(acc[dx * 4 + 1], r01[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
+        density_add(acc[dx * 4 + 2], r10[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
+        density_add(acc[dx * 4 + 3], r11[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
       }
-#pragma unroll
-      for (int dx = 0; dx < 2; dx++)
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-          for (int dz = 0; dz < 2; dz++) {
-            float rsq = (dxx[dx] + dyy[dy]) + dzz[dz];
-            density_add(acc[dx * 4 + dy * 2 + dz], rsq, t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
-          }
     }
   }
   flush(cur);
