@@ -35,17 +35,24 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(HERE, "host", "typed_atoms.h"))
     headers.append(os.path.join(HERE, "host", "pdbqt.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
-    objs, rebuilt = [], False
+    objs, todo = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_mtime):
-            cmd = [hipcc()] + FLAGS + ["-c", sp, "-o", op]
+            todo.append([hipcc()] + FLAGS + ["-c", sp, "-o", op])
+    rebuilt = bool(todo)
+    if todo:  # the translation units are independent: compile them side by side (conv3d_h2.hip alone takes ~1.5 min)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(cmd):
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-            rebuilt = True
+
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(one, todo))
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:

@@ -89,18 +89,18 @@ struct ConvArgs {
   int h2_wlds;  // conv3d_h2_kernel variant: the chunk's weights go through LDS, shared by the workgroup's waves; one halo-tile
                 // buffer.  2 = and two consecutive poses per workgroup on one copy of the weights (split-format input)
   int nposes;   // poses of the launch (set by the launcher)
+  int h2_prefetch;  // weights-in-LDS variant: touch the next (chunk, pose) item's tile towards L2 under this item's K loop
   // sticky flag (one word per scorer): an activation left the fp16 range (|a| > 65504, or NaN) where a split-fp16 kernel
   // produced or consumed it -- the call's scores are then recomputed on the fp32-MFMA kernels (engine.cpp)
   unsigned *h2_overflow;
-  int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads
+  int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
 constexpr int kMfmaCountSlots = 1024;
 
 enum { CONV_CFG_4x1_1x3 = 1 /* 1x1 96 -> 96 with one M-tile per wave: <= 128 VGPRs, four waves per SIMD */, CONV_CFG_4x1_2x1 = 0, CONV_CFG_1x4_7x1 = 2, CONV_CFG_N16_TM4 = 3, CONV_CFG_N16_TM3 = 4,
        CONV_CFG_4x1_2x3 = 5, CONV_CFG_4x1_1x5 = 6, CONV_CFG_2x2_3x1 = 7,
-       CONV_CFG_4x1_1x1 = 8, CONV_CFG_N16_TM1 = 9, CONV_CFG_N16_TM2 = 10 /* latency variants: one M-tile per wave */,
-       CONV_CFG_4x1_4x1 = 11 /* conv3d_h2_kernel only: 4 x 4 x 4-cell tiles, four M-tiles per wave (weights loaded once per 128 voxels) */ };
+       CONV_CFG_4x1_1x1 = 8, CONV_CFG_N16_TM1 = 9, CONV_CFG_N16_TM2 = 10 /* latency variants: one M-tile per wave */ };
 
 // MI355X dispatches workgroups round-robin over its 8 XCDs (workgroup i -> XCD i % 8), each with a private
 // 4 MB L2.  Tiles of one pose share halo voxels, K chunks and the candidate list, so a launch re-numbers its

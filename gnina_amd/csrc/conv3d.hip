@@ -947,7 +947,6 @@ void launch_conv(const ConvArgs &p, int cfg, int B, hipStream_t s) {
 void conv_cfg_shape(int cfg, int *wm, int *wn, int *tm, int *tn) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: *wm = 4, *wn = 1, *tm = 2, *tn = 1; break;
-    case CONV_CFG_4x1_4x1: *wm = 4, *wn = 1, *tm = 4, *tn = 1; break;
     case CONV_CFG_4x1_2x3: *wm = 4, *wn = 1, *tm = 2, *tn = 3; break;
     case CONV_CFG_4x1_1x3: *wm = 4, *wn = 1, *tm = 1, *tn = 3; break;
     case CONV_CFG_2x2_3x1: *wm = 2, *wn = 2, *tm = 3, *tn = 1; break;

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   static_assert(!WLDS || WN == 1, "weights in LDS: the four waves of a workgroup share one set of 32 output channels");
   // NP poses per workgroup (WLDS + INSPLIT): the same tile of NP consecutive poses, one after the other, on ONE copy of the
   // chunk's weights in LDS -- the weights are most of what a workgroup pulls out of L2 (143 KB against a 97 KB halo tile)
-  static_assert(NP == 1 || (WLDS && INSPLIT && TM <= 2), "several poses per workgroup: weights-in-LDS variant, split-format input");
+  static_assert(NP == 1 || (NP == 2 && WLDS && INSPLIT && TM <= 2), "two poses per workgroup: weights-in-LDS variant, split-format input");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -621,6 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
       const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
       const bool ok = hx < HX && hy < HY && hz < HZ && (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
       voff[i] = ok ? (unsigned)((x * S + y) * S + z) * 32u + (unsigned)half * 16u : 0x80000000u;  // inside an octet's [voxel][h | l] array
+      if (p.h2_dbg & 32) voff[i] = (unsigned)(((x0 + 1) * S + (y0 + 1)) * S + z0 + 1) * 32u + (unsigned)j * 16u;  // (timing: contiguous sources)
     }
   } else {
     const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
@@ -652,6 +653,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
       for (int i = 0; i < NS; i++)
         if ((i * NW + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LdsPtr)(dst + i * NW * 1024), 16, voff[i], chunk * octet_bytes, 0, 0);
+    }
+  };
+  // L2 prefetch of a tile that will be staged one phase later: a single-buffered tile cannot be DMA'd ahead of time, and
+  // its first-touch lines come from HBM, ~2 us away (measured: 2.3 us per (chunk, pose) phase with nothing else running).
+  // One dword per voxel of the NEXT item's h plane is DMA'd into a 256-byte junk region while this item's K loop runs --
+  // the lines (h and l share a 64-byte sector) are then in L2 when the real DMA asks for them.  Inline asm: the compiler
+  // must not know this writes LDS (it would hold every ds_read of the K loop back until the prefetch has landed).
+  typedef int h2_i32x4 __attribute__((ext_vector_type(4)));
+  auto prefetch_tile = [&](int chunk, int tp) {
+    if constexpr (INSPLIT) {
+      const unsigned long long a = (unsigned long long)(in_b + (size_t)tp * pose_floats);
+      h2_i32x4 rs;
+      rs.x = (int)(a & 0xffffffffull), rs.y = (int)((a >> 32) & 0xffffull), rs.z = (int)(pose_floats * 4), rs.w = 0x00020000;
+      const unsigned junk = (unsigned)(size_t)(s_live + p.nchunks * 4);
+      const int soff = chunk * octet_bytes;
+#pragma unroll
+      for (int i = 0; i < (NS + 1) / 2; i++)
+        if ((i * NW + wave) * 64 < PL) {
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(voff[i]), "s"(junk), "s"(rs), "s"(soff)
+                       : "memory");
+        }
     }
   };
   auto issue_ld = [&](int chunk) {
@@ -799,6 +824,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
         __syncthreads();
         if constexpr (!INSPLIT)
           if (next >= 0) issue_ld(next);  // (in flight during the K loop, which waits for nothing but LDS)
+        if constexpr (INSPLIT) {
+          if (p.h2_prefetch) {  // the next item's tile: towards L2 while this K loop runs
+            if (tp + 1 < NP && tp + 1 < npose) prefetch_tile(chunk, tp + 1);
+            else if (next >= 0) prefetch_tile(next, 0);
+          }
+        }
         const bool live = occ_known ? !(p.h2_dbg & 2) : chunk_live(chunk);
         if (live) {
           const char *tile = s_buf;
@@ -1252,7 +1283,7 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
     conv_h2_planar_geo(p, &sy, &sx, &pl);
     // (h2_wlds: one buffer and the chunk's weights, 14 steps of 2 KB; else two buffers)
     const size_t tiles = p.h2_wlds ? (size_t)2 * pl * 16 + 14 * 2048 : (size_t)4 * pl * 16;
-    return std::max(tiles + 32 * sizeof(int) + (size_t)p.nchunks * 4 * sizeof(int), mid_bytes);
+    return std::max(tiles + 32 * sizeof(int) + (size_t)p.nchunks * 4 * sizeof(int) + 256 /* prefetch_tile's junk region */, mid_bytes);
   }
   const int halo = p.ksize == 3 ? 1 : 0;
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
@@ -1334,7 +1365,6 @@ template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t
 bool conv_h2_has_cfg(int cfg) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1:
-    case CONV_CFG_4x1_4x1:
     case CONV_CFG_2x2_3x1:
     case CONV_CFG_1x4_7x1:
     case CONV_CFG_4x1_1x3:
@@ -1351,7 +1381,6 @@ bool conv_h2_has_cfg(int cfg) {
 int conv_h2_mt_mask(int cfg) {
   switch (cfg) {
     case CONV_CFG_4x1_2x1: return 1 | 2 | 4;
-    case CONV_CFG_4x1_4x1: return 1 | 2;
     case CONV_CFG_2x2_3x1: return 1 | 4;
     case CONV_CFG_4x1_1x1: return 1 | 4;
     default: return 1;
@@ -1364,10 +1393,6 @@ void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s) {
     case CONV_CFG_4x1_2x1:
       if (k1) launch_h2_k1<4, 1, 2, 1>(p, B, s);
       else launch_h2_k3<4, 1, 2, 1 | 2 | 4, true>(p, B, s);
-      break;
-    case CONV_CFG_4x1_4x1:
-      if (k1) throw Error(2, "launch_conv_h2: tile configuration compiled for 3x3x3 convolutions only");
-      launch_h2_k3<4, 1, 4, 1 | 2, true>(p, B, s);
       break;
     case CONV_CFG_2x2_3x1:
       if (k1) launch_h2_k1<2, 2, 3, 1>(p, B, s);

@@ -499,18 +499,7 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post) {
     if (a.coutp != 16 && o.ksize == 1 && a.mt_x) return;
     if (planar) {
       if (wm * wn != 4) return;
-      // the pooled-grid-sized layers (8 M-tile workgroups of 4 x 4 x 2 cells): 4 x 4 x 4 cells with FOUR M-tiles per wave
-      // instead -- a wave's B operands (weights, from L1 / L2: the K loop's bottleneck, measured) then feed 128 voxels, and
-      // the halo shrinks from 2.34x to 1.95x.  Not with a fused 1x1x1 conv behind it (its mid tile is sized for 3 M-tiles).
       int cfg_here = cp.cfg;
-      const int cells = a.S / 2;
-      if (cp.cfg == CONV_CFG_4x1_2x1 && cells % 4 == 0 && a.tcx == 4 && a.tcy == 4 && a.tcz == 2 && getenv("MI_GNINA_H2_TM4")) {
-        cp.h2_cfg = cfg_here = CONV_CFG_4x1_4x1;
-        a.tcz = 4;
-        a.ntz = cdiv(cells, 4);
-        tm = 4;
-        HV = std::max(HV, (size_t)10 * 10 * 10);
-      }
       // the 6^3 layers (1 x 4 waves x 7 M-tiles, one workgroup per pose): on the split-fp16 kernel the SAME tile as 4 x 1
       // waves x 2 M-tiles of ONE 32-channel group (the other groups along blockIdx.y: the small input tile is staged once
       // per group) -- every wave of a workgroup then wants the same B operands, which go through LDS once per workgroup
@@ -1659,6 +1648,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                 // 1.9-2.0 ms (weights from L1 / L2, double-buffered tile) on the headline's first conv; MI_GNINA_H2_WLDS=0/1/2)
                 const char *ev = getenv("MI_GNINA_H2_WLDS");
                 h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
+                // (L2 prefetch of the next item's tile under this item's K loop: measured, no gain -- 1.722 vs 1.717 ms; opt-in)
+                h.h2_prefetch = (getenv("MI_GNINA_H2_PF") && atoi(getenv("MI_GNINA_H2_PF")) != 0) ? 1 : 0;
               }
               h.in_split = is_split(st.conv.src) ? 1 : 0;
               h.out_split = is_split(st.conv.dst) ? 1 : 0;
