@@ -2258,6 +2258,19 @@ mi_status mi_scorer_score_grad(mi_scorer *sc, const float *lig_xyz, const int32_
   MI_CATCH_STATUS
 }
 
+mi_status mi_debug_h2_layout(const int32_t *tile_cells3, int n_mtiles, int geometry_mask, int32_t *mt_pad_y_pad_x, float *cycles) {
+  MI_TRY
+  MIG_CHECK(tile_cells3 && mt_pad_y_pad_x && n_mtiles > 0, 1, "bad arguments");
+  const int tc[3] = {tile_cells3[0], tile_cells3[1], tile_cells3[2]};
+  int mt, py, px;
+  double c = 0;
+  h2_choose_layout(tc, n_mtiles, geometry_mask, mt, py, px, &c);
+  mt_pad_y_pad_x[0] = mt, mt_pad_y_pad_x[1] = py, mt_pad_y_pad_x[2] = px;
+  if (cycles) *cycles = (float)c;
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
 mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, uint16_t *lo, float *scale_out) {
   MI_TRY
   MIG_CHECK(n >= 0 && (n == 0 || (x && hi && lo)), 1, "bad arguments");

@@ -135,6 +135,11 @@ enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
 /* calls of this scorer that were repeated on the fp32-MFMA kernels because of the range flag (diagnostics, tests) */
 int mi_scorer_h2_fallbacks(const mi_scorer *);
+/* Test hook (host only): the LDS layout the engine picks for the planar halo tile of the 3x3x3 split-fp16 kernel
+ * (conv3d_h2.hip) -- tile of tile_cells3 2x2x2 cells, n_mtiles M-tile slots per workgroup, geometry_mask bit m = M-tile
+ * geometry m compiled (0 raster, 1 stacked along x, 2 a 2 x 2 square in (x, y)) -> {geometry, pad slots per z-row, per
+ * x-plane} and the bank model's mean LDS cycles per ds_read_b128 lane group (1.0 = conflict free). */
+mi_status mi_debug_h2_layout(const int32_t *tile_cells3, int n_mtiles, int geometry_mask, int32_t *mt_pad_y_pad_x, float *cycles);
 /* Diagnostic, host only (no device needed): the operand split of the split-fp16 kernels as the model loader applies it
  * to the weights -- hi[i] = RN_fp16(x[i] * scale), lo[i] = RN_fp16(x[i] * scale - hi[i]) as IEEE binary16 bit patterns
  * (round to nearest even, subnormals kept).  scale = 0 picks the per-layer power of two the loader would: the one that

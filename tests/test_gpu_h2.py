@@ -102,3 +102,27 @@ def test_fused_1x1_conv_gives_the_bits_of_two_launches(capi, CG, monkeypatch):
         monkeypatch.delenv("MI_GNINA_H2_NO_FUSE1X1", raising=False)
     assert np.array_equal(out[0]["pose"], out[1]["pose"]) and np.array_equal(out[0]["affinity"], out[1]["affinity"])
     assert np.abs(out[0]["pose"][:4] - CG[name + "/pose"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018"])
+def test_two_poses_per_workgroup_and_an_odd_batch(capi, CG, name):
+    """the throughput tiles of the first conv take two consecutive poses per workgroup on one copy of the weights in LDS
+    (conv3d_h2_kernel NP = 2); an odd batch leaves the last workgroups one pose.  Same K order: every pose scores the bits
+    it scores alone, and MI_GNINA_H2_WLDS=0 (weights from L1 / L2, one pose per workgroup) gives the same bits."""
+    from gnina_amd import synth
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = np.concatenate([poses, synth.make_poses(np.random.RandomState(13), poses[0] - poses[0].mean(0), 93)])   # 97 poses
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    big = s.score_batch(many, lig_smt)
+    even = s.score_batch(many[:96], lig_smt)
+    assert np.array_equal(big["pose"][:96], even["pose"]) and np.array_equal(big["affinity"][:96], even["affinity"])
+    for b in (0, 95, 96):
+        one = s.score_batch(many[b:b + 1], lig_smt)
+        assert one["pose"][0] == big["pose"][b] and one["affinity"][0] == big["affinity"][b], b
+    os.environ["MI_GNINA_H2_WLDS"] = "0"
+    try:
+        plain = s.score_batch(many, lig_smt)
+    finally:
+        del os.environ["MI_GNINA_H2_WLDS"]
+    assert np.array_equal(plain["pose"], big["pose"]) and np.array_equal(plain["affinity"], big["affinity"])

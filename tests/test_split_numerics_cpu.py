@@ -71,3 +71,54 @@ def test_the_loaders_split_is_this_split(layer):
     h, l = _split(torch.from_numpy(w32).double(), torch.float16, sw)
     assert sw == 2.0 ** (13 - np.floor(np.log2(np.abs(w32).max())))
     assert np.array_equal(hi.astype(np.float64), h.numpy()) and np.array_equal(lo.astype(np.float64), l.numpy())
+
+
+def test_lds_layout_of_the_planar_halo_tile_is_conflict_free_for_the_shipped_tiles():
+    """conv3d_h2_kernel's A operands are ds_read_b128 of a planar [h plane | l plane] halo tile; the engine picks the M-tile
+    geometry and the pad slots with a bank model of MI355X's LDS (a group of 16 lanes is served in as many cycles as the
+    largest number of its lanes that hit one 16-byte slot modulo 16 at different addresses).  Restated here, lane groups
+    from the microarchitecture guide; the shipped networks' tiles must come out conflict free (the 6^3 tile: 2.0, raster
+    order over an odd tile is all its kernel shape offers), and the engine's pick must be what the restatement finds."""
+    import ctypes as C
+    from gnina_amd import capi
+    L = capi.lib()
+    L.mi_debug_h2_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+
+    def cycles(tc, mt, py, px):
+        tcx, tcy, tcz = tc
+        nc = tcx * tcy * tcz
+        hy, hz = 2 * tcy + 2, 2 * tcz + 2
+        sy = hz + py
+        sx = hy * sy + px
+        n_mt = tcx // 4 * tcy * tcz if mt == 1 else tcz if mt == 2 else (nc + 3) // 4
+        tot = 0
+        for m in range(n_mt):
+            base = []
+            for row in range(32):
+                oz, oy, ox, cim = row & 1, (row >> 1) & 1, (row >> 3) & 1, ((row >> 2) & 1) + 2 * ((row >> 4) & 1)
+                if mt == 1:
+                    cz, cy, cx = m % tcz, (m // tcz) % tcy, 4 * (m // (tcz * tcy)) + cim
+                elif mt == 2:
+                    cz, cy, cx = m, cim & 1, cim >> 1
+                else:
+                    cell = min(4 * m + cim, nc - 1)
+                    cz, cy, cx = cell % tcz, (cell // tcz) % tcy, cell // (tcz * tcy)
+                base.append((2 * cx + ox) * sx + (2 * cy + oy) * sy + 2 * cz + oz)
+            for g in groups:
+                per = {}
+                for lane in g:
+                    per.setdefault(base[lane] % 16, set()).add(base[lane])
+                tot += max(len(v) for v in per.values())
+        return tot / (2.0 * n_mt)
+
+    for tc, n_mtiles, mask, want in (((4, 4, 2), 8, 1 | 2 | 4, 1.0), ((2, 2, 6), 6, 1 | 4, 1.0), ((3, 3, 3), 8, 1 | 2 | 4, 2.0),
+                                     ((2, 2, 4), 4, 1 | 4, 1.0), ((2, 2, 3), 4, 1 | 4, 1.0)):
+        tcv = np.array(tc, dtype=np.int32)
+        out = np.zeros(3, dtype=np.int32)
+        cyc = C.c_float()
+        assert L.mi_debug_h2_layout(tcv.ctypes.data, n_mtiles, mask, out.ctypes.data, C.byref(cyc)) == 0
+        mt, py, px = (int(v) for v in out)
+        assert (mask >> mt) & 1
+        assert abs(cycles(tc, mt, py, px) - cyc.value) < 1e-6, (tc, mt, py, px)
+        assert abs(cyc.value - want) < 1e-6, (tc, mt, py, px, cyc.value)
