@@ -6,18 +6,25 @@
 //     a * w  ~=  h_a * h_w  +  h_a * l_w  +  l_a * h_w                      (dropped: l_a * l_w, relative 2^-22)
 // = three MFMAs where the fp32 kernels (conv3d.hip) issue eight for the same K = 16: 5.3x their matrix rate.  Weights are
 // split once at model load, scaled by a per-layer power of two (exact; it keeps their low parts out of the fp16 subnormal
-// range) that the epilogue takes out again; activations are split while the halo tile is staged (after the eval
-// BatchNorm, which stays fp32), so HBM holds plain fp32 tensors and this kernel is interchangeable, layer by layer, with
-// the fp32 kernels of the same program.  Measured against the float64 forward of the same operands the scores move by
-// <= 1e-6 (tools/experiments/split_precision_probe.py; the parity bar is 1e-4) -- unlike the bf16 kernels
-// (conv3d_bf16.hip: 4e-2), this IS a parity path.  Forward only (scoring calls and the forward half of gradient calls):
-// the transposed convolutions of the backward pass stay on the fp32 kernels.
+// range) that the epilogue takes out again.  Activations are split either by their PRODUCER -- the voxelizer's pooled
+// store, a conv3d_h2_kernel epilogue: the tensor then lives in HBM as [pose][octet][x][y][z][h8 | l8] ("split format",
+// conv3d.h ConvArgs::in_split) and the consumer stages it by LDS-DMA -- or while an fp32 tensor is staged (after the eval
+// BatchNorm, which stays fp32): layer by layer the kernels here are interchangeable with the fp32 kernels of the same
+// program, and a layer computes the same bits from either kind of input.  Measured against the float64 forward of the
+// same operands the scores move by <= 1e-6 (tools/experiments/split_precision_probe.py; the parity bar is 1e-4) -- unlike
+// the bf16 kernels (conv3d_bf16.hip: 4e-2), this IS a parity path.  An activation beyond the fp16 range raises the scorer's
+// flag (h2_report_overflow) and the call is repeated on the fp32 kernels (engine.cpp).  Forward only (scoring calls and
+// the forward half of gradient calls): the transposed convolutions of the backward pass stay on the fp32 kernels.
 //
+// Three kernels:
+//   conv3d_h2_kernel     3x3x3 layers, 32 output channels per wave column: one octet per K chunk, planar halo tile in LDS,
+//                        LDS-DMA staging of split-format inputs, the chunk's weights through LDS
+//   conv3d_h2_k1_kernel  1x1x1 layers (round 3's kernel): [voxel][octet][h | l] tile, fp32 input split while staging
+//   conv3d_h2_16_kernel  the Dense blocks' 16-channel layers (v_mfma_f32_16x16x32_f16)
 // Decomposition as in conv3d.hip: a workgroup owns a box of 2x2x2 cells of one pose and all (or a group of) output
 // channels; an M-tile is 32 voxels = four cells, so ReLU + pooling stay register-local in the 32x32 accumulator layout.
-// K runs over OCTETS (8 consecutive input channels at one tap), channel-major inside a K chunk; lanes 0-31 feed k = 0..7
-// of an instruction from octet 2p, lanes 32-63 k = 8..15 from octet 2p + 1.  LDS holds the halo tile as
-// [voxel][octet][h0..h7 | l0..l7] fp16: one lane's A operands of a step are 32 contiguous bytes (two ds_read_b128).
+// K runs over OCTETS (8 consecutive input channels at one tap); lanes 0-31 feed k = 0..7 of an instruction, lanes 32-63
+// k = 8..15 (the next octet of the chunk, or -- conv3d_h2_kernel -- the next tap of the same octet).
 #include "common.h"
 #include "conv3d.h"
 
