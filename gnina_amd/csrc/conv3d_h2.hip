@@ -574,31 +574,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   // is staged, and an all-zero chunk -- the ligand's channels in every tile away from the ligand -- costs no DMA, no
   // barrier, nothing.  Without them the staging finds out (s_live, one flag per chunk and wave). ----
   unsigned todo = p.nchunks >= 32 ? 0xffffffffu : ((1u << p.nchunks) - 1u);
+  unsigned todo_p[NP];  // per pose of this workgroup
+#pragma unroll
+  for (int tp = 0; tp < NP; tp++) todo_p[tp] = todo;
   bool occ_known = false;
   if constexpr (SKIP && INSPLIT) {
-    if (NP == 1 && p.in_occ && p.nchunks <= 8) {
+    if (p.in_occ && p.nchunks <= 8) {
       // blocks the halo tile touches, per axis: voxels [x0, x0 + HX) -> blocks (x0 >> 2) .. ((x0 + HX - 1) >> 2)
       const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
       const int nbx = ((x0 + HX - 1) >> 2) - bx0 + 1, nby = ((y0 + HY - 1) >> 2) - by0 + 1, nbz = ((z0 + HZ - 1) >> 2) - bz0 + 1;
       if (nbx * nby * nbz <= 64) {
+        // wave tp reads pose tp's blocks (NP <= 4 waves) and reduces them to a mask of live octets
         uint2 o8 = make_uint2(0u, 0u);
-        if (tid < nbx * nby * nbz) {
-          const int bz = bz0 + tid % nbz, by = by0 + (tid / nbz) % nby, bx = bx0 + tid / (nbz * nby);
+        if (wave < npose && lane < nbx * nby * nbz) {
+          const int bz = bz0 + lane % nbz, by = by0 + (lane / nbz) % nby, bx = bx0 + lane / (nbz * nby);
           const int nt = p.occ_nt;
           if ((unsigned)bx < (unsigned)nt && (unsigned)by < (unsigned)nt && (unsigned)bz < (unsigned)nt)
-            o8 = *reinterpret_cast<const uint2 *>(p.in_occ + (((size_t)b * nt + bx) * nt + by) * nt * 8 + (size_t)bz * 8);
+            o8 = *reinterpret_cast<const uint2 *>(p.in_occ + (((size_t)(b + wave) * nt + bx) * nt + by) * nt * 8 + (size_t)bz * 8);
         }
-        if (wave == 0) {
+        if (wave < NP) {
           unsigned m = 0u;
 #pragma unroll
           for (int o = 0; o < 8; o++) {
             const unsigned byte = ((o < 4 ? o8.x : o8.y) >> (8 * (o & 3))) & 0xffu;
             if (__builtin_amdgcn_ballot_w64(byte != 0u) != 0ull) m |= 1u << o;
           }
-          if (lane == 0) s_live[0] = (int)m;
+          if (lane == 0) s_live[wave] = (int)m;
         }
         __syncthreads();
-        todo &= (unsigned)__builtin_amdgcn_readfirstlane(s_live[0]);
+        todo = 0u;
+#pragma unroll
+        for (int tp = 0; tp < NP; tp++) {
+          todo_p[tp] &= (unsigned)__builtin_amdgcn_readfirstlane(s_live[tp]);
+          if (tp < npose) todo |= todo_p[tp];
+        }
         occ_known = true;
         __syncthreads();  // (s_live is reused below when a later launch path writes it: keep the read ahead of any write)
       }
@@ -819,13 +828,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
     while (chunk >= 0) {
       const unsigned rest = chunk >= 31 ? 0u : (todo & ~((2u << chunk) - 1u));
       const int next = rest ? __builtin_ctz(rest) : -1;
+      bool w_here = false;  // this chunk's weights are in LDS
       auto pose_pass = [&](auto tpc) __attribute__((always_inline)) {
         constexpr int tp = decltype(tpc)::value;
+        if (occ_known && !((todo_p[tp] >> chunk) & 1u)) return;  // (the occupancy bytes say: nothing of this pose in this chunk)
         if (!first) __syncthreads();  // every wave is through the previous K loop: tile (and weights) may be overwritten
         first = false;
         if constexpr (INSPLIT) issue_dma(chunk, 0, tp);
         else commit(chunk, 0);
-        if (tp == 0) issue_w(chunk);
+        if (!w_here) issue_w(chunk);
+        w_here = true;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if constexpr (INSPLIT) probe_dma(chunk, 0);
         __syncthreads();
