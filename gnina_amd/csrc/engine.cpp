@@ -104,6 +104,12 @@ struct Step {
   ConvPlan conv;         // Conv
   ConvPlan bwd;          // Conv: transposed twin for the gradient pass (grad program only)
   bool has_bwd = false;
+  // The transposed FIRST conv computes d loss / d (pooled grid); voxel_backward then reads the channels of the atoms that
+  // move.  With a rigid receptor those are the ligand's channels only: bwd_lig is the same transposed conv restricted to
+  // output channels [lig_c0, C) -- for Default2017 (16 + 19 channels) one 32-wide N tile instead of two (35 -> 64).
+  ConvPlan bwd_lig;
+  bool has_bwd_lig = false;
+  int lig_c0 = 0;
   bool has_bn = false;
   int src = -1, dst = -1;
   int pool_mode = 0;     // Pool
@@ -915,6 +921,23 @@ static Model *build_model(ModelDesc &&desc) {
           }
           // a Dense-block layer reads and extends the same concat buffer: its input gradient accumulates
           st.bwd.a.accumulate = o.src == o.dst ? 1 : 0;
+          const int c0 = d.recmap.n_channels;
+          if (o.src == m->input_dst && !st.has_bn && o.src != o.dst && c0 > 0 && c0 < o.cin &&
+              cdiv(o.cin - c0, 32) < cdiv(o.cin, 32) && !getenv("MI_GNINA_NO_LIG_BWD")) {
+            // forward weights restricted to the ligand's input channels, appended to the payload: [tap][cin - c0][cout]
+            const int taps = o.ksize * o.ksize * o.ksize, csub = o.cin - c0;
+            Op osub = o;
+            osub.cin = csub;
+            osub.w_off = (long)d.data.size();
+            d.data.resize(d.data.size() + (size_t)taps * csub * o.cout);
+            for (int tp = 0; tp < taps; tp++)
+              for (int ci = 0; ci < csub; ci++)
+                for (int co = 0; co < o.cout; co++)
+                  d.data[(size_t)osub.w_off + ((size_t)tp * csub + ci) * o.cout + co] = d.data[(size_t)o.w_off + ((size_t)tp * o.cin + c0 + ci) * o.cout + co];
+            plan_conv(*m, make_bwd_op(osub), st.bwd_lig, 0, o.src, c0, true);
+            st.has_bwd_lig = true;
+            st.lig_c0 = c0;
+          }
         }
         m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
       } else if (o.kind == OpKind::Pool) {
@@ -1738,7 +1761,10 @@ static float *run_backward(Scorer &s, int mi, int nb) {
       }
       case OpKind::Conv: {
         MIG_CHECK(st.has_bwd, 1, "gradient not supported for this layer");
-        ConvArgs a = st.bwd.a;
+        // (rigid receptor: the first conv's transposed twin computes the ligand's channels of the grid gradient only)
+        const bool lig_only = st.has_bwd_lig && !bf16 && (s.cur_flex == nullptr || s.flex_rows.empty());
+        const ConvPlan &bp = lig_only ? st.bwd_lig : st.bwd;
+        ConvArgs a = bp.a;
         const int dst = st.conv.dst, src = st.conv.src;
         a.in = g_ptr(dst) + st.conv.a.out_c0;  // Dense layers: the 16-channel slice this conv produced
         a.in_cs = m->buf_cp[dst];
@@ -1758,16 +1784,17 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         a.out = g_ptr(src);
         a.out_cs = m->buf_cp[src];
         char nm[96];
-        snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d", a.ksize, a.S, st.conv.a.cout, st.conv.cin);
+        const int cout_here = lig_only ? st.conv.cin - st.lig_c0 : st.conv.cin;  // grid-gradient channels this launch computes
+        snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d%s", a.ksize, a.S, st.conv.a.cout, cout_here, lig_only ? "_lig" : "");
         const double S3 = (double)a.S * a.S * a.S;
         if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
-        ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * st.conv.cin * st.conv.a.cout, 0.0, nb);
+        ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * cout_here * st.conv.a.cout, 0.0, nb);
         if (bf16) {
           a.sparse = 0;
           launch_conv_bf16(a, st.bwd.cfg, nb, s.stream);
         } else {
           int cfg;
-          pick_tile(st.bwd, nb, a, cfg);
+          pick_tile(bp, nb, a, cfg);
           launch_conv(a, cfg, nb, s.stream);
         }
         break;
