@@ -733,8 +733,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
     const float *src_c = in_b + c_base;
     const int nq = min(CC4, p.cin4 - chunk * CC4);
     constexpr int U = 4;
-    auto stage = [&](auto has_bn) {
-      constexpr bool BN = decltype(has_bn)::value;
+    // MASK (in_mode 1: this launch is a transposed conv behind a ReLU): the gradient passes where the forward activation
+    // was > 0 -- same voxel offsets in the activation tensor (in_act_cs == in_cs: both are strides of the conv's output buffer)
+    const float *act_c = p.in_mode == 1 ? p.in_act + (size_t)b * S * S * S * p.in_act_cs + c_base : nullptr;
+    auto stage = [&](auto has_bn, auto has_mask) {
+      constexpr bool BN = decltype(has_bn)::value, MASK = decltype(has_mask)::value;
       for (int hv = tid; hv < HV; hv += NTHREADS) {
         const int off = s_vox[hv];
         if (off < 0) continue;
@@ -742,39 +745,57 @@ __global__ __launch_bounds__(256) void conv3d_mfma16_kernel(ConvArgs p) {
         const float *src = src_c + off;
         int qb = 0;
         for (; qb + U <= nq; qb += U) {
-          float4 val[U];
+          float4 val[U], act[U];
           BnQuad bn[U];
 #pragma unroll
           for (int u = 0; u < U; u++) {
             val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+            if constexpr (MASK) act[u] = *reinterpret_cast<const float4 *>(act_c + off + (qb + u) * 4);
             if constexpr (BN) bn[u] = bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4);
           }
 #pragma unroll
           for (int u = 0; u < U; u++) {
             float4 x = val[u];
+            if constexpr (MASK) {
+              x.x = act[u].x > 0.f ? x.x : 0.f;
+              x.y = act[u].y > 0.f ? x.y : 0.f;
+              x.z = act[u].z > 0.f ? x.z : 0.f;
+              x.w = act[u].w > 0.f ? x.w : 0.f;
+            }
             if constexpr (BN) bn_apply(x, bn[u]);  // eval BatchNorm on the conv input; padding stays exactly 0
             *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
           }
         }
         if (qb < nq) {  // the tail of 1 .. U - 1 quads, its loads batched as well
-          float4 val[U - 1];
+          float4 val[U - 1], act[U - 1];
 #pragma unroll
           for (int u = 0; u < U - 1; u++)
-            if (qb + u < nq) val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+            if (qb + u < nq) {
+              val[u] = *reinterpret_cast<const float4 *>(src + (qb + u) * 4);
+              if constexpr (MASK) act[u] = *reinterpret_cast<const float4 *>(act_c + off + (qb + u) * 4);
+            }
 #pragma unroll
           for (int u = 0; u < U - 1; u++)
             if (qb + u < nq) {
               float4 x = val[u];
+              if constexpr (MASK) {
+                x.x = act[u].x > 0.f ? x.x : 0.f;
+                x.y = act[u].y > 0.f ? x.y : 0.f;
+                x.z = act[u].z > 0.f ? x.z : 0.f;
+                x.w = act[u].w > 0.f ? x.w : 0.f;
+              }
               if constexpr (BN) bn_apply(x, bn_load(p.bn_scale, p.bn_shift, c_base + (qb + u) * 4));
               *reinterpret_cast<float4 *>(dst + (qb + u) * 4) = x;
             }
         }
       }
     };
-    if (p.bn_scale)
-      stage(std::true_type{});
+    if (p.in_mode == 1)
+      stage(std::false_type{}, std::true_type{});  // (a transposed conv has no BatchNorm on its input)
+    else if (p.bn_scale)
+      stage(std::true_type{}, std::false_type{});
     else
-      stage(std::false_type{});
+      stage(std::false_type{}, std::false_type{});
     if (nq < CC4)  // partial last chunk: its missing quads still hold the previous chunk's channels
       for (int it = tid; it < HV * (CC4 - nq); it += NTHREADS) {
         const int hv = it / (CC4 - nq), c4 = nq + it - hv * (CC4 - nq);

@@ -178,7 +178,7 @@ static Op make_bwd_op(const Op &o) {
 }
 
 static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0,
-                      bool backward = false) {
+                      bool backward = false, bool n16_backward = false) {
   const int S = m.d.bufs[o.src].S;
   MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
   const int cells = S / 2;
@@ -192,7 +192,9 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   a.pool = pool_mode;
   a.out_c0 = dst_c0;
   // workgroup shape
-  const bool n16 = o.cout == 16 && pool_mode == 0 && !backward;  // Dense-block convs: 16-wide MFMA tiles
+  // Dense-block convs: 16-wide MFMA tiles -- and (n16_backward) a transposed first conv that only has to produce the <= 16
+  // ligand channels of the grid gradient (ReLU-masked input, in_mode 1, which the 16-wide kernel stages; not the max-unpool)
+  const bool n16 = (o.cout == 16 && pool_mode == 0 && !backward) || (backward && n16_backward && o.cout <= 16);
   if (n16) {
     a.coutp = 16;
     if (cells == 6) {
@@ -922,8 +924,13 @@ static Model *build_model(ModelDesc &&desc) {
           // a Dense-block layer reads and extends the same concat buffer: its input gradient accumulates
           st.bwd.a.accumulate = o.src == o.dst ? 1 : 0;
           const int c0 = d.recmap.n_channels;
-          if (o.src == m->input_dst && !st.has_bn && o.src != o.dst && c0 > 0 && c0 < o.cin &&
-              cdiv(o.cin - c0, 32) < cdiv(o.cin, 32) && !getenv("MI_GNINA_NO_LIG_BWD")) {
+          // (fewer 32-wide N tiles -- Default2017: 35 -> 19 channels, two tiles -> one -- or few enough channels for the
+          // 16-wide kernel: Default2018 / Dense, 28 -> 14; that kernel masks by the ReLU but does not un-pool, so not behind
+          // a fused max pool)
+          const bool fewer_tiles = cdiv(o.cin - c0, 32) < cdiv(o.cin, 32);
+          const bool n16_bwd = o.cin - c0 <= 16 && pool_mode != 1 && o.ksize == 3 && o.relu;
+          if (o.src == m->input_dst && !st.has_bn && o.src != o.dst && c0 > 0 && c0 < o.cin && (fewer_tiles || n16_bwd) &&
+              !getenv("MI_GNINA_NO_LIG_BWD")) {
             // forward weights restricted to the ligand's input channels, appended to the payload: [tap][cin - c0][cout]
             const int taps = o.ksize * o.ksize * o.ksize, csub = o.cin - c0;
             Op osub = o;
@@ -934,7 +941,7 @@ static Model *build_model(ModelDesc &&desc) {
               for (int ci = 0; ci < csub; ci++)
                 for (int co = 0; co < o.cout; co++)
                   d.data[(size_t)osub.w_off + ((size_t)tp * csub + ci) * o.cout + co] = d.data[(size_t)o.w_off + ((size_t)tp * o.cin + c0 + ci) * o.cout + co];
-            plan_conv(*m, make_bwd_op(osub), st.bwd_lig, 0, o.src, c0, true);
+            plan_conv(*m, make_bwd_op(osub), st.bwd_lig, 0, o.src, c0, true, n16_bwd && !fewer_tiles);
             st.has_bwd_lig = true;
             st.lig_c0 = c0;
           }
