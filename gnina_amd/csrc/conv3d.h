@@ -25,6 +25,8 @@ struct ConvArgs {
   //   in_mode 1: input masked by (in_act > 0) at the same voxel      (ReLU backward)
   //   in_mode 2: max-unpool on load: `in`, `in_argmax`, `in_act` are at S/2; a voxel receives the pooled
   //              gradient iff it was the arg-max of its 2x2x2 cell and the pooled activation was > 0
+  //   in_mode 3: average-unpool on load (generic fp32 kernel only): `in` is at S/2, `in_act` at S; a voxel receives
+  //              1/8 of its cell's gradient iff its own activation was > 0
   int in_mode;
   const unsigned char *in_argmax;  // [B][S/2]^3[in_cs] (in_mode 2)
   const float *in_act;             // mask source; stride in_act_cs

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   int *s_flag = reinterpret_cast<int *>(s_list + Q + 5);  // [nchunks][CC4] "this channel quad is non-zero in the tile"
   int *s_vox = s_flag + p.nchunks * CC4;                 // [HV] voxel index of every halo position inside the pose, -1 = padding
   // [27] sparse list building: .x = byte offset of snake tap i inside the halo tile, .y = its tap index (weight row)
-  int2 *s_tap = reinterpret_cast<int2 *>((reinterpret_cast<size_t>(s_vox + HV) + 7) & ~(size_t)7);  // (8-byte aligned)
+  // (in_mode 3 keeps a second [HV] table behind the first: the voxel's cell in the half-resolution gradient)
+  int2 *s_tap = reinterpret_cast<int2 *>((reinterpret_cast<size_t>(s_vox + (p.in_mode == 3 ? 2 : 1) * HV) + 7) & ~(size_t)7);  // (8-byte aligned)
   const int wstride_i = p.coutp * 4;                     // floats per quad row of packed weights
   auto list_entry = [&](int q, int wrow) -> int2 {
     const int tap = q / CC4, c4 = q - tap * CC4;
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
           : p.in_mode == 0 ? ((x * S + y) * S + z) * p.in_cs  // forward convs: the float offset of the voxel's channel row
                            : (x * S + y) * S + z;
     s_vox[hv] = v;
+    if (p.in_mode == 3) s_vox[HV + hv] = in ? ((x >> 1) * (S >> 1) + (y >> 1)) * (S >> 1) + (z >> 1) : -1;
     // forward staging writes the voxels inside the grid only: the zero padding is laid down once, here
     if (p.in_mode == 0 && !in)
       for (int c = 0; c < CCs; c += 4) *reinterpret_cast<float4 *>(s_tile + hv * CCs + c) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -311,6 +313,14 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
               val[u] = *reinterpret_cast<const float4 *>(p.in + cell * p.in_cs + c);
               am[u] = *reinterpret_cast<const uchar4 *>(p.in_argmax + cell * p.in_cs + c);
               act[u] = *reinterpret_cast<const float4 *>(p.in_act + cell * p.in_act_cs + c);
+            } else if (p.in_mode == 3) {
+              // transposed conv fed by an average-pooled gradient: every voxel of a cell receives 1/8 of the cell's
+              // gradient, masked by its own forward activation -- un-pooled while staging, like the max pool above
+              const int Sh = S >> 1;
+              const size_t cell = (size_t)b * Sh * Sh * Sh + s_vox[HV + hv];
+              const float4 g = *reinterpret_cast<const float4 *>(p.in + cell * p.in_cs + c);
+              val[u] = make_float4(g.x * 0.125f, g.y * 0.125f, g.z * 0.125f, g.w * 0.125f);
+              act[u] = *reinterpret_cast<const float4 *>(p.in_act + ((size_t)b * S * S * S + vi) * p.in_act_cs + c);
             } else {
 #if MI_CONV_EXPERIMENT == 1  // (tools/conv_experiments.sh: staging without its global loads)
               val[u] = make_float4(1.f, 0.5f, 0.25f, 2.f);
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
             v.z = (am[u].z == rr[u] && act[u].z > 0.f) ? v.z : 0.f;
             v.w = (am[u].w == rr[u] && act[u].w > 0.f) ? v.w : 0.f;
           } else {
-            if (p.in_mode == 1) {
+            if (p.in_mode == 1 || p.in_mode == 3) {
               v.x = act[u].x > 0.f ? v.x : 0.f;
               v.y = act[u].y > 0.f ? v.y : 0.f;
               v.z = act[u].z > 0.f ? v.z : 0.f;
@@ -901,7 +911,7 @@ size_t conv_lds_bytes(const ConvArgs &p) {
   const size_t HV = (size_t)(2 * p.tcx + 2 * halo) * (2 * p.tcy + 2 * halo) * (2 * p.tcz + 2 * halo);
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   // (the N = 16 kernel keeps a [Q + 12] offset table where this one has its [Q + 5] int2 list: sized for the larger)
-  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 6) + p.nchunks * p.cc4 + HV + 1 + 2 * 27) * sizeof(int);
+  const size_t main_bytes = HV * p.ccs * sizeof(float) + (size_t)(2 * (Q + 6) + p.nchunks * p.cc4 + (p.in_mode == 3 ? 2 : 1) * HV + 1 + 2 * 27) * sizeof(int);
   const size_t mid_bytes = p.post_w ? (size_t)p.post_rows * (p.coutp + 4) * sizeof(float) : 0;
   return main_bytes > mid_bytes ? main_bytes : mid_bytes;
 }

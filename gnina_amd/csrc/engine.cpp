@@ -1758,6 +1758,21 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   };
   auto act_ptr = [&](int id) { return act_buf(s, slot_of(id), count_of(id)); };
   auto g_ptr = [&](int id) { return gact_buf(s, slot_of(id), count_of(id)); };
+  // conv + ReLU -> stand-alone average pool (Default2018): the transposed conv un-pools the half-resolution gradient
+  // while it stages (ConvArgs::in_mode 3) and no full-resolution gradient tensor is written in between.  Generic fp32
+  // kernel only; the pool must be the only reader of the conv's output.
+  auto avg_unpool_fused = [&](int ip) {
+    if (bf16 || ip < 1 || ip >= (int)gsteps.size() || getenv("MI_GNINA_NO_UNPOOL_FUSE")) return false;
+    const Step &pl = gsteps[ip], &cv = gsteps[ip - 1];
+    if (pl.kind != OpKind::Pool || pl.pool_mode != 2 || cv.kind != OpKind::Conv || !cv.has_bwd) return false;
+    if (cv.conv.dst != pl.src || !cv.conv.a.relu || cv.conv.a.pool != 0 || cv.conv.a.out_c0 != 0) return false;
+    auto n16 = [](int c) { return c == CONV_CFG_N16_TM1 || c == CONV_CFG_N16_TM2 || c == CONV_CFG_N16_TM3 || c == CONV_CFG_N16_TM4; };
+    if (cv.has_bwd_lig || n16(cv.bwd.cfg) || (cv.bwd.has_lat && n16(cv.bwd.lat_cfg))) return false;
+    for (int j = 0; j < (int)gsteps.size(); j++)
+      if (j != ip && gsteps[j].kind != OpKind::Fc && (gsteps[j].kind == OpKind::Conv ? gsteps[j].conv.src : gsteps[j].src) == pl.src)
+        return false;
+    return true;
+  };
   for (int i = (int)gsteps.size() - 1; i >= 0; i--) {
     const Step &st = gsteps[i];
     switch (st.kind) {
@@ -1783,6 +1798,13 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           a.sparse = 1;  // un-pooled gradient: at most 1 of 8 voxels per cell is non-zero
           a.in_mode = 2;
           a.in_argmax = argm_buf(s, slot_of(dst), count_of(dst));
+        } else if (avg_unpool_fused(i + 1)) {
+          const Step &pl = gsteps[i + 1];
+          a.in = g_ptr(pl.dst);
+          a.in_cs = m->buf_cp[pl.dst];
+          a.in_mode = 3;
+          a.sparse = 0;
+          MIG_CHECK(conv_lds_bytes(a) <= 160 * 1024, 2, "conv tile exceeds LDS");
         } else {
           a.in_mode = st.conv.a.relu ? 1 : 0;
           // a gradient masked by (activation > 0) is as sparse as the ReLU'd activation: per-MFMA zero test
@@ -1818,6 +1840,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
       }
       case OpKind::Pool: {
         MIG_CHECK(st.pool_mode == 2, 1, "gradient of a stand-alone max pool is not supported");
+        if (avg_unpool_fused(i)) break;  // the transposed conv below un-pools while it stages
         ProfScope ps(s, "unpool_avg", 0.0, 0.0, nb);
         launch_unpool_avg(g_ptr(st.dst), g_ptr(st.src), nb, st.C, m->buf_cp[st.dst], m->buf_cp[st.src],
                           m->d.bufs[st.src].S, s.stream);
