@@ -95,6 +95,17 @@ struct ConvArgs {
   // sticky flag (one word per scorer): an activation left the fp16 range (|a| > 65504, or NaN) where a split-fp16 kernel
   // produced or consumed it -- the call's scores are then recomputed on the fp32-MFMA kernels (engine.cpp)
   unsigned *h2_overflow;
+  // Transposed convs of the gradient pass on the split-fp16 kernel (conv3d_h2_kernel, fp32 tensors in and out).  A gradient
+  // has no fixed range: every producer of one records the per-pose maximum of |g| (out_amax: atomicMax of the float's bits),
+  // and the consumer stages g * 2^(14 - exponent(amax)) -- exact, largest staged value in [2^14, 2^15), absolute error of a
+  // split value <= 2^-25 = 2^-39 of the pose's largest -- and un-scales its accumulators by the inverse.  The ReLU mask of
+  // the layer whose output gradient this is, is applied by the PRODUCER of that gradient (out_mask: the forward activation
+  // at the same voxel and channel, idempotent) so that the staging has nothing to look up but, behind a fused max pool, the
+  // arg-max (in_mode 2 on this kernel: `in`, `in_argmax` at S / 2, already masked).
+  const unsigned *in_amax;  // [pose] or nullptr
+  unsigned *out_amax;       // [pose] or nullptr (pool == 0 epilogues: conv3d_mfma_kernel, conv3d_h2_kernel; fc_backward)
+  const float *out_mask;    // channels-last activation tensor of the OUTPUT's shape, stride out_mask_cs; nullptr = no mask
+  int out_mask_cs;
   int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
@@ -139,7 +150,8 @@ void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in,
 
 size_t conv_h2_lds_bytes(const ConvArgs &p);
 bool conv_h2_has_cfg(int cfg);
-int conv_h2_mt_mask(int cfg);  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
+int conv_h2_mt_mask(int cfg);
+bool conv_h2_has_bwd(int cfg);  // the gradient-pass variant of conv3d_h2_kernel exists for this tile shape  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
 void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl);
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);
 
@@ -156,7 +168,9 @@ void launch_fc_heads(const float *in, const float *w, const float *bias, int n_i
 void launch_overlap_forward(const float *grid, int B, long N3, float *pose, float *aff, float *loss, float *ave_out,
                             hipStream_t s);
 void launch_overlap_backward(const float *grid, const float *ave, int B, long N3, float *gg, hipStream_t s);
-void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s);
+// (mask: the FC input's forward activation, g_in = mask > 0 ? g : 0; amax [B]: per-pose max |g_in| bits -- both optional)
+void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s,
+                        const float *mask = nullptr, unsigned *amax = nullptr);
 void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
                        hipStream_t s);
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,

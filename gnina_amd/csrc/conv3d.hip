@@ -586,6 +586,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
     atomicAdd(p.mfma_count + (wg & (kMfmaCountSlots - 1)), (unsigned long long)n_exec);
 
   // ---- epilogue: bias, ReLU, optional 2x2x2 pool, store channels-last ----
+  float out_max = 0.f;  // (ConvArgs::out_amax)
   const int So = p.pool ? S / 2 : S;
   float *out_b = p.out + (size_t)b * So * So * So * p.out_cs + p.out_c0;
   const int ncx = S / 2;  // cells per axis of the whole grid
@@ -639,17 +640,35 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
           out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
         } else {
           const float osc = p.out_scale ? p.out_scale[ch] : 1.0f;
+          if (p.out_mask) {
+            // gradient pass: the ReLU of the layer this gradient belongs to (ConvArgs::out_mask) -- the eight activations
+            // fetched ahead of the first store (a store may alias the next load as far as the compiler knows)
+            const float *mk = p.out_mask + (size_t)b * So * So * So * p.out_mask_cs + ch;
+            float a8[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+              const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+              a8[r] = mk[(((size_t)vx * So + vy) * So + vz) * p.out_mask_cs];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = a8[r] > 0.f ? v[r] : 0.f;
+          }
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
             float *dst = out_b + (((size_t)vx * So + vy) * So + vz) * p.out_cs + ch;
             float val = p.out_scale ? v[r] * osc : v[r];
             if (p.accumulate) val = *dst + val;
+            out_max = fmaxf(out_max, fabsf(val));
             *dst = val;
           }
         }
       }
     }
+  }
+  if (p.out_amax) {
+    for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
+    if (lane == 0 && out_max > 0.f) atomicMax(p.out_amax + b, __float_as_uint(out_max));
   }
 }
 
@@ -1265,22 +1284,41 @@ void launch_overlap_backward(const float *grid, const float *ave, int B, long N3
 // ---- gradient pass helpers --------------------------------------------------------------------
 // d loss / d (fc input).  loss = cross_entropy(log_softmax(z), 1) (torch_model.cpp:192-195) so
 // dz = softmax(z) - onehot(1) = (exp(lp0), exp(lp1) - 1); the affinity head does not enter the loss.
-__global__ void fc_backward_kernel(const float *raw3, const float *w, int n_in, float *g_in) {
+__global__ void fc_backward_kernel(const float *raw3, const float *w, int n_in, float *g_in, const float *mask, unsigned *amax) {
   const int b = blockIdx.y;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n_in) return;
-  const float dz0 = expf(raw3[3 * b + 0]), dz1 = expf(raw3[3 * b + 1]) - 1.0f;
-  const float4 w0 = *reinterpret_cast<const float4 *>(w + i), w1 = *reinterpret_cast<const float4 *>(w + n_in + i);
-  float4 g;
-  g.x = w0.x * dz0 + w1.x * dz1;
-  g.y = w0.y * dz0 + w1.y * dz1;
-  g.z = w0.z * dz0 + w1.z * dz1;
-  g.w = w0.w * dz0 + w1.w * dz1;
-  *reinterpret_cast<float4 *>(g_in + (size_t)b * n_in + i) = g;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n_in) {
+    const float dz0 = expf(raw3[3 * b + 0]), dz1 = expf(raw3[3 * b + 1]) - 1.0f;
+    const float4 w0 = *reinterpret_cast<const float4 *>(w + i), w1 = *reinterpret_cast<const float4 *>(w + n_in + i);
+    g.x = w0.x * dz0 + w1.x * dz1;
+    g.y = w0.y * dz0 + w1.y * dz1;
+    g.z = w0.z * dz0 + w1.z * dz1;
+    g.w = w0.w * dz0 + w1.w * dz1;
+    if (mask) {  // the ReLU behind the FC input, applied here (ConvArgs::out_mask)
+      const float4 a = *reinterpret_cast<const float4 *>(mask + (size_t)b * n_in + i);
+      g.x = a.x > 0.f ? g.x : 0.f;
+      g.y = a.y > 0.f ? g.y : 0.f;
+      g.z = a.z > 0.f ? g.z : 0.f;
+      g.w = a.w > 0.f ? g.w : 0.f;
+    }
+    *reinterpret_cast<float4 *>(g_in + (size_t)b * n_in + i) = g;
+  }
+  if (amax) {  // (NaN: fmaxf drops it -- the consumer's own range check of what it stages catches it)
+    __shared__ float s_m[4];
+    float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+      if (m > 0.f) atomicMax(amax + b, __float_as_uint(m));
+    }
+  }
 }
-
-void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s) {
-  hipLaunchKernelGGL(fc_backward_kernel, dim3((n_in / 4 + 255) / 256, B), dim3(256), 0, s, raw3, w, n_in, g_in);
+void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s, const float *mask,
+                        unsigned *amax) {
+  hipLaunchKernelGGL(fc_backward_kernel, dim3((n_in / 4 + 255) / 256, B), dim3(256), 0, s, raw3, w, n_in, g_in, mask, amax);
 }
 
 // avg_pool3d(2) backward: every voxel of a cell receives 1/8 of the pooled gradient

@@ -482,7 +482,7 @@ typedef __attribute__((address_space(3))) void *LdsPtr;
 // template parameter hipcc 7.2 silently drops the host stubs of the INSPLIT instantiations.)
 constexpr int kH2NS = 8, kH2VPT = 4;
 
-template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT, bool WLDS = false, int NP = 1>
+template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT, bool WLDS = false, int NP = 1, bool BWD = false>
 __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H2_OCC2 : TM <= 3 ? MI_H2_OCC3 : TM <= 4 ? 2 : 1) : (TM <= 2 ? 3 : TM <= 4 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
   constexpr int NW = WM * WN, NTHREADS = 64 * NW;
   static_assert(NW == 4, "staging is laid out for four waves");
@@ -490,6 +490,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   // NP poses per workgroup (WLDS + INSPLIT): the same tile of NP consecutive poses, one after the other, on ONE copy of the
   // chunk's weights in LDS -- the weights are most of what a workgroup pulls out of L2 (143 KB against a 97 KB halo tile)
   static_assert(NP == 1 || (NP == 2 && WLDS && INSPLIT && TM <= 2), "two poses per workgroup: weights-in-LDS variant, split-format input");
+  // BWD: a transposed conv of the gradient pass (ConvArgs::in_amax / in_mode 2 / out_mask / out_amax) -- its own instantiation
+  // so that the forward kernels carry none of its registers
+  static_assert(!BWD || (!INSPLIT && WLDS && NP == 1), "gradient-pass variant: fp32 tensors, weights through LDS");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,11 +566,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; read in profile mode only)
   float amax = 0.f;     // !INSPLIT: running maximum of |staged value| (range check, see split4)
   bool ovf_out = false; // out_split: a value this lane wrote left the fp16 range
+  float out_max = 0.f;  // fp32 output: running maximum of |stored value| (ConvArgs::out_amax)
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
-  const size_t pose_floats = (size_t)S * S * S * p.in_cs;
+  // (!INSPLIT, in_mode 2 -- a transposed conv behind a fused max pool: `in` and `in_argmax` are at S / 2)
+  const bool unpool = BWD && p.in_mode == 2;
+  const int Sin = unpool ? S >> 1 : S;
+  const size_t pose_floats = (size_t)Sin * Sin * Sin * p.in_cs;
   const float *in_b = p.in + (size_t)b * pose_floats;
+  // dynamic range of a gradient tensor (ConvArgs::in_amax): staged values times s_in = 2^(14 - exponent of the pose's
+  // largest), accumulators times 1 / s_in
+  float s_in = 1.f, inv_s_in = 1.f;
+  if constexpr (BWD) {
+    if (p.in_amax) {
+      const int e = (int)((p.in_amax[b] >> 23) & 0xffu);  // biased exponent; 0 = all zero (or subnormal), 255 = inf / NaN
+      if (e > 0 && e < 255) {
+        const int eb = max(4, min(250, 268 - e));  // biased exponent of 2^(14 - (e - 127)), both factors kept normal
+        s_in = __uint_as_float((unsigned)eb << 23);
+        inv_s_in = __uint_as_float((unsigned)(254 - eb) << 23);
+      }
+    }
+  }
 
   // ---- which chunks (octets) have a non-zero in this workgroup's halo tile?  With the voxelizer's occupancy bytes
   // (ConvArgs::in_occ: one byte per pose, 4 x 4 x 4-cell block of the pooled grid and octet) that is known before anything
@@ -622,6 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   constexpr int VPT = kH2VPT;
   int st_slot[VPT], st_off[VPT];
   float4 pre[VPT][2];
+  unsigned pre_am[VPT][2];  // in_mode 2: the four arg-max bytes of the quad
   __amdgpu_buffer_rsrc_t rsrc;
   if constexpr (INSPLIT) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b), 0, (int)(pose_floats * 4), 0x00020000);
@@ -653,6 +674,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
       st_slot[v] = (hx * SX + hy * SY + hz) * 16;
       if (in) {
         st_off[v] = ((x * S + y) * S + z) * p.in_cs;
+        if (unpool) {  // the voxel's cell of the pooled tensor; its position inside the cell rides in the slot's top bits
+          st_off[v] = (((x >> 1) * Sin + (y >> 1)) * Sin + (z >> 1)) * p.in_cs;
+          st_slot[v] |= (((x & 1) << 2) | ((y & 1) << 1) | (z & 1)) << 28;
+        }
       } else {  // the zero padding is laid down once, in both buffers; staging then touches the voxels inside the grid only
 #pragma unroll
         for (int k = 0; k < 2 * NBUF; k++) *reinterpret_cast<uint4 *>(s_buf + (k >> 1) * BUFB + (k & 1) * PLB + st_slot[v]) = make_uint4(0u, 0u, 0u, 0u);
@@ -703,7 +728,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
       for (int v = 0; v < VPT; v++)
 #pragma unroll
         for (int q = 0; q < 2; q++)
-          if (st_off[v] >= 0 && q < nq) pre[v][q] = *reinterpret_cast<const float4 *>(src_c + st_off[v] + q * 4);
+          if (st_off[v] >= 0 && q < nq) {
+            pre[v][q] = *reinterpret_cast<const float4 *>(src_c + st_off[v] + q * 4);
+            if constexpr (BWD)
+              if (unpool) pre_am[v][q] = *reinterpret_cast<const unsigned *>(p.in_argmax + (size_t)b * pose_floats + chunk * 8 + st_off[v] + q * 4);
+          }
     }
   };
   auto commit = [&](int chunk, int bsel) {
@@ -729,15 +758,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
               x.z = x.z * sc.z + sh.z;
               x.w = x.w * sc.w + sh.w;
             }
+            if constexpr (BWD) {
+              if (unpool) {  // max-unpool: the cell's gradient goes to the voxel that was its maximum
+                const unsigned am = pre_am[v][q], rr = (unsigned)st_slot[v] >> 28;
+                x.x = (am & 0xffu) == rr ? x.x : 0.f;
+                x.y = ((am >> 8) & 0xffu) == rr ? x.y : 0.f;
+                x.z = ((am >> 16) & 0xffu) == rr ? x.z : 0.f;
+                x.w = (am >> 24) == rr ? x.w : 0.f;
+              }
+            }
             const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
             if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {  // (a quad that is zero in all 64 voxels needs no arithmetic)
+              if constexpr (BWD) x.x *= s_in, x.y *= s_in, x.z *= s_in, x.w *= s_in;
               split4(x, h[q], l[q], amax);
               lane_nonzero = true;
             }
           }
         }
-        *reinterpret_cast<uint4 *>(dstb + st_slot[v]) = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
-        *reinterpret_cast<uint4 *>(dstb + PLB + st_slot[v]) = make_uint4(l[0].x, l[0].y, l[1].x, l[1].y);
+        const int slot = BWD ? st_slot[v] & 0x0fffffff : st_slot[v];
+        *reinterpret_cast<uint4 *>(dstb + slot) = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+        *reinterpret_cast<uint4 *>(dstb + PLB + slot) = make_uint4(l[0].x, l[0].y, l[1].x, l[1].y);
       }
       if (SKIP && lane == 0) s_live[chunk * 4 + wave] = 0;
       if (SKIP && __builtin_amdgcn_ballot_w64(lane_nonzero) != 0ull && lane == 0) s_live[chunk * 4 + wave] = 1;
@@ -965,7 +1005,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   const size_t oct_sp = (size_t)(ch >> 3) * So * So * So;
   auto finish_pose = [&](auto tpc) __attribute__((always_inline)) {  // the poses of this workgroup, one after the other
     constexpr int tp = decltype(tpc)::value;
-    float unscale = p.h2_unscale;
+    float unscale = p.h2_unscale * inv_s_in;
     bool post_done = false;
     int relu_flag = p.relu;
     if constexpr (TM <= 3) {
@@ -1030,6 +1070,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
         const unsigned w = (row & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
         if (ch < p.coutp) reinterpret_cast<unsigned *>(out_f)[(oct_sp + vox) * 8 + ch_sp] = w;
       } else if (ch < p.cout) {
+        if constexpr (BWD) out_max = fmaxf(out_max, fabsf(v));
         out_f[vox * p.out_cs + ch] = v;
       }
     };
@@ -1064,6 +1105,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
           for (int r = 1; r < 8; r++) sum = sum + v[r];
           store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
         } else {
+          if constexpr (BWD) {
+            // gradient pass: the ReLU of the layer this gradient belongs to (ConvArgs::out_mask) -- the eight activations
+            // fetched ahead of the first store (a store may alias the next load as far as the compiler knows)
+            if (p.out_mask && ch < p.cout) {
+              const float *mk = p.out_mask + (size_t)(b + tp) * So * So * So * p.out_mask_cs + ch;
+              float a8[8];
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+                a8[r] = mk[(((size_t)vx * So + vy) * So + vz) * p.out_mask_cs];
+              }
+#pragma unroll
+              for (int r = 0; r < 8; r++) v[r] = a8[r] > 0.f ? v[r] : 0.f;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
@@ -1076,6 +1132,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   finish_pose(std::integral_constant<int, 0>{});
   if constexpr (NP > 1)
     if (npose > 1) finish_pose(std::integral_constant<int, 1>{});
+  if constexpr (BWD) {
+    if (p.out_amax) {  // (ConvArgs::out_amax)
+      for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
+      if (lane == 0 && out_max > 0.f) atomicMax(p.out_amax + b, __float_as_uint(out_max));
+    }
+  }
   h2_report_overflow(p.h2_overflow, ovf_out || !(amax <= 65504.f));
 }
 
@@ -1339,6 +1401,9 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
     ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
   };
+  // a transposed conv of the gradient pass: the weights-in-LDS shapes only (conv_h2_has_bwd)
+  const bool bwd = p.in_amax || p.out_amax || p.out_mask || p.in_mode == 2;
+  if (bwd && (p.in_split || p.out_split || !p.h2_wlds)) throw Error(2, "launch_conv_h2: gradient-pass launch needs fp32 tensors and the weights-in-LDS variant");
   auto by_input = [&](auto mt, auto skip) {
     constexpr int MT = decltype(mt)::value;
     constexpr bool SK = decltype(skip)::value;
@@ -1352,10 +1417,12 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
           }
         }
         if (p.in_split) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true, true>);
+        else if (bwd) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false, true, 1, true>);
         else go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false, true>);
         return;
       }
     }
+    if (bwd) throw Error(2, "launch_conv_h2: gradient-pass variant not compiled for this tile shape");
     if (p.h2_wlds) throw Error(2, "launch_conv_h2: weights-in-LDS variant not compiled for this tile shape");
     if (p.in_split) go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true>);
     else go(conv3d_h2_kernel<WM, WN, TM, MT, SK, false>);
@@ -1396,6 +1463,9 @@ bool conv_h2_has_cfg(int cfg) {
     default: return false;
   }
 }
+
+// tile shapes whose gradient-pass (transposed conv) variant is compiled
+bool conv_h2_has_bwd(int cfg) { return cfg == CONV_CFG_4x1_2x1 || cfg == CONV_CFG_4x1_1x1; }
 
 int conv_h2_mt_mask(int cfg) {
   switch (cfg) {

@@ -109,6 +109,9 @@ struct Step {
   // output channels [lig_c0, C) -- for Default2017 (16 + 19 channels) one 32-wide N tile instead of two (35 -> 64).
   ConvPlan bwd_lig;
   bool has_bwd_lig = false;
+  // the 32-wide plan of the same restricted conv with its split-fp16 twin (bwd.h2 is the unrestricted conv's)
+  ConvPlan bwd_lig_h2;
+  bool has_bwd_lig_h2 = false;
   int lig_c0 = 0;
   bool has_bn = false;
   int src = -1, dst = -1;
@@ -140,6 +143,9 @@ struct Model {
   // written split by its producer (a conv3d_h2_kernel epilogue) because every layer reading it is a conv3d_h2_kernel layer
   // without BatchNorm; pooled_split_ok = the same holds for the pooled voxel grid, which the voxelizer then writes split
   // with a channel stride of Cp8 (whole octets).  Every other program (fp32 MFMA, gradient, bf16) keeps fp32 tensors.
+  // gradient program: the buffer is the private, ReLU'd output of ONE conv whose transposed twin has a split-fp16 plan -- the
+  // producer of its gradient then masks by the activation and records the per-pose maximum (ConvArgs::out_mask / out_amax)
+  std::vector<char> buf_bwd_h2;
   std::vector<char> buf_split;
   bool pooled_split_ok = false;
   int Cp8 = 0;
@@ -372,7 +378,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
 }
 
-static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post = false);
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post = false, bool backward = false);
 
 // ---- split-fp16 twin of a forward conv plan (conv3d_h2.hip) ----
 static unsigned short host_f2h(float f) {  // fp32 -> fp16, round to nearest even, subnormals and overflow handled
@@ -477,7 +483,9 @@ static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt
   if (cycles_out) *cycles_out = best;
 }
 
-static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post) {
+// (backward: `o` is make_bwd_op of a forward conv and `cp` its transposed plan -- weights flipped and transposed as in
+// plan_conv; the launch stages an fp32 gradient tensor with ConvArgs::in_amax scaling)
+static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post, bool backward) {
   if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
   if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
   ConvArgs a = cp.a;  // geometry, tiles, bias, BatchNorm, ReLU / pool, output slice
@@ -554,6 +562,16 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post) {
   const int kstep = n16 ? 4 : 2;
   const int Pmax = (taps * best + kstep - 1) / kstep;
   const float *w = m.d.data.data() + o.w_off;  // canonical [tap][cin][cout]
+  std::vector<float> wT;
+  if (backward) {  // W'[tap][co][ci] = W[taps-1-tap][ci][co]
+    const int fci = o.cout, fco = o.cin;  // forward cin / cout
+    wT.resize((size_t)taps * o.cin * o.cout);
+    for (int t = 0; t < taps; t++)
+      for (int ci = 0; ci < fci; ci++)
+        for (int co = 0; co < fco; co++)
+          wT[((size_t)t * fco + co) * fci + ci] = w[((size_t)(taps - 1 - t) * fci + ci) * fco + co];
+    w = wT.data();
+  }
   const float sw = h2_weight_scale(w, (size_t)taps * o.cin * o.cout);
   std::vector<unsigned short> wp((size_t)nchunks * Pmax * kstep * a.coutp * 16, 0);
   for (int ch = 0; ch < nchunks; ch++)
@@ -916,6 +934,11 @@ static Model *build_model(ModelDesc &&desc) {
         if (grad && o.cout % 4 == 0) {
           plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
           st.has_bwd = true;
+          // transposed 3x3x3 convs of the plain families on the split-fp16 kernel (run_backward decides per call)
+          const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.bn_scale_off < 0 && o.src != o.dst && o.relu && o.dst_c0 == 0 &&
+                              o.cout == d.bufs[o.dst].C && !getenv("MI_GNINA_NO_H2_BWD");
+          auto shape_ok = [](const ConvPlan &cp) { return conv_h2_has_bwd(cp.cfg) && (!cp.has_lat || conv_h2_has_bwd(cp.lat_cfg)); };
+          if (bwd_h2 && shape_ok(st.bwd)) plan_conv_h2(*m, make_bwd_op(o), st.bwd, false, true);
           if (st.has_bn) {  // d(BN x)/dx: the transposed conv's output is scaled per (forward-input) channel
             std::vector<float> sc(st.bwd.a.coutp, 0.f);
             std::copy(d.data.begin() + o.bn_scale_off, d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -944,6 +967,11 @@ static Model *build_model(ModelDesc &&desc) {
             plan_conv(*m, make_bwd_op(osub), st.bwd_lig, 0, o.src, c0, true, n16_bwd && !fewer_tiles);
             st.has_bwd_lig = true;
             st.lig_c0 = c0;
+            if (bwd_h2) {
+              plan_conv(*m, make_bwd_op(osub), st.bwd_lig_h2, 0, o.src, c0, true, false);
+              if (shape_ok(st.bwd_lig_h2)) plan_conv_h2(*m, make_bwd_op(osub), st.bwd_lig_h2, false, true);
+              st.has_bwd_lig_h2 = st.bwd_lig_h2.has_h2;
+            }
           }
         }
         m->buf_cp[dst] = round_up(d.bufs[dst].C, 4);
@@ -1017,6 +1045,15 @@ static Model *build_model(ModelDesc &&desc) {
     }
   }
   if (m->grad_supported) m->gsteps = build_steps(true, false);
+  m->buf_bwd_h2.assign(d.bufs.size(), 0);
+  for (size_t id = 0; id < d.bufs.size(); id++) {
+    int producers = 0, fit = 0;
+    for (const Step &st : m->gsteps) {
+      if (st.kind == OpKind::Conv && st.conv.dst == (int)id) producers++, fit += (st.has_bwd && st.bwd.has_h2) ? 1 : 0;
+      else if (st.kind != OpKind::Conv && st.kind != OpKind::Fc && st.dst == (int)id) producers++;
+    }
+    m->buf_bwd_h2[id] = producers == 1 && fit == 1;
+  }
   for (const Step &st : m->steps) {
     int s = st.kind == OpKind::Conv ? st.conv.src : st.src;
     MIG_CHECK(s >= 0 && m->buf_cp[s] > 0, 2, "layer program reads a buffer nothing produced");
@@ -1084,6 +1121,7 @@ struct Scorer {
   // recomputes its scores on the fp32-MFMA kernels (score_batch / score_batch_grad)
   DevBuf<unsigned char> d_occ[2];       // occupancy bytes of the split-format pooled grid (VoxArgs::occ), per buffer set
   DevBuf<unsigned> d_ovf;
+  DevBuf<unsigned> d_gamax;  // gradient pass: [buffer][cap] per-pose max |g| bits of the buffers in Model::buf_bwd_h2
   unsigned *h_ovf = nullptr;            // pinned copy
   int h2_fallbacks = 0;                 // calls recomputed because of it (mi_scorer_h2_fallbacks)
   bool ovf_pending = false;             // device-output calls in flight whose flag mi_scorer_synchronize still has to read
@@ -1576,6 +1614,37 @@ static bool use_bf16(Scorer &s, Model &m, bool grad) {
   return m.hgsteps_error.empty();
 }
 
+// Launch arguments of a layer's split-fp16 twin: the tensors of `a`, the tile pick_tile chooses for `nb` poses (or the
+// twin's own throughput tile), conv3d_h2_kernel's M-tile geometry, LDS pads and weights-in-LDS variant for that tile.
+static void h2_launch_args(const ConvPlan &cp, const ConvArgs &a, int nb, ConvArgs &h, int &cfg) {
+  h = cp.h2;
+  h.in = a.in, h.in_cs = a.in_cs, h.out = a.out, h.out_cs = a.out_cs;
+  ConvArgs geo = a;
+  pick_tile(cp, nb, geo, cfg);
+  h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
+  if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
+  if (!cp.h2_planar) return;
+  // conv3d_h2_kernel: its own M-tile geometry and LDS pads per tile
+  const bool lat = cfg != cp.cfg;
+  if (!lat && cp.h2_cfg >= 0 && !h.post_w) {  // its own throughput tile
+    cfg = cp.h2_cfg;
+    h.tcx = cp.h2.tcx, h.tcy = cp.h2.tcy, h.tcz = cp.h2.tcz;
+    h.ntx = cp.h2.ntx, h.nty = cp.h2.nty, h.ntz = cp.h2.ntz;
+  }
+  h.mt_x = lat ? cp.h2_lat_mt : cp.h2.mt_x;
+  h.h2_pad_y = lat ? cp.h2_lat_pad[0] : cp.h2.h2_pad_y;
+  h.h2_pad_x = lat ? cp.h2_lat_pad[1] : cp.h2.h2_pad_x;
+  // weights through LDS where the kernel shape has that variant (conv3d_h2.hip launch_h2_k3)
+  int wm_, wn_, tm_, tn_;
+  conv_cfg_shape(cfg, &wm_, &wn_, &tm_, &tn_);
+  // (default 2: weights through LDS, two poses per workgroup -- measured 1.76 against 1.94 (one pose) and
+  // 1.9-2.0 ms (weights from L1 / L2, double-buffered tile) on the headline's first conv; MI_GNINA_H2_WLDS=0/1/2)
+  const char *ev = getenv("MI_GNINA_H2_WLDS");
+  h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
+  // (L2 prefetch of the next item's tile under this item's K loop: measured, no gain -- 1.722 vs 1.717 ms; opt-in)
+  h.h2_prefetch = (getenv("MI_GNINA_H2_PF") && atoi(getenv("MI_GNINA_H2_PF")) != 0) ? 1 : 0;
+}
+
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
 // act[input_dst]; writes pose/aff/loss at out offsets.
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
@@ -1652,35 +1721,13 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
           } else if (use_h2) {
             // split-fp16 kernel: same tensors, same tiles (pick_tile), own K chunking and weights
-            ConvArgs h = st.conv.h2;
-            h.in = a.in, h.in_cs = a.in_cs, h.out = a.out, h.out_cs = a.out_cs, h.argmax_out = a.argmax_out;
+            ConvArgs h;
+            int cfg;
+            h2_launch_args(st.conv, a, nb, h, cfg);
+            h.argmax_out = a.argmax_out;
             h.sparse = a.sparse == 1 ? 1 : 0;  // the zero test pays on the pooled voxel grid only
             if (getenv("MI_GNINA_H2_NO_SKIP")) h.sparse = 0;
-            int cfg;
-            ConvArgs geo = a;
-            pick_tile(st.conv, nb, geo, cfg);
-            h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
-            if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
-            if (st.conv.h2_planar) {  // conv3d_h2_kernel: its own M-tile geometry and LDS pads per tile; tensor formats
-              const bool lat = cfg != st.conv.cfg;
-              if (!lat && st.conv.h2_cfg >= 0 && !h.post_w) {  // its own throughput tile
-                cfg = st.conv.h2_cfg;
-                h.tcx = st.conv.h2.tcx, h.tcy = st.conv.h2.tcy, h.tcz = st.conv.h2.tcz;
-                h.ntx = st.conv.h2.ntx, h.nty = st.conv.h2.nty, h.ntz = st.conv.h2.ntz;
-              }
-              h.mt_x = lat ? st.conv.h2_lat_mt : st.conv.h2.mt_x;
-              h.h2_pad_y = lat ? st.conv.h2_lat_pad[0] : st.conv.h2.h2_pad_y;
-              h.h2_pad_x = lat ? st.conv.h2_lat_pad[1] : st.conv.h2.h2_pad_x;
-              {  // weights through LDS where the kernel shape has that variant (conv3d_h2.hip launch_h2_k3)
-                int wm_, wn_, tm_, tn_;
-                conv_cfg_shape(cfg, &wm_, &wn_, &tm_, &tn_);
-                // (default 2: weights through LDS, two poses per workgroup -- measured 1.76 against 1.94 (one pose) and
-                // 1.9-2.0 ms (weights from L1 / L2, double-buffered tile) on the headline's first conv; MI_GNINA_H2_WLDS=0/1/2)
-                const char *ev = getenv("MI_GNINA_H2_WLDS");
-                h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
-                // (L2 prefetch of the next item's tile under this item's K loop: measured, no gain -- 1.722 vs 1.717 ms; opt-in)
-                h.h2_prefetch = (getenv("MI_GNINA_H2_PF") && atoi(getenv("MI_GNINA_H2_PF")) != 0) ? 1 : 0;
-              }
+            if (st.conv.h2_planar) {  // tensor formats
               h.in_split = is_split(st.conv.src) ? 1 : 0;
               h.out_split = is_split(st.conv.dst) ? 1 : 0;
               if (h.in_split && st.conv.src == m->input_dst) {
@@ -1773,21 +1820,37 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         return false;
     return true;
   };
+  // transposed convs on the split-fp16 kernel (default precision): the producer of a gradient such a conv will read masks
+  // it by the ReLU and records its per-pose maximum; `ready` = that has happened for the buffer's gradient in this call
+  const bool h2_bwd = !bf16 && s.conv_path != 0 && !getenv("MI_GNINA_NO_H2_BWD");
+  const size_t nbufs = m->d.bufs.size();
+  std::vector<char> ready(nbufs, 0);
+  if (h2_bwd) {
+    s.d_gamax.ensure(nbufs * (size_t)s.cap);
+    MIG_HIP(hipMemsetAsync(s.d_gamax.p, 0, nbufs * (size_t)s.cap * sizeof(unsigned), s.stream));
+  }
+  auto amax_of = [&](int id) { return s.d_gamax.p + (size_t)id * s.cap; };
+  auto wants_mask = [&](int id) { return h2_bwd && id != m->input_dst && m->buf_bwd_h2[id]; };
   for (int i = (int)gsteps.size() - 1; i >= 0; i--) {
     const Step &st = gsteps[i];
     switch (st.kind) {
       case OpKind::Fc: {
         ProfScope ps(s, "fc_backward", 2.0 * nb * 2.0 * st.n_in, 0.0, nb);
-        launch_fc_backward(s.d_raw3.p, m->dev_data.p + st.w_off, st.n_in, g_ptr(st.src), nb, s.stream);
+        const bool mk = wants_mask(st.src);
+        launch_fc_backward(s.d_raw3.p, m->dev_data.p + st.w_off, st.n_in, g_ptr(st.src), nb, s.stream,
+                           mk ? act_ptr(st.src) : nullptr, mk ? amax_of(st.src) : nullptr);
+        ready[st.src] = mk;
         break;
       }
       case OpKind::Conv: {
         MIG_CHECK(st.has_bwd, 1, "gradient not supported for this layer");
         // (rigid receptor: the first conv's transposed twin computes the ligand's channels of the grid gradient only)
         const bool lig_only = st.has_bwd_lig && !bf16 && (s.cur_flex == nullptr || s.flex_rows.empty());
-        const ConvPlan &bp = lig_only ? st.bwd_lig : st.bwd;
-        ConvArgs a = bp.a;
         const int dst = st.conv.dst, src = st.conv.src;
+        // the split-fp16 kernel: the gradient it reads must have been prepared by its producer
+        const bool use_h2 = h2_bwd && ready[dst] && (lig_only ? st.has_bwd_lig_h2 : st.bwd.has_h2);
+        const ConvPlan &bp = lig_only ? (use_h2 ? st.bwd_lig_h2 : st.bwd_lig) : st.bwd;
+        ConvArgs a = bp.a;
         a.in = g_ptr(dst) + st.conv.a.out_c0;  // Dense layers: the 16-channel slice this conv produced
         a.in_cs = m->buf_cp[dst];
         a.in_act = act_ptr(dst) + st.conv.a.out_c0;
@@ -1812,16 +1875,40 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         }
         a.out = g_ptr(src);
         a.out_cs = m->buf_cp[src];
+        // this launch produces the gradient of buffer `src`: prepare it for a split-fp16 consumer
+        const bool n16_here = bp.cfg == CONV_CFG_N16_TM1 || bp.cfg == CONV_CFG_N16_TM2 || bp.cfg == CONV_CFG_N16_TM3 || bp.cfg == CONV_CFG_N16_TM4;
+        const bool mk = wants_mask(src) && !a.accumulate && !a.out_scale && !n16_here && !(bp.has_lat && !use_h2 && bp.lat_cfg != CONV_CFG_4x1_1x1);
+        ready[src] = mk;
         char nm[96];
         const int cout_here = lig_only ? st.conv.cin - st.lig_c0 : st.conv.cin;  // grid-gradient channels this launch computes
-        snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d%s", a.ksize, a.S, st.conv.a.cout, cout_here, lig_only ? "_lig" : "");
+        snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d%s%s", a.ksize, a.S, st.conv.a.cout, cout_here, lig_only ? "_lig" : "", use_h2 ? "_h2" : "");
         const double S3 = (double)a.S * a.S * a.S;
         if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
         ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * cout_here * st.conv.a.cout, 0.0, nb);
-        if (bf16) {
+        if (use_h2) {
+          ConvArgs h;
+          int cfg;
+          h2_launch_args(bp, a, nb, h, cfg);
+          MIG_CHECK(bp.h2_planar, 2, "transposed split-fp16 conv without a planar plan");
+          h.in_split = h.out_split = 0;
+          h.h2_wlds = 1;  // (the gradient-pass variant is compiled for the weights-in-LDS shapes only)
+          h.in_mode = st.conv.a.pool == 1 ? 2 : 0;  // (the ReLU mask is in the gradient already)
+          h.in_argmax = a.in_argmax;
+          h.in_amax = amax_of(dst);
+          h.sparse = getenv("MI_GNINA_H2_BWD_SKIP") ? 1 : 0;
+          h.out_mask = mk ? act_ptr(src) : nullptr;
+          h.out_mask_cs = m->buf_cp[src];
+          h.out_amax = mk ? amax_of(src) : nullptr;
+          s.d_ovf.ensure(1);
+          h.h2_overflow = s.d_ovf.p;
+          launch_conv_h2(h, cfg, nb, s.stream);
+        } else if (bf16) {
           a.sparse = 0;
           launch_conv_bf16(a, st.bwd.cfg, nb, s.stream);
         } else {
+          a.out_mask = mk ? act_ptr(src) : nullptr;
+          a.out_mask_cs = m->buf_cp[src];
+          a.out_amax = mk ? amax_of(src) : nullptr;
           int cfg;
           pick_tile(bp, nb, a, cfg);
           launch_conv(a, cfg, nb, s.stream);

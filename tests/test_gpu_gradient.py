@@ -169,3 +169,84 @@ def test_flexible_receptor_from_pdbqt_files(capi):
     ref = s2.score_batch(lig, lig_smt)
     assert out["pose"][0] == ref["pose"][0] and out["affinity"][0] == ref["affinity"][0]
     assert np.abs(out["flex_grad"][0][0]).max() > 0 and not out["flex_grad"][0][1].any()   # OG typed, HG (polar H) not
+
+
+def _rescaled_model(name, i, k, tmp_path):
+    """`name` with convolution i (weights and bias) times k and the weights of the layer behind it -- the next convolution,
+    or the fully connected heads -- times 1 / k (k a power of two): ReLU and both pools commute with a positive factor, so
+    every score keeps its bits, the activations of that one layer are k times and their gradients 1 / k times the shipped
+    model's"""
+    import struct
+    raw = bytearray(open(os.path.join(WEIGHTS, name + ".mgw"), "rb").read())
+    blob = cnn_ref.Blob(bytes(raw))
+    (hl,) = struct.unpack("<I", raw[8:12])
+    off = 12 + hl
+    off += (-off) % 64
+    data = np.frombuffer(raw, dtype="<f4", offset=off).copy()
+    convs = [t for t in blob.ops if t[0] == "conv"]
+    i %= len(convs)
+    kk, cin, cout, w_off, b_off = int(convs[i][1]), int(convs[i][4]), int(convs[i][5]), int(convs[i][8]), int(convs[i][9])
+    data[w_off:w_off + kk ** 3 * cin * cout] *= np.float32(k)
+    data[b_off:b_off + cout] *= np.float32(k)
+    if i + 1 < len(convs):
+        kk, cin, cout, w_off = int(convs[i + 1][1]), int(convs[i + 1][4]), int(convs[i + 1][5]), int(convs[i + 1][8])
+        data[w_off:w_off + kk ** 3 * cin * cout] *= np.float32(1.0 / k)
+    else:
+        fc = next(t for t in blob.ops if t[0] == "fc")
+        data[int(fc[3]):int(fc[3]) + 3 * int(fc[2])] *= np.float32(1.0 / k)
+    raw[off:] = data.tobytes()
+    path = os.path.join(str(tmp_path), f"{name}_conv{i}_x{k:g}.mgw")
+    with open(path, "wb") as f:
+        f.write(bytes(raw))
+    return path
+
+
+@pytest.mark.parametrize("name", ["default2017", "crossdock_default2018"])
+def test_split_fp16_transposed_convs_are_fp32_grade(capi, CG, name, tmp_path, monkeypatch):
+    """Gradient calls run their 3x3x3 transposed convs on the split-fp16 kernel (conv3d_h2_kernel's gradient-pass variant:
+    per-pose power-of-two scaling by the producer-recorded maximum, ConvArgs::in_amax; ReLU masks applied by the producer,
+    out_mask).  Against the same call on the fp32-MFMA kernels (MI_GNINA_NO_H2_BWD at run time): same scores, atom
+    gradients within 5e-6 of each pose's largest -- rigid receptor (ligand channels only), flexible rows (all channels), and
+    with the gradient behind the last convolution 2^12 times larger / behind the first one 2^6 times smaller than the
+    shipped model's (same scores)."""
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+
+    def both(f):
+        monkeypatch.delenv("MI_GNINA_NO_H2_BWD", raising=False)
+        a = f()
+        monkeypatch.setenv("MI_GNINA_NO_H2_BWD", "1")
+        b = f()
+        monkeypatch.delenv("MI_GNINA_NO_H2_BWD", raising=False)
+        return a, b
+
+    def close(a, b, key):
+        B = len(a[key])
+        scale = np.maximum(np.abs(b[key]).reshape(B, -1).max(1), 1e-30)
+        return (np.abs(a[key] - b[key]).reshape(B, -1).max(1) / scale).max()
+
+    s0 = capi.Scorer([name])
+    s0.set_receptor(rec_xyz, rec_smt)
+    shipped = s0.score_grad(poses, lig_smt)
+    for model in (name, _rescaled_model(name, -1, 2.0 ** -12, tmp_path), _rescaled_model(name, 0, 2.0 ** 6, tmp_path)):
+        s = capi.Scorer([capi.Model(model)])
+        s.set_receptor(rec_xyz, rec_smt)
+        s.enable_profile(True)
+        a, b = both(lambda: s.score_grad(poses, lig_smt))
+        prof = s.profile()
+        s.enable_profile(False)
+        rows = prof if isinstance(prof, list) else prof.get("kernels", prof)
+        names = [r["kernel"] for r in rows]
+        assert sum(n.startswith("convT3") and n.endswith("_h2") for n in names) == 3, names   # the split-fp16 launches ...
+        assert sum(n.startswith("convT3") and not n.endswith("_h2") for n in names) == 3, names  # ... and the fp32 ones
+        assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["loss"], b["loss"])
+        assert np.abs(b["lig_grad"]).max() > 0 and np.abs(a["lig_grad"]).max() > 0, (model, np.abs(a["lig_grad"]).max(), np.abs(b["lig_grad"]).max(), a["loss"])
+        assert close(a, b, "lig_grad") < 5e-6, (model, close(a, b, "lig_grad"))
+        assert np.abs(a["pose"] - shipped["pose"]).max() < 1e-6 and close(a, shipped, "lig_grad") < 1e-5, model
+        assert s.h2_fallbacks() == 0
+        # flexible rows: the transposed first conv computes every channel
+        rows_f = np.argsort(np.linalg.norm(rec_xyz - poses[0].mean(0), axis=1))[:12].astype(np.int32)
+        flex = np.repeat(rec_xyz[rows_f][None], len(poses), 0) + np.float32(0.1)
+        s.set_flex(rows_f)
+        a, b = both(lambda: s.score_flex(poses, lig_smt, flex))
+        assert np.array_equal(a["pose"], b["pose"])
+        assert close(a, b, "lig_grad") < 5e-6 and close(a, b, "flex_grad") < 5e-6
