@@ -106,6 +106,10 @@ struct ConvArgs {
   unsigned *out_amax;       // [pose] or nullptr (pool == 0 epilogues: conv3d_mfma_kernel, conv3d_h2_kernel; fc_backward)
   const float *out_mask;    // channels-last activation tensor of the OUTPUT's shape, stride out_mask_cs; nullptr = no mask
   int out_mask_cs;
+  // output channels [out_mask_c0, out_mask_c1) the mask and the maximum apply to (Dense blocks: the launch that writes the
+  // final value of the NEXT layer's 16-channel slice of the concat buffer's gradient prepares that slice, after its own
+  // out_scale / accumulate; the other channels are written as ever)
+  int out_mask_c0, out_mask_c1;
   int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
@@ -168,6 +172,9 @@ void launch_fc_heads(const float *in, const float *w, const float *bias, int n_i
 void launch_overlap_forward(const float *grid, int B, long N3, float *pose, float *aff, float *loss, float *ave_out,
                             hipStream_t s);
 void launch_overlap_backward(const float *grid, const float *ave, int B, long N3, float *gg, hipStream_t s);
+// in place over a channel slice: g = act > 0 ? g : 0, amax[b] = max |g| (float bits) -- see conv3d.hip
+void launch_grad_mask_amax(float *g, const float *act, int C, int g_cs, int act_cs, long vox_per_pose, int B, unsigned *amax,
+                           hipStream_t s);
 // (mask: the FC input's forward activation, g_in = mask > 0 ? g : 0; amax [B]: per-pose max |g_in| bits -- both optional)
 void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in, int B, hipStream_t s,
                         const float *mask = nullptr, unsigned *amax = nullptr);

@@ -640,27 +640,40 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
           out_b[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
         } else {
           const float osc = p.out_scale ? p.out_scale[ch] : 1.0f;
-          if (p.out_mask) {
-            // gradient pass: the ReLU of the layer this gradient belongs to (ConvArgs::out_mask) -- the eight activations
-            // fetched ahead of the first store (a store may alias the next load as far as the compiler knows)
-            const float *mk = p.out_mask + (size_t)b * So * So * So * p.out_mask_cs + ch;
-            float a8[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-              const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-              a8[r] = mk[(((size_t)vx * So + vy) * So + vz) * p.out_mask_cs];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = a8[r] > 0.f ? v[r] : 0.f;
-          }
+          // gradient pass (ConvArgs::out_mask / out_amax): the ReLU of the layer this gradient belongs to and its per-pose
+          // maximum, on the channels [out_mask_c0, out_mask_c1).  The activations and, when accumulating, the old values are
+          // fetched ahead of the first store (a store may alias the next load as far as the compiler knows).
+          // (The loads sit behind wave-uniform branches only, every lane with a valid address: a per-lane `cond ? load : c` is
+          // compiled into a branch, a wait and a select per element.)
+          const bool in_range = ch >= p.out_mask_c0 && ch < p.out_mask_c1;
+          const int ch_m = in_range ? ch : p.out_mask_c0;
+          const bool any_msk = p.out_mask && __builtin_amdgcn_ballot_w64(in_range) != 0ull;  // (wave-uniform)
+          float a8[8], o8[8];
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-            float *dst = out_b + (((size_t)vx * So + vy) * So + vz) * p.out_cs + ch;
+            const size_t vox = ((size_t)vx * So + vy) * So + vz;
+            a8[r] = 1.f, o8[r] = 0.f;
+            if (any_msk) a8[r] = p.out_mask[((size_t)b * So * So * So + vox) * p.out_mask_cs + ch_m];
+            if (p.accumulate) o8[r] = out_b[vox * p.out_cs + ch];
+          }
+          // (every fetched value is consumed before the first store is issued: the compiler otherwise sinks each load down
+          // to its use, behind the previous store it may alias)
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
             float val = p.out_scale ? v[r] * osc : v[r];
-            if (p.accumulate) val = *dst + val;
-            out_max = fmaxf(out_max, fabsf(val));
-            *dst = val;
+            if (p.accumulate) val = o8[r] + val;
+            if (in_range) {
+              val = a8[r] > 0.f ? val : 0.f;
+              out_max = fmaxf(out_max, fabsf(val));
+            }
+            v[r] = val;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+            out_b[(((size_t)vx * So + vy) * So + vz) * p.out_cs + ch] = v[r];
           }
         }
       }
@@ -668,7 +681,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((TM * TN <= 2 || (TM == 1 && TN == 3
   }
   if (p.out_amax) {
     for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
-    if (lane == 0 && out_max > 0.f) atomicMax(p.out_amax + b, __float_as_uint(out_max));
+    // (a plain read first: the maximum settles after a few workgroups, and same-line atomics serialize in L2 -- ~9 ns each,
+      // 0.25 ms per launch when every wave issues one; a stale read only costs an atomic that changes nothing)
+      if (lane == 0 && __float_as_uint(out_max) > __hip_atomic_load(p.out_amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(p.out_amax + b, __float_as_uint(out_max));
   }
 }
 
@@ -1312,7 +1328,7 @@ __global__ void fc_backward_kernel(const float *raw3, const float *w, int n_in, 
     __syncthreads();
     if (threadIdx.x == 0) {
       m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-      if (m > 0.f) atomicMax(amax + b, __float_as_uint(m));
+      if (__float_as_uint(m) > __hip_atomic_load(amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax + b, __float_as_uint(m));
     }
   }
 }
@@ -1344,6 +1360,44 @@ void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int i
   long total = (long)B * S * S * S * C;
   hipLaunchKernelGGL(unpool_avg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_pooled, g_full, C,
                      in_cs, out_cs, S, total);
+}
+
+// Gradient pass, ahead of a split-fp16 transposed conv that reads a channel slice of a concat buffer's gradient (Dense
+// blocks: the slice has accumulated contributions of every later layer, so no producer could prepare it): in place,
+// g = act > 0 ? g : 0 over the slice's C channels (a multiple of 4), and the per-pose maximum of |g| (ConvArgs::in_amax).
+__global__ void grad_mask_amax_kernel(float *g, const float *act, int C4, int g_cs, int act_cs, long vox_per_pose, unsigned *amax) {
+  const int b = blockIdx.y;
+  const long items = vox_per_pose * C4;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+    const long vox = i / C4;
+    const int q = (int)(i - vox * C4);
+    float4 *gp = reinterpret_cast<float4 *>(g + ((size_t)b * vox_per_pose + vox) * g_cs + q * 4);
+    const float4 a = *reinterpret_cast<const float4 *>(act + ((size_t)b * vox_per_pose + vox) * act_cs + q * 4);
+    float4 v = *gp;
+    v.x = a.x > 0.f ? v.x : 0.f;
+    v.y = a.y > 0.f ? v.y : 0.f;
+    v.z = a.z > 0.f ? v.z : 0.f;
+    v.w = a.w > 0.f ? v.w : 0.f;
+    *gp = v;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  __shared__ float s_m[4];
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (__float_as_uint(m) > __hip_atomic_load(amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax + b, __float_as_uint(m));
+  }
+}
+
+void launch_grad_mask_amax(float *g, const float *act, int C, int g_cs, int act_cs, long vox_per_pose, int B, unsigned *amax,
+                           hipStream_t s) {
+  const long items = vox_per_pose * (C / 4);
+  const long want = (items + 1023) / 1024;
+  const unsigned blocks = (unsigned)(want < 64 ? want : 64);  // (four items per thread and more)
+  hipLaunchKernelGGL(grad_mask_amax_kernel, dim3(blocks, B), dim3(256), 0, s, g, act, C / 4, g_cs, act_cs, vox_per_pose, amax);
 }
 
 // ensemble mean / variance over models (cnn_torch_scorer.cpp:177-191)

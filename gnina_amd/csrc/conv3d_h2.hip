@@ -1070,12 +1070,78 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
         const unsigned w = (row & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
         if (ch < p.coutp) reinterpret_cast<unsigned *>(out_f)[(oct_sp + vox) * 8 + ch_sp] = w;
       } else if (ch < p.cout) {
-        if constexpr (BWD) out_max = fmaxf(out_max, fabsf(v));
         out_f[vox * p.out_cs + ch] = v;
       }
     };
     // (two loads and a select: a pointer chosen at run time would live in scratch)
     const float bias = ch < p.coutp ? (post_done ? p.post_bias[ch] : p.bias[ch]) : 0.f;
+    if constexpr (BWD) {
+      // Gradient pass (no ReLU, no pool, fp32 output).  Dense-block layers scale and accumulate (ConvArgs::out_scale /
+      // accumulate, as in conv3d_mfma_kernel's epilogue); then the ReLU of the layer this gradient belongs to, on the channels
+      // [out_mask_c0, out_mask_c1) (ConvArgs::out_mask), and the maximum of what is stored there.  Every activation and
+      // old value of the wave's 2 TM cells is fetched ahead of the first store: a store may alias the next load as far as
+      // the compiler knows, and one exposed round trip to HBM per cell is a fifth of a short K loop.
+      const bool msk = p.out_mask && ch >= p.out_mask_c0 && ch < p.out_mask_c1 && ch < p.cout;
+      const bool accum = p.accumulate && ch < p.cout;
+      const float osc = (p.out_scale && ch < p.cout) ? p.out_scale[ch] : 1.0f;
+      float a8[TM][2][8], o8[TM][2][8];
+      size_t vox0[TM][2];
+      bool valid[TM][2];
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          int cx, cy, cz;
+          valid[m][half] = cell_of(wm * TM + m, kh + 2 * half, cx, cy, cz);
+          const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+          valid[m][half] = valid[m][half] && gcx < ncx && gcy < ncx && gcz < ncx;
+          vox0[m][half] = ((size_t)(2 * gcx) * So + 2 * gcy) * So + 2 * gcz;
+          if (!valid[m][half]) vox0[m][half] = 0;
+        }
+      // (the loads sit behind wave-uniform branches only and every lane has a valid address -- a per-lane `cond ? load : c`
+      // is compiled into a branch, a wait and a select per element)
+      const int ch_m = msk ? ch : p.out_mask_c0, ch_a = accum ? ch : 0;
+      const bool any_msk = __builtin_amdgcn_ballot_w64(msk) != 0ull;  // (waves of the other 32-channel groups skip the fetch)
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const size_t vox = vox0[m][half] + ((size_t)(r >> 2) * So + ((r >> 1) & 1)) * So + (r & 1);
+            a8[m][half][r] = 1.f, o8[m][half][r] = 0.f;
+            if (any_msk) a8[m][half][r] = p.out_mask[((size_t)(b + tp) * So * So * So + vox) * p.out_mask_cs + ch_m];
+            if (p.accumulate) o8[m][half][r] = out_f[vox * p.out_cs + ch_a];
+          }
+      // (every fetched value is consumed before the first store is issued: the compiler otherwise sinks each load down to
+      // its use, behind the previous store it may alias)
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            float v = acc[tp][m][half * 8 + r] * unscale + bias;
+            if (p.out_scale) v = v * osc;
+            if (p.accumulate) v = o8[m][half][r] + v;
+            if (msk) v = a8[m][half][r] > 0.f ? v : 0.f;
+            if (valid[m][half] && ch >= p.out_mask_c0 && ch < p.out_mask_c1) out_max = fmaxf(out_max, fabsf(v));
+            acc[tp][m][half * 8 + r] = v;
+          }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          if (!valid[m][half] || ch >= p.cout) continue;
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const size_t vox = vox0[m][half] + ((size_t)(r >> 2) * So + ((r >> 1) & 1)) * So + (r & 1);
+            out_f[vox * p.out_cs + ch] = acc[tp][m][half * 8 + r];
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < TM; m++) {
 #pragma unroll
@@ -1105,21 +1171,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
           for (int r = 1; r < 8; r++) sum = sum + v[r];
           store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
         } else {
-          if constexpr (BWD) {
-            // gradient pass: the ReLU of the layer this gradient belongs to (ConvArgs::out_mask) -- the eight activations
-            // fetched ahead of the first store (a store may alias the next load as far as the compiler knows)
-            if (p.out_mask && ch < p.cout) {
-              const float *mk = p.out_mask + (size_t)(b + tp) * So * So * So * p.out_mask_cs + ch;
-              float a8[8];
-#pragma unroll
-              for (int r = 0; r < 8; r++) {
-                const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-                a8[r] = mk[(((size_t)vx * So + vy) * So + vz) * p.out_mask_cs];
-              }
-#pragma unroll
-              for (int r = 0; r < 8; r++) v[r] = a8[r] > 0.f ? v[r] : 0.f;
-            }
-          }
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
@@ -1135,7 +1186,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   if constexpr (BWD) {
     if (p.out_amax) {  // (ConvArgs::out_amax)
       for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
-      if (lane == 0 && out_max > 0.f) atomicMax(p.out_amax + b, __float_as_uint(out_max));
+      // (a plain read first: the maximum settles after a few workgroups, and same-line atomics serialize in L2 -- ~9 ns each,
+      // 0.25 ms per launch when every wave issues one; a stale read only costs an atomic that changes nothing)
+      if (lane == 0 && __float_as_uint(out_max) > __hip_atomic_load(p.out_amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(p.out_amax + b, __float_as_uint(out_max));
     }
   }
   h2_report_overflow(p.h2_overflow, ovf_out || !(amax <= 65504.f));
@@ -1402,7 +1456,7 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
   };
   // a transposed conv of the gradient pass: the weights-in-LDS shapes only (conv_h2_has_bwd)
-  const bool bwd = p.in_amax || p.out_amax || p.out_mask || p.in_mode == 2;
+  const bool bwd = p.in_amax || p.out_amax || p.out_mask || p.in_mode == 2 || p.out_scale || p.accumulate;
   if (bwd && (p.in_split || p.out_split || !p.h2_wlds)) throw Error(2, "launch_conv_h2: gradient-pass launch needs fp32 tensors and the weights-in-LDS variant");
   auto by_input = [&](auto mt, auto skip) {
     constexpr int MT = decltype(mt)::value;

@@ -109,7 +109,12 @@ struct Step {
   // output channels [lig_c0, C) -- for Default2017 (16 + 19 channels) one 32-wide N tile instead of two (35 -> 64).
   ConvPlan bwd_lig;
   bool has_bwd_lig = false;
-  // the 32-wide plan of the same restricted conv with its split-fp16 twin (bwd.h2 is the unrestricted conv's)
+  // The transposed conv on the split-fp16 kernel (3x3x3 behind a ReLU; its own plan: the one tile shape the gradient-pass
+  // variant is compiled for).  bwd_h2_kind 1: the conv's private output -- the producer of that buffer's gradient applies the
+  // ReLU mask and records the per-pose maximum (Model::buf_bwd_h2); 2: a channel slice of a concat buffer (Dense blocks) --
+  // a small kernel does both ahead of the launch (launch_grad_mask_amax).  bwd_lig_h2: the ligand-channel restriction.
+  ConvPlan bwd_h2;
+  int bwd_h2_kind = 0;
   ConvPlan bwd_lig_h2;
   bool has_bwd_lig_h2 = false;
   int lig_c0 = 0;
@@ -183,8 +188,10 @@ static Op make_bwd_op(const Op &o) {
   return b;
 }
 
+// (force_std: the 4 x 1 waves x 2 M-tiles shape whatever the layer -- the only one conv3d_h2_kernel's gradient-pass variant
+// is compiled for)
 static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0,
-                      bool backward = false, bool n16_backward = false) {
+                      bool backward = false, bool n16_backward = false, bool force_std = false) {
   const int S = m.d.bufs[o.src].S;
   MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
   const int cells = S / 2;
@@ -220,10 +227,10 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     cp.cfg = CONV_CFG_4x1_1x5;  // 1x1 bottleneck 160 -> 160: 4 waves x 1 M-tile = 16 cells
     if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 3;  // 12 cells used of 16
     else a.tcx = 2, a.tcy = 2, a.tcz = 4;
-  } else if (cells == 3 && NT % 4 == 0) {
+  } else if (cells == 3 && NT % 4 == 0 && !force_std) {
     cp.cfg = CONV_CFG_1x4_7x1;
     a.tcx = a.tcy = a.tcz = 3;
-  } else if (cells == 6 && NT % 2 == 0) {
+  } else if (cells == 6 && NT % 2 == 0 && !force_std) {
     cp.cfg = CONV_CFG_2x2_3x1;  // 24 cells = 6 M-tiles: 2 x 2 waves x 3 M-tiles, one wave per SIMD (a 3 x 2 = 6-wave
                                 // workgroup loads two SIMDs twice as much as the other two: measured 2.08 -> 1.71 ms)
     a.tcx = 2, a.tcy = 2, a.tcz = 6;
@@ -934,11 +941,15 @@ static Model *build_model(ModelDesc &&desc) {
         if (grad && o.cout % 4 == 0) {
           plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
           st.has_bwd = true;
-          // transposed 3x3x3 convs of the plain families on the split-fp16 kernel (run_backward decides per call)
-          const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.bn_scale_off < 0 && o.src != o.dst && o.relu && o.dst_c0 == 0 &&
-                              o.cout == d.bufs[o.dst].C && !getenv("MI_GNINA_NO_H2_BWD");
+          // transposed 3x3x3 convs on the split-fp16 kernel (run_backward decides per call)
+          const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.relu && pool_mode != 2 && dst_c0 % 4 == 0 && !getenv("MI_GNINA_NO_H2_BWD");
           auto shape_ok = [](const ConvPlan &cp) { return conv_h2_has_bwd(cp.cfg) && (!cp.has_lat || conv_h2_has_bwd(cp.lat_cfg)); };
-          if (bwd_h2 && shape_ok(st.bwd)) plan_conv_h2(*m, make_bwd_op(o), st.bwd, false, true);
+          if (bwd_h2) {
+            plan_conv(*m, make_bwd_op(o), st.bwd_h2, 0, o.src, 0, true, false, true);
+            if (shape_ok(st.bwd_h2)) plan_conv_h2(*m, make_bwd_op(o), st.bwd_h2, false, true);
+            const bool is_private = o.bn_scale_off < 0 && o.src != o.dst && dst_c0 == 0 && o.cout == d.bufs[dst].C;
+            if (st.bwd_h2.has_h2) st.bwd_h2_kind = is_private ? 1 : (pool_mode == 0 && !getenv("MI_GNINA_NO_H2_BWD_DENSE") ? 2 : 0);
+          }
           if (st.has_bn) {  // d(BN x)/dx: the transposed conv's output is scaled per (forward-input) channel
             std::vector<float> sc(st.bwd.a.coutp, 0.f);
             std::copy(d.data.begin() + o.bn_scale_off, d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
@@ -967,8 +978,8 @@ static Model *build_model(ModelDesc &&desc) {
             plan_conv(*m, make_bwd_op(osub), st.bwd_lig, 0, o.src, c0, true, n16_bwd && !fewer_tiles);
             st.has_bwd_lig = true;
             st.lig_c0 = c0;
-            if (bwd_h2) {
-              plan_conv(*m, make_bwd_op(osub), st.bwd_lig_h2, 0, o.src, c0, true, false);
+            if (st.bwd_h2_kind) {
+              plan_conv(*m, make_bwd_op(osub), st.bwd_lig_h2, 0, o.src, c0, true, false, true);
               if (shape_ok(st.bwd_lig_h2)) plan_conv_h2(*m, make_bwd_op(osub), st.bwd_lig_h2, false, true);
               st.has_bwd_lig_h2 = st.bwd_lig_h2.has_h2;
             }
@@ -1049,7 +1060,7 @@ static Model *build_model(ModelDesc &&desc) {
   for (size_t id = 0; id < d.bufs.size(); id++) {
     int producers = 0, fit = 0;
     for (const Step &st : m->gsteps) {
-      if (st.kind == OpKind::Conv && st.conv.dst == (int)id) producers++, fit += (st.has_bwd && st.bwd.has_h2) ? 1 : 0;
+      if (st.kind == OpKind::Conv && st.conv.dst == (int)id) producers++, fit += (st.has_bwd && st.bwd_h2_kind == 1) ? 1 : 0;
       else if (st.kind != OpKind::Conv && st.kind != OpKind::Fc && st.dst == (int)id) producers++;
     }
     m->buf_bwd_h2[id] = producers == 1 && fit == 1;
@@ -1824,10 +1835,11 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   // it by the ReLU and records its per-pose maximum; `ready` = that has happened for the buffer's gradient in this call
   const bool h2_bwd = !bf16 && s.conv_path != 0 && !getenv("MI_GNINA_NO_H2_BWD");
   const size_t nbufs = m->d.bufs.size();
-  std::vector<char> ready(nbufs, 0);
+  std::vector<char> ready(nbufs, 0), slice_ready(gsteps.size(), 0);
   if (h2_bwd) {
-    s.d_gamax.ensure(nbufs * (size_t)s.cap);
-    MIG_HIP(hipMemsetAsync(s.d_gamax.p, 0, nbufs * (size_t)s.cap * sizeof(unsigned), s.stream));
+    const size_t slots = nbufs + gsteps.size();  // one per buffer (kind 1) and one per step (kind 2)
+    s.d_gamax.ensure(slots * (size_t)s.cap);
+    MIG_HIP(hipMemsetAsync(s.d_gamax.p, 0, slots * (size_t)s.cap * sizeof(unsigned), s.stream));
   }
   auto amax_of = [&](int id) { return s.d_gamax.p + (size_t)id * s.cap; };
   auto wants_mask = [&](int id) { return h2_bwd && id != m->input_dst && m->buf_bwd_h2[id]; };
@@ -1848,9 +1860,11 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         const bool lig_only = st.has_bwd_lig && !bf16 && (s.cur_flex == nullptr || s.flex_rows.empty());
         const int dst = st.conv.dst, src = st.conv.src;
         // the split-fp16 kernel: the gradient it reads must have been prepared by its producer
-        const bool use_h2 = h2_bwd && ready[dst] && (lig_only ? st.has_bwd_lig_h2 : st.bwd.has_h2);
-        const ConvPlan &bp = lig_only ? (use_h2 ? st.bwd_lig_h2 : st.bwd_lig) : st.bwd;
+        const int h2_kind = (lig_only && !st.has_bwd_lig_h2) ? 0 : st.bwd_h2_kind;
+        const bool use_h2 = h2_bwd && h2_kind != 0 && (h2_kind == 2 || ready[dst]);
+        const ConvPlan &bp = use_h2 ? (lig_only ? st.bwd_lig_h2 : st.bwd_h2) : (lig_only ? st.bwd_lig : st.bwd);
         ConvArgs a = bp.a;
+        if (use_h2) a.out_scale = st.bwd.a.out_scale, a.accumulate = st.bwd.a.accumulate;  // (Dense-block layers)
         a.in = g_ptr(dst) + st.conv.a.out_c0;  // Dense layers: the 16-channel slice this conv produced
         a.in_cs = m->buf_cp[dst];
         a.in_act = act_ptr(dst) + st.conv.a.out_c0;
@@ -1877,13 +1891,34 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         a.out_cs = m->buf_cp[src];
         // this launch produces the gradient of buffer `src`: prepare it for a split-fp16 consumer
         const bool n16_here = bp.cfg == CONV_CFG_N16_TM1 || bp.cfg == CONV_CFG_N16_TM2 || bp.cfg == CONV_CFG_N16_TM3 || bp.cfg == CONV_CFG_N16_TM4;
-        const bool mk = wants_mask(src) && !a.accumulate && !a.out_scale && !n16_here && !(bp.has_lat && !use_h2 && bp.lat_cfg != CONV_CFG_4x1_1x1);
+        const bool can_prepare = !n16_here && !(bp.has_lat && !use_h2 && bp.lat_cfg != CONV_CFG_4x1_1x1);  // (kernels whose epilogue masks)
+        const bool mk = wants_mask(src) && !a.accumulate && !a.out_scale && can_prepare;
         ready[src] = mk;
+        // Dense blocks: the next launch of this pass reads a channel slice of the gradient this launch writes (or adds to) --
+        // its final value: masked and measured here, on those channels, instead of by launch_grad_mask_amax
+        int slice_step = -1, slice_c0 = 0, slice_c1 = 0;
+        if (h2_bwd && !mk && can_prepare && i > 0 && gsteps[i - 1].kind == OpKind::Conv && gsteps[i - 1].conv.dst == src &&
+            gsteps[i - 1].bwd_h2_kind == 2 && !getenv("MI_GNINA_H2_BWD_PREPASS")) {
+          const Step &nx = gsteps[i - 1];
+          const bool nx_lig = nx.has_bwd_lig && (s.cur_flex == nullptr || s.flex_rows.empty());
+          slice_c0 = nx.conv.a.out_c0, slice_c1 = slice_c0 + nx.conv.a.cout;
+          if (!(nx_lig && !nx.has_bwd_lig_h2) && slice_c1 <= (lig_only ? 0 : st.conv.cin)) slice_step = i - 1;
+        }
+        if (slice_step >= 0) slice_ready[slice_step] = 1;
+        const bool prep = mk || slice_step >= 0;
+        const float *prep_mask = prep ? act_ptr(src) : nullptr;
+        unsigned *prep_amax = mk ? amax_of(src) : slice_step >= 0 ? amax_of((int)nbufs + slice_step) : nullptr;
+        const int prep_c0 = mk ? 0 : slice_c0, prep_c1 = mk ? (1 << 30) : slice_c1;
         char nm[96];
         const int cout_here = lig_only ? st.conv.cin - st.lig_c0 : st.conv.cin;  // grid-gradient channels this launch computes
         snprintf(nm, sizeof nm, "convT%d_s%d_%dto%d%s%s", a.ksize, a.S, st.conv.a.cout, cout_here, lig_only ? "_lig" : "", use_h2 ? "_h2" : "");
         const double S3 = (double)a.S * a.S * a.S;
         if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
+        if (use_h2 && h2_kind == 2 && !slice_ready[i]) {  // a slice of a concat buffer's gradient no launch has prepared: ReLU mask and per-pose maximum, in place
+          ProfScope ps2(s, "grad_mask_amax", 0.0, 0.0, nb);
+          launch_grad_mask_amax(g_ptr(dst) + st.conv.a.out_c0, act_ptr(dst) + st.conv.a.out_c0, st.conv.a.cout, m->buf_cp[dst],
+                                m->buf_cp[dst], (long)a.S * a.S * a.S, nb, amax_of((int)nbufs + i), s.stream);
+        }
         ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * cout_here * st.conv.a.cout, 0.0, nb);
         if (use_h2) {
           ConvArgs h;
@@ -1894,11 +1929,13 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           h.h2_wlds = 1;  // (the gradient-pass variant is compiled for the weights-in-LDS shapes only)
           h.in_mode = st.conv.a.pool == 1 ? 2 : 0;  // (the ReLU mask is in the gradient already)
           h.in_argmax = a.in_argmax;
-          h.in_amax = amax_of(dst);
+          h.in_amax = h2_kind == 2 ? amax_of((int)nbufs + i) : amax_of(dst);
+          h.out_scale = a.out_scale, h.accumulate = a.accumulate;
           h.sparse = getenv("MI_GNINA_H2_BWD_SKIP") ? 1 : 0;
-          h.out_mask = mk ? act_ptr(src) : nullptr;
+          h.out_mask = prep_mask;
           h.out_mask_cs = m->buf_cp[src];
-          h.out_amax = mk ? amax_of(src) : nullptr;
+          h.out_mask_c0 = prep_c0, h.out_mask_c1 = prep_c1;
+          h.out_amax = prep_amax;
           s.d_ovf.ensure(1);
           h.h2_overflow = s.d_ovf.p;
           launch_conv_h2(h, cfg, nb, s.stream);
@@ -1906,9 +1943,10 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           a.sparse = 0;
           launch_conv_bf16(a, st.bwd.cfg, nb, s.stream);
         } else {
-          a.out_mask = mk ? act_ptr(src) : nullptr;
+          a.out_mask = prep_mask;
           a.out_mask_cs = m->buf_cp[src];
-          a.out_amax = mk ? amax_of(src) : nullptr;
+          a.out_mask_c0 = prep_c0, a.out_mask_c1 = prep_c1;
+          a.out_amax = prep_amax;
           int cfg;
           pick_tile(bp, nb, a, cfg);
           launch_conv(a, cfg, nb, s.stream);
