@@ -698,6 +698,43 @@ def config_c5(capi, synth):
     return out
 
 
+def config_gradient_calls(capi, synth):
+    """One BFGS evaluation of CNN refinement (score + d loss / d atoms, torch_model.cpp:197-221; non_cache_cnn.cpp:79-169)
+    at the headline grid, B = 256 poses per call, host pointers: the 3x3x3 transposed convs on the split-fp16 kernel (the
+    default) against the same call with every transposed conv on fp32 MFMA (MI_GNINA_NO_H2_BWD=1, the round-3 path), and
+    how far the atom gradients of the two are apart."""
+    out = {"note": "48^3 grid, B = 256, receptor 2500 atoms, ligand 32 atoms; wall time of mi_scorer_score_grad, best of 3; "
+                   "max_rel_grad_diff = max over poses of max |g_split - g_fp32| / max |g_fp32|"}
+    B = 256
+    for name in ("default2017", "crossdock_default2018", "dense"):
+        m = capi.Model(name)
+        s = capi.Scorer([m])
+        rng = np.random.RandomState(0)
+        rec_xyz, rec_smt = synth.make_receptor(rng, 2500, synth.mapped_types(m.chan_of_smt(False)))
+        lx, ls = synth.make_ligand(rng, 32, synth.mapped_types(m.chan_of_smt(True)))
+        s.set_receptor(rec_xyz, rec_smt)
+        poses = synth.make_poses(rng, lx, B)
+        row, grads = {}, {}
+        for tag, env in (("split_fp16", None), ("fp32_mfma_transposed", "1")):
+            if env is None:
+                os.environ.pop("MI_GNINA_NO_H2_BWD", None)
+            else:
+                os.environ["MI_GNINA_NO_H2_BWD"] = env
+            grads[tag] = s.score_grad(poses, ls)["lig_grad"]
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                s.score_grad(poses, ls)
+                best = min(best, time.perf_counter() - t0)
+            row[tag + "_poses_per_s"] = round(B / best, 1)
+        os.environ.pop("MI_GNINA_NO_H2_BWD", None)
+        ga, gb = grads["split_fp16"].reshape(B, -1), grads["fp32_mfma_transposed"].reshape(B, -1)
+        row["max_rel_grad_diff"] = float((np.abs(ga - gb).max(1) / np.maximum(np.abs(gb).max(1), 1e-30)).max())
+        row["speedup"] = round(row["split_fp16_poses_per_s"] / row["fp32_mfma_transposed_poses_per_s"], 3)
+        out[name] = row
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -926,7 +963,8 @@ def main():
                 for key, fn in (("real_complex", lambda: config_real_complex(capi, synth, torch, dev, args)),
                                 ("c3", lambda: config_c3(capi, cpu_s)), ("c3_real", lambda: config_c3_real(capi, cpu_s)),
                                 ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth)),
-                                ("seam_b1", lambda: config_seam_b1(capi, synth))):
+                                ("seam_b1", lambda: config_seam_b1(capi, synth)),
+                                ("gradient_calls", lambda: config_gradient_calls(capi, synth))):
                     try:
                         res["also"][key] = fn()
                     except Exception as e:  # the headline line must still print
