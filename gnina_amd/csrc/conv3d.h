@@ -155,6 +155,7 @@ void launch_gmax_backward_bf16(const void *act, const float *g_out, float *g_in,
 size_t conv_h2_lds_bytes(const ConvArgs &p);
 bool conv_h2_has_cfg(int cfg);
 int conv_h2_mt_mask(int cfg);
+bool conv_h2_has_bwd_k1(int cfg);  // ... of conv3d_h2_k1_kernel (1x1x1 behind a fused max pool)
 bool conv_h2_has_bwd(int cfg);  // the gradient-pass variant of conv3d_h2_kernel exists for this tile shape  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
 void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl);
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);

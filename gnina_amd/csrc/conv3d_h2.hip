@@ -98,8 +98,11 @@ __device__ __forceinline__ void h2_report_overflow(unsigned *flag, bool lane_ove
 // conv3d_h2_k1_kernel: the 1x1x1 convolutions (instantiated with K1 = true only: no halo, at most one voxel per thread, up
 // to six octets of it per chunk; the 3x3x3 layers run on conv3d_h2_kernel below).  Single-buffered [voxel][octet][h | l]
 // tile, fp32 input split while staging.
-template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP, bool K1 = false>
+// BWD: a transposed 1x1x1 conv of the gradient pass behind a fused max pool (Dense transitions: `in`, `in_argmax` at S / 2,
+// in_mode 2; ConvArgs::in_amax scaling, out_scale, out_mask / out_amax on a channel range -- see conv3d_h2_kernel's BWD)
+template <int WM, int WN, int TM, int TN, bool MTX, bool SKIP, bool K1 = false, bool BWD = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 : 1)) void conv3d_h2_k1_kernel(ConvArgs p) {
+  static_assert(!BWD || K1, "gradient-pass variant: 1x1x1 convs only");
   constexpr int NTHREADS = 64 * WM * WN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
   unsigned n_exec = 0;  // (M-tile, step) pairs whose MFMAs this wave executed (SKIP; a scalar counter, read in profile mode only)
   float amax = 0.f;     // running maximum of |staged value| (range check, see split4)
+  float out_max = 0.f;  // BWD: running maximum of |stored value| on the masked channel range (ConvArgs::out_amax)
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
@@ -185,12 +189,29 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
     const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
     const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
     s_vox[hv] = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    if constexpr (BWD)  // max-unpool while staging: the voxel's cell of the half-resolution tensor, its position inside the cell on top
+      if (in && p.in_mode == 2)
+        s_vox[hv] = ((((x >> 1) * (S >> 1) + (y >> 1)) * (S >> 1) + (z >> 1)) * p.in_cs) | ((((x & 1) << 2) | ((y & 1) << 1) | (z & 1)) << 28);
     if (!in)  // the zero padding is laid down once per workgroup; staging then touches the voxels inside the grid only
       for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + hv * CCs + c) = make_uint4(0u, 0u, 0u, 0u);
   }
-  const float *in_b = p.in + (size_t)b * S * S * S * p.in_cs;
+  const bool unpool = BWD && p.in_mode == 2;
+  const int Sin = unpool ? S >> 1 : S;
+  const size_t pose_floats = (size_t)Sin * Sin * Sin * p.in_cs;
+  const float *in_b = p.in + (size_t)b * pose_floats;
   const size_t wstride = (size_t)p.coutp * 16;  // fp16 elements per octet row of the packed weights
   const int Pmax = (Qmax + 1) >> 1;
+  float s_in = 1.f, inv_s_in = 1.f;  // (ConvArgs::in_amax, as in conv3d_h2_kernel)
+  if constexpr (BWD) {
+    if (p.in_amax) {
+      const int e = (int)((p.in_amax[b] >> 23) & 0xffu);
+      if (e > 0 && e < 255) {
+        const int eb = max(4, min(250, 268 - e));
+        s_in = __uint_as_float((unsigned)eb << 23);
+        inv_s_in = __uint_as_float((unsigned)(254 - eb) << 23);
+      }
+    }
+  }
 
   // ---- staging, software-pipelined over the K chunks: the fp32 quads of chunk k + 1 are loaded into registers before the
   // K loop of chunk k and split / written to LDS after it.  (A load -> split -> ds_write chain per halo voxel exposes one
@@ -200,13 +221,15 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   // HV <= VPT * NTHREADS and 2 CC8 <= NQ): 3 x 4 under a 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv.
   constexpr int VPT = K1 ? 1 : 3, NQ = K1 ? 12 : 4;
   float4 pre[VPT][NQ];
+  unsigned pre_am[VPT][NQ];  // BWD, in_mode 2: the four arg-max bytes of the quad
   auto issue = [&](int chunk) {
     const float *src_c = in_b + chunk * CC8 * 8;
     const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);  // channel quads of this chunk that exist in the input
 #pragma unroll
     for (int v = 0; v < VPT; v++) {
       const int hv = tid + v * NTHREADS;
-      const int off = hv < HV ? s_vox[hv] : -1;
+      const int off0 = hv < HV ? s_vox[hv] : -1;
+      const int off = (BWD && off0 >= 0) ? off0 & 0x0fffffff : off0;
 #pragma unroll
       for (int q = 0; q < NQ; q++)
         if (off >= 0 && q < nq) {
@@ -215,6 +238,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
 #else
           pre[v][q] = *reinterpret_cast<const float4 *>(src_c + off + q * 4);
 #endif
+          if constexpr (BWD)
+            if (unpool) pre_am[v][q] = *reinterpret_cast<const unsigned *>(p.in_argmax + (size_t)b * pose_floats + chunk * CC8 * 8 + off + q * 4);
         }
     }
   };
@@ -245,10 +270,20 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
             x.z = x.z * sc.z + sh.z;
             x.w = x.w * sc.w + sh.w;
           }
+          if constexpr (BWD) {
+            if (unpool) {  // max-unpool: the cell's gradient goes to the voxel that was its maximum
+              const unsigned am = pre_am[v][q], rr = (unsigned)off >> 28;
+              x.x = (am & 0xffu) == rr ? x.x : 0.f;
+              x.y = ((am >> 8) & 0xffu) == rr ? x.y : 0.f;
+              x.z = ((am >> 16) & 0xffu) == rr ? x.z : 0.f;
+              x.w = (am >> 24) == rr ? x.w : 0.f;
+            }
+          }
           // the pooled voxel grid and ReLU'd activations are mostly zeros: a quad that is zero in all 64 voxels of the wave
           // (3 VALU + a scalar branch to find out) needs no arithmetic
           const unsigned any = __float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w);
           if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
+            if constexpr (BWD) x.x *= s_in, x.y *= s_in, x.z *= s_in, x.w *= s_in;
             split4(x, h, l, amax);
             wave_nonzero = true;
           }
@@ -345,7 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
   // tile is split and laid down in LDS as [voxel row][octet][h | l] -- what the stand-alone 1x1x1 kernel's staging would
   // build from the tensor in HBM, which therefore never exists -- and a second, short K loop runs over its channels.  Same
   // operands, same MFMA order as the two separate kernels: same bits (the gradient program runs them separately).
-  float unscale = p.h2_unscale;
+  float unscale = p.h2_unscale * inv_s_in;
   const float *bias_ptr = p.bias;
   int relu_flag = p.relu;
   if constexpr (!K1 && TN == 1 && TM <= 3) {
@@ -442,6 +477,31 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           for (int r = 1; r < 8; r++) s = s + v[r];
           out_f[(((size_t)gcx * So + gcy) * So + gcz) * p.out_cs + ch] = s * 0.125f;
         } else {
+          if constexpr (BWD) {
+            // gradient pass: BatchNorm scale of the forward layer's input (ConvArgs::out_scale), then the ReLU mask and the
+            // maximum on the channels [out_mask_c0, out_mask_c1) (ConvArgs::out_mask / out_amax); the activations are
+            // fetched, and consumed, ahead of the first store
+            const bool in_range = ch >= p.out_mask_c0 && ch < p.out_mask_c1;
+            const bool any_msk = p.out_mask && __builtin_amdgcn_ballot_w64(in_range) != 0ull;
+            const int ch_m = in_range ? ch : p.out_mask_c0;
+            const float osc = p.out_scale ? p.out_scale[ch] : 1.0f;
+            float a8[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+              const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+              a8[r] = 1.f;
+              if (any_msk) a8[r] = p.out_mask[((size_t)b * So * So * So + ((size_t)vx * So + vy) * So + vz) * p.out_mask_cs + ch_m];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+              if (p.out_scale) v[r] = v[r] * osc;
+              if (in_range) {
+                v[r] = a8[r] > 0.f ? v[r] : 0.f;
+                out_max = fmaxf(out_max, fabsf(v[r]));
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
@@ -449,6 +509,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN <= 2 ? 3 : TM * TN <= 4 ? 2 
           }
         }
       }
+    }
+  }
+  if constexpr (BWD) {
+    if (p.out_amax) {
+      for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
+      if (lane == 0 && __float_as_uint(out_max) > __hip_atomic_load(p.out_amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(p.out_amax + b, __float_as_uint(out_max));
     }
   }
   h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
@@ -1432,6 +1499,17 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
 template <int WM, int WN, int TM, int TN> static void launch_h2_k1(const ConvArgs &p, int B, hipStream_t s) {
   const int ngroups = (p.coutp / 32 + WN * TN - 1) / (WN * TN);
   dim3 grid(B * p.ntx * p.nty * p.ntz, ngroups), block(64 * WM * WN);
+  const bool bwd = p.in_amax || p.out_amax || p.out_mask || p.in_mode == 2 || p.out_scale;
+  if (bwd) {  // a transposed conv of the gradient pass: the shapes of conv_h2_has_bwd_k1
+    if (p.accumulate || (p.in_mode != 0 && p.in_mode != 2)) throw Error(2, "launch_conv_h2: 1x1x1 gradient-pass launch: no accumulation, plain or max-unpooled input");
+    if constexpr (WM == 4 && WN == 1 && TM == 1) {
+      auto kern = conv3d_h2_k1_kernel<WM, WN, TM, TN, false, false, true, true>;
+      ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+      hipLaunchKernelGGL(kern, grid, block, conv_h2_lds_bytes(p), s, p);
+      return;
+    }
+    throw Error(2, "launch_conv_h2: 1x1x1 gradient-pass variant not compiled for this tile shape");
+  }
   auto kern = conv3d_h2_k1_kernel<WM, WN, TM, TN, false, false, true>;
   ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
   hipLaunchKernelGGL(kern, grid, block, conv_h2_lds_bytes(p), s, p);
@@ -1520,6 +1598,7 @@ bool conv_h2_has_cfg(int cfg) {
 
 // tile shapes whose gradient-pass (transposed conv) variant is compiled
 bool conv_h2_has_bwd(int cfg) { return cfg == CONV_CFG_4x1_2x1 || cfg == CONV_CFG_4x1_1x1; }
+bool conv_h2_has_bwd_k1(int cfg) { return cfg == CONV_CFG_4x1_1x1 || cfg == CONV_CFG_4x1_1x3 || cfg == CONV_CFG_4x1_1x5; }
 
 int conv_h2_mt_mask(int cfg) {
   switch (cfg) {

@@ -191,7 +191,7 @@ static Op make_bwd_op(const Op &o) {
 // (force_std: the 4 x 1 waves x 2 M-tiles shape whatever the layer -- the only one conv3d_h2_kernel's gradient-pass variant
 // is compiled for)
 static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int dst_buf, int dst_c0,
-                      bool backward = false, bool n16_backward = false, bool force_std = false) {
+                      bool backward = false, bool n16_backward = false, bool force_std = false, bool k1_wide = false) {
   const int S = m.d.bufs[o.src].S;
   MIG_CHECK(S % 2 == 0, 2, "conv spatial size must be even");
   const int cells = S / 2;
@@ -218,12 +218,12 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
       if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
       else a.tcx = 2, a.tcy = 4, a.tcz = 4;
     }
-  } else if (o.ksize == 1 && NT == 3 && cells % 4 == 0 && !backward) {
+  } else if (o.ksize == 1 && NT == 3 && cells % 4 == 0 && (!backward || k1_wide)) {
     // 1x1 bottleneck 96 -> 96: all output channels in one workgroup (input read once); one M-tile per wave keeps the
     // kernel at 128 VGPRs = four waves per SIMD (two M-tiles: 191 VGPRs, two waves, 3.54 against 3.32 ms at 24^3)
     cp.cfg = CONV_CFG_4x1_1x3;
     a.tcx = 2, a.tcy = 2, a.tcz = 4;
-  } else if (o.ksize == 1 && NT == 5 && !backward) {
+  } else if (o.ksize == 1 && NT == 5 && (!backward || k1_wide)) {
     cp.cfg = CONV_CFG_4x1_1x5;  // 1x1 bottleneck 160 -> 160: 4 waves x 1 M-tile = 16 cells
     if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 3;  // 12 cells used of 16
     else a.tcx = 2, a.tcy = 2, a.tcz = 4;
@@ -944,6 +944,16 @@ static Model *build_model(ModelDesc &&desc) {
           // transposed 3x3x3 convs on the split-fp16 kernel (run_backward decides per call)
           const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.relu && pool_mode != 2 && dst_c0 % 4 == 0 && !getenv("MI_GNINA_NO_H2_BWD");
           auto shape_ok = [](const ConvPlan &cp) { return conv_h2_has_bwd(cp.cfg) && (!cp.has_lat || conv_h2_has_bwd(cp.lat_cfg)); };
+          // 1x1x1 convs behind a fused max pool (Dense transitions) on conv3d_h2_k1_kernel's gradient-pass variant: all
+          // output channels in one workgroup, as their forward twin
+          const bool bwd_h2_k1 = !no_h2 && o.ksize == 1 && o.relu && pool_mode == 1 && dst_c0 % 4 == 0 && o.src != o.dst &&
+                                 !getenv("MI_GNINA_NO_H2_BWD") && !getenv("MI_GNINA_NO_H2_BWD_K1");
+          if (bwd_h2_k1) {
+            plan_conv(*m, make_bwd_op(o), st.bwd_h2, 0, o.src, 0, true, false, false, true);
+            if (conv_h2_has_bwd_k1(st.bwd_h2.cfg) && (!st.bwd_h2.has_lat || conv_h2_has_bwd_k1(st.bwd_h2.lat_cfg)))
+              plan_conv_h2(*m, make_bwd_op(o), st.bwd_h2, false, true);
+            if (st.bwd_h2.has_h2 && !st.bwd_h2.h2_planar && !getenv("MI_GNINA_NO_H2_BWD_DENSE")) st.bwd_h2_kind = 2;
+          }
           if (bwd_h2) {
             plan_conv(*m, make_bwd_op(o), st.bwd_h2, 0, o.src, 0, true, false, true);
             if (shape_ok(st.bwd_h2)) plan_conv_h2(*m, make_bwd_op(o), st.bwd_h2, false, true);
@@ -1917,16 +1927,16 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         if (use_h2 && h2_kind == 2 && !slice_ready[i]) {  // a slice of a concat buffer's gradient no launch has prepared: ReLU mask and per-pose maximum, in place
           ProfScope ps2(s, "grad_mask_amax", 0.0, 0.0, nb);
           launch_grad_mask_amax(g_ptr(dst) + st.conv.a.out_c0, act_ptr(dst) + st.conv.a.out_c0, st.conv.a.cout, m->buf_cp[dst],
-                                m->buf_cp[dst], (long)a.S * a.S * a.S, nb, amax_of((int)nbufs + i), s.stream);
+                                m->buf_cp[dst], st.conv.a.pool ? (long)(a.S / 2) * (a.S / 2) * (a.S / 2) : (long)a.S * a.S * a.S, nb,
+                                amax_of((int)nbufs + i), s.stream);
         }
         ProfScope ps(s, nm, 2.0 * nb * S3 * a.ksize * a.ksize * a.ksize * cout_here * st.conv.a.cout, 0.0, nb);
         if (use_h2) {
           ConvArgs h;
           int cfg;
           h2_launch_args(bp, a, nb, h, cfg);
-          MIG_CHECK(bp.h2_planar, 2, "transposed split-fp16 conv without a planar plan");
           h.in_split = h.out_split = 0;
-          h.h2_wlds = 1;  // (the gradient-pass variant is compiled for the weights-in-LDS shapes only)
+          h.h2_wlds = bp.h2_planar ? 1 : 0;  // (3x3x3: the gradient-pass variant is compiled for the weights-in-LDS shapes only)
           h.in_mode = st.conv.a.pool == 1 ? 2 : 0;  // (the ReLU mask is in the gradient already)
           h.in_argmax = a.in_argmax;
           h.in_amax = h2_kind == 2 ? amax_of((int)nbufs + i) : amax_of(dst);
