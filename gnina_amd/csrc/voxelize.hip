@@ -75,12 +75,16 @@ __device__ __forceinline__ void rot_about(const Rot3 &r, float cx, float cy, flo
 // ---------------------------------------------------------------------------------------------
 // gather_pose_atoms
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
+// (kGatherThreads = 1,024: a pose's ~2,500 candidate atoms take three passes of the block instead of ten -- each pass is three
+// barriers and a round trip to L2, and a B = 1 call waits for all of them: 31 -> 12 us; the order of the lists is the
+// atoms' index order whatever the block size)
+constexpr int kGatherThreads = 1024, kGatherWaves = kGatherThreads / 64;
+__global__ __launch_bounds__(kGatherThreads) void gather_pose_atoms(GatherArgs g) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   __shared__ float s_center[3];
-  __shared__ int s_wave_cnt[kMaxSlabs][4];
+  __shared__ int s_wave_cnt[kMaxSlabs][kGatherWaves];
   __shared__ int s_base[kMaxSlabs];
 
   const float *lig = g.lig_xyz + (size_t)b * g.L * 3;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
   if (g.rot) R = rot_of_quat(g.rot + 4 * (size_t)b);
 
   const int total = g.n_rec + n_lig;
-  for (int base = 0; base < total; base += 256) {
+  for (int base = 0; base < total; base += kGatherThreads) {
     int i = base + tid;
     bool keep = false;
     AtomRec a;
@@ -191,7 +195,11 @@ __global__ __launch_bounds__(256) void gather_pose_atoms(GatherArgs g) {
       g.cand_chan[o] = ch;
     }
     __syncthreads();
-    if (tid < g.n_slab) s_base[tid] += s_wave_cnt[tid][0] + s_wave_cnt[tid][1] + s_wave_cnt[tid][2] + s_wave_cnt[tid][3];
+    if (tid < g.n_slab) {
+      int n = 0;
+      for (int w = 0; w < kGatherWaves; w++) n += s_wave_cnt[tid][w];
+      s_base[tid] += n;
+    }
     __syncthreads();
   }
   if (tid < g.n_slab) g.cand_n[(size_t)b * g.n_slab + tid] = s_base[tid];
@@ -622,7 +630,7 @@ void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream
 }
 
 void launch_gather(const GatherArgs &g, int B, hipStream_t s) {
-  hipLaunchKernelGGL(gather_pose_atoms, dim3(B), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(gather_pose_atoms, dim3(B), dim3(kGatherThreads), 0, s, g);
 }
 
 void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
