@@ -6,7 +6,9 @@ accumulated in float64, so what is measured is the split's own error:
   * the three kept terms reproduce a 3x3x3 convolution to ~2^-22 of sum |a||w| (the dropped l*l term and the two
     roundings of the halves), i.e. fp32-accumulation grade -- while two bf16 halves, also three MFMAs, are 60x worse;
   * the weights need their per-layer power-of-two scale: without it the low halves of small weights are fp16 subnormals;
-  * the loader's split (mi_debug_split_f16, host code of libmi_gnina.so) gives the same halves as this emulation.
+  * the loader's split (mi_debug_split_f16, host code of libmi_gnina.so) gives the same halves as this emulation;
+  * gradients (no fixed range) keep that grade at any magnitude once scaled by the power of two their per-pose maximum
+    selects -- the gradient-pass kernels' ConvArgs::in_amax.
 """
 import numpy as np
 import pytest
@@ -61,6 +63,45 @@ def test_weights_need_their_power_of_two_scale(layer):
     scaled = ((_conv_split(a, tiny, torch.float16, sw) - ex).abs() / mg).max().item()
     unscaled = ((_conv_split(a, tiny, torch.float16, 1.0) - ex).abs() / mg).max().item()
     assert scaled <= 2.0 ** -21 and unscaled > 8 * scaled
+
+
+def _amax_scale(amax):
+    """the gradient-pass kernels' scale (conv3d_h2_kernel<..., BWD>: ConvArgs::in_amax): 2^(14 - exponent of the pose's
+    largest |g|), from the float's bits exactly as the kernel takes it"""
+    e = (np.float32(amax).view(np.uint32) >> 23) & 0xff
+    if e == 0 or e == 255:
+        return 1.0
+    eb = max(4, min(250, 268 - int(e)))
+    return float(np.uint32(eb << 23).view(np.float32))
+
+
+@pytest.mark.parametrize("magnitude", [1e-9, 1e-4, 1.0, 3e4, 1e9])
+def test_a_gradient_scaled_by_its_maximum_is_fp32_grade_at_any_magnitude(layer, magnitude):
+    """A gradient tensor has no fixed range (1e-9 is below fp16's, 1e9 above it): the transposed convs stage
+    g * 2^(14 - exponent(max |g|)) and un-scale the accumulators.  Whatever the magnitude, the largest staged value lands
+    in [2^14, 2^15), nothing overflows, and the three-product split keeps its 2^-21 of sum |g||w| -- elements far below the
+    maximum lose RELATIVE precision (absolute error <= 2^-25 staged = 2^-39 of the maximum), which a sum dominated by the
+    large ones cannot see."""
+    a, w, _, _ = layer
+    g = torch.Generator().manual_seed(11)
+    # a ReLU-masked gradient with eight decades of dynamic range inside one pose
+    grad = torch.randn(a.shape, generator=g, dtype=torch.float64) * torch.exp(torch.rand(a.shape, generator=g, dtype=torch.float64) * -18.0)
+    grad = (grad * (a > 0) * magnitude).to(torch.float32).to(torch.float64)
+    s = _amax_scale(float(grad.abs().max()))
+    top = float(grad.abs().max()) * s
+    assert 2.0 ** 14 <= top < 2.0 ** 15
+    sw = 2.0 ** (13 - np.floor(np.log2(float(w.abs().max()))))
+    exact = F.conv3d(grad, w, padding=1)
+    mag = F.conv3d(grad.abs(), w.abs(), padding=1)
+    got = _conv_split(grad * s, w, torch.float16, sw) / s
+    ok = mag > 0
+    err = ((got - exact).abs()[ok] / mag[ok]).max().item()
+    assert err <= 2.0 ** -21, (magnitude, err)
+    # without the scale the same tensor is either flushed (tiny) or infinite (huge) in fp16
+    if magnitude <= 1e-9:
+        assert float(_split(grad, torch.float16)[0].abs().max()) == 0.0
+    if magnitude >= 1e9:
+        assert not torch.isfinite(_split(grad, torch.float16)[0]).all()
 
 
 def test_the_loaders_split_is_this_split(layer):
