@@ -119,8 +119,13 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * activations / weights and fp32 accumulation; voxelization, the fully connected heads and the score post-processing
  * stay fp32.  Its deviation from the fp32 path is a measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.
  * Gradient calls (MI_PRECISION_FP32 / _FP32_MFMA; never bf16): the forward pass takes the same kernels as a scoring
- * call of the same precision -- a pose scores the same bits with and without its gradient -- and the transposed
- * convolutions of the backward pass run on fp32 MFMA.
+ * call of the same precision -- a pose scores the same bits with and without its gradient.  Under MI_PRECISION_FP32 the
+ * 3x3x3 transposed convolutions of the backward pass (and the Dense transitions) run on the split-fp16 kernels as well: a
+ * gradient tensor is staged times the power of two that puts its per-pose maximum into [2^14, 2^15) -- recorded by
+ * whichever kernel wrote the tensor -- so no magnitude of gradient is out of range, and the atom gradients stay within
+ * ~1e-6 of a pose's largest element of what fp32 MFMA returns (tests/test_gpu_gradient.py); the remaining transposed
+ * convolutions, and all of them under MI_PRECISION_FP32_MFMA, run on fp32 MFMA.  A pose's gradient does not depend on
+ * the other poses of the call.
  * Range of the split-fp16 kernels: the high half of an activation is an fp16 number, so a model (or an input) that
  * produces |activation| > 65504 cannot run on them -- the reference runs any --cnn_model in fp32
  * (torch_model.cpp:49-118,185).  Every split-fp16 kernel and the voxelizer feeding one raise a per-scorer flag when a
