@@ -242,6 +242,9 @@ def test_split_fp16_transposed_convs_are_fp32_grade(capi, CG, name, tmp_path, mo
         assert np.abs(b["lig_grad"]).max() > 0 and np.abs(a["lig_grad"]).max() > 0, (model, np.abs(a["lig_grad"]).max(), np.abs(b["lig_grad"]).max(), a["loss"])
         assert close(a, b, "lig_grad") < 5e-6, (model, close(a, b, "lig_grad"))
         assert np.abs(a["pose"] - shipped["pose"]).max() < 1e-6 and close(a, shipped, "lig_grad") < 1e-5, model
+        # per-pose scaling: a pose's gradient has the same bits alone (latency tiles) and in the batch
+        one = s.score_grad(poses[1:2], lig_smt)
+        assert np.array_equal(one["lig_grad"][0], a["lig_grad"][1]), model
         assert s.h2_fallbacks() == 0
         # flexible rows: the transposed first conv computes every channel
         rows_f = np.argsort(np.linalg.norm(rec_xyz - poses[0].mean(0), axis=1))[:12].astype(np.int32)
