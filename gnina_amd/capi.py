@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_debug_read_activation", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -221,6 +221,8 @@ def lib():
         L.mi_debug_acos.restype = C.c_int
         L.mi_debug_split_f16.argtypes = [f32p, C.c_int, C.c_float, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), f32p]
         L.mi_debug_split_f16.restype = C.c_int
+        L.mi_debug_read_activation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_size_t]
+        L.mi_debug_read_activation.restype = C.c_int
         L.mi_scorer_flex_count.argtypes = [vp]
         L.mi_scorer_flex_count.restype = C.c_int
         L.mi_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_char_p), C.c_int]
@@ -618,6 +620,17 @@ class Scorer:
                                              C.c_void_p(pose_ptr), C.c_void_p(aff_ptr), C.c_void_p(loss_ptr),
                                              C.c_void_p(var_ptr) if var_ptr else None,
                                              MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE))
+
+    def read_activation(self, buf, B, model_index=0):
+        """diagnostic: activation buffer `buf` of the last forward call as fp32 [B][S][S][S][C] + whether it was split
+        (mi_debug_read_activation)"""
+        info = (C.c_int32 * 3)()
+        check(lib().mi_debug_read_activation(self.handle, int(model_index), int(buf), int(B), info, None, 0))
+        S, Cc, split = info[0], info[1], info[2]
+        out = np.empty((B, S, S, S, Cc), np.float32)
+        check(lib().mi_debug_read_activation(self.handle, int(model_index), int(buf), int(B), info,
+                                             out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out, bool(split)
 
     def enable_profile(self, on=True):
         check(lib().mi_scorer_enable_profile(self.handle, int(on)))

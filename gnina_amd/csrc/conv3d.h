@@ -110,6 +110,9 @@ struct ConvArgs {
   // final value of the NEXT layer's 16-channel slice of the concat buffer's gradient prepares that slice, after its own
   // out_scale / accumulate; the other channels are written as ever)
   int out_mask_c0, out_mask_c1;
+  // conv3d_h2_d16_kernel (conv3d_h2_dense.hip; Dense-block layers on split-format tensors): byte g of d16_taps[s] = the tap
+  // (dx * 9 + dy * 3 + dz; 27 = the zero-weight filler) lane group g feeds in step s -- the order the weights are packed in
+  unsigned d16_taps[7];
   int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
@@ -159,6 +162,13 @@ bool conv_h2_has_bwd_k1(int cfg);  // ... of conv3d_h2_k1_kernel (1x1x1 behind a
 bool conv_h2_has_bwd(int cfg);  // the gradient-pass variant of conv3d_h2_kernel exists for this tile shape  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
 void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl);
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);
+// conv3d_h2_dense.hip: Dense-block layers / 1x1x1 transitions on split-format tensors
+void conv_d16_tap_order(unsigned taps4[7], unsigned char order[28]);
+bool conv_d16_layout_conflict_free(int SY, int SX);
+size_t conv_h2_d16_lds_bytes(const ConvArgs &p);
+void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s);
+size_t conv_h2_k1s_lds_bytes(const ConvArgs &p);
+void launch_conv_h2_k1s(const ConvArgs &p, int B, hipStream_t s);
 
 void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s);
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);

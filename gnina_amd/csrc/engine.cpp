@@ -71,6 +71,12 @@ struct ConvPlan {
   bool h2_planar = false;
   int h2_lat_mt = 0, h2_lat_pad[2] = {0, 0};
   int h2_cfg = -1;  // >= 0: the throughput launch takes this kernel shape and h2's own tile (tc*, nt*) instead of the fp32 plan's
+  // Dense family on split-format tensors (conv3d_h2_dense.hip), taken when the layer's buffers are split (Model::buf_split):
+  // a Dense-block layer's own plan (BatchNorm folded into the weights / a border-class bias table, one octet per K chunk,
+  // its own tile), and "the 1x1x1 plan in h2 can run on conv3d_h2_k1s_kernel" (same packed weights, split-format input)
+  bool has_d16 = false;
+  ConvArgs d16{};
+  bool has_k1s = false;
 };
 
 // Tile geometry of a launch of `nb` poses: the throughput plan, or the latency variant when the throughput
@@ -626,6 +632,100 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post, b
   cp.h2_planar = planar;
 }
 
+// ---- a Dense-block layer (BatchNorm -> 3x3x3 conv, c_in -> 16 -> ReLU, appended to the concat buffer it reads) on
+// conv3d_h2_d16_kernel: split-format concat buffer in and out, BatchNorm folded.  `cp.a` (the fp32 plan) supplies S, bias ----
+static void plan_conv_d16(Model &m, const Op &o, ConvPlan &cp) {
+  if (o.ksize != 3 || o.cout != 16 || o.src != o.dst || o.cin % 8 || o.dst_c0 % 8 || cp.a.pool != 0) return;
+  const int S = m.d.bufs[o.src].S, cells = S / 2;
+  ConvArgs a = cp.a;
+  // tiles whose A-operand reads are conflict-free without pad slots (conv3d_h2_dense.hip): 2 x 4 x 4 cells at 24^3 / 48^3
+  // (sixteen M-tiles of 4 x 2 x 2 voxels: four per wave), 2 x 2 x 6 cells at 12^3 (twelve: three per wave)
+  if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
+  else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
+  else return;  // (6^3 blocks: 0.13 ms per layer, left on conv3d_h2_16_kernel and an fp32 buffer)
+  a.ntx = cdiv(cells, a.tcx), a.nty = cdiv(cells, a.tcy), a.ntz = cdiv(cells, a.tcz);
+  a.mt_x = 0;
+  a.h2_pad_y = a.h2_pad_x = 0;
+  {
+    const int HY = 2 * a.tcy + 2, HZ = 2 * a.tcz + 2;
+    const int SY = HZ, SX = HY * SY;
+    if (!conv_d16_layout_conflict_free(SY, SX)) {  // (not the case for the tiles above; kept for other grids)
+      bool found = false;
+      for (int py = 0; py < 4 && !found; py++)
+        for (int px = 0; px < 8 && !found; px++)
+          if (conv_d16_layout_conflict_free(HZ + py, HY * (HZ + py) + px)) a.h2_pad_y = py, a.h2_pad_x = px, found = true;
+      if (!found) return;
+    }
+  }
+  unsigned char order[28];
+  conv_d16_tap_order(a.d16_taps, order);
+  const int cin8 = o.cin / 8;
+  a.nchunks = cin8;
+  a.cc4 = 1;
+  a.cin4 = o.cin / 4;
+  a.coutp = 16;
+  // folded weights W'[t][c][n] = scale[c] W[t][c][n] (canonical [tap][cin][cout]); bias table per border class
+  const float *w = m.d.data.data() + o.w_off;
+  std::vector<float> sc(o.cin, 1.f), sh(o.cin, 0.f);
+  if (o.bn_scale_off >= 0) {
+    std::copy(m.d.data.begin() + o.bn_scale_off, m.d.data.begin() + o.bn_scale_off + o.cin, sc.begin());
+    std::copy(m.d.data.begin() + o.bn_shift_off, m.d.data.begin() + o.bn_shift_off + o.cin, sh.begin());
+  }
+  std::vector<float> wf((size_t)27 * o.cin * 16);
+  for (int t = 0; t < 27; t++)
+    for (int c = 0; c < o.cin; c++)
+      for (int n = 0; n < 16; n++) wf[((size_t)t * o.cin + c) * 16 + n] = (float)((double)sc[c] * (double)w[((size_t)t * o.cin + c) * o.cout + n]);
+  const float sw = h2_weight_scale(wf.data(), wf.size());
+  // packed [chunk = octet][step][h | l][lane group][cout][8 fp16]
+  std::vector<unsigned short> wp((size_t)cin8 * 7 * 2 * 4 * 16 * 8, 0);
+  for (int ch = 0; ch < cin8; ch++)
+    for (int st = 0; st < 7; st++)
+      for (int g = 0; g < 4; g++) {
+        const int tap = order[4 * st + g];
+        if (tap > 26) continue;  // the filler: zero rows
+        for (int n = 0; n < 16; n++)
+          for (int j = 0; j < 8; j++) {
+            const float v = wf[((size_t)tap * o.cin + ch * 8 + j) * 16 + n] * sw;
+            const unsigned short hi = host_f2h(v), lo = host_f2h(v - host_h2f(hi));
+            const size_t rowh = ((((size_t)ch * 7 + st) * 2 + 0) * 4 + g) * 16 + n, rowl = ((((size_t)ch * 7 + st) * 2 + 1) * 4 + g) * 16 + n;
+            wp[rowh * 8 + j] = hi;
+            wp[rowl * 8 + j] = lo;
+          }
+      }
+  std::vector<float> wpf((wp.size() + 1) / 2, 0.f);
+  memcpy(wpf.data(), wp.data(), wp.size() * sizeof(unsigned short));
+  a.wp = push_dev(m, wpf);
+  a.h2_unscale = 1.f / sw;
+  // y = sum (x sc + sh) W = sum x (sc W) + sum over the taps INSIDE the grid of sh W: one bias row per border class of the
+  // output voxel (3 x 3 x 3: first / interior / last plane per axis; the zero padding is zero after the BatchNorm)
+  std::vector<float> tab(27 * 16, 0.f);
+  for (int cls = 0; cls < 27; cls++) {
+    const int e[3] = {cls / 9, (cls / 3) % 3, cls % 3};
+    for (int n = 0; n < 16; n++) {
+      double acc = m.d.data[o.b_off + n];
+      for (int t = 0; t < 27; t++) {
+        const int d[3] = {t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1};
+        bool inside = true;
+        for (int ax = 0; ax < 3; ax++)
+          if ((e[ax] == 0 && d[ax] < 0) || (e[ax] == 2 && d[ax] > 0)) inside = false;
+        if (!inside) continue;
+        for (int c = 0; c < o.cin; c++) acc += (double)sh[c] * (double)w[((size_t)t * o.cin + c) * o.cout + n];
+      }
+      tab[cls * 16 + n] = (float)acc;
+    }
+  }
+  a.bias_tab = push_dev(m, tab);
+  a.bn_scale = a.bn_shift = nullptr;
+  a.sparse = 0;
+  a.korder = 0;
+  a.mfma_count = nullptr;
+  a.in_split = a.out_split = 1;
+  a.h2_wlds = 2;
+  if (conv_h2_d16_lds_bytes(a) > 160 * 1024) return;
+  cp.d16 = a;
+  cp.has_d16 = true;
+}
+
 // ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
 static unsigned short host_f2bf(float f) {
   unsigned u;
@@ -890,6 +990,14 @@ static Model *build_model(ModelDesc &&desc) {
         // program's forward pass takes it for exactly the layers the forward program does: a pose scores the same bits
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
         if (!no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv, post != nullptr);
+        // Dense family on split-format tensors (forward program only; which of the two plans runs follows the buffers' format)
+        if (!no_h2 && !grad && !post && !getenv("MI_GNINA_NO_DENSE_SPLIT")) {
+          plan_conv_d16(*m, o, st.conv);
+          const ConvArgs &h = st.conv.h2;
+          st.conv.has_k1s = st.conv.has_h2 && !st.conv.h2_planar && o.ksize == 1 && o.bn_scale_off < 0 && o.cin % 8 == 0 &&
+                            (st.conv.cfg == CONV_CFG_4x1_1x3 || st.conv.cfg == CONV_CFG_4x1_1x5) && h.coutp == (st.conv.cfg == CONV_CFG_4x1_1x3 ? 96 : 160) &&
+                            h.tcx * h.tcy * h.tcz <= 16 && h.cc4 * h.nchunks == o.cin / 8 && (size_t)8 * h.tcx * h.tcy * h.tcz * (2 * h.cc4 + 1) <= 7 * 256;
+        }
         if (post && st.conv.has_h2) {
           // the 1x1x1 conv's own split-fp16 plan supplies the packed weights of the fused second pass: its K chunks must
           // be consecutive whole octet pairs ([chunk][pairs][2][coutp][h | l] is then one [pair][2][coutp][h | l] array)
@@ -1025,24 +1133,47 @@ static Model *build_model(ModelDesc &&desc) {
   m->Cp8 = round_up(m->C, 8);
   m->buf_split.assign(d.bufs.size(), 0);
   if (!getenv("MI_GNINA_NO_H2") && !getenv("MI_GNINA_H2_NO_SPLIT_TENSORS")) {
-    std::vector<int> readers(d.bufs.size(), 0), split_readers(d.bufs.size(), 0), producers(d.bufs.size(), 0), split_producers(d.bufs.size(), 0);
+    // A buffer is split when every layer reading it can stage the split format and every layer writing it can produce it.
+    // What a layer can write may depend on what it reads (conv3d_h2_k1s_kernel is the 1x1x1 kernel with the split epilogue
+    // AND the split staging): iterate down from "everything that could be" to the fixed point.
+    std::vector<int> readers(d.bufs.size(), 0);
     for (const Step &st : m->steps) {
-      if (st.kind == OpKind::Conv) {
+      const int src = st.kind == OpKind::Conv ? st.conv.src : st.src;
+      if (src >= 0) readers[src]++;
+    }
+    std::vector<char> split(d.bufs.size(), 1);
+    auto src_split = [&](int id) { return id == m->input_dst ? true : (bool)split[id]; };
+    for (int it = 0; it < (int)d.bufs.size() + 2; it++) {
+      std::vector<char> next(d.bufs.size(), 1);
+      for (size_t id = 0; id < d.bufs.size(); id++)
+        if (readers[id] == 0 || m->buf_cp[id] % 8 != 0) next[id] = 0;
+      for (const Step &st : m->steps) {
+        if (st.kind != OpKind::Conv) {
+          if (st.src >= 0) next[st.src] = 0;
+          if (st.dst >= 0) next[st.dst] = 0;
+          continue;
+        }
         const bool k3 = st.conv.has_h2 && st.conv.h2_planar;
-        readers[st.conv.src]++;
-        if (k3 && !st.has_bn) split_readers[st.conv.src]++;
-        producers[st.conv.dst]++;
         const ConvArgs &h = st.conv.h2;
-        if (k3 && h.out_c0 == 0 && h.cout == h.coutp && h.cout == d.bufs[st.conv.dst].C && h.cout % 8 == 0) split_producers[st.conv.dst]++;
-      } else {
-        if (st.src >= 0) readers[st.src]++;
-        if (st.dst >= 0) producers[st.dst]++;
+        const bool can_read = (k3 && !st.has_bn) || st.conv.has_d16 || st.conv.has_k1s;
+        // (whole octets from channel 0: conv3d_h2_kernel's epilogue; any octet-aligned slice: the Dense kernels', which run
+        // only on a split input)
+        const bool can_write = (k3 && h.out_c0 == 0 && h.cout == h.coutp && h.cout % 8 == 0) ||
+                               (st.conv.has_d16 && src_split(st.conv.src)) ||
+                               (st.conv.has_k1s && src_split(st.conv.src) && h.out_c0 % 8 == 0 && h.cout % 8 == 0);
+        if (!can_read) next[st.conv.src] = 0;
+        if (!can_write) next[st.conv.dst] = 0;
       }
+      for (size_t id = 0; id < d.bufs.size(); id++) next[id] = next[id] && split[id];
+      if (next == split) break;
+      split = next;
     }
-    for (size_t id = 0; id < d.bufs.size(); id++) {
-      if ((int)id == m->input_dst) continue;
-      m->buf_split[id] = readers[id] > 0 && readers[id] == split_readers[id] && producers[id] == 1 && split_producers[id] == 1;
-    }
+    for (size_t id = 0; id < d.bufs.size(); id++)
+      if ((int)id != m->input_dst) m->buf_split[id] = split[id];
+    // the pooled voxel grid: written by the voxelizer (either format), read by the first layers
+    std::vector<int> split_readers(d.bufs.size(), 0);
+    for (const Step &st : m->steps)
+      if (st.kind == OpKind::Conv && st.conv.has_h2 && st.conv.h2_planar && !st.has_bn) split_readers[st.conv.src]++;
     m->pooled_split_ok = readers[m->input_dst] > 0 && readers[m->input_dst] == split_readers[m->input_dst] && m->input_pool != 0;
   }
   // gradient program: conv / pool stacks (Default2017 / Default2018 families) and the Dense family
@@ -1735,11 +1866,29 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           snprintf(nm, sizeof nm, "conv%d_s%d_%dto%d%s%s", a.ksize, a.S, st.conv.cin, a.cout,
                    a.post_w ? "+conv1" : "", a.pool ? "_pool" : "");
           if (bf16) strncat(nm, "_bf16", sizeof nm - strlen(nm) - 1);
+          if (use_h2 && is_split(st.conv.src) && (st.conv.has_d16 || st.conv.has_k1s)) strncat(nm, "_sp", sizeof nm - strlen(nm) - 1);
           if (use_h2) strncat(nm, "_h2", sizeof nm - strlen(nm) - 1);
           ProfScope ps(s, nm, 2.0 * nb * S3 * (taps * st.conv.cin * a.cout + (a.post_w ? (double)a.cout * st.post_cout : 0.0)),
                        (double)nb * S3 * 4.0 * (st.conv.cin + a.cout / (a.pool ? 8.0 : 1.0)), nb);
           if (bf16) {
             launch_conv_bf16(a, st.conv.cfg, nb, s.stream);
+          } else if (use_h2 && is_split(st.conv.src) && (st.conv.has_d16 || st.conv.has_k1s)) {
+            // Dense family on split-format tensors (conv3d_h2_dense.hip): a block layer, or the 1x1x1 transition behind a block
+            ConvArgs h = st.conv.has_d16 ? st.conv.d16 : st.conv.h2;
+            h.in = a.in, h.in_cs = a.in_cs, h.out = a.out, h.out_cs = a.out_cs;
+            h.in_split = 1;
+            h.out_split = is_split(st.conv.dst) ? 1 : 0;
+            h.argmax_out = nullptr;
+            s.d_ovf.ensure(1);
+            h.h2_overflow = s.d_ovf.p;
+            h.mfma_count = nullptr;
+            if (st.conv.has_d16) {
+              MIG_CHECK(h.out_split, 2, "Dense-block layer planned on split tensors writes a buffer that is not split");
+              if (const char *ev = getenv("MI_GNINA_D16_NP")) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
+              launch_conv_h2_d16(h, nb, s.stream);
+            } else {
+              launch_conv_h2_k1s(h, nb, s.stream);
+            }
           } else if (use_h2) {
             // split-fp16 kernel: same tensors, same tiles (pick_tile), own K chunking and weights
             ConvArgs h;
@@ -2473,6 +2622,42 @@ mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, u
     hi[i] = host_f2h(v);
     lo[i] = host_f2h(v - host_h2f(hi[i]));
   }
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+// Diagnostic: activation buffer `buf` of model `mi` as the LAST forward call of this scorer left it, converted to fp32
+// channels-last [B][S][S][S][C] on the host (a split-format buffer is decoded: value = h + l).  info = {S, C, split}.
+mi_status mi_debug_read_activation(mi_scorer *sc, int mi, int buf, int B, int32_t *info, float *out, size_t out_floats) {
+  MI_TRY
+  MIG_CHECK(sc && info, 1, "NULL argument");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_CHECK(mi >= 0 && mi < (int)s.models.size(), 1, "model index out of range");
+  Model *m = s.models[mi];
+  MIG_CHECK(!m->overlap && buf >= 0 && buf < (int)m->d.bufs.size() && buf != m->input_dst && m->buf_cp[buf] > 0, 1, "no such activation buffer");
+  const BufDecl &bd = m->d.bufs[buf];
+  const int cs = m->buf_cp[buf];
+  const bool split = s.precision == 0 && s.conv_path != 0 && m->buf_split[buf];
+  info[0] = bd.S, info[1] = bd.C, info[2] = split ? 1 : 0;
+  if (!out) return MI_OK;
+  const size_t S3 = (size_t)bd.S * bd.S * bd.S;
+  MIG_CHECK(B >= 1 && B <= s.cap && out_floats >= (size_t)B * S3 * bd.C, 1, "bad batch / output size");
+  MIG_CHECK((size_t)buf < s.act.size() && s.act[buf] && s.act[buf]->n >= (size_t)B * S3 * cs, 2, "buffer not allocated by a forward call");
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  std::vector<float> raw((size_t)B * S3 * cs);
+  MIG_HIP(hipMemcpy(raw.data(), s.act[buf]->p, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; b++)
+    for (size_t v = 0; v < S3; v++)
+      for (int c = 0; c < bd.C; c++) {
+        float val;
+        if (split) {  // [octet][voxel][h0..h7 | l0..l7]
+          const unsigned short *rec = reinterpret_cast<const unsigned short *>(raw.data() + (size_t)b * S3 * cs) + (((size_t)(c >> 3) * S3 + v) * 16);
+          val = host_h2f(rec[c & 7]) + host_h2f(rec[8 + (c & 7)]);
+        } else {
+          val = raw[((size_t)b * S3 + v) * cs + c];
+        }
+        out[((size_t)b * S3 + v) * bd.C + c] = val;
+      }
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -21,10 +21,14 @@
 //    No atomics: per voxel the sum runs in atom order, which makes
 //    the result deterministic and equal to the oracle's up to the exp/sqrt approximations.
 //  * Output is either the reference layout [B][C][N][N][N] (export path, mi_voxelize_batch) or,
-//    for the CNN, the 2x2x2-pooled grid written channels-last [B][N/2][N/2][N/2][Cp] straight
-//    from registers: every shipped network starts with Max/AvgPool3d(2), so the
-//    full-resolution grid (15.5 MB/pose) never touches HBM; pooled tiles are staged in LDS and
-//    stored as 16-byte coalesced runs.
+//    for the CNN, the 2x2x2-pooled grid written straight from registers: every shipped network
+//    starts with Max/AvgPool3d(2), so the full-resolution grid (15.5 MB/pose)
+//    never touches HBM.  Two pooled formats: channels-last fp32 [B][N/2][N/2][N/2][Cp] (gradient,
+//    fp32-MFMA and bf16 programs) and -- the default forward program -- the split-fp16 kernels'
+//    octet-major tensor format [B][Cp/8][N/2][N/2][N/2][h0..h7 | l0..l7] (VoxArgs::split,
+//    conv3d.h ConvArgs::in_split), which the first convolution stages by LDS-DMA.  Pooled tiles
+//    are staged in LDS one window of channels (split: one octet) at a time and stored as 16-byte
+//    coalesced runs.
 //  * In/out decisions (which voxels are non-zero, gaussian vs quadratic zone) use thresholds on
 //    the squared distance precomputed per atom type on the host (typer.cpp) so they are
 //    bit-identical to the sqrtf-based reference arithmetic.
@@ -37,6 +41,9 @@
 namespace mig {
 
 constexpr int kVoxSplitWin = 8;  // channels per staged window of the split-format output: one octet (the format is octet-major)
+// transpose buffer of voxelize_tiles (sub-block ownership -> cell ownership): dwords between the rows of two sub-blocks
+// (64 lanes + the largest bank offset, 21) and its size
+constexpr int kVoxTrStride = 96, kVoxTrFloats = 8 * kVoxTrStride;
 
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -298,13 +305,20 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [64][kWin] (+ transpose buffer, arg-max bytes)
   const int Cp = v.Cp;
   const int nwin = (Cp + kWin - 1) / kWin;
-  float *s_tr = s_stage + 64 * kWin;                                            // [64 lanes][8 sub-blocks]
-  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + 512);         // [64][kWin], only if argmax_out
-  // where the r-th voxel (x*4 + y*2 + z) of this lane's pooling cell (cx, cy, cz) sits in s_tr: the voxel is (2 cx + rx,
-  // 2 cy + ry, 2 cz + rz), written by lane (x & 3) + 4 (y & 3) + 16 (z & 3) as its sub-block (x >> 2, y >> 2, z >> 2) --
-  // one per-lane base plus a compile-time offset per r (an immediate of the ds_read), not eight address registers
-  const int tbase = (2 * ((lane >> 4) & 1) + 8 * ((lane >> 2) & 1) + 32 * (lane & 1)) * 8 + ((lane >> 5) & 1) * 4 +
-                    ((lane >> 3) & 1) * 2 + ((lane >> 1) & 1);
+  float *s_tr = s_stage + 64 * kWin;                                            // [8 sub-blocks][kTrStride] (see tr_put below)
+  unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + kVoxTrFloats); // [64][kWin], only if argmax_out
+  // The transpose buffer, bank-conflict free in both directions (round 5; the [lane][8] layout cost 4 LDS cycles per
+  // ds_read_b32 lane group instead of 1 -- SQ_LDS_BANK_CONFLICT was 0.68 of the kernel's LDS-active cycles, next to a VALU
+  // 76 % busy).  Writer lane L = lx + 4 ly + 16 lz puts acc[k] at dword  kVoxTrStride k + F(k, L) + L,
+  // F = (k & 1) + 4 ((k >> 1) & 1) + 16 (L >> 5): for one k the 32 lanes of a ds_write_b32 lane group hit 32 consecutive
+  // dwords.  The r-th voxel (x*4 + y*2 + z) of this lane's pooling cell (cx, cy, cz) is (2 cx + rx, 2 cy + ry, 2 cz + rz),
+  // written by lane L' = (x & 3) + 4 (y & 3) + 16 (z & 3) as its sub-block k' = (x >> 2, y >> 2, z >> 2): the reading lane's
+  // bits (b5 .. b0) = (cx, cy, cz) give L' = (2 b4 + 8 b2 + 32 b0) + (rx + 4 ry + 16 rz) and k' = 4 b5 + 2 b3 + b1, so the
+  // 32 lanes of a ds_read_b32 group (b5 fixed) read dwords that are 2 b4 + 8 b2 + b1 + 4 b3 + 16 b0 + const modulo 32 --
+  // all 32 banks -- from one per-lane base plus a compile-time offset per r (an immediate of the ds_read).
+  const int tw_base = lane + 16 * (lane >> 5);  // writer: + kVoxTrStride k + (k & 1) + 4 ((k >> 1) & 1), immediates
+  const int tbase = (4 * ((lane >> 5) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 1) & 1)) * kVoxTrStride + ((lane >> 1) & 1) +
+                    4 * ((lane >> 3) & 1) + 16 * (lane & 1) + 2 * ((lane >> 4) & 1) + 8 * ((lane >> 2) & 1) + 32 * (lane & 1);
   // pooled output, tile-invariant per lane: item i = lane + 64 k of a window is float4 `part` of cell i / (kWin / 4)
   // (staged at s_stage + 4 i); eo[k] = its float offset inside the pose without the window's channel base, part in
   // the two low bits (the offset is a multiple of 4), all ones = outside the grid
@@ -374,8 +388,15 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       const int part = (int)(eo[k] & 3u);
       if (eo[k] != 0xffffffffu && c0 + 4 * part < Cp) {
         const unsigned o = (eo[k] & ~3u) + (SPLIT ? (unsigned)(cur_w * S * S * S * kWin) : (unsigned)c0);
-        // (cell * kWin + 4 * part == 4 * i: the staged tile is read back in item order)
-        const float4 item = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
+        float4 item;
+        if constexpr (SPLIT) {  // item i = lane + 64 k is dwords 4 part .. 4 part + 3 of cell i >> 1 (transposed stage: stage_put)
+          const int cell = (lane + 64 * k) >> 1;  // (part == i & 1)
+          const float *src = s_stage + 256 * part + ((cell + 16 * part) & 63);
+          item = make_float4(src[0], src[64], src[128], src[192]);
+        } else {
+          // (cell * kWin + 4 * part == 4 * i: the staged tile is read back in item order)
+          item = *reinterpret_cast<const float4 *>(s_stage + 4 * (lane + 64 * k));
+        }
         if constexpr (SPLIT) any_bits |= __float_as_uint(item.x) | __float_as_uint(item.y) | __float_as_uint(item.z) | __float_as_uint(item.w);
         *reinterpret_cast<float4 *>(out_pose + o) = item;
         if (MODE == 1 && v.argmax_out)
@@ -398,11 +419,15 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   bool ovf = false;
   auto stage_put = [&](int cw, float val) {
     if constexpr (SPLIT) {
+      // The staged octet is kept TRANSPOSED -- dword d of cell c's 32-byte record [h0..h7 | l0..l7] at dword
+      // 64 d + ((c + 16 (d >> 2)) & 63) -- so that the 32 lanes of a store group hit 32 different banks (as [cell][8 dwords]
+      // the two 16-bit stores of every flush were 8-way conflicts) and so do the 32 lanes of emit_window's reads.
       ovf |= !(val <= 65504.f);
       const unsigned hl = vox_split1(val);
-      unsigned short *row = reinterpret_cast<unsigned short *>(s_stage) + lane * (2 * kWin) + (cw >> 3) * 16 + (cw & 7);
-      row[0] = (unsigned short)(hl & 0xffffu);
-      row[8] = (unsigned short)(hl >> 16);
+      unsigned short *st16 = reinterpret_cast<unsigned short *>(s_stage);
+      const int d = cw >> 1, hf = cw & 1;  // (wave-uniform)
+      st16[(64 * d + lane) * 2 + hf] = (unsigned short)(hl & 0xffffu);
+      st16[(64 * (4 + d) + ((lane + 16) & 63)) * 2 + hf] = (unsigned short)(hl >> 16);
     } else {
       s_stage[lane * kWin + cw] = val;
     }
@@ -423,13 +448,13 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       return;
     }
     // sub-block ownership -> cell ownership (wave-synchronous LDS round trip; LDS executes a wave's accesses in order)
-    *reinterpret_cast<float4 *>(s_tr + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4 *>(s_tr + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_tr[tw_base + k * kVoxTrStride + (k & 1) + 4 * ((k >> 1) & 1)] = acc[k];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     float cv[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) cv[r] = s_tr[tbase + ((r >> 2) + 4 * ((r >> 1) & 1) + 16 * (r & 1)) * 8];
+    for (int r = 0; r < 8; r++) cv[r] = s_tr[tbase + (r >> 2) + 4 * ((r >> 1) & 1) + 16 * (r & 1)];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (MODE == 1) {
@@ -644,10 +669,10 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
-    size_t lds = (size_t)64 * 12 * sizeof(float) + 512 * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
+    size_t lds = (size_t)64 * 12 * sizeof(float) + kVoxTrFloats * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
     if (getenv("MI_VOX_LDS_PAD")) lds += (size_t)atoi(getenv("MI_VOX_LDS_PAD")) * 1024;  // occupancy experiment
     if (v.split) {
-      lds = (size_t)64 * kVoxSplitWin * sizeof(float) + 512 * sizeof(float);
+      lds = (size_t)64 * kVoxSplitWin * sizeof(float) + kVoxTrFloats * sizeof(float);
       if (mode == 1) hipLaunchKernelGGL((voxelize_tiles<1, true>), grid, block, lds, s, v);
       else hipLaunchKernelGGL((voxelize_tiles<2, true>), grid, block, lds, s, v);
     } else if (mode == 1)

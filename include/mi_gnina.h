@@ -150,6 +150,11 @@ mi_status mi_debug_h2_layout(const int32_t *tile_cells3, int n_mtiles, int geome
  * (round to nearest even, subnormals kept).  scale = 0 picks the per-layer power of two the loader would: the one that
  * lifts max |x| into [2^13, 2^14); the scale used is returned in *scale_out (may be NULL). */
 mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, uint16_t *lo, float *scale_out);
+/* Diagnostic: activation buffer `buf` (the model blob's "buf" ids) of model `model_index` as the LAST forward call of this
+ * scorer left it, decoded to fp32 channels-last [B][S][S][S][C] on the host -- a split-format buffer (h + l) as well as an
+ * fp32 one.  info[3] = {S, C, 1 if the buffer is in the split format under the scorer's precision}; out may be NULL to
+ * query info only.  tests/test_gpu_dense_split.py compares the split-fp16 and fp32-MFMA programs layer by layer with it. */
+mi_status mi_debug_read_activation(mi_scorer *, int model_index, int buf, int B, int32_t *info, float *out, size_t out_floats);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
  * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as
