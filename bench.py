@@ -247,7 +247,8 @@ def other_models(args, capi, synth, torch, dev):
 def conv1_dense(args, scorer, step, steps):
     """The dominant kernel with zero-quad skipping switched off (MI_GNINA_NO_SPARSE=1, read per launch): every
     algorithmic MAC is executed, so this rate IS the MFMA pipe's -- it does not depend on how empty the receptor is."""
-    os.environ["MI_GNINA_NO_SPARSE"] = "1"
+    from gnina_amd import capi
+    capi.set_option("MI_GNINA_NO_SPARSE", "1")
     try:
         for _ in range(2):
             step()
@@ -258,7 +259,7 @@ def conv1_dense(args, scorer, step, steps):
         prof = scorer.profile()
         scorer.enable_profile(False)
     finally:
-        del os.environ["MI_GNINA_NO_SPARSE"]
+        capi.set_option("MI_GNINA_NO_SPARSE", None)
     conv = max((r for r in prof if r["kernel"].startswith("conv")), key=lambda r: r["ms_total"])
     ms = conv["ms_total"] / conv["launches"]
     tf = conv["flops"] / conv["launches"] / (ms * 1e-3) / 1e12
@@ -716,10 +717,7 @@ def config_gradient_calls(capi, synth):
         poses = synth.make_poses(rng, lx, B)
         row, grads = {}, {}
         for tag, env in (("split_fp16", None), ("fp32_mfma_transposed", "1")):
-            if env is None:
-                os.environ.pop("MI_GNINA_NO_H2_BWD", None)
-            else:
-                os.environ["MI_GNINA_NO_H2_BWD"] = env
+            capi.set_option("MI_GNINA_NO_H2_BWD", env)
             grads[tag] = s.score_grad(poses, ls)["lig_grad"]
             best = 1e30
             for _ in range(3):
@@ -727,7 +725,7 @@ def config_gradient_calls(capi, synth):
                 s.score_grad(poses, ls)
                 best = min(best, time.perf_counter() - t0)
             row[tag + "_poses_per_s"] = round(B / best, 1)
-        os.environ.pop("MI_GNINA_NO_H2_BWD", None)
+        capi.set_option("MI_GNINA_NO_H2_BWD", None)
         ga, gb = grads["split_fp16"].reshape(B, -1), grads["fp32_mfma_transposed"].reshape(B, -1)
         row["max_rel_grad_diff"] = float((np.abs(ga - gb).max(1) / np.maximum(np.abs(gb).max(1), 1e-30)).max())
         row["speedup"] = round(row["split_fp16_poses_per_s"] / row["fp32_mfma_transposed_poses_per_s"], 3)

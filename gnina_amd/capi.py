@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_debug_read_activation", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_debug_read_activation", "mi_gnina_set_option", "mi_gnina_options", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",
@@ -98,6 +98,9 @@ def lib():
             raise MiGninaError(f"{LIB_PATH} has ABI version {L.mi_gnina_abi_version()}, this binding expects {ABI_VERSION} "
                                "(struct layouts differ): rebuild with `python __graft_entry__.py build`")
         L.mi_last_error.restype = C.c_char_p
+        L.mi_gnina_set_option.argtypes = [C.c_char_p, C.c_char_p]
+        L.mi_gnina_set_option.restype = C.c_int
+        L.mi_gnina_options.restype = C.c_char_p
         L.mi_model_load.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
         L.mi_model_load.restype = vp
         L.mi_model_load_file.argtypes = [C.c_char_p]
@@ -1162,3 +1165,28 @@ def device_acosf(x):
 
 def init(device=0):
     check(lib().mi_gnina_init(device))
+
+
+def set_option(name, value=None):
+    """mi_gnina_set_option: an experiment / A-B switch of the library (gnina_amd/csrc/options.h).  The library reads the
+    environment once per process; afterwards this is the only way to change a switch.  value None = unset."""
+    check(lib().mi_gnina_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+class option:
+    """with capi.option("MI_GNINA_H2_WLDS", 0): ... -- a switch set for the block, restored to unset afterwards"""
+
+    def __init__(self, name, value="1"):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, None)
+        return False
+
+
+def options():
+    return lib().mi_gnina_options().decode()

@@ -26,6 +26,7 @@
 #include "model.h"
 #include "typer.h"
 #include "voxelize.h"
+#include "options.h"
 
 namespace mig {
 
@@ -33,11 +34,15 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 // The one environment variable this library WRITES, once per process and -- when a pool starts worker threads -- on the
-// caller's thread before they exist (mi_pool_create): glibc does not make setenv safe against getenv in other threads,
-// and the engine reads its MI_GNINA_* switches with getenv while models load.
+// caller's thread before they exist (mi_pool_create): glibc does not make setenv safe against getenv in other threads.
+// The library's own MI_* switches are read from the environment here as well, once (options.h): nothing in the engine calls
+// getenv afterwards.
 void process_env_once() {
   static std::once_flag once;
-  std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+  std::call_once(once, [] {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    (void)option(OPT_MI_GNINA_NO_H2);
+  });
 }
 
 void ensure_max_lds(const void *kernel, int bytes) {
@@ -88,7 +93,7 @@ static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
   conv_cfg_shape(cp.cfg, &wm, &wn, &tm, &tn);
   const long groups = cdiv(a.coutp / (cp.cfg == CONV_CFG_N16_TM4 || cp.cfg == CONV_CFG_N16_TM3 ? 16 : 32), wn * tn);
   const long blocks = (long)nb * a.ntx * a.nty * a.ntz * groups;
-  if (blocks >= 512 || getenv("MI_GNINA_NO_LAT")) return;
+  if (blocks >= 512 || option(OPT_MI_GNINA_NO_LAT)) return;
   if (a.sparse == 1) return;  // the zero-quad skipping pairs up surviving quads per tile: keep one tiling so results do not depend on the batch size
   if (a.post_w) {  // the fused 1x1 conv needs every mid channel inside one workgroup
     int lwm, lwn, ltm, ltn;
@@ -242,7 +247,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     a.tcx = 2, a.tcy = 2, a.tcz = 6;
   } else {
     cp.cfg = CONV_CFG_4x1_2x1;  // 8 M-tiles = 32 cells
-    if (cells % 4 == 0 && o.ksize == 3 && !getenv("MI_GNINA_NO_MT_X"))
+    if (cells % 4 == 0 && o.ksize == 3 && !option(OPT_MI_GNINA_NO_MT_X))
       a.tcx = 4, a.tcy = 4, a.tcz = 2, a.mt_x = 1;  // M-tiles stacked along x: conflict-free A-operand reads (conv3d.h)
     else if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
     else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
@@ -268,10 +273,10 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   // (the 12^3 Dense-block layers -- 27 workgroups per pose, K loops of a few hundred MFMAs -- gain 10 % from a fifth
   // workgroup per CU: 28 KB measured 0.98 -> 0.87 ms for 96 -> 16, while the 24^3 layers lose 3-5 % with it)
   if (n16 && cells == 6) budget = 28 * 1024;
-  if (!sparse_budget && getenv("MI_GNINA_LDS_KB") && atoi(getenv("MI_GNINA_LDS_KB")) > 0)
-    budget = (size_t)atoi(getenv("MI_GNINA_LDS_KB")) * 1024;
-  if (sparse_budget && getenv("MI_GNINA_SPARSE_LDS_KB") && atoi(getenv("MI_GNINA_SPARSE_LDS_KB")) > 0)
-    budget = (size_t)atoi(getenv("MI_GNINA_SPARSE_LDS_KB")) * 1024;
+  if (!sparse_budget && option(OPT_MI_GNINA_LDS_KB) && atoi(option(OPT_MI_GNINA_LDS_KB)) > 0)
+    budget = (size_t)atoi(option(OPT_MI_GNINA_LDS_KB)) * 1024;
+  if (sparse_budget && option(OPT_MI_GNINA_SPARSE_LDS_KB) && atoi(option(OPT_MI_GNINA_SPARSE_LDS_KB)) > 0)
+    budget = (size_t)atoi(option(OPT_MI_GNINA_SPARSE_LDS_KB)) * 1024;
   int best = 1;
   for (int c = 1; c <= cin4; c++) {
     if (!sparse_budget && cin4 % c) continue;  // dense layers: equal chunks only (no wasted MFMAs)
@@ -303,7 +308,7 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
   }
   // Dense-block convs (N = 16 kernel, BatchNorm on the input): channel-major K order + per-MFMA zero test, the BN shift
   // through a border-class bias table (ConvArgs::korder / bias_tab)
-  const bool n16_skip = n16 && o.ksize == 3 && o.bn_scale_off >= 0 && !getenv("MI_GNINA_NO_RELU_SKIP");
+  const bool n16_skip = n16 && o.ksize == 3 && o.bn_scale_off >= 0 && !option(OPT_MI_GNINA_NO_RELU_SKIP);
   a.korder = n16_skip ? 1 : 0;
   for (int ch = 0; ch < a.nchunks; ch++)
     for (int pr = 0; pr < P; pr++)
@@ -446,7 +451,7 @@ static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt
   mt_out = 0, pad_y = 0, pad_x = 0;
   for (int mt = 0; mt < 3; mt++) {
     if (!((mt_mask >> mt) & 1)) continue;  // (geometries compiled for the kernel shape: conv_h2_mt_mask)
-    if (mt == 1 && (tcx % 4 != 0 || getenv("MI_GNINA_NO_MT_X"))) continue;
+    if (mt == 1 && (tcx % 4 != 0 || option(OPT_MI_GNINA_NO_MT_X))) continue;
     if (mt == 2 && !(tcx == 2 && tcy == 2)) continue;
     const int n_mt = mt == 1 ? tcx / 4 * tcy * tcz : mt == 2 ? tcz : cdiv(NC, 4);
     if (n_mt > n_mtiles) continue;
@@ -499,7 +504,7 @@ static void h2_choose_layout(const int tc[3], int n_mtiles, int mt_mask, int &mt
 // (backward: `o` is make_bwd_op of a forward conv and `cp` its transposed plan -- weights flipped and transposed as in
 // plan_conv; the launch stages an fp32 gradient tensor with ConvArgs::in_amax scaling)
 static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post, bool backward) {
-  if (getenv("MI_GNINA_NO_H2") || !conv_h2_has_cfg(cp.cfg)) return;
+  if (option(OPT_MI_GNINA_NO_H2) || !conv_h2_has_cfg(cp.cfg)) return;
   if (cp.has_lat && !conv_h2_has_cfg(cp.lat_cfg)) return;
   ConvArgs a = cp.a;  // geometry, tiles, bias, BatchNorm, ReLU / pool, output slice
   const int taps = o.ksize * o.ksize * o.ksize;
@@ -513,7 +518,7 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post, b
   if (cp.has_lat)
     HV = std::max(HV, (size_t)(2 * cp.lat_tc[0] + 2 * halo) * (2 * cp.lat_tc[1] + 2 * halo) * (2 * cp.lat_tc[2] + 2 * halo));
   size_t budget = 52 * 1024;
-  if (const char *ev = getenv("MI_GNINA_H2_LDS_KB"))
+  if (const char *ev = option(OPT_MI_GNINA_H2_LDS_KB))
     if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
   // the kernel's staging registers (conv3d_h2.hip: VPT halo voxels per thread x NQ channel quads per chunk -- 3 x 4 under a
   // 3x3x3 conv's halo, 1 x 12 for a 1x1x1 conv)
@@ -537,7 +542,7 @@ static void plan_conv_h2(Model &m, const Op &o, ConvPlan &cp, bool fused_post, b
       // with it -- 0.49 -> 0.58 ms: six M-tiles leave two of the eight slots idle and the tile is staged twice;
       // MI_GNINA_H2_WN1=all tries them.)  Not with a fused 1x1x1 conv behind it (all its input channels must sit in one
       // workgroup).
-      const char *wn1 = getenv("MI_GNINA_H2_WN1");
+      const char *wn1 = option(OPT_MI_GNINA_H2_WN1);
       const bool wn1_all = wn1 && !strcmp(wn1, "all"), wn1_off = wn1 && !strcmp(wn1, "0");
       if (!fused_post && !wn1_off && (cp.cfg == CONV_CFG_1x4_7x1 || (wn1_all && cp.cfg == CONV_CFG_2x2_3x1))) {
         const int n_mt_raster = cdiv(a.tcx * a.tcy * a.tcz, 4);
@@ -777,7 +782,7 @@ static void plan_conv_bf16(Model &m, const Op &o, ConvPlan &cp, int pool_mode, i
   const size_t HV = (size_t)(2 * a.tcx + 2 * halo) * (2 * a.tcy + 2 * halo) * (2 * a.tcz + 2 * halo);
   const int taps = o.ksize * o.ksize * o.ksize;
   size_t budget = 36 * 1024;  // small tiles, 4 workgroups per CU: staging and MFMA phases of different workgroups overlap (measured best of 24..72 KB)
-  if (const char *ev = getenv("MI_GNINA_BF16_LDS_KB"))
+  if (const char *ev = option(OPT_MI_GNINA_BF16_LDS_KB))
     if (atoi(ev) > 0) budget = (size_t)atoi(ev) * 1024;
   int best = 2;
   for (int c = 2; c <= cin8; c += 2) {
@@ -939,7 +944,7 @@ static Model *build_model(ModelDesc &&desc) {
   // never reaches HBM).  The default forward program runs such a pair as two split-fp16 kernels instead: at the f16 MFMA
   // rate the round trip of the intermediate tensor costs less than the fused fp32 kernel's MFMAs.
   auto build_steps = [&](bool grad, bool f32only) {
-    const bool no_h2 = f32only || getenv("MI_GNINA_NO_H2");
+    const bool no_h2 = f32only || option(OPT_MI_GNINA_NO_H2);
     std::vector<Step> out;
     for (size_t i = 1; i < d.ops.size(); i++) {
       const Op &o = d.ops[i];
@@ -957,7 +962,7 @@ static Model *build_model(ModelDesc &&desc) {
         const Op *post = nullptr;
         // (the default forward program fuses too -- conv3d_h2.hip carries the pair on the f16 pipe -- unless
         // MI_GNINA_H2_NO_FUSE1X1 asks for two launches)
-        if (!grad && (no_h2 || !getenv("MI_GNINA_H2_NO_FUSE1X1")) && o.ksize == 3 && i + 1 < d.ops.size() &&
+        if (!grad && (no_h2 || !option(OPT_MI_GNINA_H2_NO_FUSE1X1)) && o.ksize == 3 && i + 1 < d.ops.size() &&
             d.ops[i + 1].kind == OpKind::Conv) {
           const Op &o2 = d.ops[i + 1];
           bool used_elsewhere = false;
@@ -965,7 +970,7 @@ static Model *build_model(ModelDesc &&desc) {
             if (d.ops[j].src == o.dst || (d.ops[j].kind == OpKind::Conv && d.ops[j].dst == o.dst)) used_elsewhere = true;
           if (o2.ksize == 1 && o2.src == o.dst && o2.dst != o.dst && o.src != o.dst && o.dst_c0 == 0 && o2.dst_c0 == 0 &&
               o.cout == d.bufs[o.dst].C && o2.cin == o.cout && o2.cout == o.cout && o.cout % 32 == 0 && o.cout <= 64 &&
-              o2.bn_scale_off < 0 && !used_elsewhere && !getenv("MI_GNINA_NO_FUSE1X1")) {
+              o2.bn_scale_off < 0 && !used_elsewhere && !option(OPT_MI_GNINA_NO_FUSE1X1)) {
             post = &o2;
             dst = o2.dst;
             dst_c0 = 0;
@@ -991,7 +996,7 @@ static Model *build_model(ModelDesc &&desc) {
         // with and without its gradient (eval vs eval_deriv energies are compared inside the search)
         if (!no_h2 && (!grad || m->op_h2[conv_op_index])) plan_conv_h2(*m, o, st.conv, post != nullptr);
         // Dense family on split-format tensors (forward program only; which of the two plans runs follows the buffers' format)
-        if (!no_h2 && !grad && !post && !getenv("MI_GNINA_NO_DENSE_SPLIT")) {
+        if (!no_h2 && !grad && !post && !option(OPT_MI_GNINA_NO_DENSE_SPLIT)) {
           plan_conv_d16(*m, o, st.conv);
           const ConvArgs &h = st.conv.h2;
           st.conv.has_k1s = st.conv.has_h2 && !st.conv.h2_planar && o.ksize == 1 && o.bn_scale_off < 0 && o.cin % 8 == 0 &&
@@ -1050,23 +1055,23 @@ static Model *build_model(ModelDesc &&desc) {
           plan_conv(*m, make_bwd_op(o), st.bwd, 0, o.src, 0, true);
           st.has_bwd = true;
           // transposed 3x3x3 convs on the split-fp16 kernel (run_backward decides per call)
-          const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.relu && pool_mode != 2 && dst_c0 % 4 == 0 && !getenv("MI_GNINA_NO_H2_BWD");
+          const bool bwd_h2 = !no_h2 && o.ksize == 3 && o.relu && pool_mode != 2 && dst_c0 % 4 == 0 && !option(OPT_MI_GNINA_NO_H2_BWD);
           auto shape_ok = [](const ConvPlan &cp) { return conv_h2_has_bwd(cp.cfg) && (!cp.has_lat || conv_h2_has_bwd(cp.lat_cfg)); };
           // 1x1x1 convs behind a fused max pool (Dense transitions) on conv3d_h2_k1_kernel's gradient-pass variant: all
           // output channels in one workgroup, as their forward twin
           const bool bwd_h2_k1 = !no_h2 && o.ksize == 1 && o.relu && pool_mode == 1 && dst_c0 % 4 == 0 && o.src != o.dst &&
-                                 !getenv("MI_GNINA_NO_H2_BWD") && !getenv("MI_GNINA_NO_H2_BWD_K1");
+                                 !option(OPT_MI_GNINA_NO_H2_BWD) && !option(OPT_MI_GNINA_NO_H2_BWD_K1);
           if (bwd_h2_k1) {
             plan_conv(*m, make_bwd_op(o), st.bwd_h2, 0, o.src, 0, true, false, false, true);
             if (conv_h2_has_bwd_k1(st.bwd_h2.cfg) && (!st.bwd_h2.has_lat || conv_h2_has_bwd_k1(st.bwd_h2.lat_cfg)))
               plan_conv_h2(*m, make_bwd_op(o), st.bwd_h2, false, true);
-            if (st.bwd_h2.has_h2 && !st.bwd_h2.h2_planar && !getenv("MI_GNINA_NO_H2_BWD_DENSE")) st.bwd_h2_kind = 2;
+            if (st.bwd_h2.has_h2 && !st.bwd_h2.h2_planar && !option(OPT_MI_GNINA_NO_H2_BWD_DENSE)) st.bwd_h2_kind = 2;
           }
           if (bwd_h2) {
             plan_conv(*m, make_bwd_op(o), st.bwd_h2, 0, o.src, 0, true, false, true);
             if (shape_ok(st.bwd_h2)) plan_conv_h2(*m, make_bwd_op(o), st.bwd_h2, false, true);
             const bool is_private = o.bn_scale_off < 0 && o.src != o.dst && dst_c0 == 0 && o.cout == d.bufs[dst].C;
-            if (st.bwd_h2.has_h2) st.bwd_h2_kind = is_private ? 1 : (pool_mode == 0 && !getenv("MI_GNINA_NO_H2_BWD_DENSE") ? 2 : 0);
+            if (st.bwd_h2.has_h2) st.bwd_h2_kind = is_private ? 1 : (pool_mode == 0 && !option(OPT_MI_GNINA_NO_H2_BWD_DENSE) ? 2 : 0);
           }
           if (st.has_bn) {  // d(BN x)/dx: the transposed conv's output is scaled per (forward-input) channel
             std::vector<float> sc(st.bwd.a.coutp, 0.f);
@@ -1082,7 +1087,7 @@ static Model *build_model(ModelDesc &&desc) {
           const bool fewer_tiles = cdiv(o.cin - c0, 32) < cdiv(o.cin, 32);
           const bool n16_bwd = o.cin - c0 <= 16 && pool_mode != 1 && o.ksize == 3 && o.relu;
           if (o.src == m->input_dst && !st.has_bn && o.src != o.dst && c0 > 0 && c0 < o.cin && (fewer_tiles || n16_bwd) &&
-              !getenv("MI_GNINA_NO_LIG_BWD")) {
+              !option(OPT_MI_GNINA_NO_LIG_BWD)) {
             // forward weights restricted to the ligand's input channels, appended to the payload: [tap][cin - c0][cout]
             const int taps = o.ksize * o.ksize * o.ksize, csub = o.cin - c0;
             Op osub = o;
@@ -1128,11 +1133,11 @@ static Model *build_model(ModelDesc &&desc) {
     return out;
   };
   m->steps = build_steps(false, false);
-  m->steps32 = getenv("MI_GNINA_NO_H2") ? m->steps : build_steps(false, true);
+  m->steps32 = option(OPT_MI_GNINA_NO_H2) ? m->steps : build_steps(false, true);
   // tensor formats of the forward program (see Model::buf_split)
   m->Cp8 = round_up(m->C, 8);
   m->buf_split.assign(d.bufs.size(), 0);
-  if (!getenv("MI_GNINA_NO_H2") && !getenv("MI_GNINA_H2_NO_SPLIT_TENSORS")) {
+  if (!option(OPT_MI_GNINA_NO_H2) && !option(OPT_MI_GNINA_H2_NO_SPLIT_TENSORS)) {
     // A buffer is split when every layer reading it can stage the split format and every layer writing it can produce it.
     // What a layer can write may depend on what it reads (conv3d_h2_k1s_kernel is the 1x1x1 kernel with the split epilogue
     // AND the split staging): iterate down from "everything that could be" to the fixed point.
@@ -1245,7 +1250,7 @@ struct Scorer {
   int precision = 0;  // 0 = fp32 (parity path), 1 = bf16-MFMA forward (mi_scorer_set_precision)
   // fp32 forward convolutions: 1 = on the split-fp16 kernels where a layer has that plan (conv3d_h2.hip), 0 = fp32 MFMA only
   // (MI_PRECISION_FP32_MFMA, or MI_GNINA_CONV_PATH=f32 in the environment)
-  int conv_path = (getenv("MI_GNINA_CONV_PATH") && !strcmp(getenv("MI_GNINA_CONV_PATH"), "f32")) ? 0 : 1;
+  int conv_path = (option(OPT_MI_GNINA_CONV_PATH) && !strcmp(option(OPT_MI_GNINA_CONV_PATH), "f32")) ? 0 : 1;
   int cap = 1024;    // poses per launch of the call in flight: min(chunk, B, what the activation budget allows)
   int chunk = 1024;  // poses per launch: fewer, larger launches win (93.6k vs 87.1k poses/s at 256); 2.4 MB/pose of HBM
   bool have_receptor = false;
@@ -1400,7 +1405,7 @@ static void set_call_capacity(Scorer &s, int B, bool grad) {
   }
   if (grad) per_pose *= 2.25;  // gradient buffers + arg-max bytes
   double budget_gb = 96.0;
-  if (const char *ev = getenv("MI_GNINA_ACT_GB"))
+  if (const char *ev = option(OPT_MI_GNINA_ACT_GB))
     if (atof(ev) > 0) budget_gb = atof(ev);
   const double fit = budget_gb * 1073741824.0 / std::max(per_pose, 1.0);
   int cap = std::min(s.chunk, std::max(B, 1));
@@ -1791,10 +1796,10 @@ static void h2_launch_args(const ConvPlan &cp, const ConvArgs &a, int nb, ConvAr
   conv_cfg_shape(cfg, &wm_, &wn_, &tm_, &tn_);
   // (default 2: weights through LDS, two poses per workgroup -- measured 1.76 against 1.94 (one pose) and
   // 1.9-2.0 ms (weights from L1 / L2, double-buffered tile) on the headline's first conv; MI_GNINA_H2_WLDS=0/1/2)
-  const char *ev = getenv("MI_GNINA_H2_WLDS");
+  const char *ev = option(OPT_MI_GNINA_H2_WLDS);
   h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
   // (L2 prefetch of the next item's tile under this item's K loop: measured, no gain -- 1.722 vs 1.717 ms; opt-in)
-  h.h2_prefetch = (getenv("MI_GNINA_H2_PF") && atoi(getenv("MI_GNINA_H2_PF")) != 0) ? 1 : 0;
+  h.h2_prefetch = (option(OPT_MI_GNINA_H2_PF) && atoi(option(OPT_MI_GNINA_H2_PF)) != 0) ? 1 : 0;
 }
 
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
@@ -1843,7 +1848,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         // (not on the split-fp16 kernels: three 32-cycle MFMAs per test and an LDS round trip per dead step -- conv2 / conv3 of
         // Default2017 run 7 % / 14 % faster without it)
         const bool use_h2 = !bf16 && st.conv.has_h2 && s.conv_path != 0;
-        if (!use_h2 && !a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !getenv("MI_GNINA_NO_RELU_SKIP")) {
+        if (!use_h2 && !a.sparse && !st.has_bn && !bf16 && a.ksize == 3 && st.conv.src != m->input_dst && !option(OPT_MI_GNINA_NO_RELU_SKIP)) {
           if (st.relu_skip == 0 && nb >= 32) {
             s.d_probe.ensure(2);
             MIG_HIP(hipMemsetAsync(s.d_probe.p, 0, 2 * sizeof(unsigned), s.stream));
@@ -1858,7 +1863,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
           a.sparse = st.relu_skip == 2 ? 0 : 2;
         }
         if (st.conv.a.korder) a.sparse = 2;  // Dense-block conv planned with the channel-major K order: per-MFMA test on
-        if (getenv("MI_GNINA_NO_SPARSE")) a.sparse = 0;
+        if (option(OPT_MI_GNINA_NO_SPARSE)) a.sparse = 0;
         {
           const double S3 = (double)a.S * a.S * a.S;
           const int taps = a.ksize * a.ksize * a.ksize;
@@ -1884,7 +1889,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             h.mfma_count = nullptr;
             if (st.conv.has_d16) {
               MIG_CHECK(h.out_split, 2, "Dense-block layer planned on split tensors writes a buffer that is not split");
-              if (const char *ev = getenv("MI_GNINA_D16_NP")) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
+              if (const char *ev = option(OPT_MI_GNINA_D16_NP)) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
               launch_conv_h2_d16(h, nb, s.stream);
             } else {
               launch_conv_h2_k1s(h, nb, s.stream);
@@ -1896,7 +1901,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             h2_launch_args(st.conv, a, nb, h, cfg);
             h.argmax_out = a.argmax_out;
             h.sparse = a.sparse == 1 ? 1 : 0;  // the zero test pays on the pooled voxel grid only
-            if (getenv("MI_GNINA_H2_NO_SKIP")) h.sparse = 0;
+            if (option(OPT_MI_GNINA_H2_NO_SKIP)) h.sparse = 0;
             if (st.conv.h2_planar) {  // tensor formats
               h.in_split = is_split(st.conv.src) ? 1 : 0;
               h.out_split = is_split(st.conv.dst) ? 1 : 0;
@@ -1904,7 +1909,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                 h.in_cs = m->Cp8;
                 // the voxelizer's occupancy bytes of this buffer set -- opt-in (MI_GNINA_H2_OCC=1): on the headline workload a
                 // quarter of the (tile, octet) chunks is empty, and reading the bytes ahead of the first DMA costs as much
-                if (getenv("MI_GNINA_H2_OCC") && atoi(getenv("MI_GNINA_H2_OCC"))) {
+                if (option(OPT_MI_GNINA_H2_OCC) && atoi(option(OPT_MI_GNINA_H2_OCC))) {
                   h.in_occ = s.d_occ[pooled_slot == kPooledSlot2 ? 1 : 0].p;
                   h.occ_nt = cdiv(cdiv(m->N, 2), 4);
                 }
@@ -1914,7 +1919,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             }
             s.d_ovf.ensure(1);
             h.h2_overflow = s.d_ovf.p;
-            if (const char *ev = getenv("MI_GNINA_H2_DBG")) h.h2_dbg = atoi(ev);
+            if (const char *ev = option(OPT_MI_GNINA_H2_DBG)) h.h2_dbg = atoi(ev);
             h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
           } else {
@@ -1979,7 +1984,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   // while it stages (ConvArgs::in_mode 3) and no full-resolution gradient tensor is written in between.  Generic fp32
   // kernel only; the pool must be the only reader of the conv's output.
   auto avg_unpool_fused = [&](int ip) {
-    if (bf16 || ip < 1 || ip >= (int)gsteps.size() || getenv("MI_GNINA_NO_UNPOOL_FUSE")) return false;
+    if (bf16 || ip < 1 || ip >= (int)gsteps.size() || option(OPT_MI_GNINA_NO_UNPOOL_FUSE)) return false;
     const Step &pl = gsteps[ip], &cv = gsteps[ip - 1];
     if (pl.kind != OpKind::Pool || pl.pool_mode != 2 || cv.kind != OpKind::Conv || !cv.has_bwd) return false;
     if (cv.conv.dst != pl.src || !cv.conv.a.relu || cv.conv.a.pool != 0 || cv.conv.a.out_c0 != 0) return false;
@@ -1992,7 +1997,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   };
   // transposed convs on the split-fp16 kernel (default precision): the producer of a gradient such a conv will read masks
   // it by the ReLU and records its per-pose maximum; `ready` = that has happened for the buffer's gradient in this call
-  const bool h2_bwd = !bf16 && s.conv_path != 0 && !getenv("MI_GNINA_NO_H2_BWD");
+  const bool h2_bwd = !bf16 && s.conv_path != 0 && !option(OPT_MI_GNINA_NO_H2_BWD);
   const size_t nbufs = m->d.bufs.size();
   std::vector<char> ready(nbufs, 0), slice_ready(gsteps.size(), 0);
   if (h2_bwd) {
@@ -2044,7 +2049,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         } else {
           a.in_mode = st.conv.a.relu ? 1 : 0;
           // a gradient masked by (activation > 0) is as sparse as the ReLU'd activation: per-MFMA zero test
-          a.sparse = (a.in_mode == 1 && a.ksize == 3 && !bf16 && !getenv("MI_GNINA_NO_RELU_SKIP")) ? 2 : 0;
+          a.sparse = (a.in_mode == 1 && a.ksize == 3 && !bf16 && !option(OPT_MI_GNINA_NO_RELU_SKIP)) ? 2 : 0;
         }
         a.out = g_ptr(src);
         a.out_cs = m->buf_cp[src];
@@ -2057,7 +2062,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
         // its final value: masked and measured here, on those channels, instead of by launch_grad_mask_amax
         int slice_step = -1, slice_c0 = 0, slice_c1 = 0;
         if (h2_bwd && !mk && can_prepare && i > 0 && gsteps[i - 1].kind == OpKind::Conv && gsteps[i - 1].conv.dst == src &&
-            gsteps[i - 1].bwd_h2_kind == 2 && !getenv("MI_GNINA_H2_BWD_PREPASS")) {
+            gsteps[i - 1].bwd_h2_kind == 2 && !option(OPT_MI_GNINA_H2_BWD_PREPASS)) {
           const Step &nx = gsteps[i - 1];
           const bool nx_lig = nx.has_bwd_lig && (s.cur_flex == nullptr || s.flex_rows.empty());
           slice_c0 = nx.conv.a.out_c0, slice_c1 = slice_c0 + nx.conv.a.cout;
@@ -2090,7 +2095,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
           h.in_argmax = a.in_argmax;
           h.in_amax = h2_kind == 2 ? amax_of((int)nbufs + i) : amax_of(dst);
           h.out_scale = a.out_scale, h.accumulate = a.accumulate;
-          h.sparse = getenv("MI_GNINA_H2_BWD_SKIP") ? 1 : 0;
+          h.sparse = option(OPT_MI_GNINA_H2_BWD_SKIP) ? 1 : 0;
           h.out_mask = prep_mask;
           h.out_mask_cs = m->buf_cp[src];
           h.out_mask_c0 = prep_c0, h.out_mask_c1 = prep_c1;
@@ -2279,7 +2284,9 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
   score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
-  if (s.conv_path == 0 || *s.h_ovf == 0u || s.ovf_pending) return;
+  // (with device-output calls pending the flag is sticky and may be theirs: the repeat is then unnecessary at worst --
+  // never skipped, the header promises a flagged host-output call is repeated before it returns)
+  if (s.conv_path == 0 || *s.h_ovf == 0u) return;
   s.h2_fallbacks++;
   struct PathGuard {
     Scorer &s;
@@ -2328,7 +2335,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);
     const bool ov = s.overlap && B > s.cap;
     // the pooled grid goes out in split format when every model of the group reads it with a split-fp16 first conv
-    bool split = s.conv_path != 0 && s.precision != 1 && !getenv("MI_GNINA_H2_NO_SPLIT_TENSORS");
+    bool split = s.conv_path != 0 && s.precision != 1 && !option(OPT_MI_GNINA_H2_NO_SPLIT_TENSORS);
     for (int mi : g.models) split = split && s.models[mi]->pooled_split_ok;
     if (ov) {
       MIG_HIP(hipEventRecord(s.ev_inputs, s.stream));  // ligand / centre uploads are visible to vox_stream
@@ -2401,7 +2408,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
     s.ovf_pending = true;
     return;
   }
-  if (*s.h_ovf == 0u || s.ovf_pending) return;
+  if (*s.h_ovf == 0u) return;  // (see score_batch_grad: repeated also when the sticky flag may belong to a pending call)
   s.h2_fallbacks++;
   struct PathGuard {
     Scorer &s;
@@ -2463,6 +2470,15 @@ mi_status mi_gnina_init(int device) {
   return MI_OK;
   MI_CATCH_STATUS
 }
+
+mi_status mi_gnina_set_option(const char *name, const char *value) {
+  MI_TRY
+  MIG_CHECK(name && set_option(name, value) == 0, 1, std::string("mi_gnina_set_option: no such switch: ") + (name ? name : "(null)"));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+const char *mi_gnina_options(void) { return options_summary(); }
 
 mi_model *mi_model_load(const void *blob, size_t nbytes, const char *name) {
   MI_TRY
@@ -2545,7 +2561,7 @@ mi_scorer *mi_scorer_create(mi_model *const *models, int n_models) {
   for (auto &e : s->ev_vox_done) MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : s->ev_cnn_done) MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   MIG_HIP(hipEventCreateWithFlags(&s->ev_inputs, hipEventDisableTiming));
-  if (const char *e = getenv("MI_GNINA_OVERLAP")) s->overlap = atoi(e) != 0;
+  if (const char *e = option(OPT_MI_GNINA_OVERLAP)) s->overlap = atoi(e) != 0;
   build_groups(*s);
   return reinterpret_cast<mi_scorer *>(s.release());
   MI_CATCH_NULL
@@ -2808,21 +2824,36 @@ mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int 
   d_grid.ensure((size_t)std::min(B, s.cap) * per_pose);
   d_out.ensure((size_t)3 * B);
   const BufDecl &ib = m->d.bufs[m->input_dst];
-  for (int b0 = 0; b0 < B; b0 += s.cap) {
-    const int nb = std::min(s.cap, B - b0);
-    MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
-                           hipMemcpyHostToDevice, s.stream));
-    float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m));
-    if (m->overlap)  // the full grid is the network input
-      MIG_HIP(hipMemcpyAsync(pooled, d_grid.p, (size_t)nb * per_pose * sizeof(float), hipMemcpyDeviceToDevice, s.stream));
-    else
-      launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
-    run_program(s, mi, nb, d_out.p + b0, d_out.p + B + b0, d_out.p + 2 * (size_t)B + b0);
+  // The grids are the caller's: the entry point most likely to meet values beyond the fp16 range of the split-fp16 kernels
+  // (the reference's module.forward is fp32, torch_model.cpp:185) -- flag, fetch and repeat on the fp32-MFMA kernels like
+  // score_batch does.
+  struct PathGuard {
+    Scorer &s;
+    int saved;
+    ~PathGuard() { s.conv_path = saved; }
+  } guard{s, s.conv_path};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    h2_flag_reset(s);
+    for (int b0 = 0; b0 < B; b0 += s.cap) {
+      const int nb = std::min(s.cap, B - b0);
+      MIG_HIP(hipMemcpyAsync(d_grid.p, grids + (size_t)b0 * per_pose, (size_t)nb * per_pose * sizeof(float),
+                             hipMemcpyHostToDevice, s.stream));
+      float *pooled = act_buf(s, kPooledSlot, (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m));
+      if (m->overlap)  // the full grid is the network input
+        MIG_HIP(hipMemcpyAsync(pooled, d_grid.p, (size_t)nb * per_pose * sizeof(float), hipMemcpyDeviceToDevice, s.stream));
+      else
+        launch_pool_input(d_grid.p, pooled, nb, m->C, m->Cp, m->N, m->input_pool, s.stream);
+      run_program(s, mi, nb, d_out.p + b0, d_out.p + B + b0, d_out.p + 2 * (size_t)B + b0);
+    }
+    MIG_HIP(hipMemcpyAsync(pose, d_out.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    MIG_HIP(hipMemcpyAsync(affinity, d_out.p + B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    MIG_HIP(hipMemcpyAsync(loss, d_out.p + 2 * (size_t)B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    h2_flag_fetch(s);
+    MIG_HIP(hipStreamSynchronize(s.stream));
+    if (s.conv_path == 0 || s.precision != 0 || *s.h_ovf == 0u) break;
+    s.h2_fallbacks++;
+    s.conv_path = 0;  // (restored by the guard)
   }
-  MIG_HIP(hipMemcpyAsync(pose, d_out.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipMemcpyAsync(affinity, d_out.p + B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipMemcpyAsync(loss, d_out.p + 2 * (size_t)B, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipStreamSynchronize(s.stream));
   return MI_OK;
   MI_CATCH_STATUS
 }

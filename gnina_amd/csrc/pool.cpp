@@ -32,6 +32,7 @@
 
 #include "../../include/mi_gnina.h"
 #include "common.h"
+#include "options.h"
 
 namespace mig {
 
@@ -89,6 +90,10 @@ struct Worker {
   hipStream_t stream = nullptr;  // for the RCCL scatter / gather and staging copies (the scorer has its own)
   ncclComm_t comm = nullptr;
   DevBuf<float> d_lig, d_cen, d_out;  // staging on this device for the device-resident path
+  // split-fp16 range fallback of device-output calls (score_dev_out): after two flagged calls in a row this worker's scorer
+  // stays on the fp32-MFMA kernels -- a model that is persistently out of range does not pay the double run on every shard
+  int range_streak = 0;
+  bool range_sticky = false;
   void loop() {
     for (;;) {
       std::packaged_task<std::string()> t;
@@ -155,21 +160,30 @@ std::string on_all(Pool &p, const std::function<std::string(Worker &)> &f) {
 
 std::string last(const char *what) { return std::string(what) + ": " + mi_last_error(); }
 
-// one device-resident shard on its worker's scorer, complete on return.  A device-output call cannot repeat itself when
-// an activation leaves the split-fp16 kernels' range (mi_scorer_synchronize reports MI_ERR_RANGE, include/mi_gnina.h):
-// the shard is scored again on the fp32-MFMA kernels.
-std::string score_resident(Worker &x, const float *lig, const int32_t *smt, int nb, int L, const float *cen, float *o_pose,
-                           float *o_aff, float *o_loss, float *o_var) {
+// One device-output call on its worker's scorer, complete on return (host or device input: `flags`).  A device-output call
+// cannot repeat itself when an activation leaves the split-fp16 kernels' range (mi_scorer_synchronize reports MI_ERR_RANGE,
+// include/mi_gnina.h): the call is made again on the fp32-MFMA kernels, and the scorer goes back to the precision the pool
+// keeps it at (workers' scorers are never handed out: MI_PRECISION_FP32, or fp32-MFMA once the fallback turned sticky).
+std::string score_dev_out(Worker &x, const float *lig, const int32_t *smt, int nb, int L, const float *cen, float *o_pose,
+                          float *o_aff, float *o_loss, float *o_var, unsigned flags) {
   for (int attempt = 0; attempt < 2; attempt++) {
-    if (mi_scorer_score_batch_ex(x.scorer, lig, smt, nb, L, cen, o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE) != MI_OK)
+    if (mi_scorer_score_batch_ex(x.scorer, lig, smt, nb, L, cen, o_pose, o_aff, o_loss, o_var, flags | MI_OUT_ON_DEVICE) != MI_OK)
       return last("mi_scorer_score_batch_ex");
     const mi_status st = mi_scorer_synchronize(x.scorer);
-    if (attempt == 1) (void)mi_scorer_set_precision(x.scorer, MI_PRECISION_FP32);
-    if (st == MI_OK) return "";
+    if (attempt == 1 && !x.range_sticky) (void)mi_scorer_set_precision(x.scorer, MI_PRECISION_FP32);
+    if (st == MI_OK) {
+      if (attempt == 0) x.range_streak = 0;
+      return "";
+    }
     if (st != MI_ERR_RANGE || attempt == 1) return last("mi_scorer_synchronize");
+    if (++x.range_streak >= 2) x.range_sticky = true;
     if (mi_scorer_set_precision(x.scorer, MI_PRECISION_FP32_MFMA) != MI_OK) return last("mi_scorer_set_precision");
   }
   return "";
+}
+std::string score_resident(Worker &x, const float *lig, const int32_t *smt, int nb, int L, const float *cen, float *o_pose,
+                           float *o_aff, float *o_loss, float *o_var) {
+  return score_dev_out(x, lig, smt, nb, L, cen, o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE);
 }
 
 void shard(int B, int G, int g, int &b0, int &nb) {  // contiguous [g*B/G, (g+1)*B/G), SURVEY 8e
@@ -200,7 +214,7 @@ mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *mo
   try {
     MIG_CHECK(devices && n_devices > 0 && model_paths && n_models > 0, 1, "bad arguments");
     const int have = mi_gnina_device_count();
-    const bool allow_dup = getenv("MI_POOL_ALLOW_DUPLICATE_DEVICES") != nullptr;
+    const bool allow_dup = option(OPT_MI_POOL_ALLOW_DUPLICATE_DEVICES) != nullptr;
     bool dup = false;
     for (int g = 0; g < n_devices; g++) {
       MIG_CHECK(devices[g] >= 0 && devices[g] < have, 1, "device index out of range");
@@ -212,7 +226,7 @@ mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *mo
     process_env_once();  // (before the worker threads exist: see common.h)
     auto p = std::make_unique<Pool>();
     p->duplicates = dup;
-    p->use_rccl = !dup && getenv("MI_POOL_NO_RCCL") == nullptr;
+    p->use_rccl = !dup && option(OPT_MI_POOL_NO_RCCL) == nullptr;
     for (int g = 0; g < n_devices; g++) {
       auto wk = std::make_unique<Worker>();
       wk->device = devices[g];
@@ -314,9 +328,9 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
   if (G == 1) {  // nothing to shard: the single scorer, same bits as mi_scorer_score_batch
     const std::string err = on_all(p, [&](Worker &x) -> std::string {
       if (in_dev && out_dev) return score_resident(x, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var);
+      if (out_dev) return score_dev_out(x, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, flags);
       if (mi_scorer_score_batch_ex(x.scorer, lig_xyz, lig_smt, B, L, centers, pose, affinity, loss, aff_var, flags) != MI_OK)
         return last("mi_scorer_score_batch_ex");
-      if (out_dev && mi_scorer_synchronize(x.scorer) != MI_OK) return last("mi_scorer_synchronize");
       return "";
     });
     MIG_CHECK(err.empty(), 3, err);
@@ -561,7 +575,7 @@ mi_vina_pool *mi_vina_pool_create(const int *devices, int n_devices, const float
   try {
     MIG_CHECK(devices && n_devices > 0, 1, "bad arguments");
     const int have = mi_gnina_device_count();
-    const bool allow_dup = getenv("MI_POOL_ALLOW_DUPLICATE_DEVICES") != nullptr;
+    const bool allow_dup = option(OPT_MI_POOL_ALLOW_DUPLICATE_DEVICES) != nullptr;
     for (int g = 0; g < n_devices; g++) {
       MIG_CHECK(devices[g] >= 0 && devices[g] < have, 1, "device index out of range");
       for (int k = 0; k < g; k++) MIG_CHECK(devices[k] != devices[g] || allow_dup, 1, "a device is listed twice");
@@ -672,6 +686,13 @@ mi_status mi_vina_pool_mc_screen(mi_vina_pool *pp, int B, const int32_t *chain_l
   VinaPool &p = *reinterpret_cast<VinaPool *>(pp);
   const int G = (int)p.w.size();
   if (B == 0) return MI_OK;
+  {  // the single-handle call's argument check, ahead of the fan-out: a negative id would match no rank (its chain silently
+     // skipped), an id past the screen would fail on one worker after the others did their work
+    const int n_screen = mi_vina_screen_size(p.h.empty() ? nullptr : p.h[0]);
+    for (int b = 0; b < B; b++)
+      MIG_CHECK(chain_ligand[b] >= 0 && chain_ligand[b] < n_screen, 1, "mi_vina_pool_mc_screen: chain_ligand[" + std::to_string(b) + "] = " +
+                                                                         std::to_string(chain_ligand[b]) + " is not a ligand of the screen (" + std::to_string(n_screen) + ")");
+  }
   const size_t ns = (size_t)params[0].num_saved, cs = ns * max_conf, xs = ns * (size_t)max_heavy * 3;
   const std::string err = on_all_vina(p, [&](Worker &x, mi_vina *hv) -> std::string {
     // ligand l goes to device l % G: this device's chains, in launch order

@@ -32,6 +32,7 @@
 
 #include "common.h"
 #include "vina.h"
+#include "options.h"
 
 namespace mig {
 
@@ -2489,7 +2490,7 @@ void launch_vina_mc_cnn(const VinaEnv &env0, const VinaLigand &lig, const VinaMc
 // the line searches are spread over 4 waves; with many chains in flight the speculative trials would only take
 // issue slots from other chains.
 int vina_mc_team(int B) {
-  if (const char *e = getenv("MI_VINA_MC_WAVES")) {  // experiments: force 1, 2 or 4
+  if (const char *e = option(OPT_MI_VINA_MC_WAVES)) {  // experiments: force 1, 2 or 4
     const int w = atoi(e);
     if (w == 1 || w == 2 || w == 4) return w;
   }

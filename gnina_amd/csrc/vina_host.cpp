@@ -12,6 +12,7 @@
 #include "common.h"
 #include "typer.h"
 #include "vina.h"
+#include "options.h"
 
 namespace mig {
 
@@ -1008,7 +1009,7 @@ mi_status mi_vina_mc_batch(mi_vina *vv, int B, const uint64_t *seeds, const floa
   a.out_coords = v.d_mc_xyz.p;
   a.out_n = v.d_out_n.p;
   a.evals = v.d_evals.p;
-  static const bool prof = getenv("MI_VINA_MC_PROFILE") != nullptr;
+  static const bool prof = option(OPT_MI_VINA_MC_PROFILE) != nullptr;
   DevBuf<long long> prof_buf;  // diagnostic only; released on every exit path
   long long *d_prof = nullptr;
   if (prof) {

@@ -33,6 +33,7 @@
 //    the squared distance precomputed per atom type on the host (typer.cpp) so they are
 //    bit-identical to the sqrtf-based reference arithmetic.
 #include "voxelize.h"
+#include "options.h"
 
 #include <cstdlib>
 
@@ -670,7 +671,7 @@ void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
     size_t lds = (size_t)64 * 12 * sizeof(float) + kVoxTrFloats * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
-    if (getenv("MI_VOX_LDS_PAD")) lds += (size_t)atoi(getenv("MI_VOX_LDS_PAD")) * 1024;  // occupancy experiment
+    if (option(OPT_MI_VOX_LDS_PAD)) lds += (size_t)atoi(option(OPT_MI_VOX_LDS_PAD)) * 1024;  // occupancy experiment
     if (v.split) {
       lds = (size_t)64 * kVoxSplitWin * sizeof(float) + kVoxTrFloats * sizeof(float);
       if (mode == 1) hipLaunchKernelGGL((voxelize_tiles<1, true>), grid, block, lds, s, v);

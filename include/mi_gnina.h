@@ -53,6 +53,13 @@ enum {
  * device as far as the runtime has hardware queues, so the first call also sets GPU_MAX_HW_QUEUES=16 (HIP's
  * default is 4) unless the variable is already set -- effective only before the process's first HIP call. */
 mi_status mi_gnina_init(int device);
+/* Experiment / A-B switches (gnina_amd/csrc/options.h lists them: MI_GNINA_*, MI_POOL_*, MI_VINA_*, MI_VOX_*).  The
+ * environment is read ONCE per process, at the first library call; afterwards a switch changes only through this call
+ * (value NULL = unset) -- nothing in the library calls getenv on a scoring path.  Load-time switches (kernel selection, LDS
+ * budgets, fusion) apply to models loaded after the change, run-time ones to the next call.  MI_ERR_INVALID for an unknown
+ * name.  mi_gnina_options(): "NAME=value ..." of the switches that are set (thread-local string). */
+mi_status mi_gnina_set_option(const char *name, const char *value);
+const char *mi_gnina_options(void);
 int mi_gnina_device_count(void);
 int mi_gnina_abi_version(void);
 /* Last error message of the calling thread ("" if none). */

@@ -87,11 +87,8 @@ def test_two_poses_per_workgroup_and_odd_batches(capi, CG):
     for b in (0, 1, 31, 32):
         one = s.score_batch(many[b:b + 1], lig_smt)
         assert one["pose"][0] == big["pose"][b] and one["affinity"][0] == big["affinity"][b], b
-    os.environ["MI_GNINA_D16_NP"] = "1"
-    try:
+    with capi.option("MI_GNINA_D16_NP", 1):
         plain = s.score_batch(many, lig_smt)
-    finally:
-        del os.environ["MI_GNINA_D16_NP"]
     assert np.array_equal(plain["pose"], big["pose"]) and np.array_equal(plain["affinity"], big["affinity"])
 
 

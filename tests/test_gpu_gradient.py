@@ -212,11 +212,10 @@ def test_split_fp16_transposed_convs_are_fp32_grade(capi, CG, name, tmp_path, mo
     rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
 
     def both(f):
-        monkeypatch.delenv("MI_GNINA_NO_H2_BWD", raising=False)
+        capi.set_option("MI_GNINA_NO_H2_BWD", None)
         a = f()
-        monkeypatch.setenv("MI_GNINA_NO_H2_BWD", "1")
-        b = f()
-        monkeypatch.delenv("MI_GNINA_NO_H2_BWD", raising=False)
+        with capi.option("MI_GNINA_NO_H2_BWD"):    # (a run-time switch: mi_gnina_set_option, not the environment)
+            b = f()
         return a, b
 
     def close(a, b, key):

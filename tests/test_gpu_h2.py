@@ -94,12 +94,11 @@ def test_fused_1x1_conv_gives_the_bits_of_two_launches(capi, CG, monkeypatch):
     many = np.concatenate([poses, synth.make_poses(np.random.RandomState(11), poses[0] - poses[0].mean(0), 60)])
     out = []
     for no_fuse in (False, True):
-        if no_fuse:
-            monkeypatch.setenv("MI_GNINA_H2_NO_FUSE1X1", "1")
+        capi.set_option("MI_GNINA_H2_NO_FUSE1X1", "1" if no_fuse else None)   # (read when a model is loaded)
         s = capi.Scorer([capi.Model(name)])
         s.set_receptor(rec_xyz, rec_smt)
         out.append(s.score_batch(many, lig_smt))
-        monkeypatch.delenv("MI_GNINA_H2_NO_FUSE1X1", raising=False)
+        capi.set_option("MI_GNINA_H2_NO_FUSE1X1", None)
     assert np.array_equal(out[0]["pose"], out[1]["pose"]) and np.array_equal(out[0]["affinity"], out[1]["affinity"])
     assert np.abs(out[0]["pose"][:4] - CG[name + "/pose"]).max() < 1e-4
 
@@ -120,9 +119,6 @@ def test_two_poses_per_workgroup_and_an_odd_batch(capi, CG, name):
     for b in (0, 95, 96):
         one = s.score_batch(many[b:b + 1], lig_smt)
         assert one["pose"][0] == big["pose"][b] and one["affinity"][0] == big["affinity"][b], b
-    os.environ["MI_GNINA_H2_WLDS"] = "0"
-    try:
+    with capi.option("MI_GNINA_H2_WLDS", 0):
         plain = s.score_batch(many, lig_smt)
-    finally:
-        del os.environ["MI_GNINA_H2_WLDS"]
     assert np.array_equal(plain["pose"], big["pose"]) and np.array_equal(plain["affinity"], big["affinity"])

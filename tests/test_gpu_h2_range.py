@@ -139,7 +139,7 @@ def test_values_at_the_edge_of_the_range_do_not_raise_the_flag(capi, CG, tmp_pat
     assert np.abs(got["affinity"] - want_aff).max() < 1e-4 * max(1.0, float(np.abs(want_aff).max()))
 
 
-def test_pool_repeats_a_device_resident_shard_on_fp32_mfma(capi, CG, tmp_path, monkeypatch):
+def test_pool_repeats_a_device_resident_shard_on_fp32_mfma(capi, CG, tmp_path, allow_duplicate_devices):
     """mi_pool's device-resident path cannot see the range flag until mi_scorer_synchronize returns MI_ERR_RANGE: the
     worker then scores its shard again under MI_PRECISION_FP32_MFMA (pool.cpp score_resident) -- the caller gets the
     fp32 bits, from a pool of one device and from a sharded pool alike."""
@@ -150,7 +150,6 @@ def test_pool_repeats_a_device_resident_shard_on_fp32_mfma(capi, CG, tmp_path, m
     s.set_receptor(rec_xyz, rec_smt)
     s.set_precision("fp32_mfma")
     want = s.score_batch(poses, lig_smt)
-    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
     d_lig = torch.from_numpy(poses).cuda()
     for devices in ([0], [0, 0]):
         pool = capi.Pool([path], devices)

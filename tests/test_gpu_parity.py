@@ -370,10 +370,10 @@ def test_zero_skipping_k_order_against_the_plain_order(capi, name, monkeypatch):
     s = capi.Scorer([name])
     s.set_receptor(rec_xyz, rec_smt)
     new = s.score_batch(poses, lig_smt)
-    monkeypatch.setenv("MI_GNINA_NO_RELU_SKIP", "1")
-    s0 = capi.Scorer([name])          # a fresh model: the Dense-block plan reads the switch when it packs its weights
-    s0.set_receptor(rec_xyz, rec_smt)
-    old = s0.score_batch(poses, lig_smt)
+    with capi.option("MI_GNINA_NO_RELU_SKIP"):
+        s0 = capi.Scorer([capi.Model(name)])   # a fresh model: the Dense-block plan reads the switch when it packs its weights
+        s0.set_receptor(rec_xyz, rec_smt)
+        old = s0.score_batch(poses, lig_smt)
     assert np.abs(new["pose"] - old["pose"]).max() < 5e-6
     assert np.abs(new["affinity"] - old["affinity"]).max() < 2e-5
 

@@ -285,14 +285,14 @@ def test_mc_output_is_independent_of_the_team_size(setup, capi, monkeypatch):
     P = capi.McParams.default(60, (25 + vina.n_atoms) // 3, 10)
     ref = None
     for w in ("1", "2", "4"):
-        monkeypatch.setenv("MI_VINA_MC_WAVES", w)
+        capi.set_option("MI_VINA_MC_WAVES", w)
         out = vina.mc_batch(seeds, c1, c2, P)
         if ref is None:
             ref = out
         else:
             for a, b in zip(ref, out):
                 assert np.array_equal(a, b), w
-    monkeypatch.delenv("MI_VINA_MC_WAVES")
+    capi.set_option("MI_VINA_MC_WAVES", None)
     assert (ref[4] > 60).all()
 
 
@@ -395,7 +395,7 @@ def test_screen_launch_matches_per_ligand_chains(capi, T):
         assert np.array_equal(ef[idx], e3) and np.array_equal(intra[idx], i3)
 
 
-def test_vina_pool_splits_chains_by_chain_id_and_returns_the_single_handle_bits(setup, capi, monkeypatch):
+def test_vina_pool_splits_chains_by_chain_id_and_returns_the_single_handle_bits(setup, capi, allow_duplicate_devices):
     """mi_vina_pool (include/mi_gnina.h): parallel_mc's fan-out of chains (parallel_mc.cpp:183-214) over devices.  On a
     one-GPU box MI_POOL_ALLOW_DUPLICATE_DEVICES lets three workers share device 0 -- every shard offset of the chain
     arrays is exercised -- and a chain depends on its seed and the handle's state only, so the pool must return the bits
@@ -405,7 +405,6 @@ def test_vina_pool_splits_chains_by_chain_id_and_returns_the_single_handle_bits(
     seeds = np.arange(900, 919, dtype=np.uint64)
     P = capi.McParams.default(40, (25 + vina.n_atoms) // 3, 10)
     ref = vina.mc_batch(seeds, c1, c2, P)
-    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
     ndev = capi.lib().mi_gnina_device_count()
     devices = list(range(ndev)) if ndev >= 2 else [0, 0, 0]
     pool = capi.VinaPool(devices)

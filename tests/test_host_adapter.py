@@ -349,13 +349,12 @@ def test_pool_python_binding_matches_single_scorer():
 
 
 @pytest.mark.gpu
-def test_pool_shards_with_several_workers_on_one_gpu(monkeypatch):
+def test_pool_shards_with_several_workers_on_one_gpu(allow_duplicate_devices):
     """Every shard boundary and offset of mi_pool's host-buffer and device-resident paths, on a one-GPU box: the test hook
     MI_POOL_ALLOW_DUPLICATE_DEVICES lets devices = [0, 0, 0] run three workers (three scorers, three streams) on the same
     GPU; the device-resident path then moves the shards with device-to-device copies (RCCL refuses duplicate devices --
     with distinct devices the same shards travel through ncclSend / ncclRecv).  Results must equal one scorer's bits."""
     from gnina_amd import capi, synth
-    monkeypatch.setenv("MI_POOL_ALLOW_DUPLICATE_DEVICES", "1")
     capi.init(0)
     name = "default2017"
     m = capi.Model(name)
@@ -397,5 +396,5 @@ def test_pool_shards_with_several_workers_on_one_gpu(monkeypatch):
     info = p.info()
     assert info["ranks"] == 3 and info["device_path_transport"] == "copies" and info["calls_device_path"] == 1
     with pytest.raises(capi.MiGninaError):                        # without the hook a duplicate is an error
-        monkeypatch.delenv("MI_POOL_ALLOW_DUPLICATE_DEVICES")
+        capi.set_option("MI_POOL_ALLOW_DUPLICATE_DEVICES", None)
         capi.Pool([name], devices=[0, 0])
