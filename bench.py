@@ -696,7 +696,39 @@ def config_c5(capi, synth):
                                  "algorithmic_equivalent_tflops": round(tf, 2),
                                  "mfma_executed_fraction": round(ex / full, 4) if full else None,
                                  "note": "forward, end to end (voxelization, PCIe, host set-up included)"}}
+    s.set_precision(False)
+    out["refine"] = config_c5_refine(capi, s)
     return out
+
+
+def config_c5_refine(capi, scorer):
+    """C5 as BASELINE.json configures it: `--cnn_scoring refinement` with the Dense model at 96^3 -- refine_structure on
+    non_cache_cnn (main.cpp:131-171; one TorchModel::forward + backward + GridMaker::backward per BFGS evaluation,
+    torch_model.cpp:197-221) -- end to end through mi_cnn_refine_batch: B = 64 perturbed conformations of the C3 ligand
+    (32 atoms, 6 torsions) in the C3 receptor, default iteration cap (25 + n_atoms) / 3, parity path (split-fp16 / fp32)."""
+    from gnina_amd import vina_scene
+    sc = vina_scene.build(seed=3)
+    lig = sc["lig"]
+    v = capi.Vina()
+    v.set_ligand(lig)
+    scorer.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(5)
+    B = 64
+    confs = np.repeat(lig["conf0"].astype(np.float32)[None], B, 0)
+    confs[:, :3] += rng.uniform(-0.5, 0.5, (B, 3)).astype(np.float32)
+    confs[:, 7:] += rng.uniform(-0.4, 0.4, (B, confs.shape[1] - 7)).astype(np.float32)
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    box = capi.CnnBox.make(23.75, lo, hi)
+    start, _ = v.cnn_eval_batch(scorer, confs, box, None, deriv=False)
+    v.cnn_refine_batch(scorer, confs[:8], box, max_iters=2)     # warm-up (allocations at the gradient program's sizes)
+    t0 = time.perf_counter()
+    e, out, tries, evals = v.cnn_refine_batch(scorer, confs, box)
+    dt = time.perf_counter() - t0
+    return {"workload": "dense_1_3 @ 0.25 A (96^3), mi_cnn_refine_batch, B = 64 conformations, max_iters = (25 + 32) / 3 = 19",
+            "seconds": round(dt, 3), "poses_refined_per_s": round(B / dt, 2),
+            "cnn_evaluations": int(evals.sum()), "cnn_evaluations_per_s": round(float(evals.sum()) / dt, 1),
+            "mean_loss_before": round(float(start.mean()), 5), "mean_loss_after": round(float(e.mean()), 5),
+            "all_losses_lowered_or_equal": bool((e <= start + 1e-6).all())}
 
 
 def config_gradient_calls(capi, synth):

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
       const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
       const bool ok = j < 2 * PL && hx < HX && hy < HY && hz < HZ && (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
       voff[i] = ok ? (unsigned)((x * S + y) * S + z) * 32u + (unsigned)half * 16u : 0x80000000u;
+      if (p.h2_dbg & 32) voff[i] = (unsigned)(((x0 + 1) * S + (y0 + 1)) * S + z0 + 1) * 32u + (unsigned)j * 16u;  // (timing only: contiguous sources)
     }
   }
   const int octet_bytes = S * S * S * 32;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
     char *dst = s_tile + wave * 1024;
 #pragma unroll
     for (int i = 0; i < kD16NS; i++)
-      if ((i * 4 + wave) * 64 < 2 * PL)  // (wave-uniform; 2 PL is a multiple of 64)
+      if ((i * 4 + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (D16LdsPtr)(dst + i * 4096), 16, voff[i], chunk * octet_bytes, 0, 0);
   };
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.nchunks * kD16WBytes, 0x00020000);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int q = i * 4 + wave;
-      if (q < 2 * kD16Steps)
+      if (q < 2 * kD16Steps && !(p.h2_dbg & 8))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(s_w + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
     }
   };
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
         for (int m = 0; m < TM; m++)
           acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
       };
+      if (p.h2_dbg & 2) return;  // (timing only: no K loop)
       load_step(0, ah0, al0, wh0, wl0);
 #pragma unroll
       for (int s = 0; s < kD16Steps; s += 2) {

@@ -57,7 +57,10 @@ class NonCacheCnn:
         lig_xyz, lig_smt = coords[lb:le], self.smt[lb:le]
         for blob in self.blobs:
             rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
-            grid, cen = voxel.voxelize_pose(rec_xyz, self.rec_smt, lig_xyz, lig_smt, rmap, lmap)
+            # (the blob's own grid: a dynamic-pool model re-gridded by the test -- blob.resolution / .dimension overwritten,
+            # like gnina's metadata override for dense_1.3 at 0.25 A -- is voxelized at that grid)
+            grid, cen = voxel.voxelize_pose(rec_xyz, self.rec_smt, lig_xyz, lig_smt, rmap, lmap, None, blob.resolution,
+                                            blob.dimension, blob.radius_scaling)
             if deriv:
                 loss, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None])
                 ch, rad = voxel.type_atoms(lig_smt, lmap[0])

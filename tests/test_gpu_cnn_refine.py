@@ -375,3 +375,45 @@ def test_cnn_with_flexible_residues_in_eval_refinement_and_monte_carlo():
         assert (n1 >= 1).all() and np.isfinite(e1[:, 0]).all() and cnn1 > 0
         assert np.array_equal(n1, n2) and np.array_equal(cf1, cf2)                  # deterministic
         assert np.abs(cf1[:, 0, 13:] - d["conf0"][13:]).max() > 1e-3              # the residue's torsions were searched
+
+
+def test_c5_refinement_at_96_cubed_end_to_end(setup):
+    """BASELINE config C5 as configured: the Dense model at 0.25 A (96^3 grid, dense_1.3 -- the only family whose global
+    pool takes another grid) with --cnn_scoring refinement, i.e. refine_structure on non_cache_cnn
+    (gninasrc/main/main.cpp:131-171: quasi_newton over non_cache_cnn::eval_deriv, which is TorchModel::forward + backward +
+    GridMaker::backward per evaluation, gninasrc/lib/torch_model.cpp:197-221).  mi_cnn_refine_batch runs the whole loop on
+    the device; the oracle runs the same loop on the CPU (oracle/cnn_refine.py: voxelizer + CNN autograd + torsion-tree
+    fold + the same bfgs<>) at the same grid."""
+    capi, sc, lig, v, olig = setup
+    name, RES, DIM = "dense_1_3", 0.25, 23.75
+    m = capi.Model(name, resolution=RES, dimension=DIM)
+    assert m.grid_points == 96
+    s = capi.Scorer([m])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    rng = np.random.RandomState(21)
+    confs = random_confs(lig, rng, 6, trans=0.4, rot=0.15, tors=0.3)
+    lo, hi = sc["center"] - sc["size"] / 2, sc["center"] + sc["size"] / 2
+    box = capi.CnnBox.make(DIM, lo, hi)
+    # (i) the first two BFGS iterations against the oracle, pose by pose
+    e, out, tries, evals = v.cnn_refine_batch(s, confs[:2], box, max_iters=2)
+    blob = cnn_ref.Blob(os.path.join(WEIGHTS, name + ".mgw"))
+    blob.resolution, blob.dimension = RES, DIM
+    close = 0
+    for b in range(2):
+        nc = cnn_refine.NonCacheCnn([blob], sc["rec_xyz"], sc["rec_smt"], olig, (lo, hi), DIM)
+        eo, co, to = cnn_refine.refine_structure(nc, confs[b], 2)
+        assert to == tries[b] == 1
+        print(f"C5 refine pose {b}: device {e[b]:.6f} oracle {eo:.6f}, max |d conf| {np.abs(out[b] - co).max():.2e}, evals {evals[b]} / {nc.evals}")
+        assert abs(e[b] - eo) < 2e-3 * max(1.0, abs(eo))
+        if abs(e[b] - eo) < 1e-3 * max(1.0, abs(eo)) and np.abs(out[b] - co).max() < 5e-3 and nc.evals == evals[b]:
+            close += 1
+    assert close >= 1
+    # (ii) the full refinement: lower loss, inside the box, reproducible, and the refined poses re-score to the returned energies
+    start, _ = v.cnn_eval_batch(s, confs, box, None, deriv=False)
+    e, out, tries, evals = v.cnn_refine_batch(s, confs, box)
+    assert (e <= start + 1e-6).all() and (e < start - 1e-3).sum() >= 4
+    assert (tries == 1).all() and (evals >= 2).all()
+    after, _ = v.cnn_eval_batch(s, out, box, None, deriv=False)
+    assert np.abs(after - e).max() < 1e-4 * max(1.0, float(np.abs(e).max()))
+    e2, out2, _, _ = v.cnn_refine_batch(s, confs, box)
+    assert np.array_equal(e, e2) and np.array_equal(out, out2)
