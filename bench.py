@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 entries of `also`")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--extras-timeout", type=float, default=900.0,
+                    help="seconds the sub-benchmarks behind the timed region may take before the headline line is printed without them")
     return ap.parse_args()
 
 
@@ -91,10 +93,31 @@ def cpu_baseline(args, blob_path, rec_xyz, rec_smt, lig_smt, poses, budget_s):
         tc += b
         scores.append((p, af))
         n += 1
+    # BASELINE.md section 4.2 also asks for the all-core variant of the voxelization stage: the same C oracle, one pose per
+    # host thread (ctypes releases the GIL), as many poses in flight as there are cores -- a throughput libmolgrid's CPU
+    # path does not have (it voxelizes one pose on one thread), reported beside the faithful figure, not inside `value`
+    vox_all = None
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        m = min(len(poses), 2 * ncpu)
+
+        def vox_only(b):
+            voxel.voxelize_pose(rec_xyz, rec_smt, poses[b], lig_smt, rmap, lmap, None, blob.resolution, blob.dimension,
+                                blob.radius_scaling)
+        with ThreadPoolExecutor(max_workers=ncpu) as ex:
+            list(ex.map(vox_only, range(min(m, ncpu))))      # warm-up
+            t0 = time.perf_counter()
+            list(ex.map(vox_only, range(m)))
+            dt_all = time.perf_counter() - t0
+        vox_all = {"threads": ncpu, "poses": m, "poses_per_s": round(m / dt_all, 1),
+                   "note": "C oracle voxelizer, one pose per thread, all host cores (BASELINE.md 4.2's OpenMP-style variant)"}
+    except Exception as e:
+        vox_all = {"error": f"{type(e).__name__}: {e}"}
     return {"value": n / (tv + tc), "unit": "poses/s", "cores": cores, "kind": "port",
             "sample": f"{n} poses of the same workload, B=1 per call like the reference "
                       f"(torch_model.cpp:179); voxelize {1e3 * tv / n:.1f} ms/pose (C oracle, 1 thread) + "
-                      f"CNN {1e3 * tc / n:.1f} ms/pose (PyTorch CPU fp32, {cores} threads)"}, scores
+                      f"CNN {1e3 * tc / n:.1f} ms/pose (PyTorch CPU fp32, {cores} threads)",
+            "voxelize_all_cores": vox_all}, scores
 
 
 def pmc_entry(kernel_label):
@@ -845,90 +868,12 @@ def main():
     scorer.enable_profile(False)
     gpu_scores = d_out.cpu().numpy()
 
-    # outside the timed region: the screening pattern end to end on a fixed pose set -- contiguous pose shards scored
-    # by their ranks, one all_gather of 4 floats per pose over RCCL (shard.score_sharded) -- checked on rank 0 against
-    # scoring the whole set alone: the same bits, in pose order
-    rccl = None
-    if dist is not None:
-        vposes = synth.make_poses(np.random.RandomState(4242), lig_xyz, 256 * world + 3)
-
-        def score_np(p):
-            o = scorer.score_batch(p, lig_smt)
-            return np.stack([o["pose"], o["affinity"], o["loss"], o["variance"]], 1)
-
-        gathered = shard.score_sharded(score_np, vposes, dist, dev)
-        if rank == 0:
-            alone = score_np(vposes)
-            rccl = {"ranks": world, "backend": dist.get_backend(), "receptor_broadcast_bytes": bcast_bytes,
-                    "sharded_poses": int(len(vposes)), "allgather_equals_single_rank": bool(np.array_equal(gathered, alone))}
-            assert rccl["allgather_equals_single_rank"], "sharded scores differ from single-rank scores"
-        dist.barrier()
-
-    # strong scaling beside the weak-scaling headline: ONE batch of 8,192 poses, contiguous shards over the ranks
-    # (SURVEY 8e), inputs resident in HBM, barrier + max over ranks like the timed region above
-    strong = None
-    try:
-        S_TOTAL = 8192
-        sp = synth.make_poses(np.random.RandomState(777), lig_xyz, S_TOTAL)
-        lo, hi = shard.shard_range(S_TOTAL, rank, world)
-        d_sp = torch.from_numpy(np.ascontiguousarray(sp[lo:hi])).to(dev)
-        d_so = torch.empty(4, hi - lo, dtype=torch.float32, device=dev)
-
-        def sstep():
-            scorer.score_batch_device(d_sp.data_ptr(), lig_smt, hi - lo, L, d_so[0].data_ptr(), d_so[1].data_ptr(),
-                                      d_so[2].data_ptr(), d_so[3].data_ptr())
-        sstep()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            sstep()
-        scorer.synchronize()
-        torch.cuda.synchronize()
-        dt_s = (time.perf_counter() - t0) / 3
-        if dist is not None:
-            dist.barrier()
-            t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_s = float(t.item())
-        strong = {"total_poses": S_TOTAL, "ranks": world, "ms": round(1e3 * dt_s, 3), "poses_per_s": round(S_TOTAL / dt_s, 1),
-                  "note": "one fixed batch, contiguous pose shards, max over ranks"}
-    except Exception as e:      # the headline line must still print
-        strong = {"error": f"{type(e).__name__}: {e}"}
-
-    # the C++ in-process pool (mi_pool: one host thread + scorer per GPU, RCCL scatter / gather for device-resident
-    # poses) over the same GPUs, driven by its C++ test driver in a child process while the ranks wait: pool sizes
-    # 1, 2, 4 .. N on one 8,192-pose batch, bit-equality with the single scorer checked inside the driver
-    pool_res = None
-    if rank == 0:
-        import subprocess
-        exe = os.path.join(ROOT, "gnina_amd", "lib", "test_pool")
-        try:
-            env = dict(os.environ)
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-                env.pop(k, None)
-            out_txt, rc, err_txt = "", None, ""
-            try:
-                r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), str(world), "8192"],
-                                   capture_output=True, text=True, timeout=150, env=env)
-                out_txt, rc, err_txt = r.stdout, r.returncode, r.stderr
-            except subprocess.TimeoutExpired as te:       # keep what the driver printed before it stalled
-                out_txt = te.stdout.decode() if isinstance(te.stdout, bytes) else (te.stdout or "")
-                err_txt = "timeout after 150 s"
-            rows = [l.split() for l in out_txt.split("\n") if l.startswith("pool ")]
-            hrows = [l.split() for l in out_txt.split("\n") if l.startswith("pool_host ")]
-            pool_res = {"driver": "tests/cpp/test_pool.cpp (C++ only: mi_pool over the visible GPUs, one 8,192-pose batch)",
-                        "returncode": rc,
-                        "host_path": [{"devices": int(l[2]), "equal_to_single_scorer": l[6] == "1", "poses_per_s": float(l[8])}
-                                      for l in hrows],
-                        "device_path_rccl": [{"devices": int(l[2]), "equal_to_single_scorer": l[10] == "1",
-                                              "poses_per_s": float(l[12])} for l in rows]}
-            if rc != 0:
-                pool_res["stderr"] = err_txt[-400:]
-        except Exception as e:
-            pool_res = {"error": f"{type(e).__name__}: {e}"}
-    if dist is not None:
-        dist.barrier()
-
+    # The headline is complete here.  Everything below is outside the timed region ("also": other models, C3 / C4 / C5,
+    # the RCCL screening pattern, the in-process pool): a hang in one of those extras -- a collective that a rank never
+    # reaches, the pool driver's first run on a multi-GPU box -- must not cost the headline line.  A watchdog on every rank
+    # bounds the extras: when it fires, rank 0 prints the line with what is there and names the phase that did not
+    # return, and every rank leaves (os._exit: the blocked thread cannot be joined).
+    res = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -984,24 +929,110 @@ def main():
             "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
             "dominant_kernel_overall": dom["kernel"],
         }
-        if rccl is not None:
-            res["rccl"] = rccl
-        res["strong_scaling"] = strong
-        res["pool_in_process"] = pool_res
-        if world == 1:
-            res["also"] = other_models(args, capi, synth, torch, dev)
-            res["roofline"]["dense_no_skip"] = conv1_dense(args, scorer, step, max(3, min(args.steps, 10)))
-            if not args.no_configs:
-                cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
-                for key, fn in (("real_complex", lambda: config_real_complex(capi, synth, torch, dev, args)),
-                                ("c3", lambda: config_c3(capi, cpu_s)), ("c3_real", lambda: config_c3_real(capi, cpu_s)),
-                                ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth)),
-                                ("seam_b1", lambda: config_seam_b1(capi, synth)),
-                                ("gradient_calls", lambda: config_gradient_calls(capi, synth))):
-                    try:
-                        res["also"][key] = fn()
-                    except Exception as e:  # the headline line must still print
-                        res["also"][key] = {"error": f"{type(e).__name__}: {e}"}
+
+    import threading
+    extras_phase = {"name": "start"}
+
+    def extras_timeout():
+        if rank == 0 and res is not None:
+            res["extras_incomplete"] = {"phase": extras_phase["name"], "seconds": args.extras_timeout,
+                                        "note": "the watchdog ended the extras; the headline (timed region) above is complete"}
+            print(json.dumps(res, default=float), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_timeout, extras_timeout)
+    watchdog.daemon = True
+    watchdog.start()
+
+    # outside the timed region: the screening pattern end to end on a fixed pose set -- contiguous pose shards scored
+    # by their ranks, one all_gather of 4 floats per pose over RCCL (shard.score_sharded) -- checked on rank 0 against
+    # scoring the whole set alone: the same bits, in pose order
+    rccl = None
+    extras_phase["name"] = "rccl: sharded screening pattern (all_gather)"
+    if dist is not None:
+        vposes = synth.make_poses(np.random.RandomState(4242), lig_xyz, 256 * world + 3)
+
+        def score_np(p):
+            o = scorer.score_batch(p, lig_smt)
+            return np.stack([o["pose"], o["affinity"], o["loss"], o["variance"]], 1)
+
+        gathered = shard.score_sharded(score_np, vposes, dist, dev)
+        if rank == 0:
+            alone = score_np(vposes)
+            rccl = {"ranks": world, "backend": dist.get_backend(), "receptor_broadcast_bytes": bcast_bytes,
+                    "sharded_poses": int(len(vposes)), "allgather_equals_single_rank": bool(np.array_equal(gathered, alone))}
+            assert rccl["allgather_equals_single_rank"], "sharded scores differ from single-rank scores"
+        dist.barrier()
+
+    # strong scaling beside the weak-scaling headline: ONE batch of 8,192 poses, contiguous shards over the ranks
+    # (SURVEY 8e), inputs resident in HBM, barrier + max over ranks like the timed region above
+    strong = None
+    extras_phase["name"] = "strong scaling (one 8,192-pose batch over the ranks)"
+    try:
+        S_TOTAL = 8192
+        sp = synth.make_poses(np.random.RandomState(777), lig_xyz, S_TOTAL)
+        lo, hi = shard.shard_range(S_TOTAL, rank, world)
+        d_sp = torch.from_numpy(np.ascontiguousarray(sp[lo:hi])).to(dev)
+        d_so = torch.empty(4, hi - lo, dtype=torch.float32, device=dev)
+
+        def sstep():
+            scorer.score_batch_device(d_sp.data_ptr(), lig_smt, hi - lo, L, d_so[0].data_ptr(), d_so[1].data_ptr(),
+                                      d_so[2].data_ptr(), d_so[3].data_ptr())
+        sstep()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sstep()
+        scorer.synchronize()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / 3
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        strong = {"total_poses": S_TOTAL, "ranks": world, "ms": round(1e3 * dt_s, 3), "poses_per_s": round(S_TOTAL / dt_s, 1),
+                  "note": "one fixed batch, contiguous pose shards, max over ranks"}
+    except Exception as e:      # the headline line must still print
+        strong = {"error": f"{type(e).__name__}: {e}"}
+
+    # the C++ in-process pool (mi_pool: one host thread + scorer per GPU, RCCL scatter / gather for device-resident
+    # poses) over the same GPUs, driven by its C++ test driver in a child process while the ranks wait: pool sizes
+    # 1, 2, 4 .. N on one 8,192-pose batch, bit-equality with the single scorer checked inside the driver
+    pool_res = None
+    extras_phase["name"] = "pool_in_process (tests/cpp/test_pool.cpp child process)"
+    if rank == 0:
+        import subprocess
+        exe = os.path.join(ROOT, "gnina_amd", "lib", "test_pool")
+        try:
+            env = dict(os.environ)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            out_txt, rc, err_txt = "", None, ""
+            try:
+                r = subprocess.run([exe, os.path.join(ROOT, "gnina_amd", "weights"), str(world), "8192"],
+                                   capture_output=True, text=True, timeout=150, env=env)
+                out_txt, rc, err_txt = r.stdout, r.returncode, r.stderr
+            except subprocess.TimeoutExpired as te:       # keep what the driver printed before it stalled
+                out_txt = te.stdout.decode() if isinstance(te.stdout, bytes) else (te.stdout or "")
+                err_txt = "timeout after 150 s"
+            rows = [l.split() for l in out_txt.split("\n") if l.startswith("pool ")]
+            hrows = [l.split() for l in out_txt.split("\n") if l.startswith("pool_host ")]
+            pool_res = {"driver": "tests/cpp/test_pool.cpp (C++ only: mi_pool over the visible GPUs, one 8,192-pose batch)",
+                        "returncode": rc,
+                        "host_path": [{"devices": int(l[2]), "equal_to_single_scorer": l[6] == "1", "poses_per_s": float(l[8])}
+                                      for l in hrows],
+                        "device_path_rccl": [{"devices": int(l[2]), "equal_to_single_scorer": l[10] == "1",
+                                              "poses_per_s": float(l[12])} for l in rows]}
+            if rc != 0:
+                pool_res["stderr"] = err_txt[-400:]
+        except Exception as e:
+            pool_res = {"error": f"{type(e).__name__}: {e}"}
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        extras_phase["name"] = "cpu_baseline"
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(args, os.path.join(ROOT, "gnina_amd", "weights", args.model + ".mgw"),
                                           rec_xyz, rec_smt, lig_smt, poses, args.cpu_seconds)
@@ -1013,7 +1044,29 @@ def main():
                 "max_abs_dpose": float(np.abs(gpu_scores[0, :n] - cs[:, 0]).max()),
                 "max_abs_daffinity": float(np.abs(gpu_scores[1, :n] - cs[:, 1]).max())}
             res["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
-        print(json.dumps(res, default=float))   # (numpy scalars from the sub-benchmarks)
+        if rccl is not None:
+            res["rccl"] = rccl
+        res["strong_scaling"] = strong
+        res["pool_in_process"] = pool_res
+        if world == 1:
+            extras_phase["name"] = "also: other models"
+            res["also"] = other_models(args, capi, synth, torch, dev)
+            res["roofline"]["dense_no_skip"] = conv1_dense(args, scorer, step, max(3, min(args.steps, 10)))
+            if not args.no_configs:
+                cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+                for key, fn in (("real_complex", lambda: config_real_complex(capi, synth, torch, dev, args)),
+                                ("c3", lambda: config_c3(capi, cpu_s)), ("c3_real", lambda: config_c3_real(capi, cpu_s)),
+                                ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth)),
+                                ("seam_b1", lambda: config_seam_b1(capi, synth)),
+                                ("gradient_calls", lambda: config_gradient_calls(capi, synth))):
+                    extras_phase["name"] = "also." + key
+                    try:
+                        res["also"][key] = fn()
+                    except Exception as e:  # the headline line must still print
+                        res["also"][key] = {"error": f"{type(e).__name__}: {e}"}
+        watchdog.cancel()
+        print(json.dumps(res, default=float), flush=True)   # (numpy scalars from the sub-benchmarks)
+    watchdog.cancel()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -254,6 +254,12 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
     else if (cells == 3) a.tcx = 3, a.tcy = 3, a.tcz = 3;
     else a.tcx = 2, a.tcy = 4, a.tcz = 4;
   }
+  if (const char *ev = option(OPT_MI_GNINA_K1_TILE)) {  // experiment: tile of the 1x1x1 transitions, "x,y,z" cells (<= 16)
+    int tx_ = 0, ty_ = 0, tz_ = 0;
+    if (o.ksize == 1 && !backward && (cp.cfg == CONV_CFG_4x1_1x3 || cp.cfg == CONV_CFG_4x1_1x5) && sscanf(ev, "%d,%d,%d", &tx_, &ty_, &tz_) == 3 &&
+        tx_ > 0 && ty_ > 0 && tz_ > 0 && tx_ * ty_ * tz_ <= 16 && cells % tz_ == 0)
+      a.tcx = tx_, a.tcy = ty_, a.tcz = tz_;
+  }
   a.ntx = cdiv(cells, a.tcx);
   a.nty = cdiv(cells, a.tcy);
   a.ntz = cdiv(cells, a.tcz);

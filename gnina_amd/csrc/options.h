@@ -47,7 +47,8 @@ namespace mig {
   X(MI_GNINA_D16_NP)                 \
   X(MI_GNINA_BF16_LDS_KB)            \
   X(MI_GNINA_ACT_GB)                 \
-  X(MI_POOL_WATCHDOG_S)
+  X(MI_POOL_WATCHDOG_S)              \
+  X(MI_GNINA_K1_TILE)
 
 enum OptionId {
 #define X(n) OPT_##n,

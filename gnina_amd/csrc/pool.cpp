@@ -33,6 +33,7 @@
 #include "../../include/mi_gnina.h"
 #include "common.h"
 #include "options.h"
+#include "pool_protocol.h"
 
 namespace mig {
 
@@ -78,13 +79,8 @@ struct Rccl {
   }
 };
 
-struct Worker {
+struct Worker : TaskThread {
   int device = 0, rank = 0;
-  std::thread th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<std::packaged_task<std::string()>> q;
-  bool stop = false;
   mi_scorer *scorer = nullptr;
   std::vector<mi_model *> models;
   hipStream_t stream = nullptr;  // for the RCCL scatter / gather and staging copies (the scorer has its own)
@@ -94,29 +90,6 @@ struct Worker {
   // stays on the fp32-MFMA kernels -- a model that is persistently out of range does not pay the double run on every shard
   int range_streak = 0;
   bool range_sticky = false;
-  void loop() {
-    for (;;) {
-      std::packaged_task<std::string()> t;
-      {
-        std::unique_lock<std::mutex> l(mu);
-        cv.wait(l, [&] { return stop || !q.empty(); });
-        if (q.empty()) return;
-        t = std::move(q.front());
-        q.pop_front();
-      }
-      t();
-    }
-  }
-  std::future<std::string> post(std::function<std::string()> f) {
-    std::packaged_task<std::string()> t(std::move(f));
-    auto fut = t.get_future();
-    {
-      std::lock_guard<std::mutex> l(mu);
-      q.push_back(std::move(t));
-    }
-    cv.notify_one();
-    return fut;
-  }
 };
 
 struct Pool {
@@ -130,32 +103,15 @@ struct Pool {
   bool use_rccl = true, duplicates = false;
   std::string rccl_note;
   long calls_host = 0, calls_device = 0;
+  std::string last_phases;  // phases the last RCCL device-path call went through (mi_pool_info_json)
   std::string info;
 };
 
-// run f(worker) on every worker's thread; the first error message wins ("" = ok)
+// run f(worker) on every worker's thread; the first error message wins ("" = ok) -- pool_protocol.h run_on_all
 std::string on_all(Pool &p, const std::function<std::string(Worker &)> &f) {
-  std::vector<std::future<std::string>> futs;
-  for (auto &wk : p.w) {
-    Worker *x = wk.get();
-    // (a task that throws would leave the other workers running on references to a frame that is being unwound: every
-    // task reports through its string)
-    futs.push_back(x->post([x, &f]() -> std::string {
-      try {
-        return f(*x);
-      } catch (const std::exception &e) {
-        return std::string("worker ") + std::to_string(x->rank) + ": " + e.what();
-      } catch (...) {
-        return std::string("worker ") + std::to_string(x->rank) + ": unknown exception";
-      }
-    }));
-  }
-  std::string err;
-  for (auto &fu : futs) {
-    std::string e = fu.get();
-    if (err.empty() && !e.empty()) err = e;
-  }
-  return err;
+  std::vector<TaskThread *> th;
+  for (auto &wk : p.w) th.push_back(wk.get());
+  return run_on_all(th, "", 0.0, nullptr, [&](int r) { return f(*p.w[r]); });
 }
 
 std::string last(const char *what) { return std::string(what) + ": " + mi_last_error(); }
@@ -186,10 +142,7 @@ std::string score_resident(Worker &x, const float *lig, const int32_t *smt, int 
   return score_dev_out(x, lig, smt, nb, L, cen, o_pose, o_aff, o_loss, o_var, MI_LIG_ON_DEVICE);
 }
 
-void shard(int B, int G, int g, int &b0, int &nb) {  // contiguous [g*B/G, (g+1)*B/G), SURVEY 8e
-  b0 = (int)((long)B * g / G);
-  nb = (int)((long)B * (g + 1) / G) - b0;
-}
+void shard(int B, int G, int g, int &b0, int &nb) { pool_shard(B, G, g, b0, nb); }
 
 }  // namespace
 }  // namespace mig
@@ -232,7 +185,7 @@ mi_pool *mi_pool_create(const int *devices, int n_devices, const char *const *mo
       wk->device = devices[g];
       wk->rank = g;
       Worker *x = wk.get();
-      x->th = std::thread([x] { x->loop(); });
+      x->start();
       p->w.push_back(std::move(wk));
     }
     std::vector<std::string> paths(model_paths, model_paths + n_models);
@@ -275,12 +228,7 @@ void mi_pool_destroy(mi_pool *pp) {
     return "";
   });
   for (auto &wk : p->w) {
-    {
-      std::lock_guard<std::mutex> l(wk->mu);
-      wk->stop = true;
-    }
-    wk->cv.notify_one();
-    if (wk->th.joinable()) wk->th.join();
+    wk->join();
   }
   delete p;
 }
@@ -400,101 +348,97 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
     MIG_CHECK(err.empty(), 3, err);
     return MI_OK;
   }
-  // RCCL transport, in phases separated by host-side rendezvous (on_all returns when every worker is through): a rank
-  // that fails -- its shard's scoring, an allocation -- must not leave its peers inside an ncclGroupEnd waiting for a
-  // send or receive that is never posted, so nothing but the point-to-point calls themselves sits between a GroupStart
-  // and its GroupEnd, every rank runs every group, and the gather is posted only once ALL ranks have scored.
+  // RCCL transport: the four phases of pool_protocol.h (allocations | scatter group | scoring | gather group, host-side
+  // rendezvous between them, every rank closes every group it opened, a watchdog on the two transport phases)
   Rccl &R = p.rccl;
-  auto nc = [&](ncclResult_t r, const char *what) -> std::string {
-    return r == ncclSuccess ? "" : std::string(what) + ": " + R.GetErrorString(r);
-  };
-  auto abandon_rccl = [&](const std::string &why) {  // a failed group: the communicators are not reusable
-    (void)on_all(p, [&](Worker &x) -> std::string {
-      if (x.comm && R.CommAbort) (void)R.CommAbort(x.comm);
-      x.comm = nullptr;
+  struct RcclTransport : PoolTransport {
+    Pool &p;
+    Rccl &R;
+    const float *lig_xyz, *centers;
+    float *out[4];
+    int L;
+    RcclTransport(Pool &p_, Rccl &R_) : p(p_), R(R_) {}
+    std::string nc(ncclResult_t r, const char *what) { return r == ncclSuccess ? "" : std::string(what) + ": " + R.GetErrorString(r); }
+    // array -> (pointer of pose `first` on this rank, floats per pose): rank 0 addresses the caller's arrays, rank g its staging
+    void *at(int rank, int array, int first, int b0, size_t &per) {
+      Worker &x = *p.w[rank];
+      if (array == 0) return per = (size_t)L * 3, rank == 0 ? (void *)(lig_xyz + (size_t)first * L * 3) : (void *)x.d_lig.p;
+      if (array == 1) return per = 3, rank == 0 ? (void *)(centers + (size_t)first * 3) : (void *)x.d_cen.p;
+      per = 1;
+      return rank == 0 ? (void *)(out[array - 2] + first) : (void *)(x.d_out.p + (size_t)(array - 2) * nb_of[rank]);
+    }
+    std::vector<int> nb_of;
+    std::string group_start(int) override { return nc(R.GroupStart(), "ncclGroupStart"); }
+    std::string group_end(int) override { return nc(R.GroupEnd(), "ncclGroupEnd"); }
+    std::string send(int rank, int peer, int array, int first, int count) override {
+      size_t per;
+      void *ptr = at(rank, array, first, 0, per);
+      Worker &x = *p.w[rank];
+      return nc(R.Send(ptr, (size_t)count * per, ncclFloat, peer, x.comm, x.stream), "ncclSend");
+    }
+    std::string recv(int rank, int peer, int array, int first, int count) override {
+      size_t per;
+      void *ptr = at(rank, array, first, 0, per);
+      Worker &x = *p.w[rank];
+      return nc(R.Recv(ptr, (size_t)count * per, ncclFloat, peer, x.comm, x.stream), "ncclRecv");
+    }
+    std::string sync(int rank) override {
+      return hipStreamSynchronize(p.w[rank]->stream) == hipSuccess ? "" : "hipStreamSynchronize failed after the transfers";
+    }
+    void abort_all() override {  // (from the caller's thread: ncclCommAbort is what unblocks a rank stuck inside a group)
+      for (auto &wk : p.w) {
+        if (wk->comm && R.CommAbort) (void)R.CommAbort(wk->comm);
+        wk->comm = nullptr;
+      }
+      p.comms_ready = false;
+      p.use_rccl = false;
+    }
+  } T(p, R);
+  T.lig_xyz = lig_xyz, T.centers = centers, T.L = L;
+  T.out[0] = pose, T.out[1] = affinity, T.out[2] = loss, T.out[3] = aff_var;
+  T.nb_of.resize(G);
+  for (int g = 0; g < G; g++) {
+    int b0;
+    shard(B, G, g, b0, T.nb_of[g]);
+  }
+  struct Work : PoolWork {
+    Pool &p;
+    const float *lig_xyz, *centers;
+    const int32_t *lig_smt;
+    float *pose, *affinity, *loss, *aff_var;
+    int L;
+    Work(Pool &p_) : p(p_) {}
+    std::string alloc(int rank, int, int nb) override {
+      Worker &x = *p.w[rank];
+      if (rank != 0 && nb > 0) {
+        x.d_lig.ensure((size_t)nb * L * 3);
+        if (centers) x.d_cen.ensure((size_t)nb * 3);
+        x.d_out.ensure((size_t)4 * nb);
+      }
       return "";
-    });
+    }
+    std::string score(int rank, int, int nb) override {
+      Worker &x = *p.w[rank];
+      if (rank == 0) return score_resident(x, lig_xyz, lig_smt, nb, L, centers, pose, affinity, loss, aff_var);
+      float *o = x.d_out.p;
+      return score_resident(x, x.d_lig.p, lig_smt, nb, L, centers ? x.d_cen.p : nullptr, o, o + nb, o + 2 * (size_t)nb, aff_var ? o + 3 * (size_t)nb : nullptr);
+    }
+  } W(p);
+  W.lig_xyz = lig_xyz, W.centers = centers, W.lig_smt = lig_smt, W.pose = pose, W.affinity = affinity, W.loss = loss, W.aff_var = aff_var, W.L = L;
+  std::vector<TaskThread *> threads;
+  for (auto &wk : p.w) threads.push_back(wk.get());
+  // (MI_POOL_WATCHDOG_S: seconds a transport phase may take before its communicators are aborted; 0 = never)
+  double watchdog_s = 120.0;
+  if (const char *ev = option(OPT_MI_POOL_WATCHDOG_S)) watchdog_s = atof(ev);
+  std::string err, phases;
+  const PoolOutcome oc = pool_device_path(B, threads, T, W, aff_var ? 4 : 3, centers != nullptr, watchdog_s, err, &phases);
+  p.last_phases = phases;
+  if (oc == PoolOutcome::transport_abandoned) {  // later calls take the copy transport
     p.comms_ready = false;
     p.use_rccl = false;
-    p.rccl_note = why;
-  };
-  const int n_arr = aff_var ? 4 : 3;
-  // phase 0: staging buffers (may fail: before any RCCL call)
-  std::string err = on_all(p, [&](Worker &x) -> std::string {
-    int b0, nb;
-    shard(B, G, x.rank, b0, nb);
-    if (x.rank != 0 && nb > 0) {
-      x.d_lig.ensure((size_t)nb * L * 3);
-      if (centers) x.d_cen.ensure((size_t)nb * 3);
-      x.d_out.ensure((size_t)4 * nb);
-    }
-    return "";
-  });
-  MIG_CHECK(err.empty(), 3, err);
-  // phase 1: scatter -- rank 0 sends shard g to rank g, rank g receives it (one group per rank = one fused transfer set)
-  err = on_all(p, [&](Worker &x) -> std::string {
-    int b0, nb;
-    shard(B, G, x.rank, b0, nb);
-    std::string e = nc(R.GroupStart(), "ncclGroupStart"), e1;
-    if (!e.empty()) return e;
-    if (x.rank == 0) {
-      for (int g = 1; g < G; g++) {
-        int c0, cn;
-        shard(B, G, g, c0, cn);
-        if (cn == 0) continue;
-        if (e.empty()) e = nc(R.Send(lig_xyz + (size_t)c0 * L * 3, (size_t)cn * L * 3, ncclFloat, g, x.comm, x.stream), "ncclSend");
-        if (e.empty() && centers) e = nc(R.Send(centers + (size_t)c0 * 3, (size_t)cn * 3, ncclFloat, g, x.comm, x.stream), "ncclSend");
-      }
-    } else if (nb > 0) {
-      e = nc(R.Recv(x.d_lig.p, (size_t)nb * L * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv");
-      if (e.empty() && centers) e = nc(R.Recv(x.d_cen.p, (size_t)nb * 3, ncclFloat, 0, x.comm, x.stream), "ncclRecv");
-    }
-    e1 = nc(R.GroupEnd(), "ncclGroupEnd");  // (always: the group must be closed on this thread)
-    if (e.empty()) e = e1;
-    if (e.empty() && hipStreamSynchronize(x.stream) != hipSuccess) e = "hipStreamSynchronize failed after the scatter";
-    return e;
-  });
-  if (!err.empty()) {
-    abandon_rccl(err);
-    throw mig::Error(3, err);
+    p.rccl_note = err;
   }
-  // phase 2: every rank scores its shard (device in, device out); no RCCL call in here
-  err = on_all(p, [&](Worker &x) -> std::string {
-    int b0, nb;
-    shard(B, G, x.rank, b0, nb);
-    if (nb == 0) return "";
-    if (x.rank == 0) return score_resident(x, lig_xyz, lig_smt, nb, L, centers, pose, affinity, loss, aff_var);
-    float *o = x.d_out.p;
-    return score_resident(x, x.d_lig.p, lig_smt, nb, L, centers ? x.d_cen.p : nullptr, o, o + nb, o + 2 * (size_t)nb, aff_var ? o + 3 * (size_t)nb : nullptr);
-  });
-  MIG_CHECK(err.empty(), 3, err);  // (nothing is pending in RCCL: the call fails as a whole, the pool stays usable)
-  // phase 3: gather the scores on devices[0], straight into the caller's arrays
-  err = on_all(p, [&](Worker &x) -> std::string {
-    int b0, nb;
-    shard(B, G, x.rank, b0, nb);
-    std::string e = nc(R.GroupStart(), "ncclGroupStart"), e1;
-    if (!e.empty()) return e;
-    if (x.rank == 0) {
-      float *dst[4] = {pose, affinity, loss, aff_var};
-      for (int g = 1; g < G; g++) {
-        int c0, cn;
-        shard(B, G, g, c0, cn);
-        for (int a = 0; a < n_arr && cn > 0; a++)
-          if (e.empty()) e = nc(R.Recv(dst[a] + c0, (size_t)cn, ncclFloat, g, x.comm, x.stream), "ncclRecv");
-      }
-    } else if (nb > 0) {
-      for (int a = 0; a < n_arr; a++)
-        if (e.empty()) e = nc(R.Send(x.d_out.p + (size_t)a * nb, (size_t)nb, ncclFloat, 0, x.comm, x.stream), "ncclSend");
-    }
-    e1 = nc(R.GroupEnd(), "ncclGroupEnd");
-    if (e.empty()) e = e1;
-    if (e.empty() && hipStreamSynchronize(x.stream) != hipSuccess) e = "hipStreamSynchronize failed after the gather";
-    return e;
-  });
-  if (!err.empty()) {
-    abandon_rccl(err);
-    throw mig::Error(3, err);
-  }
+  MIG_CHECK(oc == PoolOutcome::ok, 3, err);
   return MI_OK;
   PCATCH_STATUS
 }
@@ -587,7 +531,7 @@ mi_vina_pool *mi_vina_pool_create(const int *devices, int n_devices, const float
       wk->device = devices[g];
       wk->rank = g;
       Worker *x = wk.get();
-      x->th = std::thread([x] { x->loop(); });
+      x->start();
       p->w.push_back(std::move(wk));
       p->h.push_back(nullptr);
     }
@@ -627,12 +571,7 @@ void mi_vina_pool_destroy(mi_vina_pool *pp) {
     return "";
   });
   for (auto &wk : p->w) {
-    {
-      std::lock_guard<std::mutex> l(wk->mu);
-      wk->stop = true;
-    }
-    wk->cv.notify_one();
-    if (wk->th.joinable()) wk->th.join();
+    wk->join();
   }
   delete p;
 }
@@ -743,7 +682,13 @@ const char *mi_pool_info_json(mi_pool *pp) {
   o << "], \"ranks\": " << p.w.size() << ", \"device_path_transport\": \"" << (p.use_rccl ? "rccl" : "copies") << "\""
     << ", \"rccl_loaded\": " << (p.rccl.h ? "true" : "false")
     << ", \"rccl_comms\": " << (p.comms_ready ? "true" : "false") << ", \"calls_host_path\": " << p.calls_host
-    << ", \"calls_device_path\": " << p.calls_device << "}";
+    << ", \"calls_device_path\": " << p.calls_device << ", \"last_device_path_phases\": \"" << p.last_phases << "\""
+    << ", \"rccl_note\": \"" << [&] {
+         std::string n = p.rccl_note;
+         for (char &c : n)
+           if (c == '"' || c == '\\' || c == '\n') c = ' ';
+         return n;
+       }() << "\"}";
   p.info = o.str();
   return p.info.c_str();
 }
