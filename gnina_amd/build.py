@@ -85,6 +85,15 @@ def build_host(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    # the device-path protocol on a mock transport (no GPU, no RCCL): tests/test_pool_protocol_cpu.py runs it
+    qexe = os.path.join(LIBDIR, "test_pool_protocol")
+    qsrc = os.path.join(root, "tests", "cpp", "test_pool_protocol.cpp")
+    qhdr = os.path.join(CSRC, "pool_protocol.h")
+    if force or not os.path.exists(qexe) or os.path.getmtime(qexe) < max(os.path.getmtime(qsrc), os.path.getmtime(qhdr)):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", qexe, qsrc]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return exe
 
 

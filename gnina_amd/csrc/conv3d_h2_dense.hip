@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 3 : 2)) void conv3d_h2_k1s_kernel(C
     if (chunk > 0) __syncthreads();  // every wave is through the previous chunk's K loop: the tile may be overwritten
 #pragma unroll
     for (int i = 0; i < kK1sNS; i++)
-      if ((i * 4 + wave) * 64 < total)  // (wave-uniform)
+      if ((i * 4 + wave) * 64 < total && !(p.h2_dbg & 4))  // (wave-uniform)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (D16LdsPtr)(s_tile + (i * 4 + wave) * 1024), 16, voff[i], chunk * chunk_bytes, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
@@ -366,13 +366,19 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 3 : 2)) void conv3d_h2_k1s_kernel(C
       }
     };
     auto mfma_pair = [&](const uint4 &ah, const uint4 &al, const uint4 *wh, const uint4 *wl) __attribute__((always_inline)) {
+      // (three passes over the channel groups: consecutive MFMAs never wait for each other's accumulator; per accumulator the
+      // order al*wh, ah*wl, ah*wh of conv3d_h2_k1_kernel is kept -- same bits)
 #pragma unroll
-      for (int n = 0; n < TN; n++) {
+      for (int n = 0; n < TN; n++)
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, al), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < TN; n++)
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wl[n]), acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < TN; n++)
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
-      }
     };
+    if (p.h2_dbg & 2) continue;  // (timing only: no K loop)
     load_pair(0, ah0, al0, wh0, wl0);
     int pr = 0;
     for (; pr + 1 < P; pr += 2) {
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 3 : 2)) void conv3d_h2_k1s_kernel(C
 
   // ---- epilogue (accumulator layout and cell order of conv3d_h2_k1_kernel): un-scale, bias, ReLU, optional 2x2x2 pool;
   // channels-last fp32, or the split format (the lanes of channels 2j / 2j + 1 trade halves: d16_split_pair_dword) ----
+  if (p.h2_dbg & 64) return;  // (timing only: no epilogue)
   const int So = p.pool ? S / 2 : S;
   const size_t So3 = (size_t)So * So * So;
   float *out_f = p.out + (size_t)b * So3 * p.out_cs + p.out_c0;

@@ -1893,7 +1893,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             s.d_ovf.ensure(1);
             h.h2_overflow = s.d_ovf.p;
             h.mfma_count = nullptr;
-            if (const char *ev = option(OPT_MI_GNINA_H2_DBG)) h.h2_dbg = atoi(ev);  // (timing experiments, wrong results)
+            // (timing experiments, wrong results: conv3d_h2_dense.hip's h2_dbg bits)
+            if (const char *ev = option(st.conv.has_d16 ? OPT_MI_GNINA_D16_DBG : OPT_MI_GNINA_K1S_DBG)) h.h2_dbg = atoi(ev);
             if (st.conv.has_d16) {
               MIG_CHECK(h.out_split, 2, "Dense-block layer planned on split tensors writes a buffer that is not split");
               if (const char *ev = option(OPT_MI_GNINA_D16_NP)) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;

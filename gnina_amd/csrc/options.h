@@ -48,7 +48,9 @@ namespace mig {
   X(MI_GNINA_BF16_LDS_KB)            \
   X(MI_GNINA_ACT_GB)                 \
   X(MI_POOL_WATCHDOG_S)              \
-  X(MI_GNINA_K1_TILE)
+  X(MI_GNINA_K1_TILE)                \
+  X(MI_GNINA_D16_DBG)                \
+  X(MI_GNINA_K1S_DBG)
 
 enum OptionId {
 #define X(n) OPT_##n,

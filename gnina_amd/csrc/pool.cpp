@@ -385,13 +385,10 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
     std::string sync(int rank) override {
       return hipStreamSynchronize(p.w[rank]->stream) == hipSuccess ? "" : "hipStreamSynchronize failed after the transfers";
     }
-    void abort_all() override {  // (from the caller's thread: ncclCommAbort is what unblocks a rank stuck inside a group)
-      for (auto &wk : p.w) {
+    void abort_all() override {  // (any thread, once: ncclCommAbort is what unblocks a rank stuck inside a group; the handles
+                                 // stay in place -- their own threads may be using them -- and are dropped after the call)
+      for (auto &wk : p.w)
         if (wk->comm && R.CommAbort) (void)R.CommAbort(wk->comm);
-        wk->comm = nullptr;
-      }
-      p.comms_ready = false;
-      p.use_rccl = false;
     }
   } T(p, R);
   T.lig_xyz = lig_xyz, T.centers = centers, T.L = L;
@@ -434,6 +431,7 @@ mi_status mi_pool_score_batch(mi_pool *pp, const float *lig_xyz, const int32_t *
   const PoolOutcome oc = pool_device_path(B, threads, T, W, aff_var ? 4 : 3, centers != nullptr, watchdog_s, err, &phases);
   p.last_phases = phases;
   if (oc == PoolOutcome::transport_abandoned) {  // later calls take the copy transport
+    for (auto &wk : p.w) wk->comm = nullptr;  // (aborted by the protocol)
     p.comms_ready = false;
     p.use_rccl = false;
     p.rccl_note = err;

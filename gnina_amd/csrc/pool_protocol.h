@@ -14,12 +14,14 @@
 //   phase 3  gather    group { receives | sends }   posted only once ALL ranks have scored
 //
 // A phase runs on every rank's own thread and the caller waits for all of them (host-side rendezvous between phases).
-// A failed group makes the communicators unusable: they are aborted and the pool falls back to its copy transport.  A
+// A failed group makes the communicators unusable: they are aborted -- at once, by the rank whose post failed: a peer may
+// already be blocked on the operation that will now never be matched -- and the pool falls back to its copy transport.  A
 // phase that does not return within the watchdog period is a hang inside the transport: the watchdog names the phase
 // and the ranks still inside it, aborts the communicators (ncclCommAbort is the documented way out of a blocked RCCL call)
 // and keeps waiting for the threads to come back with their errors.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -153,7 +155,10 @@ inline PoolOutcome pool_device_path(int B, const std::vector<TaskThread *> &thre
   auto note = [&](const char *ph) {
     if (phase_log) *phase_log += std::string(phase_log->empty() ? "" : " > ") + ph;
   };
-  auto abort_once = [&] { T.abort_all(); };
+  std::atomic<bool> aborted{false};
+  auto abort_once = [&] {  // (any thread: a rank whose post failed, the watchdog, the caller)
+    if (!aborted.exchange(true)) T.abort_all();
+  };
   bool hung = false;
   note("alloc");
   err = run_on_all(threads, "0: allocations", 0.0, nullptr, [&](int r) {
@@ -192,6 +197,9 @@ inline PoolOutcome pool_device_path(int B, const std::vector<TaskThread *> &thre
             if (e.empty()) e = T.send(r, 0, 2 + a, b0, nb);
         }
       }
+      // a post that failed leaves a peer with an operation nobody will match: it would sit in its group_end until the
+      // watchdog -- abort right away (ncclCommAbort releases the blocked ranks), then close this rank's group
+      if (!e.empty()) abort_once();
       const std::string e1 = T.group_end(r);  // (always: the group must be closed on this thread)
       if (e.empty()) e = e1;
       if (e.empty()) e = T.sync(r);
@@ -201,7 +209,7 @@ inline PoolOutcome pool_device_path(int B, const std::vector<TaskThread *> &thre
   note("scatter");
   err = grouped("1: scatter (rank 0 sends shard g to rank g)", true);
   if (!err.empty()) {
-    if (!hung) T.abort_all();  // a failed group: the communicators are not reusable
+    abort_once();  // a failed group: the communicators are not reusable
     return PoolOutcome::transport_abandoned;
   }
   note("score");
@@ -214,7 +222,7 @@ inline PoolOutcome pool_device_path(int B, const std::vector<TaskThread *> &thre
   note("gather");
   err = grouped("3: gather (rank g sends its scores to rank 0)", false);
   if (!err.empty()) {
-    if (!hung) T.abort_all();
+    abort_once();
     return PoolOutcome::transport_abandoned;
   }
   return PoolOutcome::ok;
