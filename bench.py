@@ -751,7 +751,7 @@ def config_c5_refine(capi, scorer):
             "seconds": round(dt, 3), "poses_refined_per_s": round(B / dt, 2),
             "cnn_evaluations": int(evals.sum()), "cnn_evaluations_per_s": round(float(evals.sum()) / dt, 1),
             "mean_loss_before": round(float(start.mean()), 5), "mean_loss_after": round(float(e.mean()), 5),
-            "all_losses_lowered_or_equal": bool((e <= start + 1e-6).all())}
+            "all_losses_lowered_or_equal": bool((e <= start + 2e-5 * np.maximum(1.0, np.abs(start))).all())}
 
 
 def config_gradient_calls(capi, synth):

@@ -113,6 +113,10 @@ struct ConvArgs {
   // conv3d_h2_d16_kernel (conv3d_h2_dense.hip; Dense-block layers on split-format tensors): byte g of d16_taps[s] = the tap
   // (dx * 9 + dy * 3 + dz; 27 = the zero-weight filler) lane group g feeds in step s -- the order the weights are packed in
   unsigned d16_taps[7];
+  // persistent launches (conv3d_h2_dense.hip): n_items = (pose pair, tile) items of the launch, set by the launcher;
+  // h2_persist = workgroups per CU the launch is capped at, each walking items blockIdx.x, + gridDim.x, ... (0 = one
+  // workgroup per item)
+  int n_items, h2_persist;
   int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
@@ -168,7 +172,7 @@ bool conv_d16_layout_conflict_free(int SY, int SX);
 size_t conv_h2_d16_lds_bytes(const ConvArgs &p);
 void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s);
 size_t conv_h2_k1s_lds_bytes(const ConvArgs &p);
-void launch_conv_h2_k1s(const ConvArgs &p, int B, hipStream_t s);
+void launch_conv_h2_k1s(ConvArgs p, int B, hipStream_t s);
 
 void launch_zero_cell_probe(const float *in, int B, int C, int cs, int S, unsigned *out, hipStream_t s);
 void launch_pool_input(const float *in, float *out, int B, int C, int Cp, int N, int mode, hipStream_t s);

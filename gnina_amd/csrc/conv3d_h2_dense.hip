@@ -32,6 +32,9 @@
 #include "conv3d.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 
 namespace mig {
@@ -84,14 +87,6 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
   const int row = lane & 15;  // A row = voxel y * 8 + z * 4 + x of the M-tile's 4 x 2 x 2 block; B column = output channel
 
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
-  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int b = (wg / tiles_per_pose) * NP;                // first pose of this workgroup
-  const int npose = NP == 1 ? 1 : min(NP, p.nposes - b);   // (the last workgroups of an odd batch have one)
-  int t = wg - (wg / tiles_per_pose) * tiles_per_pose;
-  const int tz = t % p.ntz;
-  t /= p.ntz;
-  const int ty = t % p.nty, tx = t / p.nty;
-
   const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
   const int SY = HZ + p.h2_pad_y, SX = HY * SY + p.h2_pad_x;  // strides in 16-byte slots
   const int PL = (HX * SX + 31) & ~31;                        // slots per plane; the tile = 2 PL slots = whole wave-DMAs
@@ -123,21 +118,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
     baseA[m] = ((4 * cxp + vx_r) * SX + (2 * cy + vy_r) * SY + (2 * cz + vz_r)) * 16;  // bytes inside a plane
   }
 
-  d16_f32x4 acc[NP][TM];
-#pragma unroll
-  for (int tp = 0; tp < NP; tp++)
-#pragma unroll
-    for (int m = 0; m < TM; m++) acc[tp][m] = {0.f, 0.f, 0.f, 0.f};
-
-  const int S = p.S;
-  const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
-  const size_t pose_floats = (size_t)S * S * S * p.in_cs;
-  const float *in_b = p.in + (size_t)b * pose_floats;
-
-  // staging: slot j = tid + i * 256 of the tile is half j / PL of plane slot j % PL; a lane keeps the byte offset of its
-  // slots' sources inside an octet's [voxel][h8 | l8] array -- voxels outside the grid and pad slots take an out-of-range
-  // offset, for which a buffer load returns zeros (the zero padding)
-  unsigned voff[kD16NS];
+  // staging: slot j = tid + i * 256 of the tile is half j / PL of plane slot j % PL = halo voxel (hx, hy, hz); per lane and
+  // slot that is the same for every item: hx | hy << 8 | hz << 16 | half << 24, all ones = a pad slot
+  unsigned hpos[kD16NS];
   {
     const unsigned inv_sx = ((1u << 20) + SX - 1) / SX, inv_sy = ((1u << 20) + SY - 1) / SY;  // exact for n < 2^20 / d
 #pragma unroll
@@ -148,116 +131,153 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
       const int hx = (int)(((unsigned)ps * inv_sx) >> 20);
       const int r1 = ps - hx * SX;
       const int hy = (int)(((unsigned)r1 * inv_sy) >> 20), hz = r1 - hy * SY;
-      const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
-      const bool ok = j < 2 * PL && hx < HX && hy < HY && hz < HZ && (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
-      voff[i] = ok ? (unsigned)((x * S + y) * S + z) * 32u + (unsigned)half * 16u : 0x80000000u;
-      if (p.h2_dbg & 32) voff[i] = (unsigned)(((x0 + 1) * S + (y0 + 1)) * S + z0 + 1) * 32u + (unsigned)j * 16u;  // (timing only: contiguous sources)
+      hpos[i] = (j < 2 * PL && hx < HX && hy < HY && hz < HZ) ? ((unsigned)hx | (unsigned)hy << 8 | (unsigned)hz << 16 | (unsigned)half << 24) : 0xffffffffu;
     }
   }
-  const int octet_bytes = S * S * S * 32;
-  auto issue_tile = [&](int chunk, int tp) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b + (size_t)tp * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
-    char *dst = s_tile + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < kD16NS; i++)
-      if ((i * 4 + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (D16LdsPtr)(dst + i * 4096), 16, voff[i], chunk * octet_bytes, 0, 0);
-  };
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.nchunks * kD16WBytes, 0x00020000);
-  auto issue_w = [&](int chunk) {  // piece q = (step, h | l) = 1 KB = one wave-DMA, consecutive bytes
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int q = i * 4 + wave;
-      if (q < 2 * kD16Steps && !(p.h2_dbg & 8))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(s_w + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
-    }
-  };
 
-  uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
-  bool first = true;
-  for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    bool w_here = false;  // this chunk's weights are in LDS
-    auto pose_pass = [&](auto tpc) __attribute__((always_inline)) {
-      constexpr int tp = decltype(tpc)::value;
-      if (!first) __syncthreads();  // every wave is through the previous K loop: tile (and weights) may be overwritten
-      first = false;
-      issue_tile(chunk, tp);
-      if (!w_here) issue_w(chunk);
-      w_here = true;
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      __syncthreads();
-      const char *wl_ = s_w + lane * 16;
-      auto load_step = [&](int s, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < TM; m++) {
-          const char *a = s_tile + baseA[m] + qo[s];
-          ah[m] = *reinterpret_cast<const uint4 *>(a);
-          al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
-        }
-        wh = *reinterpret_cast<const uint4 *>(wl_ + s * 2048);
-        wl = *reinterpret_cast<const uint4 *>(wl_ + s * 2048 + 1024);
-      };
-      auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) __attribute__((always_inline)) {
-        // (three passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
-#pragma unroll
-        for (int m = 0; m < TM; m++)
-          acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, al[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < TM; m++)
-          acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wl), acc[tp][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < TM; m++)
-          acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
-      };
-      if (p.h2_dbg & 2) return;  // (timing only: no K loop)
-      load_step(0, ah0, al0, wh0, wl0);
-#pragma unroll
-      for (int s = 0; s < kD16Steps; s += 2) {
-        if (s + 1 < kD16Steps) load_step(s + 1, ah1, al1, wh1, wl1);
-        mfma_step(ah0, al0, wh0, wl0);
-        if (s + 2 < kD16Steps) load_step(s + 2, ah0, al0, wh0, wl0);
-        if (s + 1 < kD16Steps) mfma_step(ah1, al1, wh1, wl1);
+  // PERSISTENT workgroups: the launch has at most (workgroups that fit the chip at once) of them and each walks the
+  // (pose pair, tile) items item, item + gridDim.x, ... -- launching a 256-thread workgroup costs ~14 ns of dispatch on this
+  // chip (27,648 of them that do nothing but their prologue and barriers take 0.37-0.42 ms: tools/experiments), a
+  // fifth of a layer's time; the item's own set-up (tile coordinates, DMA offsets) is VALU work that overlaps with the other
+  // resident workgroups' DMA phases.  gridDim.x is a multiple of 8 (or the item count), so item % 8 is this workgroup's XCD
+  // for every item and xcd_contiguous_id keeps a pose's tiles on one XCD's L2.
+  bool first = true, ovf = false;
+  for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+    const int wg = xcd_contiguous_id(item, p.n_items);
+    const int b = (wg / tiles_per_pose) * NP;                // first pose of this workgroup
+    const int npose = NP == 1 ? 1 : min(NP, p.nposes - b);   // (the last workgroups of an odd batch have one)
+    int t = wg - (wg / tiles_per_pose) * tiles_per_pose;
+    const int tz = t % p.ntz;
+    t /= p.ntz;
+    const int ty = t % p.nty, tx = t / p.nty;
+
+    d16_f32x4 acc[NP][TM];
+  #pragma unroll
+    for (int tp = 0; tp < NP; tp++)
+  #pragma unroll
+      for (int m = 0; m < TM; m++) acc[tp][m] = {0.f, 0.f, 0.f, 0.f};
+
+    const int S = p.S;
+    const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
+    const size_t pose_floats = (size_t)S * S * S * p.in_cs;
+    const float *in_b = p.in + (size_t)b * pose_floats;
+
+    // this item's DMA sources: voxels outside the grid and pad slots take an out-of-range offset, for which a buffer load
+    // returns zeros (the zero padding)
+    unsigned voff[kD16NS];
+  #pragma unroll
+    for (int i = 0; i < kD16NS; i++) {
+      const int hx = (int)(hpos[i] & 0xffu), hy = (int)((hpos[i] >> 8) & 0xffu), hz = (int)((hpos[i] >> 16) & 0xffu);
+      const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+      const bool ok = hpos[i] != 0xffffffffu && (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+      voff[i] = ok ? (unsigned)((x * S + y) * S + z) * 32u + (hpos[i] >> 24) * 16u : 0x80000000u;
+      if (p.h2_dbg & 32) voff[i] = (unsigned)(((x0 + 1) * S + (y0 + 1)) * S + z0 + 1) * 32u + (unsigned)(tid + i * 256) * 16u;  // (timing only: contiguous sources)
+    }
+    const int octet_bytes = S * S * S * 32;
+    auto issue_tile = [&](int chunk, int tp) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b + (size_t)tp * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
+      char *dst = s_tile + wave * 1024;
+  #pragma unroll
+      for (int i = 0; i < kD16NS; i++)
+        if ((i * 4 + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (D16LdsPtr)(dst + i * 4096), 16, voff[i], chunk * octet_bytes, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.nchunks * kD16WBytes, 0x00020000);
+    auto issue_w = [&](int chunk) {  // piece q = (step, h | l) = 1 KB = one wave-DMA, consecutive bytes
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = i * 4 + wave;
+        if (q < 2 * kD16Steps && !(p.h2_dbg & 8))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(s_w + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
       }
     };
-    pose_pass(std::integral_constant<int, 0>{});
-    if constexpr (NP > 1)
-      if (npose > 1) pose_pass(std::integral_constant<int, 1>{});
-  }
 
-  // ---- epilogue: accumulator row = 4 * (lane >> 4) + reg = y * 8 + z * 4 + x, column = lane & 15: a lane holds the four
-  // x-consecutive voxels of one (y, z) for one output channel.  Un-scale, border-class bias, ReLU, split, store. ----
-  const int ch = row;
-  const int oct0 = (p.out_c0 >> 3) + (ch >> 3);
-  const int ch_sp = ((ch & 7) >> 1) + (ch & 1) * 4;
-  const size_t S3 = (size_t)S * S * S;
-  bool ovf = false;
-  auto finish_pose = [&](auto tpc) __attribute__((always_inline)) {
-    constexpr int tp = decltype(tpc)::value;
-    unsigned *out_u = reinterpret_cast<unsigned *>(p.out + (size_t)(b + tp) * S3 * p.out_cs);
-#pragma unroll
-    for (int m = 0; m < TM; m++) {
-      const int mt = wave * TM + m;
-      const int cz = mt % p.tcz, cy = (mt / p.tcz) % p.tcy, cxp = mt / (p.tcz * p.tcy);
-      const int gy = 2 * (ty * p.tcy + cy) + (kg >> 1), gz = 2 * (tz * p.tcz + cz) + (kg & 1);
-      const int gx0 = 2 * tx * p.tcx + 4 * cxp;
-      const bool ok_yz = mt < n_mt && gy < S && gz < S;
-      const int cls_yz = (gy == 0 ? 0 : gy == S - 1 ? 2 : 1) * 3 + (gz == 0 ? 0 : gz == S - 1 ? 2 : 1);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int gx = gx0 + r;
-        const int cls = (gx == 0 ? 0 : gx >= S - 1 ? 2 : 1) * 9 + cls_yz;
-        float v = acc[tp][m][r] * p.h2_unscale + p.bias_tab[cls * 16 + ch];
-        if (p.relu) v = fmaxf(v, 0.f);
-        const bool ok = ok_yz && gx < S;
-        ovf |= ok && !(fabsf(v) <= 65504.f);
-        const unsigned w = d16_split_pair_dword(v, ch);
-        if (ok && ch < p.cout) out_u[((size_t)oct0 * S3 + ((size_t)gx * S + gy) * S + gz) * 8 + ch_sp] = w;
-      }
+    uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
+    for (int chunk = 0; chunk < p.nchunks; chunk++) {
+      bool w_here = false;  // this chunk's weights are in LDS
+      auto pose_pass = [&](auto tpc) __attribute__((always_inline)) {
+        constexpr int tp = decltype(tpc)::value;
+        if (!first) __syncthreads();  // every wave is through the previous K loop: tile (and weights) may be overwritten
+        first = false;
+        issue_tile(chunk, tp);
+        if (!w_here) issue_w(chunk);
+        w_here = true;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
+        const char *wl_ = s_w + lane * 16;
+        auto load_step = [&](int s, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) __attribute__((always_inline)) {
+  #pragma unroll
+          for (int m = 0; m < TM; m++) {
+            const char *a = s_tile + baseA[m] + qo[s];
+            ah[m] = *reinterpret_cast<const uint4 *>(a);
+            al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
+          }
+          wh = *reinterpret_cast<const uint4 *>(wl_ + s * 2048);
+          wl = *reinterpret_cast<const uint4 *>(wl_ + s * 2048 + 1024);
+        };
+        auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) __attribute__((always_inline)) {
+          // (three passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
+  #pragma unroll
+          for (int m = 0; m < TM; m++)
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, al[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
+  #pragma unroll
+          for (int m = 0; m < TM; m++)
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wl), acc[tp][m], 0, 0, 0);
+  #pragma unroll
+          for (int m = 0; m < TM; m++)
+            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
+        };
+        if (p.h2_dbg & 2) return;  // (timing only: no K loop)
+        load_step(0, ah0, al0, wh0, wl0);
+  #pragma unroll
+        for (int s = 0; s < kD16Steps; s += 2) {
+          if (s + 1 < kD16Steps) load_step(s + 1, ah1, al1, wh1, wl1);
+          mfma_step(ah0, al0, wh0, wl0);
+          if (s + 2 < kD16Steps) load_step(s + 2, ah0, al0, wh0, wl0);
+          if (s + 1 < kD16Steps) mfma_step(ah1, al1, wh1, wl1);
+        }
+      };
+      pose_pass(std::integral_constant<int, 0>{});
+      if constexpr (NP > 1)
+        if (npose > 1) pose_pass(std::integral_constant<int, 1>{});
     }
-  };
-  finish_pose(std::integral_constant<int, 0>{});
-  if constexpr (NP > 1)
-    if (npose > 1) finish_pose(std::integral_constant<int, 1>{});
+
+    // ---- epilogue: accumulator row = 4 * (lane >> 4) + reg = y * 8 + z * 4 + x, column = lane & 15: a lane holds the four
+    // x-consecutive voxels of one (y, z) for one output channel.  Un-scale, border-class bias, ReLU, split, store. ----
+    const int ch = row;
+    const int oct0 = (p.out_c0 >> 3) + (ch >> 3);
+    const int ch_sp = ((ch & 7) >> 1) + (ch & 1) * 4;
+    const size_t S3 = (size_t)S * S * S;
+    auto finish_pose = [&](auto tpc) __attribute__((always_inline)) {
+      constexpr int tp = decltype(tpc)::value;
+      unsigned *out_u = reinterpret_cast<unsigned *>(p.out + (size_t)(b + tp) * S3 * p.out_cs);
+  #pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const int mt = wave * TM + m;
+        const int cz = mt % p.tcz, cy = (mt / p.tcz) % p.tcy, cxp = mt / (p.tcz * p.tcy);
+        const int gy = 2 * (ty * p.tcy + cy) + (kg >> 1), gz = 2 * (tz * p.tcz + cz) + (kg & 1);
+        const int gx0 = 2 * tx * p.tcx + 4 * cxp;
+        const bool ok_yz = mt < n_mt && gy < S && gz < S;
+        const int cls_yz = (gy == 0 ? 0 : gy == S - 1 ? 2 : 1) * 3 + (gz == 0 ? 0 : gz == S - 1 ? 2 : 1);
+  #pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gx = gx0 + r;
+          const int cls = (gx == 0 ? 0 : gx >= S - 1 ? 2 : 1) * 9 + cls_yz;
+          float v = acc[tp][m][r] * p.h2_unscale + p.bias_tab[cls * 16 + ch];
+          if (p.relu) v = fmaxf(v, 0.f);
+          const bool ok = ok_yz && gx < S;
+          ovf |= ok && !(fabsf(v) <= 65504.f);
+          const unsigned w = d16_split_pair_dword(v, ch);
+          if (ok && ch < p.cout) out_u[((size_t)oct0 * S3 + ((size_t)gx * S + gy) * S + gz) * 8 + ch_sp] = w;
+        }
+      }
+    };
+    if (!(p.h2_dbg & 64)) {  // (64: timing only, no epilogue)
+      finish_pose(std::integral_constant<int, 0>{});
+      if constexpr (NP > 1)
+        if (npose > 1) finish_pose(std::integral_constant<int, 1>{});
+    }
+  }
   d16_report_overflow(p.h2_overflow, ovf);
 }
 
@@ -272,21 +292,14 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
 constexpr int kK1sNS = 7;  // wave-DMAs per thread and chunk: voxels * (2 CC8 + 1) <= kK1sNS * 256 slots
 
 template <int TN>
-__global__ __launch_bounds__(256, (TN <= 3 ? 3 : 2)) void conv3d_h2_k1s_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = lane >> 5;
   const int row = lane & 31;
-
   const int tiles_per_pose = p.ntx * p.nty * p.ntz;
-  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int b = wg / tiles_per_pose;
-  int t = wg - b * tiles_per_pose;
-  const int tz = t % p.ntz;
-  t /= p.ntz;
-  const int ty = t % p.nty, tx = t / p.nty;
-  const int n_base = blockIdx.y * TN * 32;
+  constexpr int n_base = 0;  // (all output channels in one workgroup: the input is read once)
 
   const int HX = 2 * p.tcx, HY = 2 * p.tcy, HZ = 2 * p.tcz;
   const int HV = HX * HY * HZ;
@@ -313,134 +326,150 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 3 : 2)) void conv3d_h2_k1s_kernel(C
     if (!cell_of(wave, cell_in_mt, cx, cy, cz)) cx = cy = cz = 0;
     baseA = (((2 * cx + ox) * HY + (2 * cy + oy)) * HZ + (2 * cz + oz)) * NSV * 16;  // bytes
   }
-  d16_f32x16 acc[TN];
+  // bias of this lane's channels, fetched once (the epilogue of a latency-bound workgroup must not start with a round trip)
+  float bias_r[TN];
 #pragma unroll
-  for (int n = 0; n < TN; n++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+  for (int n = 0; n < TN; n++) bias_r[n] = p.bias[n_base + n * 32 + row < p.coutp ? n_base + n * 32 + row : 0];
 
   const int S = p.S;
   const size_t S3 = (size_t)S * S * S;
   const size_t pose_floats = S3 * p.in_cs;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)b * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
-  unsigned voff[kK1sNS];
-  {
-    const unsigned inv_nsv = ((1u << 20) + NSV - 1) / NSV;  // exact for j < 2^20 / NSV
-    const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
-#pragma unroll
-    for (int i = 0; i < kK1sNS; i++) {
-      const int j = tid + i * 256;
-      const int v = (int)(((unsigned)j * inv_nsv) >> 20), pp = j - v * NSV;
-      const int t1 = (int)(((unsigned)v * inv_hz) >> 20), hz = v - t1 * HZ;
-      const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
-      const int x = tx * HX + hx, y = ty * HY + hy, z = tz * HZ + hz;
-      const bool ok = j < total && pp < 2 * CC8 && x < S && y < S && z < S;
-      voff[i] = ok ? (unsigned)((size_t)(pp >> 1) * S3 + (size_t)((x * S + y) * S + z)) * 32u + (unsigned)(pp & 1) * 16u : 0x80000000u;
-    }
-  }
   const int chunk_bytes = CC8 * (int)S3 * 32;
   const size_t wstride = (size_t)p.coutp * 16;  // fp16 elements per octet row of the packed weights
   const int P = (CC8 + 1) >> 1;                 // steps (octet pairs) per chunk
   const unsigned wlane = ((unsigned)(n_base + row) * 16u + (unsigned)kh * (unsigned)wstride) * 2u;
   const unsigned wstep = 2u * (unsigned)wstride * 2u;  // bytes per octet pair
-
-  for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    if (chunk > 0) __syncthreads();  // every wave is through the previous chunk's K loop: the tile may be overwritten
-#pragma unroll
-    for (int i = 0; i < kK1sNS; i++)
-      if ((i * 4 + wave) * 64 < total && !(p.h2_dbg & 4))  // (wave-uniform)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (D16LdsPtr)(s_tile + (i * 4 + wave) * 1024), 16, voff[i], chunk * chunk_bytes, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
-    const char *wbase = reinterpret_cast<const char *>(p.wp) + (size_t)chunk * P * 2 * wstride * 2;
-    uint4 wh0[TN], wl0[TN], wh1[TN], wl1[TN], ah0, al0, ah1, al1;
-    auto load_pair = [&](int pr, uint4 &ah, uint4 &al, uint4 *wh, uint4 *wl) __attribute__((always_inline)) {
-      const char *a = s_tile + baseA + (2 * pr + kh) * 32;
-      ah = *reinterpret_cast<const uint4 *>(a);
-      al = *reinterpret_cast<const uint4 *>(a + 16);
-#pragma unroll
-      for (int n = 0; n < TN; n++) {
-        const char *w = wbase + (wlane + (unsigned)pr * wstep + (unsigned)n * 32u * 32u);
-        wh[n] = *reinterpret_cast<const uint4 *>(w);
-        wl[n] = *reinterpret_cast<const uint4 *>(w + 16);
-      }
-    };
-    auto mfma_pair = [&](const uint4 &ah, const uint4 &al, const uint4 *wh, const uint4 *wl) __attribute__((always_inline)) {
-      // (three passes over the channel groups: consecutive MFMAs never wait for each other's accumulator; per accumulator the
-      // order al*wh, ah*wl, ah*wh of conv3d_h2_k1_kernel is kept -- same bits)
-#pragma unroll
-      for (int n = 0; n < TN; n++)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, al), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < TN; n++)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wl[n]), acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < TN; n++)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
-    };
-    if (p.h2_dbg & 2) continue;  // (timing only: no K loop)
-    load_pair(0, ah0, al0, wh0, wl0);
-    int pr = 0;
-    for (; pr + 1 < P; pr += 2) {
-      load_pair(pr + 1, ah1, al1, wh1, wl1);
-      mfma_pair(ah0, al0, wh0, wl0);
-      if (pr + 2 < P) load_pair(pr + 2, ah0, al0, wh0, wl0);
-      mfma_pair(ah1, al1, wh1, wl1);
-    }
-    if (P & 1) mfma_pair(ah0, al0, wh0, wl0);
-  }
-
-  // ---- epilogue (accumulator layout and cell order of conv3d_h2_k1_kernel): un-scale, bias, ReLU, optional 2x2x2 pool;
-  // channels-last fp32, or the split format (the lanes of channels 2j / 2j + 1 trade halves: d16_split_pair_dword) ----
-  if (p.h2_dbg & 64) return;  // (timing only: no epilogue)
-  const int So = p.pool ? S / 2 : S;
-  const size_t So3 = (size_t)So * So * So;
-  float *out_f = p.out + (size_t)b * So3 * p.out_cs + p.out_c0;
-  unsigned *out_u = reinterpret_cast<unsigned *>(p.out + (size_t)b * So3 * p.out_cs);
-  const int ncx = S / 2;
-  bool ovf = false;
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    int cx, cy, cz;
-    bool okc = cell_of(wave, kh + 2 * half, cx, cy, cz);
-    const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
-    okc = okc && gcx < ncx && gcy < ncx && gcz < ncx;
+  const int nsteps = p.nchunks * P;                    // steps of the whole K loop: step g = chunk g / P, pair g % P
+  uint4 wh[TN], wl[TN];
+  // B operands of step g, straight from L1 / L2 (36 KB of weights per layer, every wave wants all of them) -- ONE register
+  // set: the loads of step g + 1 are issued right behind the MFMAs of step g (which read their operands as they issue) and
+  // are in flight while those drain and, across a chunk boundary, through the barrier and the DMA wait
+  auto load_w = [&](int g) __attribute__((always_inline)) {
+    const char *w0 = reinterpret_cast<const char *>(p.wp) + (size_t)g * wstep;
 #pragma unroll
     for (int n = 0; n < TN; n++) {
-      const int ch = n_base + n * 32 + row;
-      const bool okn = okc && ch < p.cout;
-      const float bias = p.bias[ch < p.coutp ? ch : 0];
-      float v[8];
+      const char *w = w0 + (wlane + (unsigned)n * 32u * 32u);
+      wh[n] = *reinterpret_cast<const uint4 *>(w);
+      wl[n] = *reinterpret_cast<const uint4 *>(w + 16);
+    }
+  };
+
+  // PERSISTENT workgroups (see conv3d_h2_d16_kernel): items item, item + gridDim.x, ...
+  bool ovf = false, first = true;
+  for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+    const int wg = xcd_contiguous_id(item, p.n_items);
+    const int b = wg / tiles_per_pose;
+    int t = wg - b * tiles_per_pose;
+    const int tz = t % p.ntz;
+    t /= p.ntz;
+    const int ty = t % p.nty, tx = t / p.nty;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)b * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
+    // staging: slot j = tid + i * 256 = voxel j / NSV, piece j % NSV (2 octet + half; the last slot of a voxel is padding);
+    // a lane keeps the byte offset of its slots' sources relative to the chunk's first octet array (recomputed per item: a
+    // hundred VALU instructions against tens of microseconds of DMA, and seven registers less across the K loop)
+    unsigned voff[kK1sNS];
+    {
+      const unsigned inv_nsv = ((1u << 20) + NSV - 1) / NSV;  // exact for j < 2^20 / NSV
+      const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const float tt = acc[n][half * 8 + r] * p.h2_unscale + bias;
-        v[r] = p.relu ? fmaxf(tt, 0.f) : tt;
+      for (int i = 0; i < kK1sNS; i++) {
+        const int j = tid + i * 256;
+        const int v = (int)(((unsigned)j * inv_nsv) >> 20), pp = j - v * NSV;
+        const int t1 = (int)(((unsigned)v * inv_hz) >> 20), hz = v - t1 * HZ;
+        const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+        const int x = tx * HX + hx, y = ty * HY + hy, z = tz * HZ + hz;
+        const bool ok = j < total && pp < 2 * CC8 && x < S && y < S && z < S;
+        voff[i] = ok ? (unsigned)((size_t)(pp >> 1) * S3 + (size_t)((x * S + y) * S + z)) * 32u + (unsigned)(pp & 1) * 16u : 0x80000000u;
       }
-      auto store = [&](size_t vox, float val) __attribute__((always_inline)) {
-        if (p.out_split) {
-          ovf |= okn && !(fabsf(val) <= 65504.f);
-          const unsigned w = d16_split_pair_dword(val, ch);
-          if (okn) out_u[((size_t)((p.out_c0 + ch) >> 3) * So3 + vox) * 8 + ((ch & 7) >> 1) + (ch & 1) * 4] = w;
-        } else if (okn) {
-          out_f[vox * p.out_cs + ch] = val;
-        }
-      };
-      if (p.pool == 1) {
-        float m1, m2, mx;  // max of the cell's eight voxels (no arg-max in the forward program)
-        m1 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        m2 = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
-        mx = fmaxf(m1, m2);
-        store(((size_t)gcx * So + gcy) * So + gcz, mx);
-      } else if (p.pool == 2) {
-        float sum = v[0];
+    }
+    d16_f32x16 acc[TN];
 #pragma unroll
-        for (int r = 1; r < 8; r++) sum = sum + v[r];
-        store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
-      } else {
+    for (int n = 0; n < TN; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    load_w(0);
+    int g = 0;
+    for (int chunk = 0; chunk < p.nchunks; chunk++) {
+      if (!first) __syncthreads();  // every wave is through the previous K loop: the tile may be overwritten
+      first = false;
+#pragma unroll
+      for (int i = 0; i < kK1sNS; i++)
+        if ((i * 4 + wave) * 64 < total && !(p.h2_dbg & 4))  // (wave-uniform)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (D16LdsPtr)(s_tile + (i * 4 + wave) * 1024), 16, voff[i], chunk * chunk_bytes, 0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      __syncthreads();
+      if (p.h2_dbg & 2) {  // (timing only: no K loop)
+        g += P;
+        continue;
+      }
+      for (int pr = 0; pr < P; pr++, g++) {
+        const char *a = s_tile + baseA + (2 * pr + kh) * 32;
+        const uint4 ah = *reinterpret_cast<const uint4 *>(a);
+        const uint4 al = *reinterpret_cast<const uint4 *>(a + 16);
+        // (three passes over the channel groups: consecutive MFMAs never wait for each other's accumulator; per accumulator
+        // the order al*wh, ah*wl, ah*wh of conv3d_h2_k1_kernel is kept -- same bits)
+#pragma unroll
+        for (int n = 0; n < TN; n++)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, al), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < TN; n++)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wl[n]), acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < TN; n++)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
+        if (g + 1 < nsteps) load_w(g + 1);
+      }
+    }
+
+    // ---- epilogue (accumulator layout and cell order of conv3d_h2_k1_kernel): un-scale, bias, ReLU, optional 2x2x2 pool;
+    // channels-last fp32, or the split format (the lanes of channels 2j / 2j + 1 trade halves: d16_split_pair_dword) ----
+    if (p.h2_dbg & 64) continue;  // (timing only: no epilogue)
+    const int So = p.pool ? S / 2 : S;
+    const size_t So3 = (size_t)So * So * So;
+    float *out_f = p.out + (size_t)b * So3 * p.out_cs + p.out_c0;
+    unsigned *out_u = reinterpret_cast<unsigned *>(p.out + (size_t)b * So3 * p.out_cs);
+    const int ncx = S / 2;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      int cx, cy, cz;
+      const bool in_tile = cell_of(wave, kh + 2 * half, cx, cy, cz);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      const bool okc = in_tile && gcx < ncx && gcy < ncx && gcz < ncx;
+#pragma unroll
+      for (int n = 0; n < TN; n++) {
+        const int ch = n_base + n * 32 + row;
+        const bool okn = okc && ch < p.cout;
+        float v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-          const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
-          store(((size_t)vx * So + vy) * So + vz, v[r]);
+          const float tt = acc[n][half * 8 + r] * p.h2_unscale + bias_r[n];
+          v[r] = p.relu ? fmaxf(tt, 0.f) : tt;
+        }
+        auto store = [&](size_t vox, float val) __attribute__((always_inline)) {
+          if (p.out_split) {
+            ovf |= okn && !(fabsf(val) <= 65504.f);
+            const unsigned w = d16_split_pair_dword(val, ch);
+            if (okn) out_u[((size_t)((p.out_c0 + ch) >> 3) * So3 + vox) * 8 + ((ch & 7) >> 1) + (ch & 1) * 4] = w;
+          } else if (okn) {
+            out_f[vox * p.out_cs + ch] = val;
+          }
+        };
+        if (p.pool == 1) {
+          // max of the cell's eight voxels (no arg-max in the forward program)
+          const float m1 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), m2 = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+          store(((size_t)gcx * So + gcy) * So + gcz, fmaxf(m1, m2));
+        } else if (p.pool == 2) {
+          float sum = v[0];
+#pragma unroll
+          for (int r = 1; r < 8; r++) sum = sum + v[r];
+          store(((size_t)gcx * So + gcy) * So + gcz, sum * 0.125f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int vx = 2 * gcx + (r >> 2), vy = 2 * gcy + ((r >> 1) & 1), vz = 2 * gcz + (r & 1);
+            store(((size_t)vx * So + vy) * So + vz, v[r]);
+          }
         }
       }
     }
@@ -453,21 +482,42 @@ size_t conv_h2_k1s_lds_bytes(const ConvArgs &p) {
   return ((total + 63) & ~(size_t)63) * 16 + 64;
 }
 
-void launch_conv_h2_k1s(const ConvArgs &p, int B, hipStream_t s) {
+// persistent launches: workgroups the chip holds at once for this kernel (occupancy API, cached), a multiple of 8
+static int d16_resident_workgroups(const void *kern, size_t lds, int per_cu_cap) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, const void *, size_t>, int> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(dev, kern, lds);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    int cus = 256, occ = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    it = cache.emplace(key, std::max(cus, 8) * 1000 + occ).first;
+  }
+  const int cus = it->second / 1000, occ = std::min(it->second % 1000, per_cu_cap > 0 ? per_cu_cap : 1000);
+  return (cus * occ) & ~7;
+}
+
+void launch_conv_h2_k1s(ConvArgs p, int B, hipStream_t s) {
   const int tn = p.coutp / 32;
   const size_t total = (size_t)8 * p.tcx * p.tcy * p.tcz * (2 * p.cc4 + 1);
   if (p.ksize != 1 || !p.in_split || p.in_cs % 8 || p.tcx * p.tcy * p.tcz > 16 || total > (size_t)kK1sNS * 256 || p.bn_scale || p.post_w ||
-      (p.in_cs / 8) != p.cc4 * p.nchunks || (p.out_split && ((p.out_c0 % 8) || (p.out_cs % 8) || (p.cout % 8))) || (tn != 3 && tn != 5))
+      (p.in_cs / 8) != p.cc4 * p.nchunks || (p.out_split && ((p.out_c0 % 8) || (p.out_cs % 8) || (p.cout % 8))) || (tn != 3 && tn != 5) ||
+      2 * p.tcx > 255 || 2 * p.tcy > 255 || 2 * p.tcz > 255)
     throw Error(2, "launch_conv_h2_k1s: launch outside what the kernel covers");
-  dim3 grid(B * p.ntx * p.nty * p.ntz, 1), block(256);
   const size_t lds = conv_h2_k1s_lds_bytes(p);
-  if (tn == 3) {
-    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_k1s_kernel<3>), 160 * 1024);
-    hipLaunchKernelGGL(conv3d_h2_k1s_kernel<3>, grid, block, lds, s, p);
-  } else {
-    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_k1s_kernel<5>), 160 * 1024);
-    hipLaunchKernelGGL(conv3d_h2_k1s_kernel<5>, grid, block, lds, s, p);
-  }
+  p.n_items = B * p.ntx * p.nty * p.ntz;
+  auto go = [&](auto kern) {
+    ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+    int grid = p.n_items;
+    if (p.h2_persist != 0) grid = std::min(grid, d16_resident_workgroups(reinterpret_cast<const void *>(kern), lds, p.h2_persist));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
+  };
+  if (tn == 3) go(conv3d_h2_k1s_kernel<3>);
+  else go(conv3d_h2_k1s_kernel<5>);
 }
 
 // the tap fed by lane group g of step s is kD16TapOrder[4 s + g] (27 = the zero-weight filler): pairs (g = 0, 1) and
@@ -529,7 +579,12 @@ void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s) {
   const int tiles = p.ntx * p.nty * p.ntz;
   auto go = [&](auto kern, int np) {
     ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((B + np - 1) / np * tiles)), dim3(256), lds, s, p);
+    p.n_items = (B + np - 1) / np * tiles;
+    // persistent workgroups: as many as the chip holds at once (occupancy API), a multiple of 8 so that a workgroup stays on
+    // one XCD's items; h2_persist = 0: one workgroup per item, > 0: a cap on the workgroups per CU, < 0: no cap
+    int grid = p.n_items;
+    if (p.h2_persist != 0) grid = std::min(grid, d16_resident_workgroups(reinterpret_cast<const void *>(kern), lds, p.h2_persist));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
   };
   const bool two = p.h2_wlds >= 2 && B >= 2;
   if (n_mt <= 4) two ? go(conv3d_h2_d16_kernel<1, 2>, 2) : go(conv3d_h2_d16_kernel<1, 1>, 1);

@@ -1272,6 +1272,14 @@ struct Scorer {
   DevBuf<int> d_cand_chan2, d_cand_n2;
   hipStream_t vox_stream = nullptr;     // voxelization of chunk i+1 overlaps the CNN of chunk i (VALU vs MFMA pipes)
   hipEvent_t ev_vox_done[2] = {nullptr, nullptr}, ev_cnn_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
+  // Small calls of an ensemble (gnina scores ONE pose per DLScorer::score call, torch_model.cpp:179; the default ensemble is
+  // three models): every model's layer program runs on its own stream ("lane") off the voxelization on the main stream, with
+  // its own set of activation buffers (act_lane) -- the launches of a B = 1 program are latency, not throughput, and three
+  // independent chains of ~20 dependent kernels overlap almost entirely.  Results are the bits of the serial order.
+  std::vector<hipStream_t> lane_streams;
+  std::vector<hipEvent_t> lane_done;
+  std::vector<hipEvent_t> lane_start;   // per voxelization group
+  int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
   bool overlap = false;  // measured: no gain (conv blocks fill the LDS, the voxelizer waves cannot co-reside); MI_GNINA_OVERLAP=1 enables
   // activations: one set of buffers sized for `chunk` poses, shared by all models (max size per id)
   std::vector<std::unique_ptr<DevBuf<float>>> act;
@@ -1334,6 +1342,12 @@ struct Scorer {
     for (auto &e : ev_cnn_done)
       if (e) (void)hipEventDestroy(e);
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
+    for (auto &e : lane_done)
+      if (e) (void)hipEventDestroy(e);
+    for (auto &e : lane_start)
+      if (e) (void)hipEventDestroy(e);
+    for (auto &st : lane_streams)
+      if (st) (void)hipStreamDestroy(st);
     if (h_out4) (void)hipHostFree(h_out4);
     if (vox_stream) (void)hipStreamDestroy(vox_stream);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1389,6 +1403,7 @@ static unsigned long long *prof_counter(Scorer &s, ProfScope &ps) {
 
 constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
 constexpr size_t kPooledSlot2 = 4096;  // second pooled-grid buffer of the two-stream pipeline
+constexpr size_t kLaneSlots = 64;      // activation buffer ids per lane (Scorer::act_lane): set l owns slots [64 l, 64 l + 64)
 
 // Poses per launch for a call on B poses: the user's chunk, clipped to B and to an activation-memory budget
 // (96 GB of the 288 GB by default, MI_GNINA_ACT_GB overrides) -- a 96^3 Dense pose keeps ~110 MB of
@@ -1832,7 +1847,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   auto buf_ptr = [&](int id) -> float * {
     const BufDecl &bd = m->d.bufs[id];
     // the pooled voxel grid lives in a dedicated slot shared by all models of a voxelization group
-    const size_t slot = id == m->input_dst ? pooled_slot : (size_t)id;
+    const size_t slot = id == m->input_dst ? pooled_slot : (size_t)id + (size_t)s.act_lane * kLaneSlots;
     return act_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * (id == m->input_dst ? pooled_stride(m) : m->buf_cp[id]));
   };
   // split-format tensors (Model::buf_split) exist in the split-fp16 forward program only
@@ -1898,8 +1913,12 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             if (st.conv.has_d16) {
               MIG_CHECK(h.out_split, 2, "Dense-block layer planned on split tensors writes a buffer that is not split");
               if (const char *ev = option(OPT_MI_GNINA_D16_NP)) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
+              h.h2_persist = -1;  // (persistent launch, as many workgroups as the chip holds; MI_GNINA_D16_PERSIST=0: one per item, n: at most n per CU)
+              if (const char *ev = option(OPT_MI_GNINA_D16_PERSIST)) h.h2_persist = atoi(ev);
               launch_conv_h2_d16(h, nb, s.stream);
             } else {
+              h.h2_persist = -1;
+              if (const char *ev = option(OPT_MI_GNINA_K1S_PERSIST)) h.h2_persist = atoi(ev);
               launch_conv_h2_k1s(h, nb, s.stream);
             }
           } else if (use_h2) {
@@ -2334,7 +2353,28 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     s.last_ms[0] = s.last_ms[1] = 0.f;
     MIG_HIP(hipEventRecord(s.ev[0], s.stream));
   }
+  // Lanes (Scorer::lane_streams): a small call of an ensemble runs every model's program on its own stream.
+  int lanes_max_b = 8;
+  if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
+  const bool lanes = nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) && !(s.overlap && B > s.cap);
+  if (lanes) {
+    while ((int)s.lane_streams.size() < nm) {
+      hipStream_t st = nullptr;
+      MIG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      s.lane_streams.push_back(st);
+      hipEvent_t e = nullptr;
+      MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      s.lane_done.push_back(e);
+    }
+    while (s.lane_start.size() < s.groups.size()) {
+      hipEvent_t e = nullptr;
+      MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      s.lane_start.push_back(e);
+    }
+  }
+  int gi = -1;
   for (const VoxGroup &g : s.groups) {
+    gi++;
     Model *m0 = s.models[g.first_model];
     LigSetup ls = ragged ? setup_ligand_ragged(s, g, lig_smt, B, L) : setup_ligand(s, g, lig_smt, L);
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
@@ -2353,7 +2393,11 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     for (int b0 = 0; b0 < B; b0 += s.cap, ci++) {
       const int nb = std::min(s.cap, B - b0);
       const int set = ov ? (ci & 1) : 0;
-      const size_t slot = set ? kPooledSlot2 : kPooledSlot;
+      // (lanes: the models of group gi - 1 may still be reading their pooled grid: the groups alternate between the two
+      // slots, and a slot is voxelized into again only after the lanes of the group two back are through)
+      const size_t slot = (lanes ? (gi & 1) : set) ? kPooledSlot2 : kPooledSlot;
+      if (lanes && gi >= 2)
+        for (int mi : s.groups[gi - 2].models) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));
       float *pooled = act_buf(s, slot, pooled_n);
       if (ov) {
         if (ci >= 2) MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_cnn_done[set], 0));  // buffer set free again
@@ -2365,15 +2409,37 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
           MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
         voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, nullptr, 0, split);
       }
-      for (int mi : g.models)
-        run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
-                    s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
+      if (lanes) {
+        // every buffer a program touches is allocated before the first launch (a grow-only buffer must not move under a lane)
+        MIG_HIP(hipEventRecord(s.lane_start[gi], s.stream));
+        struct LaneGuard {  // run_program launches on s.stream into buffer set s.act_lane
+          Scorer &s;
+          hipStream_t main;
+          ~LaneGuard() { s.stream = main, s.act_lane = 0; }
+        } guard{s, s.stream};
+        for (int mi : g.models) {
+          hipStream_t ls_ = s.lane_streams[mi];
+          MIG_HIP(hipStreamWaitEvent(ls_, s.lane_start[gi], 0));
+          s.stream = ls_;
+          s.act_lane = mi + 1;
+          run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
+                      s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
+          MIG_HIP(hipEventRecord(s.lane_done[mi], ls_));
+          s.stream = guard.main;
+        }
+      } else {
+        for (int mi : g.models)
+          run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
+                      s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
+      }
       if (ov) MIG_HIP(hipEventRecord(s.ev_cnn_done[set], s.stream));
     }
     if (ov) {  // the next group's ligand set-up rewrites buffers the voxelizer reads
       MIG_HIP(hipStreamSynchronize(s.vox_stream));
     }
   }
+  if (lanes)  // the ensemble reduction (main stream) reads what the lanes wrote
+    for (int mi = 0; mi < nm; mi++) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));
   const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
   float *o_pose = pose, *o_aff = aff, *o_loss = loss, *o_var = var;
   if (!out_dev) {  // one [4][B] device block -> one copy into pinned host memory -> the caller's four arrays

@@ -50,7 +50,12 @@ namespace mig {
   X(MI_POOL_WATCHDOG_S)              \
   X(MI_GNINA_K1_TILE)                \
   X(MI_GNINA_D16_DBG)                \
-  X(MI_GNINA_K1S_DBG)
+  X(MI_GNINA_K1S_DBG)                \
+  X(MI_GNINA_NO_LANES)               \
+  X(MI_GNINA_LANES_MAX_B)            \
+  X(MI_GNINA_D16_PERSIST)            \
+  X(MI_GNINA_K1S_PERSIST)            \
+  X(MI_GNINA_H2_PERSIST)
 
 enum OptionId {
 #define X(n) OPT_##n,

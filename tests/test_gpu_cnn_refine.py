@@ -120,7 +120,10 @@ def test_cnn_refine_lowers_the_loss(setup):
     box = capi.CnnBox.make(23.5, lo, hi)
     start, _ = v.cnn_eval_batch(s, confs, box, None, deriv=False)
     e, out, tries, evals = v.cnn_refine_batch(s, confs, box)
-    assert (e <= start + 1e-6).all() and (e < start - 1e-3).sum() >= 12
+    # (a pose the search cannot improve keeps its first energy -- computed by the gradient program, which for the Dense
+    # family is not the forward program bit for bit any more: BatchNorm folded into the weights there, applied while
+    # staging here; the two agree to ~1e-6 relative)
+    assert (e <= start + 2e-5 * np.maximum(1.0, np.abs(start))).all() and (e < start - 1e-3).sum() >= 12
     assert (tries == 1).all() and (evals >= 2).all()
     after, _ = v.cnn_eval_batch(s, out, box, None, deriv=False)
     assert np.abs(after - e).max() < 1e-4
@@ -411,7 +414,7 @@ def test_c5_refinement_at_96_cubed_end_to_end(setup):
     # (ii) the full refinement: lower loss, inside the box, reproducible, and the refined poses re-score to the returned energies
     start, _ = v.cnn_eval_batch(s, confs, box, None, deriv=False)
     e, out, tries, evals = v.cnn_refine_batch(s, confs, box)
-    assert (e <= start + 1e-6).all() and (e < start - 1e-3).sum() >= 4
+    assert (e <= start + 2e-5 * np.maximum(1.0, np.abs(start))).all() and (e < start - 1e-3).sum() >= 4
     assert (tries == 1).all() and (evals >= 2).all()
     after, _ = v.cnn_eval_batch(s, out, box, None, deriv=False)
     assert np.abs(after - e).max() < 1e-4 * max(1.0, float(np.abs(e).max()))

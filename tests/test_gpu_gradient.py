@@ -48,7 +48,11 @@ def test_ligand_gradient_matches_oracle(capi, CG, name):
     s.set_receptor(rec_xyz, rec_smt)
     out = s.score_grad(poses, lig_smt)
     fwd = s.score_batch(poses, lig_smt)
-    assert np.abs(out["pose"] - fwd["pose"]).max() < 1e-6 and np.abs(out["loss"] - fwd["loss"]).max() < 1e-5
+    # (Default2017 / Default2018: the gradient call's forward half computes the forward program's bits.  Dense: the forward
+    # program folds the blocks' BatchNorm into the split weights (conv3d_h2_dense.hip), the gradient program applies it while
+    # staging -- same arithmetic to ~1e-6, not the same bits)
+    tol = 5e-6 if name.startswith("dense") else 1e-6
+    assert np.abs(out["pose"] - fwd["pose"]).max() < tol and np.abs(out["loss"] - fwd["loss"]).max() < 1e-5 * max(1.0, float(np.abs(fwd["loss"]).max()))
     assert np.abs(out["pose"] - CG[name + "/pose"]).max() < 1e-4
     for b in range(len(poses)):
         loss0, g0 = oracle_lig_gradient(blob, rec_xyz, rec_smt, poses[b], lig_smt)
@@ -123,7 +127,7 @@ def test_flexible_receptor_rows(capi, CG, name):
     s.set_flex(rows)
     out = s.score_flex(poses, lig_smt, flex)
     fwd = s.score_flex(poses, lig_smt, flex, grad=False)
-    assert np.abs(out["pose"] - fwd["pose"]).max() < 1e-6
+    assert np.abs(out["pose"] - fwd["pose"]).max() < (5e-6 if name.startswith("dense") else 1e-6)
     rmap, lmap = voxel.typer_parse(blob.recmap_text()), voxel.typer_parse(blob.ligmap_text())
     for b in range(2):
         rx = rec_xyz.copy()
@@ -132,7 +136,11 @@ def test_flexible_receptor_rows(capi, CG, name):
         s2 = capi.Scorer([name])
         s2.set_receptor(rx, rec_smt)
         ref = s2.score_batch(poses[b:b + 1], lig_smt)
-        assert out["pose"][b] == ref["pose"][0] and out["affinity"][b] == ref["affinity"][0]
+        if name.startswith("dense"):   # (gradient program vs forward program: see test_ligand_gradient_matches_oracle)
+            assert abs(out["pose"][b] - ref["pose"][0]) < 5e-6 and abs(out["affinity"][b] - ref["affinity"][0]) < 5e-5
+            assert fwd["pose"][b] == ref["pose"][0] and fwd["affinity"][b] == ref["affinity"][0]   # forward vs forward: bits
+        else:
+            assert out["pose"][b] == ref["pose"][0] and out["affinity"][b] == ref["affinity"][0]
         grid, c = voxel.voxelize_pose(rx, rec_smt, poses[b], lig_smt, rmap, lmap)
         loss, gg = cnn_ref.loss_and_grid_gradient(blob, grid[None])
         ch, rad = voxel.type_atoms(rec_smt[rows], rmap[0])
