@@ -35,6 +35,11 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(HERE, "host", "typed_atoms.h"))
     headers.append(os.path.join(HERE, "host", "pdbqt.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
+    # a library newer than every source and header is current even when the object files are gone (the GPU box receives the
+    # built .so without lib/obj/: no reason to spend its minutes on recompiling everything)
+    src_mtime = max([hdr_mtime] + [os.path.getmtime(os.path.join(CSRC, s_)) for s_ in SOURCES])
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_mtime:
+        return LIB
     objs, todo = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

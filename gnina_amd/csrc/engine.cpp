@@ -45,6 +45,19 @@ void process_env_once() {
   });
 }
 
+// One CNN scoring call at a time per device.  gnina itself scores under DLScorer::mtx -- one recursive mutex shared by a
+// scorer and all its copies ("todo, enable parallel scoring", dl_scorer.h:26, cnn_torch_scorer.cpp:106) -- so the seam never
+// sees two calls in flight; callers of the C ABI may, and on MI355X two scorers' kernels running side by side on two
+// hardware queues do NOT give the bits each gives alone: measured round 5 (tools/experiments/concurrency_diag*.py) -- with a
+// Dense model on a second host thread ~5 % of the B = 1 calls of the first deviate by up to 3e-2 in the affinity; the
+// candidate lists are the quiet run's, the pooled voxel grid is not (a few cells whose accumulation saw another order);
+// GPU_MAX_HW_QUEUES=1 or this lock give 0 of 1,200.  Host-output calls hold the lock until their results are back;
+// device-output calls (MI_OUT_ON_DEVICE, the pools: one worker per device) only while they enqueue.
+static std::recursive_mutex &device_call_lock(int device) {
+  static std::recursive_mutex locks[64];
+  return locks[device >= 0 && device < 64 ? device : 0];
+}
+
 void ensure_max_lds(const void *kernel, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<int, const void *>> done;
@@ -1280,6 +1293,8 @@ struct Scorer {
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
+  int dbg_cap = 0, dbg_nslab = 0;       // geometry of the last voxelize_chunk's candidate lists (mi_debug_read_candidates)
+  int device = 0;                       // the HIP device the scorer was created on (device_call_lock)
   bool overlap = false;  // measured: no gain (conv blocks fill the LDS, the voxelizer waves cannot co-reside); MI_GNINA_OVERLAP=1 enables
   // activations: one set of buffers sized for `chunk` poses, shared by all models (max size per id)
   std::vector<std::unique_ptr<DevBuf<float>>> act;
@@ -1724,6 +1739,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.cand_n = cand_n.p;
   ga.cap = cap;
   ga.n_slab = n_slab;
+  s.dbg_cap = cap, s.dbg_nslab = n_slab;
   ga.res = m->d.resolution;
   {
     ProfScope ps(s, "gather_pose_atoms", 0.0, (double)nb * (tr.n + ls.n_lig) * 36.0, nb, vs);
@@ -2308,6 +2324,7 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
                              float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
                              float *flex_grad = nullptr) {
   if (B <= 0) return score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
+  std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
   score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
@@ -2356,7 +2373,10 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   // Lanes (Scorer::lane_streams): a small call of an ensemble runs every model's program on its own stream.
   int lanes_max_b = 8;
   if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
-  const bool lanes = nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) && !(s.overlap && B > s.cap);
+  // OPT-IN (MI_GNINA_LANES=1): kernels of different models running side by side do not reproduce the serial call's bits on
+  // this chip (see device_call_lock), and the default ensemble's B = 1 call gained 4 % from them (1,240 -> 1,196 us)
+  const bool lanes_on = option(OPT_MI_GNINA_LANES) && atoi(option(OPT_MI_GNINA_LANES)) != 0;
+  const bool lanes = lanes_on && nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) && !(s.overlap && B > s.cap);
   if (lanes) {
     while ((int)s.lane_streams.size() < nm) {
       hipStream_t st = nullptr;
@@ -2474,6 +2494,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
                         const float *centers, float *pose, float *aff, float *loss, float *var, unsigned flags,
                         bool ragged = false) {
   if (B <= 0) return score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
+  std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
   score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
@@ -2630,6 +2651,7 @@ mi_scorer *mi_scorer_create(mi_model *const *models, int n_models) {
     m->refs++;
     s->models.push_back(m);
   }
+  MIG_HIP(hipGetDevice(&s->device));
   MIG_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   MIG_HIP(hipStreamCreateWithFlags(&s->vox_stream, hipStreamNonBlocking));
   for (auto &e : s->ev_vox_done) MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2724,18 +2746,23 @@ mi_status mi_debug_read_activation(mi_scorer *sc, int mi, int buf, int B, int32_
   Scorer &s = *reinterpret_cast<Scorer *>(sc);
   MIG_CHECK(mi >= 0 && mi < (int)s.models.size(), 1, "model index out of range");
   Model *m = s.models[mi];
-  MIG_CHECK(!m->overlap && buf >= 0 && buf < (int)m->d.bufs.size() && buf != m->input_dst && m->buf_cp[buf] > 0, 1, "no such activation buffer");
+  MIG_CHECK(!m->overlap && buf >= 0 && buf < (int)m->d.bufs.size() && m->buf_cp[buf] > 0, 1, "no such activation buffer");
   const BufDecl &bd = m->d.bufs[buf];
-  const int cs = m->buf_cp[buf];
-  const bool split = s.precision == 0 && s.conv_path != 0 && m->buf_split[buf];
+  // (the pooled voxel grid -- buffer input_dst, slot kPooledSlot -- is readable when the call wrote it as fp32: the
+  // fp32-MFMA program, or MI_GNINA_H2_NO_SPLIT_TENSORS)
+  const bool pooled = buf == m->input_dst;
+  MIG_CHECK(!pooled || s.conv_path == 0 || option(OPT_MI_GNINA_H2_NO_SPLIT_TENSORS), 1, "the pooled grid of this call is in the split format");
+  const int cs = pooled ? pooled_stride(m) : m->buf_cp[buf];
+  const bool split = !pooled && s.precision == 0 && s.conv_path != 0 && m->buf_split[buf];
   info[0] = bd.S, info[1] = bd.C, info[2] = split ? 1 : 0;
   if (!out) return MI_OK;
   const size_t S3 = (size_t)bd.S * bd.S * bd.S;
   MIG_CHECK(B >= 1 && B <= s.cap && out_floats >= (size_t)B * S3 * bd.C, 1, "bad batch / output size");
-  MIG_CHECK((size_t)buf < s.act.size() && s.act[buf] && s.act[buf]->n >= (size_t)B * S3 * cs, 2, "buffer not allocated by a forward call");
+  const size_t slot = pooled ? kPooledSlot : (size_t)buf;
+  MIG_CHECK(slot < s.act.size() && s.act[slot] && s.act[slot]->n >= (size_t)B * S3 * cs, 2, "buffer not allocated by a forward call");
   MIG_HIP(hipStreamSynchronize(s.stream));
   std::vector<float> raw((size_t)B * S3 * cs);
-  MIG_HIP(hipMemcpy(raw.data(), s.act[buf]->p, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+  MIG_HIP(hipMemcpy(raw.data(), s.act[slot]->p, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (int b = 0; b < B; b++)
     for (size_t v = 0; v < S3; v++)
       for (int c = 0; c < bd.C; c++) {
@@ -2748,6 +2775,23 @@ mi_status mi_debug_read_activation(mi_scorer *sc, int mi, int buf, int B, int32_
         }
         out[((size_t)b * S3 + v) * bd.C + c] = val;
       }
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+// Diagnostic: the candidate lists gather_pose_atoms left for pose 0 of the last call: info = {n_slab, cap}; counts [n_slab],
+// chan [n_slab][cap], rec [n_slab][cap][8] (AtomRec as floats); pass NULL arrays to query info.
+mi_status mi_debug_read_candidates(mi_scorer *sc, int32_t *info, int32_t *counts, int32_t *chan, float *rec) {
+  MI_TRY
+  MIG_CHECK(sc && info, 1, "NULL argument");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  info[0] = s.dbg_nslab, info[1] = s.dbg_cap;
+  if (!counts) return MI_OK;
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  const size_t n = (size_t)s.dbg_nslab * s.dbg_cap;
+  MIG_HIP(hipMemcpy(counts, s.d_cand_n.p, s.dbg_nslab * sizeof(int), hipMemcpyDeviceToHost));
+  if (chan) MIG_HIP(hipMemcpy(chan, s.d_cand_chan.p, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (rec) MIG_HIP(hipMemcpy(rec, s.d_cand.p, n * sizeof(AtomRec), hipMemcpyDeviceToHost));
   return MI_OK;
   MI_CATCH_STATUS
 }
@@ -2845,6 +2889,7 @@ mi_status mi_voxelize_batch(mi_scorer *sc, int mi, const float *lig_xyz, const i
   MIG_CHECK(mi >= 0 && mi < (int)s.models.size(), 1, "model index out of range");
   MIG_CHECK(B >= 0 && L >= 0 && grid_out && (B == 0 || (lig_xyz && lig_smt)), 1, "bad arguments");
   if (B == 0) return MI_OK;
+  std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
   RotScope rot_scope(s, B);  // mi_scorer_set_rotations applies to this call too (and is consumed by it)
   const VoxGroup *grp = nullptr;
   for (auto &g : s.groups)
@@ -2888,6 +2933,7 @@ mi_status mi_model_forward_grids(mi_scorer *sc, int mi, const float *grids, int 
   MI_TRY
   MIG_CHECK(sc, 1, "NULL scorer");
   Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
   MIG_CHECK(mi >= 0 && mi < (int)s.models.size() && B >= 0 && grids && pose && affinity && loss, 1, "bad arguments");
   if (B == 0) return MI_OK;
   Model *m = s.models[mi];

@@ -52,10 +52,11 @@ namespace mig {
   X(MI_GNINA_D16_DBG)                \
   X(MI_GNINA_K1S_DBG)                \
   X(MI_GNINA_NO_LANES)               \
+  X(MI_GNINA_LANES)                  \
   X(MI_GNINA_LANES_MAX_B)            \
   X(MI_GNINA_D16_PERSIST)            \
   X(MI_GNINA_K1S_PERSIST)            \
-  X(MI_GNINA_H2_PERSIST)
+  X(MI_VOX_DBG)
 
 enum OptionId {
 #define X(n) OPT_##n,

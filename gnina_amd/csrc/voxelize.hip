@@ -374,6 +374,10 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   int cur_w = 0;
   // window cur_w of the staged tile -> out[b][cx][cy][cz][cur_w * kWin ...]: 64 cells x kWin / 4 float4, then cleared
   auto emit_window = [&]() {
+    if (v.dbg & 4) {  // (timing only)
+      cur_w++;
+      return;
+    }
     __builtin_amdgcn_s_waitcnt(0);  // wave-synchronous: the LDS writes of flush() complete before the reads
     __builtin_amdgcn_wave_barrier();
     const int S = v.N / 2;
@@ -448,6 +452,10 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
           }
       return;
     }
+    if (v.dbg & 2) {  // (timing only)
+      while (cur_w < c / kWin) emit_window();
+      return;
+    }
     // sub-block ownership -> cell ownership (wave-synchronous LDS round trip; LDS executes a wave's accesses in order)
 #pragma unroll
     for (int k = 0; k < 8; k++) s_tr[tw_base + k * kVoxTrStride + (k & 1) + 4 * ((k >> 1) & 1)] = acc[k];
@@ -500,6 +508,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       float ddz = fmaxf(0.f, fmaxf(tloz - a.z, a.z - thiz));
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
       hit = d2 <= a.t2 * 1.0001f + 1e-4f;  // conservative superset of "some voxel has rsq < t2"
+      if (v.dbg & 8) hit = false;  // (timing only)
     }
     unsigned long long mask = __ballot(hit);
     // the record of a hit comes back through the scalar cache, the next hit's record is requested before this one is
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0.f;
       }
+      if (v.dbg & 1) continue;  // (timing only)
       // squared distances of this lane's eight voxels, two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations
       // as the scalar forms, in the same order -- (dx^2 + dy^2) + dz^2 -- at half the instruction count; the kernel's time
       // is its VALU instruction count)
@@ -664,7 +674,9 @@ void launch_gather(const GatherArgs &g, int B, hipStream_t s) {
     hipLaunchKernelGGL(gather_pose_atoms<256>, dim3(B), dim3(256), 0, s, g);
 }
 
-void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s) {
+void launch_voxelize(const VoxArgs &v_in, int B, int mode, hipStream_t s) {
+  VoxArgs v = v_in;
+  v.dbg = option(OPT_MI_VOX_DBG) ? atoi(option(OPT_MI_VOX_DBG)) : 0;
   const int nt = v.tiles_per_axis;
   dim3 grid(nt * nt * nt * B), block(64);
   if (mode == 0) {

@@ -49,9 +49,15 @@ enum {
 /* ---- process / thread setup --------------------------------------------------------------
  * Replaces initializeCUDA(int device) (gninasrc/lib/dl_scorer.h:20-21, called main.cpp:753 and
  * parallel_mc.cpp:197): must be called in every host thread that uses the engine.
- * Every scorer / mi_vina handle owns a HIP stream; handles driven from different host threads overlap on the
+ * Every scorer / mi_vina handle owns a HIP stream; mi_vina handles driven from different host threads overlap on the
  * device as far as the runtime has hardware queues, so the first call also sets GPU_MAX_HW_QUEUES=16 (HIP's
- * default is 4) unless the variable is already set -- effective only before the process's first HIP call. */
+ * default is 4) unless the variable is already set -- effective only before the process's first HIP call.
+ * CNN scoring calls (mi_scorer_score_*, mi_voxelize_batch, mi_model_forward_grids) on different scorers of ONE device
+ * are serialised by the library, as gnina serialises them under DLScorer::mtx (dl_scorer.h:26, cnn_torch_scorer.cpp:106:
+ * one mutex shared by a scorer and its copies): two scorers' kernels side by side on two hardware queues do not give the
+ * bits each gives alone on this chip (round 5; tests/test_gpu_concurrency.py).  Host-output calls hold
+ * the device's lock until their results are back; MI_OUT_ON_DEVICE calls only while they enqueue -- the caller orders
+ * those (the pools drive one scorer per device). */
 mi_status mi_gnina_init(int device);
 /* Experiment / A-B switches (gnina_amd/csrc/options.h lists them: MI_GNINA_*, MI_POOL_*, MI_VINA_*, MI_VOX_*).  The
  * environment is read ONCE per process, at the first library call; afterwards a switch changes only through this call
@@ -162,6 +168,10 @@ mi_status mi_debug_split_f16(const float *x, int n, float scale, uint16_t *hi, u
  * fp32 one.  info[3] = {S, C, 1 if the buffer is in the split format under the scorer's precision}; out may be NULL to
  * query info only.  tests/test_gpu_dense_split.py compares the split-fp16 and fp32-MFMA programs layer by layer with it. */
 mi_status mi_debug_read_activation(mi_scorer *, int model_index, int buf, int B, int32_t *info, float *out, size_t out_floats);
+/* Diagnostic: the candidate lists gather_pose_atoms left for pose 0 of the last call (what voxelize_tiles read): info[2] =
+ * {n_slab, cap}; counts[n_slab]; chan[n_slab][cap] (channel of every candidate, ascending per list); rec[n_slab][cap][8]
+ * (x y z radius and the density constants).  Pass NULL arrays to query info only.  tools/experiments/concurrency_diag3.py. */
+mi_status mi_debug_read_candidates(mi_scorer *, int32_t *info, int32_t *counts, int32_t *chan, float *rec);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
  * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+export DIAG_CALLS=300
+for env in "MI_VOX_DBG=64" "MI_VOX_DBG=96" "MI_VOX_DBG=112" ""; do
+  echo "== [$env]"
+  env $env timeout 300 python tools/experiments/concurrency_diag.py dense_1_3,dense_1_3_PT_KD_3 dense_1_3,crossdock_default2018_KD_4 2>&1 | tail -4
+done
