@@ -369,11 +369,15 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
     // hundred VALU instructions against tens of microseconds of DMA, and seven registers less across the K loop)
     unsigned voff[kK1sNS];
     {
+      // (from an OPAQUE copy of the thread index: the slot -> (voxel, piece) decomposition is tile-invariant, and hoisted out
+      // of the item loop it was 30 spilled dwords -- stored once, reloaded for every item)
+      int tid_i = tid;
+      asm volatile("" : "+v"(tid_i));
       const unsigned inv_nsv = ((1u << 20) + NSV - 1) / NSV;  // exact for j < 2^20 / NSV
       const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
 #pragma unroll
       for (int i = 0; i < kK1sNS; i++) {
-        const int j = tid + i * 256;
+        const int j = tid_i + i * 256;
         const int v = (int)(((unsigned)j * inv_nsv) >> 20), pp = j - v * NSV;
         const int t1 = (int)(((unsigned)v * inv_hz) >> 20), hz = v - t1 * HZ;
         const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
@@ -425,6 +429,12 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
     // ---- epilogue (accumulator layout and cell order of conv3d_h2_k1_kernel): un-scale, bias, ReLU, optional 2x2x2 pool;
     // channels-last fp32, or the split format (the lanes of channels 2j / 2j + 1 trade halves: d16_split_pair_dword) ----
     if (p.h2_dbg & 64) continue;  // (timing only: no epilogue)
+    // (the epilogue's lane-derived values from an opaque copy of the thread index, for the same reason as voff above: the
+    // channel offsets of the TN groups are tile-invariant, and hoisted out of the item loop they are spilled)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int row = tid_e & 31, kh = (tid_e >> 5) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
     const int So = p.pool ? S / 2 : S;
     const size_t So3 = (size_t)So * So * So;
     float *out_f = p.out + (size_t)b * So3 * p.out_cs + p.out_c0;
