@@ -55,6 +55,11 @@ void process_env_once() {
 // device-output calls (MI_OUT_ON_DEVICE, the pools: one worker per device) only while they enqueue.
 static std::recursive_mutex &device_call_lock(int device) {
   static std::recursive_mutex locks[64];
+  // (MI_GNINA_NO_CALL_LOCK=1, a diagnostic for tools/experiments/concurrency_diag*.py: every call gets a lock of its own)
+  if (option(OPT_MI_GNINA_NO_CALL_LOCK)) {
+    static thread_local std::recursive_mutex own;
+    return own;
+  }
   return locks[device >= 0 && device < 64 ? device : 0];
 }
 

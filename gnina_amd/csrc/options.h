@@ -56,7 +56,8 @@ namespace mig {
   X(MI_GNINA_LANES_MAX_B)            \
   X(MI_GNINA_D16_PERSIST)            \
   X(MI_GNINA_K1S_PERSIST)            \
-  X(MI_VOX_DBG)
+  X(MI_VOX_DBG)                      \
+  X(MI_GNINA_NO_CALL_LOCK)
 
 enum OptionId {
 #define X(n) OPT_##n,
