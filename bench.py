@@ -586,7 +586,10 @@ def config_seam_b1(capi, synth):
     rec_xyz, rec_smt = synth.make_receptor(rng, 2500, rt)
     lx, ls = synth.make_ligand(rng, 32, lt)
     pose1 = synth.make_poses(rng, lx, 1)
-    out = {"note": "B = 1 per call, host pointers, synchronous; median of 60 calls after 10 warm-up calls; microseconds"}
+    out = {"note": "B = 1 per call, host pointers, synchronous; median of 60 calls after 10 warm-up calls; microseconds.  "
+                   "four_threads: four scorers on four host threads -- since round 5 the library runs one CNN scoring call at a "
+                   "time per device, as gnina does under DLScorer::mtx (two scorers' kernels side by side do not reproduce the "
+                   "single-thread bits: DESIGN 3.10), so this is what the lock allows, not concurrency on the GPU"}
     for label, models in (("default2017", ["default2017"]),
                           ("default_ensemble", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])):
         s = capi.Scorer(models)
