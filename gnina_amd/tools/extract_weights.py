@@ -133,7 +133,273 @@ def _maps_to_lines(text, key):
     return out
 
 
-def convert(pt_path, name=None):
+# ----------------------------------------------------------------------------------------------
+# Generic path: any TorchScript module whose frozen graph is a feed-forward stack of the operators gnina's
+# architectures are made of (what `--cnn_model file.pt` may hand to TorchModel, torch_model.cpp:49-118):
+#   max_pool3d / avg_pool3d (kernel = stride = 2, or kernel = the whole grid: global max pool), _convolution / conv3d
+#   (kernel 1 or 3, stride 1, "same" padding, no groups / dilation), relu behind a convolution, batch_norm in eval mode
+#   (in front of a convolution: kept as the conv's input scale / shift; behind one: folded into its weights), cat along
+#   the channels of tensors that extend one another (DenseNet blocks: cat([a, b]), cat([a, b, c]), ...), view / flatten,
+#   two linear heads on the flattened features (pose: 2 outputs, affinity: 1), log_softmax / squeeze on the way out.
+# The walk assigns every tensor a (buffer, first channel, channels, grid points per side) and emits the same program
+# lines the family-specific paths above write by hand.  Anything else raises, naming the operator.
+# ----------------------------------------------------------------------------------------------
+def _const(v):
+    n = v.node()
+    if n.kind() != "prim::Constant":
+        raise ValueError(f"expected a constant, got {n.kind()}")
+    return v.toIValue()
+
+
+def _ints(v):
+    n = v.node()
+    if n.kind() == "prim::ListConstruct":
+        return [int(_const(i)) for i in n.inputs()]
+    x = _const(v)
+    return [int(i) for i in x] if isinstance(x, (list, tuple)) else [int(x)]
+
+
+def convert_graph(module, blob, C0, N):
+    """Walk the frozen graph of `module` (input: the [B, C0, N, N, N] grid) and append its program to `blob`."""
+    frozen = torch.jit.freeze(module.eval())
+    g = frozen.graph
+    # a SCRIPTED module carries its Python control flow (BatchNorm's `if input.dim() != 5: raise ...`): with the input's
+    # shape known the checks fold away and what is left is the operator stack a traced module has from the start
+    torch._C._jit_pass_inline(g)
+    torch._C._jit_pass_complete_shape_analysis(g, (torch.zeros(1, C0, N, N, N),), False)
+    torch._C._jit_pass_peephole(g, False)
+    torch._C._jit_pass_constant_propagation(g)
+    torch._C._jit_pass_dce(g)
+    L = blob.lines
+    inputs = list(g.inputs())
+    x_in = inputs[-1]
+    b_in = blob.buf(N, C0)
+    # tensor value -> dict(buf, c0, C, S, kind, node) ; kind: "grid" | "act" | "flat" | "pose" | "aff"
+    T = {x_in.debugName(): dict(buf=b_in, c0=0, C=C0, S=N, kind="grid")}
+    nodes = list(g.nodes())
+    uses = {}
+    for nd in nodes:
+        for i in nd.inputs():
+            uses.setdefault(i.debugName(), []).append(nd)
+
+    # concat groups: a tensor that is the FIRST member of cats gets a buffer wide enough for the longest of them
+    cat_total = {}   # first member name -> total channels (filled lazily once channel counts are known)
+    cat_members = {}  # member name -> (first member name, index in the longest list)
+    longest = {}
+    for nd in nodes:
+        if nd.kind() == "aten::cat":
+            lst = nd.inputsAt(0).node()
+            if lst.kind() != "prim::ListConstruct" or int(_const(nd.inputsAt(1))) != 1:
+                raise ValueError("cat: only lists of tensors along the channel dimension")
+            names = [i.debugName() for i in lst.inputs()]
+            first = names[0]
+            if first not in longest or len(names) > len(longest[first]):
+                if first in longest and longest[first] != names[:len(longest[first])]:
+                    raise ValueError("cat: lists starting at one tensor must extend one another")
+                longest[first] = names
+            elif names != longest[first][:len(names)]:
+                raise ValueError("cat: lists starting at one tensor must extend one another")
+    for first, names in longest.items():
+        for k, n in enumerate(names):
+            cat_members[n] = (first, k)
+
+    pending_bn = {}  # tensor name (BN output) -> (source descriptor, scale, shift)
+    conv_lines = {}  # conv output name -> index into L (to set its relu flag) and folded-BN bookkeeping
+    out_pose = out_aff = None
+    head = {}
+    log_softmax_seen = False
+
+    def conv_out_channels(nd):
+        return nd.inputsAt(1).toIValue().shape[0]
+
+    def channels_of(name, seen=None):
+        """channels of a tensor that may not have been produced yet (needed to size a concat buffer up front)"""
+        if name in T:
+            return T[name]["C"]
+        for nd in nodes:
+            for o in nd.outputs():
+                if o.debugName() == name:
+                    k = nd.kind()
+                    if k in ("aten::_convolution", "aten::conv3d"):
+                        return conv_out_channels(nd)
+                    if k in ("aten::relu", "aten::relu_", "aten::batch_norm", "aten::max_pool3d", "aten::avg_pool3d"):
+                        return channels_of(nd.inputsAt(0).debugName())
+                    if k == "aten::cat":
+                        return sum(channels_of(i.debugName()) for i in nd.inputsAt(0).node().inputs())
+        raise ValueError(f"cannot size tensor {name}")
+
+    def place_output(name, C, S):
+        """(buf, c0) where a freshly produced [C] x S^3 tensor must live: inside its concat buffer, or a buffer of its own"""
+        if name in cat_members:
+            first, k = cat_members[name]
+            names = longest[first]
+            if k == 0:
+                total = sum(channels_of(n) for n in names)
+                return blob.buf(S, total), 0
+            base = T[first]
+            c0 = sum(T[n]["C"] for n in names[:k])
+            if base["S"] != S:
+                raise ValueError("cat: members of different grid sizes")
+            return base["buf"], c0
+        return blob.buf(S, C), 0
+
+    for nd in nodes:
+        k = nd.kind()
+        outs = [o.debugName() for o in nd.outputs()]
+        if k in ("prim::Constant", "prim::ListConstruct"):
+            continue
+        if k in ("aten::max_pool3d", "aten::avg_pool3d"):
+            src = T[nd.inputsAt(0).debugName()]
+            ks, st = _ints(nd.inputsAt(1)), _ints(nd.inputsAt(2))
+            st = st or ks
+            pad = _ints(nd.inputsAt(3))
+            if any(pad) or len(set(ks)) != 1 or ks != st:
+                raise ValueError(f"{k}: kernel = stride, no padding, cubic")
+            mode = "max" if k == "aten::max_pool3d" else "avg"
+            if ks[0] == 2:
+                S = src["S"] // 2
+                buf, c0 = place_output(outs[0], src["C"], S)
+                if c0 != 0 or src["c0"] != 0:
+                    raise ValueError("pool: operands must start at channel 0 of their buffers")
+                L.append(f"pool {mode} {src['buf']} {buf}")
+                T[outs[0]] = dict(buf=buf, c0=0, C=src["C"], S=S, kind="act")
+            elif ks[0] == src["S"] and mode == "max":
+                buf = blob.buf(1, src["C"])
+                L.append(f"gmax {src['buf']} {buf}")
+                T[outs[0]] = dict(buf=buf, c0=0, C=src["C"], S=1, kind="act")
+            else:
+                raise ValueError(f"{k} with kernel {ks} on a grid of {src['S']}")
+        elif k == "aten::adaptive_max_pool3d":
+            src = T[nd.inputsAt(0).debugName()]
+            if _ints(nd.inputsAt(1)) != [1, 1, 1]:
+                raise ValueError("adaptive_max_pool3d: output size 1 only")
+            buf = blob.buf(1, src["C"])
+            L.append(f"gmax {src['buf']} {buf}")
+            T[outs[0]] = dict(buf=buf, c0=0, C=src["C"], S=1, kind="act")
+        elif k == "aten::batch_norm":
+            src_name = nd.inputsAt(0).debugName()
+            w, b, mean, var = (nd.inputsAt(i).toIValue() for i in (1, 2, 3, 4))
+            training, eps = bool(_const(nd.inputsAt(5))), float(_const(nd.inputsAt(7)))
+            if training:
+                raise ValueError("batch_norm in training mode")
+            alpha = (w.float() if w is not None else torch.ones_like(var.float())) / torch.sqrt(var.float() + eps)
+            shift = (b.float() if b is not None else torch.zeros_like(var.float())) - mean.float() * alpha
+            if src_name in conv_lines and len(uses.get(src_name, [])) == 1:  # conv -> BN: fold into the conv
+                conv_lines[src_name]["fold"] = (alpha, shift)
+                T[outs[0]] = T[src_name]
+                conv_lines[outs[0]] = conv_lines[src_name]
+            else:  # BN -> conv: the conv's input scale / shift
+                pending_bn[outs[0]] = (T[src_name], alpha, shift)
+        elif k in ("aten::_convolution", "aten::conv3d"):
+            in_name = nd.inputsAt(0).debugName()
+            bn = pending_bn.get(in_name)
+            src = bn[0] if bn else T[in_name]
+            w = nd.inputsAt(1).toIValue()
+            bias = nd.inputsAt(2).toIValue()
+            stride, padding, dilation = _ints(nd.inputsAt(3)), _ints(nd.inputsAt(4)), _ints(nd.inputsAt(5))
+            if k == "aten::_convolution":
+                transposed, groups = bool(_const(nd.inputsAt(6))), int(_const(nd.inputsAt(8)))
+            else:
+                transposed, groups = False, int(_const(nd.inputsAt(6)))
+            co, ci, kk = w.shape[0], w.shape[1], w.shape[2]
+            if (transposed or groups != 1 or set(stride) != {1} or set(dilation) != {1} or kk not in (1, 3) or
+                    tuple(w.shape[2:]) != (kk, kk, kk) or set(padding) != {kk // 2}):
+                raise ValueError("convolution: kernel 1 or 3, stride 1, 'same' padding, no groups / dilation / transposition")
+            if src["c0"] != 0 or ci != src["C"]:
+                raise ValueError("convolution: the input must be channels [0, C) of its buffer")
+            # where the result lives is decided by the tensor the rest of the graph sees: the convolution's output, or what a
+            # BatchNorm / ReLU that are its only consumers make of it
+            final = outs[0]
+            while len(uses.get(final, [])) == 1 and uses[final][0].kind() in ("aten::batch_norm", "aten::relu", "aten::relu_"):
+                final = uses[final][0].output().debugName()
+            buf, c0 = place_output(final, co, src["S"])
+            conv_lines[outs[0]] = dict(w=w.double(), b=(bias.double() if bias is not None else torch.zeros(co, dtype=torch.float64)),
+                                       src=src["buf"], dst=buf, c0=c0, relu=False, bn=(bn[1], bn[2]) if bn else None, k=kk,
+                                       line=len(L))
+            L.append(None)  # written once relu / a folded BatchNorm behind it are known
+            T[outs[0]] = dict(buf=buf, c0=c0, C=co, S=src["S"], kind="act")
+        elif k in ("aten::relu", "aten::relu_"):
+            in_name = nd.inputsAt(0).debugName()
+            if in_name not in conv_lines or len(uses.get(in_name, [])) != 1:
+                raise ValueError("relu: only directly behind a convolution (or its folded BatchNorm)")
+            conv_lines[in_name]["relu"] = True
+            if in_name in cat_members:
+                raise ValueError("cat of a pre-activation tensor")
+            T[outs[0]] = T[in_name]
+            conv_lines[outs[0]] = conv_lines[in_name]
+        elif k == "aten::cat":
+            names = [i.debugName() for i in nd.inputsAt(0).node().inputs()]
+            first = T[names[0]]
+            if first["c0"] != 0:
+                raise ValueError("cat: the first member must start its buffer")
+            c = 0
+            for n in names:
+                if T[n]["buf"] != first["buf"] or T[n]["c0"] != c:
+                    raise ValueError("cat: members are not consecutive channel ranges of one buffer")
+                c += T[n]["C"]
+            T[outs[0]] = dict(buf=first["buf"], c0=0, C=c, S=first["S"], kind="act")
+        elif k in ("aten::view", "aten::reshape", "aten::flatten"):
+            src = T[nd.inputsAt(0).debugName()]
+            if src["c0"] != 0:
+                raise ValueError("flatten: of a whole buffer only")
+            T[outs[0]] = dict(src, kind="flat")
+        elif k == "aten::linear":
+            src = T[nd.inputsAt(0).debugName()]
+            if src["kind"] != "flat":
+                raise ValueError("linear: on the flattened features only")
+            w, b = nd.inputsAt(1).toIValue(), nd.inputsAt(2).toIValue()
+            role = "pose" if w.shape[0] == 2 else "aff" if w.shape[0] == 1 else None
+            if role is None or role in head or w.shape[1] != src["C"] * src["S"] ** 3:
+                raise ValueError("linear: one head with 2 outputs (pose) and one with 1 (affinity) on the same features")
+            head[role] = (w, b if b is not None else torch.zeros(w.shape[0]), src)
+            T[outs[0]] = dict(buf=-1, c0=0, C=w.shape[0], S=0, kind=role)
+        elif k in ("aten::log_softmax", "aten::squeeze", "aten::unsqueeze", "aten::dropout", "aten::contiguous"):
+            src = T[nd.inputsAt(0).debugName()]
+            if k == "aten::log_softmax":
+                if src["kind"] != "pose":
+                    raise ValueError("log_softmax: on the pose head only")
+                log_softmax_seen = True
+            T[outs[0]] = src
+        elif k == "prim::TupleConstruct":
+            a, b = (T[i.debugName()] for i in nd.inputs())
+            if a["kind"] != "pose" or b["kind"] != "aff":
+                raise ValueError("the module must return (pose logits [B, 2], affinity [B])")
+            out_pose, out_aff = a, b
+        else:
+            raise ValueError(f"unsupported operator {k} in the model's graph")
+    if out_pose is None or set(head) != {"pose", "aff"} or head["pose"][2] is not head["aff"][2] and head["pose"][2] != head["aff"][2]:
+        raise ValueError("the module must return (pose logits [B, 2], affinity [B]) from two linear heads on the same features")
+    # the convolutions, now that relu flags and folded BatchNorms are known
+    done = set()
+    for name, cl in conv_lines.items():
+        if cl["line"] in done:
+            continue
+        done.add(cl["line"])
+        w, b = cl["w"], cl["b"]
+        if "fold" in cl:  # conv -> BN: W' = alpha[co] W, b' = alpha b + shift
+            alpha, shift = cl["fold"]
+            w = w * alpha.double().view(-1, 1, 1, 1, 1)
+            b = b * alpha.double() + shift.double()
+        co, ci, kk = w.shape[0], w.shape[1], cl["k"]
+        wt = w.permute(2, 3, 4, 1, 0).reshape(kk ** 3, ci, co).float().numpy()
+        w_off = blob.add(wt)
+        b_off = blob.add(b.float().numpy())
+        s_off = t_off = -1
+        if cl["bn"] is not None:
+            s_off = blob.add(cl["bn"][0].numpy())
+            t_off = blob.add(cl["bn"][1].numpy())
+        L[cl["line"]] = f"conv {kk} {cl['src']} {cl['dst']} {ci} {co} {cl['c0']} {int(cl['relu'])} {w_off} {b_off} {s_off} {t_off}"
+    wp, bp, src = head["pose"]
+    wa, ba, _ = head["aff"]
+    S, C = src["S"], src["C"]
+    w = torch.cat([wp, wa], 0).reshape(3, C, S * S * S).permute(0, 2, 1).contiguous()
+    w_off = blob.add(w.float().numpy())
+    b_off = blob.add(torch.cat([bp.float().reshape(-1), ba.float().reshape(-1)]).numpy())
+    L.append(f"fc {src['buf']} {S * S * S * C} {w_off} {b_off}")
+    return log_softmax_seen
+
+
+def convert(pt_path, name=None, generic=False):
     extra = {"metadata": ""}
     m = torch.jit.load(pt_path, map_location="cpu", _extra_files=extra)
     md = extra["metadata"]
@@ -163,7 +429,16 @@ def convert(pt_path, name=None):
     S = N // 2
 
     keys = list(sd.keys())
-    if any(k.endswith("unit1_conv1.weight") for k in keys):  # Default2017Affinity
+    if generic:
+        keys = ["<generic>"]
+    if generic or not (any(k.endswith(("unit1_conv1.weight", "unit1_conv.weight")) for k in keys) or
+                       any("dense_block_0" in k for k in keys) or (family == "Overlap" and not keys)):
+        # an architecture this file has no hand-written path for (`--cnn_model file.pt`): walk its graph
+        blob.lines.append("generic 1")
+        log_softmax = convert_graph(m, blob, C0, N)
+        if bool(meta.get("skip_softmax", False)) and not log_softmax:
+            raise ValueError("skip_softmax on a module that returns raw logits is not supported")
+    elif any(k.endswith("unit1_conv1.weight") for k in keys):  # Default2017Affinity
         p = "features."
         assert sd[p + "unit1_conv1.weight"].shape[1] == C0
         b_in = blob.buf(N, C0)
@@ -230,6 +505,12 @@ def convert(pt_path, name=None):
 
 
 def main(argv):
+    if len(argv) >= 2 and argv[0] == "--generic":  # force the graph walk (also for the shipped families: a self-check)
+        data, name = convert(argv[1], generic=True)
+        out = argv[2] if len(argv) > 2 else name + ".mgw"
+        open(out, "wb").write(data)
+        print("wrote", out, len(data), "bytes")
+        return
     if len(argv) >= 3 and argv[0] == "--all":
         os.makedirs(argv[2], exist_ok=True)
         for f in sorted(os.listdir(argv[1])):

@@ -73,8 +73,11 @@ const char *mi_last_error(void);
 
 /* ---- models -------------------------------------------------------------------------------
  * Replaces TorchModel<isCUDA>::TorchModel(std::istream&, name, log) (gninasrc/lib/torch_model.h:32,
- * torch_model.cpp:49-118): `blob` is a MIGNINA1 weight blob (gnina_amd/tools/extract_weights.py
- * output for one .pt of gninasrc/lib/models/).  Returns NULL on failure (see mi_last_error). */
+ * torch_model.cpp:49-118): `blob` is a MIGNINA1 weight blob -- gnina_amd/tools/extract_weights.py's output for one .pt of
+ * gninasrc/lib/models/, or for a user's `--cnn_model file.pt` of another architecture: any TorchScript module whose graph
+ * is a feed-forward stack of 2x2x2 / global pools, 1x1x1 / 3x3x3 "same" convolutions, ReLU, eval BatchNorm, channel
+ * concatenation and two linear heads is written as the same layer program (the tool names the first operator outside that
+ * set; tests/test_extract_generic_cpu.py, tests/test_gpu_custom_model.py).  Returns NULL on failure (see mi_last_error). */
 mi_model *mi_model_load(const void *blob, size_t nbytes, const char *name);
 mi_model *mi_model_load_file(const char *path);
 /* The same weights on another grid: "resolution" / "dimension" as the metadata of a user-supplied model
