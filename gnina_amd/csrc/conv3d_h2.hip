@@ -773,9 +773,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
     if constexpr (INSPLIT) {
       const unsigned long long a = (unsigned long long)(in_b + (size_t)tp * pose_floats);
       h2_i32x4 rs;
-      rs.x = (int)(a & 0xffffffffull), rs.y = (int)((a >> 32) & 0xffffull), rs.z = (int)(pose_floats * 4), rs.w = 0x00020000;
+      // (wave-uniform by construction; readfirstlane makes that a fact for the "s" constraint of the asm below -- without it a
+      // shift in register pressure once put the descriptor in VGPRs, which the instruction does not take)
+      rs.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull)), rs.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
+      rs.z = __builtin_amdgcn_readfirstlane((int)(pose_floats * 4)), rs.w = 0x00020000;
       const unsigned junk = (unsigned)(size_t)(s_live + p.nchunks * 4);
-      const int soff = chunk * octet_bytes;
+      const int soff = __builtin_amdgcn_readfirstlane(chunk * octet_bytes);
 #pragma unroll
       for (int i = 0; i < (NS + 1) / 2; i++)
         if ((i * NW + wave) * 64 < PL) {

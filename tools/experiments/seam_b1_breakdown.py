@@ -3,7 +3,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from gnina_amd import capi, synth
 capi.init(0)
-for name in ("default2017",):
+import sys as _s
+for name in (_s.argv[1:] or ["default2017"]):
     m = capi.Model(name); s = capi.Scorer([m])
     rng = np.random.RandomState(0)
     rec_xyz, rec_smt = synth.make_receptor(rng, 2500, synth.mapped_types(m.chan_of_smt(False)))
