@@ -79,7 +79,7 @@ struct VoxArgs {
   // split mode: occupancy bytes for the first convolution's zero skipping, [pose][tiles_per_axis]^3[8] -- byte w of a tile
   // (= a 4 x 4 x 4-cell block of the pooled grid) is non-zero iff window (octet) w of the tile holds a non-zero value
   unsigned char *occ;
-  // timing experiments only (MI_VOX_DBG; wrong results): 1 = hits are found but not evaluated, 2 = flushes do no transpose /
+  // timing experiments only (MI_VOX_DBG in a -DMI_VOX_TIMING build; wrong results): 1 = hits are found but not evaluated, 2 = flushes do no transpose /
   // pooling / staging, 4 = windows are not stored, 8 = no hit test (no hits)
   int dbg;
 };

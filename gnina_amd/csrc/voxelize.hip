@@ -241,24 +241,28 @@ __device__ __forceinline__ float div_rn(float a, float b, float y) {
 // adding +0 give the same bits (the accumulators are sums of non-negative terms and start at +0).
 __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
                                             float qa, float qb, float qc) {
+  // (round 5: straight-line inside the support test.  The kernel issues MORE scalar than vector instructions -- the
+  // exec-mask bookkeeping of nested zone branches was 15 SALU instructions per evaluated sub-block next to 13 VALU -- and a
+  // sub-block that an atom reaches almost always has lanes in both zones, so both sides ran anyway.  What is left: the
+  // support test and the thin-shell redo.  Same operations per lane, same bits: a lane whose tail value is <= 0 adds +0.)
   if (rsq < t2) {
-    if (rsq <= g2) {
-      acc = acc + __builtin_amdgcn_exp2f(rsq * kexp);
-    } else {
-      float dr = __builtin_amdgcn_sqrtf(rsq) * inv_ar;
-      float q = (qa * dr + qb) * dr + qc;
-      if (q < 4e-6f) {
-        // thin shell next to the 1.5 r cut-off, where the tail is ~1e-7 and its SIGN decides whether
-        // the voxel is non-zero: redo it with the reference's exact operation sequence
-        // (correctly rounded sqrtf and divide, unfused polynomial) so the support set is bit-exact.
-        // (sqrt_rn / div_rn: the same correctly rounded results in 14 instructions instead of the 28 of the generic
-        // sequences, which also handle denormals and scale their inputs -- rsq is 1..12 A^2 here.  Checked exhaustively
-        // against sqrtf and '/' for every float in [0.25, 64) x 414 radii: tools/microbench/exact_sqrt_div_check.hip)
-        float dre = div_rn(sqrt_rn(rsq), ar, inv_ar);
-        q = (qa * dre + qb) * dre + qc;
-      }
-      if (q > 0.f) acc = acc + q;
+    const bool gauss = rsq <= g2;
+    const float gv = __builtin_amdgcn_exp2f(rsq * kexp);
+    float dr = __builtin_amdgcn_sqrtf(rsq) * inv_ar;
+    float q = (qa * dr + qb) * dr + qc;
+    if (!gauss && q < 4e-6f) {
+      // thin shell next to the 1.5 r cut-off, where the tail is ~1e-7 and its SIGN decides whether
+      // the voxel is non-zero: redo it with the reference's exact operation sequence
+      // (correctly rounded sqrtf and divide, unfused polynomial) so the support set is bit-exact.
+      // (sqrt_rn / div_rn: the same correctly rounded results in 14 instructions instead of the 28 of the generic
+      // sequences, which also handle denormals and scale their inputs -- rsq is 1..12 A^2 here.  Checked exhaustively
+      // against sqrtf and '/' for every float in [0.25, 64) x 414 radii: tools/microbench/exact_sqrt_div_check.hip)
+      float dre = div_rn(sqrt_rn(rsq), ar, inv_ar);
+      q = (qa * dre + qb) * dre + qc;
     }
+    float qp;
+    asm("v_max_f32 %0, 0, %1" : "=v"(qp) : "v"(q));  // (q is never a NaN: no canonicalising v_max in front)
+    acc = acc + (gauss ? gv : qp);
   }
 }
 
@@ -275,6 +279,15 @@ __device__ __forceinline__ unsigned vox_split1(float x) {
   const vox_f32x2 b = {x, r};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(b, vox_f16x2));
 }
+
+// The MI_VOX_DBG timing switches (wrong results; DESIGN 3.10's breakdown) exist only in a build with -DMI_VOX_TIMING: the
+// tile kernel is bound by its scalar instruction count, and four tests of a kernel argument per hit / flush / window are
+// part of it.
+#ifdef MI_VOX_TIMING
+#define VOX_DBG(bit) (v.dbg & (bit))
+#else
+#define VOX_DBG(bit) false
+#endif
 
 // MODE 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last.  SPLIT (pooled modes): VoxArgs::split.
 template <int MODE, bool SPLIT = false>
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   int cur_w = 0;
   // window cur_w of the staged tile -> out[b][cx][cy][cz][cur_w * kWin ...]: 64 cells x kWin / 4 float4, then cleared
   auto emit_window = [&]() {
-    if (v.dbg & 4) {  // (timing only)
+    if (VOX_DBG(4)) {  // (timing only)
       cur_w++;
       return;
     }
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
           }
       return;
     }
-    if (v.dbg & 2) {  // (timing only)
+    if (VOX_DBG(2)) {  // (timing only)
       while (cur_w < c / kWin) emit_window();
       return;
     }
@@ -508,27 +521,26 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       float ddz = fmaxf(0.f, fmaxf(tloz - a.z, a.z - thiz));
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
       hit = d2 <= a.t2 * 1.0001f + 1e-4f;  // conservative superset of "some voxel has rsq < t2"
-      if (v.dbg & 8) hit = false;  // (timing only)
+      if (VOX_DBG(8)) hit = false;  // (timing only)
     }
     unsigned long long mask = __ballot(hit);
     // the record of a hit comes back through the scalar cache, the next hit's record is requested before this one is
     // evaluated
     f32x8 rec_n = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
     int c_n = -1;
-    if (mask) {
-      const int src = __builtin_ctzll(mask);
-      rec_n = candc[base + src];
-      c_n = chanc[base + src];
-    }
+    // (byte offsets in 32 bits: s_load with an SGPR offset instead of two 64-bit shift-and-add sequences per hit)
+    typedef const __attribute__((address_space(4))) char *ConstBytePtr;
+    auto fetch = [&](int src) {
+      const unsigned i = (unsigned)(base + src);
+      rec_n = *(ConstRecPtr)((ConstBytePtr)candc + (i << 5));
+      c_n = *(ConstIntPtr)((ConstBytePtr)chanc + (i << 2));
+    };
+    if (mask) fetch(__builtin_ctzll(mask));
     while (mask) {
       mask &= mask - 1;
       const f32x8 rec = rec_n;
       const int c = c_n;
-      if (mask) {
-        const int src = __builtin_ctzll(mask);
-        rec_n = candc[base + src];
-        c_n = chanc[base + src];
-      }
+      if (mask) fetch(__builtin_ctzll(mask));
       const float ax = rec[0], ay = rec[1], az = rec[2], ar = rec[3], t2 = rec[4], g2 = rec[5], kexp = rec[6],
                   inv_ar = rec[7];
       if (c != cur) {
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0.f;
       }
-      if (v.dbg & 1) continue;  // (timing only)
+      if (VOX_DBG(1)) continue;  // (timing only)
       // squared distances of this lane's eight voxels, two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations
       // as the scalar forms, in the same order -- (dx^2 + dy^2) + dz^2 -- at half the instruction count; the kernel's time
       // is its VALU instruction count)
