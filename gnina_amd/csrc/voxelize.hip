@@ -245,9 +245,20 @@ __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, flo
   // exec-mask bookkeeping of nested zone branches was 15 SALU instructions per evaluated sub-block next to 13 VALU -- and a
   // sub-block that an atom reaches almost always has lanes in both zones, so both sides ran anyway.  What is left: the
   // support test and the thin-shell redo.  Same operations per lane, same bits: a lane whose tail value is <= 0 adds +0.)
+  // (a sub-block nobody reaches -- five of eight -- costs v_cmp + s_cbranch_vccz this way; "if (rsq < t2)" alone compiles to
+  // s_and_saveexec, s_cbranch_execz and an s_or at the join)
+  if (__builtin_amdgcn_ballot_w64(rsq < t2) == 0ull) return;
+  asm volatile("");
   if (rsq < t2) {
     const bool gauss = rsq <= g2;
-    const float gv = __builtin_amdgcn_exp2f(rsq * kexp);
+    // (the exponential only where a lane of the sub-block is in the Gaussian zone -- the shell between r and 1.5 r is 70 %
+    // of an atom's support, and v_exp_f32 is a quarter-rate instruction; the empty asm keeps the compiler from turning
+    // the wave-uniform branch back into a select)
+    float gv = 0.f;
+    if (__builtin_amdgcn_ballot_w64(gauss) != 0ull) {
+      gv = __builtin_amdgcn_exp2f(rsq * kexp);
+      asm volatile("" : "+v"(gv));
+    }
     float dr = __builtin_amdgcn_sqrtf(rsq) * inv_ar;
     float q = (qa * dr + qb) * dr + qc;
     if (!gauss && q < 4e-6f) {
@@ -259,10 +270,10 @@ __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, flo
       // against sqrtf and '/' for every float in [0.25, 64) x 414 radii: tools/microbench/exact_sqrt_div_check.hip)
       float dre = div_rn(sqrt_rn(rsq), ar, inv_ar);
       q = (qa * dre + qb) * dre + qc;
+      // (only here can the value be <= 0 -- everywhere else it is >= 4e-6: the reference's "if (q > 0)" as a clamp, +0 added)
+      asm("v_max_f32 %0, 0, %0" : "+v"(q));
     }
-    float qp;
-    asm("v_max_f32 %0, 0, %1" : "=v"(qp) : "v"(q));  // (q is never a NaN: no canonicalising v_max in front)
-    acc = acc + (gauss ? gv : qp);
+    acc = acc + (gauss ? gv : q);
   }
 }
 
