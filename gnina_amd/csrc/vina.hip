@@ -2365,6 +2365,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_MC_TP_WAV
 //   phase 3    : last container insert, emit
 // Chain state between launches lives in global memory (st_f / st_i).
 // ---------------------------------------------------------------------------------------------
+template <bool ACC>  // (accurate_line_search / simple ascent: their own instantiation, like vina_mc_kernel's)
 __global__ __launch_bounds__(64) void vina_mc_cnn_kernel(VinaEnv env, VinaLigand L, VinaMcArgs a, VinaMcCnnState st) {
   constexpr int HR = kHRegTp, PG = kPairGroupTp;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2419,7 +2420,7 @@ __global__ __launch_bounds__(64) void vina_mc_cnn_kernel(VinaEnv env, VinaLigand
       if (tmp_e < best_e || n_out < a.num_saved) {  // refine with the full caps on the Vina grids (monte_carlo.cpp:128-131)
         for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
         wave_sync();
-        (void)bfgs_wave<HR, PG>(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals, tm, nullptr);
+        (void)bfgs_wave<HR, PG, ACC>(env, L, w, k, a.auth[0], a.auth[1], a.auth[2], a.max_iters, evals, tm, nullptr);
         for (int i = lane; i < nc; i += 64) tmp[i] = k.x[i], mconf[i] = k.x_new[i];
         flag = 3;
       }
@@ -2445,7 +2446,7 @@ __global__ __launch_bounds__(64) void vina_mc_cnn_kernel(VinaEnv env, VinaLigand
       for (int i = lane; i < nc; i += 64) k.x[i] = tmp[i];
       wave_sync();
       mutate_wave<PG>(env, L, w, rng, k.x, mconf, a.amplitude);
-      (void)bfgs_wave<HR, PG>(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals, tm, nullptr);
+      (void)bfgs_wave<HR, PG, ACC>(env, L, w, k, a.hunt[0], a.hunt[1], a.hunt[2], a.max_iters, evals, tm, nullptr);
       for (int i = lane; i < nc; i += 64) sf[nc + i] = k.x[i], mconf[i] = k.x_new[i];
       wave_sync();
     }
@@ -2482,8 +2483,13 @@ void launch_vina_mc_cnn(const VinaEnv &env0, const VinaLigand &lig, const VinaMc
   a.conf_stride = 7 + lig.n_nodes - 1;
   a.coord_stride = 3 * lig.n_heavy;
   const size_t lds = vina_mc_lds_bytes(lig.n_atoms, lig.n_nodes, lig.n_pairs, lig.n_heavy, a.num_saved, env.stage, 1);
-  big_lds(vina_mc_cnn_kernel);
-  hipLaunchKernelGGL(vina_mc_cnn_kernel, dim3(B), dim3(64), lds, s, env, lig, a, st);
+  if (env.accurate_ls) {  // --accurate_line_search / --simple_ascent
+    big_lds(vina_mc_cnn_kernel<true>);
+    hipLaunchKernelGGL(vina_mc_cnn_kernel<true>, dim3(B), dim3(64), lds, s, env, lig, a, st);
+  } else {
+    big_lds(vina_mc_cnn_kernel<false>);
+    hipLaunchKernelGGL(vina_mc_cnn_kernel<false>, dim3(B), dim3(64), lds, s, env, lig, a, st);
+  }
 }
 
 // Waves per chain: a single docking job (few chains) is bound by the latency of dependent evaluations, so

@@ -1555,7 +1555,6 @@ mi_status mi_vina_mc_cnn_batch(mi_vina *vv, mi_scorer *sc, int B, const uint64_t
   MIG_CHECK(box->cnn_dimension > 0, 1, "box->cnn_dimension must be the CNN grid dimension");
   Vina &v = *reinterpret_cast<Vina *>(vv);
   MIG_CHECK(v.have_cache && v.have_lig, 4, "build the cache and set the ligand first");
-  MIG_CHECK(!v.accurate_ls, 1, "the device CNN Monte-Carlo chains run fast_line_search only (see mi_vina_set_line_search)");
   MIG_CHECK(P->num_saved > 0 && P->num_saved <= 64 && P->n_steps >= 1 && P->max_iters >= 0 && P->temperature > 0, 1,
             "bad Monte-Carlo parameters (num_saved must be in [1, 64], n_steps >= 1)");
   if (B == 0) return MI_OK;

@@ -313,8 +313,7 @@ enum { MI_VINA_APPROX_LINEAR = 0, MI_VINA_APPROX_SPLINE = 1 };
  * Recipes' lnsrch) instead of fast_line_search; 0 (default) returns to the fast one.  kind 2 = --simple_ascent
  * (minimization_params::Simple, quasi_newton.cpp:77-79): simple_gradient_ascent (bfgs.h:234-355), steepest descent under
  * the accurate line search with no quasi-Newton update.  (The enum's fourth value, ConjugateGradient, has no
- * implementation in the reference either: quasi_newton.cpp runs bfgs<> for it.)  mi_vina_mc_cnn_batch's device
- * chains support the fast search only. */
+ * implementation in the reference either: quasi_newton.cpp runs bfgs<> for it.) */
 mi_status mi_vina_set_line_search(mi_vina *, int kind);
 /* Strict summation order (on = 1): every energy sum of this handle's evaluations -- cache::eval / eval_deriv over the
  * atoms (cache.cpp:52-83), non_cache over the receptor atoms (non_cache.cpp:52-83,125-179), the interacting pairs

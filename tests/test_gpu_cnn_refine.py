@@ -209,6 +209,43 @@ def test_monte_carlo_with_the_cnn_as_metropolis_energy(setup):
     assert not np.array_equal(cfA[:, 0], cfV[:, 0])                                  # the CNN accepts differently
 
 
+@pytest.mark.parametrize("kind", [1, 2])
+def test_cnn_metropolis_chains_under_the_accurate_line_search(setup, kind):
+    """--accurate_line_search / --simple_ascent with --cnn_scoring metrorescore (minimization_params, bfgs.h:104-180,234-355;
+    parallel_mc.cpp:145-155): the device chains of mi_vina_mc_cnn_batch run the handle's line search like every other
+    minimiser of the handle.  One step: the first candidate is always accepted, so conformation, coordinates and
+    evaluation counts are bit-identical to the plain Vina chain under the same search; they differ from the fast
+    search's; longer chains are deterministic."""
+    capi, sc, lig, v, olig = setup
+    s = capi.Scorer(["crossdock_default2018"])
+    s.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    gd = ovina.setup_grid_dims(sc["center"], sc["size"])
+    types = sorted(set(int(t) for t in lig["smt"] if t > 1))
+    v.set_receptor(sc["rec_xyz"], sc["rec_smt"])
+    v.build_cache(list(gd.begin), list(gd.end), list(gd.n), types, 1e3)
+    box = capi.CnnBox.make(23.5, list(gd.begin), list(gd.end), slope=1e3)
+    seeds = np.arange(11, 11 + 16, dtype=np.uint64)
+    iters = (25 + len(lig["smt"])) // 3
+    P1 = capi.McParams.default(1, iters, 10)
+    lo, hi = list(gd.begin), list(gd.end)
+    nf, ef, cff, _, evf, _ = v.mc_cnn_batch(s, seeds, lo, hi, P1, box)
+    try:
+        v.set_line_search(True, simple=(kind == 2))
+        n0, e0, cf0, xyz0, ev0 = v.mc_batch(seeds, lo, hi, P1)
+        n1, e1, cf1, xyz1, ev1, cnn1 = v.mc_cnn_batch(s, seeds, lo, hi, P1, box)
+        assert (n0 == 1).all() and (n1 == 1).all() and cnn1 == 2 * len(seeds)
+        assert np.array_equal(cf0[:, 0], cf1[:, 0]) and np.array_equal(xyz0[:, 0], xyz1[:, 0]) and np.array_equal(ev0, ev1)
+        assert not np.array_equal(cf1[:, 0], cff[:, 0]) and not np.array_equal(ev1, evf)   # not the fast search's chains
+        P = capi.McParams.default(12, iters, 10)
+        nA, eA, cfA, _, evA, cnnA = v.mc_cnn_batch(s, seeds[:6], lo, hi, P, box)
+        nB, eB, cfB, _, evB, _ = v.mc_cnn_batch(s, seeds[:6], lo, hi, P, box)
+        assert cnnA == 2 * 12 * 6 and (nA >= 1).all()
+        assert np.array_equal(eA, eB) and np.array_equal(cfA, cfB) and np.array_equal(evA, evB)
+        assert all(np.all(np.diff(eA[b, :nA[b]]) >= 0) for b in range(6))
+    finally:
+        v.set_line_search(False)
+
+
 @pytest.mark.parametrize("mix_force", [False, True])
 def test_cnn_eval_deriv_with_a_user_grid(setup, mix_force):
     """--user_grid in non_cache_cnn::eval_deriv (non_cache_cnn.cpp:141-151): per heavy atom, curled on its own, also
