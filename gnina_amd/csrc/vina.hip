@@ -815,10 +815,11 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
   float e_part = 0.f;
   // strict mode (seq_add): the receptor term, the other_pairs sum, the ligand-pair sum and model::eval's user-grid
   // term, each accumulated in the reference's order, wave-uniform
-  // (eval_intramolecular of a model with flexible residues keeps the butterfly: model.cu:352-399 adds the flex-rigid
-  // terms and the flex-flex pairs one by one onto the ligand's pair sum)
-  const bool strict = env.strict != 0 && !(MODE == 4 && L.lig_end > L.lig_begin && L.pair_cap != nullptr);
-  float s_rec = 0.f, s_p1 = 0.f, s_p0 = 0.f;
+  // (eval_intramolecular of a model with flexible residues -- flex4 -- adds the flex-rigid terms and then the flex-flex
+  // pairs one by one onto the ligand's pair sum, model.cu:352-399: e_run below)
+  const bool strict = env.strict != 0;
+  const bool flex4 = MODE == 4 && L.lig_end > L.lig_begin && L.pair_cap != nullptr;
+  float s_rec = 0.f, s_p1 = 0.f, s_p0 = 0.f, e_run = 0.f;
   GridTap tap[kTapIt];
   bool tap_on[kTapIt];
   auto place_atom = [&](int i, float &cx, float &cy, float &cz) {
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
         }
         if (strict) {  // pairs in list order, other_pairs and the ligand's own summed apart (model.cu:206-216)
           const bool oth = (other >> u) & 1;
-          if (L.pair_cap) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in[u] && oth));
+          if (L.pair_cap && !flex4) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in[u] && oth));
           seq_add(s_p0, pe, __builtin_amdgcn_ballot_w64(in[u] && !oth));
         } else {
           e_part += pe;
@@ -1086,7 +1087,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       }
     }
     if (strict) {
-      if (L.pair_cap) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in && oth));
+      if (L.pair_cap && !flex4) seq_add(s_p1, pe, __builtin_amdgcn_ballot_w64(in && oth));
       seq_add(s_p0, pe, __builtin_amdgcn_ballot_w64(in && !oth));
     } else {
       e_part += pe;
@@ -1097,7 +1098,50 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
       w.cx[sl.y] = out.x, w.cy[sl.y] = out.y, w.cz[sl.y] = out.z;
     }
   }
-  if (MODE == 4 && has_flex && env.rec) {
+  if (MODE == 4 && has_flex && strict) {
+    // strict order: e = 0 + the ligand's pair sum; then every flex-rigid term in (atom, receptor atom) order; then every
+    // flex-flex pair of other_pairs in list order -- one running sum, as model.cu:352-399 adds them
+    e_run = 0.f + rl(s_p0, 0);
+    for (int i = 0; env.rec && i < L.n_movable; i++) {
+      if (i >= L.lig_begin && i < L.lig_end) continue;
+      const int t1 = L.smt[i];
+      if (t1 <= 1) continue;
+      const float ax = w.coords[3 * i], ay = w.coords[3 * i + 1], az = w.coords[3 * i + 2];
+      for (int j0 = 0; j0 < env.n_rec; j0 += 64) {
+        const int j = j0 + lane;
+        const float4 r = env.rec[j < env.n_rec ? j : 0];
+        const float rx = ax - r.x, ry = ay - r.y, rz = az - r.z;
+        const float r2 = rx * rx + ry * ry + rz * rz;
+        const bool in = j < env.n_rec && r2 < env.cutoff_sqr;
+        float pe = 0.f;
+        if (in) {
+          pe = prec_eval(env, t1, __float_as_int(r.w), r2);
+          curl1(pe, v1);
+        }
+        seq_add(e_run, pe, __builtin_amdgcn_ballot_w64(in));
+      }
+    }
+    for (int pb = 0; pb < L.n_pairs; pb += 64) {
+      const int p = pb + lane;
+      const bool valid = p < L.n_pairs;
+      const int2 ab = L.pairs[valid ? p : 0];
+      const float rx = w.coords[3 * ab.y] - w.coords[3 * ab.x], ry = w.coords[3 * ab.y + 1] - w.coords[3 * ab.x + 1],
+                  rz = w.coords[3 * ab.y + 2] - w.coords[3 * ab.x + 2];
+      const float r2 = rx * rx + ry * ry + rz * rz;
+      const bool in = valid && L.pair_cap[valid ? p : 0] && r2 < env.cutoff_sqr && pair_counts(valid ? p : 0, ab);
+      float pe = 0.f;
+      if (in) {
+        if (env.exact || env.spline) {
+          pe = prec_eval(env, L.smt[ab.x], L.smt[ab.y], r2);
+        } else {
+          const long base = (long)tri_idx(L.smt[ab.x], L.smt[ab.y]) * env.n;
+          pe = env.fast[base + (int)(env.factor * r2)];
+        }
+        curl1(pe, v2);
+      }
+      seq_add(e_run, pe, __builtin_amdgcn_ballot_w64(in));
+    }
+  } else if (MODE == 4 && has_flex && env.rec) {
     // eval_intramolecular's flex-rigid term (model.cu:364-384): every heavy movable atom outside the ligand against
     // every heavy atom of the rigid receptor, each PAIR curled with v[1] (the igrid curls an atom's sum instead)
     for (int i = 0; i < L.n_movable; i++) {
@@ -1162,6 +1206,7 @@ __device__ __forceinline__ float eval_conf(const VinaEnv &env, const VinaLigand 
     if (MODE == 0) e_strict = s_rec + ((0.f + s_p1) + s_p0);  // model::eval_deriv: e = ig.eval_deriv; ie = ...; e += ie
     else if (MODE == 1) e_strict = (s_rec + s_p1) + s_p0;      // model::evale adds other_pairs, model::eval the ligand's
     else if (MODE == 2) e_strict = s_rec;
+    else if (flex4) e_strict = e_run;
     else e_strict = (0.f + s_p1) + s_p0;
   }
   if ((MODE == 1 || (MODE == 2 && env.ug_model)) && env.ug_data) {

@@ -320,7 +320,8 @@ mi_status mi_vina_set_line_search(mi_vina *, int kind);
  * (model.cu:22-60) -- is added in the reference's order instead of a wavefront butterfly.  Forces, coordinates and
  * sinf / cosf already follow the reference bit for bit in either mode; with strict order the energies do too, so BFGS
  * runs and Monte-Carlo chains reproduce the reference's trajectories exactly (about 1 us more per evaluation; default
- * 0).  Not covered: eval_intramolecular of a model with flexible residues. */
+ * 0).  eval_intramolecular of a model with flexible residues (with_deriv = 4, the `intramolecular` of
+ * mi_vina_final_energies) adds its flex-rigid and flex-flex terms one by one like model.cu:352-399. */
 mi_status mi_vina_set_strict_order(mi_vina *, int on);
 /* Diagnostic: sn[i], cs[i] = the device's sinf(x[i]), cosf(x[i]) as the Vina kernels compute them -- glibc's
  * algorithm restated in fp64 so that tree.h / quaternion.h's std::sin / std::cos give the host's bits (|x| < 120). */

@@ -289,6 +289,8 @@ def test_flexible_residues_in_the_search_on_the_device(capi):
             assert biteq(e, G[P + f"bfgs/v10/{iters}/e"]) and biteq(cf, G[P + f"bfgs/v10/{iters}/conf"]), iters
         n, e, cf, xyz, ev = v.mc_batch(seeds, list(G[P + "begin"]), list(G[P + "end"]), capi.McParams.default(1, 2, 20))
         assert biteq(e[:, 0], G[P + "mcshort/1/e0"]) and biteq(cf[:, 0], G[P + "mcshort/1/conf0"])
+        # eval_intramolecular of the combined model: ligand pairs, then flex-rigid, then flex-flex terms on one running sum
+        assert biteq(v.final_energies(confs, float(F["num_tors"]))[1], F["intra"])
     finally:
         v.set_strict_order(False)
     for iters, need in ((1, 10), (3, 6)):   # default mode (clashing random starts: an energy's last bit decides a trial)
