@@ -13,4 +13,4 @@ print('   headline %.0f %s, %.3f ms/step' % (d['value'], d['unit'], d['ms_per_st
 for k in d.get('kernels', []):
     if 'vox' in k['kernel'] or 'gather' in k['kernel']: print('   %-40s x%-2d %.4f ms' % (k['kernel'], k['launches_per_step'], k['ms_per_step']))
 "; }
-for i in 1 2; do timeout 300 python bench.py --no-configs --no-cpu-baseline --steps 6 --warmup 2 2>/dev/null | kern; done
+for i in 1 2; do timeout 300 python bench.py --no-configs --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | kern; done
