@@ -604,8 +604,9 @@ def config_seam_b1(capi, synth):
     pose1 = synth.make_poses(rng, lx, 1)
     out = {"note": "B = 1 per call, host pointers, synchronous; median of 60 calls after 0.3 s of warm-up calls; microseconds.  "
                    "four_threads: four scorers on four host threads -- since round 5 the library runs one CNN scoring call at a "
-                   "time per device, as gnina does under DLScorer::mtx (two scorers' kernels side by side do not reproduce the "
-                   "single-thread bits: DESIGN 3.10), so this is what the lock allows, not concurrency on the GPU"}
+                   "time per device, as gnina does under DLScorer::mtx (a voxelizer next to another scorer's conv kernels does "
+                   "not reproduce the single-thread bits: DESIGN 3.10), so this is what the lock allows; an ensemble's models "
+                   "run on their own streams behind the voxelization (lanes)"}
     for label, models in (("default2017", ["default2017"]),
                           ("default_ensemble", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])):
         s = capi.Scorer(models)

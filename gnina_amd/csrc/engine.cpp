@@ -51,7 +51,8 @@ void process_env_once() {
 // hardware queues do NOT give the bits each gives alone: measured round 5 (tools/experiments/concurrency_diag*.py) -- with a
 // Dense model on a second host thread ~5 % of the B = 1 calls of the first deviate by up to 3e-2 in the affinity; the
 // candidate lists are the quiet run's, the pooled voxel grid is not (a few cells whose accumulation saw another order);
-// GPU_MAX_HW_QUEUES=1 or this lock give 0 of 1,200.  Host-output calls hold the lock until their results are back;
+// GPU_MAX_HW_QUEUES=1 or this lock give 0 of 1,200 (what deviates is a voxelizer next to another queue's LDS-DMA conv
+// workgroups; conv programs side by side are clean: the lanes below).  Host-output calls hold the lock until their results are back;
 // device-output calls (MI_OUT_ON_DEVICE, the pools: one worker per device) only while they enqueue.
 static std::recursive_mutex &device_call_lock(int device) {
   static std::recursive_mutex locks[64];
@@ -61,6 +62,29 @@ static std::recursive_mutex &device_call_lock(int device) {
     return own;
   }
   return locks[device >= 0 && device < 64 ? device : 0];
+}
+
+// The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: calls are serialised per device, so
+// one set is enough -- and a set per scorer is harmful: four scorers x three priority streams oversubscribe the hardware
+// queues and the runtime time-slices them (gnina's default ensemble from four threads: 777 -> 110 poses/s).  One stream
+// priority per lane, cycling through the device's range: the HIP runtime keeps a pool of hardware queues per priority, so
+// lanes of different priority never share a hardware queue.  (With plain streams and the default four queues per pool, two
+// of the three lanes of gnina's default ensemble landed on one queue and ran one after the other: 1,289 us per B = 1 call
+// against 726 us with GPU_MAX_HW_QUEUES=8, 717 us with priorities.)  Called under device_call_lock; never destroyed.
+static hipStream_t device_lane_stream(int device, int k) {
+  static std::mutex mu;
+  static std::vector<hipStream_t> pool[64];
+  std::lock_guard<std::mutex> lock(mu);
+  std::vector<hipStream_t> &v = pool[device >= 0 && device < 64 ? device : 0];
+  while ((int)v.size() <= k) {
+    int least = 0, greatest = 0;
+    MIG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int span = least - greatest + 1;
+    hipStream_t st = nullptr;
+    MIG_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, span > 1 ? greatest + (int)v.size() % span : 0));
+    v.push_back(st);
+  }
+  return v[k];
 }
 
 void ensure_max_lds(const void *kernel, int bytes) {
@@ -1294,7 +1318,7 @@ struct Scorer {
   // three models): every model's layer program runs on its own stream ("lane") off the voxelization on the main stream, with
   // its own set of activation buffers (act_lane) -- the launches of a B = 1 program are latency, not throughput, and three
   // independent chains of ~20 dependent kernels overlap almost entirely.  Results are the bits of the serial order.
-  std::vector<hipStream_t> lane_streams;
+  std::vector<hipStream_t> lane_streams;  // (the device's shared set: device_lane_stream)
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
@@ -1366,8 +1390,6 @@ struct Scorer {
       if (e) (void)hipEventDestroy(e);
     for (auto &e : lane_start)
       if (e) (void)hipEventDestroy(e);
-    for (auto &st : lane_streams)
-      if (st) (void)hipStreamDestroy(st);
     if (h_out4) (void)hipHostFree(h_out4);
     if (vox_stream) (void)hipStreamDestroy(vox_stream);
     if (stream) (void)hipStreamDestroy(stream);
@@ -2378,15 +2400,24 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   // Lanes (Scorer::lane_streams): a small call of an ensemble runs every model's program on its own stream.
   int lanes_max_b = 8;
   if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
-  // OPT-IN (MI_GNINA_LANES=1): kernels of different models running side by side do not reproduce the serial call's bits on
-  // this chip (see device_call_lock), and the default ensemble's B = 1 call gained 4 % from them (1,240 -> 1,196 us)
-  const bool lanes_on = option(OPT_MI_GNINA_LANES) && atoi(option(OPT_MI_GNINA_LANES)) != 0;
-  const bool lanes = lanes_on && nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) && !(s.overlap && B > s.cap);
+  // On by default (MI_GNINA_LANES=0 or MI_GNINA_NO_LANES=1: one stream).  What must never run side by side on this chip is
+  // a voxelizer and another queue's LDS-DMA conv workgroups (device_call_lock); the lanes start after every group's grid is
+  // voxelized and run conv programs only: 1,800 B = 1 calls of three ensembles, every one the serial call's bits
+  // (tools/experiments/lanes_diag3.py), gnina's default ensemble 1,260 -> 717 us per B = 1 call.
+  const bool lanes_on = !option(OPT_MI_GNINA_LANES) || atoi(option(OPT_MI_GNINA_LANES)) != 0;
+  // (at most two voxel groups: one pooled slot each, all voxelized BEFORE the first lane starts -- a voxelizer running next to
+  // another queue's LDS-DMA conv workgroups is the combination that deviates, conv kernels side by side are not)
+  const bool lanes = lanes_on && nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) &&
+                     !(s.overlap && B > s.cap) && s.groups.size() <= 2;
+  struct LaneJob {
+    int gi;
+    size_t slot;
+    bool split;
+  };
+  std::vector<LaneJob> lane_jobs;
   if (lanes) {
     while ((int)s.lane_streams.size() < nm) {
-      hipStream_t st = nullptr;
-      MIG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      s.lane_streams.push_back(st);
+      s.lane_streams.push_back(device_lane_stream(s.device, (int)s.lane_streams.size() % 8));
       hipEvent_t e = nullptr;
       MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       s.lane_done.push_back(e);
@@ -2417,12 +2448,9 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     int ci = 0;
     for (int b0 = 0; b0 < B; b0 += s.cap, ci++) {
       const int nb = std::min(s.cap, B - b0);
-      const int set = ov ? (ci & 1) : 0;
-      // (lanes: the models of group gi - 1 may still be reading their pooled grid: the groups alternate between the two
-      // slots, and a slot is voxelized into again only after the lanes of the group two back are through)
-      const size_t slot = (lanes ? (gi & 1) : set) ? kPooledSlot2 : kPooledSlot;
-      if (lanes && gi >= 2)
-        for (int mi : s.groups[gi - 2].models) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));
+      // (lanes: group gi voxelizes into slot / candidate / occupancy set gi, on the main stream, one group after the other)
+      const int set = lanes ? (gi & 1) : ov ? (ci & 1) : 0;
+      const size_t slot = set ? kPooledSlot2 : kPooledSlot;
       float *pooled = act_buf(s, slot, pooled_n);
       if (ov) {
         if (ci >= 2) MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_cnn_done[set], 0));  // buffer set free again
@@ -2435,23 +2463,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
         voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, nullptr, 0, split);
       }
       if (lanes) {
-        // every buffer a program touches is allocated before the first launch (a grow-only buffer must not move under a lane)
-        MIG_HIP(hipEventRecord(s.lane_start[gi], s.stream));
-        struct LaneGuard {  // run_program launches on s.stream into buffer set s.act_lane
-          Scorer &s;
-          hipStream_t main;
-          ~LaneGuard() { s.stream = main, s.act_lane = 0; }
-        } guard{s, s.stream};
-        for (int mi : g.models) {
-          hipStream_t ls_ = s.lane_streams[mi];
-          MIG_HIP(hipStreamWaitEvent(ls_, s.lane_start[gi], 0));
-          s.stream = ls_;
-          s.act_lane = mi + 1;
-          run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
-                      s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
-          MIG_HIP(hipEventRecord(s.lane_done[mi], ls_));
-          s.stream = guard.main;
-        }
+        lane_jobs.push_back(LaneJob{gi, slot, split});  // (B <= cap: one chunk per group)
       } else {
         for (int mi : g.models)
           run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
@@ -2463,8 +2475,30 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       MIG_HIP(hipStreamSynchronize(s.vox_stream));
     }
   }
-  if (lanes)  // the ensemble reduction (main stream) reads what the lanes wrote
+  if (lanes) {
+    // every grid is voxelized: now every model's program on its own stream
+    // (every buffer a program touches is allocated before its first launch: a grow-only buffer must not move under a lane)
+    MIG_HIP(hipEventRecord(s.lane_start[0], s.stream));
+    struct LaneGuard {  // run_program launches on s.stream into buffer set s.act_lane
+      Scorer &s;
+      hipStream_t main;
+      ~LaneGuard() { s.stream = main, s.act_lane = 0; }
+    } guard{s, s.stream};
+    for (const LaneJob &job : lane_jobs)
+      for (int mi : s.groups[job.gi].models) {
+        hipStream_t ls_ = s.lane_streams[mi];
+        MIG_HIP(hipStreamWaitEvent(ls_, s.lane_start[0], 0));
+        s.stream = ls_;
+        s.act_lane = mi + 1;
+        run_program(s, mi, B, s.d_pose_m.p + (size_t)mi * B, s.d_aff_m.p + (size_t)mi * B, s.d_loss_m.p + (size_t)mi * B, false,
+                    job.slot, job.split);
+        MIG_HIP(hipEventRecord(s.lane_done[mi], ls_));
+        s.stream = guard.main;
+      }
+    s.stream = guard.main, s.act_lane = 0;
+    // the ensemble reduction (main stream) reads what the lanes wrote
     for (int mi = 0; mi < nm; mi++) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));
+  }
   const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
   float *o_pose = pose, *o_aff = aff, *o_loss = loss, *o_var = var;
   if (!out_dev) {  // one [4][B] device block -> one copy into pinned host memory -> the caller's four arrays

@@ -56,8 +56,9 @@ def test_two_threads_give_the_single_thread_bits(capi, pair):
 
 
 def test_default_ensemble_small_calls_are_reproducible(capi):
-    """gnina's default ensemble at B = 1 (DLScorer::score as gnina calls it): 60 calls, the same bits every time and the
-    goldens' scores; the per-model streams (MI_GNINA_LANES=1) are off by default."""
+    """gnina's default ensemble at B = 1 (DLScorer::score as gnina calls it): the models' programs run on their own streams
+    (lanes; every voxel group is voxelized before the first lane starts).  Same bits every time, the goldens' scores, and
+    the bits of the one-stream call (MI_GNINA_NO_LANES=1), per model."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
     names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]
     rec_xyz, rec_smt, lig_smt, poses = (G[f"{names[0]}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
@@ -71,3 +72,17 @@ def test_default_ensemble_small_calls_are_reproducible(capi):
             first = got
             assert np.abs(got[:, 1] - want_aff).max() < 1e-4
         assert np.array_equal(got, first), rep
+    # per model, against the same calls on one stream
+    def per_model(sc, reps):
+        out = []
+        for rep in range(reps):
+            b = rep % len(poses)
+            sc.score_batch(poses[b:b + 1], lig_smt)
+            out.append([[float(x[0]) for x in sc.last_model_outputs(m, 1)[:2]] for m in range(len(names))])
+        return np.array(out)
+    lanes = per_model(s, 150)
+    with capi.option("MI_GNINA_NO_LANES", "1"):
+        s1 = capi.Scorer(names)
+        s1.set_receptor(rec_xyz, rec_smt)
+        serial = per_model(s1, 150)
+    assert np.array_equal(lanes, serial), int((np.abs(lanes - serial).max(axis=(1, 2)) > 0).sum())
