@@ -1340,8 +1340,18 @@ struct Scorer {
   unsigned *h_ovf = nullptr;            // pinned copy
   int h2_fallbacks = 0;                 // calls recomputed because of it (mi_scorer_h2_fallbacks)
   bool ovf_pending = false;             // device-output calls in flight whose flag mi_scorer_synchronize still has to read
-  int lig_cache_group = -1, lig_cache_n = 0;  // setup_ligand cache: group / ligand types the device arrays describe
-  std::vector<int32_t> lig_cache_smt;
+  // setup_ligand cache, one per voxel group: the same ligand is scored call after call (poses of one docking run), and an
+  // ensemble with two groups (gnina's default: the Dense pair + a Default2018) would otherwise re-upload four arrays and
+  // synchronise twice per call (~90 us of a B = 1 call)
+  struct LigDev {
+    DevBuf<int> perm, chan;
+    DevBuf<LigConsts> consts;
+    DevBuf<unsigned char> typed;
+    std::vector<int32_t> smt;
+    int n = 0;
+    bool valid = false;
+  };
+  std::vector<std::unique_ptr<LigDev>> lig_dev;
   std::vector<int> flex_rows;           // receptor rows with per-pose coordinates
   DevBuf<float> d_flex, d_flex_grad;    // [B][n_flex][3]
   const float *cur_flex = nullptr;      // device flex coordinates of the call in flight (or nullptr)
@@ -1620,6 +1630,10 @@ static void set_flex(Scorer &s, const int32_t *rows, int n_flex) {
 struct LigSetup {
   int n_lig = 0;  // typed ligand atoms (ragged: the largest count of any pose)
   bool ragged = false;
+  // the device-side description gather_pose_atoms / voxel_backward read (the group's cached arrays, or the per-pose ones)
+  const int *perm = nullptr, *chan = nullptr;
+  const LigConsts *consts = nullptr;
+  const unsigned char *typed = nullptr;
 };
 
 // Ragged batch (virtual screening): pose b has its own ligand -- rows [0, rows_b) of
@@ -1661,27 +1675,31 @@ static LigSetup setup_ligand_ragged(Scorer &s, const VoxGroup &g, const int32_t 
   s.d_lig_chan.upload(chan.data(), chan.size(), s.stream);
   s.d_lig_consts.upload(lc.data(), lc.size(), s.stream);
   s.d_lig_typed.upload(typed.data(), typed.size(), s.stream);
-  s.lig_cache_group = -1;  // the per-pose arrays overwrite the cached single-ligand description
   s.d_pose_rows.upload(rows.data(), rows.size(), s.stream);
   s.d_pose_nlig.upload(nl.data(), nl.size(), s.stream);
   MIG_HIP(hipStreamSynchronize(s.stream));
   LigSetup ls;
   ls.n_lig = max_n;
   ls.ragged = true;
+  ls.perm = s.d_lig_perm.p, ls.chan = s.d_lig_chan.p, ls.consts = s.d_lig_consts.p, ls.typed = s.d_lig_typed.p;
   return ls;
 }
 
 // Type the ligand rows with the group's ligand map, upload permutation / constants.
 static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_smt, int L) {
   Model *m = s.models[g.first_model];
-  // the same ligand is scored call after call (poses of one docking run): keep its device-side description
-  if (s.lig_cache_group == g.first_model && (int)s.lig_cache_smt.size() == L &&
-      std::equal(s.lig_cache_smt.begin(), s.lig_cache_smt.end(), lig_smt)) {
+  const size_t gi = (size_t)(&g - s.groups.data());
+  while (s.lig_dev.size() < s.groups.size()) s.lig_dev.emplace_back(new Scorer::LigDev);
+  Scorer::LigDev &d = *s.lig_dev[gi < s.lig_dev.size() ? gi : 0];
+  auto made = [&]() {
     LigSetup ls;
-    ls.n_lig = s.lig_cache_n;
+    ls.n_lig = d.n;
+    ls.perm = d.perm.p, ls.chan = d.chan.p, ls.consts = d.consts.p, ls.typed = d.typed.p;
     return ls;
-  }
-  s.lig_cache_group = -1;
+  };
+  // the same ligand is scored call after call (poses of one docking run): keep its device-side description
+  if (d.valid && (int)d.smt.size() == L && std::equal(d.smt.begin(), d.smt.end(), lig_smt)) return made();
+  d.valid = false;
   std::vector<int> idx;
   std::vector<unsigned char> typed(L, 0);
   for (int i = 0; i < L; i++) {
@@ -1702,18 +1720,18 @@ static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_sm
     lc[k] = LigConsts{dc.ar, dc.t2, dc.g2, dc.kexp, dc.inv_ar};
     chan[k] = m->d.ligmap.chan_of_smt[lig_smt[idx[k]]] + m->d.recmap.n_channels;  // torch_model.cpp:168
   }
-  s.d_lig_perm.upload(idx.data(), idx.size(), s.stream);
-  s.d_lig_chan.upload(chan.data(), chan.size(), s.stream);
-  s.d_lig_consts.upload(lc.data(), lc.size(), s.stream);
-  s.d_lig_typed.upload(typed.data(), typed.size(), s.stream);
+  // (a pending device-output call may still read the arrays being replaced: drain the stream first)
+  MIG_HIP(hipStreamSynchronize(s.stream));
+  d.perm.upload(idx.data(), idx.size(), s.stream);
+  d.chan.upload(chan.data(), chan.size(), s.stream);
+  d.consts.upload(lc.data(), lc.size(), s.stream);
+  d.typed.upload(typed.data(), typed.size(), s.stream);
   // the uploads read from stack vectors: make them complete before those die
   MIG_HIP(hipStreamSynchronize(s.stream));
-  LigSetup ls;
-  ls.n_lig = (int)idx.size();
-  s.lig_cache_group = g.first_model;
-  s.lig_cache_smt.assign(lig_smt, lig_smt + L);
-  s.lig_cache_n = ls.n_lig;
-  return ls;
+  d.n = (int)idx.size();
+  d.smt.assign(lig_smt, lig_smt + L);
+  d.valid = true;
+  return made();
 }
 
 // gather + voxelize poses [b0, b0+nb) of the batch for one group. mode: 0 full grid, 1/2 pooled.
@@ -1743,11 +1761,11 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   }
   ga.lig_xyz = d_lig_xyz + (size_t)b0 * L * 3;
   ga.L = L;
-  ga.lig_perm = s.d_lig_perm.p;
-  ga.lig_consts = s.d_lig_consts.p;
-  ga.lig_chan = s.d_lig_chan.p;
+  ga.lig_perm = ls.perm;
+  ga.lig_consts = ls.consts;
+  ga.lig_chan = ls.chan;
   ga.n_lig = ls.n_lig;
-  ga.lig_typed = s.d_lig_typed.p;
+  ga.lig_typed = ls.typed;
   if (ls.ragged) {  // per-pose ligand descriptions
     ga.lig_perm += (size_t)b0 * L;
     ga.lig_consts += (size_t)b0 * L;
@@ -1868,10 +1886,18 @@ static void h2_launch_args(const ConvPlan &cp, const ConvArgs &a, int nb, ConvAr
 
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
 // act[input_dst]; writes pose/aff/loss at out offsets.
+// The layer program a call runs for model m (forward or gradient, bf16 / split-fp16 / fp32-MFMA).
+static const std::vector<Step> &program_steps(Scorer &s, Model &m, bool grad) {
+  const bool bf16 = use_bf16(s, m, grad);
+  return bf16 ? (grad ? m.hgsteps : m.hsteps) : (grad ? m.gsteps : (s.conv_path != 0 ? m.steps : m.steps32));
+}
+
+// (step_lo, step_hi: the steps [step_lo, step_hi) of the program only -- the lanes enqueue their programs a few steps at a time)
 static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, float *loss, bool grad = false,
-                        size_t pooled_slot = 0, bool pooled_split = false) {
+                        size_t pooled_slot = 0, bool pooled_split = false, int step_lo = 0, int step_hi = 1 << 30) {
   Model *m = s.models[mi];
   if (m->overlap) {
+    if (step_lo > 0) return;
     const long N3 = (long)m->N * m->N * m->N;
     const float *grid = act_buf(s, pooled_slot, (size_t)s.cap * 2 * N3);
     s.d_ave.ensure(s.cap);
@@ -1881,7 +1907,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
     return;
   }
   const bool bf16 = use_bf16(s, *m, grad);
-  const std::vector<Step> &steps = bf16 ? (grad ? m->hgsteps : m->hsteps) : (grad ? m->gsteps : (s.conv_path != 0 ? m->steps : m->steps32));
+  const std::vector<Step> &steps = program_steps(s, *m, grad);
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
@@ -1897,7 +1923,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   const bool fwd_h2 = !bf16 && !grad && s.conv_path != 0;
   MIG_CHECK(!pooled_split || (fwd_h2 && m->pooled_split_ok), 2, "pooled grid written split for a program that reads fp32");
   auto is_split = [&](int id) { return fwd_h2 && (id == m->input_dst ? pooled_split : (bool)m->buf_split[id]); };
-  for (const Step &st : steps) {
+  for (int si = std::max(step_lo, 0); si < std::min(step_hi, (int)steps.size()); si++) {
+    const Step &st = steps[si];
     switch (st.kind) {
       case OpKind::Conv: {
         ConvArgs a = st.conv.a;
@@ -2286,9 +2313,9 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
         VoxBackArgs vb{};
         vb.lig_xyz = d_lig + (size_t)b0 * L * 3;
         vb.L = L;
-        vb.lig_perm = s.d_lig_perm.p;
-        vb.lig_consts = s.d_lig_consts.p;
-        vb.lig_chan = s.d_lig_chan.p;
+        vb.lig_perm = ls.perm;
+        vb.lig_consts = ls.consts;
+        vb.lig_chan = ls.chan;
         vb.n_lig = ls.n_lig;
         vb.centers = s.d_centers.p + (size_t)b0 * 3;
         vb.grad_pooled = g0;
@@ -2484,17 +2511,28 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       hipStream_t main;
       ~LaneGuard() { s.stream = main, s.act_lane = 0; }
     } guard{s, s.stream};
+    // The programs are enqueued round robin, kLaneSlice steps of each model at a time: a launch costs the host ~4.4 us, a
+    // Dense program has 18 of them, and enqueued one program after the other the second Dense lane started 80 us and the
+    // third lane 310 us behind the first (kernel trace, tools/experiments/r5_run57.sh).
+    int kLaneSlice = 2;  // (MI_GNINA_LANE_SLICE: an experiment switch; a large value enqueues one program after the other)
+    if (const char *ev = option(OPT_MI_GNINA_LANE_SLICE)) kLaneSlice = std::max(1, atoi(ev));
+    int longest = 0;
     for (const LaneJob &job : lane_jobs)
       for (int mi : s.groups[job.gi].models) {
-        hipStream_t ls_ = s.lane_streams[mi];
-        MIG_HIP(hipStreamWaitEvent(ls_, s.lane_start[0], 0));
-        s.stream = ls_;
-        s.act_lane = mi + 1;
-        run_program(s, mi, B, s.d_pose_m.p + (size_t)mi * B, s.d_aff_m.p + (size_t)mi * B, s.d_loss_m.p + (size_t)mi * B, false,
-                    job.slot, job.split);
-        MIG_HIP(hipEventRecord(s.lane_done[mi], ls_));
-        s.stream = guard.main;
+        MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[0], 0));
+        Model &m = *s.models[mi];
+        longest = std::max(longest, m.overlap ? 1 : (int)program_steps(s, m, false).size());
       }
+    for (int lo = 0; lo < longest; lo += kLaneSlice)
+      for (const LaneJob &job : lane_jobs)
+        for (int mi : s.groups[job.gi].models) {
+          s.stream = s.lane_streams[mi];
+          s.act_lane = mi + 1;
+          run_program(s, mi, B, s.d_pose_m.p + (size_t)mi * B, s.d_aff_m.p + (size_t)mi * B, s.d_loss_m.p + (size_t)mi * B,
+                      false, job.slot, job.split, lo, lo + kLaneSlice);
+          s.stream = guard.main;
+        }
+    for (int mi = 0; mi < nm; mi++) MIG_HIP(hipEventRecord(s.lane_done[mi], s.lane_streams[mi]));
     s.stream = guard.main, s.act_lane = 0;
     // the ensemble reduction (main stream) reads what the lanes wrote
     for (int mi = 0; mi < nm; mi++) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));

@@ -54,6 +54,7 @@ namespace mig {
   X(MI_GNINA_NO_LANES)               \
   X(MI_GNINA_LANES)                  \
   X(MI_GNINA_LANES_MAX_B)            \
+  X(MI_GNINA_LANE_SLICE)             \
   X(MI_GNINA_D16_PERSIST)            \
   X(MI_GNINA_K1S_PERSIST)            \
   X(MI_VOX_DBG)                      \
