@@ -1410,8 +1410,12 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
     const unsigned wlane = ((unsigned)kg * 16u + (unsigned)row) * 32u;
     const int *lp = s_qoff + kg;
     int qo_next = lp[0];
-    uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
-    auto load_step = [&](int st, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) {
+    // The A operands come from LDS one step ahead (ping-pong); the weights come from L2 and are requested FOUR steps ahead
+    // (a ring of four register sets, the loop unrolled by four): one step ahead, a chunk's 14 steps were a chain of 14 L2
+    // round trips -- 3.6 us per chunk with one or two workgroups on the chip, which is what a B = 1 call of a Dense model
+    // spends in its four 6^3 layers (47-59 us each).  Same MFMAs in the same order.
+    uint4 wh[4], wl[4], ah0[TM], al0[TM], ah1[TM], al1[TM];
+    auto load_a = [&](uint4 *ah, uint4 *al, int st_next) {
       const int qo = qo_next;
 #pragma unroll
       for (int m = 0; m < TM; m++) {
@@ -1419,32 +1423,41 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
         ah[m] = *reinterpret_cast<const uint4 *>(a);
         al[m] = *reinterpret_cast<const uint4 *>(a + 16);
       }
-      const char *w = wbase + (wlane + (unsigned)st * (4u * 16u * 32u));
-      wh = *reinterpret_cast<const uint4 *>(w);
-      wl = *reinterpret_cast<const uint4 *>(w + 16);
-      qo_next = lp[4 * st + 4];
+      qo_next = lp[4 * st_next];
     };
-    auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) {
+    auto load_w = [&](int st, uint4 &h, uint4 &l) {
+      const char *w = wbase + (wlane + (unsigned)st * (4u * 16u * 32u));
+      h = *reinterpret_cast<const uint4 *>(w);
+      l = *reinterpret_cast<const uint4 *>(w + 16);
+    };
+    auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &h, const uint4 &l) {
       // (three independent passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
 #pragma unroll
       for (int m = 0; m < TM; m++)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, h), acc[m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < TM; m++)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wl), acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, l), acc[m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < TM; m++)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, wh), acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, h), acc[m], 0, 0, 0);
     };
-    load_step(0, ah0, al0, wh0, wl0);
-    int st = 0;
-    for (; st + 1 < NS; st += 2) {
-      load_step(st + 1, ah1, al1, wh1, wl1);
-      mfma_step(ah0, al0, wh0, wl0);
-      if (st + 2 < NS) load_step(st + 2, ah0, al0, wh0, wl0);
-      mfma_step(ah1, al1, wh1, wl1);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (u < NS) load_w(u, wh[u], wl[u]);
+    load_a(ah0, al0, 1);
+    for (int st = 0; st < NS; st += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (st + u < NS) {
+          uint4 *ah_c = (u & 1) ? ah1 : ah0, *al_c = (u & 1) ? al1 : al0;
+          uint4 *ah_n = (u & 1) ? ah0 : ah1, *al_n = (u & 1) ? al0 : al1;
+          if (st + u + 1 < NS) load_a(ah_n, al_n, st + u + 2);
+          mfma_step(ah_c, al_c, wh[u], wl[u]);
+          if (st + u + 4 < NS) load_w(st + u + 4, wh[u], wl[u]);
+        }
+      }
     }
-    if (NS & 1) mfma_step(ah0, al0, wh0, wl0);
   }
 
   // epilogue: accumulator row = 4 * (lane >> 4) + reg, column = lane & 15
