@@ -54,10 +54,12 @@ enum {
  * default is 4) unless the variable is already set -- effective only before the process's first HIP call.
  * CNN scoring calls (mi_scorer_score_*, mi_voxelize_batch, mi_model_forward_grids) on different scorers of ONE device
  * are serialised by the library, as gnina serialises them under DLScorer::mtx (dl_scorer.h:26, cnn_torch_scorer.cpp:106:
- * one mutex shared by a scorer and its copies): two scorers' kernels side by side on two hardware queues do not give the
- * bits each gives alone on this chip (round 5; tests/test_gpu_concurrency.py).  Host-output calls hold
- * the device's lock until their results are back; MI_OUT_ON_DEVICE calls only while they enqueue -- the caller orders
- * those (the pools drive one scorer per device). */
+ * one mutex shared by a scorer and its copies): a voxelizer next to another scorer's conv kernels on a second hardware
+ * queue does not give the bits it gives alone on this chip (round 5; tests/test_gpu_concurrency.py).
+ * Host-output calls hold the device's lock until their results are back; MI_OUT_ON_DEVICE calls only while they enqueue --
+ * the caller orders those (the pools drive one scorer per device).  Within a call of at most 8 poses the models of an
+ * ensemble run on streams of their own behind the voxelization (conv programs side by side are clean; same bits as on one
+ * stream; MI_GNINA_LANES=0 switches it off). */
 mi_status mi_gnina_init(int device);
 /* Experiment / A-B switches (gnina_amd/csrc/options.h lists them: MI_GNINA_*, MI_POOL_*, MI_VINA_*, MI_VOX_*).  The
  * environment is read ONCE per process, at the first library call; afterwards a switch changes only through this call
