@@ -145,6 +145,24 @@ def pmc_entry(kernel_label):
         return None
 
 
+def voxelizer_issue_committed(kernel_prefix="voxelize_tiles<1, true"):
+    """The tile kernel's bound is the vector instruction issue rate (one VALU instruction per SIMD every four cycles), not
+    HBM: SQ_INSTS_VALU x 4 cycles / 1,024 SIMDs against the kernel's own GPU cycles (GRBM_GUI_ACTIVE counts all eight XCDs),
+    both from the COMMITTED rocprofv3 passes (profiles/latest_pmc.json) -- counters only, no clock assumed."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        k = next(v for n, v in ks.items() if n.startswith(kernel_prefix))
+        valu, salu, cyc = k["SQ_INSTS_VALU"], k["SQ_INSTS_SALU"], k["GRBM_GUI_ACTIVE"] / 8.0
+        return {"valu_insts_per_launch": round(valu), "salu_insts_per_launch": round(salu),
+                "gpu_cycles_per_launch": round(cyc), "frac": round(valu * 4.0 / 1024.0 / cyc, 4),
+                "scalar_alu_frac": round(salu / 256.0 / cyc, 4),
+                "note": "VALU instructions x 4 cycles / 1,024 SIMDs over the kernel's cycles; scalar: SALU instructions / 256 "
+                        "CUs (one scalar ALU per CU) over the same cycles; profiles/latest_pmc.json (committed), not this run"}
+    except Exception:
+        return None
+
+
 def pmc_traffic_committed(kernel_label):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes -- not measured in this run
     (profiles/latest_pmc.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
@@ -955,9 +973,10 @@ def main():
                           "peak_GBs": PEAK_HBM_GBS,
                           "frac": round(vox["bytes"] / 8 / vox["launches"] / (vox_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                           "poses_per_launch": vox["poses"] // vox["launches"],
+                          "valu_issue_from_committed_pmc": voxelizer_issue_committed(),
                           "note": "bytes actually written: the 2x2x2-pooled grid, C*(N/2)^3*4 per pose (the un-fused "
-                                  "C*N^3*4 figure of SURVEY 8d is 8x that and never exists in HBM); VALU-bound "
-                                  "(exp/sqrt per atom-voxel pair), not HBM-bound"},
+                                  "C*N^3*4 figure of SURVEY 8d is 8x that and never exists in HBM); bound by its vector "
+                                  "instruction issue rate (valu_issue_from_committed_pmc), not by HBM"},
             "sum_kernel_ms_per_step": round(total_kernel_ms, 3),
             "dominant_kernel_overall": dom["kernel"],
         }

@@ -1,0 +1,39 @@
+"""bench.py's host-side helpers (no GPU): argument defaults, the spin-up loop, and the figures it derives from the committed
+rocprofv3 passes (profiles/latest_pmc.json)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_defaults_follow_the_contract(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 3 and 0.0 <= a.spinup_seconds <= 2.0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
+
+
+def test_spin_up_runs_untimed_steps_and_synchronises_each():
+    calls = []
+    n = bench.spin_up(lambda: calls.append("s"), lambda: calls.append("y"), 0.02)
+    assert n >= 1 and calls.count("s") == n and calls.count("y") == n and calls[:2] == ["s", "y"]
+    assert bench.spin_up(lambda: calls.append("x"), lambda: None, 0.0) == 0
+
+
+def test_voxelizer_issue_figures_from_the_committed_counters():
+    v = bench.voxelizer_issue_committed()
+    assert v is not None, "profiles/latest_pmc.json has no voxelize_tiles<1, true> entry"
+    # one VALU instruction per SIMD every four cycles, one scalar ALU per CU: neither fraction can exceed 1
+    assert 0.5 < v["frac"] <= 1.0 and 0.2 < v["scalar_alu_frac"] <= 1.0
+    assert v["valu_insts_per_launch"] > v["salu_insts_per_launch"]   # (round 5: it used to be the other way round)
+    assert bench.voxelizer_issue_committed("no such kernel") is None
+
+
+def test_committed_traffic_of_the_dominant_kernel():
+    e = bench.pmc_entry("conv3_s24_35to32_pool_h2")
+    assert e is not None and 1e9 < e["hbm_bytes_per_launch"] < 1e10
