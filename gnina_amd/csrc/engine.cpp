@@ -76,7 +76,20 @@ static hipStream_t device_lane_stream(int device, int k) {
   static std::vector<hipStream_t> pool[64];
   std::lock_guard<std::mutex> lock(mu);
   std::vector<hipStream_t> &v = pool[device >= 0 && device < 64 ? device : 0];
+  // (a stream belongs to the device that is current when it is created: a caller thread that is on another device --
+  // mi_gnina_init not called in it -- must not put the lanes there)
+  struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int want) {
+      int cur = -1;
+      if (hipGetDevice(&cur) == hipSuccess && cur != want && want >= 0 && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+      if (prev >= 0) (void)hipSetDevice(prev);
+    }
+  };
   while ((int)v.size() <= k) {
+    DeviceGuard on_device(device);
     int least = 0, greatest = 0;
     MIG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     const int span = least - greatest + 1;
