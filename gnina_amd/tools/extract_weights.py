@@ -284,11 +284,15 @@ def convert_graph(module, blob, C0, N):
                 raise ValueError("batch_norm in training mode")
             alpha = (w.float() if w is not None else torch.ones_like(var.float())) / torch.sqrt(var.float() + eps)
             shift = (b.float() if b is not None else torch.zeros_like(var.float())) - mean.float() * alpha
-            if src_name in conv_lines and len(uses.get(src_name, [])) == 1:  # conv -> BN: fold into the conv
+            foldable = (src_name in conv_lines and len(uses.get(src_name, [])) == 1 and not conv_lines[src_name]["relu"] and
+                        "fold" not in conv_lines[src_name])
+            if foldable:  # conv -> BN (no ReLU in between, one BatchNorm only): fold into the conv
                 conv_lines[src_name]["fold"] = (alpha, shift)
                 T[outs[0]] = T[src_name]
                 conv_lines[outs[0]] = conv_lines[src_name]
-            else:  # BN -> conv: the conv's input scale / shift
+            else:  # BN -> conv (conv -> ReLU -> BN -> conv included): the NEXT conv's input scale / shift
+                if any(u.kind() not in ("aten::_convolution", "aten::conv3d") for u in uses.get(outs[0], [])) or not uses.get(outs[0]):
+                    raise ValueError("batch_norm: behind a ReLU (or a second BatchNorm) its output must feed convolutions only")
                 pending_bn[outs[0]] = (T[src_name], alpha, shift)
         elif k in ("aten::_convolution", "aten::conv3d"):
             in_name = nd.inputsAt(0).debugName()

@@ -1,8 +1,9 @@
-"""Two small architectures that are NOT among gnina's shipped families -- what `--cnn_model file.pt` may hand to TorchModel
+"""Three small architectures that are NOT among gnina's shipped families -- what `--cnn_model file.pt` may hand to TorchModel
 (gninasrc/lib/torch_model.cpp:49-118) -- for the generic TorchScript path of gnina_amd/tools/extract_weights.py.
 `Stack`: avg pool, 3x3x3 / 1x1x1 convolutions with channel counts the shipped models do not have, a BatchNorm BEHIND a
 convolution (folded), two pools, fixed-size heads.  `MiniDense`: a two-layer DenseNet block (BatchNorm in FRONT of its
-convolutions, concatenation), a 1x1x1 transition, a global max pool, size-independent heads."""
+convolutions, concatenation), a 1x1x1 transition, a global max pool, size-independent heads.  `PostAct`: BatchNorm BEHIND a ReLU (conv -> ReLU -> BN -> conv) and behind
+a pool -- not foldable into the producing conv (the converter once folded it anyway and mis-scored silently)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -57,10 +58,34 @@ class MiniDense(nn.Module):
         return F.log_softmax(self.pose(g), dim=1), self.aff(g).squeeze(-1)
 
 
+class PostAct(nn.Module):
+    """conv -> ReLU -> BatchNorm -> conv: the BatchNorm sits BEHIND the activation, so it cannot be folded into the conv in
+    front of it (relu(alpha y + shift) != alpha relu(y) + shift); it is the next conv's input transform."""
+
+    def __init__(self, cin=28):
+        super().__init__()
+        self.c1 = nn.Conv3d(cin, 16, 3, padding=1)
+        self.bn1 = nn.BatchNorm3d(16)
+        self.c2 = nn.Conv3d(16, 24, 3, padding=1)
+        self.bn2 = nn.BatchNorm3d(24)
+        self.c3 = nn.Conv3d(24, 8, 1)
+        self.pose = nn.Linear(1728, 2)
+        self.aff = nn.Linear(1728, 1)
+
+    def forward(self, x):
+        x = F.max_pool3d(x, 2)
+        x = self.bn1(F.relu(self.c1(x)))
+        x = F.max_pool3d(F.relu(self.c2(x)), 2)
+        x = F.relu(self.c3(self.bn2(x)))
+        x = F.max_pool3d(x, 2)
+        x = x.view(-1, 1728)
+        return F.log_softmax(self.pose(x), dim=1), self.aff(x).squeeze(-1)
+
+
 def make(kind, seed=0):
     """the module in eval mode with seeded weights and non-trivial BatchNorm statistics"""
     torch.manual_seed(seed)
-    m = {"stack": Stack, "minidense": MiniDense}[kind]()
+    m = {"stack": Stack, "minidense": MiniDense, "postact": PostAct}[kind]()
     for mod in m.modules():
         if isinstance(mod, nn.BatchNorm3d):
             with torch.no_grad():

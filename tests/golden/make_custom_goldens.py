@@ -1,4 +1,4 @@
-"""Goldens for the generic TorchScript path (`--cnn_model file.pt` of an architecture that is not a shipped family): the two
+"""Goldens for the generic TorchScript path (`--cnn_model file.pt` of an architecture that is not a shipped family): the three
 architectures of tests/custom_models.py are scripted, saved with gnina's metadata, converted by
 gnina_amd/tools/extract_weights.py (its graph walk) and run BY TORCH ITSELF on the oracle's grids of the seeded golden
 complex.  Writes tests/golden/custom_<kind>.mgw (what the engine loads) and tests/golden/custom_goldens.npz (what it must
@@ -20,7 +20,7 @@ G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
 base = "dense_1_3"  # the seeded complex these goldens share (default 28-channel maps)
 rec_xyz, rec_smt, lig_smt, poses = (G[f"{base}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
 out = {}
-for kind in ("stack", "minidense"):
+for kind in ("stack", "minidense", "postact"):
     with tempfile.TemporaryDirectory() as d:
         pt = os.path.join(d, f"custom_{kind}.pt")
         m = custom_models.save_scripted(kind, pt)

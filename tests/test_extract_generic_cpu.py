@@ -30,14 +30,16 @@ def _check(pt_path, module, generic, C0=None, tol=2e-5):
     return blob
 
 
-@pytest.mark.parametrize("kind", ["stack", "minidense"])
+@pytest.mark.parametrize("kind", ["stack", "minidense", "postact"])
 def test_custom_architectures(kind, tmp_path):
     path = str(tmp_path / f"{kind}.pt")
     m = custom_models.save_scripted(kind, path)
     blob = _check(path, m, generic=False)  # (not a shipped family: the graph walk is taken by itself)
     assert blob.meta.get("generic") == "1"
     kinds = [t[0] for t in blob.ops]
-    assert kinds.count("conv") == (4 if kind == "stack" else 4) and kinds[-1] == "fc"
+    assert kinds.count("conv") == (3 if kind == "postact" else 4) and kinds[-1] == "fc"
+    if kind == "postact":  # both BatchNorms stay input transforms of the NEXT conv; nothing was folded across the ReLU
+        assert [int(t[10]) >= 0 for t in blob.ops if t[0] == "conv"] == [False, True, True]
     if kind == "minidense":
         assert "gmax" in kinds and sum(1 for t in blob.ops if t[0] == "conv" and int(t[10]) >= 0) == 2  # BatchNorm kept in front of 2 convs
 
@@ -51,6 +53,28 @@ def test_unsupported_operator_is_named(tmp_path):
     path = str(tmp_path / "bad.pt")
     torch.jit.save(torch.jit.script(Bad()), path)
     with pytest.raises(ValueError, match="unsupported operator aten::tanh"):
+        extract_weights.convert(path)
+
+
+def test_batchnorm_behind_relu_feeding_a_head_is_named(tmp_path):
+    """conv -> ReLU -> BN -> flatten -> linear: the BatchNorm has no convolution to become the input transform of"""
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv3d(28, 4, 3, padding=1)
+            self.bn = torch.nn.BatchNorm3d(4)
+            self.pose = torch.nn.Linear(55296, 2)
+            self.aff = torch.nn.Linear(55296, 1)
+
+        def forward(self, x):
+            x = torch.nn.functional.max_pool3d(x, 2)
+            x = self.bn(torch.relu(self.c(x))).view(-1, 55296)
+            return torch.log_softmax(self.pose(x), dim=1), self.aff(x).squeeze(-1)
+
+    import json
+    path = str(tmp_path / "bnhead.pt")
+    torch.jit.save(torch.jit.script(M().eval()), path, _extra_files={"metadata": json.dumps({"resolution": 0.5, "dimension": 23.5})})
+    with pytest.raises(ValueError, match="batch_norm"):
         extract_weights.convert(path)
 
 

@@ -22,7 +22,7 @@ def capi():
     return c
 
 
-@pytest.mark.parametrize("kind", ["stack", "minidense"])
+@pytest.mark.parametrize("kind", ["stack", "minidense", "postact"])
 def test_custom_architecture_scores_like_torch(capi, kind):
     G = np.load(os.path.join(GOLD, "cnn_goldens.npz"))
     W = np.load(os.path.join(GOLD, "custom_goldens.npz"))
@@ -42,7 +42,7 @@ def test_custom_architecture_scores_like_torch(capi, kind):
     assert np.abs(ref["affinity"] - W[kind + "/affinity"]).max() < 1e-4 * scale
 
 
-@pytest.mark.parametrize("kind", ["stack", "minidense"])
+@pytest.mark.parametrize("kind", ["stack", "minidense", "postact"])
 def test_custom_architecture_gradient(capi, kind):
     """d loss / d ligand atoms against the oracle's autograd through the same program (the gradient program plans the
     transposed convolutions of whatever layers the model has)."""
