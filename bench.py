@@ -58,7 +58,7 @@ def spin_up(step, sync, seconds):
     """Untimed steps for `seconds`.  After an idle period the GPU needs ~30 ms of continuous work before its clocks are at
     their steady state: in a kernel trace of this bench the headline step takes 3.98, 3.66, 3.62, 3.54, 3.48, 3.46, 3.44,
     3.40 ms ... 3.40 ms after every pause (first conv 2.01 -> 1.71 ms), so three warm-up steps put the timed region on
-    the ramp (tools/experiments/r5_run50.sh).  The W warm-up steps of the contract still follow."""
+    the ramp (tools/experiments/r5_calls.sh 50).  The W warm-up steps of the contract still follow."""
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         step()

@@ -1,4 +1,4 @@
-"""B = 1 calls of gnina's default ensemble (run under rocprofv3 --kernel-trace: tools/experiments/r5_run57.sh)."""
+"""B = 1 calls of gnina's default ensemble (run under rocprofv3 --kernel-trace: tools/experiments/r5_calls.sh 57)."""
 import os
 import sys
 import time
