@@ -25,7 +25,7 @@ SYMBOLS = [
     "mi_scorer_set_chunk", "mi_scorer_enable_timing", "mi_scorer_last_timing",
     "mi_scorer_enable_profile", "mi_scorer_profile_json",
     "mi_vina_create", "mi_vina_destroy", "mi_vina_table_size", "mi_vina_table", "mi_vina_set_receptor",
-    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_debug_read_activation", "mi_debug_read_candidates", "mi_gnina_set_option", "mi_gnina_options", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
+    "mi_vina_build_cache", "mi_vina_cache_grid", "mi_user_grid_parse", "mi_vina_set_user_grid", "mi_vina_set_approximation", "mi_vina_pair_eval", "mi_vina_set_line_search", "mi_vina_set_strict_order", "mi_debug_sincos", "mi_debug_explog", "mi_debug_acos", "mi_debug_split_f16", "mi_debug_h2_layout", "mi_debug_read_activation", "mi_debug_read_candidates", "mi_debug_vox_stress", "mi_gnina_set_option", "mi_gnina_options", "mi_scorer_flex_count", "mi_pool_create", "mi_pool_destroy", "mi_pool_size", "mi_pool_set_receptor", "mi_pool_score_batch", "mi_pool_score_ragged", "mi_pool_info_json", "mi_vina_set_ligand", "mi_vina_eval_batch",
     "mi_vina_bfgs_batch", "mi_vina_stream", "mi_vina_mc_batch", "mi_vina_ligand_heavy_atoms",
     "mi_vina_set_screen", "mi_vina_screen_size", "mi_vina_screen_dims", "mi_vina_mc_screen",
     "mi_vina_eval_screen", "mi_vina_refine_screen", "mi_vina_final_energies_screen",

@@ -1335,6 +1335,10 @@ struct Scorer {
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
+  // mi_debug_vox_stress: the quiet run's pooled grid, the mismatch log, the trap ring of a -DMI_VOX_TRAP build
+  DevBuf<unsigned> d_dbg_ref, d_dbg_trap;
+  DevBuf<int> d_dbg_log;
+  unsigned *dbg_trap = nullptr;         // handed to voxelize_tiles (VoxArgs::trap) while a stress run is on
   int dbg_cap = 0, dbg_nslab = 0;       // geometry of the last voxelize_chunk's candidate lists (mi_debug_read_candidates)
   int device = 0;                       // the HIP device the scorer was created on (device_call_lock)
   bool overlap = false;  // measured: no gain (conv blocks fill the LDS, the voxelizer waves cannot co-reside); MI_GNINA_OVERLAP=1 enables
@@ -1750,7 +1754,8 @@ static LigSetup setup_ligand(Scorer &s, const VoxGroup &g, const int32_t *lig_sm
 // gather + voxelize poses [b0, b0+nb) of the batch for one group. mode: 0 full grid, 1/2 pooled.
 static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, const float *d_lig_xyz, int L,
                            const float *d_centers_in, unsigned flags, int b0, int nb, int mode, float *out,
-                           unsigned char *argmax_out = nullptr, hipStream_t vs = nullptr, int set = 0, bool split = false) {
+                           unsigned char *argmax_out = nullptr, hipStream_t vs = nullptr, int set = 0, bool split = false,
+                           bool skip_gather = false) {
   if (!vs) vs = s.stream;
   DevBuf<AtomRec> &cand = set ? s.d_cand2 : s.d_cand;
   DevBuf<int> &cand_chan = set ? s.d_cand_chan2 : s.d_cand_chan;
@@ -1799,7 +1804,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.n_slab = n_slab;
   s.dbg_cap = cap, s.dbg_nslab = n_slab;
   ga.res = m->d.resolution;
-  {
+  if (!skip_gather) {  // (skipped only by mi_debug_vox_stress: the lists of the previous launch, untouched)
     ProfScope ps(s, "gather_pose_atoms", 0.0, (double)nb * (tr.n + ls.n_lig) * 36.0, nb, vs);
     launch_gather(ga, nb, vs);
   }
@@ -1821,6 +1826,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   va.qc = m->qc;
   va.out = out;
   va.argmax_out = argmax_out;
+  va.trap = s.dbg_trap;
   if (split) {  // the pooled grid in split format (Model::pooled_split_ok): whole octets, h | l halves
     MIG_CHECK(mode != 0 && !argmax_out, 2, "split-format voxel grid: pooled forward output only");
     va.split = 1;
@@ -2526,7 +2532,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     } guard{s, s.stream};
     // The programs are enqueued round robin, kLaneSlice steps of each model at a time: a launch costs the host ~4.4 us, a
     // Dense program has 18 of them, and enqueued one program after the other the second Dense lane started 80 us and the
-    // third lane 310 us behind the first (kernel trace, tools/experiments/r5_run57.sh).
+    // third lane 310 us behind the first (kernel trace, tools/experiments/r5_calls.sh 57).
     int kLaneSlice = 2;  // (MI_GNINA_LANE_SLICE: an experiment switch; a large value enqueues one program after the other)
     if (const char *ev = option(OPT_MI_GNINA_LANE_SLICE)) kLaneSlice = std::max(1, atoi(ev));
     int longest = 0;
@@ -2882,6 +2888,65 @@ mi_status mi_debug_read_candidates(mi_scorer *sc, int32_t *info, int32_t *counts
   MIG_HIP(hipMemcpy(counts, s.d_cand_n.p, s.dbg_nslab * sizeof(int), hipMemcpyDeviceToHost));
   if (chan) MIG_HIP(hipMemcpy(chan, s.d_cand_chan.p, n * sizeof(int), hipMemcpyDeviceToHost));
   if (rec) MIG_HIP(hipMemcpy(rec, s.d_cand.p, n * sizeof(AtomRec), hipMemcpyDeviceToHost));
+  return MI_OK;
+  MI_CATCH_STATUS
+}
+
+// Diagnostic (tools/experiments/vox_stress.py): gather + voxelize ONE pose `iters` times on the scorer's stream -- no
+// network behind it, no device_call_lock -- and compare the pooled grid of every iteration, on the device, with the one
+// this scorer produced when called with MI_STRESS_MAKE_REF (a quiet moment).  flags: 1 = make the reference and return,
+// 2 = gather only before the first iteration (the candidate lists are then never rewritten while the tiles run), 4 = fill
+// the grid with 0xFF bytes before every iteration (a lost store shows), 8 = hand the tile kernel a trap ring (a
+// -DMI_VOX_TRAP build reports into it; trap_out [1024][16] receives it).  log [log_cap][4]: row 0 = {differing dwords,
+// 0, workgroups of the compare kernel that saw one, 0}, then {iteration, dword index, got, want} per differing dword.
+mi_status mi_debug_vox_stress(mi_scorer *sc, const float *lig_xyz, const int32_t *lig_smt, int L, int iters, int flags,
+                              int32_t *log, int log_cap, uint32_t *trap_out) {
+  MI_TRY
+  MIG_CHECK(sc && lig_xyz && lig_smt && L > 0, 1, "NULL argument");
+  Scorer &s = *reinterpret_cast<Scorer *>(sc);
+  MIG_CHECK(s.have_receptor, 4, "mi_scorer_set_receptor must be called before scoring");
+  const VoxGroup &g = s.groups[0];
+  Model *m0 = s.models[g.first_model];
+  MIG_CHECK(m0->input_pool != 0, 1, "pooled-input models only");
+  set_call_capacity(s, 1, false);
+  s.d_lig.upload(lig_xyz, (size_t)L * 3, s.stream);
+  s.d_centers.ensure(3);
+  LigSetup ls = setup_ligand(s, g, lig_smt, L);
+  const BufDecl &ib = m0->d.bufs[m0->input_dst];
+  bool split = s.conv_path != 0 && s.precision != 1 && !option(OPT_MI_GNINA_H2_NO_SPLIT_TENSORS);
+  for (int mi : g.models) split = split && s.models[mi]->pooled_split_ok;
+  const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);
+  float *pooled = act_buf(s, kPooledSlot, pooled_n);
+  const size_t n_dw = (size_t)ib.S * ib.S * ib.S * (split ? m0->Cp8 : m0->buf_cp[m0->input_dst]);
+  s.d_dbg_ref.ensure(n_dw);
+  h2_flag_reset(s);
+  if (flags & 1) {
+    voxelize_chunk(s, g, ls, s.d_lig.p, L, nullptr, 0, 0, 1, m0->input_pool, pooled, nullptr, nullptr, 0, split);
+    MIG_HIP(hipMemcpyAsync(s.d_dbg_ref.p, pooled, n_dw * 4, hipMemcpyDeviceToDevice, s.stream));
+    MIG_HIP(hipStreamSynchronize(s.stream));
+    return MI_OK;
+  }
+  MIG_CHECK(log && log_cap >= 2 && iters >= 1, 1, "bad log / iteration arguments");
+  s.d_dbg_log.ensure((size_t)log_cap * 4);
+  MIG_HIP(hipMemsetAsync(s.d_dbg_log.p, 0, (size_t)log_cap * 16, s.stream));
+  struct TrapGuard {
+    Scorer &s;
+    ~TrapGuard() { s.dbg_trap = nullptr; }
+  } trap_guard{s};
+  if (flags & 8) {
+    s.d_dbg_trap.ensure(1024 * 16);
+    MIG_HIP(hipMemsetAsync(s.d_dbg_trap.p, 0, 1024 * 16 * 4, s.stream));
+    s.dbg_trap = s.d_dbg_trap.p;
+  }
+  for (int it = 0; it < iters; it++) {
+    if (flags & 4) MIG_HIP(hipMemsetAsync(pooled, 0xFF, n_dw * 4, s.stream));
+    voxelize_chunk(s, g, ls, s.d_lig.p, L, nullptr, 0, 0, 1, m0->input_pool, pooled, nullptr, nullptr, 0, split, (flags & 2) && it > 0);
+    launch_dword_compare(reinterpret_cast<const unsigned *>(pooled), s.d_dbg_ref.p, n_dw, it, s.d_dbg_log.p, log_cap, s.stream);
+    if ((it & 63) == 63) MIG_HIP(hipStreamSynchronize(s.stream));  // (a shallow queue: the launches stay B = 1-call shaped)
+  }
+  MIG_HIP(hipMemcpyAsync(log, s.d_dbg_log.p, (size_t)log_cap * 16, hipMemcpyDeviceToHost, s.stream));
+  if ((flags & 8) && trap_out) MIG_HIP(hipMemcpyAsync(trap_out, s.d_dbg_trap.p, 1024 * 16 * 4, hipMemcpyDeviceToHost, s.stream));
+  MIG_HIP(hipStreamSynchronize(s.stream));
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -82,6 +82,11 @@ struct VoxArgs {
   // timing experiments only (MI_VOX_DBG in a -DMI_VOX_TIMING build; wrong results): 1 = hits are found but not evaluated, 2 = flushes do no transpose /
   // pooling / staging, 4 = windows are not stored, 8 = no hit test (no hits)
   int dbg;
+  // -DMI_VOX_TRAP builds only (tools/experiments/vox_stress.py; nullptr otherwise and ignored by the product build): a ring
+  // of 16-dword records -- [0] = records written so far, record r at dwords 16 (r + 1) ... -- into which the tile kernel
+  // reports what must never happen: a hit whose channel is below the current one, a record that differs between the scalar
+  // and the vector load path, a window index outside the staged window, a damaged LDS canary
+  unsigned *trap;
 };
 
 struct VoxBackArgs {
@@ -107,5 +112,8 @@ void launch_gather(const GatherArgs &g, int B, hipStream_t s);
 // ([B][N/2]^3[Cp], fully written).
 void launch_voxelize(const VoxArgs &v, int B, int mode, hipStream_t s);
 void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream_t s);
+// diagnostic: dwords of got[] that differ from want[]: log[0] += their number, log[1] += 1 if any, and the first
+// (cap - 1) of them as {iter, index, got, want} from log[4] on
+void launch_dword_compare(const unsigned *got, const unsigned *want, size_t n, int iter, int *log, int cap, hipStream_t s);
 
 }  // namespace mig

@@ -239,8 +239,18 @@ __device__ __forceinline__ float div_rn(float a, float b, float y) {
 // "v = 0; if (...) v = ...; acc += v" the compiler emits a zero-initialisation and an add for every sub-block an atom
 // does not reach (five of eight on average), on a kernel whose time is its VALU instruction count.  Adding nothing and
 // adding +0 give the same bits (the accumulators are sums of non-negative terms and start at +0).
+#ifdef MI_VOX_TRAP
+#define VOX_TRAP_VIOL_PARAM , bool &viol
+#define VOX_TRAP_VIOL_ARG , viol
+#else
+#define VOX_TRAP_VIOL_PARAM
+#define VOX_TRAP_VIOL_ARG
+#endif
+#ifndef MI_VOX_FIX
+#define MI_VOX_FIX 0
+#endif
 __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
-                                            float qa, float qb, float qc) {
+                                            float qa, float qb, float qc VOX_TRAP_VIOL_PARAM) {
   // (round 5: straight-line inside the support test.  The kernel issues MORE scalar than vector instructions -- the
   // exec-mask bookkeeping of nested zone branches was 15 SALU instructions per evaluated sub-block next to 13 VALU -- and a
   // sub-block that an atom reaches almost always has lanes in both zones, so both sides ran anyway.  What is left: the
@@ -248,8 +258,19 @@ __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, flo
   // (a sub-block nobody reaches -- five of eight -- costs v_cmp + s_cbranch_vccz this way; "if (rsq < t2)" alone compiles to
   // s_and_saveexec, s_cbranch_execz and an s_or at the join)
   if (__builtin_amdgcn_ballot_w64(rsq < t2) == 0ull) return;
+#if MI_VOX_FIX == 3
+  asm volatile("s_nop 7");  // (experiment: wait states between the v_cmp and the s_and_saveexec that reads its mask)
+#else
   asm volatile("");
+#endif
   if (rsq < t2) {
+#ifdef MI_VOX_TRAP
+    {  // a lane in here whose own distance is outside the support: the exec mask is not the compare's result
+      float rsq_again = rsq;
+      asm volatile("s_nop 4\n\tv_mov_b32 %0, %0" : "+v"(rsq_again));
+      viol |= !(rsq_again < t2);
+    }
+#endif
     const bool gauss = rsq <= g2;
     // (the exponential only where a lane of the sub-block is in the Gaussian zone -- the shell between r and 1.5 r is 70 %
     // of an atom's support, and v_exp_f32 is a quarter-rate instruction; the empty asm keeps the compiler from turning
@@ -300,6 +321,26 @@ __device__ __forceinline__ unsigned vox_split1(float x) {
 #define VOX_DBG(bit) false
 #endif
 
+// -DMI_VOX_TRAP (a diagnostic build, tools/experiments/vox_stress.py): the tile kernel reports what must never happen into
+// VoxArgs::trap.  Record: kind, pose, tile, six words of detail, HW_ID, XCC_ID, s_memtime.
+#ifdef MI_VOX_TRAP
+constexpr int kVoxTrapPad = 64;  // canary dwords in front of and behind the kernel's LDS
+__device__ __forceinline__ void vox_trap(unsigned *ring, unsigned kind, unsigned pose, unsigned tile, unsigned a, unsigned b,
+                                         unsigned c, unsigned d, unsigned e, unsigned f) {
+  if (!ring || threadIdx.x != 0) return;
+  const unsigned slot = atomicAdd(ring, 1u);
+  if (slot >= 1023u) return;
+  unsigned *r = ring + 16 * (slot + 1);
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  r[0] = kind, r[1] = pose, r[2] = tile, r[3] = a, r[4] = b, r[5] = c, r[6] = d, r[7] = e, r[8] = f;
+  r[9] = __builtin_amdgcn_s_getreg(0xF804);   // HW_REG_HW_ID: wave / SIMD / CU / SH / SE ...
+  r[10] = __builtin_amdgcn_s_getreg(0xF814);  // HW_REG_XCC_ID
+  r[11] = (unsigned)t, r[12] = (unsigned)(t >> 32);
+}
+#else
+constexpr int kVoxTrapPad = 0;
+#endif
+
 // MODE 0: full grid [B][C][N][N][N]; 1: max-pooled, 2: avg-pooled, channels last.  SPLIT (pooled modes): VoxArgs::split.
 template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
@@ -327,11 +368,31 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
   // waves per SIMD decide.)
   // (split format: a window is whole octets -- one: 4 KB of LDS with the transpose buffer, like the fp32 windows' 5 KB)
   constexpr int kWin = SPLIT ? kVoxSplitWin : 12;
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [64][kWin] (+ transpose buffer, arg-max bytes)
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];  // [64][kWin] (+ transpose buffer, arg-max bytes)
+  float *const s_stage = s_lds + kVoxTrapPad;
   const int Cp = v.Cp;
   const int nwin = (Cp + kWin - 1) / kWin;
   float *s_tr = s_stage + 64 * kWin;                                            // [8 sub-blocks][kTrStride] (see tr_put below)
   unsigned char *s_arg = reinterpret_cast<unsigned char *>(s_tr + kVoxTrFloats); // [64][kWin], only if argmax_out
+#ifdef MI_VOX_TRAP
+  // canaries: 64 dwords in front of the stage and 64 behind the transpose buffer (split builds: no arg-max bytes)
+  unsigned *const s_can0 = reinterpret_cast<unsigned *>(s_lds), *const s_can1 = reinterpret_cast<unsigned *>(s_tr + kVoxTrFloats);
+  if constexpr (SPLIT) {
+    s_can0[lane] = 0xC0DE0000u | (unsigned)lane;
+    s_can1[lane] = 0xCAFE0000u | (unsigned)lane;
+  }
+  auto check_canaries = [&](unsigned where) {
+    if constexpr (SPLIT) {
+      const unsigned a0 = s_can0[lane], a1 = s_can1[lane];
+      const unsigned long long bad0 = __ballot(a0 != (0xC0DE0000u | (unsigned)lane)), bad1 = __ballot(a1 != (0xCAFE0000u | (unsigned)lane));
+      if (bad0 | bad1) {
+        const int l0 = bad0 ? __builtin_ctzll(bad0) : 0, l1 = bad1 ? __builtin_ctzll(bad1) : 0;
+        vox_trap(v.trap, 3u, blockIdx.x, where, (unsigned)bad0, (unsigned)(bad0 >> 32), (unsigned)bad1, (unsigned)(bad1 >> 32),
+                 (unsigned)__builtin_amdgcn_readlane((int)a0, l0), (unsigned)__builtin_amdgcn_readlane((int)a1, l1));
+      }
+    }
+  };
+#endif
   // The transpose buffer, bank-conflict free in both directions (round 5; the [lane][8] layout cost 4 LDS cycles per
   // ds_read_b32 lane group instead of 1 -- SQ_LDS_BANK_CONFLICT was 0.68 of the kernel's LDS-active cycles, next to a VALU
   // 76 % busy).  Writer lane L = lx + 4 ly + 16 lz puts acc[k] at dword  kVoxTrStride k + F(k, L) + L,
@@ -404,6 +465,9 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     }
     __builtin_amdgcn_s_waitcnt(0);  // wave-synchronous: the LDS writes of flush() complete before the reads
     __builtin_amdgcn_wave_barrier();
+#ifdef MI_VOX_TRAP
+    check_canaries(0x100u + (unsigned)cur_w);
+#endif
     const int S = v.N / 2;
     const int c0 = cur_w * kWin;
     // (uniform 64-bit base of the pose + a 32-bit offset inside it -- a pooled pose is at most 48^3 x 36 floats: the
@@ -511,6 +575,9 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
         asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m1), "v"(m2));
       }
       while (cur_w < c / kWin) emit_window();
+#ifdef MI_VOX_TRAP
+      if (c - cur_w * kWin < 0 || c - cur_w * kWin >= kWin) vox_trap(v.trap, 5u, blockIdx.x, (unsigned)tile_id, (unsigned)c, (unsigned)cur_w, (unsigned)cur, 0u, 0u, 0u);
+#endif
       stage_put(c - cur_w * kWin, m);
       if (!SPLIT && v.argmax_out) s_arg[lane * kWin + (c - cur_w * kWin)] = (unsigned char)am;
     } else {
@@ -539,19 +606,41 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
     // evaluated
     f32x8 rec_n = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
     int c_n = -1;
+#ifdef MI_VOX_TRAP
+    unsigned i_n = 0u;
+#endif
     // (byte offsets in 32 bits: s_load with an SGPR offset instead of two 64-bit shift-and-add sequences per hit)
     typedef const __attribute__((address_space(4))) char *ConstBytePtr;
     auto fetch = [&](int src) {
       const unsigned i = (unsigned)(base + src);
       rec_n = *(ConstRecPtr)((ConstBytePtr)candc + (i << 5));
       c_n = *(ConstIntPtr)((ConstBytePtr)chanc + (i << 2));
+#ifdef MI_VOX_TRAP
+      i_n = i;
+#endif
     };
     if (mask) fetch(__builtin_ctzll(mask));
     while (mask) {
       mask &= mask - 1;
       const f32x8 rec = rec_n;
       const int c = c_n;
+#ifdef MI_VOX_TRAP
+      {
+        const unsigned i_cur = i_n;
+        // the same record through the vector path, past the non-coherent caches (agent-scope atomic loads: sc1)
+        const int c_vec = __hip_atomic_load(cand_chan + i_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned x_vec = __hip_atomic_load(reinterpret_cast<const unsigned *>(cand + i_cur), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t2_vec = __hip_atomic_load(reinterpret_cast<const unsigned *>(cand + i_cur) + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool differ = c_vec != c || x_vec != __float_as_uint(rec[0]) || t2_vec != __float_as_uint(rec[4]);
+        if (__ballot(differ) != 0ull)
+          vox_trap(v.trap, 2u, blockIdx.x, (unsigned)tile_id, i_cur, (unsigned)c, (unsigned)__builtin_amdgcn_readfirstlane(c_vec), __float_as_uint(rec[0]),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)x_vec), (unsigned)n);
+        if (c < cur) vox_trap(v.trap, 1u, blockIdx.x, (unsigned)tile_id, i_cur, (unsigned)c, (unsigned)cur, (unsigned)cur_w, (unsigned)__builtin_amdgcn_readfirstlane(c_vec), (unsigned)n);
+      }
+#endif
+#if MI_VOX_FIX != 5
       if (mask) fetch(__builtin_ctzll(mask));
+#endif
       const float ax = rec[0], ay = rec[1], az = rec[2], ar = rec[3], t2 = rec[4], g2 = rec[5], kexp = rec[6],
                   inv_ar = rec[7];
       if (c != cur) {
@@ -564,26 +653,71 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
       // squared distances of this lane's eight voxels, two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations
       // as the scalar forms, in the same order -- (dx^2 + dy^2) + dz^2 -- at half the instruction count; the kernel's time
       // is its VALU instruction count)
+#ifdef MI_VOX_TRAP
+      bool viol = false;
+#endif
+#if MI_VOX_FIX == 1
+      // (experiment: the same IEEE operations without the packed instructions)
+      float dx2[2], dy2[2], dz2[2];
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const float ddx = gx[d] - ax, ddy = gy[d] - ay, ddz = gz[d] - az;
+        dx2[d] = ddx * ddx, dy2[d] = ddy * ddy, dz2[d] = ddz * ddz;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+          for (int dz = 0; dz < 2; dz++)
+            density_add(acc[dx * 4 + dy * 2 + dz], (dx2[dx] + dy2[dy]) + dz2[dz], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc VOX_TRAP_VIOL_ARG);
+#else
       const vox_f32x2 gx2 = {gx[0], gx[1]}, gy2 = {gy[0], gy[1]}, gz2 = {gz[0], gz[1]};
+#if MI_VOX_FIX == 4
+      // (experiment: the atom's coordinates in VGPRs -- no packed instruction reads an SGPR)
+      float axv, ayv, azv;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(axv) : "s"(ax));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(ayv) : "s"(ay));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(azv) : "s"(az));
+      const vox_f32x2 ax2 = {axv, axv}, ay2 = {ayv, ayv}, az2 = {azv, azv};
+#else
       const vox_f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+#endif
       vox_f32x2 dxx = gx2 - ax2, dyy = gy2 - ay2, dzz = gz2 - az2;
       dxx = dxx * dxx, dyy = dyy * dyy, dzz = dzz * dzz;
       const vox_f32x2 dy0 = {dyy[0], dyy[0]}, dy1 = {dyy[1], dyy[1]}, dz0 = {dzz[0], dzz[0]}, dz1 = {dzz[1], dzz[1]};
       const vox_f32x2 xy0 = dxx + dy0, xy1 = dxx + dy1;          // [dx] for dy = 0 / 1
-      const vox_f32x2 r00 = xy0 + dz0, r01 = xy0 + dz1, r10 = xy1 + dz0, r11 = xy1 + dz1;  // r<dy><dz>[dx]
+      vox_f32x2 r00 = xy0 + dz0, r01 = xy0 + dz1, r10 = xy1 + dz0, r11 = xy1 + dz1;  // r<dy><dz>[dx]
+#if MI_VOX_FIX == 2
+      asm volatile("s_nop 7" : "+v"(r00), "+v"(r01), "+v"(r10), "+v"(r11));  // (experiment: the packed results have landed before any compare reads them)
+#endif
 #pragma unroll
       for (int dx = 0; dx < 2; dx++) {
-        density_add(acc[dx * 4 + 0], r00[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
-        density_add(acc[dx * 4 + 1], r01[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
-        density_add(acc[dx * 4 + 2], r10[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
-        density_add(acc[dx * 4 + 3], r11[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc);
+        density_add(acc[dx * 4 + 0], r00[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc VOX_TRAP_VIOL_ARG);
+        density_add(acc[dx * 4 + 1], r01[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc VOX_TRAP_VIOL_ARG);
+        density_add(acc[dx * 4 + 2], r10[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc VOX_TRAP_VIOL_ARG);
+        density_add(acc[dx * 4 + 3], r11[dx], t2, g2, kexp, ar, inv_ar, v.qa, v.qb, v.qc VOX_TRAP_VIOL_ARG);
       }
+#endif
+#if MI_VOX_FIX == 5
+      if (mask) fetch(__builtin_ctzll(mask));  // (experiment: no scalar load in flight while the packed instructions run)
+#endif
+#ifdef MI_VOX_TRAP
+      {
+        const unsigned long long vm = __ballot(viol);
+        if (vm) vox_trap(v.trap, 9u, blockIdx.x, (unsigned)tile_id, (unsigned)vm, (unsigned)(vm >> 32), (unsigned)c, (unsigned)cur_w, 0u, (unsigned)n);
+      }
+#endif
     }
   }
   flush(cur);
 
   if (MODE != 0)
     while (cur_w < nwin) emit_window();  // the last window, and windows no atom of this tile belongs to (zeros)
+#ifdef MI_VOX_TRAP
+  check_canaries(0x200u);
+  if (MODE != 0 && cur_w != nwin) vox_trap(v.trap, 8u, blockIdx.x, (unsigned)tile_id, (unsigned)cur_w, (unsigned)nwin, (unsigned)cur, 0u, 0u, 0u);
+#endif
   if constexpr (SPLIT)
     if (v.overflow && __ballot(ovf) != 0ull && lane == 0) atomicOr(v.overflow, 1u);
 }
@@ -690,6 +824,26 @@ void launch_voxel_backward(const VoxBackArgs &a, int B, int pool_mode, hipStream
     hipLaunchKernelGGL(voxel_backward_kernel<0>, grid, block, 0, s, a);
 }
 
+// diagnostic (mi_debug_vox_stress): see voxelize.h
+__global__ void dword_compare_kernel(const unsigned *got, const unsigned *want, size_t n, int iter, int *log, int cap) {
+  bool any = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned a = got[i], b = want[i];
+    if (a != b) {
+      any = true;
+      const int k = atomicAdd(log, 1);
+      if (k < cap - 1) {
+        int *e = log + 4 * (k + 1);
+        e[0] = iter, e[1] = (int)i, e[2] = (int)a, e[3] = (int)b;
+      }
+    }
+  }
+  if (__syncthreads_or(any) && threadIdx.x == 0) atomicAdd(log + 2, 1);  // workgroups that saw a difference
+}
+void launch_dword_compare(const unsigned *got, const unsigned *want, size_t n, int iter, int *log, int cap, hipStream_t s) {
+  hipLaunchKernelGGL(dword_compare_kernel, dim3(64), dim3(256), 0, s, got, want, n, iter, log, cap);
+}
+
 void launch_gather(const GatherArgs &g, int B, hipStream_t s) {
   if (B <= 64)
     hipLaunchKernelGGL(gather_pose_atoms<1024>, dim3(B), dim3(1024), 0, s, g);
@@ -705,10 +859,10 @@ void launch_voxelize(const VoxArgs &v_in, int B, int mode, hipStream_t s) {
   if (mode == 0) {
     hipLaunchKernelGGL(voxelize_tiles<0>, grid, block, 0, s, v);
   } else {
-    size_t lds = (size_t)64 * 12 * sizeof(float) + kVoxTrFloats * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0);  // kWin = 12
+    size_t lds = (size_t)64 * 12 * sizeof(float) + kVoxTrFloats * sizeof(float) + (v.argmax_out ? (size_t)64 * 12 : 0) + kVoxTrapPad * sizeof(float);  // kWin = 12
     if (option(OPT_MI_VOX_LDS_PAD)) lds += (size_t)atoi(option(OPT_MI_VOX_LDS_PAD)) * 1024;  // occupancy experiment
     if (v.split) {
-      lds = (size_t)64 * kVoxSplitWin * sizeof(float) + kVoxTrFloats * sizeof(float);
+      lds = (size_t)64 * kVoxSplitWin * sizeof(float) + kVoxTrFloats * sizeof(float) + 2 * kVoxTrapPad * sizeof(float);
       if (mode == 1) hipLaunchKernelGGL((voxelize_tiles<1, true>), grid, block, lds, s, v);
       else hipLaunchKernelGGL((voxelize_tiles<2, true>), grid, block, lds, s, v);
     } else if (mode == 1)

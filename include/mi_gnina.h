@@ -177,6 +177,14 @@ mi_status mi_debug_read_activation(mi_scorer *, int model_index, int buf, int B,
  * {n_slab, cap}; counts[n_slab]; chan[n_slab][cap] (channel of every candidate, ascending per list); rec[n_slab][cap][8]
  * (x y z radius and the density constants).  Pass NULL arrays to query info only.  tools/experiments/concurrency_diag3.py. */
 mi_status mi_debug_read_candidates(mi_scorer *, int32_t *info, int32_t *counts, int32_t *chan, float *rec);
+/* Diagnostic (tools/experiments/vox_stress.py; round 6's hunt for what a second hardware queue does to the voxelizer):
+ * gather + voxelize ONE pose `iters` times on the scorer's stream, nothing else, and compare every iteration's pooled grid on
+ * the device with the grid a call with flag 1 recorded.  flags: 1 = record the reference grid and return; 2 = gather only
+ * before the first iteration; 4 = fill the grid with 0xFF bytes before every iteration; 8 = hand the tile kernel a trap
+ * ring (a -DMI_VOX_TRAP build of voxelize.hip reports into it) and copy it to trap_out [1024][16].  log [log_cap][4]: row 0 =
+ * {differing dwords, 0, compare workgroups that saw one, 0}, then {iteration, dword index, got, want}. */
+mi_status mi_debug_vox_stress(mi_scorer *, const float *lig_xyz, const int32_t *lig_smt, int L, int iters, int flags,
+                              int32_t *log, int log_cap, uint32_t *trap_out);
 /* Virtual screening (1 receptor x many ligands): B poses that may each belong to a
  * different ligand, in one batch.  lig_xyz [B][Lmax][3], lig_smt [B][Lmax]: pose b's atoms are the leading
  * rows with smt >= 0, the remaining rows are padding (smt = -1, coordinates ignored).  Everything else as
