@@ -15,8 +15,18 @@ SOURCES = ["engine.cpp", "options.cpp", "model.cpp", "typer.cpp", "voxelize.hip"
            "../host/typed_atoms.cpp", "../host/pdbqt.cpp"]
 # -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
 # bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).
+# -target-feature -packed-fp32-ops: NO packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in any
+# kernel of the library.  Round 6 (DESIGN.md "concurrency"): a chain of dependent packed-fp32 instructions gives wrong
+# results in the upper half of a wavefront (lanes 32-63) in a few launches per thousand while another queue's Dense conv
+# kernels share the SIMD -- what made voxelize_tiles deviate next to a second scorer; reproduced with a synthetic victim
+# (tools/microbench/pk_f32_next_to_mfma.hip) next to the real aggressor.  The same arithmetic in scalar fp32 instructions is
+# clean (0 of 50,000 launches) and costs nothing measurable (voxelizer 0.872 -> 0.871 ms, headline / Dense / fp32-MFMA
+# unchanged: tools/experiments/r6_conc5.sh), so the instruction class is off for every translation unit: the conv epilogues
+# and the Vina kernels used it too and may run next to another scorer's kernels just the same.  (The flag reaches the host
+# compilation as well, which reports it as unknown: filtered below.)  tests/test_cabi_cpu.py disassembles the library.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-x", "hip"]
+         "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-x", "hip"]
+_HOST_NOISE = "is not a recognized feature for this target (ignoring feature)"
 
 
 def hipcc():
@@ -54,7 +64,12 @@ def build(force=False, verbose=False):
         def one(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            err = "\n".join(l for l in r.stderr.splitlines() if _HOST_NOISE not in l)
+            if err.strip():
+                print(err, file=sys.stderr, flush=True)
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
 
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(one, todo))

@@ -45,32 +45,37 @@ void process_env_once() {
   });
 }
 
-// One CNN scoring call at a time per device.  gnina itself scores under DLScorer::mtx -- one recursive mutex shared by a
-// scorer and all its copies ("todo, enable parallel scoring", dl_scorer.h:26, cnn_torch_scorer.cpp:106) -- so the seam never
-// sees two calls in flight; callers of the C ABI may, and on MI355X two scorers' kernels running side by side on two
-// hardware queues do NOT give the bits each gives alone: measured round 5 (tools/experiments/concurrency_diag*.py) -- with a
-// Dense model on a second host thread ~5 % of the B = 1 calls of the first deviate by up to 3e-2 in the affinity; the
-// candidate lists are the quiet run's, the pooled voxel grid is not (a few cells whose accumulation saw another order);
-// GPU_MAX_HW_QUEUES=1 or this lock give 0 of 1,200 (what deviates is a voxelizer next to another queue's LDS-DMA conv
-// workgroups; conv programs side by side are clean: the lanes below).  Host-output calls hold the lock until their results are back;
-// device-output calls (MI_OUT_ON_DEVICE, the pools: one worker per device) only while they enqueue.
+// Scoring calls of different scorers on one device run side by side (each scorer on its own stream, driven by its own host
+// thread) -- which is how gnina drives the seam: fresh_copy() hands every worker thread and every Monte-Carlo task a NEW
+// CNNTorchScorer with a NEW mutex (cnn_torch_scorer.h:54, dl_scorer.h:43-44, main.cpp:1436-1438, parallel_mc.cpp:145-146).
+//
+// Rounds 5 took a per-device lock here because two scorers on two hardware queues did not reproduce their single-thread
+// bits (~5 % of B = 1 calls, up to 6e-2 in the affinity).  Round 6 found what deviated and why the lock only hid it (DESIGN
+// "concurrency"): voxelize_tiles' squared distances, formed with PACKED-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32), came
+// out wrong in the upper half of a wavefront (lanes 32-63) in ~2 % of its launches whenever the Dense family's f16-MFMA conv
+// K loops shared the SIMDs -- lanes outside an atom's support then passed the range test and added e^-2 (2 d/r - 3)^2.
+// Evidence: the voxelizer alone as the victim (mi_debug_vox_stress, every launch compared on the device), an in-kernel
+// trap that cleared the lists / the scalar loads / the LDS / the exec mask, and builds of the kernel that differ in one thing:
+// without packed-fp32 instructions 0 of 50,000 launches and 0 of 9,000 two-thread calls deviate, with them (any operand
+// form, scalar load in flight or not, wait states added) ~1.4-2 %.  voxelize.hip is therefore compiled without them
+// (gnina_amd/build.py, tests/test_cabi_cpu.py checks the device code).  MI_GNINA_CALL_LOCK=1 brings the old serialisation
+// back for A/B measurements; nothing depends on it.
 static std::recursive_mutex &device_call_lock(int device) {
   static std::recursive_mutex locks[64];
-  // (MI_GNINA_NO_CALL_LOCK=1, a diagnostic for tools/experiments/concurrency_diag*.py: every call gets a lock of its own)
-  if (option(OPT_MI_GNINA_NO_CALL_LOCK)) {
-    static thread_local std::recursive_mutex own;
+  if (!option(OPT_MI_GNINA_CALL_LOCK) || atoi(option(OPT_MI_GNINA_CALL_LOCK)) == 0) {
+    static thread_local std::recursive_mutex own;  // (no serialisation: a lock nobody else takes)
     return own;
   }
   return locks[device >= 0 && device < 64 ? device : 0];
 }
 
-// The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: calls are serialised per device, so
-// one set is enough -- and a set per scorer is harmful: four scorers x three priority streams oversubscribe the hardware
+// The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: a set per scorer is harmful -- four
+// scorers x three priority streams oversubscribe the hardware
 // queues and the runtime time-slices them (gnina's default ensemble from four threads: 777 -> 110 poses/s).  One stream
 // priority per lane, cycling through the device's range: the HIP runtime keeps a pool of hardware queues per priority, so
 // lanes of different priority never share a hardware queue.  (With plain streams and the default four queues per pool, two
 // of the three lanes of gnina's default ensemble landed on one queue and ran one after the other: 1,289 us per B = 1 call
-// against 726 us with GPU_MAX_HW_QUEUES=8, 717 us with priorities.)  Called under device_call_lock; never destroyed.
+// against 726 us with GPU_MAX_HW_QUEUES=8, 717 us with priorities.)  Thread-safe; never destroyed.
 static hipStream_t device_lane_stream(int device, int k) {
   static std::mutex mu;
   static std::vector<hipStream_t> pool[64];
@@ -1325,8 +1330,6 @@ struct Scorer {
   DevBuf<unsigned char> d_lig_typed;
   DevBuf<AtomRec> d_cand, d_cand2;
   DevBuf<int> d_cand_chan2, d_cand_n2;
-  hipStream_t vox_stream = nullptr;     // voxelization of chunk i+1 overlaps the CNN of chunk i (VALU vs MFMA pipes)
-  hipEvent_t ev_vox_done[2] = {nullptr, nullptr}, ev_cnn_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
   // Small calls of an ensemble (gnina scores ONE pose per DLScorer::score call, torch_model.cpp:179; the default ensemble is
   // three models): every model's layer program runs on its own stream ("lane") off the voxelization on the main stream, with
   // its own set of activation buffers (act_lane) -- the launches of a B = 1 program are latency, not throughput, and three
@@ -1335,13 +1338,14 @@ struct Scorer {
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
+  size_t centers_stride = 0;            // lanes: voxel group 1 writes its grid centres behind group 0's (voxelize_chunk)
+  std::vector<int> last_lane;           // per model: the set its last forward program wrote (mi_debug_read_activation)
   // mi_debug_vox_stress: the quiet run's pooled grid, the mismatch log, the trap ring of a -DMI_VOX_TRAP build
   DevBuf<unsigned> d_dbg_ref, d_dbg_trap;
   DevBuf<int> d_dbg_log;
   unsigned *dbg_trap = nullptr;         // handed to voxelize_tiles (VoxArgs::trap) while a stress run is on
   int dbg_cap = 0, dbg_nslab = 0;       // geometry of the last voxelize_chunk's candidate lists (mi_debug_read_candidates)
-  int device = 0;                       // the HIP device the scorer was created on (device_call_lock)
-  bool overlap = false;  // measured: no gain (conv blocks fill the LDS, the voxelizer waves cannot co-reside); MI_GNINA_OVERLAP=1 enables
+  int device = 0;                       // the HIP device the scorer was created on
   // activations: one set of buffers sized for `chunk` poses, shared by all models (max size per id)
   std::vector<std::unique_ptr<DevBuf<float>>> act;
   std::vector<std::unique_ptr<DevBuf<float>>> gact;            // gradients w.r.t. the activation buffers
@@ -1408,17 +1412,11 @@ struct Scorer {
       (void)hipEventDestroy(r.e1);
     }
     for (auto &e : ev_pool) (void)hipEventDestroy(e);
-    for (auto &e : ev_vox_done)
-      if (e) (void)hipEventDestroy(e);
-    for (auto &e : ev_cnn_done)
-      if (e) (void)hipEventDestroy(e);
-    if (ev_inputs) (void)hipEventDestroy(ev_inputs);
     for (auto &e : lane_done)
       if (e) (void)hipEventDestroy(e);
     for (auto &e : lane_start)
       if (e) (void)hipEventDestroy(e);
     if (h_out4) (void)hipHostFree(h_out4);
-    if (vox_stream) (void)hipStreamDestroy(vox_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -1471,7 +1469,7 @@ static unsigned long long *prof_counter(Scorer &s, ProfScope &ps) {
 }
 
 constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
-constexpr size_t kPooledSlot2 = 4096;  // second pooled-grid buffer of the two-stream pipeline
+constexpr size_t kPooledSlot2 = 4096;  // pooled grid of an ensemble's second voxel group when its models run on lanes
 constexpr size_t kLaneSlots = 64;      // activation buffer ids per lane (Scorer::act_lane): set l owns slots [64 l, 64 l + 64)
 
 // Poses per launch for a call on B poses: the user's chunk, clipped to B and to an activation-memory budget
@@ -1796,7 +1794,7 @@ static void voxelize_chunk(Scorer &s, const VoxGroup &g, const LigSetup &ls, con
   ga.rot = s.cur_rot ? s.cur_rot + (size_t)b0 * 4 : nullptr;
   ga.center_typed_only = (flags & MI_CENTER_TYPED_ONLY) ? 1 : 0;
   ga.half_dim = m->d.dimension / 2.0f;
-  ga.centers_out = s.d_centers.p + (size_t)b0 * 3;
+  ga.centers_out = s.d_centers.p + (size_t)set * s.centers_stride + (size_t)b0 * 3;
   ga.cand = cand.p;
   ga.cand_chan = cand_chan.p;
   ga.cand_n = cand_n.p;
@@ -1927,6 +1925,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   }
   const bool bf16 = use_bf16(s, *m, grad);
   const std::vector<Step> &steps = program_steps(s, *m, grad);
+  if (s.last_lane.size() < s.models.size()) s.last_lane.resize(s.models.size(), 0);
+  s.last_lane[mi] = s.act_lane;
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
     const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
@@ -2446,15 +2446,18 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   // Lanes (Scorer::lane_streams): a small call of an ensemble runs every model's program on its own stream.
   int lanes_max_b = 8;
   if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
-  // On by default (MI_GNINA_LANES=0 or MI_GNINA_NO_LANES=1: one stream).  What must never run side by side on this chip is
-  // a voxelizer and another queue's LDS-DMA conv workgroups (device_call_lock); the lanes start after every group's grid is
-  // voxelized and run conv programs only: 1,800 B = 1 calls of three ensembles, every one the serial call's bits
-  // (tools/experiments/lanes_diag3.py), gnina's default ensemble 1,260 -> 717 us per B = 1 call.
+  // On by default (MI_GNINA_LANES=0 or MI_GNINA_NO_LANES=1: one stream).  Every group's grid is voxelized first (main stream),
+  // then every model's program starts on its own stream: 1,800 B = 1 calls of three ensembles, every one the serial call's
+  // bits (tools/experiments/lanes_diag3.py), gnina's default ensemble 1,260 -> 717 us per B = 1 call.
   const bool lanes_on = !option(OPT_MI_GNINA_LANES) || atoi(option(OPT_MI_GNINA_LANES)) != 0;
-  // (at most two voxel groups: one pooled slot each, all voxelized BEFORE the first lane starts -- a voxelizer running next to
-  // another queue's LDS-DMA conv workgroups is the combination that deviates, conv kernels side by side are not)
+  // (at most two voxel groups: one pooled slot each)
+  // (a lane's activation set is slots [64 l, 64 l + 64): a model with more buffers than that -- the generic converter emits one
+  // per conv / pool output -- would run into the next lane's set, and lane 64 into kPooledSlot2: such ensembles take one stream)
+  size_t max_bufs = 0;
+  for (Model *m : s.models) max_bufs = std::max(max_bufs, m->d.bufs.size());
+  const bool lane_slots_ok = max_bufs <= kLaneSlots && ((size_t)nm + 1) * kLaneSlots <= kPooledSlot2;
   const bool lanes = lanes_on && nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) &&
-                     !(s.overlap && B > s.cap) && s.groups.size() <= 2;
+                     s.groups.size() <= 2 && lane_slots_ok;
   struct LaneJob {
     int gi;
     size_t slot;
@@ -2468,63 +2471,62 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       s.lane_done.push_back(e);
     }
-    while (s.lane_start.size() < s.groups.size()) {
+    while (s.lane_start.size() < s.groups.size() + 1) {  // one per voxel group + "the call's inputs are uploaded"
       hipEvent_t e = nullptr;
       MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       s.lane_start.push_back(e);
     }
   }
+  // the ligand's description per voxel group first (cached per group; a miss uploads on the main stream and waits)
+  // (a ragged batch's per-pose arrays are one set per scorer: its groups are set up and voxelized one after the other)
+  std::vector<LigSetup> lsv;
+  if (!ragged)
+    for (const VoxGroup &g : s.groups) lsv.push_back(setup_ligand(s, g, lig_smt, L));
+  // Lanes: the groups are voxelized SIDE BY SIDE -- group 0 on the main stream, group 1 on the lane of its first model, each
+  // into its own pooled slot / candidate lists / occupancy bytes / centres -- and a model's lane starts behind ITS group's grid
+  // (round 6: a voxelizer may run next to conv kernels; until then every grid was voxelized before the first lane started, and
+  // a B = 1 call of gnina's default ensemble spent 230 us in two gathers and two voxelizations one after the other).
+  s.centers_stride = lanes ? (size_t)B * 3 : 0;
+  if (lanes) {
+    s.d_centers.ensure((size_t)2 * B * 3);
+    MIG_HIP(hipEventRecord(s.lane_start[s.groups.size()], s.stream));
+  }
   int gi = -1;
   for (const VoxGroup &g : s.groups) {
     gi++;
     Model *m0 = s.models[g.first_model];
-    LigSetup ls = ragged ? setup_ligand_ragged(s, g, lig_smt, B, L) : setup_ligand(s, g, lig_smt, L);
+    const LigSetup ls = ragged ? setup_ligand_ragged(s, g, lig_smt, B, L) : lsv[gi];
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
-    // Two-stream pipeline: chunk i+1 is voxelized (VALU-bound) on vox_stream while the CNN of chunk i
-    // (MFMA-bound) runs on the main stream; the pooled grid and candidate lists are double buffered.
     const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);
-    const bool ov = s.overlap && B > s.cap;
     // the pooled grid goes out in split format when every model of the group reads it with a split-fp16 first conv
     bool split = s.conv_path != 0 && s.precision != 1 && !option(OPT_MI_GNINA_H2_NO_SPLIT_TENSORS);
     for (int mi : g.models) split = split && s.models[mi]->pooled_split_ok;
-    if (ov) {
-      MIG_HIP(hipEventRecord(s.ev_inputs, s.stream));  // ligand / centre uploads are visible to vox_stream
-      MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_inputs, 0));
-    }
-    int ci = 0;
-    for (int b0 = 0; b0 < B; b0 += s.cap, ci++) {
+    for (int b0 = 0; b0 < B; b0 += s.cap) {
       const int nb = std::min(s.cap, B - b0);
-      // (lanes: group gi voxelizes into slot / candidate / occupancy set gi, on the main stream, one group after the other)
-      const int set = lanes ? (gi & 1) : ov ? (ci & 1) : 0;
+      const int set = lanes ? (gi & 1) : 0;
       const size_t slot = set ? kPooledSlot2 : kPooledSlot;
       float *pooled = act_buf(s, slot, pooled_n);
-      if (ov) {
-        if (ci >= 2) MIG_HIP(hipStreamWaitEvent(s.vox_stream, s.ev_cnn_done[set], 0));  // buffer set free again
-        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, s.vox_stream, set, split);
-        MIG_HIP(hipEventRecord(s.ev_vox_done[set], s.vox_stream));
-        MIG_HIP(hipStreamWaitEvent(s.stream, s.ev_vox_done[set], 0));
-      } else {
-        if (m0->input_pool == 0)
-          MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
-        voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, nullptr, 0, split);
+      hipStream_t vs = s.stream;
+      if (lanes && gi > 0 && !ragged) {
+        vs = s.lane_streams[g.first_model];
+        MIG_HIP(hipStreamWaitEvent(vs, s.lane_start[s.groups.size()], 0));
       }
+      if (m0->input_pool == 0)
+        MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), vs));
+      voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, nullptr, vs, set, split);
       if (lanes) {
+        MIG_HIP(hipEventRecord(s.lane_start[gi], vs));
         lane_jobs.push_back(LaneJob{gi, slot, split});  // (B <= cap: one chunk per group)
       } else {
         for (int mi : g.models)
           run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
                       s.d_loss_m.p + (size_t)mi * B + b0, false, slot, split);
       }
-      if (ov) MIG_HIP(hipEventRecord(s.ev_cnn_done[set], s.stream));
-    }
-    if (ov) {  // the next group's ligand set-up rewrites buffers the voxelizer reads
-      MIG_HIP(hipStreamSynchronize(s.vox_stream));
     }
   }
   if (lanes) {
-    // every grid is voxelized: now every model's program on its own stream
+    // now every model's program on its own stream, behind its group's grid
     // (every buffer a program touches is allocated before its first launch: a grow-only buffer must not move under a lane)
-    MIG_HIP(hipEventRecord(s.lane_start[0], s.stream));
     struct LaneGuard {  // run_program launches on s.stream into buffer set s.act_lane
       Scorer &s;
       hipStream_t main;
@@ -2538,7 +2540,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     int longest = 0;
     for (const LaneJob &job : lane_jobs)
       for (int mi : s.groups[job.gi].models) {
-        MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[0], 0));
+        MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[job.gi], 0));
         Model &m = *s.models[mi];
         longest = std::max(longest, m.overlap ? 1 : (int)program_steps(s, m, false).size());
       }
@@ -2749,11 +2751,6 @@ mi_scorer *mi_scorer_create(mi_model *const *models, int n_models) {
   }
   MIG_HIP(hipGetDevice(&s->device));
   MIG_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  MIG_HIP(hipStreamCreateWithFlags(&s->vox_stream, hipStreamNonBlocking));
-  for (auto &e : s->ev_vox_done) MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &e : s->ev_cnn_done) MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  MIG_HIP(hipEventCreateWithFlags(&s->ev_inputs, hipEventDisableTiming));
-  if (const char *e = option(OPT_MI_GNINA_OVERLAP)) s->overlap = atoi(e) != 0;
   build_groups(*s);
   return reinterpret_cast<mi_scorer *>(s.release());
   MI_CATCH_NULL
@@ -2854,7 +2851,8 @@ mi_status mi_debug_read_activation(mi_scorer *sc, int mi, int buf, int B, int32_
   if (!out) return MI_OK;
   const size_t S3 = (size_t)bd.S * bd.S * bd.S;
   MIG_CHECK(B >= 1 && B <= s.cap && out_floats >= (size_t)B * S3 * bd.C, 1, "bad batch / output size");
-  const size_t slot = pooled ? kPooledSlot : (size_t)buf;
+  // (a call that ran on lanes wrote this model's buffers into its lane's set)
+  const size_t slot = pooled ? kPooledSlot : (size_t)buf + (size_t)(mi < (int)s.last_lane.size() ? s.last_lane[mi] : 0) * kLaneSlots;
   MIG_CHECK(slot < s.act.size() && s.act[slot] && s.act[slot]->n >= (size_t)B * S3 * cs, 2, "buffer not allocated by a forward call");
   MIG_HIP(hipStreamSynchronize(s.stream));
   std::vector<float> raw((size_t)B * S3 * cs);

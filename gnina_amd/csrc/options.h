@@ -28,7 +28,6 @@ namespace mig {
   X(MI_VINA_MC_WAVES)                \
   X(MI_VINA_MC_PROFILE)              \
   X(MI_POOL_NO_RCCL)                 \
-  X(MI_GNINA_OVERLAP)                \
   X(MI_GNINA_NO_UNPOOL_FUSE)         \
   X(MI_GNINA_NO_SPARSE)              \
   X(MI_GNINA_NO_LIG_BWD)             \
@@ -58,7 +57,8 @@ namespace mig {
   X(MI_GNINA_D16_PERSIST)            \
   X(MI_GNINA_K1S_PERSIST)            \
   X(MI_VOX_DBG)                      \
-  X(MI_GNINA_NO_CALL_LOCK)
+  X(MI_GNINA_NO_CALL_LOCK)           \
+  X(MI_GNINA_CALL_LOCK)
 
 enum OptionId {
 #define X(n) OPT_##n,

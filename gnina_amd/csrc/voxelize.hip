@@ -246,8 +246,14 @@ __device__ __forceinline__ float div_rn(float a, float b, float y) {
 #define VOX_TRAP_VIOL_PARAM
 #define VOX_TRAP_VIOL_ARG
 #endif
+// MI_VOX_FIX: how the hit loop forms its eight squared distances.  1 (the product): scalar fp32 instructions.  0: the round-5
+// form, packed fp32 (v_pk_add_f32 / v_pk_mul_f32 on float2 values: half the instructions) -- which, built WITH packed-fp32
+// instructions (tools/experiments/build_variant.sh: the product's flags switch them off), gives wrong distances in lanes
+// 32-63 of a wavefront in ~2 % of the launches that run next to a second scorer's Dense conv kernels (round 6, DESIGN
+// "concurrency").  2 .. 5: the builds that told what it was NOT (wait states behind the packed results, behind the compare,
+// SGPR operands of the packed instructions, a scalar load in flight): all four deviate like 0.
 #ifndef MI_VOX_FIX
-#define MI_VOX_FIX 0
+#define MI_VOX_FIX 1
 #endif
 __device__ __forceinline__ void density_add(float &acc, float rsq, float t2, float g2, float kexp, float ar, float inv_ar,
                                             float qa, float qb, float qc VOX_TRAP_VIOL_PARAM) {
@@ -650,14 +656,13 @@ __global__ __launch_bounds__(64, 8) void voxelize_tiles(VoxArgs v) {
         for (int i = 0; i < 8; i++) acc[i] = 0.f;
       }
       if (VOX_DBG(1)) continue;  // (timing only)
-      // squared distances of this lane's eight voxels, two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations
-      // as the scalar forms, in the same order -- (dx^2 + dy^2) + dz^2 -- at half the instruction count; the kernel's time
-      // is its VALU instruction count)
 #ifdef MI_VOX_TRAP
       bool viol = false;
 #endif
 #if MI_VOX_FIX == 1
-      // (experiment: the same IEEE operations without the packed instructions)
+      // squared distances of this lane's eight voxels, (dx^2 + dy^2) + dz^2 like the oracle, in scalar fp32 instructions (see
+      // MI_VOX_FIX above: the packed form computed the same bits with half the instructions -- until a neighbour queue's conv
+      // kernels shared the SIMD; measured cost of the scalar form: none, 0.872 -> 0.871 ms)
       float dx2[2], dy2[2], dz2[2];
 #pragma unroll
       for (int d = 0; d < 2; d++) {

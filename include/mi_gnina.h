@@ -52,14 +52,15 @@ enum {
  * Every scorer / mi_vina handle owns a HIP stream; mi_vina handles driven from different host threads overlap on the
  * device as far as the runtime has hardware queues, so the first call also sets GPU_MAX_HW_QUEUES=16 (HIP's
  * default is 4) unless the variable is already set -- effective only before the process's first HIP call.
- * CNN scoring calls (mi_scorer_score_*, mi_voxelize_batch, mi_model_forward_grids) on different scorers of ONE device
- * are serialised by the library, as gnina serialises them under DLScorer::mtx (dl_scorer.h:26, cnn_torch_scorer.cpp:106:
- * one mutex shared by a scorer and its copies): a voxelizer next to another scorer's conv kernels on a second hardware
- * queue does not give the bits it gives alone on this chip (round 5; tests/test_gpu_concurrency.py).
- * Host-output calls hold the device's lock until their results are back; MI_OUT_ON_DEVICE calls only while they enqueue --
- * the caller orders those (the pools drive one scorer per device).  Within a call of at most 8 poses the models of an
- * ensemble run on streams of their own behind the voxelization (conv programs side by side are clean; same bits as on one
- * stream; MI_GNINA_LANES=0 switches it off). */
+ * THREADS.  A scorer (and an mi_vina handle) is driven by one host thread at a time; DIFFERENT scorers of one device may be
+ * driven from different host threads at the same time, host-output and MI_OUT_ON_DEVICE calls alike -- that is how gnina
+ * drives the seam: fresh_copy() gives every worker thread and every Monte-Carlo task a new CNNTorchScorer with a mutex of
+ * its own (cnn_torch_scorer.h:54, dl_scorer.h:43-44, main.cpp:1436-1438, parallel_mc.cpp:145-146).  Every call gives the
+ * bits the same call gives alone (tests/test_gpu_concurrency.py: two threads, host and device outputs).  Rounds 5 serialised
+ * such calls per device because a voxelizer next to another scorer's conv kernels deviated; round 6 traced that to the
+ * voxelizer's packed-fp32 instructions (DESIGN.md "concurrency"), removed them, and removed the lock (MI_GNINA_CALL_LOCK=1
+ * brings it back for A/B measurements).  Within a call of at most 8 poses the models of an ensemble run on streams of their
+ * own behind the voxelization (same bits as on one stream; MI_GNINA_LANES=0 switches it off). */
 mi_status mi_gnina_init(int device);
 /* Experiment / A-B switches (gnina_amd/csrc/options.h lists them: MI_GNINA_*, MI_POOL_*, MI_VINA_*, MI_VOX_*).  The
  * environment is read ONCE per process, at the first library call; afterwards a switch changes only through this call

@@ -55,6 +55,29 @@ def test_product_sources_never_touch_the_oracle():
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: the failure path is for GPU-less hosts")
+def test_device_code_has_no_packed_fp32_instructions(capi, tmp_path):
+    """Round 6 (DESIGN.md "concurrency"): chains of packed-fp32 VALU instructions give wrong results in lanes 32-63 while
+    another queue's Dense conv kernels share the SIMD -- voxelize_tiles deviated next to a second scorer because of them.  The
+    library is compiled with the instruction class switched off (gnina_amd/build.py FLAGS): no kernel may contain one."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not present")
+    from gnina_amd import build as b
+    so = str(tmp_path / "lib.so")
+    shutil.copy(b.LIB, so)
+    subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=str(tmp_path))
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(objs) >= 6, objs  # one code object per .hip translation unit
+    kernels, packed = 0, []
+    for f in objs:
+        out = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        kernels += out.count("s_endpgm")
+        packed += [ln.strip() for ln in out.splitlines() if "v_pk_" in ln and "_f32" in ln]
+    assert kernels > 50 and not packed, packed[:5]
+
+
 def test_fails_loudly_without_gpu(capi):
     assert capi.lib().mi_gnina_device_count() == 0
     with pytest.raises(capi.MiGninaError):

@@ -1,10 +1,12 @@
-"""Two scorers of one device driven from two host threads (the C ABI allows it; gnina itself scores under DLScorer::mtx,
-gninasrc/lib/dl_scorer.h:26, cnn_torch_scorer.cpp:106): every call must give the bits the scorer gives alone.
+"""Several scorers of one device driven from several host threads at the same time -- how gnina drives the seam: fresh_copy()
+hands every worker thread / Monte-Carlo task a new CNNTorchScorer with a mutex of its own (gninasrc/lib/cnn_torch_scorer.h:54,
+dl_scorer.h:43-44, main.cpp:1436-1438, parallel_mc.cpp:145-146).  Every call must give the bits the scorer gives alone.
 
-Round 5 found that it did not -- with a Dense model on the second thread ~5 % of the B = 1 calls deviated (up to 3e-2 in the
-affinity): kernels of two hardware queues running side by side change what the voxelizer accumulates.  The library now holds
-a per-device lock for the duration of a host-output scoring call (engine.cpp device_call_lock), which is also the reference's
-behaviour.  The ensemble path that ran an ensemble's models on their own streams ("lanes") is opt-in for the same reason."""
+Round 5 found that it did not (~5 % of B = 1 calls next to a Dense model, up to 6e-2 in the affinity) and serialised the calls
+per device.  Round 6 found the cause -- voxelize_tiles' packed-fp32 instructions go wrong in the upper half of a wavefront
+while the Dense family's f16-MFMA K loops share the SIMD (DESIGN.md "concurrency"; tools/experiments/vox_stress.py) --, took
+those instructions out of the voxelizer and took the lock away: these tests run WITHOUT any serialisation, host-output and
+device-output calls, and with an ensemble's models on their own streams (lanes: on by default for calls of <= 8 poses)."""
 import os
 import threading
 
@@ -57,7 +59,7 @@ def test_two_threads_give_the_single_thread_bits(capi, pair):
 
 def test_default_ensemble_small_calls_are_reproducible(capi):
     """gnina's default ensemble at B = 1 (DLScorer::score as gnina calls it): the models' programs run on their own streams
-    (lanes; every voxel group is voxelized before the first lane starts).  Same bits every time, the goldens' scores, and
+    (lanes, behind the voxelization of the ensemble's groups).  Same bits every time, the goldens' scores, and
     the bits of the one-stream call (MI_GNINA_NO_LANES=1), per model."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
     names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]
@@ -86,3 +88,75 @@ def test_default_ensemble_small_calls_are_reproducible(capi):
         s1.set_receptor(rec_xyz, rec_smt)
         serial = per_model(s1, 150)
     assert np.array_equal(lanes, serial), int((np.abs(lanes - serial).max(axis=(1, 2)) > 0).sum())
+
+
+def test_two_threads_device_output_calls(capi):
+    """MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE calls (what the pools and a device-resident caller make) return after they enqueue:
+    two threads then have voxelizers and conv kernels of two scorers in flight side by side for the whole run."""
+    import torch
+    G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
+    pair = ("crossdock_default2018_KD_4", "dense_1_3")
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"dense_1_3/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    N, P, L = 300, len(poses), poses.shape[1]
+    dev = torch.device("cuda:0")
+    d_lig = torch.from_numpy(np.ascontiguousarray(poses, np.float32)).to(dev)
+
+    def loop(s, d_out):  # call k scores pose k % P into row k of d_out[0..3]
+        for k in range(N):
+            b = k % P
+            s.score_batch_device(d_lig[b].data_ptr(), lig_smt, 1, L, d_out[0][k:].data_ptr(), d_out[1][k:].data_ptr(),
+                                 d_out[2][k:].data_ptr(), d_out[3][k:].data_ptr())
+        s.synchronize()
+
+    scorers, refs, outs = [], [], []
+    for n in pair:
+        s = capi.Scorer([n])
+        s.set_receptor(rec_xyz, rec_smt)
+        scorers.append(s)
+        d_ref = torch.zeros(4, N, device=dev)
+        loop(s, d_ref)
+        refs.append(d_ref.cpu().numpy())
+        assert np.abs(refs[-1][0, :P] - G[n + "/pose"]).max() < 1e-4
+        outs.append(torch.zeros(4, N, device=dev))
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=loop, args=(s, o)) for s, o in zip(scorers, outs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for n, o, r in zip(pair, outs, refs):
+        got = o.cpu().numpy()
+        assert np.array_equal(got[:2], r[:2]), (n, int((np.abs(got[:2] - r[:2]).max(axis=0) > 0).sum()), "of", N, "calls deviate")
+
+
+def test_four_threads_default_ensemble(capi):
+    """Four fresh copies of gnina's default ensemble scoring B = 1 poses from four threads (main.cpp:1436-1438): their lanes
+    share the device's lane streams, their voxelizers run next to each other's Dense conv kernels; same bits as one thread."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
+    names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{names[0]}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    N = 120
+
+    def loop(s, out):
+        for rep in range(N):
+            b = rep % len(poses)
+            r = s.score_batch(poses[b:b + 1], lig_smt)
+            out.append((float(r["pose"][0]), float(r["affinity"][0])))
+
+    scorers = []
+    for _ in range(4):
+        s = capi.Scorer(names)
+        s.set_receptor(rec_xyz, rec_smt)
+        scorers.append(s)
+    ref = []
+    loop(scorers[0], ref)
+    ref = np.array(ref)
+    outs = [[] for _ in scorers]
+    th = [threading.Thread(target=loop, args=(s, o)) for s, o in zip(scorers, outs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, o in enumerate(outs):
+        assert np.array_equal(np.array(o), ref), (i, int((np.abs(np.array(o) - ref).max(axis=1) > 0).sum()), "of", N, "calls deviate")
