@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi_gnina.so")
-SOURCES = ["engine.cpp", "options.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_h2.hip", "conv3d_h2_dense.hip", "vina.hip", "vina_host.cpp", "pool.cpp",
+SOURCES = ["engine.cpp", "options.cpp", "model.cpp", "typer.cpp", "voxelize.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_h2.hip", "conv3d_h2_dense.hip", "conv3d_h2_ws.hip", "vina.hip", "vina_host.cpp", "pool.cpp",
            "../host/typed_atoms.cpp", "../host/pdbqt.cpp"]
 # -ffp-contract=off: fp32 ops round exactly as written (the voxelizer's in/out decisions must be
 # bit-identical to the reference arithmetic); fused ops are spelled out (fmaf / MFMA builtins).

@@ -117,6 +117,9 @@ struct ConvArgs {
   // h2_persist = workgroups per CU the launch is capped at, each walking items blockIdx.x, + gridDim.x, ... (0 = one
   // workgroup per item)
   int n_items, h2_persist;
+  // conv3d_h2_ws_kernel (conv3d_h2_ws.hip): > 0 = the launch may take the stationary-weights kernel with a ring of this many
+  // halo-tile buffers (2 .. 5) where it covers the layer (conv_h2_ws_covers) and the batch is large enough; 0 = never
+  int h2_ws;
   int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
 };
 
@@ -166,6 +169,10 @@ bool conv_h2_has_bwd_k1(int cfg);  // ... of conv3d_h2_k1_kernel (1x1x1 behind a
 bool conv_h2_has_bwd(int cfg);  // the gradient-pass variant of conv3d_h2_kernel exists for this tile shape  // bit m set: conv3d_h2_kernel is compiled with M-tile geometry m (ConvArgs::mt_x) for this shape
 void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl);
 void launch_conv_h2(const ConvArgs &p, int cfg, int B, hipStream_t s);
+// conv3d_h2_ws.hip: the first 3x3x3 convolution with stationary weights and a ring of halo tiles
+bool conv_h2_ws_covers(const ConvArgs &p, int B);
+size_t conv_h2_ws_lds_bytes(int ring);
+void launch_conv_h2_ws(ConvArgs p, int B, int ring, hipStream_t s);
 // conv3d_h2_dense.hip: Dense-block layers / 1x1x1 transitions on split-format tensors
 void conv_d16_tap_order(unsigned taps4[7], unsigned char order[28]);
 bool conv_d16_layout_conflict_free(int SY, int SX);

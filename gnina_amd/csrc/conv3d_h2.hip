@@ -1558,6 +1558,11 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
     if constexpr (WN == 1 && TM <= 2) {  // (weights through LDS: the shapes whose four waves share their output channels)
       if (p.h2_wlds) {
         if constexpr (TM == 2) {  // (the throughput shape) two poses per workgroup on one copy of the weights
+          if constexpr (SK && MT == 1 && WM == 4)
+            if (p.in_split && p.h2_ws > 0 && B >= 32 && conv_h2_ws_covers(p, B)) {  // stationary weights, ring of tiles (conv3d_h2_ws.hip)
+              launch_conv_h2_ws(p, B, p.h2_ws, s);
+              return;
+            }
           if (p.in_split && p.h2_wlds >= 2 && B >= 2) {
             grid.x = (unsigned)((B + 1) / 2 * p.ntx * p.nty * p.ntz);
             go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true, true, 2>);

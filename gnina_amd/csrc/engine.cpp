@@ -9,6 +9,8 @@
 // uploaded once instead of per pose, models with identical type maps share one voxelization,
 // results leave the device once per batch instead of three .item() syncs per pose.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +69,26 @@ static std::recursive_mutex &device_call_lock(int device) {
     return own;
   }
   return locks[device >= 0 && device < 64 ? device : 0];
+}
+
+// Is this scorer the only one scoring on its device?  A call of a scorer that has the device to itself spreads an ensemble's
+// models over the lane streams; when other scorers are at work on the device as well -- gnina's worker threads, each with its
+// fresh_copy() -- every call stays on its own stream: the device is busy anyway, and lanes of several scorers queue up behind
+// each other on the shared (priority) lane streams while calls without lanes starve next to them (measured, gnina's default
+// ensemble at B = 1, poses/s from 1 / 2 / 4 threads: lanes always 1,635 / 2,091 / 1,045; never 889 / 1,738 / 1,985; lanes for the
+// call that happens to arrive first only: 1,648 / 1,010 / 3,342 -- hence "another scorer scored here within the last 20 ms",
+// which all the scorers of a busy device agree on).
+struct DeviceActivity {
+  std::atomic<const void *> last_scorer{nullptr};
+  std::atomic<long long> last_ns{0};
+};
+static DeviceActivity g_activity[64];
+static bool scorer_alone_on_device(int device, const void *scorer) {
+  DeviceActivity &a = g_activity[device >= 0 && device < 64 ? device : 0];
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  const void *prev = a.last_scorer.exchange(scorer);
+  const long long prev_ns = a.last_ns.exchange(now);
+  return prev == nullptr || prev == scorer || now - prev_ns > 20000000ll;
 }
 
 // The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: a set per scorer is harmful -- four
@@ -1338,6 +1360,7 @@ struct Scorer {
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
+  bool alone_on_device = true;          // no other scorer has scored on the device lately (scorer_alone_on_device)
   size_t centers_stride = 0;            // lanes: voxel group 1 writes its grid centres behind group 0's (voxelize_chunk)
   std::vector<int> last_lane;           // per model: the set its last forward program wrote (mi_debug_read_activation)
   // mi_debug_vox_stress: the quiet run's pooled grid, the mismatch log, the trap ring of a -DMI_VOX_TRAP build
@@ -1899,6 +1922,9 @@ static void h2_launch_args(const ConvPlan &cp, const ConvArgs &a, int nb, ConvAr
   h.h2_wlds = (wn_ == 1 && tm_ <= 2) ? (ev ? atoi(ev) : 2) : 0;
   // (L2 prefetch of the next item's tile under this item's K loop: measured, no gain -- 1.722 vs 1.717 ms; opt-in)
   h.h2_prefetch = (option(OPT_MI_GNINA_H2_PF) && atoi(option(OPT_MI_GNINA_H2_PF)) != 0) ? 1 : 0;
+  // stationary weights + a ring of halo tiles for the first convolution where the kernel covers it (conv3d_h2_ws.hip);
+  // MI_GNINA_H2_WS = ring size 2 .. 5, 0 = conv3d_h2_kernel
+  h.h2_ws = option(OPT_MI_GNINA_H2_WS) ? atoi(option(OPT_MI_GNINA_H2_WS)) : 0;
 }
 
 // Run the layer program of model mi on `nb` poses whose pooled grid already sits in
@@ -2025,7 +2051,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                 h.in_cs = m->Cp8;
                 // the voxelizer's occupancy bytes of this buffer set -- opt-in (MI_GNINA_H2_OCC=1): on the headline workload a
                 // quarter of the (tile, octet) chunks is empty, and reading the bytes ahead of the first DMA costs as much
-                if (option(OPT_MI_GNINA_H2_OCC) && atoi(option(OPT_MI_GNINA_H2_OCC))) {
+                // (conv3d_h2_ws_kernel builds its round list from them: always, when that kernel may take the launch)
+                if ((option(OPT_MI_GNINA_H2_OCC) && atoi(option(OPT_MI_GNINA_H2_OCC))) || h.h2_ws > 0) {
                   h.in_occ = s.d_occ[pooled_slot == kPooledSlot2 ? 1 : 0].p;
                   h.occ_nt = cdiv(cdiv(m->N, 2), 4);
                 }
@@ -2457,7 +2484,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   for (Model *m : s.models) max_bufs = std::max(max_bufs, m->d.bufs.size());
   const bool lane_slots_ok = max_bufs <= kLaneSlots && ((size_t)nm + 1) * kLaneSlots <= kPooledSlot2;
   const bool lanes = lanes_on && nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) &&
-                     s.groups.size() <= 2 && lane_slots_ok;
+                     s.groups.size() <= 2 && lane_slots_ok && s.alone_on_device;
   struct LaneJob {
     int gi;
     size_t slot;
@@ -2593,6 +2620,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
                         bool ragged = false) {
   if (B <= 0) return score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
   std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
+  s.alone_on_device = scorer_alone_on_device(s.device, &s) || (option(OPT_MI_GNINA_LANES) && atoi(option(OPT_MI_GNINA_LANES)) > 1);  // (MI_GNINA_LANES=2: lanes whatever else runs)
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
   score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);

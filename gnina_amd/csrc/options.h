@@ -58,7 +58,8 @@ namespace mig {
   X(MI_GNINA_K1S_PERSIST)            \
   X(MI_VOX_DBG)                      \
   X(MI_GNINA_NO_CALL_LOCK)           \
-  X(MI_GNINA_CALL_LOCK)
+  X(MI_GNINA_CALL_LOCK)              \
+  X(MI_GNINA_H2_WS)
 
 enum OptionId {
 #define X(n) OPT_##n,

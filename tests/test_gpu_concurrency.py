@@ -12,6 +12,7 @@ import threading
 
 import numpy as np
 import pytest
+import torch  # (before the library initialises HIP: a torch imported afterwards finds no device)
 
 pytestmark = pytest.mark.gpu
 
@@ -93,7 +94,6 @@ def test_default_ensemble_small_calls_are_reproducible(capi):
 def test_two_threads_device_output_calls(capi):
     """MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE calls (what the pools and a device-resident caller make) return after they enqueue:
     two threads then have voxelizers and conv kernels of two scorers in flight side by side for the whole run."""
-    import torch
     G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
     pair = ("crossdock_default2018_KD_4", "dense_1_3")
     rec_xyz, rec_smt, lig_smt, poses = (G[f"dense_1_3/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
