@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_h2_ws_kernel(ConvArgs p) {
         constexpr int TP = decltype(tpc)::value;
         if constexpr (TP < J) {
           uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
+          ws_f32x16 &acc0 = acc[TP][0], &acc1 = acc[TP][1];  // (named here: asm operands alone do not make a generic lambda capture)
+          unsigned &n_ex = n_exec;
           int qo_next = lp[0];
           auto load_pair = [&](int pr, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) __attribute__((always_inline)) {
             const int qo = qo_next;
@@ -317,19 +319,41 @@ __global__ __launch_bounds__(256, 1) void conv3d_h2_ws_kernel(ConvArgs p) {
             wl = *reinterpret_cast<const uint4 *>(wl_ + pr * 2048 + 1024);
             qo_next = lp[2 * pr + 2];
           };
+          // The MFMAs of a step as ONE asm statement.  With one wave per SIMD nothing fills the gaps of this wave's instruction
+          // stream: an s_waitcnt or a scalar add that hipcc places between two MFMAs on the SAME accumulator costs ~43 cycles
+          // (MI355X_MICROARCH.md), and three MFMAs in a row on one accumulator wait for each other -- the first version of this
+          // kernel ran its K loops at a quarter of the MFMA rate.  Here the two M-tiles' chains are interleaved (per accumulator
+          // still al * wh, ah * wl, ah * wh: same bits), every operand is waited for before the group, nothing sits inside it.
           auto mfma_pair = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) __attribute__((always_inline)) {
-#pragma unroll
-            for (int m = 0; m < TM; m++) {
-              // all 32 voxels x 16 k of this step zero (h = 0 implies l = 0): nothing to add
-              const unsigned any = ah[m].x | ah[m].y | ah[m].z | ah[m].w;
-              unsigned long long lv;
-              asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv) : "v"(any));
-              if (lv == 0ull) continue;
-              n_exec++;
-              acc[TP][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, al[m]), __builtin_bit_cast(ws_f16x8, wh), acc[TP][m], 0, 0, 0);
-              acc[TP][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah[m]), __builtin_bit_cast(ws_f16x8, wl), acc[TP][m], 0, 0, 0);
-              acc[TP][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah[m]), __builtin_bit_cast(ws_f16x8, wh), acc[TP][m], 0, 0, 0);
-            }
+            // all 32 voxels x 16 k of an M-tile's step zero (h = 0 implies l = 0): nothing to add
+            const unsigned any0 = ah[0].x | ah[0].y | ah[0].z | ah[0].w, any1 = ah[1].x | ah[1].y | ah[1].z | ah[1].w;
+            unsigned long long lv0, lv1;
+            asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv0) : "v"(any0));
+            asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(lv1) : "v"(any1));
+            const ws_f16x8 ah0v = __builtin_bit_cast(ws_f16x8, ah[0]), al0v = __builtin_bit_cast(ws_f16x8, al[0]), ah1v = __builtin_bit_cast(ws_f16x8, ah[1]),
+                           al1v = __builtin_bit_cast(ws_f16x8, al[1]), whv = __builtin_bit_cast(ws_f16x8, wh), wlv = __builtin_bit_cast(ws_f16x8, wl);
+            // (ONE statement with the three cases behind scalar branches INSIDE it: as three statements in three C++ branches
+            // the register allocator gave every case its own accumulator registers and copied 16-64 AGPRs around per step --
+            // right behind the MFMAs, whose results had not landed: slow and wrong)
+            asm volatile(
+                "s_nop 1\n\t"
+                "s_cmp_eq_u64 %9, 0\n\ts_cbranch_scc1 .Lws_a%=\n\t"
+                "s_cmp_eq_u64 %10, 0\n\ts_cbranch_scc1 .Lws_b%=\n\t"
+                "v_mfma_f32_32x32x16_f16 %0, %4, %7, %0\n\tv_mfma_f32_32x32x16_f16 %1, %6, %7, %1\n\t"
+                "v_mfma_f32_32x32x16_f16 %0, %3, %8, %0\n\tv_mfma_f32_32x32x16_f16 %1, %5, %8, %1\n\t"
+                "v_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n\tv_mfma_f32_32x32x16_f16 %1, %5, %7, %1\n\t"
+                "s_add_u32 %2, %2, 2\n\ts_branch .Lws_d%=\n"
+                ".Lws_b%=:\n\t"  // M-tile 0 only
+                "v_mfma_f32_32x32x16_f16 %0, %4, %7, %0\n\tv_mfma_f32_32x32x16_f16 %0, %3, %8, %0\n\tv_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n\t"
+                "s_add_u32 %2, %2, 1\n\ts_branch .Lws_d%=\n"
+                ".Lws_a%=:\n\t"  // M-tile 0 dead
+                "s_cmp_eq_u64 %10, 0\n\ts_cbranch_scc1 .Lws_d%=\n\t"
+                "v_mfma_f32_32x32x16_f16 %1, %6, %7, %1\n\tv_mfma_f32_32x32x16_f16 %1, %5, %8, %1\n\tv_mfma_f32_32x32x16_f16 %1, %5, %7, %1\n\t"
+                "s_add_u32 %2, %2, 1\n"
+                ".Lws_d%=:"
+                : "+a"(acc0), "+a"(acc1), "+s"(n_ex)
+                : "v"(ah0v), "v"(al0v), "v"(ah1v), "v"(al1v), "v"(whv), "v"(wlv), "s"(lv0), "s"(lv1)
+                : "scc");
           };
           load_pair(0, ah0, al0, wh0, wl0);
 #pragma unroll 1
@@ -339,6 +363,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_h2_ws_kernel(ConvArgs p) {
             if (pr + 2 < kWsP) load_pair(pr + 2, ah0, al0, wh0, wl0);
             mfma_pair(ah1, al1, wh1, wl1);
           }
+          // (the compiler does not know the asm statements were MFMAs: their results must have landed before any code of its
+          // own -- accumulator moves between the poses' K loops, the epilogue -- reads them: 8-pass XDL write -> VALU read)
+          asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc0), "+a"(acc1));
         }
       };
       switch (tp) {

@@ -122,3 +122,24 @@ def test_two_poses_per_workgroup_and_an_odd_batch(capi, CG, name):
     with capi.option("MI_GNINA_H2_WLDS", 0):
         plain = s.score_batch(many, lig_smt)
     assert np.array_equal(plain["pose"], big["pose"]) and np.array_equal(plain["affinity"], big["affinity"])
+
+
+@pytest.mark.parametrize("name", ["default2017", "dense"])
+def test_stationary_weights_first_conv_gives_the_same_bits(capi, CG, name):
+    """conv3d_h2_ws_kernel (conv3d_h2_ws.hip, round 6, opt-in MI_GNINA_H2_WS = ring size): one persistent workgroup per CU,
+    a chunk's weights DMA'd once per 8 poses, the accumulators of 8 poses resident, halo tiles through a ring with hand-counted
+    vmcnt.  Same tile, K order and MFMA order per accumulator as conv3d_h2_kernel: same bits, for batches that are and are
+    not multiples of 8, for every ring size, for the pooled (default2017) and the un-pooled split-output (Dense) first conv."""
+    from gnina_amd import synth
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = np.concatenate([poses, synth.make_poses(np.random.RandomState(17), poses[0] - poses[0].mean(0), 63)])   # 67 poses
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    ref = s.score_batch(many, lig_smt)
+    assert np.abs(ref["pose"][:len(poses)] - CG[name + "/pose"]).max() < 1e-4
+    for ring in (2, 4, 5):
+        with capi.option("MI_GNINA_H2_WS", ring):
+            got = s.score_batch(many, lig_smt)
+            part = s.score_batch(many[:40], lig_smt)
+        assert np.array_equal(got["pose"], ref["pose"]) and np.array_equal(got["affinity"], ref["affinity"]), ring
+        assert np.array_equal(part["pose"], ref["pose"][:40]) and np.array_equal(part["affinity"], ref["affinity"][:40]), ring
