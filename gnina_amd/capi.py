@@ -559,7 +559,7 @@ class Scorer:
     def set_precision(self, bf16):
         """False / 0 / "fp32": the parity path (split-fp16 forward convolutions where planned); True / 1 / "bf16": the bf16
         path; 2 / "fp32_mfma": fp32 MFMA for every layer (include/mi_gnina.h, mi_scorer_set_precision)."""
-        code = {"fp32": 0, "bf16": 1, "fp32_mfma": 2}.get(bf16, bf16)
+        code = {"fp32": 0, "bf16": 1, "fp32_mfma": 2, "fp16": 3}.get(bf16, bf16)
         check(lib().mi_scorer_set_precision(self.handle, int(code)))
 
     def set_rotations(self, quats):

@@ -117,6 +117,9 @@ struct ConvArgs {
   // h2_persist = workgroups per CU the launch is capped at, each walking items blockIdx.x, + gridDim.x, ... (0 = one
   // workgroup per item)
   int n_items, h2_persist;
+  // MI_PRECISION_FP16 (the reduced-precision forward mode, BASELINE config 5): the split-fp16 kernels issue the h * h MFMA
+  // only -- one of the three per product: activations and weights rounded to fp16, fp32 accumulation
+  int h2_honly;
   // conv3d_h2_ws_kernel (conv3d_h2_ws.hip): > 0 = the launch may take the stationary-weights kernel with a ring of this many
   // halo-tile buffers (2 .. 5) where it covers the layer (conv_h2_ws_covers) and the batch is large enough; 0 = never
   int h2_ws;

@@ -78,7 +78,8 @@ constexpr int kD16NS = 6;      // wave-DMAs per thread and chunk: 2 PL <= kD16NS
 constexpr int kD16Steps = 7;   // 28 tap slots / 4 per instruction
 constexpr int kD16WBytes = kD16Steps * 2048;  // a chunk's B operands: [step][h | l][lane group][16 couts][8 fp16]
 
-template <int TM, int NP>
+// HONLY (MI_PRECISION_FP16, round 6): the h * h MFMA of every product only, and nothing of the l planes is DMA'd or read
+template <int TM, int NP, bool HONLY = false>
 __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
       char *dst = s_tile + wave * 1024;
   #pragma unroll
       for (int i = 0; i < kD16NS; i++)
-        if ((i * 4 + wave) * 64 < 2 * PL && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
+        // (MI_PRECISION_FP16: the wave-DMAs that lie in the l plane are not issued -- nothing reads it)
+        if ((i * 4 + wave) * 64 < (HONLY ? PL : 2 * PL) && !(p.h2_dbg & 4))  // (wave-uniform; 2 PL is a multiple of 64)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (D16LdsPtr)(dst + i * 4096), 16, voff[i], chunk * octet_bytes, 0, 0);
     };
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.nchunks * kD16WBytes, 0x00020000);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
   #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = i * 4 + wave;
-        if (q < 2 * kD16Steps && !(p.h2_dbg & 8))
+        if (q < 2 * kD16Steps && !(p.h2_dbg & 8) && !(HONLY && (q & 1)))  // (odd pieces: the l halves)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(s_w + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
       }
     };
@@ -210,19 +212,21 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
           for (int m = 0; m < TM; m++) {
             const char *a = s_tile + baseA[m] + qo[s];
             ah[m] = *reinterpret_cast<const uint4 *>(a);
-            al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
+            if constexpr (!HONLY) al[m] = *reinterpret_cast<const uint4 *>(a + PLB);
           }
           wh = *reinterpret_cast<const uint4 *>(wl_ + s * 2048);
-          wl = *reinterpret_cast<const uint4 *>(wl_ + s * 2048 + 1024);
+          if constexpr (!HONLY) wl = *reinterpret_cast<const uint4 *>(wl_ + s * 2048 + 1024);
         };
         auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &wh, const uint4 &wl) __attribute__((always_inline)) {
           // (three passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
+          if constexpr (!HONLY) {  // (MI_PRECISION_FP16: the h * h product only)
   #pragma unroll
-          for (int m = 0; m < TM; m++)
-            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, al[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
+            for (int m = 0; m < TM; m++)
+              acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, al[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
   #pragma unroll
-          for (int m = 0; m < TM; m++)
-            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wl), acc[tp][m], 0, 0, 0);
+            for (int m = 0; m < TM; m++)
+              acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wl), acc[tp][m], 0, 0, 0);
+          }
   #pragma unroll
           for (int m = 0; m < TM; m++)
             acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(d16_f16x8, ah[m]), __builtin_bit_cast(d16_f16x8, wh), acc[tp][m], 0, 0, 0);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kK1sNS = 7;  // wave-DMAs per thread and chunk: voxels * (2 CC8 + 1) <= kK1sNS * 256 slots
 
-template <int TN>
+template <int TN, bool HONLY = false>
 __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
     for (int n = 0; n < TN; n++) {
       const char *w = w0 + (wlane + (unsigned)n * 32u * 32u);
       wh[n] = *reinterpret_cast<const uint4 *>(w);
-      wl[n] = *reinterpret_cast<const uint4 *>(w + 16);
+      if constexpr (!HONLY) wl[n] = *reinterpret_cast<const uint4 *>(w + 16);
     }
   };
 
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
         const int t1 = (int)(((unsigned)v * inv_hz) >> 20), hz = v - t1 * HZ;
         const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
         const int x = tx * HX + hx, y = ty * HY + hy, z = tz * HZ + hz;
-        const bool ok = j < total && pp < 2 * CC8 && x < S && y < S && z < S;
+        const bool ok = j < total && pp < 2 * CC8 && x < S && y < S && z < S && !(HONLY && (pp & 1));  // (MI_PRECISION_FP16: no l halves)
         voff[i] = ok ? (unsigned)((size_t)(pp >> 1) * S3 + (size_t)((x * S + y) * S + z)) * 32u + (unsigned)(pp & 1) * 16u : 0x80000000u;
       }
     }
@@ -410,15 +414,18 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
       for (int pr = 0; pr < P; pr++, g++) {
         const char *a = s_tile + baseA + (2 * pr + kh) * 32;
         const uint4 ah = *reinterpret_cast<const uint4 *>(a);
-        const uint4 al = *reinterpret_cast<const uint4 *>(a + 16);
+        uint4 al = ah;
+        if constexpr (!HONLY) al = *reinterpret_cast<const uint4 *>(a + 16);
         // (three passes over the channel groups: consecutive MFMAs never wait for each other's accumulator; per accumulator
         // the order al*wh, ah*wl, ah*wh of conv3d_h2_k1_kernel is kept -- same bits)
+        if constexpr (!HONLY) {  // (MI_PRECISION_FP16: the h * h product only)
 #pragma unroll
-        for (int n = 0; n < TN; n++)
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, al), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
+          for (int n = 0; n < TN; n++)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, al), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < TN; n++)
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wl[n]), acc[n], 0, 0, 0);
+          for (int n = 0; n < TN; n++)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wl[n]), acc[n], 0, 0, 0);
+        }
 #pragma unroll
         for (int n = 0; n < TN; n++)
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(d16_f16x8, ah), __builtin_bit_cast(d16_f16x8, wh[n]), acc[n], 0, 0, 0);
@@ -526,6 +533,11 @@ void launch_conv_h2_k1s(ConvArgs p, int B, hipStream_t s) {
     if (p.h2_persist != 0) grid = std::min(grid, d16_resident_workgroups(reinterpret_cast<const void *>(kern), lds, p.h2_persist));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
   };
+  if (p.h2_honly) {
+    if (tn == 3) go(conv3d_h2_k1s_kernel<3, true>);
+    else go(conv3d_h2_k1s_kernel<5, true>);
+    return;
+  }
   if (tn == 3) go(conv3d_h2_k1s_kernel<3>);
   else go(conv3d_h2_k1s_kernel<5>);
 }
@@ -597,6 +609,13 @@ void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
   };
   const bool two = p.h2_wlds >= 2 && B >= 2;
+  if (p.h2_honly) {  // (MI_PRECISION_FP16: the two-pose variants -- a throughput mode)
+    if (n_mt <= 4) two ? go(conv3d_h2_d16_kernel<1, 2, true>, 2) : go(conv3d_h2_d16_kernel<1, 1, true>, 1);
+    else if (n_mt <= 8) two ? go(conv3d_h2_d16_kernel<2, 2, true>, 2) : go(conv3d_h2_d16_kernel<2, 1, true>, 1);
+    else if (n_mt <= 12) two ? go(conv3d_h2_d16_kernel<3, 2, true>, 2) : go(conv3d_h2_d16_kernel<3, 1, true>, 1);
+    else two ? go(conv3d_h2_d16_kernel<4, 2, true>, 2) : go(conv3d_h2_d16_kernel<4, 1, true>, 1);
+    return;
+  }
   if (n_mt <= 4) two ? go(conv3d_h2_d16_kernel<1, 2>, 2) : go(conv3d_h2_d16_kernel<1, 1>, 1);
   else if (n_mt <= 8) two ? go(conv3d_h2_d16_kernel<2, 2>, 2) : go(conv3d_h2_d16_kernel<2, 1>, 1);
   else if (n_mt <= 12) two ? go(conv3d_h2_d16_kernel<3, 2>, 2) : go(conv3d_h2_d16_kernel<3, 1>, 1);

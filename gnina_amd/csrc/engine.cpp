@@ -76,19 +76,30 @@ static std::recursive_mutex &device_call_lock(int device) {
 // fresh_copy() -- every call stays on its own stream: the device is busy anyway, and lanes of several scorers queue up behind
 // each other on the shared (priority) lane streams while calls without lanes starve next to them (measured, gnina's default
 // ensemble at B = 1, poses/s from 1 / 2 / 4 threads: lanes always 1,635 / 2,091 / 1,045; never 889 / 1,738 / 1,985; lanes for the
-// call that happens to arrive first only: 1,648 / 1,010 / 3,342 -- hence "another scorer scored here within the last 20 ms",
+// call that happens to arrive first only: 1,648 / 1,010 / 3,342 -- hence "another scorer began a call here within the last 20 ms",
 // which all the scorers of a busy device agree on).
-struct DeviceActivity {
-  std::atomic<const void *> last_scorer{nullptr};
-  std::atomic<long long> last_ns{0};
+struct DeviceActivity {  // the scorers seen lately on a device: (scorer, start of its last call), a handful of slots
+  static constexpr int kSlots = 16;
+  std::atomic<const void *> scorer[kSlots];
+  std::atomic<long long> last_ns[kSlots];
 };
 static DeviceActivity g_activity[64];
 static bool scorer_alone_on_device(int device, const void *scorer) {
   DeviceActivity &a = g_activity[device >= 0 && device < 64 ? device : 0];
   const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  const void *prev = a.last_scorer.exchange(scorer);
-  const long long prev_ns = a.last_ns.exchange(now);
-  return prev == nullptr || prev == scorer || now - prev_ns > 20000000ll;
+  bool alone = true;
+  int mine = -1, oldest = 0;
+  for (int i = 0; i < DeviceActivity::kSlots; i++) {
+    const void *sc = a.scorer[i].load(std::memory_order_relaxed);
+    const long long t = a.last_ns[i].load(std::memory_order_relaxed);
+    if (sc == scorer) mine = i;
+    else if (sc != nullptr && now - t < 20000000ll) alone = false;
+    if (t < a.last_ns[oldest].load(std::memory_order_relaxed)) oldest = i;
+  }
+  if (mine < 0) mine = oldest;  // (a race between two new scorers for one slot costs one of them a stale entry for one call)
+  a.scorer[mine].store(scorer, std::memory_order_relaxed);
+  a.last_ns[mine].store(now, std::memory_order_relaxed);
+  return alone;
 }
 
 // The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: a set per scorer is harmful -- four
@@ -1336,6 +1347,7 @@ struct Scorer {
   std::vector<Model *> models;
   hipStream_t stream = nullptr;
   int precision = 0;  // 0 = fp32 (parity path), 1 = bf16-MFMA forward (mi_scorer_set_precision)
+  int h2_honly = 0;   // MI_PRECISION_FP16: scoring calls' split-fp16 kernels issue the h * h MFMA only (ConvArgs::h2_honly)
   // fp32 forward convolutions: 1 = on the split-fp16 kernels where a layer has that plan (conv3d_h2.hip), 0 = fp32 MFMA only
   // (MI_PRECISION_FP32_MFMA, or MI_GNINA_CONV_PATH=f32 in the environment)
   int conv_path = (option(OPT_MI_GNINA_CONV_PATH) && !strcmp(option(OPT_MI_GNINA_CONV_PATH), "f32")) ? 0 : 1;
@@ -2023,6 +2035,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             s.d_ovf.ensure(1);
             h.h2_overflow = s.d_ovf.p;
             h.mfma_count = nullptr;
+            h.h2_honly = (!grad && s.h2_honly) ? 1 : 0;  // (MI_PRECISION_FP16: scoring calls only)
             // (timing experiments, wrong results: conv3d_h2_dense.hip's h2_dbg bits)
             if (const char *ev = option(st.conv.has_d16 ? OPT_MI_GNINA_D16_DBG : OPT_MI_GNINA_K1S_DBG)) h.h2_dbg = atoi(ev);
             if (st.conv.has_d16) {
@@ -2062,6 +2075,8 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             }
             s.d_ovf.ensure(1);
             h.h2_overflow = s.d_ovf.p;
+            h.h2_honly = (!grad && s.h2_honly) ? 1 : 0;  // (MI_PRECISION_FP16: scoring calls only)
+            if (h.h2_honly) h.h2_ws = 0;
             if (const char *ev = option(OPT_MI_GNINA_H2_DBG)) h.h2_dbg = atoi(ev);
             h.mfma_count = (h.sparse && h.coutp != 16) ? prof_counter(s, ps) : nullptr;
             launch_conv_h2(h, cfg, nb, s.stream);
@@ -2980,11 +2995,12 @@ mi_status mi_debug_vox_stress(mi_scorer *sc, const float *lig_xyz, const int32_t
 mi_status mi_scorer_set_precision(mi_scorer *sc, int precision) {
   MI_TRY
   MIG_CHECK(sc, 1, "NULL scorer");
-  MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16 || precision == MI_PRECISION_FP32_MFMA, 1,
+  MIG_CHECK(precision == MI_PRECISION_FP32 || precision == MI_PRECISION_BF16 || precision == MI_PRECISION_FP32_MFMA || precision == MI_PRECISION_FP16, 1,
             "unknown precision");
   Scorer &s = *reinterpret_cast<Scorer *>(sc);
   s.precision = precision == MI_PRECISION_BF16 ? 1 : 0;
   if (precision != MI_PRECISION_BF16) s.conv_path = precision == MI_PRECISION_FP32_MFMA ? 0 : 1;
+  s.h2_honly = precision == MI_PRECISION_FP16 ? 1 : 0;
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -137,8 +137,19 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * MI_PRECISION_BF16 (BASELINE config 5, "bf16 MFMA path") runs the convolutions on v_mfma_f32_32x32x16_bf16 with bf16
  * activations / weights and fp32 accumulation; voxelization, the fully connected heads and the score post-processing
  * stay fp32.  Its deviation from the fp32 path is a measured tolerance (tests/test_gpu_bf16.py), not the 1e-4 bar.
- * Gradient calls (MI_PRECISION_FP32 / _FP32_MFMA; never bf16): the forward pass takes the same kernels as a scoring
- * call of the same precision -- a pose scores the same bits with and without its gradient.  Under MI_PRECISION_FP32 the
+ * MI_PRECISION_FP16 (round 6: the reduced-precision mode for config 5's Dense network) runs the parity path's own program
+ * and tensors, but the Dense family's block layers and transitions (conv3d_h2_d16_kernel / conv3d_h2_k1s_kernel: nine tenths
+ * of a Dense pose's FLOPs) issue only the h * h MFMA of every product and neither DMA nor read the l planes: activations and
+ * weights rounded to fp16 (11 significant bits against bf16's 8), fp32 accumulation, one MFMA where the parity path issues
+ * three.  The other layers keep the parity arithmetic; scoring calls only (gradient calls run the parity path); measured
+ * tolerance in tests/test_gpu_bf16.py.
+ * Gradient calls (MI_PRECISION_FP32 / _FP32_MFMA; never bf16): the forward half runs the split-fp16 kernels on fp32
+ * tensors (the backward pass reads the activations as masks).  For the Default2017 / Default2018 families that is the K
+ * order and MFMA order of a scoring call: a pose scores the same bits with and without its gradient.  The Dense family's
+ * scoring calls run its block layers on split-format concat buffers with the BatchNorm folded into the weights
+ * (conv3d_h2_dense.hip) while gradient calls apply the BatchNorm while staging: a Dense pose's score differs by <= 2e-6
+ * between the two kinds of call (tests/test_gpu_gradient.py asserts that bound; 50 times below the parity bar, but not
+ * zero: a caller that compares energies of the two kinds of call, like non_cache_cnn::eval vs eval_deriv, sees it).  Under MI_PRECISION_FP32 the
  * 3x3x3 transposed convolutions of the backward pass (and the Dense transitions) run on the split-fp16 kernels as well: a
  * gradient tensor is staged times the power of two that puts its per-pose maximum into [2^14, 2^15) -- recorded by
  * whichever kernel wrote the tensor -- so no magnitude of gradient is out of range, and the atom gradients stay within
@@ -155,7 +166,7 @@ mi_status mi_scorer_score_batch_ex(mi_scorer *, const float *lig_xyz, const int3
  * Small values: an activation below 2^-14 has a subnormal high half, below 2^-24 it is taken as zero -- an absolute
  * error of at most 2^-25 per activation, far below the parity bar for weights of any sane magnitude
  * (tests/test_gpu_h2_range.py drives both ends). */
-enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2 };
+enum { MI_PRECISION_FP32 = 0, MI_PRECISION_BF16 = 1, MI_PRECISION_FP32_MFMA = 2, MI_PRECISION_FP16 = 3 };
 mi_status mi_scorer_set_precision(mi_scorer *, int precision);
 /* calls of this scorer that were repeated on the fp32-MFMA kernels because of the range flag (diagnostics, tests) */
 int mi_scorer_h2_fallbacks(const mi_scorer *);
