@@ -22,6 +22,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The library asks the HIP runtime for 16 hardware queues per priority instead of 4 (mi_gnina_init; include/mi_gnina.h) -- which
+# only counts before the process's FIRST HIP call, and in this process that call is torch's (device tensors, torch.distributed).
+# So the variable is set here, as any host that initialises HIP before the library must (INTEGRATION.md "Threads"): with the
+# default 4, gnina's default ensemble at B = 1 takes 736 instead of 592 us per call and four threads reach 1,805 instead of
+# 3,361 poses/s (tools/experiments/seam_b1_in_bench.py).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same guide)

@@ -71,13 +71,15 @@ static std::recursive_mutex &device_call_lock(int device) {
   return locks[device >= 0 && device < 64 ? device : 0];
 }
 
-// Is this scorer the only one scoring on its device?  A call of a scorer that has the device to itself spreads an ensemble's
-// models over the lane streams; when other scorers are at work on the device as well -- gnina's worker threads, each with its
-// fresh_copy() -- every call stays on its own stream: the device is busy anyway, and lanes of several scorers queue up behind
-// each other on the shared (priority) lane streams while calls without lanes starve next to them (measured, gnina's default
-// ensemble at B = 1, poses/s from 1 / 2 / 4 threads: lanes always 1,635 / 2,091 / 1,045; never 889 / 1,738 / 1,985; lanes for the
-// call that happens to arrive first only: 1,648 / 1,010 / 3,342 -- hence "another scorer began a call here within the last 20 ms",
-// which all the scorers of a busy device agree on).
+// Lanes or not?  A call of at most eight poses may spread an ensemble's models over the device's lane streams (priority streams
+// shared by all scorers of the device).  That is the fastest thing to do while at most one OTHER scorer is at work on the device;
+// with more -- gnina's worker threads, each with its fresh_copy() -- the lanes of several scorers queue up behind each other on
+// the shared streams, and every call stays on its scorer's own stream instead.  Measured on gnina's default ensemble at B = 1,
+// poses/s from 1 / 2 / 4 host threads: lanes always 1,640 / 2,062 / 1,066; never 881 / 1,734 / 1,985; this rule 1,669 / 2,100 /
+// 3,279.  (A mixed population -- some calls on lanes, some not -- is the worst regime: 1,010 from two threads; hence a rule all
+// scorers of a device agree on: "how many other scorers began a call here within the last 20 ms".  Why four plain scorers reach
+// 3,279 once lane streams exist and 1,985 when none was ever created is the runtime's stream -> hardware-queue placement, not
+// looked into further.)
 struct DeviceActivity {  // the scorers seen lately on a device: (scorer, start of its last call), a handful of slots
   static constexpr int kSlots = 16;
   std::atomic<const void *> scorer[kSlots];
@@ -87,19 +89,19 @@ static DeviceActivity g_activity[64];
 static bool scorer_alone_on_device(int device, const void *scorer) {
   DeviceActivity &a = g_activity[device >= 0 && device < 64 ? device : 0];
   const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  bool alone = true;
+  int others = 0;
   int mine = -1, oldest = 0;
   for (int i = 0; i < DeviceActivity::kSlots; i++) {
     const void *sc = a.scorer[i].load(std::memory_order_relaxed);
     const long long t = a.last_ns[i].load(std::memory_order_relaxed);
     if (sc == scorer) mine = i;
-    else if (sc != nullptr && now - t < 20000000ll) alone = false;
+    else if (sc != nullptr && now - t < 20000000ll) others++;
     if (t < a.last_ns[oldest].load(std::memory_order_relaxed)) oldest = i;
   }
   if (mine < 0) mine = oldest;  // (a race between two new scorers for one slot costs one of them a stale entry for one call)
   a.scorer[mine].store(scorer, std::memory_order_relaxed);
   a.last_ns[mine].store(now, std::memory_order_relaxed);
-  return alone;
+  return others <= 1;
 }
 
 // The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: a set per scorer is harmful -- four
@@ -2549,7 +2551,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       const size_t slot = set ? kPooledSlot2 : kPooledSlot;
       float *pooled = act_buf(s, slot, pooled_n);
       hipStream_t vs = s.stream;
-      if (lanes && gi > 0 && !ragged) {
+      if (lanes && gi > 0 && !ragged && !option(OPT_MI_GNINA_VOX_SERIAL)) {  // (MI_GNINA_VOX_SERIAL=1: the groups one after the other on the main stream)
         vs = s.lane_streams[g.first_model];
         MIG_HIP(hipStreamWaitEvent(vs, s.lane_start[s.groups.size()], 0));
       }

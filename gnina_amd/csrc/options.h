@@ -59,7 +59,8 @@ namespace mig {
   X(MI_VOX_DBG)                      \
   X(MI_GNINA_NO_CALL_LOCK)           \
   X(MI_GNINA_CALL_LOCK)              \
-  X(MI_GNINA_H2_WS)
+  X(MI_GNINA_H2_WS)                  \
+  X(MI_GNINA_VOX_SERIAL)
 
 enum OptionId {
 #define X(n) OPT_##n,
