@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--spinup-seconds", type=float, default=0.3,
                     help="untimed steps in front of the warm-up steps until the GPU's clocks are at their steady state")
+    ap.add_argument("--only", default="", help="comma-separated keys of `also` to run (default: all): real_complex,c3,c3_real,c4,c5,seam_b1,gradient_calls")
     ap.add_argument("--extras-timeout", type=float, default=900.0,
                     help="seconds the sub-benchmarks behind the timed region may take before the headline line is printed without them")
     return ap.parse_args()
@@ -1159,6 +1160,8 @@ def main():
                                 ("c4", lambda: config_c4(capi, synth)), ("c5", lambda: config_c5(capi, synth)),
                                 ("seam_b1", lambda: config_seam_b1(capi, synth)),
                                 ("gradient_calls", lambda: config_gradient_calls(capi, synth))):
+                    if args.only and key not in args.only.split(","):
+                        continue
                     extras_phase["name"] = "also." + key
                     try:
                         res["also"][key] = fn()

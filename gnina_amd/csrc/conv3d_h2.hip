@@ -550,13 +550,13 @@ typedef __attribute__((address_space(3))) void *LdsPtr;
 constexpr int kH2NS = 8, kH2VPT = 4;
 
 template <int WM, int WN, int TM, int MT, bool SKIP, bool INSPLIT, bool WLDS = false, int NP = 1, bool BWD = false>
-__global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H2_OCC2 : TM <= 3 ? MI_H2_OCC3 : TM <= 4 ? 2 : 1) : (TM <= 2 ? 3 : TM <= 4 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WLDS ? (NP >= 4 ? 2 : 3) : INSPLIT ? (TM <= 2 ? MI_H2_OCC2 : TM <= 3 ? MI_H2_OCC3 : TM <= 4 ? 2 : 1) : (TM <= 2 ? 3 : TM <= 4 ? 2 : 1))) void conv3d_h2_kernel(ConvArgs p) {
   constexpr int NW = WM * WN, NTHREADS = 64 * NW;
   static_assert(NW == 4, "staging is laid out for four waves");
   static_assert(!WLDS || WN == 1, "weights in LDS: the four waves of a workgroup share one set of 32 output channels");
   // NP poses per workgroup (WLDS + INSPLIT): the same tile of NP consecutive poses, one after the other, on ONE copy of the
   // chunk's weights in LDS -- the weights are most of what a workgroup pulls out of L2 (143 KB against a 97 KB halo tile)
-  static_assert(NP == 1 || (NP == 2 && WLDS && INSPLIT && TM <= 2), "two poses per workgroup: weights-in-LDS variant, split-format input");
+  static_assert(NP == 1 || ((NP == 2 || NP == 4) && WLDS && INSPLIT && TM <= 2), "two / four poses per workgroup: weights-in-LDS variant, split-format input");
   // BWD: a transposed conv of the gradient pass (ConvArgs::in_amax / in_mode 2 / out_mask / out_amax) -- its own instantiation
   // so that the forward kernels carry none of its registers
   static_assert(!BWD || (!INSPLIT && WLDS && NP == 1), "gradient-pass variant: fp32 tensors, weights through LDS");
@@ -990,6 +990,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
       pose_pass(std::integral_constant<int, 0>{});
       if constexpr (NP > 1)
         if (npose > 1) pose_pass(std::integral_constant<int, 1>{});
+      if constexpr (NP > 2) {
+        if (npose > 2) pose_pass(std::integral_constant<int, 2>{});
+        if (npose > 3) pose_pass(std::integral_constant<int, 3>{});
+      }
       chunk = next;
     }
   } else {
@@ -1253,6 +1257,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? 3 : INSPLIT ? (TM <= 2 ? MI_H
   finish_pose(std::integral_constant<int, 0>{});
   if constexpr (NP > 1)
     if (npose > 1) finish_pose(std::integral_constant<int, 1>{});
+  if constexpr (NP > 2) {
+    if (npose > 2) finish_pose(std::integral_constant<int, 2>{});
+    if (npose > 3) finish_pose(std::integral_constant<int, 3>{});
+  }
   if constexpr (BWD) {
     if (p.out_amax) {  // (ConvArgs::out_amax)
       for (int o = 32; o; o >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, o));
@@ -1561,6 +1569,12 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
           if constexpr (SK && MT == 1 && WM == 4)
             if (p.in_split && p.h2_ws > 0 && B >= 32 && conv_h2_ws_covers(p, B)) {  // stationary weights, ring of tiles (conv3d_h2_ws.hip)
               launch_conv_h2_ws(p, B, p.h2_ws, s);
+              return;
+            }
+          if constexpr (SK && MT == 1 && WM == 4)
+            if (p.in_split && p.h2_wlds >= 4 && B >= 4 && !p.post_w) {  // (experiment: four poses per workgroup on one copy of the weights)
+              grid.x = (unsigned)((B + 3) / 4 * p.ntx * p.nty * p.ntz);
+              go(conv3d_h2_kernel<WM, WN, TM, MT, SK, true, true, 4>);
               return;
             }
           if (p.in_split && p.h2_wlds >= 2 && B >= 2) {

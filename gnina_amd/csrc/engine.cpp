@@ -2705,6 +2705,11 @@ mi_status mi_gnina_init(int device) {
   MIG_CHECK(n > 0, 3, "no HIP device visible");
   MIG_CHECK(device >= 0 && device < n, 1, "device index out of range");
   MIG_HIP(hipSetDevice(device));
+  // The device's first three lane streams are created NOW, ahead of the streams of whatever else the process sets up (mi_vina
+  // handles, pools, the host's own): which hardware queue a stream lands on is decided by the runtime from what exists at
+  // that moment, and lanes created behind a few dozen short-lived streams shared queues with each other -- gnina's default
+  // ensemble at B = 1 took 0.88-0.96 ms instead of 0.60 after the bench's C3 / C5 configurations had run in the process.
+  for (int k = 0; k < 3; k++) (void)device_lane_stream(device, k);
   return MI_OK;
   MI_CATCH_STATUS
 }
