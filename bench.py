@@ -650,7 +650,7 @@ def config_seam_b1(capi, synth):
     out = {"note": "B = 1 per call, host pointers, synchronous; median of 60 calls after 0.3 s of warm-up calls; microseconds.  "
                    "two / four_threads: scorers on host threads of their own (gnina: one fresh_copy() per worker thread), scoring "
                    "side by side -- round 6 removed the per-device lock of round 5 (its cause, packed-fp32 instructions next to "
-                   "another queue's MFMAs, is compiled out: DESIGN section 6); a scorer that has the device to itself runs an "
+                   "another queue's MFMAs, is compiled out: DESIGN.md §6); a scorer that has the device to itself runs an "
                    "ensemble's models on streams of their own (lanes), scorers that share it stay on their own streams"}
     for label, models in (("default2017", ["default2017"]),
                           ("default_ensemble", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])):
@@ -874,7 +874,7 @@ def main():
     dist = None
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         # (ProcessGroupNCCL's heartbeat monitor thread: the same step measures 3.71 ms without it against 3.77 with it,
-        # and 3.63 ms in a process without a process group -- DESIGN section 5)
+        # and 3.63 ms in a process without a process group -- DESIGN.md §5)
         os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

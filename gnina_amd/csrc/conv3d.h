@@ -69,7 +69,7 @@ struct ConvArgs {
   // M-tile geometry: 0 = the four cells of an M-tile are consecutive cells of the tile in (x, y, z) raster order;
   // 1 = they are stacked along x (tcx % 4 == 0); 2 (conv3d_h2_kernel only) = a 2 x 2 square in (x, y), tcx == tcy == 2.  With a 4 x 4 x 2-cell tile (halo 10 x 10 x 6, odd quad stride) the
   // sixteen lanes of every ds_read_b128 lane group then hit sixteen different 16-byte LDS slots (no bank conflict;
-  // the raster order costs 3 LDS cycles per group) -- see DESIGN.md section 3.1.
+  // the raster order costs 3 LDS cycles per group) -- see LAB.md §3.1.
   int mt_x;
   // split-fp16 kernels (conv3d_h2.hip) only: cc4 counts OCTETS per K chunk, ccs fp16 elements per halo voxel in LDS, cin4
   // stays the input's channel QUADS, wp is the packed [chunk][pair][2][coutp][h0..h7 | l0..l7] fp16 array of the weights

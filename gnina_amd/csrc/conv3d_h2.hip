@@ -18,7 +18,7 @@
 //
 // Three kernels:
 //   conv3d_h2_kernel     3x3x3 layers, 32 output channels per wave column: one octet per K chunk, planar halo tile in LDS,
-//                        LDS-DMA staging of split-format inputs, the chunk's weights through LDS
+//                        LDS-DMA staging of split-format inputs, the chunk's weights through LDS (LAB.md §3.9)
 //   conv3d_h2_k1_kernel  1x1x1 layers (round 3's kernel): [voxel][octet][h | l] tile, fp32 input split while staging
 //   conv3d_h2_16_kernel  the Dense blocks' 16-channel layers (v_mfma_f32_16x16x32_f16)
 // Decomposition as in conv3d.hip: a workgroup owns a box of 2x2x2 cells of one pose and all (or a group of) output

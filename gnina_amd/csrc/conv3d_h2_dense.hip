@@ -5,7 +5,7 @@
 // (c_in -> 16) -> ReLU -> append to the concat buffer (the TorchScript the reference runs at
 // gninasrc/lib/torch_model.cpp:185).  Until round 4 those layers ran on conv3d_h2_16_kernel: fp32 concat buffer, BatchNorm
 // and the fp16 split applied while staging (2.3 times per element, halo included), weights fetched by every wave from
-// L1 / L2, A-operand reads at 0.48 bank conflicts each.  This file is the first convolution's recipe
+// L1 / L2, A-operand reads at 0.48 bank conflicts each.  This file is the first convolution's recipe (LAB.md §3.9)
 // applied to them:
 //
 //   * the concat buffer lives in HBM in the SPLIT FORMAT ([pose][octet][x][y][z][h0..h7 | l0..l7] fp16, conv3d.h
@@ -21,7 +21,7 @@
 //   * an M-tile is 4 x 2 x 2 voxels (row = y * 8 + z * 4 + x) and the taps are PAIRED (kD16TapOrder) so that every
 //     ds_read_b128 lane group of the A operands hits sixteen different 16-byte slots modulo 16 with NO pad slots for the
 //     tiles used (z-row stride 2 mod 4, x-plane stride 4 mod 8 slots: d16_layout_conflict_free checks the plan with the
-//     bank model of MI355X_MICROARCH.md / DESIGN.md 3.1).
+//     bank model of MI355X_MICROARCH.md / LAB.md §3.1).
 //
 // Also here: conv3d_h2_k1s_kernel, the 1x1x1 transitions (96 -> 96 at 24^3, 160 -> 160 at 12^3, + ReLU + max pool) reading
 // a split-format concat buffer by LDS-DMA and writing fp32 or split output.
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
 
   // PERSISTENT workgroups: the launch has at most (workgroups that fit the chip at once) of them and each walks the
   // (pose pair, tile) items item, item + gridDim.x, ... -- launching a 256-thread workgroup costs ~14 ns of dispatch on this
-  // chip (27,648 of them that do nothing but their prologue and barriers take 0.37-0.42 ms: tools/experiments), a
+  // chip (27,648 of them that do nothing but their prologue and barriers take 0.37-0.42 ms: tools/experiments, LAB.md §3.10), a
   // fifth of a layer's time; the item's own set-up (tile coordinates, DMA offsets) is VALU work that overlaps with the other
   // resident workgroups' DMA phases.  gridDim.x is a multiple of 8 (or the item count), so item % 8 is this workgroup's XCD
   // for every item and xcd_contiguous_id keeps a pose's tiles on one XCD's L2.

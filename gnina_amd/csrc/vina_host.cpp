@@ -167,7 +167,7 @@ static void build_tables(Vina &v, const float *w, float cutoff, float factor) {
 // derivative at both ends through them.  The reference solves the (n + 1) x (n + 1) system by inverting the dense
 // matrix in fp32 with Eigen (a third-party header library); the system is tridiagonal and diagonally dominant, here
 // it is solved directly (Thomas algorithm, double accumulation), coefficients rounded to fp32 in the reference's
-// formulas -- same spline to ~1e-6 of its scale, not bit-identical (stated in DESIGN.md section 4).
+// formulas -- same spline to ~1e-6 of its scale, not bit-identical (stated in DESIGN.md §4).
 static void build_splines(Vina &v, float cutoff, float factor) {
   const unsigned n = (unsigned)(factor * cutoff);
   MIG_CHECK(n >= 2 && n < 65536, 1, "spline approximation: factor * cutoff must give 2 .. 65535 intervals");

@@ -318,7 +318,7 @@ __device__ __forceinline__ unsigned vox_split1(float x) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(b, vox_f16x2));
 }
 
-// The MI_VOX_DBG timing switches (wrong results; DESIGN 3.10's breakdown) exist only in a build with -DMI_VOX_TIMING: the
+// The MI_VOX_DBG timing switches (wrong results; LAB.md §3.10's breakdown) exist only in a build with -DMI_VOX_TIMING: the
 // tile kernel is bound by its scalar instruction count, and four tests of a kernel argument per hit / flush / window are
 // part of it.
 #ifdef MI_VOX_TIMING

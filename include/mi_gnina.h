@@ -58,7 +58,7 @@ enum {
  * its own (cnn_torch_scorer.h:54, dl_scorer.h:43-44, main.cpp:1436-1438, parallel_mc.cpp:145-146).  Every call gives the
  * bits the same call gives alone (tests/test_gpu_concurrency.py: two threads, host and device outputs).  Rounds 5 serialised
  * such calls per device because a voxelizer next to another scorer's conv kernels deviated; round 6 traced that to the
- * voxelizer's packed-fp32 instructions (DESIGN.md "concurrency"), removed them, and removed the lock (MI_GNINA_CALL_LOCK=1
+ * voxelizer's packed-fp32 instructions, removed them, and removed the lock (MI_GNINA_CALL_LOCK=1
  * brings it back for A/B measurements).  Within a call of at most 8 poses the models of an ensemble run on streams of their
  * own behind the voxelization (same bits as on one stream; MI_GNINA_LANES=0 switches it off). */
 mi_status mi_gnina_init(int device);

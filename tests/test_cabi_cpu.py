@@ -56,7 +56,7 @@ def test_product_sources_never_touch_the_oracle():
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: the failure path is for GPU-less hosts")
 def test_device_code_has_no_packed_fp32_instructions(capi, tmp_path):
-    """Round 6 (DESIGN.md "concurrency"): chains of packed-fp32 VALU instructions give wrong results in lanes 32-63 while
+    """Round 6: chains of packed-fp32 VALU instructions give wrong results in lanes 32-63 while
     another queue's Dense conv kernels share the SIMD -- voxelize_tiles deviated next to a second scorer because of them.  The
     library is compiled with the instruction class switched off (gnina_amd/build.py FLAGS): no kernel may contain one."""
     import shutil

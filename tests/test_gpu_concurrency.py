@@ -4,7 +4,7 @@ dl_scorer.h:43-44, main.cpp:1436-1438, parallel_mc.cpp:145-146).  Every call mus
 
 Round 5 found that it did not (~5 % of B = 1 calls next to a Dense model, up to 6e-2 in the affinity) and serialised the calls
 per device.  Round 6 found the cause -- voxelize_tiles' packed-fp32 instructions go wrong in the upper half of a wavefront
-while the Dense family's f16-MFMA K loops share the SIMD (DESIGN.md "concurrency"; tools/experiments/vox_stress.py) --, took
+while the Dense family's f16-MFMA K loops share the SIMD (tools/experiments/vox_stress.py) --, took
 those instructions out of the voxelizer and took the lock away: these tests run WITHOUT any serialisation, host-output and
 device-output calls, and with an ensemble's models on their own streams (lanes: on by default for calls of <= 8 poses)."""
 import os

@@ -1,4 +1,4 @@
-"""What does a second hardware queue do to the voxelizer?  (round 6; DESIGN "concurrency")
+"""What does a second hardware queue do to the voxelizer?  (round 6)
 
 The victim is the voxelizer ALONE: one scorer runs gather_pose_atoms + voxelize_tiles for one pose again and again
 (mi_debug_vox_stress: no network behind it, no per-device lock) and every iteration's pooled grid is compared ON THE DEVICE

@@ -1,7 +1,7 @@
 // pk_f32_next_to_mfma.hip -- do the packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32) of one kernel give wrong
 // results while ANOTHER kernel's MFMA waves share the SIMD?
 //
-// Round 6 (DESIGN "what a second hardware queue does to the voxelizer"): voxelize_tiles next to a Dense scorer's conv
+// Round 6: voxelize_tiles next to a Dense scorer's conv
 // kernels on a second hardware queue produced, in ~2 % of its launches, squared distances that were wrong in the UPPER HALF
 // of a wavefront (lanes 32-63); the build of the same kernel without v_pk_*_f32 was clean in 20,000 launches.  This is the
 // smallest program that asks the hardware the same question:

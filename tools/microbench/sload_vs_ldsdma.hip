@@ -2,7 +2,7 @@
 // the way voxelize_tiles fetches the record of a hit) see wrong data while a kernel full of LDS-DMA (buffer_load_dwordx4 ... lds,
 // the way the split-fp16 conv kernels stage their tiles) runs on a second hardware queue of the same process?
 //
-// two scorers on two host threads do not reproduce their single-thread bits when the LDS-DMA kernels are in
+// LAB.md §3.10: two scorers on two host threads do not reproduce their single-thread bits when the LDS-DMA kernels are in
 // the mix; this is the smallest program that asks the hardware the same question.
 //   victim   : single-wave workgroups, each checks `iters` pseudo-random records of a read-only table fetched (a) by scalar
 //              loads, (b) by vector loads; every dword is a function of its index, mismatches are counted
