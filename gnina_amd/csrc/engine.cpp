@@ -72,14 +72,13 @@ static std::recursive_mutex &device_call_lock(int device) {
 }
 
 // Lanes or not?  A call of at most eight poses may spread an ensemble's models over the device's lane streams (priority streams
-// shared by all scorers of the device).  That is the fastest thing to do while at most one OTHER scorer is at work on the device;
-// with more -- gnina's worker threads, each with its fresh_copy() -- the lanes of several scorers queue up behind each other on
-// the shared streams, and every call stays on its scorer's own stream instead.  Measured on gnina's default ensemble at B = 1,
-// poses/s from 1 / 2 / 4 host threads: lanes always 1,640 / 2,062 / 1,066; never 881 / 1,734 / 1,985; this rule 1,669 / 2,100 /
-// 3,279.  (A mixed population -- some calls on lanes, some not -- is the worst regime: 1,010 from two threads; hence a rule all
-// scorers of a device agree on: "how many other scorers began a call here within the last 20 ms".  Why four plain scorers reach
-// 3,279 once lane streams exist and 1,985 when none was ever created is the runtime's stream -> hardware-queue placement, not
-// looked into further.)
+// shared by all scorers of the device).  That is the fastest thing to do for a scorer that has the device to itself; when other
+// scorers are at work on it as well -- gnina's worker threads, each with its fresh_copy() -- the lanes of several scorers queue
+// up behind each other on the shared streams, and every call stays on its scorer's own stream.  Measured on gnina's default
+// ensemble at B = 1, poses/s from 1 / 2 / 4 host threads (bench.py's seam_b1, round 6): this rule 1,661 / 1,703 / 3,300; lanes
+// always 1,640 / 2,062 / 1,066; never 881 / 1,734 / 1,985.  (A mixed population -- some calls on lanes, some not -- is the worst
+// regime, 1,010 from two threads: hence a rule all scorers of a device agree on, "did another scorer begin a call here within
+// the last 20 ms".  Which hardware queue a stream sits on matters as much as the rule: Scorer::lane_offset.)
 struct DeviceActivity {  // the scorers seen lately on a device: (scorer, start of its last call), a handful of slots
   static constexpr int kSlots = 16;
   std::atomic<const void *> scorer[kSlots];
@@ -101,7 +100,7 @@ static bool scorer_alone_on_device(int device, const void *scorer) {
   if (mine < 0) mine = oldest;  // (a race between two new scorers for one slot costs one of them a stale entry for one call)
   a.scorer[mine].store(scorer, std::memory_order_relaxed);
   a.last_ns[mine].store(now, std::memory_order_relaxed);
-  return others <= 1;
+  return others <= (option(OPT_MI_GNINA_LANES_OTHERS) ? atoi(option(OPT_MI_GNINA_LANES_OTHERS)) : 0);  // (MI_GNINA_LANES_OTHERS: A/B switch)
 }
 
 // The lane streams of a device (see Scorer::lane_streams), shared by all its scorers: a set per scorer is harmful -- four
@@ -1371,6 +1370,16 @@ struct Scorer {
   // its own set of activation buffers (act_lane) -- the launches of a B = 1 program are latency, not throughput, and three
   // independent chains of ~20 dependent kernels overlap almost entirely.  Results are the bits of the serial order.
   std::vector<hipStream_t> lane_streams;  // (the device's shared set: device_lane_stream)
+  // Which of the device's eight lane streams the models take: model mi runs on stream (lane_offset + mi) % 8.  The hardware
+  // queue -- and with it the command-processor pipe -- a stream sits on is the runtime's choice from what existed when the
+  // stream was created, and an ensemble call of ~60 dependent launches is 0.59 ms on one choice of three streams and 0.95-1.26
+  // ms on others (round 6, tools/experiments: MI_GNINA_LANE_OFFSET=0..5: 983 / 948 / 588 / 643 / 1,264 / 1,001 us).  So a scorer
+  // TRIES the eight offsets on its first synchronous lane calls (kLaneTunePer calls each, the fastest of the later ones
+  // counts) and keeps the best.
+  int lane_offset = 0, lane_streams_offset = -1;
+  int lane_tune_calls = 0, lane_tune_best = 0, lane_tune_B = 0;
+  double lane_tune_best_us = 1e30, lane_tune_cur_us = 1e30;
+  bool last_call_lanes = false;
   std::vector<hipEvent_t> lane_done;
   std::vector<hipEvent_t> lane_start;   // per voxelization group
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
@@ -2508,9 +2517,13 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     bool split;
   };
   std::vector<LaneJob> lane_jobs;
+  s.last_call_lanes = lanes;
   if (lanes) {
-    while ((int)s.lane_streams.size() < nm) {
-      s.lane_streams.push_back(device_lane_stream(s.device, (int)s.lane_streams.size() % 8));
+    if (option(OPT_MI_GNINA_LANE_OFFSET)) s.lane_offset = atoi(option(OPT_MI_GNINA_LANE_OFFSET)) & 7;  // (fixed by hand: no tuning)
+    if (s.lane_streams_offset != s.lane_offset) s.lane_streams.clear();
+    s.lane_streams_offset = s.lane_offset;
+    while ((int)s.lane_streams.size() < nm) s.lane_streams.push_back(device_lane_stream(s.device, ((int)s.lane_streams.size() + s.lane_offset) % 8));
+    while ((int)s.lane_done.size() < nm) {
       hipEvent_t e = nullptr;
       MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       s.lane_done.push_back(e);
@@ -2640,7 +2653,21 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   s.alone_on_device = scorer_alone_on_device(s.device, &s) || (option(OPT_MI_GNINA_LANES) && atoi(option(OPT_MI_GNINA_LANES)) > 1);  // (MI_GNINA_LANES=2: lanes whatever else runs)
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
+  const auto t_call = std::chrono::steady_clock::now();
   score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
+  // lane-offset tuning (Scorer::lane_offset): synchronous lane calls of one batch size, kLaneTunePer per candidate
+  constexpr int kLaneTunePer = 4, kLaneCands = 8;
+  if (s.last_call_lanes && !(flags & MI_OUT_ON_DEVICE) && s.lane_tune_calls < kLaneCands * kLaneTunePer && !option(OPT_MI_GNINA_LANE_OFFSET) &&
+      (int)s.models.size() <= kLaneCands && (s.lane_tune_calls == 0 || B == s.lane_tune_B)) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+    s.lane_tune_B = B;
+    const int k = s.lane_tune_calls % kLaneTunePer;
+    if (k == 0) s.lane_tune_cur_us = 1e30;             // (the first call on a new set of streams is not counted)
+    else s.lane_tune_cur_us = std::min(s.lane_tune_cur_us, us);
+    if (k == kLaneTunePer - 1 && s.lane_tune_cur_us < s.lane_tune_best_us) s.lane_tune_best_us = s.lane_tune_cur_us, s.lane_tune_best = s.lane_offset;
+    s.lane_tune_calls++;
+    s.lane_offset = s.lane_tune_calls < kLaneCands * kLaneTunePer ? s.lane_tune_calls / kLaneTunePer : s.lane_tune_best;
+  }
   if (s.conv_path == 0) return;
   if (flags & MI_OUT_ON_DEVICE) {
     s.ovf_pending = true;
@@ -2709,7 +2736,7 @@ mi_status mi_gnina_init(int device) {
   // handles, pools, the host's own): which hardware queue a stream lands on is decided by the runtime from what exists at
   // that moment, and lanes created behind a few dozen short-lived streams shared queues with each other -- gnina's default
   // ensemble at B = 1 took 0.88-0.96 ms instead of 0.60 after the bench's C3 / C5 configurations had run in the process.
-  for (int k = 0; k < 3; k++) (void)device_lane_stream(device, k);
+  for (int k = 0; k < 8; k++) (void)device_lane_stream(device, k);
   return MI_OK;
   MI_CATCH_STATUS
 }

@@ -60,7 +60,9 @@ namespace mig {
   X(MI_GNINA_NO_CALL_LOCK)           \
   X(MI_GNINA_CALL_LOCK)              \
   X(MI_GNINA_H2_WS)                  \
-  X(MI_GNINA_VOX_SERIAL)
+  X(MI_GNINA_VOX_SERIAL)             \
+  X(MI_GNINA_LANES_OTHERS)           \
+  X(MI_GNINA_LANE_OFFSET)
 
 enum OptionId {
 #define X(n) OPT_##n,
