@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned ws_split1(float x) {
 }
 
 constexpr int kWsNT = 5;    // wave-DMAs per wave and tile: a tile buffer = kWsNT * 256 slots of 16 bytes >= 2 PL
-constexpr int kWsNW = 7;    // wave-DMAs per wave and chunk of weights: 28 pieces of 1 KB
+// (weights: 28 pieces of 1 KB per chunk, seven wave-DMAs per wave: issue_w spells them out)
 constexpr int kWsP = 14;    // steps per chunk: 27 taps in pairs
 constexpr int kWsTileB = kWsNT * 256 * 16, kWsWB = kWsP * 2048;
 
