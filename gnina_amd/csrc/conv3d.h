@@ -117,13 +117,17 @@ struct ConvArgs {
   // h2_persist = workgroups per CU the launch is capped at, each walking items blockIdx.x, + gridDim.x, ... (0 = one
   // workgroup per item)
   int n_items, h2_persist;
+  // conv3d_h2_d16_kernel, GRP variants (launches that leave a workgroup alone on its CU: per-pose calls): the K chunks of a
+  // tile are DMA'd d16_group at a time -- one L2 round trip for the group instead of one per chunk -- into as many
+  // [tile | weights] sets in LDS; same MFMAs in the same order.  Set by the launcher.
+  int d16_group;
   // MI_PRECISION_FP16 (the reduced-precision forward mode, BASELINE config 5): the split-fp16 kernels issue the h * h MFMA
   // only -- one of the three per product: activations and weights rounded to fp16, fp32 accumulation
   int h2_honly;
   // conv3d_h2_ws_kernel (conv3d_h2_ws.hip): > 0 = the launch may take the stationary-weights kernel with a ring of this many
   // halo-tile buffers (2 .. 5) where it covers the layer (conv_h2_ws_covers) and the batch is large enough; 0 = never
   int h2_ws;
-  int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run
+  int h2_dbg;  // timing experiments only (MI_GNINA_H2_DBG; wrong results): 1 = no chunk-level live test, 2 = no K loop, 4 = no staging, 8 = no weight loads, 16 = no A-operand reads, 32 = the tile's DMA sources are one contiguous run, 64 = no epilogue (d16 / k1s), 128 = no chunk groups in conv3d_h2_d16_kernel (right results)
 };
 
 constexpr int kMfmaCountSlots = 1024;

@@ -1273,13 +1273,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WLDS ? (NP >= 4 ? 2 : 3) : INSPLIT ?
   h2_report_overflow(p.h2_overflow, ovf_out || !(amax <= 65504.f));
 }
 
+// conv3d_h2_16_kernel's LDS in front of its optional weight buffers: tile, tap offsets, voxel offsets (16-byte aligned)
+__host__ __device__ inline size_t h2_16_main_lds_bytes(size_t HX, size_t SX, int Qmax, size_t HV) {
+  const size_t b = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Qmax + 8 + 3) & ~3) * sizeof(int) + (HV + 4) * sizeof(int);
+  return (b + 1023) & ~(size_t)1023;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 16-output-channel variant for the Dense blocks (Cout = 16): v_mfma_f32_16x16x32_f16.  An M-tile is 16 voxels = two cells
 // (row = cell * 8 + x * 4 + y * 2 + z, as in conv3d_mfma16_kernel); the 32 k of an instruction are four octets, lane
 // group l >> 4 feeding the fourth it owns.  Eval BatchNorm (scale and shift, fp32) is applied while staging; no zero test
 // (three 16-cycle MFMAs per test are not worth one, and BatchNorm'ed activations are not zeros).
 // ---------------------------------------------------------------------------------------------
-template <int TM>
+//
+// WL (round 6; the 6^3 layers): the chunk's packed weights (Smax steps x 2 KB) go through LDS, DMA'd one chunk ahead into
+// one of two buffers as [step][h | l][lane] -- a per-pose call has three workgroups on the chip for such a layer, each
+// pulling 300 KB of weights that nothing else has touched since the previous call, and with the register ring (four steps
+// ahead, ~100 MFMA cycles each) every step waited out most of an L2 miss: 3.5 us per chunk for 0.6 us of MFMAs.  Same
+// operands into the same MFMAs in the same order.
+template <int TM, bool WL = false>
 __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(ConvArgs p) {
   constexpr int NTHREADS = 256;
   const int tid = threadIdx.x;
@@ -1311,6 +1323,8 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
   _Float16 *s_tile = smem_h2;
   int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HX * SX + 7) & ~(size_t)7));  // [Qmax + 8] byte offsets
   int *s_vox = s_qoff + ((Qmax + 8 + 3) & ~3);
+  // (WL) two weight buffers behind the kernel's other LDS: h2_16_main_lds_bytes
+  char *const s_wbuf = reinterpret_cast<char *>(smem_h2) + h2_16_main_lds_bytes(HX, SX, Qmax, HV);
   for (int q = tid; q < Qmax + 8; q += NTHREADS) {
     const int qq = q < Qmax ? q : Qmax - 1;
     const int c8 = qq / taps, tap = qq - c8 * taps;
@@ -1332,6 +1346,9 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
 #pragma unroll
   for (int m = 0; m < TM; m++) acc[m] = {0.f, 0.f, 0.f, 0.f};
   float amax = 0.f;  // running maximum of |staged value| (range check, see split4)
+  // a wave none of whose M-tiles has a cell of the tile (a 1 x 1 x 3-cell latency tile at 6^3 keeps two of the four busy)
+  // stages and synchronises with the others but skips the K loops: its LDS reads would compete with theirs
+  const bool wave_has_cells = wm * TM * 2 < NC;
 
   const int S = p.S;
   const int x0 = tx * 2 * p.tcx - halo, y0 = ty * 2 * p.tcy - halo, z0 = tz * 2 * p.tcz - halo;
@@ -1401,11 +1418,39 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
       }
     }
   };
+  // (WL) a chunk's weights = 2 Smax pieces of 1 KB (step, h | l): wave w DMAs the pieces w, w + 4, ... (h or l of the steps
+  // (w >> 1), (w >> 1) + 2, ...); lane i's 16 bytes come from byte i * 32 of the step's 2 KB and land at byte i * 16 of the piece
+  const int wbuf_bytes = Smax * 2048;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(static_cast<const void *>(p.wp)), 0, p.nchunks * wbuf_bytes, 0x00020000);
+  auto issue_w = [&](int chunk) {
+    if constexpr (WL) {
+      // (inline asm: behind the builtin the compiler waits for vmcnt(0) in front of the next LDS read it cannot tell apart)
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(s_wbuf - reinterpret_cast<char *>(smem_h2)) + (chunk & 1) * wbuf_bytes + wm * 1024);
+      unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(chunk * wbuf_bytes + (wm >> 1) * 2048 + (wm & 1) * 16);
+      const unsigned wl32 = (unsigned)lane * 32u;
+      const int npieces = __builtin_amdgcn_readfirstlane((2 * Smax - wm + 3) >> 2);
+      unsigned keep, m0v;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 %1, %2" : "=&s"(keep), "=&s"(m0v) : "s"(dst));
+      for (int i = 0; i < npieces; i++) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(wl32), "s"(rsrc_w), "s"(soff) : "memory");
+        m0v += 0x1000u;
+        soff += 4096u;
+      }
+      asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
+    }
+  };
   __syncthreads();  // s_vox
+  if constexpr (WL) issue_w(0);
   issue(0);
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     if (chunk > 0) __syncthreads();
     commit(chunk);
+    if constexpr (WL) {
+      // this chunk's weights (requested one K loop ago, in front of this chunk's activation loads) are in LDS; the other
+      // buffer was last read by the K loop in front of the barrier above
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (chunk + 1 < p.nchunks) issue_w(chunk + 1);
+    }
     if (chunk + 1 < p.nchunks) issue(chunk + 1);
     __syncthreads();
     const int nq = min(2 * CC8, p.cin4 - chunk * 2 * CC8);
@@ -1434,9 +1479,15 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
       qo_next = lp[4 * st_next];
     };
     auto load_w = [&](int st, uint4 &h, uint4 &l) {
-      const char *w = wbase + (wlane + (unsigned)st * (4u * 16u * 32u));
-      h = *reinterpret_cast<const uint4 *>(w);
-      l = *reinterpret_cast<const uint4 *>(w + 16);
+      if constexpr (WL) {
+        const char *w = s_wbuf + (chunk & 1) * wbuf_bytes + st * 2048 + lane * 16;
+        h = *reinterpret_cast<const uint4 *>(w);
+        l = *reinterpret_cast<const uint4 *>(w + 1024);
+      } else {
+        const char *w = wbase + (wlane + (unsigned)st * (4u * 16u * 32u));
+        h = *reinterpret_cast<const uint4 *>(w);
+        l = *reinterpret_cast<const uint4 *>(w + 16);
+      }
     };
     auto mfma_step = [&](const uint4 *ah, const uint4 *al, const uint4 &h, const uint4 &l) {
       // (three independent passes over the M-tiles: consecutive MFMAs never wait for each other's accumulator)
@@ -1450,6 +1501,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
       for (int m = 0; m < TM; m++)
         acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, h), acc[m], 0, 0, 0);
     };
+    if (!wave_has_cells) continue;
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (u < NS) load_w(u, wh[u], wl[u]);
@@ -1515,6 +1567,8 @@ size_t conv_h2_lds_bytes(const ConvArgs &p) {
   const size_t HX = 2 * p.tcx + 2 * halo, HY = 2 * p.tcy + 2 * halo, HZ = 2 * p.tcz + 2 * halo, HV = HX * HY * HZ;
   const int Q = (p.ksize == 3 ? 27 : 1) * p.cc4;
   const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // (pads: 16-wide kernel only)
+  if (p.coutp == 16 && p.h2_wlds)  // conv3d_h2_16_kernel<TM, true>: two buffers of a chunk's packed weights behind the rest
+    return h2_16_main_lds_bytes(HX, SX, Q, HV) + (size_t)2 * ((Q + 3) / 4) * 2048;
   const size_t main_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16) + (size_t)((Q + 8 + 3) & ~3) * sizeof(int) + (HV + 4) * sizeof(int);
   return std::max(main_bytes, mid_bytes);
 }
@@ -1609,8 +1663,22 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
   if (!launched) throw Error(2, "launch_conv_h2: M-tile geometry not compiled for this tile shape");
 }
 
-template <int TM> static void launch_h2_16(const ConvArgs &p, int B, hipStream_t s) {
+template <int TM> static void launch_h2_16(ConvArgs p, int B, hipStream_t s) {
   dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
+  // weights through LDS (WL) for the 3x3x3 layers at 6^3 (h2_wlds: 0 = never, 1 = those, 2 = every 3x3x3 layer the buffers fit)
+  const int mode = p.h2_wlds;
+  p.h2_wlds = 0;
+  // (a launch that fills the chip hides the weights' latency behind its other workgroups, and the buffers cost it one of
+  // them per CU: Dense at 1,024 poses per step 68.4 k poses/s without, 67.1 k with)
+  if (p.ksize == 3 && mode > 0 && (mode >= 2 || (p.S <= 6 && grid.x <= 512))) {
+    p.h2_wlds = 1;
+    if (conv_h2_lds_bytes(p) > 160 * 1024) p.h2_wlds = 0;
+  }
+  if (p.h2_wlds) {
+    ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_kernel<TM, true>), 160 * 1024);
+    hipLaunchKernelGGL((conv3d_h2_16_kernel<TM, true>), grid, block, conv_h2_lds_bytes(p), s, p);
+    return;
+  }
   ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_kernel<TM>), 160 * 1024);
   hipLaunchKernelGGL((conv3d_h2_16_kernel<TM>), grid, block, conv_h2_lds_bytes(p), s, p);
 }

@@ -79,7 +79,11 @@ constexpr int kD16Steps = 7;   // 28 tap slots / 4 per instruction
 constexpr int kD16WBytes = kD16Steps * 2048;  // a chunk's B operands: [step][h | l][lane group][16 couts][8 fp16]
 
 // HONLY (MI_PRECISION_FP16, round 6): the h * h MFMA of every product only, and nothing of the l planes is DMA'd or read
-template <int TM, int NP, bool HONLY = false>
+// GRP (round 6, per-pose calls): a workgroup that is alone on its CU has nobody to hide its DMA round trips behind -- one
+// exposed L2 round trip (~2 us) per K chunk, 28 of them in a Dense model's 24^3 block and 60 in its 12^3 block at B = 1.
+// With GRP the chunks are requested ConvArgs::d16_group at a time into that many [tile | weights] sets (the CU's LDS is
+// otherwise idle) and the K loops of the group run back to back: the same MFMAs in the same order, a round trip per group.
+template <int TM, int NP, bool HONLY = false, bool GRP = false>
 __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,8 +98,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
   const int PLB = PL * 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem_d16[];
-  char *const s_tile = smem_d16;            // [h plane | l plane]
-  char *const s_w = smem_d16 + 2 * PLB;     // [kD16WBytes]
+  // set g of a group: [h plane | l plane | kD16WBytes of weights] at smem_d16 + g * GB (one set without GRP)
+  const int GB = 2 * PLB + kD16WBytes;
+  const int D = GRP ? p.d16_group : 1;
 
   // this lane's tap of every step: byte offset inside a plane (tap 27, the zero-weight filler, reads tap 0's slot)
   int qo[kD16Steps];
@@ -175,9 +180,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
       if (p.h2_dbg & 32) voff[i] = (unsigned)(((x0 + 1) * S + (y0 + 1)) * S + z0 + 1) * 32u + (unsigned)(tid + i * 256) * 16u;  // (timing only: contiguous sources)
     }
     const int octet_bytes = S * S * S * 32;
-    auto issue_tile = [&](int chunk, int tp) {
+    auto issue_tile = [&](int chunk, int tp, int g) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in_b + (size_t)tp * pose_floats), 0, (int)(pose_floats * 4), 0x00020000);
-      char *dst = s_tile + wave * 1024;
+      char *dst = smem_d16 + g * GB + wave * 1024;
   #pragma unroll
       for (int i = 0; i < kD16NS; i++)
         // (MI_PRECISION_FP16: the wave-DMAs that lie in the l plane are not issued -- nothing reads it)
@@ -185,28 +190,33 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (D16LdsPtr)(dst + i * 4096), 16, voff[i], chunk * octet_bytes, 0, 0);
     };
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.nchunks * kD16WBytes, 0x00020000);
-    auto issue_w = [&](int chunk) {  // piece q = (step, h | l) = 1 KB = one wave-DMA, consecutive bytes
+    auto issue_w = [&](int chunk, int g) {  // piece q = (step, h | l) = 1 KB = one wave-DMA, consecutive bytes
   #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = i * 4 + wave;
         if (q < 2 * kD16Steps && !(p.h2_dbg & 8) && !(HONLY && (q & 1)))  // (odd pieces: the l halves)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(s_w + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (D16LdsPtr)(smem_d16 + g * GB + 2 * PLB + q * 1024), 16, (unsigned)lane * 16u, chunk * kD16WBytes + q * 1024, 0, 0);
       }
     };
 
     uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
-    for (int chunk = 0; chunk < p.nchunks; chunk++) {
-      bool w_here = false;  // this chunk's weights are in LDS
+    for (int chunk = 0; chunk < p.nchunks; chunk += D) {
+      const int ng = GRP ? min(D, p.nchunks - chunk) : 1;  // chunks of this group
+      bool w_here = false;  // this group's weights are in LDS
       auto pose_pass = [&](auto tpc) __attribute__((always_inline)) {
         constexpr int tp = decltype(tpc)::value;
         if (!first) __syncthreads();  // every wave is through the previous K loop: tile (and weights) may be overwritten
         first = false;
-        issue_tile(chunk, tp);
-        if (!w_here) issue_w(chunk);
+        for (int g = 0; g < ng; g++) {
+          issue_tile(chunk + g, tp, g);
+          if (!w_here) issue_w(chunk + g, g);
+        }
         w_here = true;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
-        const char *wl_ = s_w + lane * 16;
+        for (int g = 0; g < ng; g++) {
+        const char *const s_tile = smem_d16 + g * GB;
+        const char *wl_ = s_tile + 2 * PLB + lane * 16;
         auto load_step = [&](int s, uint4 *ah, uint4 *al, uint4 &wh, uint4 &wl) __attribute__((always_inline)) {
   #pragma unroll
           for (int m = 0; m < TM; m++) {
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
           mfma_step(ah0, al0, wh0, wl0);
           if (s + 2 < kD16Steps) load_step(s + 2, ah0, al0, wh0, wl0);
           if (s + 1 < kD16Steps) mfma_step(ah1, al1, wh1, wl1);
+        }
         }
       };
       pose_pass(std::integral_constant<int, 0>{});
@@ -597,8 +608,19 @@ void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s) {
   if (p.tcx % 2 || 2 * PL > kD16NS * 256 || n_mt > 16 || p.cout > 16 || p.ksize != 3 || !p.in_split || !p.out_split || p.in_cs % 8 || p.out_cs % 8 ||
       p.out_c0 % 8 || !p.bias_tab || p.pool || p.bn_scale)
     throw Error(2, "launch_conv_h2_d16: launch outside what the kernel covers");
-  const size_t lds = conv_h2_d16_lds_bytes(p);
+  size_t lds = conv_h2_d16_lds_bytes(p);
   const int tiles = p.ntx * p.nty * p.ntz;
+  const bool two = p.h2_wlds >= 2 && B >= 2;
+  // one pose per workgroup and few enough workgroups that each has (a share of) a CU's LDS to itself: the GRP variants, as
+  // many chunk sets as that share holds (<= 6: a wave has up to 10 DMAs per chunk in flight and vmcnt counts to 63)
+  p.d16_group = 1;
+  if (!two && !p.h2_honly && !(p.h2_dbg & 128)) {
+    const long per_cu = ((long)B * tiles + 255) / 256;
+    const long fit = (long)(160 * 1024) / ((long)lds * per_cu);
+    p.d16_group = (int)std::max(1L, std::min({6L, (long)p.nchunks, fit}));
+    lds *= (size_t)p.d16_group;
+  }
+  const bool grp = p.d16_group > 1;
   auto go = [&](auto kern, int np) {
     ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
     p.n_items = (B + np - 1) / np * tiles;
@@ -608,12 +630,18 @@ void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s) {
     if (p.h2_persist != 0) grid = std::min(grid, d16_resident_workgroups(reinterpret_cast<const void *>(kern), lds, p.h2_persist));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
   };
-  const bool two = p.h2_wlds >= 2 && B >= 2;
   if (p.h2_honly) {  // (MI_PRECISION_FP16: the two-pose variants -- a throughput mode)
     if (n_mt <= 4) two ? go(conv3d_h2_d16_kernel<1, 2, true>, 2) : go(conv3d_h2_d16_kernel<1, 1, true>, 1);
     else if (n_mt <= 8) two ? go(conv3d_h2_d16_kernel<2, 2, true>, 2) : go(conv3d_h2_d16_kernel<2, 1, true>, 1);
     else if (n_mt <= 12) two ? go(conv3d_h2_d16_kernel<3, 2, true>, 2) : go(conv3d_h2_d16_kernel<3, 1, true>, 1);
     else two ? go(conv3d_h2_d16_kernel<4, 2, true>, 2) : go(conv3d_h2_d16_kernel<4, 1, true>, 1);
+    return;
+  }
+  if (grp) {
+    if (n_mt <= 4) go(conv3d_h2_d16_kernel<1, 1, false, true>, 1);
+    else if (n_mt <= 8) go(conv3d_h2_d16_kernel<2, 1, false, true>, 1);
+    else if (n_mt <= 12) go(conv3d_h2_d16_kernel<3, 1, false, true>, 1);
+    else go(conv3d_h2_d16_kernel<4, 1, false, true>, 1);
     return;
   }
   if (n_mt <= 4) two ? go(conv3d_h2_d16_kernel<1, 2>, 2) : go(conv3d_h2_d16_kernel<1, 1>, 1);

@@ -162,6 +162,10 @@ struct ConvPlan {
   bool has_lat = false;
   int lat_cfg = 0;
   int lat_tc[3] = {0, 0, 0};
+  // a coarser latency tile for launches the finest one would cut into more than 512 workgroups (6^3 Dense layers)
+  bool has_lat2 = false;
+  int lat2_cfg = 0;
+  int lat2_tc[3] = {0, 0, 0};
   // the same layer on the split-fp16 kernels (conv3d_h2.hip; forward, same tiles, own K chunking and packed weights)
   bool has_h2 = false;
   ConvArgs h2{};
@@ -175,6 +179,9 @@ struct ConvPlan {
   // its own tile), and "the 1x1x1 plan in h2 can run on conv3d_h2_k1s_kernel" (same packed weights, split-format input)
   bool has_d16 = false;
   ConvArgs d16{};
+  // the d16 plan's latency tile (2 x 2 x 2 cells = four M-tiles, one per wave) for launches its throughput tile would cut
+  // into fewer workgroups than the chip has CUs; same packed weights, same K order
+  int d16_lat_tc[3] = {0, 0, 0};
   bool has_k1s = false;
 };
 
@@ -199,6 +206,10 @@ static void pick_tile(const ConvPlan &cp, int nb, ConvArgs &a, int &cfg) {
   a.tcx = cp.lat_tc[0], a.tcy = cp.lat_tc[1], a.tcz = cp.lat_tc[2];
   a.mt_x = 0;  // (the latency tiles keep the raster order of cells)
   const int cells = a.S / 2;
+  if (cp.has_lat2 && (long)nb * cdiv(cells, a.tcx) * cdiv(cells, a.tcy) * cdiv(cells, a.tcz) * groups > 512) {
+    cfg = cp.lat2_cfg;
+    a.tcx = cp.lat2_tc[0], a.tcy = cp.lat2_tc[1], a.tcz = cp.lat2_tc[2];
+  }
   a.ntx = cdiv(cells, a.tcx);
   a.nty = cdiv(cells, a.tcy);
   a.ntz = cdiv(cells, a.tcz);
@@ -484,8 +495,19 @@ static void plan_conv(Model &m, const Op &o, ConvPlan &cp, int pool_mode, int ds
       cp.lat_cfg = CONV_CFG_N16_TM1;
       cp.lat_tc[0] = 2, cp.lat_tc[1] = 2, cp.lat_tc[2] = 2;
     } else {
-      cp.lat_cfg = CONV_CFG_N16_TM2;  // 4 waves x 2 M-tiles x 2 cells = 16 cells >= 1 x 3 x 3
-      cp.lat_tc[0] = 1, cp.lat_tc[1] = cells == 3 ? 3 : 2, cp.lat_tc[2] = cells == 3 ? 3 : 4;
+      if (cells == 3) {
+        // 6^3: nine workgroups of 1 x 1 x 3 cells per pose (two waves with cells).  The K loop of the 16-wide kernel is bound by
+        // LDS reads (every A byte feeds 16 output channels only): three workgroups of nine cells ran a chunk's 14 steps in
+        // 2.4 us, and the way to more LDS bandwidth is more CUs
+        cp.lat_cfg = CONV_CFG_N16_TM1;
+        cp.lat_tc[0] = 1, cp.lat_tc[1] = 1, cp.lat_tc[2] = 3;
+        cp.has_lat2 = true;  // 4 waves x 2 M-tiles x 2 cells = 16 cells >= 1 x 3 x 3: three workgroups per pose
+        cp.lat2_cfg = CONV_CFG_N16_TM2;
+        cp.lat2_tc[0] = 1, cp.lat2_tc[1] = 3, cp.lat2_tc[2] = 3;
+      } else {
+        cp.lat_cfg = CONV_CFG_N16_TM2;  // 4 waves x 2 M-tiles x 2 cells = 16 cells
+        cp.lat_tc[0] = 1, cp.lat_tc[1] = 2, cp.lat_tc[2] = 4;
+      }
     }
   } else {
     cp.lat_cfg = CONV_CFG_4x1_1x1;  // 4 M-tiles = 16 cells, one 32-wide N tile per workgroup
@@ -829,6 +851,10 @@ static void plan_conv_d16(Model &m, const Op &o, ConvPlan &cp) {
   if (conv_h2_d16_lds_bytes(a) > 160 * 1024) return;
   cp.d16 = a;
   cp.has_d16 = true;
+  // The K loop of this kernel is bound by LDS reads (an A byte feeds 16 output channels: 40 KB of ds_read_b128 per step and
+  // CU against 192 cycles of MFMA with four M-tiles per wave), so a per-pose call -- 54 workgroups at 24^3, 9 at 12^3 -- is
+  // faster on MORE CUs with one M-tile per wave: 2 x 2 x 2 cells, conflict-free without pads (z-row stride 6, x-plane 36 slots)
+  if (cells % 2 == 0 && conv_d16_layout_conflict_free(6, 36) && !option(OPT_MI_GNINA_NO_LAT)) cp.d16_lat_tc[0] = cp.d16_lat_tc[1] = cp.d16_lat_tc[2] = 2;
 }
 
 // ---- bf16 program (conv3d_bf16.hip): octets of 8 channels, bf16 activations, fp32 accumulation ----
@@ -1925,7 +1951,12 @@ static void h2_launch_args(const ConvPlan &cp, const ConvArgs &a, int nb, ConvAr
   pick_tile(cp, nb, geo, cfg);
   h.tcx = geo.tcx, h.tcy = geo.tcy, h.tcz = geo.tcz, h.ntx = geo.ntx, h.nty = geo.nty, h.ntz = geo.ntz, h.mt_x = geo.mt_x;
   if (h.post_w) h.post_rows = geo.post_rows;  // (pick_tile: rows of the tile it chose)
-  if (!cp.h2_planar) return;
+  if (!cp.h2_planar) {
+    // conv3d_h2_16_kernel: weights through LDS for the 6^3 layers (1), every layer the buffers fit (2), never (0)
+    h.h2_wlds = 0;
+    if (h.coutp == 16 && h.ksize == 3) h.h2_wlds = option(OPT_MI_GNINA_H16_WLDS) ? atoi(option(OPT_MI_GNINA_H16_WLDS)) : 1;
+    return;
+  }
   // conv3d_h2_kernel: its own M-tile geometry and LDS pads per tile
   const bool lat = cfg != cp.cfg;
   if (!lat && cp.h2_cfg >= 0 && !h.post_w) {  // its own throughput tile
@@ -2051,6 +2082,14 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
             if (const char *ev = option(st.conv.has_d16 ? OPT_MI_GNINA_D16_DBG : OPT_MI_GNINA_K1S_DBG)) h.h2_dbg = atoi(ev);
             if (st.conv.has_d16) {
               MIG_CHECK(h.out_split, 2, "Dense-block layer planned on split tensors writes a buffer that is not split");
+              if (st.conv.d16_lat_tc[0] > 0 && (long)nb * h.ntx * h.nty * h.ntz < 256) {
+                const int cells = h.S / 2, *tc = st.conv.d16_lat_tc;
+                if ((long)nb * cdiv(cells, tc[0]) * cdiv(cells, tc[1]) * cdiv(cells, tc[2]) <= 512) {
+                  h.tcx = tc[0], h.tcy = tc[1], h.tcz = tc[2];
+                  h.ntx = cdiv(cells, tc[0]), h.nty = cdiv(cells, tc[1]), h.ntz = cdiv(cells, tc[2]);
+                  h.h2_pad_y = h.h2_pad_x = 0;
+                }
+              }
               if (const char *ev = option(OPT_MI_GNINA_D16_NP)) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
               h.h2_persist = -1;  // (persistent launch, as many workgroups as the chip holds; MI_GNINA_D16_PERSIST=0: one per item, n: at most n per CU)
               if (const char *ev = option(OPT_MI_GNINA_D16_PERSIST)) h.h2_persist = atoi(ev);
@@ -2548,6 +2587,25 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     s.d_centers.ensure((size_t)2 * B * 3);
     MIG_HIP(hipEventRecord(s.lane_start[s.groups.size()], s.stream));
   }
+  // run_program launches on s.stream into buffer set s.act_lane: a lane's slices set both and this puts them back
+  struct LaneGuard {
+    Scorer &s;
+    hipStream_t main;
+    ~LaneGuard() { s.stream = main, s.act_lane = 0; }
+  } guard{s, s.stream};
+  // The programs are enqueued round robin, kLaneSlice steps of each model at a time: a launch costs the host ~4.4 us, a
+  // Dense program has 18 of them, and enqueued one program after the other the second Dense lane started 80 us and the
+  // third lane 310 us behind the first (kernel trace, tools/experiments/r5_calls.sh 57).
+  int kLaneSlice = 2;  // (MI_GNINA_LANE_SLICE: an experiment switch; a large value enqueues one program after the other)
+  if (const char *ev = option(OPT_MI_GNINA_LANE_SLICE)) kLaneSlice = std::max(1, atoi(ev));
+  std::vector<int> lane_lo(nm, 0);  // steps of model mi's program enqueued so far
+  auto lane_slice = [&](int mi, size_t slot, bool split, int lo, int hi) {
+    s.stream = s.lane_streams[mi];
+    s.act_lane = mi + 1;
+    run_program(s, mi, B, s.d_pose_m.p + (size_t)mi * B, s.d_aff_m.p + (size_t)mi * B, s.d_loss_m.p + (size_t)mi * B, false, slot, split, lo, hi);
+    s.stream = guard.main, s.act_lane = 0;
+    lane_lo[mi] = hi;
+  };
   int gi = -1;
   for (const VoxGroup &g : s.groups) {
     gi++;
@@ -2574,6 +2632,12 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       if (lanes) {
         MIG_HIP(hipEventRecord(s.lane_start[gi], vs));
         lane_jobs.push_back(LaneJob{gi, slot, split});  // (B <= cap: one chunk per group)
+        // the first launches of this group's programs go out BEFORE the next group's gather and voxelizer: the host is what
+        // the front of a per-pose call waits for (the first conv of a Dense lane started 20 us behind its grid)
+        for (int mi : g.models) {
+          MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[gi], 0));
+          if (!s.models[mi]->overlap && !option(OPT_MI_GNINA_LANE_SLICE)) lane_slice(mi, slot, split, 0, kLaneSlice);
+        }
       } else {
         for (int mi : g.models)
           run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
@@ -2584,32 +2648,16 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   if (lanes) {
     // now every model's program on its own stream, behind its group's grid
     // (every buffer a program touches is allocated before its first launch: a grow-only buffer must not move under a lane)
-    struct LaneGuard {  // run_program launches on s.stream into buffer set s.act_lane
-      Scorer &s;
-      hipStream_t main;
-      ~LaneGuard() { s.stream = main, s.act_lane = 0; }
-    } guard{s, s.stream};
-    // The programs are enqueued round robin, kLaneSlice steps of each model at a time: a launch costs the host ~4.4 us, a
-    // Dense program has 18 of them, and enqueued one program after the other the second Dense lane started 80 us and the
-    // third lane 310 us behind the first (kernel trace, tools/experiments/r5_calls.sh 57).
-    int kLaneSlice = 2;  // (MI_GNINA_LANE_SLICE: an experiment switch; a large value enqueues one program after the other)
-    if (const char *ev = option(OPT_MI_GNINA_LANE_SLICE)) kLaneSlice = std::max(1, atoi(ev));
     int longest = 0;
     for (const LaneJob &job : lane_jobs)
       for (int mi : s.groups[job.gi].models) {
-        MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[job.gi], 0));
         Model &m = *s.models[mi];
         longest = std::max(longest, m.overlap ? 1 : (int)program_steps(s, m, false).size());
       }
     for (int lo = 0; lo < longest; lo += kLaneSlice)
       for (const LaneJob &job : lane_jobs)
-        for (int mi : s.groups[job.gi].models) {
-          s.stream = s.lane_streams[mi];
-          s.act_lane = mi + 1;
-          run_program(s, mi, B, s.d_pose_m.p + (size_t)mi * B, s.d_aff_m.p + (size_t)mi * B, s.d_loss_m.p + (size_t)mi * B,
-                      false, job.slot, job.split, lo, lo + kLaneSlice);
-          s.stream = guard.main;
-        }
+        for (int mi : s.groups[job.gi].models)
+          if (lane_lo[mi] <= lo) lane_slice(mi, job.slot, job.split, lo, lo + kLaneSlice);
     for (int mi = 0; mi < nm; mi++) MIG_HIP(hipEventRecord(s.lane_done[mi], s.lane_streams[mi]));
     s.stream = guard.main, s.act_lane = 0;
     // the ensemble reduction (main stream) reads what the lanes wrote

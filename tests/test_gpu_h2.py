@@ -143,3 +143,35 @@ def test_stationary_weights_first_conv_gives_the_same_bits(capi, CG, name):
             part = s.score_batch(many[:40], lig_smt)
         assert np.array_equal(got["pose"], ref["pose"]) and np.array_equal(got["affinity"], ref["affinity"]), ring
         assert np.array_equal(part["pose"], ref["pose"][:40]) and np.array_equal(part["affinity"], ref["affinity"][:40]), ring
+
+
+def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
+    """The two things a per-pose call of a Dense model runs differently since round 6 -- the K chunks of a block layer DMA'd
+    in groups (conv3d_h2_d16_kernel<.., GRP>, conv3d_h2_dense.hip) and the 6^3 layers' weights through LDS, a chunk ahead
+    (conv3d_h2_16_kernel<.., WL>, conv3d_h2.hip) -- feed the same operands to the same MFMAs in the same order: B = 1, B = 3
+    and a batch score the same bits with the variants on (default), off, and with the weight buffers on every 16-wide layer."""
+    from gnina_amd import synth
+    name = "dense"
+    rec_xyz, rec_smt, lig_smt, poses = (CG[f"{name}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+    many = np.concatenate([poses, synth.make_poses(np.random.RandomState(23), poses[0] - poses[0].mean(0), 29)])   # 33 poses
+    s = capi.Scorer([name])
+    s.set_receptor(rec_xyz, rec_smt)
+    ref = s.score_batch(many, lig_smt)
+    assert np.abs(ref["pose"][:len(poses)] - CG[name + "/pose"]).max() < 1e-4
+
+    def check(tag):
+        one = [s.score_batch(many[k:k + 1], lig_smt) for k in range(4)]
+        three = s.score_batch(many[4:7], lig_smt)
+        full = s.score_batch(many, lig_smt)
+        for k in range(4):
+            assert one[k]["pose"][0] == ref["pose"][k] and one[k]["affinity"][0] == ref["affinity"][k], (tag, k)
+        assert np.array_equal(three["pose"], ref["pose"][4:7]) and np.array_equal(three["affinity"], ref["affinity"][4:7]), tag
+        assert np.array_equal(full["pose"], ref["pose"]) and np.array_equal(full["affinity"], ref["affinity"]), tag
+
+    check("default")
+    with capi.option("MI_GNINA_D16_DBG", 128):
+        check("no chunk groups")
+    with capi.option("MI_GNINA_H16_WLDS", 0):
+        check("weights from L2")
+    with capi.option("MI_GNINA_H16_WLDS", 2):
+        check("weights through LDS wherever they fit")

@@ -10,6 +10,8 @@ sys.path.insert(0, ROOT)
 from gnina_amd import capi  # noqa: E402
 
 capi.init(0)
+for o in sys.argv[1:]:
+    capi.set_option(*o.split("=", 1))
 G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
 rec_xyz, rec_smt, lig_smt, poses = (G[f"dense_1_3/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
 s = capi.Scorer(["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])
