@@ -121,6 +121,8 @@ struct ConvArgs {
   // tile are DMA'd d16_group at a time -- one L2 round trip for the group instead of one per chunk -- into as many
   // [tile | weights] sets in LDS; same MFMAs in the same order.  Set by the launcher.
   int d16_group;
+  // conv3d_h2_16_ring_kernel (conv3d_h2.hip): ring slots of a launch of few small workgroups; set by the launcher
+  int h16_ring;
   // MI_PRECISION_FP16 (the reduced-precision forward mode, BASELINE config 5): the split-fp16 kernels issue the h * h MFMA
   // only -- one of the three per product: activations and weights rounded to fp16, fp32 accumulation
   int h2_honly;
@@ -210,6 +212,6 @@ void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in
 void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
                        hipStream_t s);
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
-                            float *pose, float *aff, float *loss, float *var, hipStream_t s);
+                            float *pose, float *aff, float *loss, float *var, hipStream_t s, unsigned *ovf_in = nullptr, unsigned *ovf_out = nullptr);
 
 }  // namespace mig

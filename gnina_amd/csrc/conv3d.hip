@@ -1409,9 +1409,15 @@ void launch_grad_mask_amax(float *g, const float *act, int C, int g_cs, int act_
 }
 
 // ensemble mean / variance over models (cnn_torch_scorer.cpp:177-191)
+// (ovf_in / ovf_out: the call's range flag, copied along -- a host-output call has the results and the flag written straight
+// into pinned host memory by this kernel instead of two copies behind it: ~10 us of a per-pose call)
 __global__ void ensemble_reduce_kernel(const float *pose_m, const float *aff_m, const float *loss_m, int n_models,
-                                       int B, float *pose, float *aff, float *loss, float *var) {
+                                       int B, float *pose, float *aff, float *loss, float *var, unsigned *ovf_in, unsigned *ovf_out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0 && ovf_out) {  // (and the device flag is left cleared for the next call: no memset in front of that one)
+    *ovf_out = ovf_in ? *ovf_in : 0u;
+    if (ovf_in) *ovf_in = 0u;
+  }
   if (b >= B) return;
   double sc = 0.0;   // reference accumulates the score in double (cnn_torch_scorer.cpp:117)
   float af = 0.f, ls = 0.f;
@@ -1439,9 +1445,9 @@ __global__ void ensemble_reduce_kernel(const float *pose_m, const float *aff_m, 
 }
 
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
-                            float *pose, float *aff, float *loss, float *var, hipStream_t s) {
+                            float *pose, float *aff, float *loss, float *var, hipStream_t s, unsigned *ovf_in, unsigned *ovf_out) {
   hipLaunchKernelGGL(ensemble_reduce_kernel, dim3((B + 127) / 128), dim3(128), 0, s, pose_m, aff_m, loss_m,
-                     n_models, B, pose, aff, loss, var);
+                     n_models, B, pose, aff, loss, var, ovf_in, ovf_out);
 }
 
 }  // namespace mig

@@ -1546,6 +1546,294 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 3 : 2)) void conv3d_h2_16_kernel(Co
   h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3d_h2_16_ring_kernel (round 6): conv3d_h2_16_kernel for launches of a few small workgroups -- the 6^3 layers of a
+// per-pose call: nine workgroups of 1 x 1 x 3 cells on a 256-CU chip.  There the layer is a chain of memory round trips:
+// every K chunk needs 16 fresh input channels of the tile (fp32, written by the previous launch) and 28 KB of packed weights
+// (nobody else has touched them since the previous call), the K loop behind them is 0.4 us, and requested one chunk ahead
+// each chunk waited ~1.5 us for its operands.  Here BOTH come by LDS-DMA into a ring of ConvArgs::h16_ring slots
+// ([raw fp32 channels as [quad][halo voxel] | weights as [step][h | l][lane]]), requested h16_ring - 1 chunks ahead
+// and counted in by hand (every wave issues the same number of wave-DMAs per chunk; the only VMEM operations of the loop);
+// "staging" reads the raw slot from LDS, applies the BatchNorm, splits and writes the tile.  Same values into the same
+// MFMAs in the same order as conv3d_h2_16_kernel: same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kH16RingSteps = 14;  // steps (octet quartets) of a chunk of at most two octets x 27 taps
+constexpr int kH16RingMaxRaw = 4;  // raw wave-DMAs per wave and chunk: quads x halo voxels (rounded to 64) <= 4 * 256
+
+__device__ __forceinline__ void h2_wait_vm(int n) {  // s_waitcnt vmcnt(n), n wave-uniform: a scalar branch to the immediate
+#define MIG_VM1(N) case N: __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14)); break;
+#define MIG_VM4(N) MIG_VM1(N) MIG_VM1(N + 1) MIG_VM1(N + 2) MIG_VM1(N + 3)
+#define MIG_VM16(N) MIG_VM4(N) MIG_VM4(N + 4) MIG_VM4(N + 8) MIG_VM4(N + 12)
+  switch (n) {
+    MIG_VM16(0) MIG_VM16(16) MIG_VM16(32)
+    MIG_VM4(48) MIG_VM4(52) MIG_VM4(56) MIG_VM1(60) MIG_VM1(61) MIG_VM1(62)
+    default: __builtin_amdgcn_s_waitcnt(0x0F70 | 15 | (3 << 14)); break;  // vmcnt(63)
+  }
+#undef MIG_VM16
+#undef MIG_VM4
+#undef MIG_VM1
+}
+
+template <int TM>
+__global__ __launch_bounds__(256, 1) void conv3d_h2_16_ring_kernel(ConvArgs p) {
+  constexpr int NTHREADS = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, row = lane & 15;
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+
+  const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
+  const int HV = HX * HY * HZ;
+  const int CC8 = p.cc4, CCs = p.ccs;
+  const int SZ = CCs, SY = HZ * SZ + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // fp16 elements
+  constexpr int taps = 27;
+  const int Qmax = taps * CC8;
+  const int Smax = (Qmax + 3) >> 2;
+  const int NQ = 2 * CC8;                       // channel quads per voxel and chunk (<= 4)
+  const int HVp = (HV + 63) & ~63;
+  const int n_raw = (NQ * HVp + 255) >> 8;      // wave-DMAs per wave and chunk: the raw channels ...
+  const int n_w = (2 * Smax + 3) >> 2;          // ... and the weights (pieces of 1 KB: (step, h | l))
+  const int raw_bytes = n_raw * 4096, slot_bytes = raw_bytes + n_w * 4096;
+  const int R = p.h16_ring;
+
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h2[];
+  _Float16 *s_tile = smem_h2;
+  int *s_qoff = reinterpret_cast<int *>(smem_h2 + (((size_t)HX * SX + 7) & ~(size_t)7));
+  int *s_vox = s_qoff + ((Qmax + 8 + 3) & ~3);
+  // (s_vox holds HVp entries here; behind it the layer's BatchNorm scale and shift, 2 x nchunks x 16 floats: as scalar loads
+  // from global memory inside `commit` they were a round trip per chunk that nothing hid -- 2.7 us per chunk)
+  const int cpad = p.nchunks * CC8 * 8;
+  float *const s_bn = reinterpret_cast<float *>(reinterpret_cast<char *>(smem_h2) + h2_16_main_lds_bytes(HX, SX, Qmax, HVp));
+  const int ring_off = (int)(h2_16_main_lds_bytes(HX, SX, Qmax, HVp) + (((size_t)2 * cpad * sizeof(float) + 1023) & ~(size_t)1023));
+  char *const s_ring = reinterpret_cast<char *>(smem_h2) + ring_off;
+  if (p.bn_scale)
+    for (int c = tid; c < cpad; c += NTHREADS) {
+      const bool has = c < p.cin4 * 4;  // (the arrays hold the layer's input channels, padded to whole quads)
+      s_bn[c] = has ? p.bn_scale[c] : 1.f;
+      s_bn[cpad + c] = has ? p.bn_shift[c] : 0.f;
+    }
+  const float bias_pre = p.bias[row < p.cout ? row : 0];  // (the epilogue must not start with a round trip either)
+  for (int q = tid; q < Qmax + 8; q += NTHREADS) {
+    const int qq = q < Qmax ? q : Qmax - 1;
+    const int c8 = qq / taps, tap = qq - c8 * taps;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = ((dx * SX + dy * SY + dz * SZ) + c8 * 16) * 2;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 2) & 1, cell_in_mt = row >> 3;
+  int baseA[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) {
+    int cell = (wm * TM + m) * 2 + cell_in_mt;
+    if (cell >= NC) cell = 0;
+    const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    baseA[m] = ((2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz) * SZ) * 2;  // bytes
+  }
+  h2_f32x4 acc[TM];
+#pragma unroll
+  for (int m = 0; m < TM; m++) acc[m] = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  const bool wave_has_cells = wm * TM * 2 < NC;
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
+  // this thread's halo voxel (HV <= 256: the launcher), zero padding laid down once
+  int st_dst = 0, my_off = -1;
+  if (tid < HV) {
+    const int t1 = (int)(((unsigned)tid * inv_hz) >> 20), hz = tid - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    my_off = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    st_dst = hx * SX + hy * SY + hz * SZ;
+    if (!in)
+      for (int c = 0; c < CCs; c += 8) *reinterpret_cast<uint4 *>(s_tile + st_dst + c) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int hv = tid; hv < HVp; hv += NTHREADS) s_vox[hv] = hv == tid ? my_off : -1;
+  __syncthreads();  // s_vox, s_qoff
+
+  int qo[kH16RingSteps];  // this lane group's octet of every step of a chunk: byte offset inside the tile
+#pragma unroll
+  for (int st = 0; st < kH16RingSteps; st++) qo[st] = s_qoff[min(4 * st + kg, Qmax + 7)];
+  // DMA sources of the raw channels: slot j = tid + i * 256 = quad j / HVp of halo voxel j % HVp (consecutive lanes =
+  // consecutive voxels: staging reads its voxel's quads conflict-free); outside the grid / the slots: out of range = zeros
+  unsigned voff[kH16RingMaxRaw];
+#pragma unroll
+  for (int i = 0; i < kH16RingMaxRaw; i++) {
+    const int j = tid + i * NTHREADS;
+    const int q = j / HVp, hv = j - q * HVp;
+    const int off = (i < n_raw && q < NQ) ? s_vox[hv] : -1;
+    voff[i] = off >= 0 ? (unsigned)(off + q * 4) * 4u : 0x80000000u;
+  }
+  typedef int h16_i32x4 __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [&](const void *base, unsigned bytes) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)base;
+    h16_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull)), rs.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
+    rs.z = __builtin_amdgcn_readfirstlane((int)bytes), rs.w = 0x00020000;
+    return rs;
+  };
+  const size_t pose_floats = (size_t)S * S * S * p.in_cs;
+  const h16_i32x4 rsrc_in = make_rsrc(p.in + (size_t)b * pose_floats, (unsigned)(pose_floats * 4));
+  const int wchunk = Smax * 2048;
+  const h16_i32x4 rsrc_w = make_rsrc(p.wp, (unsigned)(p.nchunks * wchunk));
+  const unsigned wl32 = (unsigned)lane * 32u;
+  // (inline asm: the compiler must not know these write LDS -- it would hold the K loop's reads back until every chunk
+  // requested ahead has landed; conv3d_h2_ws.hip)
+  auto issue_chunk = [&](int chunk) __attribute__((always_inline)) {
+    const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane(ring_off + (chunk % R) * slot_bytes + wm * 1024);
+    const unsigned soff_in = (unsigned)__builtin_amdgcn_readfirstlane(chunk * CC8 * 32);
+    unsigned keep, m0v;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 %1, %2" : "=&s"(keep), "=&s"(m0v) : "s"(slot));
+#pragma unroll
+    for (int i = 0; i < kH16RingMaxRaw; i++)
+      if (i < n_raw) {
+        if (!(p.h2_dbg & 512))  // (timing only)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(voff[i]), "s"(rsrc_in), "s"(soff_in) : "memory");
+        m0v += 0x1000u;
+      }
+    unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(chunk * wchunk + (wm >> 1) * 2048 + (wm & 1) * 16);
+    for (int i = 0; i < n_w; i++) {
+      if (!(p.h2_dbg & 1024))  // (timing only)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(wl32), "s"(rsrc_w), "s"(soff) : "memory");
+      m0v += 0x1000u;
+      soff += 4096u;
+    }
+    asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
+  };
+  // VMEM operations per wave and chunk (the timing switches leave some out: they wait for everything instead)
+  const int opc = (p.h2_dbg & (512 | 1024)) ? 0 : n_raw + n_w;
+
+  auto commit = [&](int chunk) __attribute__((always_inline)) {
+    if (my_off < 0) return;  // zero padding, laid down once (and the threads behind the halo)
+    const int c_base = chunk * CC8 * 8;
+    const int nq = min(NQ, p.cin4 - chunk * NQ);
+    const char *raw = s_ring + (chunk % R) * slot_bytes;
+    _Float16 *dst = s_tile + st_dst;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q >= NQ) continue;
+      _Float16 *d = dst + (q >> 1) * 16 + (q & 1) * 4;
+      uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+      if (q < nq) {  // (quads the input does not have are zero: conv3d_h2_16_kernel)
+        float4 x = *reinterpret_cast<const float4 *>(raw + ((size_t)q * HVp + tid) * 16);
+        if (p.bn_scale) {
+          const float4 sc = *reinterpret_cast<const float4 *>(s_bn + c_base + q * 4);
+          const float4 sh = *reinterpret_cast<const float4 *>(s_bn + cpad + c_base + q * 4);
+          x.x = x.x * sc.x + sh.x;
+          x.y = x.y * sc.y + sh.y;
+          x.z = x.z * sc.z + sh.z;
+          x.w = x.w * sc.w + sh.w;
+        }
+        split4(x, h, l, amax);
+      }
+      *reinterpret_cast<uint2 *>(d) = h;
+      *reinterpret_cast<uint2 *>(d + 8) = l;
+    }
+  };
+
+  for (int c = 0; c < R - 1 && c < p.nchunks; c++) issue_chunk(c);
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    if (chunk > 0) __syncthreads();  // every wave is through K loop chunk - 1: the tile and ring slot (chunk - 1) % R are free
+    if (chunk + R - 1 < p.nchunks) issue_chunk(chunk + R - 1);
+    h2_wait_vm(opc * (min(chunk + R - 1, p.nchunks - 1) - chunk));  // this wave's part of chunk `chunk` has landed
+    __syncthreads();                                                // ... and everybody's
+    if (!(p.h2_dbg & 2048)) commit(chunk);  // (timing only)
+    __syncthreads();
+    if (!wave_has_cells || (p.h2_dbg & 256)) continue;  // (256: timing only, no K loop)
+    const int nq = min(NQ, p.cin4 - chunk * NQ);
+    const int cc8_here = min(CC8, (nq + 1) >> 1);
+    const int NS = (cc8_here * taps + 3) >> 2;
+    const char *wbuf = s_ring + (chunk % R) * slot_bytes + raw_bytes + lane * 16;
+    // One wave per SIMD and nothing else on the CU: the K loop is a chain of LDS round trips unless the operands of a step
+    // are requested several steps ahead -- a ring of four register sets, three steps ahead, the loop unrolled over the (at
+    // most kH16RingSteps) steps of a chunk so that the tap offsets (qo, in registers) and the sets are addressed statically
+    uint4 ah[4][TM], al[4][TM], wh[4], wl[4];
+    auto load_step = [&](int st, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const char *a = reinterpret_cast<const char *>(s_tile) + baseA[m] + qo[st];
+        ah[set][m] = *reinterpret_cast<const uint4 *>(a);
+        al[set][m] = *reinterpret_cast<const uint4 *>(a + 16);
+      }
+      wh[set] = *reinterpret_cast<const uint4 *>(wbuf + st * 2048);
+      wl[set] = *reinterpret_cast<const uint4 *>(wbuf + st * 2048 + 1024);
+    };
+    auto mfma_step = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[set][m]), __builtin_bit_cast(f16x8, wh[set]), acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[set][m]), __builtin_bit_cast(f16x8, wl[set]), acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; m++)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[set][m]), __builtin_bit_cast(f16x8, wh[set]), acc[m], 0, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < 3; st++)
+      if (st < NS) load_step(st, st);
+#pragma unroll
+    for (int st = 0; st < kH16RingSteps; st++) {
+      if (st < NS) {
+        if (st + 3 < kH16RingSteps && st + 3 < NS) load_step(st + 3, (st + 3) & 3);
+        mfma_step(st & 3);
+      }
+    }
+  }
+
+  // epilogue (conv3d_h2_16_kernel's)
+  const float unscale = p.h2_unscale;
+  float *out_b = p.out + (size_t)b * S * S * S * p.out_cs + p.out_c0;
+  const int ncx = S / 2;
+  const int ch = row;
+  if (ch < p.cout) {
+    const float bias = bias_pre;
+#pragma unroll
+    for (int m = 0; m < TM; m++) {
+      const int cell = (wm * TM + m) * 2 + (kg >> 1);
+      if (cell >= NC) continue;
+      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx >= ncx || gcy >= ncx || gcz >= ncx) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int vx = 2 * gcx + (kg & 1), vy = 2 * gcy + (r >> 1), vz = 2 * gcz + (r & 1);
+        float v = acc[m][r] * unscale + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        out_b[(((size_t)vx * S + vy) * S + vz) * p.out_cs + ch] = v;
+      }
+    }
+  }
+  h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
+}
+
+// LDS of conv3d_h2_16_ring_kernel with `ring` slots; 0 = the launch is outside what the kernel covers
+size_t conv_h2_16_ring_lds_bytes(const ConvArgs &p, int ring) {
+  if (p.ksize != 3 || p.coutp != 16 || p.cc4 < 1 || p.cc4 > 2 || ring < 2) return 0;
+  const size_t HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2, HV = HX * HY * HZ;
+  if (HV > 256) return 0;
+  const size_t HVp = (HV + 63) & ~(size_t)63, NQ = 2 * p.cc4;
+  const size_t n_raw = (NQ * HVp + 255) >> 8;
+  if (n_raw > (size_t)kH16RingMaxRaw) return 0;
+  const int Q = 27 * p.cc4, Smax = (Q + 3) >> 2;
+  const size_t n_w = (2 * (size_t)Smax + 3) >> 2;
+  if ((n_raw + n_w) * (size_t)(ring - 1) > 62) return 0;  // (vmcnt counts to 63)
+  const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;
+  const size_t bn_bytes = ((size_t)2 * p.nchunks * p.cc4 * 8 * sizeof(float) + 1023) & ~(size_t)1023;
+  return h2_16_main_lds_bytes(HX, SX, Q, HVp) + bn_bytes + (size_t)ring * (n_raw + n_w) * 4096;
+}
+
 // geometry of conv3d_h2_kernel's planar halo tile (16-byte slots): z-row and x-plane strides, slots per plane
 void conv_h2_planar_geo(const ConvArgs &p, int *sy, int *sx, int *pl) {
   const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
@@ -1665,8 +1953,10 @@ template <int WM, int WN, int TM, int MTMASK, bool SKIP_OK> static void launch_h
 
 template <int TM> static void launch_h2_16(ConvArgs p, int B, hipStream_t s) {
   dim3 grid(B * p.ntx * p.nty * p.ntz), block(256);
-  // weights through LDS (WL) for the 3x3x3 layers at 6^3 (h2_wlds: 0 = never, 1 = those, 2 = every 3x3x3 layer the buffers fit)
-  const int mode = p.h2_wlds;
+  // weights through LDS (WL) for the 3x3x3 layers at 6^3 (h2_wlds: 0 = never, 1 = those, 2 = every 3x3x3 layer the buffers fit;
+  // + 4: no ring kernel for launches of few small workgroups)
+  const int mode = p.h2_wlds & 3;
+  const bool ring_ok = p.h2_wlds > 0 && !(p.h2_wlds & 4);
   p.h2_wlds = 0;
   // (a launch that fills the chip hides the weights' latency behind its other workgroups, and the buffers cost it one of
   // them per CU: Dense at 1,024 poses per step 68.4 k poses/s without, 67.1 k with)
@@ -1674,6 +1964,18 @@ template <int TM> static void launch_h2_16(ConvArgs p, int B, hipStream_t s) {
     p.h2_wlds = 1;
     if (conv_h2_lds_bytes(p) > 160 * 1024) p.h2_wlds = 0;
   }
+  // a few small workgroups (the 6^3 layers of a per-pose call): operands through a ring, requested chunks ahead
+  if constexpr (TM <= 2)
+    if (p.ksize == 3 && ring_ok && grid.x <= 256 && !p.accumulate) {
+      for (int ring = 4; ring >= 3; ring--) {
+        const size_t lds = conv_h2_16_ring_lds_bytes(p, ring);
+        if (lds == 0 || lds > 160 * 1024) continue;
+        p.h16_ring = std::min(ring, std::max(2, p.nchunks));
+        ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_ring_kernel<TM>), 160 * 1024);
+        hipLaunchKernelGGL((conv3d_h2_16_ring_kernel<TM>), grid, block, lds, s, p);
+        return;
+      }
+    }
   if (p.h2_wlds) {
     ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_kernel<TM, true>), 160 * 1024);
     hipLaunchKernelGGL((conv3d_h2_16_kernel<TM, true>), grid, block, conv_h2_lds_bytes(p), s, p);

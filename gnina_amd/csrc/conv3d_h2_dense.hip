@@ -199,6 +199,26 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
       }
     };
 
+    // (GRP: a workgroup alone on its CU) the epilogue's border-class bias, fetched in front of the K loops: as a load behind
+    // them it was a round trip nothing hid
+    float bias_pre[GRP ? TM : 1][4];
+    if constexpr (GRP) {
+      const int ch = row;
+#pragma unroll
+      for (int m = 0; m < TM; m++) {
+        const int mt = wave * TM + m;
+        const int cz = mt % p.tcz, cy = (mt / p.tcz) % p.tcy, cxp = mt / (p.tcz * p.tcy);
+        const int gy = 2 * (ty * p.tcy + cy) + (kg >> 1), gz = 2 * (tz * p.tcz + cz) + (kg & 1);
+        const int gx0 = 2 * tx * p.tcx + 4 * cxp;
+        const int cls_yz = (gy == 0 ? 0 : gy == S - 1 ? 2 : 1) * 3 + (gz == 0 ? 0 : gz == S - 1 ? 2 : 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gx = gx0 + r;
+          const int cls = (gx == 0 ? 0 : gx >= S - 1 ? 2 : 1) * 9 + cls_yz;
+          bias_pre[m][r] = p.bias_tab[min(cls, 26) * 16 + ch];
+        }
+      }
+    }
     uint4 wh0, wl0, wh1, wl1, ah0[TM], al0[TM], ah1[TM], al1[TM];
     for (int chunk = 0; chunk < p.nchunks; chunk += D) {
       const int ng = GRP ? min(D, p.nchunks - chunk) : 1;  // chunks of this group
@@ -278,7 +298,10 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
         for (int r = 0; r < 4; r++) {
           const int gx = gx0 + r;
           const int cls = (gx == 0 ? 0 : gx >= S - 1 ? 2 : 1) * 9 + cls_yz;
-          float v = acc[tp][m][r] * p.h2_unscale + p.bias_tab[cls * 16 + ch];
+          float bias_v;
+          if constexpr (GRP) bias_v = bias_pre[m][r];
+          else bias_v = p.bias_tab[cls * 16 + ch];
+          float v = acc[tp][m][r] * p.h2_unscale + bias_v;
           if (p.relu) v = fmaxf(v, 0.f);
           const bool ok = ok_yz && gx < S;
           ovf |= ok && !(fabsf(v) <= 65504.f);

@@ -1431,6 +1431,7 @@ struct Scorer {
   DevBuf<unsigned> d_ovf;
   DevBuf<unsigned> d_gamax;  // gradient pass: [buffer][cap] per-pose max |g| bits of the buffers in Model::buf_bwd_h2
   unsigned *h_ovf = nullptr;            // pinned copy
+  bool ovf_clean = false;               // the device flag is known to be zero (cleared by the last call's reduction kernel)
   int h2_fallbacks = 0;                 // calls recomputed because of it (mi_scorer_h2_fallbacks)
   bool ovf_pending = false;             // device-output calls in flight whose flag mi_scorer_synchronize still has to read
   // setup_ligand cache, one per voxel group: the same ligand is scored call after call (poses of one docking run), and an
@@ -2359,6 +2360,10 @@ static void h2_flag_reset(Scorer &s) {
   s.d_ovf.ensure(1);
   if (!s.h_ovf) MIG_HIP(hipHostMalloc((void **)&s.h_ovf, sizeof(unsigned), hipHostMallocDefault));
   if (s.ovf_pending) return;  // device-output calls since the last synchronize: the flag stays sticky across them
+  if (s.ovf_clean) {  // (the previous call's reduction kernel cleared it: score_batch_once, out_direct)
+    s.ovf_clean = false;
+    return;
+  }
   MIG_HIP(hipMemsetAsync(s.d_ovf.p, 0, sizeof(unsigned), s.stream));
 }
 // after the call's work is enqueued; the caller synchronizes the stream before reading *s.h_ovf
@@ -2665,13 +2670,10 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   }
   const bool out_dev = (flags & MI_OUT_ON_DEVICE) != 0;
   float *o_pose = pose, *o_aff = aff, *o_loss = loss, *o_var = var;
-  if (!out_dev) {  // one [4][B] device block -> one copy into pinned host memory -> the caller's four arrays
-    s.d_out4.ensure((size_t)4 * B);
-    o_pose = s.d_out4.p, o_aff = s.d_out4.p + B, o_loss = s.d_out4.p + 2 * (size_t)B, o_var = s.d_out4.p + 3 * (size_t)B;
-  }
-  launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, o_pose, o_aff, o_loss, o_var, s.stream);
-  if (s.timing) MIG_HIP(hipEventRecord(s.ev[2], s.stream));
-  s.last_B = B;
+  // A host-output call: one [4][B] block in pinned host memory -> the caller's four arrays.  Small calls have the reduction
+  // kernel write that block (and the range flag) itself -- the kernel's stores cross the bus instead of two copies enqueued
+  // behind it, ~10 us of a per-pose call; larger ones go through a device block and one copy (MI_GNINA_OUT_COPY=1: always).
+  const bool out_direct = !out_dev && B <= 4096 && !option(OPT_MI_GNINA_OUT_COPY) && s.h_ovf && s.d_ovf.p && !s.ovf_pending;
   if (!out_dev) {
     if (s.h_out4_n < (size_t)4 * B) {
       if (s.h_out4) (void)hipHostFree(s.h_out4);
@@ -2679,9 +2681,24 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
       MIG_HIP(hipHostMalloc((void **)&s.h_out4, (size_t)4 * B * sizeof(float), hipHostMallocDefault));
       s.h_out4_n = (size_t)4 * B;
     }
-    MIG_HIP(hipMemcpyAsync(s.h_out4, s.d_out4.p, (size_t)4 * B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    h2_flag_fetch(s);
+    float *blk = s.h_out4;
+    if (!out_direct) {
+      s.d_out4.ensure((size_t)4 * B);
+      blk = s.d_out4.p;
+    }
+    o_pose = blk, o_aff = blk + B, o_loss = blk + 2 * (size_t)B, o_var = blk + 3 * (size_t)B;
+  }
+  launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, o_pose, o_aff, o_loss, o_var, s.stream,
+                         out_direct ? s.d_ovf.p : nullptr, out_direct ? s.h_ovf : nullptr);
+  if (s.timing) MIG_HIP(hipEventRecord(s.ev[2], s.stream));
+  s.last_B = B;
+  if (!out_dev) {
+    if (!out_direct) {
+      MIG_HIP(hipMemcpyAsync(s.h_out4, s.d_out4.p, (size_t)4 * B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+      h2_flag_fetch(s);
+    }
     MIG_HIP(hipStreamSynchronize(s.stream));
+    s.ovf_clean = out_direct;
     memcpy(pose, s.h_out4, B * sizeof(float));
     memcpy(aff, s.h_out4 + B, B * sizeof(float));
     memcpy(loss, s.h_out4 + 2 * (size_t)B, B * sizeof(float));

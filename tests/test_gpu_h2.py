@@ -148,7 +148,8 @@ def test_stationary_weights_first_conv_gives_the_same_bits(capi, CG, name):
 def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
     """The two things a per-pose call of a Dense model runs differently since round 6 -- the K chunks of a block layer DMA'd
     in groups (conv3d_h2_d16_kernel<.., GRP>, conv3d_h2_dense.hip) and the 6^3 layers' weights through LDS, a chunk ahead
-    (conv3d_h2_16_kernel<.., WL>, conv3d_h2.hip) -- feed the same operands to the same MFMAs in the same order: B = 1, B = 3
+    (conv3d_h2_16_kernel<.., WL>; conv3d_h2_16_ring_kernel with both operands through a ring for launches of few small
+    workgroups; conv3d_h2.hip) -- feed the same operands to the same MFMAs in the same order: B = 1, B = 3
     and a batch score the same bits with the variants on (default), off, and with the weight buffers on every 16-wide layer."""
     from gnina_amd import synth
     name = "dense"
@@ -175,3 +176,5 @@ def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
         check("weights from L2")
     with capi.option("MI_GNINA_H16_WLDS", 2):
         check("weights through LDS wherever they fit")
+    with capi.option("MI_GNINA_H16_WLDS", 5):
+        check("no operand ring for the launches of few small workgroups")

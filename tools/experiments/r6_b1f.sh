@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 timeout 900 python -m pytest tests/test_gpu_h2.py tests/test_gpu_parity.py tests/test_gpu_concurrency.py -m gpu -x -q 2>&1 | tail -4
 timeout 300 python tools/experiments/seam_b1_ensemble.py
-timeout 300 python tools/experiments/seam_b1_ensemble.py MI_GNINA_NO_LAT=1
+timeout 300 python tools/experiments/seam_b1_ensemble.py MI_GNINA_H16_WLDS=5
 OUT=$R/gpurun_out/prof_r6b1f; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace -f csv -d $OUT/trace -o t -- python $R/tools/experiments/b1_timeline.py > $OUT/log.txt 2>&1
