@@ -770,6 +770,12 @@ static void plan_conv_d16(Model &m, const Op &o, ConvPlan &cp) {
   if (cells % 4 == 0) a.tcx = 2, a.tcy = 4, a.tcz = 4;
   else if (cells == 6) a.tcx = 2, a.tcy = 2, a.tcz = 6;
   else return;  // (6^3 blocks: 0.13 ms per layer, left on conv3d_h2_16_kernel and an fp32 buffer)
+  if (const char *ev = option(OPT_MI_GNINA_D16_TILE))  // (experiment: "xyz" cells of the throughput tile where it divides the grid, e.g. 224)
+    if (strlen(ev) == 3) {
+      const int tx = ev[0] - '0', ty = ev[1] - '0', tz = ev[2] - '0';
+      if (tx >= 2 && tx % 2 == 0 && ty >= 1 && tz >= 1 && cells % tx == 0 && cells % ty == 0 && cells % tz == 0 && (tx / 2) * ty * tz <= 16)
+        a.tcx = tx, a.tcy = ty, a.tcz = tz;
+    }
   a.ntx = cdiv(cells, a.tcx), a.nty = cdiv(cells, a.tcy), a.ntz = cdiv(cells, a.tcz);
   a.mt_x = 0;
   a.h2_pad_y = a.h2_pad_x = 0;
