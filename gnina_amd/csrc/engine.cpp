@@ -2377,6 +2377,16 @@ static void h2_flag_fetch(Scorer &s) {
   MIG_HIP(hipMemcpyAsync(s.h_ovf, s.d_ovf.p, sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
 }
 
+// the scorer's pinned host block for a call's outputs, at least n floats
+static void ensure_pinned_out(Scorer &s, size_t n) {
+  if (s.h_out4_n >= n) return;
+  if (s.h_out4) (void)hipHostFree(s.h_out4);
+  s.h_out4 = nullptr;
+  s.h_out4_n = 0;
+  MIG_HIP(hipHostMalloc((void **)&s.h_out4, n * sizeof(float), hipHostMallocDefault));
+  s.h_out4_n = n;
+}
+
 static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t *lig_smt, int B, int L,
                                   const float *centers, float *pose, float *aff, float *loss, float *var,
                                   float *lig_grad, unsigned flags, const float *flex_xyz = nullptr,
@@ -2476,20 +2486,35 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
   s.d_aff.ensure(B);
   s.d_loss.ensure(B);
   s.d_var.ensure(B);
-  launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, s.d_pose.p, s.d_aff.p, s.d_loss.p, s.d_var.p,
-                         s.stream);
+  // Outputs through ONE pinned host block [pose | aff | loss | var | lig_grad | flex_grad]: the reduction kernel writes the
+  // first four (and the range flag) itself, the gradients take one copy each -- into pinned memory, so really asynchronous --
+  // and the caller's arrays are filled by memcpy.  As six hipMemcpyAsync into the caller's (pageable) arrays the tail of a
+  // B = 1 gradient call was ~100 us of its 370: each such copy is staged and waited for (kernel trace, r6_b1grad.sh).
+  const size_t n_lg = lig_grad ? (size_t)B * L * 3 : 0, n_fg = flex_grad ? (size_t)B * n_flex * 3 : 0;
+  ensure_pinned_out(s, (size_t)4 * B + n_lg + n_fg);
+  const bool out_direct = B <= 4096 && !option(OPT_MI_GNINA_OUT_COPY) && s.h_ovf && s.d_ovf.p && !s.ovf_pending;
+  float *h4 = s.h_out4, *h_lg = s.h_out4 + (size_t)4 * B, *h_fg = h_lg + n_lg;
+  if (out_direct) {
+    launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, h4, h4 + B, h4 + 2 * (size_t)B, h4 + 3 * (size_t)B, s.stream,
+                           s.d_ovf.p, s.h_ovf);
+  } else {
+    s.d_out4.ensure((size_t)4 * B);
+    float *d4 = s.d_out4.p;
+    launch_ensemble_reduce(s.d_pose_m.p, s.d_aff_m.p, s.d_loss_m.p, nm, B, d4, d4 + B, d4 + 2 * (size_t)B, d4 + 3 * (size_t)B, s.stream);
+    MIG_HIP(hipMemcpyAsync(h4, d4, (size_t)4 * B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    h2_flag_fetch(s);
+  }
   s.last_B = B;
-  if (flex_grad)
-    MIG_HIP(hipMemcpyAsync(flex_grad, s.d_flex_grad.p, (size_t)B * n_flex * 3 * sizeof(float), hipMemcpyDeviceToHost,
-                           s.stream));
-  MIG_HIP(hipMemcpyAsync(pose, s.d_pose.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipMemcpyAsync(aff, s.d_aff.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  MIG_HIP(hipMemcpyAsync(loss, s.d_loss.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  if (var) MIG_HIP(hipMemcpyAsync(var, s.d_var.p, B * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  if (lig_grad)
-    MIG_HIP(hipMemcpyAsync(lig_grad, s.d_lig_grad.p, (size_t)B * L * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-  h2_flag_fetch(s);
+  if (n_lg) MIG_HIP(hipMemcpyAsync(h_lg, s.d_lig_grad.p, n_lg * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+  if (n_fg) MIG_HIP(hipMemcpyAsync(h_fg, s.d_flex_grad.p, n_fg * sizeof(float), hipMemcpyDeviceToHost, s.stream));
   MIG_HIP(hipStreamSynchronize(s.stream));
+  s.ovf_clean = out_direct;
+  memcpy(pose, h4, B * sizeof(float));
+  memcpy(aff, h4 + B, B * sizeof(float));
+  memcpy(loss, h4 + 2 * (size_t)B, B * sizeof(float));
+  if (var) memcpy(var, h4 + 3 * (size_t)B, B * sizeof(float));
+  if (n_lg) memcpy(lig_grad, h_lg, n_lg * sizeof(float));
+  if (n_fg) memcpy(flex_grad, h_fg, n_fg * sizeof(float));
 }
 
 // A call whose split-fp16 kernels met an activation outside the fp16 range (|a| > 65504: a user model with large
@@ -2681,12 +2706,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   // behind it, ~10 us of a per-pose call; larger ones go through a device block and one copy (MI_GNINA_OUT_COPY=1: always).
   const bool out_direct = !out_dev && B <= 4096 && !option(OPT_MI_GNINA_OUT_COPY) && s.h_ovf && s.d_ovf.p && !s.ovf_pending;
   if (!out_dev) {
-    if (s.h_out4_n < (size_t)4 * B) {
-      if (s.h_out4) (void)hipHostFree(s.h_out4);
-      s.h_out4 = nullptr;
-      MIG_HIP(hipHostMalloc((void **)&s.h_out4, (size_t)4 * B * sizeof(float), hipHostMallocDefault));
-      s.h_out4_n = (size_t)4 * B;
-    }
+    ensure_pinned_out(s, (size_t)4 * B);
     float *blk = s.h_out4;
     if (!out_direct) {
       s.d_out4.ensure((size_t)4 * B);
