@@ -211,6 +211,7 @@ void launch_fc_backward(const float *raw3, const float *w, int n_in, float *g_in
                         const float *mask = nullptr, unsigned *amax = nullptr);
 void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int in_cs, int out_cs, int S,
                        hipStream_t s);
+void launch_sum_models(const float *src, int n_models, size_t n, float *dst, hipStream_t s);
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
                             float *pose, float *aff, float *loss, float *var, hipStream_t s, unsigned *ovf_in = nullptr, unsigned *ovf_out = nullptr);
 

@@ -1477,6 +1477,20 @@ __global__ void ensemble_reduce_kernel(const float *pose_m, const float *aff_m, 
   if (var) var[b] = v;
 }
 
+// dst[i] = ((0 + src[0][i]) + src[1][i]) + ... : the per-model gradients of a gradient call on lanes, added in model order --
+// the additions a one-stream call makes when every model accumulates into the one zeroed buffer
+__global__ void sum_models_kernel(const float *src, int n_models, size_t n, float *dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int m = 0; m < n_models; m++) acc = acc + src[(size_t)m * n + i];
+  dst[i] = acc;
+}
+void launch_sum_models(const float *src, int n_models, size_t n, float *dst, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(sum_models_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, n_models, n, dst);
+}
+
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
                             float *pose, float *aff, float *loss, float *var, hipStream_t s, unsigned *ovf_in, unsigned *ovf_out) {
   hipLaunchKernelGGL(ensemble_reduce_kernel, dim3((B + 127) / 128), dim3(128), 0, s, pose_m, aff_m, loss_m,

@@ -1417,6 +1417,10 @@ struct Scorer {
   int act_lane = 0;                     // run_program: activation buffer set in use (0 = the shared set)
   bool alone_on_device = true;          // no other scorer has scored on the device lately (scorer_alone_on_device)
   size_t centers_stride = 0;            // lanes: voxel group 1 writes its grid centres behind group 0's (voxelize_chunk)
+  // gradient calls on lanes (score_batch_grad_once): the pooled-grid slot of the group whose model run_program / run_backward
+  // is working on, and the per-model gradient accumulators the lanes write before they are summed in model order
+  size_t grad_pooled_slot = 0;
+  DevBuf<float> d_lig_grad_m, d_flex_grad_m;
   std::vector<int> last_lane;           // per model: the set its last forward program wrote (mi_debug_read_activation)
   // mi_debug_vox_stress: the quiet run's pooled grid, the mismatch log, the trap ring of a -DMI_VOX_TRAP build
   DevBuf<unsigned> d_dbg_ref, d_dbg_trap;
@@ -1549,6 +1553,7 @@ static unsigned long long *prof_counter(Scorer &s, ProfScope &ps) {
 
 constexpr size_t kPooledSlot = 0;  // buffer id 0 (the full grid) is never materialised, reuse its slot
 constexpr size_t kPooledSlot2 = 4096;  // pooled grid of an ensemble's second voxel group when its models run on lanes
+constexpr size_t kGamaxLaneSlots = 256;  // gradient-maximum slots (Scorer::d_gamax) per lane of a gradient call on lanes
 constexpr size_t kLaneSlots = 64;      // activation buffer ids per lane (Scorer::act_lane): set l owns slots [64 l, 64 l + 64)
 
 // Poses per launch for a call on B poses: the user's chunk, clipped to B and to an activation-memory budget
@@ -2016,7 +2021,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   s.last_lane[mi] = s.act_lane;
   auto arg_ptr = [&](int id) -> unsigned char * {
     const BufDecl &bd = m->d.bufs[id];
-    const size_t slot = id == m->input_dst ? kPooledSlot : (size_t)id;
+    const size_t slot = id == m->input_dst ? pooled_slot : (size_t)id + (size_t)s.act_lane * kLaneSlots;
     return argm_buf(s, slot, (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id]);
   };
   auto buf_ptr = [&](int id) -> float * {
@@ -2162,7 +2167,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
         ProfScope ps(s, "fc_heads", 2.0 * nb * 3.0 * st.n_in, (double)nb * st.n_in * 4.0, nb);
         launch_fc_heads(buf_ptr(st.src), m->dev_data.p + st.w_off, m->dev_data.p + st.b_off, st.n_in,
                         m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff, loss,
-                        grad ? (s.d_raw3.ensure((size_t)3 * s.cap), s.d_raw3.p) : nullptr, nb, s.stream);
+                        grad ? (s.d_raw3.ensure((size_t)3 * s.cap * (s.act_lane + 1)), s.d_raw3.p + (size_t)3 * s.cap * s.act_lane) : nullptr, nb, s.stream);
         break;
       }
       case OpKind::Overlap:  // handled above: the Overlap model has no layer program
@@ -2188,13 +2193,17 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   }
   const bool bf16 = use_bf16(s, *m, true);
   const std::vector<Step> &gsteps = bf16 ? m->hgsteps : m->gsteps;
-  auto slot_of = [&](int id) { return id == m->input_dst ? kPooledSlot : (size_t)id; };
+  // (lanes: a model's buffers live in its lane's slot set; the pooled grid and its arg-max bytes belong to the model's voxel
+  // group -- Scorer::grad_pooled_slot --, the GRADIENT of the pooled grid to the model: slot 0 of its lane's set)
+  const size_t lane_base = (size_t)s.act_lane * kLaneSlots;
+  auto slot_of = [&](int id) { return id == m->input_dst ? s.grad_pooled_slot : (size_t)id + lane_base; };
+  auto gslot_of = [&](int id) { return id == m->input_dst ? lane_base : (size_t)id + lane_base; };
   auto count_of = [&](int id) {
     const BufDecl &bd = m->d.bufs[id];
     return (size_t)s.cap * bd.S * bd.S * bd.S * m->buf_cp[id];
   };
   auto act_ptr = [&](int id) { return act_buf(s, slot_of(id), count_of(id)); };
-  auto g_ptr = [&](int id) { return gact_buf(s, slot_of(id), count_of(id)); };
+  auto g_ptr = [&](int id) { return gact_buf(s, gslot_of(id), count_of(id)); };
   // conv + ReLU -> stand-alone average pool (Default2018): the transposed conv un-pools the half-resolution gradient
   // while it stages (ConvArgs::in_mode 3) and no full-resolution gradient tensor is written in between.  Generic fp32
   // kernel only; the pool must be the only reader of the conv's output.
@@ -2217,10 +2226,11 @@ static float *run_backward(Scorer &s, int mi, int nb) {
   std::vector<char> ready(nbufs, 0), slice_ready(gsteps.size(), 0);
   if (h2_bwd) {
     const size_t slots = nbufs + gsteps.size();  // one per buffer (kind 1) and one per step (kind 2)
-    s.d_gamax.ensure(slots * (size_t)s.cap);
-    MIG_HIP(hipMemsetAsync(s.d_gamax.p, 0, slots * (size_t)s.cap * sizeof(unsigned), s.stream));
+    MIG_CHECK(s.act_lane == 0 || slots <= kGamaxLaneSlots, 2, "gradient lanes: model with more gradient-maximum slots than a lane's share");
+    s.d_gamax.ensure(s.act_lane == 0 ? slots * (size_t)s.cap : (size_t)(s.act_lane + 1) * kGamaxLaneSlots * s.cap);
+    MIG_HIP(hipMemsetAsync(s.d_gamax.p + (size_t)s.act_lane * kGamaxLaneSlots * s.cap, 0, slots * (size_t)s.cap * sizeof(unsigned), s.stream));
   }
-  auto amax_of = [&](int id) { return s.d_gamax.p + (size_t)id * s.cap; };
+  auto amax_of = [&](int id) { return s.d_gamax.p + (size_t)s.act_lane * kGamaxLaneSlots * s.cap + (size_t)id * s.cap; };
   auto wants_mask = [&](int id) { return h2_bwd && id != m->input_dst && m->buf_bwd_h2[id]; };
   for (int i = (int)gsteps.size() - 1; i >= 0; i--) {
     const Step &st = gsteps[i];
@@ -2228,7 +2238,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
       case OpKind::Fc: {
         ProfScope ps(s, "fc_backward", 2.0 * nb * 2.0 * st.n_in, 0.0, nb);
         const bool mk = wants_mask(st.src);
-        launch_fc_backward(s.d_raw3.p, m->dev_data.p + st.w_off, st.n_in, g_ptr(st.src), nb, s.stream,
+        launch_fc_backward(s.d_raw3.p + (size_t)3 * s.cap * s.act_lane, m->dev_data.p + st.w_off, st.n_in, g_ptr(st.src), nb, s.stream,
                            mk ? act_ptr(st.src) : nullptr, mk ? amax_of(st.src) : nullptr);
         ready[st.src] = mk;
         break;
@@ -2377,6 +2387,8 @@ static void h2_flag_fetch(Scorer &s) {
   MIG_HIP(hipMemcpyAsync(s.h_ovf, s.d_ovf.p, sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
 }
 
+static void lane_tune_after_call(Scorer &s, int B, double us);
+
 // the scorer's pinned host block for a call's outputs, at least n floats
 static void ensure_pinned_out(Scorer &s, size_t n) {
   if (s.h_out4_n >= n) return;
@@ -2425,22 +2437,87 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
     s.d_flex_grad.ensure((size_t)B * n_flex * 3);
     MIG_HIP(hipMemsetAsync(s.d_flex_grad.p, 0, (size_t)B * n_flex * 3 * sizeof(float), s.stream));
   }
+  // Lanes (as in score_batch_once): a small gradient call of an ensemble runs every model -- forward program, backward pass,
+  // voxel backward -- on a stream of its own, in its own buffer set, the voxel groups side by side; every model accumulates
+  // its (scaled) atom gradients into a buffer of its own and the buffers are added in model order at the end, which are the
+  // additions the one-stream call makes.  gnina's default ensemble at B = 1: 1,616 -> ~? us per call.
+  int lanes_max_b = 8;
+  if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
+  size_t max_bufs = 0;
+  bool any_overlap = false;
+  for (Model *m : s.models) max_bufs = std::max(max_bufs, m->d.bufs.size()), any_overlap = any_overlap || m->overlap;
+  const bool lanes = nm > 1 && B <= lanes_max_b && B <= s.cap && !s.profile && !option(OPT_MI_GNINA_NO_LANES) &&
+                     (!option(OPT_MI_GNINA_LANES) || atoi(option(OPT_MI_GNINA_LANES)) != 0) && !option(OPT_MI_GNINA_NO_GRAD_LANES) &&
+                     s.groups.size() <= 2 && max_bufs <= kLaneSlots && ((size_t)nm + 1) * kLaneSlots <= kPooledSlot2 && !any_overlap &&
+                     s.alone_on_device;
+  s.last_call_lanes = lanes;
+  struct GradLaneGuard {  // run_program / run_backward launch on s.stream into buffer set s.act_lane around s.grad_pooled_slot
+    Scorer &s;
+    hipStream_t main;
+    ~GradLaneGuard() { s.stream = main, s.act_lane = 0, s.grad_pooled_slot = kPooledSlot, s.centers_stride = 0; }
+  } lane_guard{s, s.stream};
+  const size_t n_lg_all = (size_t)B * L * 3, n_fg_all = (size_t)B * n_flex * 3;
+  if (lanes) {
+    if (s.lane_streams_offset != s.lane_offset) s.lane_streams.clear();
+    s.lane_streams_offset = s.lane_offset;
+    while ((int)s.lane_streams.size() < nm) s.lane_streams.push_back(device_lane_stream(s.device, ((int)s.lane_streams.size() + s.lane_offset) % 8));
+    while ((int)s.lane_done.size() < nm) {
+      hipEvent_t e = nullptr;
+      MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      s.lane_done.push_back(e);
+    }
+    while (s.lane_start.size() < s.groups.size() + 1) {
+      hipEvent_t e = nullptr;
+      MIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      s.lane_start.push_back(e);
+    }
+    // (every shared buffer at its final size before the first lane starts: a grow-only buffer must not move under a lane)
+    s.d_raw3.ensure((size_t)3 * s.cap * (nm + 1));
+    s.d_gamax.ensure((size_t)(nm + 1) * kGamaxLaneSlots * s.cap);
+    s.d_ovf.ensure(1);
+    s.d_lig_grad_m.ensure((size_t)nm * n_lg_all);
+    MIG_HIP(hipMemsetAsync(s.d_lig_grad_m.p, 0, (size_t)nm * n_lg_all * sizeof(float), s.stream));
+    if (flex_xyz) {
+      s.d_flex_grad_m.ensure((size_t)nm * n_fg_all);
+      MIG_HIP(hipMemsetAsync(s.d_flex_grad_m.p, 0, (size_t)nm * n_fg_all * sizeof(float), s.stream));
+    }
+    s.centers_stride = (size_t)B * 3;
+    s.d_centers.ensure((size_t)2 * B * 3);
+    MIG_HIP(hipEventRecord(s.lane_start[s.groups.size()], s.stream));  // the call's inputs are uploaded, its accumulators cleared
+  }
+  int gi = -1;
   for (const VoxGroup &g : s.groups) {
+    gi++;
     Model *m0 = s.models[g.first_model];
     LigSetup ls = setup_ligand(s, g, lig_smt, L);
     const BufDecl &ib = m0->d.bufs[m0->input_dst];
     const size_t pooled_n = (size_t)s.cap * ib.S * ib.S * ib.S * pooled_stride(m0);  // (one size per slot: DevBuf::ensure re-allocates when asked for more)
     for (int b0 = 0; b0 < B; b0 += s.cap) {
       const int nb = std::min(s.cap, B - b0);
-      float *pooled = act_buf(s, kPooledSlot, pooled_n);
-      unsigned char *am0 = m0->input_pool == 1 ? argm_buf(s, kPooledSlot, pooled_n) : nullptr;
+      const int set = lanes ? (gi & 1) : 0;
+      const size_t pslot = set ? kPooledSlot2 : kPooledSlot;
+      float *pooled = act_buf(s, pslot, pooled_n);
+      unsigned char *am0 = m0->input_pool == 1 ? argm_buf(s, pslot, pooled_n) : nullptr;
+      hipStream_t vs = s.stream;
+      if (lanes && gi > 0) {
+        vs = s.lane_streams[g.first_model];
+        MIG_HIP(hipStreamWaitEvent(vs, s.lane_start[s.groups.size()], 0));
+      }
       if (m0->input_pool == 0)  // full-resolution grid (Overlap model): the tile kernel only writes touched voxels
-        MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), s.stream));
-      voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, am0);
+        MIG_HIP(hipMemsetAsync(pooled, 0, (size_t)nb * ib.S * ib.S * ib.S * m0->buf_cp[m0->input_dst] * sizeof(float), vs));
+      voxelize_chunk(s, g, ls, d_lig, L, d_cen, flags, b0, nb, m0->input_pool, pooled, am0, vs, set);
+      if (lanes) MIG_HIP(hipEventRecord(s.lane_start[gi], vs));
       for (int mi : g.models) {
         Model *m = s.models[mi];
+        if (lanes) {
+          MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[gi], 0));
+          if (gi == 0) MIG_HIP(hipStreamWaitEvent(s.lane_streams[mi], s.lane_start[s.groups.size()], 0));
+          s.stream = s.lane_streams[mi];
+          s.act_lane = mi + 1;
+        }
+        s.grad_pooled_slot = pslot;
         run_program(s, mi, nb, s.d_pose_m.p + (size_t)mi * B + b0, s.d_aff_m.p + (size_t)mi * B + b0,
-                    s.d_loss_m.p + (size_t)mi * B + b0, true);
+                    s.d_loss_m.p + (size_t)mi * B + b0, true, pslot);
         float *g0 = run_backward(s, mi, nb);
         VoxBackArgs vb{};
         vb.lig_xyz = d_lig + (size_t)b0 * L * 3;
@@ -2449,7 +2526,7 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
         vb.lig_consts = ls.consts;
         vb.lig_chan = ls.chan;
         vb.n_lig = ls.n_lig;
-        vb.centers = s.d_centers.p + (size_t)b0 * 3;
+        vb.centers = s.d_centers.p + (size_t)set * s.centers_stride + (size_t)b0 * 3;
         vb.grad_pooled = g0;
         vb.argmax = am0;
         vb.N = m->N;
@@ -2458,7 +2535,7 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
         vb.half_dim = m->d.dimension / 2.0f;
         vb.qa = m->qa;
         vb.qb = m->qb;
-        vb.lig_grad = s.d_lig_grad.p + (size_t)b0 * L * 3;
+        vb.lig_grad = (lanes ? s.d_lig_grad_m.p + (size_t)mi * n_lg_all : s.d_lig_grad.p) + (size_t)b0 * L * 3;
         vb.scale = 1.0f / (float)nm;
         vb.accumulate = 1;
         vb.rot = s.cur_rot ? s.cur_rot + (size_t)b0 * 4 : nullptr;
@@ -2474,13 +2551,23 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
           vb.lig_consts = tr.flex_consts.p;
           vb.lig_chan = tr.flex_chan.p;
           vb.n_lig = tr.n_flex_typed;
-          vb.lig_grad = s.d_flex_grad.p + (size_t)b0 * n_flex * 3;
+          vb.lig_grad = (lanes ? s.d_flex_grad_m.p + (size_t)mi * n_fg_all : s.d_flex_grad.p) + (size_t)b0 * n_flex * 3;
           ProfScope ps(s, "voxel_backward_flex", 0.0, 0.0, nb);
           launch_voxel_backward(vb, nb, m->input_pool, s.stream);
         }
         MIG_HIP(hipGetLastError());
+        if (lanes) {
+          MIG_HIP(hipEventRecord(s.lane_done[mi], s.stream));
+          s.stream = lane_guard.main, s.act_lane = 0;
+        }
       }
     }
+  }
+  s.grad_pooled_slot = kPooledSlot;
+  if (lanes) {  // the per-model gradients, added in model order
+    for (int mi = 0; mi < nm; mi++) MIG_HIP(hipStreamWaitEvent(s.stream, s.lane_done[mi], 0));
+    launch_sum_models(s.d_lig_grad_m.p, nm, n_lg_all, s.d_lig_grad.p, s.stream);
+    if (flex_xyz) launch_sum_models(s.d_flex_grad_m.p, nm, n_fg_all, s.d_flex_grad.p, s.stream);
   }
   s.d_pose.ensure(B);
   s.d_aff.ensure(B);
@@ -2526,9 +2613,12 @@ static void score_batch_grad(Scorer &s, const float *lig_xyz, const int32_t *lig
                              float *flex_grad = nullptr) {
   if (B <= 0) return score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
   std::lock_guard<std::recursive_mutex> one_call(device_call_lock(s.device));
+  s.alone_on_device = scorer_alone_on_device(s.device, &s) || (option(OPT_MI_GNINA_LANES) && atoi(option(OPT_MI_GNINA_LANES)) > 1);
   RotScope rot_scope(s, B);
   h2_flag_reset(s);
+  const auto t_call = std::chrono::steady_clock::now();
   score_batch_grad_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, lig_grad, flags, flex_xyz, flex_grad);
+  lane_tune_after_call(s, B, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count());
   // (with device-output calls pending the flag is sticky and may be theirs: the repeat is then unnecessary at worst --
   // never skipped, the header promises a flagged host-output call is repeated before it returns)
   if (s.conv_path == 0 || *s.h_ovf == 0u) return;
@@ -2733,6 +2823,23 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   }
 }
 
+// lane-offset tuning (Scorer::lane_offset) behind a synchronous call that ran on lanes: calls of one batch size, kLaneTunePer
+// per candidate assignment of models to lane streams, the fastest kept (scoring and gradient calls share the choice: whichever
+// kind comes first tunes)
+static void lane_tune_after_call(Scorer &s, int B, double us) {
+  constexpr int kLaneTunePer = 4, kLaneCands = 8;
+  if (!s.last_call_lanes || s.lane_tune_calls >= kLaneCands * kLaneTunePer || option(OPT_MI_GNINA_LANE_OFFSET) ||
+      (int)s.models.size() > kLaneCands || (s.lane_tune_calls != 0 && B != s.lane_tune_B))
+    return;
+  s.lane_tune_B = B;
+  const int k = s.lane_tune_calls % kLaneTunePer;
+  if (k == 0) s.lane_tune_cur_us = 1e30;             // (the first call on a new set of streams is not counted)
+  else s.lane_tune_cur_us = std::min(s.lane_tune_cur_us, us);
+  if (k == kLaneTunePer - 1 && s.lane_tune_cur_us < s.lane_tune_best_us) s.lane_tune_best_us = s.lane_tune_cur_us, s.lane_tune_best = s.lane_offset;
+  s.lane_tune_calls++;
+  s.lane_offset = s.lane_tune_calls < kLaneCands * kLaneTunePer ? s.lane_tune_calls / kLaneTunePer : s.lane_tune_best;
+}
+
 // (see score_batch_grad.)  A device-output call (MI_OUT_ON_DEVICE) returns before its kernels ran: the flag then stays
 // sticky until mi_scorer_synchronize, which reports it as MI_ERR_RANGE -- the caller repeats those calls under
 // MI_PRECISION_FP32_MFMA (mi_pool_score_batch does).
@@ -2746,19 +2853,7 @@ static void score_batch(Scorer &s, const float *lig_xyz, const int32_t *lig_smt,
   h2_flag_reset(s);
   const auto t_call = std::chrono::steady_clock::now();
   score_batch_once(s, lig_xyz, lig_smt, B, L, centers, pose, aff, loss, var, flags, ragged);
-  // lane-offset tuning (Scorer::lane_offset): synchronous lane calls of one batch size, kLaneTunePer per candidate
-  constexpr int kLaneTunePer = 4, kLaneCands = 8;
-  if (s.last_call_lanes && !(flags & MI_OUT_ON_DEVICE) && s.lane_tune_calls < kLaneCands * kLaneTunePer && !option(OPT_MI_GNINA_LANE_OFFSET) &&
-      (int)s.models.size() <= kLaneCands && (s.lane_tune_calls == 0 || B == s.lane_tune_B)) {
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
-    s.lane_tune_B = B;
-    const int k = s.lane_tune_calls % kLaneTunePer;
-    if (k == 0) s.lane_tune_cur_us = 1e30;             // (the first call on a new set of streams is not counted)
-    else s.lane_tune_cur_us = std::min(s.lane_tune_cur_us, us);
-    if (k == kLaneTunePer - 1 && s.lane_tune_cur_us < s.lane_tune_best_us) s.lane_tune_best_us = s.lane_tune_cur_us, s.lane_tune_best = s.lane_offset;
-    s.lane_tune_calls++;
-    s.lane_offset = s.lane_tune_calls < kLaneCands * kLaneTunePer ? s.lane_tune_calls / kLaneTunePer : s.lane_tune_best;
-  }
+  if (!(flags & MI_OUT_ON_DEVICE)) lane_tune_after_call(s, B, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count());
   if (s.conv_path == 0) return;
   if (flags & MI_OUT_ON_DEVICE) {
     s.ovf_pending = true;

@@ -91,6 +91,41 @@ def test_default_ensemble_small_calls_are_reproducible(capi):
     assert np.array_equal(lanes, serial), int((np.abs(lanes - serial).max(axis=(1, 2)) > 0).sum())
 
 
+def test_default_ensemble_gradient_calls_on_lanes(capi):
+    """Gradient calls (score + d loss / d atoms: CNN refinement, torch_model.cpp:197-221) of gnina's default ensemble at
+    B = 1 .. 3 run every model -- forward program, backward pass, voxel backward -- on a stream and in a buffer set of its own,
+    the per-model atom gradients added in model order at the end: the additions of the one-stream call.  Same scores and the
+    same gradient bits as with MI_GNINA_NO_GRAD_LANES=1, every time, and a scoring call in between does not disturb them."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "cnn_goldens.npz"))
+    names = ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"]
+    rec_xyz, rec_smt, lig_smt, poses = (G[f"{names[0]}/{k}"] for k in ("rec_xyz", "rec_smt", "lig_smt", "poses"))
+
+    def run(sc, reps):
+        out = []
+        for rep in range(reps):
+            b, n = rep % len(poses), 1 + rep % 3
+            batch = np.concatenate([poses, poses])[b:b + n]
+            r = sc.score_grad(batch, lig_smt)
+            if rep % 5 == 0:
+                sc.score_batch(batch[:1], lig_smt)
+            out.append((r["pose"].copy(), r["affinity"].copy(), r["loss"].copy(), r["lig_grad"].copy()))
+        return out
+
+    with capi.option("MI_GNINA_NO_GRAD_LANES", "1"):
+        s1 = capi.Scorer(names)
+        s1.set_receptor(rec_xyz, rec_smt)
+        serial = run(s1, 40)
+        assert not s1.last_call_on_lanes() if hasattr(s1, "last_call_on_lanes") else True
+    s = capi.Scorer(names)
+    s.set_receptor(rec_xyz, rec_smt)
+    lanes = run(s, 40)
+    again = run(s, 40)
+    for k, (a, b, c) in enumerate(zip(serial, lanes, again)):
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(y, z), k
+    assert np.isfinite(lanes[0][3]).all() and np.abs(lanes[0][3]).max() > 0
+
+
 def test_two_threads_device_output_calls(capi):
     """MI_LIG_ON_DEVICE | MI_OUT_ON_DEVICE calls (what the pools and a device-resident caller make) return after they enqueue:
     two threads then have voxelizers and conv kernels of two scorers in flight side by side for the whole run."""
