@@ -165,7 +165,9 @@ def voxelizer_issue_committed(kernel_prefix="voxelize_tiles<1, true"):
                 "gpu_cycles_per_launch": round(cyc), "frac": round(valu * 4.0 / 1024.0 / cyc, 4),
                 "scalar_alu_frac": round(salu / 256.0 / cyc, 4),
                 "note": "VALU instructions x 4 cycles / 1,024 SIMDs over the kernel's cycles; scalar: SALU instructions / 256 "
-                        "CUs (one scalar ALU per CU) over the same cycles; profiles/latest_pmc.json (committed), not this run"}
+                        "CUs (one scalar ALU per CU) over the same cycles; profiles/latest_pmc.json (committed), not this run; instruction and "
+                        "cycle counters come from SEPARATE rocprofv3 passes, so the ratio carries their run-to-run spread (a few per cent: "
+                        "a value just above 1 means 'at the issue rate')"}
     except Exception:
         return None
 

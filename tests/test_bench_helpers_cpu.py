@@ -28,8 +28,9 @@ def test_spin_up_runs_untimed_steps_and_synchronises_each():
 def test_voxelizer_issue_figures_from_the_committed_counters():
     v = bench.voxelizer_issue_committed()
     assert v is not None, "profiles/latest_pmc.json has no voxelize_tiles<1, true> entry"
-    # one VALU instruction per SIMD every four cycles, one scalar ALU per CU: neither fraction can exceed 1
-    assert 0.5 < v["frac"] <= 1.0 and 0.2 < v["scalar_alu_frac"] <= 1.0
+    # one VALU instruction per SIMD every four cycles, one scalar ALU per CU: neither fraction can exceed 1 -- up to the
+    # run-to-run spread of the separate counter passes the two numbers of a ratio come from (a few per cent)
+    assert 0.5 < v["frac"] <= 1.05 and 0.2 < v["scalar_alu_frac"] <= 1.05
     assert v["valu_insts_per_launch"] > v["salu_insts_per_launch"]   # (round 5: it used to be the other way round)
     assert bench.voxelizer_issue_committed("no such kernel") is None
 
