@@ -653,7 +653,8 @@ def config_seam_b1(capi, synth):
                    "two / four_threads: scorers on host threads of their own (gnina: one fresh_copy() per worker thread), scoring "
                    "side by side -- round 6 removed the per-device lock of round 5 (its cause, packed-fp32 instructions next to "
                    "another queue's MFMAs, is compiled out: DESIGN.md §6); a scorer that has the device to itself runs an "
-                   "ensemble's models on streams of their own (lanes), scorers that share it stay on their own streams"}
+                   "ensemble's models on streams of their own (lanes; gradient calls too), scorers that share it stay on their own streams; "
+                   "per-pose launches have their own tiles, operand rings and prologue fetches (DESIGN.md §3.2)"}
     for label, models in (("default2017", ["default2017"]),
                           ("default_ensemble", ["dense_1_3", "dense_1_3_PT_KD_3", "crossdock_default2018_KD_4"])):
         s = capi.Scorer(models)
