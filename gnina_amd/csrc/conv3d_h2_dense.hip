@@ -636,11 +636,12 @@ void launch_conv_h2_d16(ConvArgs p, int B, hipStream_t s) {
   const bool two = p.h2_wlds >= 2 && B >= 2;
   // one pose per workgroup and few enough workgroups that each has (a share of) a CU's LDS to itself: the GRP variants, as
   // many chunk sets as that share holds (<= 6: a wave has up to 10 DMAs per chunk in flight and vmcnt counts to 63)
-  p.d16_group = 1;
-  if (!two && !p.h2_honly && !(p.h2_dbg & 128)) {
+  if (two || p.h2_honly || (p.h2_dbg & 128)) p.d16_group = 1;
+  else {
     const long per_cu = ((long)B * tiles + 255) / 256;
     const long fit = (long)(160 * 1024) / ((long)lds * per_cu);
-    p.d16_group = (int)std::max(1L, std::min({6L, (long)p.nchunks, fit}));
+    const long cap = p.d16_group > 0 ? std::min(6L, (long)p.d16_group) : 6L;  // (the caller's cap, MI_GNINA_D16_GROUP_MAX; 0 = none)
+    p.d16_group = (int)std::max(1L, std::min({cap, (long)p.nchunks, fit}));
     lds *= (size_t)p.d16_group;
   }
   const bool grp = p.d16_group > 1;

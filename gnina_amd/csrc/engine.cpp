@@ -2103,6 +2103,7 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                 }
               }
               if (const char *ev = option(OPT_MI_GNINA_D16_NP)) h.h2_wlds = atoi(ev) >= 2 ? 2 : 1;
+              h.d16_group = option(OPT_MI_GNINA_D16_GROUP_MAX) ? atoi(option(OPT_MI_GNINA_D16_GROUP_MAX)) : 0;  // (cap on the chunk groups of per-pose launches; 0 = the launcher's)
               h.h2_persist = -1;  // (persistent launch, as many workgroups as the chip holds; MI_GNINA_D16_PERSIST=0: one per item, n: at most n per CU)
               if (const char *ev = option(OPT_MI_GNINA_D16_PERSIST)) h.h2_persist = atoi(ev);
               launch_conv_h2_d16(h, nb, s.stream);

@@ -50,6 +50,7 @@ namespace mig {
   X(MI_GNINA_K1_TILE)                \
   X(MI_GNINA_D16_DBG)                \
   X(MI_GNINA_D16_TILE)               \
+  X(MI_GNINA_D16_GROUP_MAX)          \
   X(MI_GNINA_H16_WLDS)               \
   X(MI_GNINA_OUT_COPY)               \
   X(MI_GNINA_NO_GRAD_LANES)          \
