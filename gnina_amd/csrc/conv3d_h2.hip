@@ -1818,6 +1818,274 @@ __global__ __launch_bounds__(256, 1) void conv3d_h2_16_ring_kernel(ConvArgs p) {
   h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3d_h2_16_pc_kernel (round 6): conv3d_h2_16_ring_kernel for tiles of at most four cells and 128 halo voxels -- the
+// 1 x 1 x 3-cell tiles of the 6^3 layers, where waves 0-1 hold the (one and a half) M-tiles and waves 2-3 have none.  There
+// the ring kernel's chunk was: staging by all waves, barrier, a K loop of two waves (42 dependent MFMAs on one accumulator,
+// ~1 us, nothing else to issue), barrier.  Here the idle waves are the PRODUCERS: while waves 0-1 run the K loop of chunk c
+// on one tile buffer, waves 2-3 (thread 128 + v owns halo voxel v) stage chunk c + 1 into the other -- one barrier per chunk.
+// Raw channels are requested three chunks ahead and weights two (each is needed two iterations after its request), three
+// slots each.  Same values into the same MFMAs in the same order: same bits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void conv3d_h2_16_pc_kernel(ConvArgs p) {
+  constexpr int NTHREADS = 256, TM = 1, RS = 3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, row = lane & 15;
+  const bool producer = wm >= 2;
+
+  const int tiles_per_pose = p.ntx * p.nty * p.ntz;
+  const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int b = wg / tiles_per_pose;
+  int t = wg - b * tiles_per_pose;
+  const int tz = t % p.ntz;
+  t /= p.ntz;
+  const int ty = t % p.nty, tx = t / p.nty;
+
+  const int HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2;
+  const int HV = HX * HY * HZ;  // <= 128: the launcher
+  const int CC8 = p.cc4, CCs = p.ccs;
+  const int SZ = CCs, SY = HZ * SZ + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;  // fp16 elements
+  constexpr int taps = 27;
+  const int Qmax = taps * CC8;
+  const int Smax = (Qmax + 3) >> 2;
+  const int NQ = 2 * CC8;
+  const int HVp = (HV + 63) & ~63;
+  const int n_raw = (NQ * HVp + 255) >> 8, n_w = (2 * Smax + 3) >> 2;
+  const int raw_bytes = n_raw * 4096, w_bytes = n_w * 4096;
+  const int n = p.nchunks;
+
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h2[];
+  const int tile_bytes = (int)((((size_t)HX * SX + 7) & ~(size_t)7) * sizeof(_Float16));
+  char *const s_base = reinterpret_cast<char *>(smem_h2);
+  int *s_qoff = reinterpret_cast<int *>(s_base + 2 * tile_bytes);
+  int *s_vox = s_qoff + ((Qmax + 8 + 3) & ~3);
+  const int cpad = n * CC8 * 8;
+  const int bn_off = (2 * tile_bytes + ((Qmax + 8 + 3) & ~3) * 4 + (HVp + 4) * 4 + 1023) & ~1023;
+  float *const s_bn = reinterpret_cast<float *>(s_base + bn_off);
+  const int raw_off = bn_off + (int)(((size_t)2 * cpad * sizeof(float) + 1023) & ~(size_t)1023);
+  const int w_off = raw_off + RS * raw_bytes;
+  if (p.bn_scale)
+    for (int c = tid; c < cpad; c += NTHREADS) {
+      const bool has = c < p.cin4 * 4;
+      s_bn[c] = has ? p.bn_scale[c] : 1.f;
+      s_bn[cpad + c] = has ? p.bn_shift[c] : 0.f;
+    }
+  const float bias_pre = p.bias[row < p.cout ? row : 0];
+  for (int q = tid; q < Qmax + 8; q += NTHREADS) {
+    const int qq = q < Qmax ? q : Qmax - 1;
+    const int c8 = qq / taps, tap = qq - c8 * taps;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    s_qoff[q] = ((dx * SX + dy * SY + dz * SZ) + c8 * 16) * 2;
+  }
+
+  const int NC = p.tcx * p.tcy * p.tcz;  // <= 4: waves 0-1 cover them
+  const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 2) & 1, cell_in_mt = row >> 3;
+  int baseA;
+  {
+    int cell = wm * 2 + cell_in_mt;
+    if (cell >= NC) cell = 0;
+    const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+    baseA = ((2 * cx + ox) * SX + (2 * cy + oy) * SY + (2 * cz + oz) * SZ) * 2;  // bytes
+  }
+  h2_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  const bool wave_has_cells = wm * 2 < NC;
+
+  const int S = p.S;
+  const int x0 = tx * 2 * p.tcx - 1, y0 = ty * 2 * p.tcy - 1, z0 = tz * 2 * p.tcz - 1;
+  const unsigned inv_hz = ((1u << 20) + HZ - 1) / HZ, inv_hy = ((1u << 20) + HY - 1) / HY;
+  // thread 128 + v owns halo voxel v; the zero padding is laid down once, in both tile buffers
+  const int hv_mine = tid - 128;
+  int st_dst = 0, my_off = -1;
+  if (hv_mine >= 0 && hv_mine < HV) {
+    const int t1 = (int)(((unsigned)hv_mine * inv_hz) >> 20), hz = hv_mine - t1 * HZ;
+    const int hx = (int)(((unsigned)t1 * inv_hy) >> 20), hy = t1 - hx * HY;
+    const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+    const bool in = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S;
+    my_off = in ? ((x * S + y) * S + z) * p.in_cs : -1;
+    st_dst = hx * SX + hy * SY + hz * SZ;
+    if (!in)
+      for (int c = 0; c < CCs; c += 8) {
+        *reinterpret_cast<uint4 *>(s_base + (st_dst + c) * 2) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(s_base + tile_bytes + (st_dst + c) * 2) = make_uint4(0u, 0u, 0u, 0u);
+      }
+  }
+  if (tid < HVp) s_vox[tid] = -1;
+  __syncthreads();
+  if (hv_mine >= 0 && hv_mine < HVp) s_vox[hv_mine] = my_off;
+  __syncthreads();  // s_vox, s_qoff
+
+  int qo[kH16RingSteps];
+#pragma unroll
+  for (int st = 0; st < kH16RingSteps; st++) qo[st] = s_qoff[min(4 * st + kg, Qmax + 7)];
+  unsigned voff[kH16RingMaxRaw];
+#pragma unroll
+  for (int i = 0; i < kH16RingMaxRaw; i++) {
+    const int j = tid + i * NTHREADS;
+    const int q = j / HVp, hv = j - q * HVp;
+    const int off = (i < n_raw && q < NQ) ? s_vox[hv] : -1;
+    voff[i] = off >= 0 ? (unsigned)(off + q * 4) * 4u : 0x80000000u;
+  }
+  typedef int h16_i32x4 __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [&](const void *base, unsigned bytes) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)base;
+    h16_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull)), rs.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
+    rs.z = __builtin_amdgcn_readfirstlane((int)bytes), rs.w = 0x00020000;
+    return rs;
+  };
+  const size_t pose_floats = (size_t)S * S * S * p.in_cs;
+  const h16_i32x4 rsrc_in = make_rsrc(p.in + (size_t)b * pose_floats, (unsigned)(pose_floats * 4));
+  const int wchunk = Smax * 2048;
+  const h16_i32x4 rsrc_w = make_rsrc(p.wp, (unsigned)(n * wchunk));
+  const unsigned wl32 = (unsigned)lane * 32u;
+  // (inline asm DMAs, counted by hand: conv3d_h2_16_ring_kernel)
+  auto issue_raw = [&](int chunk) __attribute__((always_inline)) {
+    if (chunk >= n) return;
+    unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane(raw_off + (chunk % RS) * raw_bytes + wm * 1024);
+    const unsigned soff_in = (unsigned)__builtin_amdgcn_readfirstlane(chunk * CC8 * 32);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=&s"(keep));
+#pragma unroll
+    for (int i = 0; i < kH16RingMaxRaw; i++)
+      if (i < n_raw) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(voff[i]), "s"(rsrc_in), "s"(soff_in) : "memory");
+        m0v += 0x1000u;
+      }
+    asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
+  };
+  auto issue_w = [&](int chunk) __attribute__((always_inline)) {
+    if (chunk >= n) return;
+    unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane(w_off + (chunk % RS) * w_bytes + wm * 1024);
+    unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(chunk * wchunk + (wm >> 1) * 2048 + (wm & 1) * 16);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=&s"(keep));
+    for (int i = 0; i < n_w; i++) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(wl32), "s"(rsrc_w), "s"(soff) : "memory");
+      m0v += 0x1000u;
+      soff += 4096u;
+    }
+    asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
+  };
+  // VMEM operations of "iteration i" (i >= -2): the raw channels of chunk i + 3 and the weights of chunk i + 2
+  auto ops_of = [&](int i) { return (i + 3 < n ? n_raw : 0) + (i + 2 < n ? n_w : 0); };
+
+  auto commit = [&](int chunk) __attribute__((always_inline)) {  // producers: chunk -> tile buffer chunk & 1
+    if (my_off < 0) return;
+    const int c_base = chunk * CC8 * 8;
+    const int nq = min(NQ, p.cin4 - chunk * NQ);
+    const char *raw = s_base + raw_off + (chunk % RS) * raw_bytes;
+    _Float16 *dst = reinterpret_cast<_Float16 *>(s_base + (chunk & 1) * tile_bytes) + st_dst;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q >= NQ) continue;
+      _Float16 *d = dst + (q >> 1) * 16 + (q & 1) * 4;
+      uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+      if (q < nq) {
+        float4 x = *reinterpret_cast<const float4 *>(raw + ((size_t)q * HVp + hv_mine) * 16);
+        if (p.bn_scale) {
+          const float4 sc = *reinterpret_cast<const float4 *>(s_bn + c_base + q * 4);
+          const float4 sh = *reinterpret_cast<const float4 *>(s_bn + cpad + c_base + q * 4);
+          x.x = x.x * sc.x + sh.x;
+          x.y = x.y * sc.y + sh.y;
+          x.z = x.z * sc.z + sh.z;
+          x.w = x.w * sc.w + sh.w;
+        }
+        split4(x, h, l, amax);
+      }
+      *reinterpret_cast<uint2 *>(d) = h;
+      *reinterpret_cast<uint2 *>(d + 8) = l;
+    }
+  };
+
+  // prologue: raw 0 | raw 1, weights 0 ("iteration -2") | raw 2, weights 1 ("iteration -1"); chunk 0 is staged before the loop
+  issue_raw(0);
+  issue_raw(1), issue_w(0);
+  issue_raw(2), issue_w(1);
+  h2_wait_vm(ops_of(-2) + ops_of(-1));
+  __syncthreads();
+  if (producer) commit(0);
+  for (int chunk = 0; chunk < n; chunk++) {
+    // raw channels of chunk + 1 and weights of `chunk` (requested two iterations ago) have landed: this wave's part ...
+    h2_wait_vm(ops_of(chunk - 1));
+    __syncthreads();  // ... and everybody's; tile buffer chunk & 1 is staged, the K loop of chunk - 1 and the staging of `chunk` are over
+    issue_raw(chunk + 3), issue_w(chunk + 2);
+    if (producer) {
+      if (chunk + 1 < n) commit(chunk + 1);
+      continue;
+    }
+    if (!wave_has_cells) continue;
+    const int nq = min(NQ, p.cin4 - chunk * NQ);
+    const int cc8_here = min(CC8, (nq + 1) >> 1);
+    const int NS = (cc8_here * taps + 3) >> 2;
+    const char *wbuf = s_base + w_off + (chunk % RS) * w_bytes + lane * 16;
+    const char *tile = s_base + (chunk & 1) * tile_bytes;
+    uint4 ah[4], al[4], wh[4], wl[4];
+    auto load_step = [&](int st, int set) __attribute__((always_inline)) {
+      const char *a = tile + baseA + qo[st];
+      ah[set] = *reinterpret_cast<const uint4 *>(a);
+      al[set] = *reinterpret_cast<const uint4 *>(a + 16);
+      wh[set] = *reinterpret_cast<const uint4 *>(wbuf + st * 2048);
+      wl[set] = *reinterpret_cast<const uint4 *>(wbuf + st * 2048 + 1024);
+    };
+#pragma unroll
+    for (int st = 0; st < 3; st++)
+      if (st < NS) load_step(st, st);
+#pragma unroll
+    for (int st = 0; st < kH16RingSteps; st++) {
+      if (st < NS) {
+        if (st + 3 < kH16RingSteps && st + 3 < NS) load_step(st + 3, (st + 3) & 3);
+        const int set = st & 3;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[set]), __builtin_bit_cast(f16x8, wh[set]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[set]), __builtin_bit_cast(f16x8, wl[set]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[set]), __builtin_bit_cast(f16x8, wh[set]), acc, 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue (conv3d_h2_16_kernel's)
+  const float unscale = p.h2_unscale;
+  float *out_b = p.out + (size_t)b * S * S * S * p.out_cs + p.out_c0;
+  const int ncx = S / 2;
+  const int ch = row;
+  if (ch < p.cout && wave_has_cells) {
+    const int cell = wm * 2 + (kg >> 1);
+    if (cell < NC) {
+      const int cz = cell % p.tcz, cy = (cell / p.tcz) % p.tcy, cx = cell / (p.tcz * p.tcy);
+      const int gcx = tx * p.tcx + cx, gcy = ty * p.tcy + cy, gcz = tz * p.tcz + cz;
+      if (gcx < ncx && gcy < ncx && gcz < ncx) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int vx = 2 * gcx + (kg & 1), vy = 2 * gcy + (r >> 1), vz = 2 * gcz + (r & 1);
+          float v = acc[r] * unscale + bias_pre;
+          if (p.relu) v = fmaxf(v, 0.f);
+          out_b[(((size_t)vx * S + vy) * S + vz) * p.out_cs + ch] = v;
+        }
+      }
+    }
+  }
+  h2_report_overflow(p.h2_overflow, !(amax <= 65504.f));
+}
+
+// LDS of conv3d_h2_16_pc_kernel; 0 = the launch is outside what the kernel covers
+size_t conv_h2_16_pc_lds_bytes(const ConvArgs &p) {
+  if (p.ksize != 3 || p.coutp != 16 || p.cc4 < 1 || p.cc4 > 2) return 0;
+  const size_t HX = 2 * p.tcx + 2, HY = 2 * p.tcy + 2, HZ = 2 * p.tcz + 2, HV = HX * HY * HZ;
+  if (HV > 128 || p.tcx * p.tcy * p.tcz > 4) return 0;
+  const size_t HVp = (HV + 63) & ~(size_t)63, NQ = 2 * p.cc4;
+  const size_t n_raw = (NQ * HVp + 255) >> 8;
+  const int Q = 27 * p.cc4, Smax = (Q + 3) >> 2;
+  const size_t n_w = (2 * (size_t)Smax + 3) >> 2;
+  if (n_raw > (size_t)kH16RingMaxRaw || 2 * (n_raw + n_w) > 62) return 0;
+  const size_t SY = HZ * p.ccs + 8 * p.h2_pad_y, SX = HY * SY + 8 * p.h2_pad_x;
+  const size_t tile_bytes = ((HX * SX + 7) & ~(size_t)7) * sizeof(_Float16);
+  const size_t bn_off = (2 * tile_bytes + (size_t)((Q + 8 + 3) & ~3) * 4 + (HVp + 4) * 4 + 1023) & ~(size_t)1023;
+  const size_t bn_bytes = ((size_t)2 * p.nchunks * p.cc4 * 8 * sizeof(float) + 1023) & ~(size_t)1023;
+  return bn_off + bn_bytes + 3 * (n_raw + n_w) * 4096;
+}
+
 // LDS of conv3d_h2_16_ring_kernel with `ring` slots; 0 = the launch is outside what the kernel covers
 size_t conv_h2_16_ring_lds_bytes(const ConvArgs &p, int ring) {
   if (p.ksize != 3 || p.coutp != 16 || p.cc4 < 1 || p.cc4 > 2 || ring < 2) return 0;
@@ -1956,7 +2224,7 @@ template <int TM> static void launch_h2_16(ConvArgs p, int B, hipStream_t s) {
   // weights through LDS (WL) for the 3x3x3 layers at 6^3 (h2_wlds: 0 = never, 1 = those, 2 = every 3x3x3 layer the buffers fit;
   // + 4: no ring kernel for launches of few small workgroups)
   const int mode = p.h2_wlds & 3;
-  const bool ring_ok = p.h2_wlds > 0 && !(p.h2_wlds & 4);
+  const bool ring_ok = p.h2_wlds > 0 && !(p.h2_wlds & 4), pc_ok = !(p.h2_wlds & 8);
   p.h2_wlds = 0;
   // (a launch that fills the chip hides the weights' latency behind its other workgroups, and the buffers cost it one of
   // them per CU: Dense at 1,024 poses per step 68.4 k poses/s without, 67.1 k with)
@@ -1964,7 +2232,17 @@ template <int TM> static void launch_h2_16(ConvArgs p, int B, hipStream_t s) {
     p.h2_wlds = 1;
     if (conv_h2_lds_bytes(p) > 160 * 1024) p.h2_wlds = 0;
   }
-  // a few small workgroups (the 6^3 layers of a per-pose call): operands through a ring, requested chunks ahead
+  // a few small workgroups (the 6^3 layers of a per-pose call): operands through a ring, requested chunks ahead; tiles whose
+  // cells fit two waves take the producer / consumer form (h2_wlds + 8: not)
+  if constexpr (TM == 1)
+    if (p.ksize == 3 && ring_ok && pc_ok && grid.x <= 256 && !p.accumulate) {
+      const size_t lds = conv_h2_16_pc_lds_bytes(p);
+      if (lds != 0 && lds <= 160 * 1024) {
+        ensure_max_lds(reinterpret_cast<const void *>(conv3d_h2_16_pc_kernel), 160 * 1024);
+        hipLaunchKernelGGL(conv3d_h2_16_pc_kernel, grid, block, lds, s, p);
+        return;
+      }
+    }
   if constexpr (TM <= 2)
     if (p.ksize == 3 && ring_ok && grid.x <= 256 && !p.accumulate) {
       for (int ring = 4; ring >= 3; ring--) {

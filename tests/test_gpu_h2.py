@@ -178,3 +178,5 @@ def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
         check("weights through LDS wherever they fit")
     with capi.option("MI_GNINA_H16_WLDS", 5):
         check("no operand ring for the launches of few small workgroups")
+    with capi.option("MI_GNINA_H16_WLDS", 9):
+        check("the ring kernel without its producer / consumer form (conv3d_h2_16_pc_kernel)")
