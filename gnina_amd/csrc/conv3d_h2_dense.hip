@@ -328,8 +328,12 @@ __global__ __launch_bounds__(256, 3) void conv3d_h2_d16_kernel(ConvArgs p) {
 // replaces read 96 fp32 channels per voxel into registers, split them and wrote LDS: 2.66 ms for 5.4 GB at 24^3.
 // ---------------------------------------------------------------------------------------------
 constexpr int kK1sNS = 7;  // wave-DMAs per thread and chunk: voxels * (2 CC8 + 1) <= kK1sNS * 256 slots
+// bytes of one chunk's tile set in LDS (`total` 16-byte slots, whole wave-DMAs, + the finite pad behind the last voxel)
+__host__ __device__ inline size_t conv_h2_k1s_set_bytes(int total) { return ((((size_t)total + 63) & ~(size_t)63) * 16 + 64 + 1023) & ~(size_t)1023; }
 
-template <int TN, bool HONLY = false>
+// GRP (round 6, per-pose calls; see conv3d_h2_d16_kernel): the K chunks' tiles are DMA'd ConvArgs::d16_group at a time into as
+// many LDS sets -- one round trip per group instead of one per chunk for a workgroup that is alone on its CU
+template <int TN, bool HONLY = false, bool GRP = false>
 __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -348,7 +352,10 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
   char *const s_tile = smem_k1s;
   // (an odd CC8 leaves the second half-wave of a chunk's last step on the voxel's pad slot and the 16 bytes behind it --
   // the next voxel's first slot, or, behind the last voxel, this one: zero weight rows cancel them, but they must be finite)
-  if (tid < 4) reinterpret_cast<unsigned *>(s_tile + (size_t)((total + 63) & ~63) * 16)[tid] = 0u;
+  const int D = GRP ? p.d16_group : 1;
+  const int set_bytes = (int)conv_h2_k1s_set_bytes(total);
+  if (tid < 4)
+    for (int gi = 0; gi < D; gi++) reinterpret_cast<unsigned *>(s_tile + (size_t)gi * set_bytes + (size_t)((total + 63) & ~63) * 16)[tid] = 0u;
 
   const int NC = p.tcx * p.tcy * p.tcz;
   const int oz = row & 1, oy = (row >> 1) & 1, ox = (row >> 3) & 1;
@@ -432,21 +439,25 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
 
     load_w(0);
     int g = 0;
-    for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    for (int chunk0 = 0; chunk0 < p.nchunks; chunk0 += D) {
+      const int ng = GRP ? min(D, p.nchunks - chunk0) : 1;  // chunks of this group
       if (!first) __syncthreads();  // every wave is through the previous K loop: the tile may be overwritten
       first = false;
+      for (int gi = 0; gi < ng; gi++) {
 #pragma unroll
-      for (int i = 0; i < kK1sNS; i++)
-        if ((i * 4 + wave) * 64 < total && !(p.h2_dbg & 4))  // (wave-uniform)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (D16LdsPtr)(s_tile + (i * 4 + wave) * 1024), 16, voff[i], chunk * chunk_bytes, 0, 0);
+        for (int i = 0; i < kK1sNS; i++)
+          if ((i * 4 + wave) * 64 < total && !(p.h2_dbg & 4))  // (wave-uniform)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (D16LdsPtr)(s_tile + gi * set_bytes + (i * 4 + wave) * 1024), 16, voff[i], (chunk0 + gi) * chunk_bytes, 0, 0);
+      }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       __syncthreads();
       if (p.h2_dbg & 2) {  // (timing only: no K loop)
-        g += P;
+        g += P * ng;
         continue;
       }
+      for (int gi = 0; gi < ng; gi++)
       for (int pr = 0; pr < P; pr++, g++) {
-        const char *a = s_tile + baseA + (2 * pr + kh) * 32;
+        const char *a = s_tile + gi * set_bytes + baseA + (2 * pr + kh) * 32;
         const uint4 ah = *reinterpret_cast<const uint4 *>(a);
         uint4 al = ah;
         if constexpr (!HONLY) al = *reinterpret_cast<const uint4 *>(a + 16);
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256, (TN <= 3 ? 4 : 3)) void conv3d_h2_k1s_kernel(C
 
 size_t conv_h2_k1s_lds_bytes(const ConvArgs &p) {
   const size_t total = (size_t)8 * p.tcx * p.tcy * p.tcz * (2 * p.cc4 + 1);
-  return ((total + 63) & ~(size_t)63) * 16 + 64;
+  return conv_h2_k1s_set_bytes((int)total);
 }
 
 // persistent launches: workgroups the chip holds at once for this kernel (occupancy API, cached), a multiple of 8
@@ -559,8 +570,17 @@ void launch_conv_h2_k1s(ConvArgs p, int B, hipStream_t s) {
       (p.in_cs / 8) != p.cc4 * p.nchunks || (p.out_split && ((p.out_c0 % 8) || (p.out_cs % 8) || (p.cout % 8))) || (tn != 3 && tn != 5) ||
       2 * p.tcx > 255 || 2 * p.tcy > 255 || 2 * p.tcz > 255)
     throw Error(2, "launch_conv_h2_k1s: launch outside what the kernel covers");
-  const size_t lds = conv_h2_k1s_lds_bytes(p);
+  size_t lds = conv_h2_k1s_lds_bytes(p);
   p.n_items = B * p.ntx * p.nty * p.ntz;
+  // few enough workgroups that each has (a share of) a CU's LDS to itself: the chunk groups of the GRP variants
+  const long cap = p.d16_group > 0 ? std::min(6L, (long)p.d16_group) : 6L;
+  p.d16_group = 1;
+  if (!p.h2_honly && !(p.h2_dbg & 128)) {
+    const long per_cu = ((long)p.n_items + 255) / 256;
+    const long fit = (long)(160 * 1024) / ((long)lds * per_cu);
+    p.d16_group = (int)std::max(1L, std::min({cap, (long)p.nchunks, fit}));
+    lds *= (size_t)p.d16_group;
+  }
   auto go = [&](auto kern) {
     ensure_max_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
     int grid = p.n_items;
@@ -570,6 +590,11 @@ void launch_conv_h2_k1s(ConvArgs p, int B, hipStream_t s) {
   if (p.h2_honly) {
     if (tn == 3) go(conv3d_h2_k1s_kernel<3, true>);
     else go(conv3d_h2_k1s_kernel<5, true>);
+    return;
+  }
+  if (p.d16_group > 1) {
+    if (tn == 3) go(conv3d_h2_k1s_kernel<3, false, true>);
+    else go(conv3d_h2_k1s_kernel<5, false, true>);
     return;
   }
   if (tn == 3) go(conv3d_h2_k1s_kernel<3>);
