@@ -1286,6 +1286,84 @@ __global__ __launch_bounds__(256) void fc_heads_kernel(const float *in, const fl
   }
 }
 
+// Global max pool + heads in one launch for per-pose calls (a Dense model ends "whole-grid max pool -> three heads": two
+// dependent launches of ~9 and ~4 us on the critical path of every call).  One workgroup of 1,024 threads per pose: four voxel
+// slices x 256 channels take the maxima (order-free), the first 256 threads then run fc_heads_kernel's arithmetic on them from
+// LDS -- the same partial sums in the same order, the same bits.  The pooled activations are written out as gmax_kernel does.
+__global__ __launch_bounds__(1024) void gmax_heads_kernel(const float *in, float *gmax_out, int C, int in_cs, int out_cs, int S3,
+                                                          const float *w, const float *bias, int skip_softmax, int logistic_loss,
+                                                          float *pose, float *aff, float *loss) {
+  constexpr int kMaxC = 1024;
+  __shared__ __attribute__((aligned(16))) float s_x[kMaxC];
+  __shared__ float s_part[4][256];
+  __shared__ float red[3][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int part = tid >> 8, cl = tid & 255;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + cl;
+    const float *src = in + (size_t)b * S3 * in_cs + (c < C ? c : 0);
+    float m = src[(size_t)(part < S3 ? part : 0) * in_cs];
+#pragma unroll 8
+    for (int v = part + 4; v < S3; v += 4) m = fmaxf(m, src[(size_t)v * in_cs]);
+    s_part[part][cl] = m;
+    __syncthreads();
+    if (part == 0 && c < C) {
+      m = fmaxf(fmaxf(m, s_part[1][cl]), fmaxf(s_part[2][cl], s_part[3][cl]));
+      s_x[c] = m;
+      gmax_out[(size_t)b * out_cs + c] = m;
+    }
+    __syncthreads();
+  }
+  // ---- fc_heads_kernel on s_x (n_in = C), threads 0 .. 255 ----
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (tid < 256) {
+    const float4 *x = reinterpret_cast<const float4 *>(s_x);
+    const float4 *w0 = reinterpret_cast<const float4 *>(w);
+    const float4 *w1 = reinterpret_cast<const float4 *>(w + C);
+    const float4 *w2 = reinterpret_cast<const float4 *>(w + 2 * (size_t)C);
+    const int n4 = C / 4;
+    for (int i = tid; i < n4; i += 256) {
+      float4 xv = x[i], a = w0[i], bb = w1[i], c = w2[i];
+      s0 = fmaf(xv.x, a.x, s0); s0 = fmaf(xv.y, a.y, s0); s0 = fmaf(xv.z, a.z, s0); s0 = fmaf(xv.w, a.w, s0);
+      s1 = fmaf(xv.x, bb.x, s1); s1 = fmaf(xv.y, bb.y, s1); s1 = fmaf(xv.z, bb.z, s1); s1 = fmaf(xv.w, bb.w, s1);
+      s2 = fmaf(xv.x, c.x, s2); s2 = fmaf(xv.y, c.y, s2); s2 = fmaf(xv.z, c.z, s2); s2 = fmaf(xv.w, c.w, s2);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      s0 += __shfl_down(s0, off);
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+    }
+    if ((tid & 63) == 0) {
+      red[0][tid >> 6] = s0;
+      red[1][tid >> 6] = s1;
+      red[2][tid >> 6] = s2;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float z0 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + bias[0];
+    float z1 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + bias[1];
+    float a = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) + bias[2];
+    float m = fmaxf(z0, z1);
+    float lse = logf(expf(z0 - m) + expf(z1 - m));
+    float lp0 = (z0 - m) - lse, lp1 = (z1 - m) - lse;
+    float m2 = fmaxf(lp0, lp1);
+    float e0 = expf(lp0 - m2), e1 = expf(lp1 - m2);
+    float ps = skip_softmax ? lp1 : e1 / (e0 + e1);
+    float ls = logistic_loss ? -logf(lp1) : -((lp1 - m2) - logf(e0 + e1));
+    pose[b] = ps;
+    aff[b] = a;
+    loss[b] = ls;
+  }
+}
+
+bool gmax_heads_covers(int C) { return C % 4 == 0 && C <= 1024; }
+void launch_gmax_heads(const float *in, float *gmax_out, int B, int C, int in_cs, int out_cs, int S, const float *w, const float *bias,
+                       int skip_softmax, int logistic_loss, float *pose, float *aff, float *loss, hipStream_t s) {
+  hipLaunchKernelGGL(gmax_heads_kernel, dim3(B), dim3(1024), 0, s, in, gmax_out, C, in_cs, out_cs, S * S * S, w, bias, skip_softmax,
+                     logistic_loss, pose, aff, loss);
+}
+
 void launch_fc_heads(const float *in, const float *w, const float *bias, int n_in, int skip_softmax,
                      int logistic_loss, float *pose, float *aff, float *loss, float *raw3, int B, hipStream_t s) {
   hipLaunchKernelGGL(fc_heads_kernel, dim3(B), dim3(256), 0, s, in, w, bias, n_in, skip_softmax, logistic_loss,

@@ -2034,7 +2034,17 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
   const bool fwd_h2 = !bf16 && !grad && s.conv_path != 0;
   MIG_CHECK(!pooled_split || (fwd_h2 && m->pooled_split_ok), 2, "pooled grid written split for a program that reads fp32");
   auto is_split = [&](int id) { return fwd_h2 && (id == m->input_dst ? pooled_split : (bool)m->buf_split[id]); };
-  for (int si = std::max(step_lo, 0); si < std::min(step_hi, (int)steps.size()); si++) {
+  // per-pose scoring calls: a whole-grid max pool and the heads behind it run as one launch (conv3d.hip gmax_heads_kernel);
+  // a pure function of the program and the call, so that a lane's slices agree on it wherever they are cut
+  auto gmax_fused = [&](int si) {
+    if (si < 0 || si + 1 >= (int)steps.size()) return false;
+    const Step &g = steps[si], &fc = steps[si + 1];
+    return g.kind == OpKind::GMax && fc.kind == OpKind::Fc && !grad && !g.src_bf16 && nb <= 8 && !s.profile &&
+           !option(OPT_MI_GNINA_NO_GMAX_FUSE) && fc.src == g.dst && fc.n_in == g.C && m->buf_cp[g.dst] == g.C && gmax_heads_covers(g.C);
+  };
+  int si0 = std::max(step_lo, 0);
+  if (si0 > 0 && gmax_fused(si0 - 1)) si0++;  // (the previous slice's max pool took this slice's first step along)
+  for (int si = si0; si < std::min(step_hi, (int)steps.size()); si++) {
     const Step &st = steps[si];
     switch (st.kind) {
       case OpKind::Conv: {
@@ -2157,6 +2167,15 @@ static void run_program(Scorer &s, int mi, int nb, float *pose, float *aff, floa
                        m->d.bufs[st.src].S, st.pool_mode, s.stream);
         break;
       case OpKind::GMax:
+        // per-pose scoring calls: the whole-grid max pool and the heads behind it in one launch (conv3d.hip gmax_heads_kernel)
+        if (gmax_fused(si)) {
+          const Step &fc = steps[si + 1];
+          launch_gmax_heads(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst], m->d.bufs[st.src].S,
+                            m->dev_data.p + fc.w_off, m->dev_data.p + fc.b_off, m->d.skip_softmax, m->d.apply_logistic_loss, pose, aff,
+                            loss, s.stream);
+          si++;  // (the Fc step is done)
+          break;
+        }
         if (st.src_bf16)
           launch_gmax_bf16(buf_ptr(st.src), buf_ptr(st.dst), nb, st.C, m->buf_cp[st.src], m->buf_cp[st.dst],
                            m->d.bufs[st.src].S, s.stream);

@@ -146,7 +146,8 @@ def test_stationary_weights_first_conv_gives_the_same_bits(capi, CG, name):
 
 
 def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
-    """The two things a per-pose call of a Dense model runs differently since round 6 -- the K chunks of a block layer DMA'd
+    """What a per-pose call of a Dense model runs differently since round 6 (also: chunk groups in the 1x1x1 transitions, the
+    whole-grid max pool fused with the heads) -- the K chunks of a block layer DMA'd
     in groups (conv3d_h2_d16_kernel<.., GRP>, conv3d_h2_dense.hip) and the 6^3 layers' weights through LDS, a chunk ahead
     (conv3d_h2_16_kernel<.., WL>; conv3d_h2_16_ring_kernel with both operands through a ring for launches of few small
     workgroups; conv3d_h2.hip) -- feed the same operands to the same MFMAs in the same order: B = 1, B = 3
@@ -178,5 +179,9 @@ def test_dense_per_pose_variants_give_the_same_bits(capi, CG):
         check("weights through LDS wherever they fit")
     with capi.option("MI_GNINA_H16_WLDS", 5):
         check("no operand ring for the launches of few small workgroups")
+    with capi.option("MI_GNINA_NO_GMAX_FUSE", 1):
+        check("whole-grid max pool and heads as two launches (one for small calls: gmax_heads_kernel)")
+    with capi.option("MI_GNINA_K1S_DBG", 128):
+        check("the 1x1x1 transitions' chunks one DMA round trip each")
     with capi.option("MI_GNINA_H16_WLDS", 9):
         check("the ring kernel without its producer / consumer form (conv3d_h2_16_pc_kernel)")
