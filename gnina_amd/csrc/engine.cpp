@@ -1466,6 +1466,7 @@ struct Scorer {
   // outputs per model [n_models][B] and reduced
   DevBuf<float> d_pose_m, d_aff_m, d_loss_m, d_pose, d_aff, d_loss, d_var, d_out4;
   float *h_out4 = nullptr;  // pinned staging of the four output arrays
+  float *h_lig_pin = nullptr;  // pinned block a small synchronous scoring call hands its poses over in (read by gather_pose_atoms)
   size_t h_out4_n = 0;
   int last_B = 0;
   // per-kernel profiling (mi_scorer_enable_profile): HIP events around every launch on `stream`
@@ -1500,6 +1501,7 @@ struct Scorer {
     for (auto &e : lane_start)
       if (e) (void)hipEventDestroy(e);
     if (h_out4) (void)hipHostFree(h_out4);
+    if (h_lig_pin) (void)hipHostFree(h_lig_pin);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -2664,8 +2666,18 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
   const float *d_lig = lig_xyz;
   const float *d_cen = centers;
   if (!(flags & MI_LIG_ON_DEVICE)) {
-    s.d_lig.upload(lig_xyz, (size_t)B * L * 3, s.stream);
-    d_lig = s.d_lig.p;
+    // A small synchronous call hands its poses over in pinned host memory, which the gather kernel reads directly (it stages
+    // them in LDS once): a hipMemcpyAsync from the caller's pageable array is a staged copy the call's first kernel waits for.
+    // (Not for device-output calls: they return before the gather ran, and the next call would overwrite the block.)
+    const size_t n_lig_f = (size_t)B * L * 3;
+    if (n_lig_f <= 1536 && !(flags & MI_OUT_ON_DEVICE) && !option(OPT_MI_GNINA_LIG_COPY)) {
+      if (!s.h_lig_pin) MIG_HIP(hipHostMalloc((void **)&s.h_lig_pin, 1536 * sizeof(float), hipHostMallocDefault));
+      memcpy(s.h_lig_pin, lig_xyz, n_lig_f * sizeof(float));
+      d_lig = s.h_lig_pin;
+    } else {
+      s.d_lig.upload(lig_xyz, n_lig_f, s.stream);
+      d_lig = s.d_lig.p;
+    }
     if (centers) {
       s.d_centers_in.upload(centers, (size_t)B * 3, s.stream);
       d_cen = s.d_centers_in.p;

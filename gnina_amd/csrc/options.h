@@ -53,6 +53,7 @@ namespace mig {
   X(MI_GNINA_D16_GROUP_MAX)          \
   X(MI_GNINA_H16_WLDS)               \
   X(MI_GNINA_OUT_COPY)               \
+  X(MI_GNINA_LIG_COPY)               \
   X(MI_GNINA_NO_GMAX_FUSE)           \
   X(MI_GNINA_NO_GRAD_LANES)          \
   X(MI_GNINA_K1S_DBG)                \
