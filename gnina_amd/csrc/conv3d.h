@@ -214,6 +214,7 @@ void launch_unpool_avg(const float *g_pooled, float *g_full, int B, int C, int i
 bool gmax_heads_covers(int C);
 void launch_gmax_heads(const float *in, float *gmax_out, int B, int C, int in_cs, int out_cs, int S, const float *w, const float *bias,
                        int skip_softmax, int logistic_loss, float *pose, float *aff, float *loss, hipStream_t s);
+void launch_zero_u32(unsigned *p, size_t n, hipStream_t s);
 void launch_sum_models(const float *src, int n_models, size_t n, float *dst, hipStream_t s);
 void launch_ensemble_reduce(const float *pose_m, const float *aff_m, const float *loss_m, int n_models, int B,
                             float *pose, float *aff, float *loss, float *var, hipStream_t s, unsigned *ovf_in = nullptr, unsigned *ovf_out = nullptr);

@@ -1555,6 +1555,17 @@ __global__ void ensemble_reduce_kernel(const float *pose_m, const float *aff_m, 
   if (var) var[b] = v;
 }
 
+// n dwords of zeros in ONE launch (hipMemsetAsync takes two fill kernels for sizes like 25 dwords -- 5 us each on the critical
+// path of a per-pose gradient call)
+__global__ void zero_u32_kernel(unsigned *p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+void launch_zero_u32(unsigned *p, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
 // dst[i] = ((0 + src[0][i]) + src[1][i]) + ... : the per-model gradients of a gradient call on lanes, added in model order --
 // the additions a one-stream call makes when every model accumulates into the one zeroed buffer
 __global__ void sum_models_kernel(const float *src, int n_models, size_t n, float *dst) {

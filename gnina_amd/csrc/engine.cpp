@@ -2250,7 +2250,7 @@ static float *run_backward(Scorer &s, int mi, int nb) {
     const size_t slots = nbufs + gsteps.size();  // one per buffer (kind 1) and one per step (kind 2)
     MIG_CHECK(s.act_lane == 0 || slots <= kGamaxLaneSlots, 2, "gradient lanes: model with more gradient-maximum slots than a lane's share");
     s.d_gamax.ensure(s.act_lane == 0 ? slots * (size_t)s.cap : (size_t)(s.act_lane + 1) * kGamaxLaneSlots * s.cap);
-    MIG_HIP(hipMemsetAsync(s.d_gamax.p + (size_t)s.act_lane * kGamaxLaneSlots * s.cap, 0, slots * (size_t)s.cap * sizeof(unsigned), s.stream));
+    launch_zero_u32(s.d_gamax.p + (size_t)s.act_lane * kGamaxLaneSlots * s.cap, slots * (size_t)s.cap, s.stream);
   }
   auto amax_of = [&](int id) { return s.d_gamax.p + (size_t)s.act_lane * kGamaxLaneSlots * s.cap + (size_t)id * s.cap; };
   auto wants_mask = [&](int id) { return h2_bwd && id != m->input_dst && m->buf_bwd_h2[id]; };
@@ -2445,7 +2445,7 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
   s.d_aff_m.ensure((size_t)nm * B);
   s.d_loss_m.ensure((size_t)nm * B);
   s.d_lig_grad.ensure((size_t)B * L * 3);
-  MIG_HIP(hipMemsetAsync(s.d_lig_grad.p, 0, (size_t)B * L * 3 * sizeof(float), s.stream));
+  launch_zero_u32(reinterpret_cast<unsigned *>(s.d_lig_grad.p), (size_t)B * L * 3, s.stream);  // (one launch; a memset of this size takes two)
   const int n_flex = (int)s.flex_rows.size();
   MIG_CHECK(!flex_xyz || n_flex > 0, 1, "flex coordinates given but mi_scorer_set_flex declared no flexible rows");
   MIG_CHECK(!flex_grad || flex_xyz, 1, "flex gradient without flex coordinates");
@@ -2498,7 +2498,7 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
     s.d_gamax.ensure((size_t)(nm + 1) * kGamaxLaneSlots * s.cap);
     s.d_ovf.ensure(1);
     s.d_lig_grad_m.ensure((size_t)nm * n_lg_all);
-    MIG_HIP(hipMemsetAsync(s.d_lig_grad_m.p, 0, (size_t)nm * n_lg_all * sizeof(float), s.stream));
+    launch_zero_u32(reinterpret_cast<unsigned *>(s.d_lig_grad_m.p), (size_t)nm * n_lg_all, s.stream);
     if (flex_xyz) {
       s.d_flex_grad_m.ensure((size_t)nm * n_fg_all);
       MIG_HIP(hipMemsetAsync(s.d_flex_grad_m.p, 0, (size_t)nm * n_fg_all * sizeof(float), s.stream));
