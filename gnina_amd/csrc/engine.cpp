@@ -2463,7 +2463,7 @@ static void score_batch_grad_once(Scorer &s, const float *lig_xyz, const int32_t
   // voxel backward -- on a stream of its own, in its own buffer set, the voxel groups side by side; every model accumulates
   // its (scaled) atom gradients into a buffer of its own and the buffers are added in model order at the end, which are the
   // additions the one-stream call makes.  gnina's default ensemble at B = 1: 1,616 -> ~? us per call.
-  int lanes_max_b = 8;
+  int lanes_max_b = 64;  // (measured: lanes win up to 64 poses per call -- B = 9: 1,137 -> 652 us, B = 64: 2,699 -> 2,414; gradient calls alike)
   if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
   size_t max_bufs = 0;
   bool any_overlap = false;
@@ -2694,7 +2694,7 @@ static void score_batch_once(Scorer &s, const float *lig_xyz, const int32_t *lig
     MIG_HIP(hipEventRecord(s.ev[0], s.stream));
   }
   // Lanes (Scorer::lane_streams): a small call of an ensemble runs every model's program on its own stream.
-  int lanes_max_b = 8;
+  int lanes_max_b = 64;  // (measured: lanes win up to 64 poses per call -- B = 9: 1,137 -> 652 us, B = 64: 2,699 -> 2,414; gradient calls alike)
   if (const char *ev = option(OPT_MI_GNINA_LANES_MAX_B)) lanes_max_b = atoi(ev);
   // On by default (MI_GNINA_LANES=0 or MI_GNINA_NO_LANES=1: one stream).  Every group's grid is voxelized first (main stream),
   // then every model's program starts on its own stream: 1,800 B = 1 calls of three ensembles, every one the serial call's
