@@ -671,6 +671,16 @@ def config_seam_b1(capi, synth):
                 f()
                 ts.append(time.perf_counter() - t0)
             row["fwd_bwd_us" if grad else "fwd_us"] = round(float(np.median(ts)) * 1e6, 1)
+        # a ligand's nine output poses in one call (lanes serve calls of up to 64 poses: DESIGN.md §3.2)
+        pose9 = synth.make_poses(np.random.RandomState(9), lx, 9)
+        for _ in range(20):
+            s.score_batch(pose9, ls)
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            s.score_batch(pose9, ls)
+            ts.append(time.perf_counter() - t0)
+        row["fwd_us_nine_poses_per_call"] = round(float(np.median(ts)) * 1e6, 1)
         # four worker threads, one scorer each (ctypes releases the GIL during the call)
         scorers = []
         for _ in range(4):
