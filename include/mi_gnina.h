@@ -59,7 +59,7 @@ enum {
  * bits the same call gives alone (tests/test_gpu_concurrency.py: two threads, host and device outputs).  Rounds 5 serialised
  * such calls per device because a voxelizer next to another scorer's conv kernels deviated; round 6 traced that to the
  * voxelizer's packed-fp32 instructions, removed them, and removed the lock (MI_GNINA_CALL_LOCK=1
- * brings it back for A/B measurements).  Within a call of at most 8 poses the models of an ensemble run on streams of their
+ * brings it back for A/B measurements).  Within a call of at most 64 poses the models of an ensemble run on streams of their
  * own behind the voxelization (same bits as on one stream; MI_GNINA_LANES=0 switches it off). */
 mi_status mi_gnina_init(int device);
 /* Experiment / A-B switches (gnina_amd/csrc/options.h lists them: MI_GNINA_*, MI_POOL_*, MI_VINA_*, MI_VOX_*).  The
